@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""Benchmark of the DH3D hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload local|global] [--no-cpu-baseline]
+
+A "step" is one forward of the hot path over one batch of synthetic clouds already resident in HBM:
+  local  (default, BASELINE config[1]): local-descriptor forward, basic_config, N=8192 K=8, batch 8 / GPU
+  global (BASELINE config[2])         : global-descriptor forward, global_config, N=4096, batch 32 / GPU
+One process per GPU (torchrun env), weak scaling over clouds, no data-path collective (clouds are
+independent); the timed region is bracketed by barrier + synchronize and the max over ranks is taken.
+Rank 0 prints ONE JSON line.  The step is a hipGraph replay of dh3d_amd.model.DH3D.forward.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md)
+F32_MFMA_PEAK_TF = 157.3  # dense f32 MFMA = f32 vector peak
+
+WORKLOADS = {
+    "local": dict(preset="basic_config", B=8, N=8192, seed=2002, out="xyz_feat",
+                  name="local-descriptor forward (basic_config), N=8192 K=8, batch=8 per GPU"),
+    "global": dict(preset="global_config", B=32, N=4096, seed=3003, out="globaldesc",
+                   name="global-descriptor forward (global_config), N=4096, 64-cluster NetVLAD, batch=32 per GPU"),
+}
+
+
+def build_model(preset, dev, seed=0):
+    from dh3d_amd import ConfigFactory
+    from dh3d_amd.model import DH3D
+    m = DH3D(ConfigFactory(preset).getconfig()).init_synthetic(seed)
+    return m.to(dev).eval().prepare()
+
+
+def synthetic_clouds(B, N, seed, dev, rank=0):
+    rng = np.random.default_rng(seed + rank)
+    return torch.from_numpy(rng.random((B, N, 3), dtype=np.float32)).to(dev)
+
+
+def time_steps(run, pts, steps, warmup, dev):
+    from dh3d_amd import dist as D
+    for _ in range(warmup):
+        run(pts)
+    torch.cuda.synchronize(dev)
+    D.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run(pts)
+    torch.cuda.synchronize(dev)
+    D.barrier()
+    dt = time.perf_counter() - t0
+    return D.max_over_ranks(dt, dev)
+
+
+def event_time_ms(fn, iters=50, warm=5):
+    """Average duration of fn() (kernels on torch's current stream) from HIP events on that stream."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def flex_conv_roofline(dev, B=8, N=8192, K=8, Din=64, Dout=64):
+    """The kernel BASELINE.json names: flex_conv at N=8192, K=8 (stage-1 layer 64->64, batch 8).
+    Algorithmic figures per launch:
+      Bc = 4*[B*N*(Din+Dout+3+K) + 4*Din*Dout]   compulsory HBM bytes
+      Bg = 4*B*N*[K*(Din+4)+3+Dout]              bytes requested by the gather (cache hierarchy)
+      F  = 2*B*N*4*Din*(K+Dout)                  flops of the factorised form (gather-reduce + GEMM)"""
+    from dh3d_amd import pm
+    g = torch.Generator(device="cpu").manual_seed(1)
+    xyz = torch.rand(B, N, 3, generator=g).to(dev)
+    f = torch.randn(B, N, Din, generator=g).to(dev)
+    nbr, _ = pm.knn_xyz(xyz, K)
+    theta = (torch.randn(3, Din, Dout, generator=g) / Din ** 0.5).to(dev)
+    bias = (torch.randn(Din, Dout, generator=g) / (8 * Din) ** 0.5).to(dev)
+    wp = pm.pack_flex_weight(theta, bias)
+    fb = torch.zeros(Dout, device=dev)
+    ms = event_time_ms(lambda: pm.flex_conv(f, xyz, nbr, wp, Dout, pre_bias=fb, scale=fb + 1, shift=fb,
+                                            act=pm.ACT_RELU))
+    t = ms * 1e-3
+    Bc = 4.0 * (B * N * (Din + Dout + 3 + K) + 4 * Din * Dout)
+    Bg = 4.0 * B * N * (K * (Din + 4) + 3 + Dout)
+    F = 2.0 * B * N * 4 * Din * (K + Dout)
+    return {
+        "bound": "hbm", "kernel": "flex_conv_pm_kernel<%d,%d> B=%d N=%d K=%d" % (Din, Dout, B, N, K),
+        "achieved": Bc / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": Bc / t / 1e9 / HBM_PEAK_GBS,
+        "traffic": None, "launch_ms": ms, "algorithmic_bytes": Bc,
+        "gather_effective": {"achieved": Bg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": Bg / t / 1e9 / HBM_PEAK_GBS, "bytes": Bg},
+        "mfma_f32": {"achieved": F / t / 1e12, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": F / t / 1e12 / F32_MFMA_PEAK_TF, "flops": F},
+        "binding_roof": "f32 MFMA (compute) -- see DESIGN.md: flex_conv is FP32-compute-bound at every DH3D shape",
+    }
+
+
+def kernel_breakdown(dev, B, N):
+    """Stand-alone event timings of the main kernels at the bench shape (ms per launch)."""
+    from dh3d_amd import pm, ops
+    xyz = torch.rand(B, N, 3, device=dev)
+    out = {}
+    out["knn_xyz K=8"] = event_time_ms(lambda: pm.knn_xyz(xyz, 8), iters=10, warm=2)
+    out["fps N->N/8"] = event_time_ms(lambda: ops.farthest_point_sample(N // 8, xyz), iters=5, warm=1)
+    sub = xyz[:, : N // 8].contiguous()
+    out["three_nn"] = event_time_ms(lambda: ops.three_nn(xyz, sub), iters=10, warm=2)
+    return out
+
+
+def cpu_baseline(workload):
+    """The CPU oracle (numpy graph + C ops, oracle/) on ONE cloud of the workload, one core."""
+    from oracle import model_np
+    from dh3d_amd.model import tf_variable_name
+    wl = WORKLOADS[workload]
+    from dh3d_amd import ConfigFactory
+    from dh3d_amd.model import DH3D
+    model = DH3D(ConfigFactory(wl["preset"]).getconfig()).init_synthetic(0)
+    w = {tf_variable_name(k): v.detach().numpy() for k, v in model.state_dict().items()}
+    pts = np.random.default_rng(wl["seed"]).random((1, wl["N"], 3), dtype=np.float32)
+    torch.set_num_threads(1)
+    t0 = time.perf_counter()
+    model_np.forward(pts, w, detection=False, extract_global=(workload == "global"))
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "point-clouds/sec", "cores": 1, "kind": "port",
+            "sample": "1 cloud of N=%d through oracle/model_np.forward (C oracle ops + numpy dense), %.1f s" % (wl["N"], dt),
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="local")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline / breakdown / second workload")
+    args = ap.parse_args()
+
+    from dh3d_amd import dist as D
+    rank, world = D.init_from_env()
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+
+    def measure(workload):
+        wl = WORKLOADS[workload]
+        model = build_model(wl["preset"], dev, seed=0)
+        pts = synthetic_clouds(wl["B"], wl["N"], wl["seed"], dev, rank)
+        with torch.no_grad():
+            run = model.graphed(pts, outputs=(wl["out"],))
+            dt = time_steps(run, pts, args.steps, args.warmup, dev)
+        clouds = wl["B"] * world * args.steps
+        return clouds / dt, dt / args.steps * 1e3
+
+    value, ms = measure(args.workload)
+    wl = WORKLOADS[args.workload]
+    line = {
+        "metric": "point-clouds/sec", "value": value, "unit": "point-clouds/sec", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": wl["name"], "clouds_per_gpu": wl["B"], "points": wl["N"], "knn": 8,
+                   "parallelism": "clouds sharded over %d GPU(s), no data-path collective" % world,
+                   "weights": "random-init (no checkpoint blobs exist upstream)", "execution": "hipGraph replay"},
+    }
+    if rank == 0 and not args.no_extras:
+        with torch.no_grad():
+            line["roofline"] = flex_conv_roofline(dev)
+            line["kernels_ms"] = kernel_breakdown(dev, wl["B"], wl["N"])
+        if world == 1:
+            other = "global" if args.workload == "local" else "local"
+            ov, oms = measure(other)
+            line["other_workload"] = {"workload": WORKLOADS[other]["name"], "value": ov,
+                                      "unit": "point-clouds/sec", "ms_per_step": oms}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args.workload)
+    D.barrier()
+    if rank == 0:
+        print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

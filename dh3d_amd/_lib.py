@@ -1,0 +1,147 @@
+"""ctypes binding of libdh3d_hip.so (the C ABI declared in include/dh3d_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a kernel reports an
+error, this module raises.  PyTorch tensors are used only as device-memory containers (data_ptr)
+and for the current HIP stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdh3d_hip.so")
+
+DH3D_OK = 0
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+
+_lib = None
+
+c_fp = ctypes.c_void_p  # device pointers travel as void*
+c_int = ctypes.c_int
+c_size_t = ctypes.c_size_t
+c_float = ctypes.c_float
+
+
+class Epilogue(ctypes.Structure):
+    """struct dh3d_epilogue"""
+    _fields_ = [("pre_bias", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p),
+                ("act", ctypes.c_int)]
+
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+_SIGNATURES = {
+    "dh3d_version": [],
+    "dh3d_arch": [],
+    "dh3d_status_string": [c_int],
+    "dh3d_knn_bruteforce": [c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp],
+    "dh3d_knn_bruteforce_xyz": [c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp],
+    "dh3d_flex_conv_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp],
+    "dh3d_flex_conv_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp,
+                           c_fp, c_fp, c_fp],
+    "dh3d_flex_pool_fwd": [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp],
+    "dh3d_flex_pool_bwd": [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp],
+    "dh3d_conv_pointset_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp],
+    "dh3d_conv_pointset_bwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp,
+                               c_fp],
+    "dh3d_farthest_point_sample": [c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp],
+    "dh3d_group_point_fwd": [c_int, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp],
+    "dh3d_group_point_bwd": [c_int, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp],
+    "dh3d_three_nn": [c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp],
+    "dh3d_three_interpolate_fwd": [c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp],
+    "dh3d_three_interpolate_bwd": [c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp],
+    "dh3d_pack_weight": [c_fp, c_int, c_int, c_fp, c_fp],
+    "dh3d_pack_flex_weight": [c_fp, c_fp, c_int, c_int, c_fp, c_fp],
+    "dh3d_flex_conv_pm_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int,
+                              ctypes.POINTER(Epilogue), c_fp, c_fp],
+    "dh3d_flex_pool_pm_fwd": [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp],
+    "dh3d_conv_pointset_pm_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, ctypes.POINTER(Epilogue),
+                                  c_fp, c_fp],
+    "dh3d_linear_pm_fwd": [c_fp, c_int, c_fp, c_int, c_fp, c_int, c_int, ctypes.POINTER(Epilogue), c_fp, c_fp,
+                           c_fp],
+    "dh3d_se_res_pm_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp],
+    "dh3d_three_interpolate_idw_fwd": [c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp],
+    "dh3d_l2norm_concat_fwd": [c_fp, c_int, c_int, c_float, c_fp, c_int, c_fp, c_fp],
+    "dh3d_mlp_head_pm_fwd": [c_fp, c_int, c_int, c_fp, c_int, ctypes.POINTER(Epilogue), c_fp, c_float, c_fp,
+                             c_fp],
+    "dh3d_netvlad_workspace_bytes": [c_int, c_int, c_int, c_int],
+    "dh3d_netvlad_aggregate_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp,
+                                   c_size_t, c_fp, c_fp],
+    "dh3d_netvlad_head_workspace_bytes": [c_int, c_int, c_int],
+    "dh3d_netvlad_head_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_float, c_fp,
+                              c_size_t, c_fp, c_fp],
+}
+_RESTYPES = {
+    "dh3d_arch": ctypes.c_char_p,
+    "dh3d_status_string": ctypes.c_char_p,
+    "dh3d_netvlad_workspace_bytes": c_size_t,
+    "dh3d_netvlad_head_workspace_bytes": c_size_t,
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def lib():
+    """Load libdh3d_hip.so (once).  Raises if it was not built -- there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError(
+                "dh3d_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C dh3d_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the header and the library disagree
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, c_int)
+        _lib = handle
+    return _lib
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def check(status, what):
+    if status != DH3D_OK:
+        msg = lib().dh3d_status_string(status).decode()
+        if status in (1, 2):
+            raise ValueError("%s: %s" % (what, msg))
+        raise RuntimeError("%s: %s" % (what, msg))
+
+
+def make_epilogue(pre_bias=None, scale=None, shift=None, act=ACT_NONE):
+    ep = Epilogue()
+    ep.pre_bias = pre_bias.data_ptr() if pre_bias is not None else None
+    ep.scale = scale.data_ptr() if scale is not None else None
+    ep.shift = shift.data_ptr() if shift is not None else None
+    ep.act = act
+    return ep
+
+
+def require_cuda_f32(t, name, ndim=None):
+    if not isinstance(t, torch.Tensor):
+        raise ValueError("%s must be a torch.Tensor" % name)
+    if t.dtype != torch.float32:
+        raise ValueError("%s must be float32, got %s" % (name, t.dtype))
+    if not t.is_cuda:
+        raise ValueError("%s must live on the GPU (the HIP path has no CPU fallback)" % name)
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError("%s must have rank %d, got shape %s" % (name, ndim, tuple(t.shape)))
+    return t.contiguous()
+
+
+def require_cuda_i32(t, name, ndim=None):
+    if not isinstance(t, torch.Tensor):
+        raise ValueError("%s must be a torch.Tensor" % name)
+    if t.dtype != torch.int32:
+        raise ValueError("%s must be int32, got %s" % (name, t.dtype))
+    if not t.is_cuda:
+        raise ValueError("%s must live on the GPU (the HIP path has no CPU fallback)" % name)
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError("%s must have rank %d, got shape %s" % (name, ndim, tuple(t.shape)))
+    return t.contiguous()

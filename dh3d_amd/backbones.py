@@ -1,0 +1,357 @@
+"""FlexConv + SE encoder, detector / attention heads and NetVLAD on the fused HIP kernels.
+
+Mirrors core/backbones.py (se_res_bottleneck :45-55, flex_conv_dilate :58-101, backbone_local_dilate
+:104-127, detection_block :132-151, globalatt_block :156-173, global_before_assemble :178-186,
+global_netvald_block :202-279, context_gating :282-320) and the glue of core/tf_utils.py
+(flexconv_withBatchnorm :48-64, convolution_pointset_withBatchnorm :67-83, subsample :86-96,
+feature_conv1d_1 :99-109).
+
+Differences that are deliberate:
+  * activations stay point-major [B, N, C] end to end -- the reference transposes between [B,C,N] and
+    [B,N,C] around every block (backbones.py:35,41,68-69,87,108,110);
+  * BatchNorm (inference statistics), biases and activations are folded into the producing kernel;
+  * the geometry chain FPS -> gather -> kNN(N/8) -> three_nn depends only on xyz: it runs on a side HIP
+    stream concurrently with stage 1, and is computed once where the reference computes it twice
+    (stage2 and global_before_assemble use identical xyz / npoint / k).
+
+Parameter names follow the checkpoint variable names ('/' -> '.', 'mean/EMA' -> 'mean_EMA'); see
+dh3d_amd.model.tf_variable_name.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import pm
+
+
+# --------------------------------------------------------------------------- parameter holders
+class TPBatchNorm(nn.Module):
+    """tensorpack BatchNorm variables: gamma, beta, mean/EMA, variance/EMA (inference statistics)."""
+
+    def __init__(self, channels, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.gamma = nn.Parameter(torch.ones(channels))
+        self.beta = nn.Parameter(torch.zeros(channels))
+        self.register_buffer("mean_EMA", torch.zeros(channels))
+        self.register_buffer("variance_EMA", torch.ones(channels))
+
+    def fold(self):
+        scale = self.gamma * torch.rsqrt(self.variance_EMA + self.eps)
+        shift = self.beta - self.mean_EMA * scale
+        return scale.contiguous(), shift.contiguous()
+
+
+class SlimBatchNorm(nn.Module):
+    """slim / tf.contrib.layers batch_norm variables: gamma, beta, moving_mean, moving_variance."""
+
+    def __init__(self, channels, eps=1e-3):
+        super().__init__()
+        self.eps = eps
+        self.gamma = nn.Parameter(torch.ones(channels))
+        self.beta = nn.Parameter(torch.zeros(channels))
+        self.register_buffer("moving_mean", torch.zeros(channels))
+        self.register_buffer("moving_variance", torch.ones(channels))
+
+    def fold(self):
+        scale = self.gamma * torch.rsqrt(self.moving_variance + self.eps)
+        shift = self.beta - self.moving_mean * scale
+        return scale.contiguous(), shift.contiguous()
+
+
+class Conv2D1x1(nn.Module):
+    """tensorpack Conv2D(kernel_shape=1): W [1,1,Cin,Cout], b [Cout], optional BatchNorm 'bn'."""
+
+    def __init__(self, cin, cout, bn=True, bn_eps=1e-5, bias_init=0.0):
+        super().__init__()
+        self.cin, self.cout = cin, cout
+        self.W = nn.Parameter(torch.randn(1, 1, cin, cout) * math.sqrt(2.0 / cin))
+        self.b = nn.Parameter(torch.full((cout,), float(bias_init)))
+        self.bn = TPBatchNorm(cout, bn_eps) if bn else None
+        self._prep = None
+
+    def prepare(self):
+        W2 = self.W.detach().reshape(self.cin, self.cout).contiguous()
+        p = {"W2": W2, "b": self.b.detach().contiguous()}
+        if self.cout % 64 == 0 and self.cin % 8 == 0:
+            p["wp"] = pm.pack_weight(W2)
+        if self.bn is not None:
+            p["scale"], p["shift"] = [t.detach() for t in self.bn.fold()]
+        else:
+            p["scale"], p["shift"] = None, None
+        self._prep = p
+        return p
+
+    def forward(self, x, x2=None, act=pm.ACT_RELU, residual=None):
+        p = self._prep or self.prepare()
+        return pm.linear(x, p["wp"], self.cout, x2=x2, pre_bias=p["b"], scale=p["scale"], shift=p["shift"],
+                         act=act, residual=residual)
+
+
+class FeatureConv1d(nn.Module):
+    """feature_conv1d_1 (core/tf_utils.py:99-109): variable scope '<name>/tfconv0'."""
+
+    def __init__(self, cin, cout, bn=True, bn_eps=1e-5):
+        super().__init__()
+        self.tfconv0 = Conv2D1x1(cin, cout, bn=bn, bn_eps=bn_eps)
+
+    def forward(self, x, x2=None, act=pm.ACT_RELU, residual=None):
+        return self.tfconv0(x, x2=x2, act=act, residual=residual)
+
+
+class FlexConvParams(nn.Module):
+    """Weights of one FlexConvolution layer (core/layers.py:268-295)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.cin, self.cout = cin, cout
+        limit = math.sqrt(6.0 / (cin + cout))
+        self.position_theta = nn.Parameter(torch.empty(3, cin, cout).uniform_(-limit, limit))
+        self.position_bias = nn.Parameter(torch.zeros(cin, cout))
+        self.feature_bias = nn.Parameter(torch.zeros(cout, 1))
+
+
+class SEBlock(nn.Module):
+    """se_res_bottleneck weights: f1 (C -> C/4, ReLU), f2 (C/4 -> C, sigmoid); no BatchNorm."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.channels = channels
+        self.f1 = FeatureConv1d(channels, channels // 4, bn=False)
+        self.f2 = FeatureConv1d(channels // 4, channels, bn=False)
+        self._prep = None
+
+    def prepare(self):
+        c = self.channels
+        self._prep = (self.f1.tfconv0.W.detach().reshape(c, c // 4).contiguous(),
+                      self.f1.tfconv0.b.detach().contiguous(),
+                      self.f2.tfconv0.W.detach().reshape(c // 4, c).contiguous(),
+                      self.f2.tfconv0.b.detach().contiguous())
+        return self._prep
+
+    def forward(self, x, pool):
+        W1, b1, W2, b2 = self._prep or self.prepare()
+        return pm.se_res(x, pool, W1, b1, W2, b2)
+
+
+# --------------------------------------------------------------------------- geometry (xyz-only work)
+class Geometry(object):
+    """Everything the forward needs that depends on coordinates only."""
+
+    def __init__(self, xyz, knn_num, nbr=None):
+        self.xyz = xyz
+        self.knn_num = knn_num
+        self.nbr = nbr          # [B,N,K] int32
+        self.levels = {}        # dilate -> dict(idx, xyz_s, nbr_s, nn3_dist, nn3_idx)
+
+    def level(self, dilate, knn):
+        key = (dilate, knn)
+        if key not in self.levels:
+            self.levels[key] = compute_level(self.xyz, dilate, knn)
+        return self.levels[key]
+
+
+def gather_rows(points, idx):
+    """points [B,N,C], idx [B,m] -> [B,m,C]  (group_point with nsample = 1, core/tf_utils.py:92-95)."""
+    p = L.require_cuda_f32(points, "points", 3)
+    ix = L.require_cuda_i32(idx, "idx", 2)
+    b, n, c = p.shape
+    m = ix.shape[1]
+    out = torch.empty((b, m, c), dtype=torch.float32, device=p.device)
+    L.check(L.lib().dh3d_group_point_fwd(b, n, c, m, 1, L.ptr(p), L.ptr(ix), L.ptr(out), L.stream_ptr()),
+            "group_point")
+    return out
+
+
+def compute_level(xyz, dilate, knn):
+    """FPS -> gather xyz -> kNN on the sampled set -> three_nn back to the full set."""
+    B, N, _ = xyz.shape
+    npoint = N // dilate
+    idx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
+    L.check(L.lib().dh3d_farthest_point_sample(B, N, npoint, L.ptr(xyz), None, L.ptr(idx), L.stream_ptr()),
+            "farthest_point_sample")
+    xyz_s = gather_rows(xyz, idx)
+    nbr_s, _ = pm.knn_xyz(xyz_s, knn)
+    d3 = torch.empty((B, N, 3), dtype=torch.float32, device=xyz.device)
+    i3 = torch.empty((B, N, 3), dtype=torch.int32, device=xyz.device)
+    L.check(L.lib().dh3d_three_nn(B, N, npoint, L.ptr(xyz), L.ptr(xyz_s), L.ptr(d3), L.ptr(i3), L.stream_ptr()),
+            "three_nn")
+    return {"idx": idx, "xyz_s": xyz_s, "nbr_s": nbr_s, "nn3_dist": d3, "nn3_idx": i3}
+
+
+# --------------------------------------------------------------------------- flex_conv_dilate
+class FlexConvDilate(nn.Module):
+    """flex_conv_dilate (core/backbones.py:58-101)."""
+
+    def __init__(self, cin, outdims, dilate, knn=8, concat=True, add_se="max_pool", upsample=True,
+                 bn_eps=1e-5):
+        super().__init__()
+        if add_se not in ("max_pool", ""):
+            raise NotImplementedError("add_se=%r: only 'max_pool' / '' are used by the shipped backbones" % add_se)
+        self.cin, self.outdims, self.dilate, self.knn = cin, list(outdims), dilate, knn
+        self.concat, self.add_se, self.upsample = concat, add_se, upsample
+        c = cin
+        for i, d in enumerate(outdims):
+            setattr(self, "flexconv_%d" % i, FlexConvParams(c, d))
+            setattr(self, "flexconv_%d_bn" % i, TPBatchNorm(d, bn_eps))
+            c = d
+        if add_se == "max_pool":
+            self.se = SEBlock(outdims[-1])
+        if concat:
+            self.concat_conv1d = FeatureConv1d(outdims[-1] + cin, outdims[-1], bn=True, bn_eps=bn_eps)
+        self._prep = None
+
+    def prepare(self):
+        prep = []
+        for i, d in enumerate(self.outdims):
+            fc = getattr(self, "flexconv_%d" % i)
+            bn = getattr(self, "flexconv_%d_bn" % i)
+            scale, shift = [t.detach() for t in bn.fold()]
+            prep.append({
+                "wp": pm.pack_flex_weight(fc.position_theta.detach(), fc.position_bias.detach()),
+                "fb": fc.feature_bias.detach().reshape(-1).contiguous(),
+                "scale": scale, "shift": shift, "dout": d,
+            })
+        self._prep = prep
+        if self.add_se == "max_pool":
+            self.se.prepare()
+        if self.concat:
+            self.concat_conv1d.tfconv0.prepare()
+        return prep
+
+    def forward(self, geo, feat, nbr=None):
+        """geo: Geometry; feat [B,N,cin]; nbr [B,N,K] for dilate == 1 (else computed on the sampled set)."""
+        prep = self._prep or self.prepare()
+        if self.dilate > 1:
+            lv = geo.level(self.dilate, self.knn)
+            xyz_s, nbr_s = lv["xyz_s"], lv["nbr_s"]
+            x = gather_rows(feat, lv["idx"])
+        else:
+            xyz_s, nbr_s, x = geo.xyz, (nbr if nbr is not None else geo.nbr), feat
+        for p in prep:
+            x = pm.flex_conv(x, xyz_s, nbr_s, p["wp"], p["dout"], pre_bias=p["fb"], scale=p["scale"],
+                             shift=p["shift"], act=pm.ACT_RELU)
+        if self.add_se == "max_pool":
+            x = self.se(x, pm.flex_pool(x, nbr_s))
+        if self.upsample and self.dilate > 1:
+            x = pm.three_interpolate_idw(x, lv["nn3_idx"], lv["nn3_dist"])
+        if self.concat:
+            x = self.concat_conv1d(x, x2=feat, act=pm.ACT_RELU)
+        return x
+
+
+# --------------------------------------------------------------------------- local backbone
+class BackboneLocalDilate(nn.Module):
+    """backbone_local_dilate (core/backbones.py:104-127)."""
+
+    def __init__(self, featdim=128, dilate2=8, bn_eps=1e-5):
+        super().__init__()
+        if featdim != 128:
+            raise NotImplementedError("featdim < 128 ('final_fc') is not used by the shipped configs")
+        self.initconv = nn.Module()
+        limit = math.sqrt(6.0 / (3 + 32))
+        self.initconv.position_theta = nn.Parameter(torch.empty(3, 32).uniform_(-limit, limit))
+        self.initconv.position_bias = nn.Parameter(torch.zeros(32))
+        self.initconv_bn = TPBatchNorm(32, bn_eps)
+        self.stage1 = FlexConvDilate(32, [64, 64], dilate=1, knn=8, concat=False, add_se="max_pool", bn_eps=bn_eps)
+        self.before_stage2_conv1d = FeatureConv1d(64, 64, bn=True, bn_eps=bn_eps)
+        self.stage2 = FlexConvDilate(64, [128, 128], dilate=dilate2, knn=8, concat=True, add_se="max_pool",
+                                     bn_eps=bn_eps)
+        self.local_stage1_shortcut = FeatureConv1d(64, 128, bn=True, bn_eps=bn_eps)
+        self._prep = None
+
+    def prepare(self):
+        scale, shift = [t.detach() for t in self.initconv_bn.fold()]
+        self._prep = {"theta": self.initconv.position_theta.detach().contiguous(),
+                      "bias": self.initconv.position_bias.detach().contiguous(), "scale": scale, "shift": shift}
+        self.stage1.prepare()
+        self.before_stage2_conv1d.tfconv0.prepare()
+        self.stage2.prepare()
+        self.local_stage1_shortcut.tfconv0.prepare()
+        return self._prep
+
+    def forward(self, geo):
+        p = self._prep or self.prepare()
+        nn_8 = geo.nbr if geo.nbr.shape[2] == 8 else geo.nbr[:, :, 0:8].contiguous()  # backbones.py:105
+        init = pm.conv_pointset_xyz(geo.xyz, nn_8, p["theta"], p["bias"], scale=p["scale"], shift=p["shift"],
+                                    act=pm.ACT_RELU)
+        init = pm.flex_pool(init, nn_8)
+        x1 = self.stage1(geo, init, nbr=nn_8)
+        x2 = self.before_stage2_conv1d(x1, act=pm.ACT_RELU)
+        x2 = self.stage2(geo, x2)
+        feat = self.local_stage1_shortcut(x1, act=pm.ACT_RELU, residual=x2)  # BNReLU(conv(x1)) + x2 (:123)
+        return geo.xyz, feat
+
+
+# --------------------------------------------------------------------------- heads
+class PointMLPHead(nn.Module):
+    """detection_block (:132-151) / globalatt_block (:156-173): Conv2D chain -> 1 logit -> sigmoid."""
+
+    def __init__(self, cin, conv_dims, fc_bias_init=0.0, bn_eps=1e-5):
+        super().__init__()
+        self.conv_dims = list(conv_dims)
+        c = cin
+        for i, d in enumerate(conv_dims):
+            setattr(self, "detec_conv%d" % i, Conv2D1x1(c, d, bn=True, bn_eps=bn_eps))
+            c = d
+        self.detec_conv_fc = Conv2D1x1(c, 1, bn=False, bias_init=fc_bias_init)
+        self._prep = None
+
+    def prepare(self):
+        for i in range(len(self.conv_dims)):
+            getattr(self, "detec_conv%d" % i).prepare()
+        self._prep = {"w_fc": self.detec_conv_fc.W.detach().reshape(-1).contiguous(),
+                      "b_fc": float(self.detec_conv_fc.b.detach().reshape(-1)[0].item())}
+        return self._prep
+
+    def forward(self, x):
+        p = self._prep or self.prepare()
+        n = len(self.conv_dims)
+        for i in range(n - 1):
+            x = getattr(self, "detec_conv%d" % i)(x, act=pm.ACT_RELU)
+        last = getattr(self, "detec_conv%d" % (n - 1))
+        lp = last._prep
+        return pm.mlp_head(x, lp["wp"], last.cout, p["w_fc"], p["b_fc"], pre_bias=lp["b"], scale=lp["scale"],
+                           shift=lp["shift"], act=pm.ACT_RELU)
+
+
+class NetVLAD(nn.Module):
+    """global_netvald_block + context_gating (core/backbones.py:202-320); variables live at the root scope."""
+
+    def __init__(self, feature_size=256, cluster_size=64, output_dim=256, add_batch_norm=True, gating=True,
+                 slim_bn_eps=1e-3):
+        super().__init__()
+        if not (add_batch_norm and gating):
+            raise NotImplementedError("shipped configs use add_batch_norm=True, gating=True")
+        D, C, O = feature_size, cluster_size, output_dim
+        self.D, self.C, self.O = D, C, O
+        self.cluster_weights = nn.Parameter(torch.randn(D, C) / math.sqrt(D))
+        self.cluster_bn = SlimBatchNorm(C, slim_bn_eps)
+        self.cluster_weights2 = nn.Parameter(torch.randn(1, D, C) / math.sqrt(D))
+        self.hidden1_weights = nn.Parameter(torch.randn(C * D, O) / math.sqrt(C))
+        self.bn = SlimBatchNorm(O, slim_bn_eps)
+        self.gating_weights = nn.Parameter(torch.randn(O, O) / math.sqrt(O))
+        self.gating_bn = SlimBatchNorm(O, slim_bn_eps)
+        self._prep = None
+
+    def prepare(self):
+        cs, ch = [t.detach() for t in self.cluster_bn.fold()]
+        s1, h1 = [t.detach() for t in self.bn.fold()]
+        s2, h2 = [t.detach() for t in self.gating_bn.fold()]
+        self._prep = {
+            "wc": pm.pack_weight(self.cluster_weights.detach().contiguous()),
+            "cs": cs, "ch": ch,
+            "W2": self.cluster_weights2.detach().reshape(self.D, self.C).contiguous(),
+            "Wh": self.hidden1_weights.detach().contiguous(), "s1": s1, "h1": h1,
+            "Wg": self.gating_weights.detach().contiguous(), "s2": s2, "h2": h2,
+        }
+        return self._prep
+
+    def forward(self, features, att, l2_eps=0.0):
+        """features [B,N,256], att [B,N,1] -> [B,256] ('final_global'); l2_eps > 0 also applies
+        tf.nn.l2_normalize(dim=-1, epsilon=l2_eps) (core/model.py:205)."""
+        p = self._prep or self.prepare()
+        vlad = pm.netvlad_aggregate(features, att, p["wc"], p["cs"], p["ch"], p["W2"])
+        return pm.netvlad_head(vlad, p["Wh"], p["s1"], p["h1"], p["Wg"], p["s2"], p["h2"], l2_eps=l2_eps)

@@ -1,0 +1,320 @@
+// Per-point dense layers of the DH3D backbone for gfx950 (core/tf_utils.py:99-109 feature_conv1d_1,
+// core/backbones.py:45-55 se_res_bottleneck, :132-173 detection / attention heads,
+// core/model.py:177-181 l2-normalise + concat).  In the reference these are tensorpack Conv2D /
+// BatchNorm / TF element-wise ops with a transpose between every block; here every layer is one
+// kernel on [R, C] rows (R = B*N points): rows staged through LDS once, exact-f32 MFMA GEMM against a
+// fragment-packed weight, and bias + BatchNorm + activation (+ residual) applied in the store.
+#include "mfma_gemm.h"
+
+namespace {
+
+// ------------------------------------------------------------------ weight packing
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restrict__ W, int Kd, int Dout,
+                                                         float *__restrict__ packed) {
+  const int KB = Kd / 8;
+  const long long total = (long long)Kd * Dout;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total;
+       e += (long long)gridDim.x * 256) {
+    const int t = (int)(e & 3);
+    const int lane = (int)((e >> 2) & 63);
+    const long long blk = e >> 8;  // nb*KB + kb
+    const int kb = (int)(blk % KB);
+    const int nb = (int)(blk / KB);
+    const int k = kb * 8 + 4 * (lane >> 5) + t;
+    const int col = nb * 32 + (lane & 31);
+    packed[e] = W[(size_t)k * Dout + col];
+  }
+}
+
+// Wcat = [bias; theta_x; theta_y; theta_z] ([4*Din, Dout]) packed directly from theta/bias.
+__global__ __launch_bounds__(256) void pack_flex_weight_kernel(const float *__restrict__ theta,
+                                                              const float *__restrict__ bias, int Din,
+                                                              int Dout, float *__restrict__ packed) {
+  const int Kd = 4 * Din;
+  const int KB = Kd / 8;
+  const long long total = (long long)Kd * Dout;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total;
+       e += (long long)gridDim.x * 256) {
+    const int t = (int)(e & 3);
+    const int lane = (int)((e >> 2) & 63);
+    const long long blk = e >> 8;
+    const int kb = (int)(blk % KB);
+    const int nb = (int)(blk / KB);
+    const int k = kb * 8 + 4 * (lane >> 5) + t;
+    const int col = nb * 32 + (lane & 31);
+    const int comp = k / Din, i = k % Din;
+    packed[e] = comp == 0 ? bias[(size_t)i * Dout + col]
+                          : theta[((size_t)(comp - 1) * Din + i) * Dout + col];
+  }
+}
+
+// ------------------------------------------------------------------ linear
+constexpr int kTM = 64;
+
+// Stage rows [grow0, grow0+64) of [x1 | x2] into LDS (ld = Kd+4), zero-filling past R.
+__device__ __forceinline__ void stage_rows(const float *__restrict__ x1, int C1,
+                                           const float *__restrict__ x2, int C2, long long grow0,
+                                           long long R, float *s_A, int ld) {
+  const int Kd = C1 + C2;
+  const int kv = Kd / 4;
+  for (int e = threadIdx.x; e < kTM * kv; e += 256) {
+    const int p = e / kv;
+    const int c4 = (e - p * kv) * 4;
+    const long long g = grow0 + p;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g < R) {
+      v = c4 < C1 ? *reinterpret_cast<const float4 *>(x1 + g * C1 + c4)
+                  : *reinterpret_cast<const float4 *>(x2 + g * C2 + (c4 - C1));
+    }
+    *reinterpret_cast<float4 *>(s_A + (size_t)p * ld + c4) = v;
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void linear_pm_kernel(const float *__restrict__ x1, int C1,
+                                                       const float *__restrict__ x2, int C2,
+                                                       const float *__restrict__ wpacked, long long R,
+                                                       int Dout, EpilogueArgs ep,
+                                                       const float *__restrict__ residual,
+                                                       float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float s_A[];
+  const int Kd = C1 + C2;
+  const int ld = Kd + 4;
+  const long long grow0 = (long long)blockIdx.x * kTM;
+  stage_rows(x1, C1, x2, C2, grow0, R, s_A, ld);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6;
+  const int row0 = (wave & 1) * 32;
+  const int cb0 = wave >> 1;
+  f32x16 acc[NT];
+  zero_acc<NT>(acc);
+  wave_gemm_f32<NT>(s_A, ld, row0, wpacked, Kd / 8, cb0, 2, acc);
+  wave_store_f32<NT>(acc, grow0, row0, cb0, 2, R, Dout, ep, residual, out);
+}
+
+// ------------------------------------------------------------------ MLP head (wide hidden layer kept on chip)
+// att[r] = sigmoid( sum_j relu(bn(h[r,:] @ W[:,j] + b[j])) * w_fc[j] + b_fc ); H = 64*PASSES*... columns.
+__global__ __launch_bounds__(256) void mlp_head_pm_kernel(const float *__restrict__ h, int C,
+                                                         const float *__restrict__ wpacked, int H,
+                                                         EpilogueArgs ep, const float *__restrict__ w_fc,
+                                                         float b_fc, long long R,
+                                                         float *__restrict__ att) {
+  extern __shared__ __attribute__((aligned(16))) float s_A[];
+  __shared__ float s_part[2][kTM];  // [column-half wave group][row]
+  const int ld = C + 4;
+  const long long grow0 = (long long)blockIdx.x * kTM;
+  stage_rows(h, C, h, 0, grow0, R, s_A, ld);  // (a literal nullptr here crashes hipcc 7.2's inliner)
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int row0 = (wave & 1) * 32;
+  const int NB = H / 32;
+  float part[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) part[r] = 0.f;
+  // wave (row block rb, column parity cp) walks column blocks cp, cp+2, ... two at a time
+  for (int cb = (wave >> 1); cb < NB; cb += 4) {
+    f32x16 acc[2];
+    zero_acc<2>(acc);
+    wave_gemm_f32<2>(s_A, ld, row0, wpacked, C / 8, cb, 2, acc);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = (cb + 2 * j) * 32 + (lane & 31);
+      float pb = 0.f, sc = 1.f, sh = 0.f;
+      if (ep.pre_bias) pb = ep.pre_bias[col];
+      if (ep.scale) sc = ep.scale[col];
+      if (ep.shift) sh = ep.shift[col];
+      const float wf = w_fc[col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[r] = fmaf(dh3d_act((acc[j][r] + pb) * sc + sh, ep.act), wf, part[r]);
+    }
+  }
+  // reduce over the 32 columns held by the lanes of each half-wave
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) part[r] += __shfl_xor(part[r], off, 64);
+  }
+  if ((lane & 31) == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_part[wave >> 1][row0 + mfma_row(r, lane)] = part[r];
+  }
+  __syncthreads();
+  if (threadIdx.x < kTM) {
+    const long long g = grow0 + threadIdx.x;
+    if (g < R) {
+      const float logit = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + b_fc;
+      att[g] = 1.f / (1.f + expf(-logit));
+    }
+  }
+}
+
+// ------------------------------------------------------------------ squeeze-excite residual
+template <int C>
+__global__ __launch_bounds__(256) void se_res_pm_kernel(const float *__restrict__ x,
+                                                       const float *__restrict__ pool,
+                                                       const float *__restrict__ W1,
+                                                       const float *__restrict__ b1,
+                                                       const float *__restrict__ W2,
+                                                       const float *__restrict__ b2, long long R,
+                                                       float *__restrict__ out) {
+  constexpr int Cq = C / 4;
+  constexpr int LDP = C + 1;
+  __shared__ float s_pool[kTM * LDP];
+  __shared__ float s_h[kTM * (Cq + 1)];
+  __shared__ float s_W1[C * Cq];
+  __shared__ __attribute__((aligned(16))) float s_W2[Cq * C];
+  const int tid = threadIdx.x;
+  const long long grow0 = (long long)blockIdx.x * kTM;
+  for (int e = tid; e < C * Cq; e += 256) { s_W1[e] = W1[e]; s_W2[e] = W2[e]; }
+  for (int e = tid; e < kTM * C; e += 256) {
+    const int p = e / C, c = e % C;
+    const long long g = grow0 + p;
+    s_pool[p * LDP + c] = g < R ? pool[g * C + c] : 0.f;
+  }
+  __syncthreads();
+  // squeeze: thread (p = tid/4, j-range (tid%4)*Cq/4 ...)
+  {
+    const int p = tid >> 2;
+    constexpr int JW = Cq / 4;
+    const int j0 = (tid & 3) * JW;
+    float acc[JW];
+#pragma unroll
+    for (int j = 0; j < JW; ++j) acc[j] = b1[j0 + j];
+    for (int c = 0; c < C; ++c) {
+      const float v = s_pool[p * LDP + c];
+#pragma unroll
+      for (int j = 0; j < JW; ++j) acc[j] = fmaf(v, s_W1[c * Cq + j0 + j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < JW; ++j) s_h[p * (Cq + 1) + j0 + j] = acc[j] > 0.f ? acc[j] : 0.f;
+  }
+  __syncthreads();
+  // excite: thread (p = tid/4, channel range (tid%4)*C/4 ...), 4 channels at a time
+  {
+    const int p = tid >> 2;
+    const long long g = grow0 + p;
+    constexpr int CW = C / 4;
+    const int c0 = (tid & 3) * CW;
+    if (g < R) {
+      for (int cc = 0; cc < CW; cc += 4) {
+        const int c = c0 + cc;
+        float4 gate = *reinterpret_cast<const float4 *>(b2 + c);
+        for (int j = 0; j < Cq; ++j) {
+          const float hv = s_h[p * (Cq + 1) + j];
+          const float4 w = *reinterpret_cast<const float4 *>(&s_W2[j * C + c]);
+          gate.x = fmaf(hv, w.x, gate.x); gate.y = fmaf(hv, w.y, gate.y);
+          gate.z = fmaf(hv, w.z, gate.z); gate.w = fmaf(hv, w.w, gate.w);
+        }
+        const float4 xv = *reinterpret_cast<const float4 *>(x + g * C + c);
+        float4 r;
+        r.x = xv.x + xv.x * (1.f / (1.f + expf(-gate.x)));
+        r.y = xv.y + xv.y * (1.f / (1.f + expf(-gate.y)));
+        r.z = xv.z + xv.z * (1.f / (1.f + expf(-gate.z)));
+        r.w = xv.w + xv.w * (1.f / (1.f + expf(-gate.w)));
+        r.x = r.x > 0.f ? r.x : 0.f; r.y = r.y > 0.f ? r.y : 0.f;
+        r.z = r.z > 0.f ? r.z : 0.f; r.w = r.w > 0.f ? r.w : 0.f;
+        *reinterpret_cast<float4 *>(out + g * C + c) = r;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ l2 normalise (+ prefix concat)
+__global__ __launch_bounds__(256) void l2norm_concat_kernel(const float *__restrict__ x, long long R, int C,
+                                                           float eps, const float *__restrict__ prefix,
+                                                           int P, float *__restrict__ out) {
+  const int sub = threadIdx.x & 31;                        // 32 lanes per row
+  const long long row = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (row >= R) return;                                    // whole 32-lane group exits together
+  float ss = 0.f;
+  for (int c = sub; c < C; c += 32) { const float v = x[row * C + c]; ss = fmaf(v, v, ss); }
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+  const float inv = rsqrtf(fmaxf(ss, eps));  // tf.nn.l2_normalize: x * rsqrt(max(sum(x^2), eps))
+  float *o = out + row * (P + C);
+  for (int c = sub; c < P; c += 32) o[c] = prefix[row * P + c];
+  for (int c = sub; c < C; c += 32) o[P + c] = x[row * C + c] * inv;
+}
+
+}  // namespace
+
+DH3D_API int dh3d_pack_weight(const float *W, int Kd, int Dout, float *packed, void *stream) {
+  DH3D_REQUIRE(W && packed && Kd > 0 && Dout > 0);
+  DH3D_SUPPORTED(Kd % 8 == 0 && Dout % 32 == 0);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(dh3d_cdiv((long long)Kd * Dout, 256)), dim3(256), 0,
+                     (hipStream_t)stream, W, Kd, Dout, packed);
+  return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_pack_flex_weight(const float *theta, const float *bias, int Din, int Dout,
+                                   float *packed, void *stream) {
+  DH3D_REQUIRE(theta && bias && packed && Din > 0 && Dout > 0);
+  DH3D_SUPPORTED(Din % 2 == 0 && Dout % 32 == 0);
+  hipLaunchKernelGGL(pack_flex_weight_kernel, dim3(dh3d_cdiv((long long)4 * Din * Dout, 256)), dim3(256),
+                     0, (hipStream_t)stream, theta, bias, Din, Dout, packed);
+  return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_linear_pm_fwd(const float *x1, int C1, const float *x2, int C2, const float *wpacked,
+                                int R, int Dout, const dh3d_epilogue *ep, const float *residual,
+                                float *out, void *stream) {
+  DH3D_REQUIRE(x1 && wpacked && out && R > 0 && C1 > 0 && C2 >= 0 && Dout > 0 && (C2 == 0 || x2));
+  const int Kd = C1 + C2;
+  DH3D_SUPPORTED(C1 % 4 == 0 && C2 % 4 == 0 && Kd % 8 == 0 && Dout % 64 == 0 && Dout <= 256 && Kd <= 512);
+  const size_t lds = sizeof(float) * kTM * (Kd + 4);
+  const EpilogueArgs e = dh3d_ep(ep);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(dh3d_cdiv(R, kTM)), block(256);
+#define DH3D_LIN_CASE(NTV)                                                                            \
+  {                                                                                                   \
+    auto kern = linear_pm_kernel<NTV>;                                                                \
+    DH3D_ALLOW_BIG_LDS(kern);                                                                         \
+    hipLaunchKernelGGL(kern, grid, block, lds, s, x1, C1, x2, C2, wpacked, (long long)R, Dout, e,     \
+                       residual, out);                                                                \
+  }
+  switch (Dout / 64) {
+    case 1: DH3D_LIN_CASE(1) break;
+    case 2: DH3D_LIN_CASE(2) break;
+    case 3: DH3D_LIN_CASE(3) break;
+    default: DH3D_LIN_CASE(4) break;
+  }
+#undef DH3D_LIN_CASE
+  return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_mlp_head_pm_fwd(const float *h, int R, int C, const float *wpacked, int H,
+                                  const dh3d_epilogue *ep, const float *w_fc, float b_fc, float *att,
+                                  void *stream) {
+  DH3D_REQUIRE(h && wpacked && w_fc && att && R > 0 && C > 0 && H > 0);
+  DH3D_SUPPORTED(C % 8 == 0 && C <= 512 && H % 128 == 0);
+  const size_t lds = sizeof(float) * kTM * (C + 4);
+  auto kern = mlp_head_pm_kernel;
+  DH3D_ALLOW_BIG_LDS(kern);
+  hipLaunchKernelGGL(kern, dim3(dh3d_cdiv(R, kTM)), dim3(256), lds, (hipStream_t)stream, h, C, wpacked, H,
+                     dh3d_ep(ep), w_fc, b_fc, (long long)R, att);
+  return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_se_res_pm_fwd(const float *x, const float *pool, const float *W1, const float *b1,
+                                const float *W2, const float *b2, int R, int C, float *out,
+                                void *stream) {
+  DH3D_REQUIRE(x && pool && W1 && b1 && W2 && b2 && out && R > 0);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(dh3d_cdiv(R, kTM)), block(256);
+  if (C == 64)
+    hipLaunchKernelGGL(se_res_pm_kernel<64>, grid, block, 0, s, x, pool, W1, b1, W2, b2, (long long)R, out);
+  else if (C == 128)
+    hipLaunchKernelGGL(se_res_pm_kernel<128>, grid, block, 0, s, x, pool, W1, b1, W2, b2, (long long)R, out);
+  else
+    return DH3D_ERR_UNSUPPORTED;
+  return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_l2norm_concat_fwd(const float *x, int R, int C, float eps, const float *prefix, int P,
+                                    float *out, void *stream) {
+  DH3D_REQUIRE(x && out && R > 0 && C > 0 && P >= 0 && (P == 0 || prefix));
+  hipLaunchKernelGGL(l2norm_concat_kernel, dim3(dh3d_cdiv(R, 8)), dim3(256), 0, (hipStream_t)stream, x,
+                     (long long)R, C, eps, prefix, P, out);
+  return dh3d_launch_status();
+}

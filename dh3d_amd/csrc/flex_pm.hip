@@ -1,0 +1,211 @@
+// Fused point-major flex operators for gfx950 (the model path).
+//
+// flex_conv (reference: user_ops/kernels/flex_conv_kernel_gpu.cu.cc:46-158) computes
+//     out[n,o] = sum_k sum_i ( bias[i,o] + sum_d theta[d,i,o] * (p[nk,d]-p[n,d]) ) * f[nk,i].
+// The reference synthesises a weight per (k,i,o): 9 flop per MAC, f32-VALU bound by 17-80x over its
+// memory time.  Pulling the k-sum inside gives the exact algebraic factorisation
+//     out[n,:] = [S0 | Sx | Sy | Sz][n,:] @ [bias; theta_x; theta_y; theta_z]
+//     S0[n,i] = sum_k f[nk,i]      Sd[n,i] = sum_k (p[nk,d]-p[n,d]) * f[nk,i]
+// i.e. a K-neighbour gather-reduce (memory shaped: each neighbour row f[nk,:] is one contiguous
+// 4*Din-byte read in the point-major layout) followed by a [TM, 4*Din] x [4*Din, Dout] GEMM on the
+// exact-f32 MFMA pipe.  One kernel: phase A fills the S tile in LDS, phase B runs the GEMM from LDS
+// and applies feature_bias + BatchNorm + activation in the store.  Workgroups are tiles of
+// consecutive points of one cloud, so an XCD's L2 sees one cloud's features at a time.
+#include <float.h>
+
+#include "mfma_gemm.h"
+
+namespace {
+
+// ------------------------------------------------------------------ flex_conv
+template <int DIN, int DOUT>
+struct FlexCfg {
+  static constexpr int TM = DIN <= 64 ? 64 : 32;    // points per workgroup
+  static constexpr int KD = 4 * DIN;                // GEMM depth
+  static constexpr int LD = KD + 4;                 // LDS leading dimension (floats)
+  static constexpr int MB = TM / 32;                // 32-row blocks
+  static constexpr int NB = DOUT / 32;              // 32-col blocks
+  static constexpr int NT = NB * MB / 4;            // tiles per wave
+  static constexpr int LPR = DIN / 4;               // lanes per gathered row (float4 each)
+  static constexpr int PPR = 256 / LPR;             // points per gather round
+  static constexpr int ROUNDS = TM / PPR;
+  static_assert(NT >= 1 && NB * MB % 4 == 0, "tile must split over 4 waves");
+};
+
+template <int DIN, int DOUT>
+__global__ __launch_bounds__(256) void flex_conv_pm_kernel(
+    const float *__restrict__ feat, const float *__restrict__ xyz, const int32_t *__restrict__ nbr,
+    const float *__restrict__ wpacked, long long R, int N, int K, EpilogueArgs ep,
+    float *__restrict__ out) {
+  using C = FlexCfg<DIN, DOUT>;
+  extern __shared__ __attribute__((aligned(16))) float s_S[];  // [TM][LD]
+  const int tid = threadIdx.x;
+  const long long grow0 = (long long)blockIdx.x * C::TM;
+
+  // ---- phase A: gather-reduce S = [S0|Sx|Sy|Sz] for TM points
+  const int r4 = (tid % C::LPR) * 4;
+#pragma unroll
+  for (int rd = 0; rd < C::ROUNDS; ++rd) {
+    const int p = rd * C::PPR + tid / C::LPR;
+    const long long n = grow0 + p;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), sx = s0, sy = s0, sz = s0;
+    if (n < R) {
+      const long long cloud0 = (n / N) * N;
+      const float px = xyz[n * 3], py = xyz[n * 3 + 1], pz = xyz[n * 3 + 2];
+      const int32_t *nb = nbr + n * K;
+#pragma unroll 4
+      for (int k = 0; k < K; ++k) {
+        const long long g = cloud0 + nb[k];
+        const float4 f = *reinterpret_cast<const float4 *>(feat + g * DIN + r4);
+        const float dx = xyz[g * 3] - px, dy = xyz[g * 3 + 1] - py, dz = xyz[g * 3 + 2] - pz;
+        s0.x += f.x; s0.y += f.y; s0.z += f.z; s0.w += f.w;
+        sx.x = fmaf(dx, f.x, sx.x); sx.y = fmaf(dx, f.y, sx.y); sx.z = fmaf(dx, f.z, sx.z); sx.w = fmaf(dx, f.w, sx.w);
+        sy.x = fmaf(dy, f.x, sy.x); sy.y = fmaf(dy, f.y, sy.y); sy.z = fmaf(dy, f.z, sy.z); sy.w = fmaf(dy, f.w, sy.w);
+        sz.x = fmaf(dz, f.x, sz.x); sz.y = fmaf(dz, f.y, sz.y); sz.z = fmaf(dz, f.z, sz.z); sz.w = fmaf(dz, f.w, sz.w);
+      }
+    }
+    float *row = s_S + (size_t)p * C::LD + r4;
+    *reinterpret_cast<float4 *>(row) = s0;
+    *reinterpret_cast<float4 *>(row + DIN) = sx;
+    *reinterpret_cast<float4 *>(row + 2 * DIN) = sy;
+    *reinterpret_cast<float4 *>(row + 3 * DIN) = sz;
+  }
+  __syncthreads();
+
+  // ---- phase B: S @ Wcat on the f32 MFMA pipe, epilogue in the store
+  const int wave = tid >> 6;
+  const int row0 = (C::MB == 2) ? (wave & 1) * 32 : 0;
+  const int cb0 = (C::MB == 2) ? (wave >> 1) : wave;
+  constexpr int cbstride = (C::MB == 2) ? 2 : 4;
+  f32x16 acc[C::NT];
+  zero_acc<C::NT>(acc);
+  wave_gemm_f32<C::NT>(s_S, C::LD, row0, wpacked, C::KD / 8, cb0, cbstride, acc);
+  wave_store_f32<C::NT>(acc, grow0, row0, cb0, cbstride, R, DOUT, ep, nullptr, out);
+}
+
+template <int DIN, int DOUT>
+int flex_conv_pm_launch(const float *feat, const float *xyz, const int32_t *nbr, const float *wpacked,
+                        int B, int N, int K, const EpilogueArgs &ep, float *out, hipStream_t s) {
+  using C = FlexCfg<DIN, DOUT>;
+  const long long R = (long long)B * N;
+  const size_t lds = sizeof(float) * C::TM * C::LD;
+  auto kern = flex_conv_pm_kernel<DIN, DOUT>;
+  DH3D_ALLOW_BIG_LDS(kern);
+  hipLaunchKernelGGL(kern, dim3(dh3d_cdiv(R, C::TM)), dim3(256), lds, s, feat, xyz, nbr, wpacked, R, N, K,
+                     ep, out);
+  return dh3d_launch_status();
+}
+
+// ------------------------------------------------------------------ flex_pool
+__global__ __launch_bounds__(256) void flex_pool_pm_kernel(const float *__restrict__ feat,
+                                                          const int32_t *__restrict__ nbr, long long R,
+                                                          int N, int K, int C, float *__restrict__ out,
+                                                          int32_t *__restrict__ argmax) {
+  const int cv = C / 4;
+  const long long total = R * cv;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total;
+       e += (long long)gridDim.x * 256) {
+    const long long n = e / cv;
+    const int c4 = (int)(e - n * cv) * 4;
+    const long long cloud0 = (n / N) * N;
+    const int32_t *nb = nbr + n * K;
+    float4 best = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+    int4 bi = make_int4(0, 0, 0, 0);
+#pragma unroll 4
+    for (int k = 0; k < K; ++k) {
+      const int g = nb[k];
+      const float4 v = *reinterpret_cast<const float4 *>(feat + (cloud0 + g) * C + c4);
+      if (best.x < v.x) { best.x = v.x; bi.x = g; }
+      if (best.y < v.y) { best.y = v.y; bi.y = g; }
+      if (best.z < v.z) { best.z = v.z; bi.z = g; }
+      if (best.w < v.w) { best.w = v.w; bi.w = g; }
+    }
+    *reinterpret_cast<float4 *>(out + n * C + c4) = best;
+    if (argmax) *reinterpret_cast<int4 *>(argmax + n * C + c4) = bi;
+  }
+}
+
+// ------------------------------------------------------------------ conv_pointset on coordinates
+// out[n,o] = sum_k sum_i theta[i,o]*(x[nk,i]-x[n0,i]) + bias[o]  (conv_pointset_kernel.cc:46-64), Din=3.
+__global__ __launch_bounds__(256) void conv_pointset_pm_kernel(
+    const float *__restrict__ xyz, const int32_t *__restrict__ nbr, const float *__restrict__ theta,
+    const float *__restrict__ bias, long long R, int N, int K, int Dout, EpilogueArgs ep,
+    float *__restrict__ out) {
+  const int cv = Dout / 4;
+  const long long total = R * cv;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total;
+       e += (long long)gridDim.x * 256) {
+    const long long n = e / cv;
+    const int o4 = (int)(e - n * cv) * 4;
+    const long long cloud0 = (n / N) * N;
+    const int32_t *nb = nbr + n * K;
+    const long long g0 = cloud0 + nb[0];
+    const float x0 = xyz[g0 * 3], y0 = xyz[g0 * 3 + 1], z0 = xyz[g0 * 3 + 2];
+    const float4 tx = *reinterpret_cast<const float4 *>(theta + o4);
+    const float4 ty = *reinterpret_cast<const float4 *>(theta + Dout + o4);
+    const float4 tz = *reinterpret_cast<const float4 *>(theta + 2 * Dout + o4);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < K; ++k) {
+      const long long g = cloud0 + nb[k];
+      const float dx = xyz[g * 3] - x0, dy = xyz[g * 3 + 1] - y0, dz = xyz[g * 3 + 2] - z0;
+      acc.x = fmaf(tz.x, dz, fmaf(ty.x, dy, fmaf(tx.x, dx, acc.x)));
+      acc.y = fmaf(tz.y, dz, fmaf(ty.y, dy, fmaf(tx.y, dx, acc.y)));
+      acc.z = fmaf(tz.z, dz, fmaf(ty.z, dy, fmaf(tx.z, dx, acc.z)));
+      acc.w = fmaf(tz.w, dz, fmaf(ty.w, dy, fmaf(tx.w, dx, acc.w)));
+    }
+    const float4 bq = *reinterpret_cast<const float4 *>(bias + o4);
+    float4 r;
+    r.x = dh3d_epilogue_apply(acc.x + bq.x, o4, ep);
+    r.y = dh3d_epilogue_apply(acc.y + bq.y, o4 + 1, ep);
+    r.z = dh3d_epilogue_apply(acc.z + bq.z, o4 + 2, ep);
+    r.w = dh3d_epilogue_apply(acc.w + bq.w, o4 + 3, ep);
+    *reinterpret_cast<float4 *>(out + n * Dout + o4) = r;
+  }
+}
+
+inline int flat_grid(long long total) {
+  long long g = (total + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
+}  // namespace
+
+DH3D_API int dh3d_flex_conv_pm_fwd(const float *features, const float *xyz, const int32_t *nbr,
+                                   const float *wpacked, int B, int N, int K, int Din, int Dout,
+                                   const dh3d_epilogue *ep, float *out, void *stream) {
+  DH3D_REQUIRE(features && xyz && nbr && wpacked && out && B > 0 && N > 0 && K > 0);
+  const EpilogueArgs e = dh3d_ep(ep);
+  hipStream_t s = (hipStream_t)stream;
+#define DH3D_FLEX_CASE(DI, DO) \
+  if (Din == DI && Dout == DO) return flex_conv_pm_launch<DI, DO>(features, xyz, nbr, wpacked, B, N, K, e, out, s)
+  DH3D_FLEX_CASE(32, 64);
+  DH3D_FLEX_CASE(32, 128);
+  DH3D_FLEX_CASE(64, 64);
+  DH3D_FLEX_CASE(64, 128);
+  DH3D_FLEX_CASE(64, 256);
+  DH3D_FLEX_CASE(128, 128);
+  DH3D_FLEX_CASE(128, 256);
+#undef DH3D_FLEX_CASE
+  return DH3D_ERR_UNSUPPORTED;
+}
+
+DH3D_API int dh3d_flex_pool_pm_fwd(const float *features, const int32_t *nbr, int B, int N, int K, int C,
+                                   float *out, int32_t *argmax, void *stream) {
+  DH3D_REQUIRE(features && nbr && out && B > 0 && N > 0 && K > 0 && C > 0);
+  DH3D_SUPPORTED(C % 4 == 0);
+  const long long R = (long long)B * N;
+  hipLaunchKernelGGL(flex_pool_pm_kernel, dim3(flat_grid(R * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                     features, nbr, R, N, K, C, out, argmax);
+  return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_conv_pointset_pm_fwd(const float *xyz, const int32_t *nbr, const float *theta,
+                                       const float *bias, int B, int N, int K, int Dout,
+                                       const dh3d_epilogue *ep, float *out, void *stream) {
+  DH3D_REQUIRE(xyz && nbr && theta && bias && out && B > 0 && N > 0 && K > 0 && Dout > 0);
+  DH3D_SUPPORTED(Dout % 4 == 0);
+  const long long R = (long long)B * N;
+  hipLaunchKernelGGL(conv_pointset_pm_kernel, dim3(flat_grid(R * (Dout / 4))), dim3(256), 0,
+                     (hipStream_t)stream, xyz, nbr, theta, bias, R, N, K, Dout, dh3d_ep(ep), out);
+  return dh3d_launch_status();
+}

@@ -1,0 +1,86 @@
+// Exact-f32 MFMA tile GEMM shared by the fused point-major kernels.
+//
+// out[TM x Dout] = A[TM x Kd] (row-major in LDS) * W[Kd x Dout] (fragment-packed in global memory).
+//
+// v_mfma_f32_32x32x2_f32 takes ONE f32 of A and of B per lane per instruction:
+//   A operand: lane l holds A[i = l&31][k = l>>5]      B operand: lane l holds B[k = l>>5][j = l&31]
+//   D (16 regs): row = (reg&3) + 8*(reg>>2) + 4*(l>>5), col = l&31
+// A dot product may visit k in any order, so k is consumed in blocks of 8 with the order
+// {t, 4+t | t=0..3}: lane half h = l>>5 fetches the four consecutive values k = 8*kb + 4*h + t with a
+// single 16-byte access (ds_read_b128 for A, global_load_dwordx4 for the packed W) and feeds them to
+// four back-to-back MFMAs.  The result is a plain f32 fma chain per output (no reduced precision).
+//
+// Packed W layout (dh3d_pack_weight): packed[((nb*KB + kb)*64 + lane)*4 + t]
+//      = W[8*kb + 4*(lane>>5) + t][32*nb + (lane&31)],  KB = Kd/8, nb = column block of 32.
+// LDS leading dimension must be Kd+4 floats: 16-byte aligned rows and (ld/4) odd, which makes the
+// ds_read_b128 A-fragment reads bank-conflict free (rows differ mod 16 inside each 16-lane group).
+#pragma once
+#include "common.h"
+
+// NT column blocks (cb0, cb0+cbstride, ...) of one 32-row block starting at LDS row `row0`.
+template <int NT>
+__device__ __forceinline__ void wave_gemm_f32(const float *s_A, int ldA, int row0,
+                                              const float *__restrict__ wpacked, int KB, int cb0,
+                                              int cbstride, f32x16 (&acc)[NT]) {
+  const int lane = threadIdx.x & 63;
+  const float *aptr = s_A + (size_t)(row0 + (lane & 31)) * ldA + 4 * (lane >> 5);
+  const f32x4 *wp = reinterpret_cast<const f32x4 *>(wpacked) + lane;
+  f32x4 bnext[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) bnext[j] = wp[(size_t)((cb0 + j * cbstride) * KB) * 64];
+  for (int kb = 0; kb < KB; ++kb) {
+    const f32x4 a4 = *reinterpret_cast<const f32x4 *>(aptr + kb * 8);
+    f32x4 bcur[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      bcur[j] = bnext[j];
+      if (kb + 1 < KB) bnext[j] = wp[(size_t)((cb0 + j * cbstride) * KB + kb + 1) * 64];
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0], bcur[j][0], acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1], bcur[j][1], acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[2], bcur[j][2], acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[3], bcur[j][3], acc[j], 0, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ int mfma_row(int reg, int lane) {
+  return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+}
+
+template <int NT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[NT]) {
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+}
+
+// Epilogue + store of one wave's tiles to a row-major [R, Dout] output; optional residual added
+// after the activation.  grow0 = global row of LDS row 0 of this workgroup's tile.
+template <int NT>
+__device__ __forceinline__ void wave_store_f32(const f32x16 (&acc)[NT], long long grow0, int row0,
+                                               int cb0, int cbstride, long long R, int Dout,
+                                               const EpilogueArgs &ep, const float *__restrict__ residual,
+                                               float *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = (cb0 + j * cbstride) * 32 + (lane & 31);
+    float pb = 0.f, sc = 1.f, sh = 0.f;
+    if (ep.pre_bias) pb = ep.pre_bias[col];
+    if (ep.scale) sc = ep.scale[col];
+    if (ep.shift) sh = ep.shift[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long long grow = grow0 + row0 + mfma_row(r, lane);
+      if (grow < R) {
+        float v = dh3d_act((acc[j][r] + pb) * sc + sh, ep.act);
+        if (residual) v += residual[grow * Dout + col];
+        out[grow * Dout + col] = v;
+      }
+    }
+  }
+}

@@ -1,0 +1,313 @@
+// Attention-weighted NetVLAD aggregation + context gating for gfx950
+// (core/backbones.py:202-320, adopted there from PCAN/loupe).  The reference runs ~15 un-fused TF ops
+// with many passes over the [B*N, 256] feature map.  Here:
+//   K1 netvlad_assign_accumulate : per chunk of points of one cloud -- row l2-normalise into LDS,
+//        assignment GEMM (xn @ Wc, f32 MFMA), BN + softmax + attention weighting in LDS, then the
+//        VLAD contraction  vladT[c,d] += sum_p a[p,c] * xn[p,d]  as a second MFMA GEMM whose
+//        accumulators stay in registers across all tiles of the chunk.  x is read from HBM once.
+//   K2 netvlad_finalize          : sum chunk partials (fixed order -> deterministic), subtract
+//        a_sum * W2, intra-normalise per cluster, flatten d-major, L2-normalise.
+//   K3 netvlad_hidden_splitk     : [B,16384] x [16384,256] projection, split over K so that the
+//        16.8 MB weight streams from HBM exactly once across all CUs.
+//   K4 netvlad_gate              : reduce split-K partials, BN, context gating, final L2-normalise.
+#include "mfma_gemm.h"
+
+namespace {
+
+constexpr int kD = 256;   // feature size
+constexpr int kCl = 64;   // clusters
+constexpr int kTM = 64;   // points per tile
+constexpr int kLDX = kD + 4;
+constexpr int kLDA = kTM + 4;  // actT [cluster][point]
+
+// chunks per cloud: each workgroup keeps a [64 x 256] accumulator over its chunk
+static inline int netvlad_chunks(int B, int N) {
+  const int tiles = (N + kTM - 1) / kTM;
+  int ch = 256 / (B > 0 ? B : 1);
+  if (ch < 1) ch = 1;
+  if (ch > 16) ch = 16;
+  if (ch > tiles) ch = tiles;
+  return ch;
+}
+
+__global__ __launch_bounds__(256) void netvlad_assign_accumulate(
+    const float *__restrict__ x, const float *__restrict__ att, const float *__restrict__ wc_packed,
+    const float *__restrict__ bn_scale, const float *__restrict__ bn_shift, int N, int chunks,
+    float *__restrict__ part_vlad /*[B][chunks][Cl][D]*/, float *__restrict__ part_asum /*[B][chunks][Cl]*/) {
+  extern __shared__ __attribute__((aligned(16))) float s_mem[];
+  float *s_x = s_mem;                         // [kTM][kLDX]  l2-normalised rows
+  float *s_aT = s_mem + kTM * kLDX;           // [kCl][kLDA]  assignment, transposed
+  float *s_asum = s_aT + kCl * kLDA;          // [kCl]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int tiles = (N + kTM - 1) / kTM;
+  const int t_begin = (int)((long long)tiles * chunk / chunks);
+  const int t_end = (int)((long long)tiles * (chunk + 1) / chunks);
+  const float *xb = x + (size_t)b * N * kD;
+  const float *attb = att + (size_t)b * N;
+
+  if (tid < kCl) s_asum[tid] = 0.f;
+  // VLAD accumulators: wave -> cluster block (wave&1), feature blocks (wave>>1) + 2j, j<4
+  f32x16 vacc[4];
+  zero_acc<4>(vacc);
+
+  for (int t = t_begin; t < t_end; ++t) {
+    const int p0 = t * kTM;
+    __syncthreads();  // previous tile's LDS fully consumed
+    // ---- stage + row l2-normalise: 4 threads per row, 64 floats each
+    {
+      const int p = tid >> 2, q = tid & 3;
+      const int n = p0 + p;
+      float4 v[16];
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        v[i] = n < N ? *reinterpret_cast<const float4 *>(xb + (size_t)n * kD + (i * 4 + q) * 4)
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
+        ss = fmaf(v[i].x, v[i].x, ss); ss = fmaf(v[i].y, v[i].y, ss);
+        ss = fmaf(v[i].z, v[i].z, ss); ss = fmaf(v[i].w, v[i].w, ss);
+      }
+      ss += __shfl_xor(ss, 1, 64);
+      ss += __shfl_xor(ss, 2, 64);
+      const float inv = rsqrtf(fmaxf(ss, 1e-12f));  // tf.nn.l2_normalize default epsilon
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float4 w = v[i];
+        w.x *= inv; w.y *= inv; w.z *= inv; w.w *= inv;
+        *reinterpret_cast<float4 *>(s_x + (size_t)p * kLDX + (i * 4 + q) * 4) = w;
+      }
+    }
+    __syncthreads();
+    // ---- assignment logits = xn @ Wc : [64 x 256] x [256 x 64], one 32x32 tile per wave
+    {
+      f32x16 acc[1];
+      zero_acc<1>(acc);
+      const int row0 = (wave & 1) * 32, cb = wave >> 1;
+      wave_gemm_f32<1>(s_x, kLDX, row0, wc_packed, kD / 8, cb, 2, acc);
+      const int col = cb * 32 + (lane & 31);
+      const float sc = bn_scale[col], sh = bn_shift[col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_aT[(size_t)col * kLDA + row0 + mfma_row(r, lane)] = fmaf(acc[0][r], sc, sh);
+    }
+    __syncthreads();
+    // ---- softmax over the 64 clusters of each point, times attention: 4 threads per point
+    {
+      const int p = tid >> 2, q = tid & 3;
+      const int n = p0 + p;
+      float e[16];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { e[i] = s_aT[(size_t)(i * 4 + q) * kLDA + p]; mx = fmaxf(mx, e[i]); }
+      mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { e[i] = expf(e[i] - mx); sum += e[i]; }
+      sum += __shfl_xor(sum, 1, 64);
+      sum += __shfl_xor(sum, 2, 64);
+      const float w = n < N ? attb[n] / sum : 0.f;  // rows past N contribute nothing
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s_aT[(size_t)(i * 4 + q) * kLDA + p] = e[i] * w;
+    }
+    __syncthreads();
+    // ---- a_sum[c] += sum_p a[p,c]
+    if (tid < kCl) {
+      float s = 0.f;
+      for (int p = 0; p < kTM; ++p) s += s_aT[(size_t)tid * kLDA + p];
+      s_asum[tid] += s;
+    }
+    // ---- vladT[c,d] += sum_p aT[c,p] * xn[p,d]: A = aT (LDS, ld kLDA), B = xn read from LDS
+    {
+      const int row0 = (wave & 1) * 32;  // cluster block
+      const float *aptr = s_aT + (size_t)(row0 + (lane & 31)) * kLDA + 4 * (lane >> 5);
+#pragma unroll 2
+      for (int kb = 0; kb < kTM / 8; ++kb) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4 *>(aptr + kb * 8);
+        const float *brow = s_x + (size_t)(kb * 8 + 4 * (lane >> 5)) * kLDX + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int d0 = ((wave >> 1) + 2 * j) * 32;
+          const float b0 = brow[d0], b1 = brow[kLDX + d0], b2 = brow[2 * kLDX + d0], b3 = brow[3 * kLDX + d0];
+          vacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0], b0, vacc[j], 0, 0, 0);
+          vacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1], b1, vacc[j], 0, 0, 0);
+          vacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[2], b2, vacc[j], 0, 0, 0);
+          vacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[3], b3, vacc[j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- write this chunk's partials
+  float *pv = part_vlad + ((size_t)b * chunks + chunk) * kCl * kD;
+  {
+    const int row0 = (wave & 1) * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int d = ((wave >> 1) + 2 * j) * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pv[(size_t)(row0 + mfma_row(r, lane)) * kD + d] = vacc[j][r];
+    }
+  }
+  if (tid < kCl) part_asum[((size_t)b * chunks + chunk) * kCl + tid] = s_asum[tid];
+}
+
+__device__ __forceinline__ float block_sum(float v, float *s_red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// grid (B), block 256: thread t owns feature d = t for all 64 clusters.
+__global__ __launch_bounds__(256) void netvlad_finalize(const float *__restrict__ part_vlad,
+                                                       const float *__restrict__ part_asum,
+                                                       const float *__restrict__ W2 /*[D][Cl]*/,
+                                                       int chunks, float *__restrict__ vlad /*[B][D*Cl]*/) {
+  __shared__ float s_asum[kCl];
+  __shared__ float s_csq[4][kCl];
+  __shared__ float s_red[4];
+  const int b = blockIdx.x, d = threadIdx.x, lane = d & 63, wave = d >> 6;
+  if (d < kCl) {
+    float s = 0.f;
+    for (int ch = 0; ch < chunks; ++ch) s += part_asum[((size_t)b * chunks + ch) * kCl + d];
+    s_asum[d] = s;
+  }
+  __syncthreads();
+  float v[kCl];
+#pragma unroll
+  for (int c = 0; c < kCl; ++c) {
+    float s = 0.f;
+    for (int ch = 0; ch < chunks; ++ch) s += part_vlad[(((size_t)b * chunks + ch) * kCl + c) * kD + d];
+    v[c] = s - s_asum[c] * W2[(size_t)d * kCl + c];  // vlad - a_sum * cluster_weights2 (backbones.py:249-256)
+  }
+  // intra-normalisation: per cluster c over the 256 features (tf.nn.l2_normalize(vlad, 1))
+#pragma unroll
+  for (int c = 0; c < kCl; ++c) {
+    float sq = v[c] * v[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    if (lane == 0) s_csq[wave][c] = sq;
+  }
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int c = 0; c < kCl; ++c) {
+    const float csq = (s_csq[0][c] + s_csq[1][c]) + (s_csq[2][c] + s_csq[3][c]);
+    v[c] *= rsqrtf(fmaxf(csq, 1e-12f));
+    tot = fmaf(v[c], v[c], tot);
+  }
+  const float all = block_sum(tot, s_red);
+  const float inv = rsqrtf(fmaxf(all, 1e-12f));
+  float *o = vlad + (size_t)b * kD * kCl + (size_t)d * kCl;  // flatten d-major: index d*Cl + c
+#pragma unroll
+  for (int c = 0; c < kCl; c += 4)
+    *reinterpret_cast<float4 *>(o + c) = make_float4(v[c] * inv, v[c + 1] * inv, v[c + 2] * inv, v[c + 3] * inv);
+}
+
+// Split-K projection: grid (KS, ceil(B/32)); block 256 = one thread per output column (O == 256).
+constexpr int kKSlice = 128;
+__global__ __launch_bounds__(256) void netvlad_hidden_splitk(const float *__restrict__ vlad,
+                                                            const float *__restrict__ Wh, int B, int Kd,
+                                                            int O, float *__restrict__ part /*[KS][B][O]*/) {
+  __shared__ float s_v[32][kKSlice + 1];
+  const int ks = blockIdx.x, b0 = blockIdx.y * 32, o = threadIdx.x;
+  const int k0 = ks * kKSlice;
+  const int nb = min(32, B - b0);
+  for (int e = threadIdx.x; e < 32 * kKSlice; e += 256) {
+    const int bb = e / kKSlice, k = e % kKSlice;
+    s_v[bb][k] = (bb < nb && k0 + k < Kd) ? vlad[(size_t)(b0 + bb) * Kd + k0 + k] : 0.f;
+  }
+  __syncthreads();
+  float acc[32];
+#pragma unroll
+  for (int bb = 0; bb < 32; ++bb) acc[bb] = 0.f;
+  const int klen = min(kKSlice, Kd - k0);
+  for (int k = 0; k < klen; ++k) {
+    const float w = Wh[(size_t)(k0 + k) * O + o];
+#pragma unroll
+    for (int bb = 0; bb < 32; ++bb) acc[bb] = fmaf(s_v[bb][k], w, acc[bb]);
+  }
+#pragma unroll
+  for (int bb = 0; bb < 32; ++bb)
+    if (bb < nb) part[((size_t)ks * B + b0 + bb) * O + o] = acc[bb];
+}
+
+// grid (B), block 256 (O == 256): reduce split-K, BN, gating, optional final l2-normalise.
+__global__ __launch_bounds__(256) void netvlad_gate(const float *__restrict__ part, int KS, int B, int O,
+                                                   const float *__restrict__ bn1_scale,
+                                                   const float *__restrict__ bn1_shift,
+                                                   const float *__restrict__ Wg,
+                                                   const float *__restrict__ bn2_scale,
+                                                   const float *__restrict__ bn2_shift, float l2_eps,
+                                                   float *__restrict__ out) {
+  __shared__ float s_h[256];
+  __shared__ float s_red[4];
+  const int b = blockIdx.x, o = threadIdx.x;
+  float h = 0.f;
+  for (int ks = 0; ks < KS; ++ks) h += part[((size_t)ks * B + b) * O + o];
+  h = fmaf(h, bn1_scale[o], bn1_shift[o]);
+  s_h[o] = h;
+  __syncthreads();
+  float g = 0.f;
+  for (int j = 0; j < O; ++j) g = fmaf(s_h[j], Wg[(size_t)j * O + o], g);
+  g = fmaf(g, bn2_scale[o], bn2_shift[o]);
+  float v = h * (1.f / (1.f + expf(-g)));
+  if (l2_eps > 0.f) {
+    const float all = block_sum(v * v, s_red);
+    v *= rsqrtf(fmaxf(all, l2_eps));
+  }
+  out[(size_t)b * O + o] = v;
+}
+
+}  // namespace
+
+DH3D_API size_t dh3d_netvlad_workspace_bytes(int B, int N, int D, int Cl) {
+  if (B <= 0 || N <= 0 || D != kD || Cl != kCl) return 0;
+  const int ch = netvlad_chunks(B, N);
+  return sizeof(float) * ((size_t)B * ch * kCl * kD + (size_t)B * ch * kCl);
+}
+
+DH3D_API int dh3d_netvlad_aggregate_fwd(const float *x, const float *att, const float *wc_packed,
+                                        const float *bn_scale, const float *bn_shift, const float *W2,
+                                        int B, int N, int D, int Cl, void *workspace,
+                                        size_t workspace_bytes, float *vlad, void *stream) {
+  DH3D_REQUIRE(x && att && wc_packed && bn_scale && bn_shift && W2 && workspace && vlad && B > 0 && N > 0);
+  DH3D_SUPPORTED(D == kD && Cl == kCl && B <= 65535);
+  DH3D_REQUIRE(workspace_bytes >= dh3d_netvlad_workspace_bytes(B, N, D, Cl));
+  const int ch = netvlad_chunks(B, N);
+  float *part_vlad = static_cast<float *>(workspace);
+  float *part_asum = part_vlad + (size_t)B * ch * kCl * kD;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = sizeof(float) * (kTM * kLDX + kCl * kLDA + kCl);
+  auto kern = netvlad_assign_accumulate;
+  DH3D_ALLOW_BIG_LDS(kern);
+  hipLaunchKernelGGL(kern, dim3(ch, B), dim3(256), lds, s, x, att, wc_packed, bn_scale, bn_shift, N, ch,
+                     part_vlad, part_asum);
+  hipLaunchKernelGGL(netvlad_finalize, dim3(B), dim3(256), 0, s, part_vlad, part_asum, W2, ch, vlad);
+  return dh3d_launch_status();
+}
+
+DH3D_API size_t dh3d_netvlad_head_workspace_bytes(int B, int Kd, int O) {
+  if (B <= 0 || Kd <= 0 || O != 256) return 0;
+  return sizeof(float) * (size_t)dh3d_cdiv(Kd, kKSlice) * B * O;
+}
+
+DH3D_API int dh3d_netvlad_head_fwd(const float *vlad, const float *Wh, const float *bn1_scale,
+                                   const float *bn1_shift, const float *Wg, const float *bn2_scale,
+                                   const float *bn2_shift, int B, int Kd, int O, float l2_eps,
+                                   void *workspace, size_t workspace_bytes, float *out, void *stream) {
+  DH3D_REQUIRE(vlad && Wh && bn1_scale && bn1_shift && Wg && bn2_scale && bn2_shift && workspace && out);
+  DH3D_REQUIRE(B > 0 && Kd > 0);
+  DH3D_SUPPORTED(O == 256 && B <= 65535);
+  DH3D_REQUIRE(workspace_bytes >= dh3d_netvlad_head_workspace_bytes(B, Kd, O));
+  const int KS = dh3d_cdiv(Kd, kKSlice);
+  float *part = static_cast<float *>(workspace);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(netvlad_hidden_splitk, dim3(KS, dh3d_cdiv(B, 32)), dim3(256), 0, s, vlad, Wh, B, Kd, O,
+                     part);
+  hipLaunchKernelGGL(netvlad_gate, dim3(B), dim3(256), 0, s, part, KS, B, O, bn1_scale, bn1_shift, Wg,
+                     bn2_scale, bn2_shift, l2_eps, out);
+  return dh3d_launch_status();
+}

@@ -1,0 +1,84 @@
+"""One process per GPU over RCCL/xGMI (torch.distributed backend "nccl" IS RCCL on ROCm).
+
+The reference is single-GPU (train.py:75 SimpleTrainer; no collective anywhere).  Every hot-path op
+is independent per cloud, so the concatenated Siamese batch [anchors, positives, negatives,
+other-negatives] (core/model.py:139-146) shards over ranks by cloud with NO data-path collective;
+the only exchange is the all-gather of the [clouds_per_rank, 256] global descriptors that the
+triplet / quadruplet loss needs in role order (core/losses.py:175-178).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun). Returns (rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world
+
+
+def shard_plan(num_clouds, world):
+    """Contiguous block partition of the role-ordered batch, padded to equal counts.
+
+    Returns (per_rank, padded_total); cloud i lives on rank i // per_rank at slot i % per_rank.
+    RCCL all-gather needs equal counts, so the tail rank carries masked padding slots."""
+    per_rank = (num_clouds + world - 1) // world
+    return per_rank, per_rank * world
+
+
+def local_slice(num_clouds, rank, world):
+    """[start, stop) of the real clouds owned by `rank` (may be empty on tail ranks)."""
+    per_rank, _ = shard_plan(num_clouds, world)
+    start = min(rank * per_rank, num_clouds)
+    return start, min(start + per_rank, num_clouds)
+
+
+def shard_batch(points, rank, world):
+    """points [Bt, N, 3] (role-ordered) -> this rank's [per_rank, N, 3] block, zero-padded + mask."""
+    Bt = points.shape[0]
+    per_rank, _ = shard_plan(Bt, world)
+    start, stop = local_slice(Bt, rank, world)
+    out = points.new_zeros((per_rank,) + tuple(points.shape[1:]))
+    if stop > start:
+        out[: stop - start] = points[start:stop]
+        if stop - start < per_rank:  # padding clouds repeat a real one so kernels see valid geometry
+            out[stop - start:] = points[start:start + 1]
+    mask = torch.zeros(per_rank, dtype=torch.bool, device=points.device)
+    mask[: stop - start] = True
+    return out, mask
+
+
+def all_gather_descriptors(local_desc, num_clouds):
+    """local_desc [per_rank, D] -> [num_clouds, D] in the original role order on every rank.
+
+    One all-gather of per_rank*D floats per rank (24.6 KB total for the Oxford-shaped batch): latency
+    bound, no reduction.  With world == 1 this is the identity."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local_desc[:num_clouds]
+    world = dist.get_world_size()
+    gathered = torch.empty((world * local_desc.shape[0],) + tuple(local_desc.shape[1:]), dtype=local_desc.dtype,
+                           device=local_desc.device)
+    dist.all_gather_into_tensor(gathered, local_desc.contiguous())
+    return gathered[:num_clouds]
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value, device):
+    """Scalar max over ranks (bench timing contract)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

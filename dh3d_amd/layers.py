@@ -1,0 +1,117 @@
+"""Layer wrappers in the reference's channels-first convention (mirrors core/layers.py).
+
+KnnBruteforce (core/layers.py:49-107), FlexPooling (:110-175), FlexConvolution (:178-339, :439-461),
+ConvolutionPointset (:564-707): same constructor arguments that matter, same weight names
+(position_theta / position_bias / feature_bias), same tensor layouts ([B, C, N] features,
+[B, K, N] neighbourhoods).  They call the drop-in operators of dh3d_amd.ops and are differentiable
+through the registered gradients.  The fused point-major model path lives in dh3d_amd.backbones.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import ops
+
+__all__ = ["KnnBruteforce", "knn_bruteforce", "FlexPooling", "flex_pooling", "FlexConvolution",
+           "ConvolutionPointset"]
+
+
+class KnnBruteforce(nn.Module):
+    """positions [B, Dp, N] -> (neighborhoods [B, K, N] int32, distances [B, K, N])."""
+
+    def __init__(self, k, data_format="simple"):
+        super().__init__()
+        assert k > 0
+        assert data_format in ["simple", "expanded"]
+        self.k = k
+        self.data_format = data_format
+
+    def forward(self, positions):
+        if self.data_format == "expanded":
+            positions = positions.squeeze(2)
+        nn_, dist = ops.knn_bruteforce(positions, k=self.k)
+        nn_ = nn_.transpose(1, 2).contiguous()      # core/layers.py:92
+        dist = dist.transpose(1, 2).contiguous()    # core/layers.py:93
+        if self.data_format == "expanded":
+            nn_ = nn_.unsqueeze(2)
+        return nn_, dist
+
+
+def knn_bruteforce(positions, k, data_format="simple"):
+    return KnnBruteforce(k, data_format=data_format)(positions)
+
+
+class FlexPooling(nn.Module):
+    def __init__(self, data_format="simple"):
+        super().__init__()
+        assert data_format in ["simple", "expanded"]
+        self.data_format = data_format
+
+    def forward(self, features, neighborhoods):
+        if self.data_format == "expanded":
+            features, neighborhoods = features.squeeze(2), neighborhoods.squeeze(2)
+        y, _ = ops.flex_pooling(features, neighborhoods)
+        if self.data_format == "expanded":
+            y = y.unsqueeze(2)
+        return y
+
+
+def flex_pooling(features, neighborhoods, data_format="simple"):
+    return FlexPooling(data_format=data_format)(features, neighborhoods)
+
+
+class FlexConvolution(nn.Module):
+    """Weights: position_theta [Dp, Din, Dout], position_bias [Din, Dout], feature_bias [Dout, 1]."""
+
+    def __init__(self, in_channels, filters, dp=3, activation=None, use_feature_bias=True,
+                 data_format="simple"):
+        super().__init__()
+        assert data_format in ["simple", "expanded"]
+        self.filters = int(filters)
+        self.activation = activation
+        self.data_format = data_format
+        # glorot-uniform like the Keras default kernel initializer; zeros for both biases (layers.py:231-233)
+        limit = math.sqrt(6.0 / (in_channels + filters))
+        self.position_theta = nn.Parameter(torch.empty(dp, in_channels, filters).uniform_(-limit, limit))
+        self.position_bias = nn.Parameter(torch.zeros(in_channels, filters))
+        self.feature_bias = nn.Parameter(torch.zeros(filters, 1)) if use_feature_bias else None
+
+    def forward(self, features, positions, neighborhoods):
+        if self.data_format == "expanded":
+            features, positions, neighborhoods = features.squeeze(2), positions.squeeze(2), neighborhoods.squeeze(2)
+        y = ops.flex_convolution(features, positions, neighborhoods, self.position_theta, self.position_bias)
+        if self.feature_bias is not None:
+            y = y + self.feature_bias
+        if self.activation is not None:
+            y = self.activation(y)
+        if self.data_format == "expanded":
+            y = y.unsqueeze(2)
+        return y
+
+
+class ConvolutionPointset(nn.Module):
+    """Weights: position_theta [Din, Dout], position_bias [Dout] (+ feature_bias [Dout,1] if enabled)."""
+
+    def __init__(self, in_channels, filters, activation=None, use_feature_bias=False, data_format="simple"):
+        super().__init__()
+        assert data_format in ["simple", "expanded"]
+        self.filters = int(filters)
+        self.activation = activation
+        self.data_format = data_format
+        limit = math.sqrt(6.0 / (in_channels + filters))
+        self.position_theta = nn.Parameter(torch.empty(in_channels, filters).uniform_(-limit, limit))
+        self.position_bias = nn.Parameter(torch.zeros(filters))
+        self.feature_bias = nn.Parameter(torch.zeros(filters, 1)) if use_feature_bias else None
+
+    def forward(self, features, neighborhoods):
+        if self.data_format == "expanded":
+            features, neighborhoods = features.squeeze(2), neighborhoods.squeeze(2)
+        y = ops.convolution_pointset(features, neighborhoods, self.position_theta, self.position_bias)
+        if self.feature_bias is not None:
+            y = y + self.feature_bias
+        if self.activation is not None:
+            y = self.activation(y)
+        if self.data_format == "expanded":
+            y = y.unsqueeze(2)
+        return y

@@ -1,0 +1,230 @@
+"""DH3D forward API on the MI355X kernels (mirrors core/model.py).
+
+`DH3D(config)` keeps the reference's method names and named outputs:
+    compute_local(points)  -> (newpoints [Bt,N,3], localdesc [Bt,N,128])      core/model.py:99-108
+    compute_global(outs)   -> globaldesc [Bt,256] (un-normalised)             core/model.py:112-133
+    forward(points)        -> dict with 'pointclouds', 'knn_inds', 'feat', 'feat_l2normed',
+                              'xyz_feat' [Bt,N,131], 'xyz_feat_att' [Bt,N,132] (detection),
+                              'globaldesc' [Bt,256] (extract_global)           core/model.py:135-210
+Only inference-mode BatchNorm is implemented on the fused path (training-mode statistics: see DESIGN.md).
+
+The forward is launch-bound when driven op by op from Python (about 30 short kernels), so
+`DH3D.graphed(example)` captures it into one hipGraph (two streams: feature path + geometry path)
+and replays it with static buffers.
+"""
+import torch
+from torch import nn
+
+from . import backbones as bb
+from . import pm
+from .configs import ConfigFactory, dotdict
+
+
+def tf_variable_name(state_dict_key):
+    """state_dict key -> TensorFlow checkpoint variable name (models/*/*.index)."""
+    name = state_dict_key.replace(".", "/")
+    name = name.replace("mean_EMA", "mean/EMA").replace("variance_EMA", "variance/EMA")
+    return name
+
+
+class DH3D(nn.Module):
+    def __init__(self, config=None):
+        super().__init__()
+        if config is None:
+            config = ConfigFactory("basic_config").getconfig()
+        self.config = config if isinstance(config, dotdict) else dotdict(config)
+        cfg = self.config
+        if cfg.local_backbone not in (None, "backbone_local_dilate"):
+            raise NotImplementedError("local_backbone %r" % cfg.local_backbone)
+        tp_eps = cfg.tp_bn_eps if cfg.tp_bn_eps is not None else 1e-5
+        slim_eps = cfg.slim_bn_eps if cfg.slim_bn_eps is not None else 1e-3
+        self.input_knn_indices = bool(cfg.num_points and cfg.num_points > 8192)  # core/model.py:38
+        self.knn_num = cfg.knn_num or 8
+
+        # ---- local backbone: variables live at the root scope (initconv, stage1, ...)
+        local = bb.BackboneLocalDilate(featdim=cfg.featdim or 128, dilate2=8, bn_eps=tp_eps)
+        for name, child in list(local.named_children()):
+            self.add_module(name, child)
+        self._local_names = [n for n, _ in local.named_children()]
+
+        if cfg.detection:
+            self.detection_block_reliable = bb.PointMLPHead(128, [128, 256, 1024], fc_bias_init=1.0 / 8,
+                                                            bn_eps=tp_eps)
+        if cfg.extract_global:
+            if cfg.global_backbone not in (None, "global_before_assemble"):
+                raise NotImplementedError("global_backbone %r" % cfg.global_backbone)
+            gl_dims = list(cfg.gl_dims or [256])
+            self.global_before_assemble = bb.FlexConvDilate(128, gl_dims, dilate=cfg.gl_dilate or 8,
+                                                            knn=self.knn_num, concat=False, add_se="",
+                                                            upsample=True, bn_eps=tp_eps)
+            conv_dims = [256, 1024] if gl_dims[-1] > 256 else [1024]  # backbones.py:159-162
+            self.globalatt = bb.PointMLPHead(gl_dims[-1], conv_dims, bn_eps=tp_eps)
+            nv = bb.NetVLAD(gl_dims[-1], 64, 256, add_batch_norm=cfg.add_batch_norm is not False,
+                            slim_bn_eps=slim_eps)
+            # NetVLAD variables are created at the root variable scope (backbones.py:212-276)
+            self.cluster_weights = nv.cluster_weights
+            self.cluster_bn = nv.cluster_bn
+            self.cluster_weights2 = nv.cluster_weights2
+            self.hidden1_weights = nv.hidden1_weights
+            self.bn = nv.bn
+            self.gating_weights = nv.gating_weights
+            self.gating_bn = nv.gating_bn
+            object.__setattr__(self, "_netvlad", nv)  # not registered twice
+        object.__setattr__(self, "_local", local)
+        self._geo_stream = None
+        self._prepared = False
+
+    # ------------------------------------------------------------------ weights
+    @torch.no_grad()
+    def init_synthetic(self, seed=0):
+        """Random weights of the benchmark recipe: N(0,1)/sqrt(fan_in), identity BatchNorm."""
+        g = torch.Generator().manual_seed(seed)
+        for name, p in self.named_parameters():
+            leaf = name.split(".")[-1]
+            if leaf in ("gamma",):
+                p.fill_(1.0)
+            elif leaf in ("beta", "b", "feature_bias"):
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+            elif leaf == "position_theta" and p.dim() == 3:
+                p.copy_(torch.randn(p.shape, generator=g) / (p.shape[1] ** 0.5))
+            elif leaf == "position_bias" and p.dim() == 2:
+                p.copy_(torch.randn(p.shape, generator=g) / ((8 * p.shape[0]) ** 0.5))
+            elif leaf == "position_theta":  # initconv [3, 32]
+                p.copy_(torch.randn(p.shape, generator=g) * 4.0)
+            elif leaf == "position_bias":
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+            elif leaf == "W":
+                p.copy_(torch.randn(p.shape, generator=g) / (p.shape[2] ** 0.5))
+            elif leaf in ("cluster_weights", "cluster_weights2", "gating_weights"):
+                p.copy_(torch.randn(p.shape, generator=g) / (p.shape[-2] ** 0.5))
+            elif leaf == "hidden1_weights":
+                p.copy_(torch.randn(p.shape, generator=g) / 8.0)
+        self._prepared = False
+        return self
+
+    def prepare(self):
+        """Fold BatchNorm and pack weights for the kernels.  Call after loading / moving weights."""
+        self._local.prepare()
+        if self.config.detection:
+            self.detection_block_reliable.prepare()
+        if self.config.extract_global:
+            self.global_before_assemble.prepare()
+            self.globalatt.prepare()
+            self._netvlad.prepare()
+        self._prepared = True
+        return self
+
+    def _check_mode(self):
+        if self.training:
+            raise NotImplementedError(
+                "training-mode BatchNorm is not implemented on the fused path; call model.eval()")
+        if not self._prepared:
+            self.prepare()
+
+    # ------------------------------------------------------------------ geometry on a side stream
+    def _geometry(self, points, knn_inds=None):
+        geo = bb.Geometry(points, self.knn_num)
+        main = torch.cuda.current_stream()
+        if self._geo_stream is None:
+            self._geo_stream = torch.cuda.Stream(device=points.device)
+        side = self._geo_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            lv = geo.level(8, self.knn_num)  # stage2 (dilate2=8) and global (gl_dilate=8) share it
+            for t in lv.values():
+                t.record_stream(main)
+        if knn_inds is not None:
+            geo.nbr = knn_inds.contiguous()
+        else:
+            geo.nbr, _ = pm.knn_xyz(points, self.knn_num)  # core/model.py:157
+        geo._side = side
+        return geo
+
+    # ------------------------------------------------------------------ reference API
+    def compute_local(self, points, knn_inds=None, _geo=None):
+        self._check_mode()
+        geo = _geo if _geo is not None else self._geometry(points, knn_inds)
+        p = self._local._prep
+        nn_8 = geo.nbr if geo.nbr.shape[2] == 8 else geo.nbr[:, :, 0:8].contiguous()
+        init = pm.conv_pointset_xyz(geo.xyz, nn_8, p["theta"], p["bias"], scale=p["scale"], shift=p["shift"],
+                                    act=pm.ACT_RELU)
+        init = pm.flex_pool(init, nn_8)
+        x1 = self.stage1(geo, init, nbr=nn_8)
+        x2 = self.before_stage2_conv1d(x1, act=pm.ACT_RELU)
+        torch.cuda.current_stream().wait_stream(geo._side)  # FPS / kNN(N/8) / three_nn are needed from here
+        x2 = self.stage2(geo, x2)
+        feat = self.local_stage1_shortcut(x1, act=pm.ACT_RELU, residual=x2)
+        self._last_geo = geo
+        return points, feat
+
+    def compute_global(self, outs, l2_eps=0.0):
+        self._check_mode()
+        points, localdesc = outs["xyz"], outs["feat"]
+        geo = outs.get("_geo")
+        if geo is None:
+            geo = self._geometry(points, None)
+            torch.cuda.current_stream().wait_stream(geo._side)
+        forglobal = self.global_before_assemble(geo, localdesc)
+        att = self.globalatt(forglobal)
+        return self._netvlad(forglobal, att, l2_eps=l2_eps)
+
+    def forward(self, points, knn_inds=None):
+        """points [Bt, N, 3] float32 on the GPU (anchor/pos/neg already concatenated, core/model.py:139-146).
+        knn_inds [Bt, N, K] int32 is required iff num_points > 8192 (core/model.py:148-155)."""
+        self._check_mode()
+        cfg = self.config
+        if points.dim() != 3 or points.shape[2] != 3:
+            raise ValueError("points must be [Bt, N, 3]")
+        if self.input_knn_indices and knn_inds is None:
+            raise ValueError("num_points > 8192: pass knn_inds [Bt, N, K] (the reference feeds host kNN)")
+        outs = {"pointclouds": points, "xyz": points}
+        geo = self._geometry(points, knn_inds)
+        outs["knn_inds"] = geo.nbr
+        newpoints, localdesc = self.compute_local(points, _geo=geo)
+        outs["feat"] = localdesc
+        xyz_feat = pm.l2norm_concat(localdesc, 1e-8, prefix=newpoints)  # l2_normalize(dim=2, eps=1e-8) + concat
+        outs["xyz_feat"] = xyz_feat
+        outs["feat_l2normed"] = xyz_feat[:, :, 3:]
+        if cfg.detection:
+            att = self.detection_block_reliable(localdesc)
+            outs["attention"] = att
+            outs["xyz_feat_att"] = torch.cat([xyz_feat, att], dim=-1)
+        if cfg.extract_global:
+            outs["_geo"] = geo
+            outs["globaldesc"] = self.compute_global(outs, l2_eps=1e-8)  # model.py:205
+            del outs["_geo"]
+        return outs
+
+    # ------------------------------------------------------------------ hipGraph replay
+    def graphed(self, example_points, example_knn=None, outputs=None, warmup=2):
+        """Capture forward() for inputs shaped like `example_points` into a hipGraph.
+
+        Returns a callable f(points[, knn_inds]) -> dict of output tensors (static buffers, overwritten by
+        the next call)."""
+        self._check_mode()
+        static_in = example_points.clone()
+        static_knn = example_knn.clone() if example_knn is not None else None
+        keep = outputs
+        s = torch.cuda.Stream(device=example_points.device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self.forward(static_in, static_knn)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            outs = self.forward(static_in, static_knn)
+        if keep is not None:
+            outs = {k: v for k, v in outs.items() if k in keep}
+
+        def run(points, knn_inds=None):
+            static_in.copy_(points)
+            if static_knn is not None and knn_inds is not None:
+                static_knn.copy_(knn_inds)
+            graph.replay()
+            return outs
+
+        run.graph = graph
+        run.static_input = static_in
+        return run

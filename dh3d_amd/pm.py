@@ -1,0 +1,188 @@
+"""Point-major ([B,N,C]) fused kernels used by the model path (section B of include/dh3d_hip.h).
+
+Thin, allocation-only wrappers: each function validates shapes, allocates the output with torch and
+enqueues one C-ABI call on the current stream.  No function here has a CPU or eager-torch fallback.
+"""
+import torch
+
+from . import _lib as L
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID = L.ACT_NONE, L.ACT_RELU, L.ACT_SIGMOID
+
+
+def _ep(pre_bias, scale, shift, act):
+    return L.make_epilogue(pre_bias, scale, shift, act)
+
+
+def knn_xyz(xyz, k):
+    """xyz [B,N,3] -> (nbr [B,N,K] int32, dist [B,N,K]); same function as ops.knn_bruteforce."""
+    x = L.require_cuda_f32(xyz, "xyz", 3)
+    B, N, _ = x.shape
+    nn = torch.empty((B, N, k), dtype=torch.int32, device=x.device)
+    dist = torch.empty((B, N, k), dtype=torch.float32, device=x.device)
+    L.check(L.lib().dh3d_knn_bruteforce_xyz(L.ptr(x), B, N, k, L.ptr(nn), L.ptr(dist), L.stream_ptr()), "knn_xyz")
+    return nn, dist
+
+
+def pack_weight(W):
+    """W [Kd, Dout] row-major -> MFMA fragment order (see mfma_gemm.h)."""
+    W = L.require_cuda_f32(W, "W", 2)
+    out = torch.empty_like(W)
+    L.check(L.lib().dh3d_pack_weight(L.ptr(W), W.shape[0], W.shape[1], L.ptr(out), L.stream_ptr()), "pack_weight")
+    return out
+
+
+def pack_flex_weight(theta, bias):
+    """theta [3,Din,Dout], bias [Din,Dout] -> packed [4*Din, Dout] = [bias; theta_x; theta_y; theta_z]."""
+    t = L.require_cuda_f32(theta, "theta", 3)
+    b = L.require_cuda_f32(bias, "bias", 2)
+    if t.shape[0] != 3:
+        raise ValueError("point-major flex_conv needs Dp == 3")
+    Din, Dout = b.shape
+    out = torch.empty((4 * Din, Dout), dtype=torch.float32, device=t.device)
+    L.check(L.lib().dh3d_pack_flex_weight(L.ptr(t), L.ptr(b), Din, Dout, L.ptr(out), L.stream_ptr()),
+            "pack_flex_weight")
+    return out
+
+
+def flex_conv(features, xyz, nbr, wpacked, Dout, pre_bias=None, scale=None, shift=None, act=ACT_NONE):
+    f = L.require_cuda_f32(features, "features", 3)
+    x = L.require_cuda_f32(xyz, "xyz", 3)
+    nb = L.require_cuda_i32(nbr, "nbr", 3)
+    B, N, Din = f.shape
+    K = nb.shape[2]
+    if tuple(x.shape) != (B, N, 3) or tuple(nb.shape[:2]) != (B, N):
+        raise ValueError("flex_conv: xyz/nbr do not match features [B,N,*]")
+    out = torch.empty((B, N, Dout), dtype=torch.float32, device=f.device)
+    ep = _ep(pre_bias, scale, shift, act)
+    L.check(L.lib().dh3d_flex_conv_pm_fwd(L.ptr(f), L.ptr(x), L.ptr(nb), L.ptr(wpacked), B, N, K, Din, Dout, ep,
+                                          L.ptr(out), L.stream_ptr()), "flex_conv_pm")
+    return out
+
+
+def flex_pool(features, nbr, want_argmax=False):
+    f = L.require_cuda_f32(features, "features", 3)
+    nb = L.require_cuda_i32(nbr, "nbr", 3)
+    B, N, C = f.shape
+    K = nb.shape[2]
+    out = torch.empty_like(f)
+    argmax = torch.empty((B, N, C), dtype=torch.int32, device=f.device) if want_argmax else None
+    L.check(L.lib().dh3d_flex_pool_pm_fwd(L.ptr(f), L.ptr(nb), B, N, K, C, L.ptr(out), L.ptr(argmax),
+                                          L.stream_ptr()), "flex_pool_pm")
+    return (out, argmax) if want_argmax else out
+
+
+def conv_pointset_xyz(xyz, nbr, theta, bias, pre_bias=None, scale=None, shift=None, act=ACT_NONE):
+    x = L.require_cuda_f32(xyz, "xyz", 3)
+    nb = L.require_cuda_i32(nbr, "nbr", 3)
+    B, N, _ = x.shape
+    K = nb.shape[2]
+    Dout = theta.shape[1]
+    out = torch.empty((B, N, Dout), dtype=torch.float32, device=x.device)
+    ep = _ep(pre_bias, scale, shift, act)
+    L.check(L.lib().dh3d_conv_pointset_pm_fwd(L.ptr(x), L.ptr(nb), L.ptr(theta), L.ptr(bias), B, N, K, Dout, ep,
+                                              L.ptr(out), L.stream_ptr()), "conv_pointset_pm")
+    return out
+
+
+def linear(x1, wpacked, Dout, x2=None, pre_bias=None, scale=None, shift=None, act=ACT_NONE, residual=None):
+    """out = epilogue([x1 | x2] @ W) (+ residual); x* are [..., C] with identical leading dims."""
+    a = L.require_cuda_f32(x1, "x1")
+    lead = a.shape[:-1]
+    C1 = a.shape[-1]
+    R = a.numel() // C1
+    C2 = 0
+    b = None
+    if x2 is not None:
+        b = L.require_cuda_f32(x2, "x2")
+        C2 = b.shape[-1]
+        if b.shape[:-1] != lead:
+            raise ValueError("linear: x1/x2 leading dims differ")
+    res = None
+    if residual is not None:
+        res = L.require_cuda_f32(residual, "residual")
+    out = torch.empty(lead + (Dout,), dtype=torch.float32, device=a.device)
+    ep = _ep(pre_bias, scale, shift, act)
+    L.check(L.lib().dh3d_linear_pm_fwd(L.ptr(a), C1, L.ptr(b), C2, L.ptr(wpacked), R, Dout, ep, L.ptr(res),
+                                       L.ptr(out), L.stream_ptr()), "linear_pm")
+    return out
+
+
+def se_res(x, pool, W1, b1, W2, b2):
+    a = L.require_cuda_f32(x, "x")
+    p = L.require_cuda_f32(pool, "pool")
+    C = a.shape[-1]
+    R = a.numel() // C
+    out = torch.empty_like(a)
+    L.check(L.lib().dh3d_se_res_pm_fwd(L.ptr(a), L.ptr(p), L.ptr(W1), L.ptr(b1), L.ptr(W2), L.ptr(b2), R, C,
+                                       L.ptr(out), L.stream_ptr()), "se_res_pm")
+    return out
+
+
+def three_interpolate_idw(points, idx, dist):
+    p = L.require_cuda_f32(points, "points", 3)
+    ix = L.require_cuda_i32(idx, "idx", 3)
+    d = L.require_cuda_f32(dist, "dist", 3)
+    b, m, c = p.shape
+    n = ix.shape[1]
+    out = torch.empty((b, n, c), dtype=torch.float32, device=p.device)
+    L.check(L.lib().dh3d_three_interpolate_idw_fwd(b, m, c, n, L.ptr(p), L.ptr(ix), L.ptr(d), L.ptr(out),
+                                                   L.stream_ptr()), "three_interpolate_idw")
+    return out
+
+
+def l2norm_concat(x, eps, prefix=None):
+    a = L.require_cuda_f32(x, "x")
+    C = a.shape[-1]
+    R = a.numel() // C
+    P = 0
+    pf = None
+    if prefix is not None:
+        pf = L.require_cuda_f32(prefix, "prefix")
+        P = pf.shape[-1]
+    out = torch.empty(a.shape[:-1] + (P + C,), dtype=torch.float32, device=a.device)
+    L.check(L.lib().dh3d_l2norm_concat_fwd(L.ptr(a), R, C, float(eps), L.ptr(pf), P, L.ptr(out), L.stream_ptr()),
+            "l2norm_concat")
+    return out
+
+
+def mlp_head(h, wpacked, H, w_fc, b_fc, pre_bias=None, scale=None, shift=None, act=ACT_RELU):
+    a = L.require_cuda_f32(h, "h")
+    C = a.shape[-1]
+    R = a.numel() // C
+    out = torch.empty(a.shape[:-1] + (1,), dtype=torch.float32, device=a.device)
+    ep = _ep(pre_bias, scale, shift, act)
+    L.check(L.lib().dh3d_mlp_head_pm_fwd(L.ptr(a), R, C, L.ptr(wpacked), H, ep, L.ptr(w_fc), float(b_fc),
+                                         L.ptr(out), L.stream_ptr()), "mlp_head_pm")
+    return out
+
+
+def netvlad_aggregate(x, att, wc_packed, bn_scale, bn_shift, W2):
+    a = L.require_cuda_f32(x, "x", 3)
+    B, N, D = a.shape
+    Cl = W2.shape[-1]
+    t = L.require_cuda_f32(att, "att").reshape(B, N)
+    ws_bytes = L.lib().dh3d_netvlad_workspace_bytes(B, N, D, Cl)
+    if ws_bytes == 0:
+        raise ValueError("netvlad_aggregate: unsupported shape D=%d Cl=%d" % (D, Cl))
+    ws = torch.empty((ws_bytes // 4,), dtype=torch.float32, device=a.device)
+    vlad = torch.empty((B, D * Cl), dtype=torch.float32, device=a.device)
+    L.check(L.lib().dh3d_netvlad_aggregate_fwd(L.ptr(a), L.ptr(t), L.ptr(wc_packed), L.ptr(bn_scale),
+                                               L.ptr(bn_shift), L.ptr(W2), B, N, D, Cl, L.ptr(ws), ws_bytes,
+                                               L.ptr(vlad), L.stream_ptr()), "netvlad_aggregate")
+    return vlad
+
+
+def netvlad_head(vlad, Wh, bn1_scale, bn1_shift, Wg, bn2_scale, bn2_shift, l2_eps=0.0):
+    v = L.require_cuda_f32(vlad, "vlad", 2)
+    B, Kd = v.shape
+    O = Wh.shape[1]
+    ws_bytes = L.lib().dh3d_netvlad_head_workspace_bytes(B, Kd, O)
+    if ws_bytes == 0:
+        raise ValueError("netvlad_head: unsupported output dim %d" % O)
+    ws = torch.empty((ws_bytes // 4,), dtype=torch.float32, device=v.device)
+    out = torch.empty((B, O), dtype=torch.float32, device=v.device)
+    L.check(L.lib().dh3d_netvlad_head_fwd(L.ptr(v), L.ptr(Wh), L.ptr(bn1_scale), L.ptr(bn1_shift), L.ptr(Wg),
+                                          L.ptr(bn2_scale), L.ptr(bn2_shift), B, Kd, O, float(l2_eps), L.ptr(ws),
+                                          ws_bytes, L.ptr(out), L.stream_ptr()), "netvlad_head")
+    return out

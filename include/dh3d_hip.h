@@ -1,0 +1,228 @@
+/*
+ * dh3d_hip.h -- C ABI of libdh3d_hip.so, the MI355X (gfx950) implementation of the DH3D
+ * point-cloud feature-extraction hot path.
+ *
+ * Contract (every entry point):
+ *   - plain device pointers + sizes, no framework types; `stream` is a hipStream_t passed as void*;
+ *   - returns an int status (DH3D_OK = 0); never throws, never allocates or frees device memory,
+ *     never synchronises the device; all work is enqueued on `stream` (graph-capturable);
+ *   - the caller owns every buffer including scratch; gradient outputs are zeroed by the library
+ *     (hipMemsetAsync on `stream`), as the reference kernels do with cudaMemset;
+ *   - float32 + int32 only; re-entrant, no global mutable state.
+ *
+ * Section A are drop-ins for the reference's TF custom ops, in the reference's tensor layouts
+ * (user_ops: channels-first [B,C,N]; tf_ops: channels-last [B,N,C]).  Section B are the fused
+ * point-major ([B,N,C]) kernels the dh3d_amd model path is built from; they compute the same
+ * functions (see each comment) with layouts chosen for gfx950.
+ *
+ * Reference citations are file:line in the upstream DH3D tree.
+ */
+#ifndef DH3D_HIP_H_
+#define DH3D_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DH3D_OK 0
+#define DH3D_ERR_INVALID_ARGUMENT 1 /* what TF reports as errors::InvalidArgument */
+#define DH3D_ERR_UNSUPPORTED 2      /* shape outside what the kernels implement    */
+#define DH3D_ERR_LAUNCH 3           /* hipGetLastError() != success after a launch  */
+
+#define DH3D_ACT_NONE 0
+#define DH3D_ACT_RELU 1
+#define DH3D_ACT_SIGMOID 2
+
+/* Library / build identification. */
+int dh3d_version(void);                 /* 100*major + minor */
+const char *dh3d_arch(void);            /* "gfx950" */
+const char *dh3d_status_string(int st); /* static string */
+
+/* ===================================================================================== *
+ * A. Drop-in operators (reference layouts)
+ * ===================================================================================== */
+
+/* KnnBruteforce -- replaces KnnBruteforceFunctor<GPUDevice,float,int>
+ * (user_ops/kernels/knn_bruteforce_kernel_gpu.cu.cc:163-228; op user_ops/ops/knn_bruteforce.cc:11-35).
+ * positions [B,Dp,N] -> nn [B,N,K] int32, dist [B,N,K] (Euclidean, ascending; self at rank 0).
+ * Bit-exact ids incl. the CUB tie order.  Dp must be 3, 1 <= K <= 64.  N > 8192 (unsupported
+ * upstream) is accepted with the ladder continued as (1024, ceil(N/1024)). */
+int dh3d_knn_bruteforce(const float *positions, int B, int Dp, int N, int K, int32_t *nn,
+                        float *dist, void *stream);
+
+/* Same function on point-major coordinates xyz [B,N,3] (the layout the model holds clouds in,
+ * core/model.py:146); saves the transpose of core/model.py:157. */
+int dh3d_knn_bruteforce_xyz(const float *xyz, int B, int N, int K, int32_t *nn, float *dist,
+                            void *stream);
+
+/* FlexConv -- replaces FlexConvFunctor<GPUDevice,float> (flex_conv_kernel_gpu.cu.cc:392-441;
+ * op user_ops/ops/flex_conv.cc:25-83).  Argument order is the functor's:
+ * features [B,Din,N], theta [Dp,Din,Dout], bias [Din,Dout], neighborhood [B,K,N] int32,
+ * positions [B,Dp,N] -> output [B,Dout,N].  Centre point = point n (gpu.cu.cc:77-79). */
+int dh3d_flex_conv_fwd(const float *features, const float *theta, const float *bias,
+                       const int32_t *neighborhood, const float *positions, int B, int N, int K,
+                       int Dp, int Din, int Dout, float *output, void *stream);
+
+/* FlexConvGrad -- replaces FlexConvGrad<GPUDevice,float> (flex_conv_kernel_gpu.cu.cc:446-548).
+ * Centre point = rank-0 neighbour (gpu.cu.cc:196-202,314).  Zeroes the three outputs first. */
+int dh3d_flex_conv_bwd(const float *features, const float *theta, const float *bias,
+                       const int32_t *neighborhood, const float *positions, const float *topdiff,
+                       int B, int N, int K, int Dp, int Din, int Dout, float *grad_features,
+                       float *grad_theta, float *grad_bias, void *stream);
+
+/* FlexPool -- replaces FlexPoolFunctor<GPUDevice,float> (flex_pool_kernel_gpu.cu.cc:100-125).
+ * features [B,D,N], neighborhood [B,K,N] -> output [B,D,N], argmax [B,D,N] (global point id). */
+int dh3d_flex_pool_fwd(const float *features, const int32_t *neighborhood, int B, int N, int K,
+                       int D, float *output, int32_t *argmax, void *stream);
+
+/* FlexPoolGrad -- replaces FlexPoolGrad<GPUDevice,float> (flex_pool_kernel_gpu.cu.cc:131-157). */
+int dh3d_flex_pool_bwd(const float *topdiff, const int32_t *argmax, int B, int N, int D,
+                       float *grad_features, void *stream);
+
+/* ConvPointset -- replaces ConvPointsetFunctor<GPUDevice,float>
+ * (conv_pointset_kernel_gpu.cu.cc:354-402).  features [B,Din,N], theta [Din,Dout], bias [Dout],
+ * neighborhood [B,K,N] -> output [B,Dout,N]; bias added once (the CPU functor's rule,
+ * conv_pointset_kernel.cc:60). */
+int dh3d_conv_pointset_fwd(const float *features, const float *theta, const float *bias,
+                           const int32_t *neighborhood, int B, int N, int K, int Din, int Dout,
+                           float *output, void *stream);
+
+/* ConvPointsetGrad -- replaces ConvPointsetGrad<GPUDevice,float> (gpu.cu.cc:408-503). */
+int dh3d_conv_pointset_bwd(const float *features, const float *theta,
+                           const int32_t *neighborhood, const float *topdiff, int B, int N, int K,
+                           int Din, int Dout, float *grad_features, float *grad_theta,
+                           float *grad_bias, void *stream);
+
+/* FarthestPointSample -- replaces farthestpointsamplingLauncher (tf_ops/sampling/tf_sampling.cpp:94,
+ * tf_sampling_g.cu:105-170,203-205).  inp [B,N,3] -> out [B,m] int32, first pick 0, bit-exact tie
+ * order.  `temp` is the reference's [32,N] scratch: accepted for signature parity, unused (the
+ * running min-distances live in registers); may be NULL.  N <= 16384. */
+int dh3d_farthest_point_sample(int B, int N, int m, const float *inp, float *temp, int32_t *out,
+                               void *stream);
+
+/* GroupPoint / GroupPointGrad -- replace groupPointLauncher / groupPointGradLauncher
+ * (tf_ops/grouping/tf_grouping.cpp:208-274, tf_grouping_g.cu:94-132).
+ * points [b,n,c], idx [b,m,nsample] -> out [b,m,nsample,c]. */
+int dh3d_group_point_fwd(int b, int n, int c, int m, int nsample, const float *points,
+                         const int32_t *idx, float *out, void *stream);
+int dh3d_group_point_bwd(int b, int n, int c, int m, int nsample, const float *grad_out,
+                         const int32_t *idx, float *grad_points, void *stream);
+
+/* ThreeNN -- replaces threenn_cpu (tf_ops/interpolation/tf_interpolate.cpp:60-103).
+ * xyz1 [b,n,3], xyz2 [b,m,3] -> dist [b,n,3] (SQUARED, ascending), idx [b,n,3]. */
+int dh3d_three_nn(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist,
+                  int32_t *idx, void *stream);
+
+/* ThreeInterpolate / Grad -- replace threeinterpolate_cpu / threeinterpolate_grad_cpu
+ * (tf_interpolate.cpp:107-153).  points [b,m,c], idx/weight [b,n,3] -> out [b,n,c]. */
+int dh3d_three_interpolate_fwd(int b, int m, int c, int n, const float *points,
+                               const int32_t *idx, const float *weight, float *out, void *stream);
+int dh3d_three_interpolate_bwd(int b, int n, int c, int m, const float *grad_out,
+                               const int32_t *idx, const float *weight, float *grad_points,
+                               void *stream);
+
+/* ===================================================================================== *
+ * B. Fused point-major kernels (model path)
+ *    Activations are [B,N,C] (C contiguous).  Neighbourhoods are [B,N,K] (the kNN op's native
+ *    output, knn_bruteforce_op.cc:44-49).  Every kernel can apply the per-channel epilogue
+ *        y = act( scale[c] * (x + pre_bias[c]) + shift[c] )
+ *    which folds feature_bias (core/layers.py:330-331), inference BatchNorm
+ *    (core/tf_utils.py:60-63) and the activation; scale/shift/pre_bias may be NULL.
+ * ===================================================================================== */
+
+typedef struct dh3d_epilogue {
+  const float *pre_bias; /* [C] or NULL */
+  const float *scale;    /* [C] or NULL */
+  const float *shift;    /* [C] or NULL */
+  int act;               /* DH3D_ACT_* */
+} dh3d_epilogue;
+
+/* Packs a row-major weight W [Kd, Dout] (Kd%8==0, Dout%32==0) into the MFMA fragment order the
+ * GEMM kernels stream: out[(nb*KB+kb)*256 + lane*4 + t] = W[kb*8 + 4*(lane>>5) + t][nb*32 + (lane&31)].
+ * For flex_conv, W is the stacked [bias; theta_x; theta_y; theta_z] of shape [4*Din, Dout]. */
+int dh3d_pack_weight(const float *W, int Kd, int Dout, float *packed, void *stream);
+/* Stacks flex_conv parameters theta [3,Din,Dout], bias [Din,Dout] into packed [4*Din,Dout]. */
+int dh3d_pack_flex_weight(const float *theta, const float *bias, int Din, int Dout, float *packed,
+                          void *stream);
+
+/* flex_conv forward (same function as dh3d_flex_conv_fwd, Dp = 3) in the factorised form
+ *   out[n,:] = [S0 | Sx | Sy | Sz][n,:] @ [bias; theta_x; theta_y; theta_z],
+ *   S0[n,i] = sum_k f[nk,i],  Sd[n,i] = sum_k (p[nk,d]-p[n,d]) f[nk,i]
+ * as one kernel: K-neighbour gather-reduce into LDS, then an exact-f32 MFMA GEMM, then epilogue.
+ * features [B,N,Din], xyz [B,N,3], nbr [B,N,K], wpacked from dh3d_pack_flex_weight.
+ * Din in {32,64,128}, Dout % 32 == 0, Dout <= 256. */
+int dh3d_flex_conv_pm_fwd(const float *features, const float *xyz, const int32_t *nbr,
+                          const float *wpacked, int B, int N, int K, int Din, int Dout,
+                          const dh3d_epilogue *ep, float *out, void *stream);
+
+/* flex_pool forward, point-major: out[n,c] = max_k f[nbr[n,k],c], argmax may be NULL. C % 4 == 0. */
+int dh3d_flex_pool_pm_fwd(const float *features, const int32_t *nbr, int B, int N, int K, int C,
+                          float *out, int32_t *argmax, void *stream);
+
+/* conv_pointset forward on coordinates (Din = 3), point-major, + epilogue:
+ * xyz [B,N,3], theta [3,Dout], bias [Dout] -> out [B,N,Dout].  Dout % 4 == 0, Dout <= 128. */
+int dh3d_conv_pointset_pm_fwd(const float *xyz, const int32_t *nbr, const float *theta,
+                              const float *bias, int B, int N, int K, int Dout,
+                              const dh3d_epilogue *ep, float *out, void *stream);
+
+/* Per-point linear layer (the 1x1 Conv2D of core/tf_utils.py:99-109):
+ *   out[r,:] = epilogue( [x1[r,:] | x2[r,:]] @ W + b ) (+ residual[r,:] after the activation)
+ * x1 [R,C1], x2 [R,C2] or NULL (fuses the concat of core/backbones.py:98-100), wpacked from
+ * dh3d_pack_weight with Kd = C1+C2; b folded into ep->pre_bias.  C1,C2 % 8 == 0, Dout % 32 == 0. */
+int dh3d_linear_pm_fwd(const float *x1, int C1, const float *x2, int C2, const float *wpacked,
+                       int R, int Dout, const dh3d_epilogue *ep, const float *residual, float *out,
+                       void *stream);
+
+/* Squeeze-excite residual block (core/backbones.py:45-55), one kernel:
+ *   g = sigmoid(relu(pool @ W1 + b1) @ W2 + b2);  out = relu(x + x*g)
+ * x, pool [R,C]; W1 [C,C/4], W2 [C/4,C] row-major (unpacked).  C in {64,128}. */
+int dh3d_se_res_pm_fwd(const float *x, const float *pool, const float *W1, const float *b1,
+                       const float *W2, const float *b2, int R, int C, float *out, void *stream);
+
+/* three_nn + inverse-distance weights + three_interpolate (core/backbones.py:90-96) fused:
+ * weight = (1/max(d,1e-10)) / sum(1/max(d,1e-10)).  idx/dist from dh3d_three_nn.
+ * points [b,m,c] -> out [b,n,c]; c % 4 == 0. */
+int dh3d_three_interpolate_idw_fwd(int b, int m, int c, int n, const float *points,
+                                   const int32_t *idx, const float *dist, float *out, void *stream);
+
+/* Row-wise L2 normalisation x / sqrt(max(sum x^2, eps)) (tf.nn.l2_normalize, core/model.py:177,205)
+ * with optional prefix columns copied in front (the xyz of 'xyz_feat', core/model.py:181):
+ * out[r,:] = [prefix[r,:P] | normalised x[r,:C]]. */
+int dh3d_l2norm_concat_fwd(const float *x, int R, int C, float eps, const float *prefix, int P,
+                           float *out, void *stream);
+
+/* Point-wise attention / detector head (core/backbones.py:132-173): a chain of per-point linear
+ * layers ending in a 1-channel logit + sigmoid, with the last wide hidden layer never written to
+ * memory:  att[r] = sigmoid( relu(bn(h[r,:] @ W + b)) . w_fc + b_fc ),  h [R,C], W packed [C,H]. */
+int dh3d_mlp_head_pm_fwd(const float *h, int R, int C, const float *wpacked, int H,
+                         const dh3d_epilogue *ep, const float *w_fc, float b_fc, float *att,
+                         void *stream);
+
+/* Attention-weighted NetVLAD aggregation (core/backbones.py:202-262), stage 1+2:
+ *   xn = l2norm(x); a = softmax(bn(xn @ Wc)) * att;  vlad[b,d,c] = sum_n a[n,c] xn[n,d] - (sum_n a[n,c]) W2[d,c]
+ *   then intra-normalise over d per cluster and L2-normalise the flattened [D*Cl] vector (d-major).
+ * x [B,N,D], att [B,N], wc_packed = pack(Wc [D,Cl]), bn as (scale,shift) [Cl], W2 [D,Cl]
+ * -> vlad [B, D*Cl].  D = 256, Cl = 64.  workspace: dh3d_netvlad_workspace_bytes(B,N,D,Cl). */
+size_t dh3d_netvlad_workspace_bytes(int B, int N, int D, int Cl);
+int dh3d_netvlad_aggregate_fwd(const float *x, const float *att, const float *wc_packed,
+                               const float *bn_scale, const float *bn_shift, const float *W2, int B,
+                               int N, int D, int Cl, void *workspace, size_t workspace_bytes,
+                               float *vlad, void *stream);
+
+/* NetVLAD projection + context gating (core/backbones.py:262-320):
+ *   h = bn1(vlad @ Wh);  out = h * sigmoid(bn2(h @ Wg));  optional final L2 normalise (model.py:205).
+ * vlad [B,Kd], Wh [Kd,O], Wg [O,O] row-major; bn as (scale,shift) [O]. O = 256.
+ * workspace: dh3d_netvlad_head_workspace_bytes(B,Kd,O). */
+size_t dh3d_netvlad_head_workspace_bytes(int B, int Kd, int O);
+int dh3d_netvlad_head_fwd(const float *vlad, const float *Wh, const float *bn1_scale,
+                          const float *bn1_shift, const float *Wg, const float *bn2_scale,
+                          const float *bn2_shift, int B, int Kd, int O, float l2_eps,
+                          void *workspace, size_t workspace_bytes, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DH3D_HIP_H_ */

@@ -1,0 +1,192 @@
+"""numpy restatement of the DH3D forward graph (TEST INFRASTRUCTURE ONLY).
+
+Follows the reference's Python graph code line by line, in the reference's own tensor layouts (with
+its transposes), calling the C oracle for the custom ops:
+    core/model.py:135-210 (build_graph), core/backbones.py:45-127,156-320, core/tf_utils.py:48-109.
+Weights come in as a dict keyed by TensorFlow variable name (models/*/*.index naming), so this file
+shares no code with dh3d_amd.  BatchNorm is inference mode; the third-party epsilons (tensorpack
+1e-5, slim 1e-3) are parameters -- PARITY UNPINNED at that boundary.
+Dense algebra runs in float32 numpy (matmul order differs from TF; tolerance 1e-4 covers it).
+"""
+import numpy as np
+
+from . import cpu as O
+
+
+def _bn(x, w, scope, axis, eps, names=("gamma", "beta", "mean/EMA", "variance/EMA")):
+    shape = [1] * x.ndim
+    shape[axis] = -1
+    g, b, m, v = [w["%s/%s" % (scope, n)].reshape(shape) for n in names]
+    return (x - m) / np.sqrt(v + np.float32(eps)) * g + b
+
+
+def _slim_bn(x, w, scope, eps):
+    return _bn(x, w, scope, x.ndim - 1, eps, names=("gamma", "beta", "moving_mean", "moving_variance"))
+
+
+def _relu(x):
+    return np.maximum(x, 0)
+
+
+def _sigmoid(x):
+    return (1.0 / (1.0 + np.exp(-x.astype(np.float64)))).astype(np.float32)
+
+
+def _conv1x1(x, w, scope, bn_eps=None, act=None):
+    """tensorpack Conv2D(kernel 1) on channels-last x [..., Cin]; scope holds W [1,1,Cin,Cout], b, bn/*."""
+    W = w[scope + "/W"].reshape(w[scope + "/W"].shape[2], -1)
+    y = x @ W + w[scope + "/b"]
+    if bn_eps is not None:
+        y = _bn(y, w, scope + "/bn", y.ndim - 1, bn_eps)
+    if act is not None:
+        y = act(y)
+    return y.astype(np.float32)
+
+
+def _l2_normalize(x, axis, eps):
+    ss = np.sum(x * x, axis=axis, keepdims=True)
+    return (x / np.sqrt(np.maximum(ss, np.float32(eps)))).astype(np.float32)
+
+
+def knn_bruteforce_layer(points_T, k):
+    """core/layers.py:85-98: op output [B,N,K] -> [B,K,N]."""
+    nn, dist = O.knn_bruteforce(points_T, k)
+    return np.ascontiguousarray(nn.transpose(0, 2, 1)), np.ascontiguousarray(dist.transpose(0, 2, 1))
+
+
+def flexconv_bn(feats_T, points_T, nn, w, scope, eps):
+    """flexconv_withBatchnorm, core/tf_utils.py:48-64 (+ feature_bias, core/layers.py:330-331)."""
+    x = O.flex_convolution(feats_T, points_T, nn, w[scope + "/position_theta"], w[scope + "/position_bias"],
+                           center_self=True)
+    x = x + w[scope + "/feature_bias"].reshape(1, -1, 1)
+    return _relu(_bn(x, w, scope + "_bn", 1, eps)).astype(np.float32)
+
+
+def se_res_bottleneck(l, pool_l, w, scope):
+    """core/backbones.py:45-55."""
+    pool_T = pool_l.transpose(0, 2, 1)
+    sq = _conv1x1(pool_T, w, scope + "/f1/tfconv0", act=_relu)
+    sq = _conv1x1(sq, w, scope + "/f2/tfconv0", act=_sigmoid)
+    return _relu(l + l * sq.transpose(0, 2, 1)).astype(np.float32)
+
+
+def subsample(points, feat, targetnum):
+    """core/tf_utils.py:86-96."""
+    kp = O.farthest_point_sample(targetnum, points)[:, :, None]
+    feat_s = O.group_point(feat, kp)[:, :, 0, :]
+    xyz_s = O.group_point(points, kp)[:, :, 0, :]
+    return xyz_s, feat_s, kp
+
+
+def flex_conv_dilate(xyz, feat, dilate, knn, outdims, scope, w, eps, knn_indices=None, concat=True,
+                     add_se="max_pool", upsample=True):
+    """core/backbones.py:58-101."""
+    N = xyz.shape[1]
+    if dilate > 1:
+        points_s, feat_s, _ = subsample(xyz, feat, N // dilate)
+    else:
+        points_s, feat_s = xyz, feat
+    feats_T = np.ascontiguousarray(feat_s.transpose(0, 2, 1))
+    points_T = np.ascontiguousarray(points_s.transpose(0, 2, 1))
+    if knn_indices is None:
+        knn_indices, _ = knn_bruteforce_layer(points_T, knn)
+    x = feats_T
+    for i, d in enumerate(outdims):
+        x = flexconv_bn(x, points_T, knn_indices, w, "%s/flexconv_%d" % (scope, i), eps)
+    if add_se == "max_pool":
+        x_pool, _ = O.flex_pooling(x, knn_indices)
+        x = se_res_bottleneck(x, x_pool, w, scope + "/se")
+    new_feat = np.ascontiguousarray(x.transpose(0, 2, 1))
+    if upsample and dilate > 1:
+        dist, idx = O.three_nn(xyz, points_s)
+        dist = np.maximum(dist, np.float32(1e-10))
+        norm = np.sum(np.float32(1.0) / dist, axis=2, keepdims=True)
+        weight = (np.float32(1.0) / dist) / norm
+        new_feat = O.three_interpolate(new_feat, idx, weight.astype(np.float32))
+    if concat:
+        new_feat = np.concatenate([new_feat, feat], axis=2)
+        new_feat = _conv1x1(new_feat, w, scope + "/concat_conv1d/tfconv0", bn_eps=eps, act=_relu)
+    return xyz, new_feat
+
+
+def backbone_local_dilate(points, knn_ind, w, eps):
+    """core/backbones.py:104-127."""
+    nn_8 = np.ascontiguousarray(knn_ind[:, 0:8, :])
+    pts_T = np.ascontiguousarray(points.transpose(0, 2, 1))
+    init = O.convolution_pointset(pts_T, nn_8, w["initconv/position_theta"], w["initconv/position_bias"])
+    init = _relu(_bn(init, w, "initconv_bn", 1, eps)).astype(np.float32)
+    init, _ = O.flex_pooling(init, nn_8)
+    init = np.ascontiguousarray(init.transpose(0, 2, 1))
+    _, x1 = flex_conv_dilate(points, init, 1, 8, [64, 64], "stage1", w, eps, knn_indices=nn_8, concat=False)
+    x2 = _conv1x1(x1, w, "before_stage2_conv1d/tfconv0", bn_eps=eps, act=_relu)
+    _, x2 = flex_conv_dilate(points, x2, 8, 8, [128, 128], "stage2", w, eps, knn_indices=None, concat=True)
+    feat = _conv1x1(x1, w, "local_stage1_shortcut/tfconv0", bn_eps=eps, act=_relu) + x2
+    return points, feat.astype(np.float32)
+
+
+def detection_block(features, w, eps, scope="detection_block_reliable"):
+    """core/backbones.py:132-151."""
+    x = features
+    for i in range(3):
+        x = _conv1x1(x, w, "%s/detec_conv%d" % (scope, i), bn_eps=eps, act=_relu)
+    return _sigmoid(_conv1x1(x, w, scope + "/detec_conv_fc"))
+
+
+def globalatt_block(features, w, eps, scope="globalatt"):
+    """core/backbones.py:156-173 (featdim <= 256 -> conv_dims [1024])."""
+    x = _conv1x1(features, w, scope + "/detec_conv0", bn_eps=eps, act=_relu)
+    return _sigmoid(_conv1x1(x, w, scope + "/detec_conv_fc"))
+
+
+def global_netvlad_block(features, att, w, slim_eps, cluster_size=64):
+    """core/backbones.py:202-279 + context_gating :282-320."""
+    B, N, D = features.shape
+    x = _l2_normalize(features.reshape(-1, D), 1, 1e-12)
+    act = x @ w["cluster_weights"]
+    act = _slim_bn(act, w, "cluster_bn", slim_eps)
+    act = act - act.max(axis=1, keepdims=True)
+    act = np.exp(act)
+    act = (act / act.sum(axis=1, keepdims=True)).astype(np.float32)
+    act = act * att.reshape(-1, 1)
+    act = act.reshape(B, N, cluster_size)
+    a_sum = act.sum(axis=1, keepdims=True)             # [B,1,C]
+    a = a_sum * w["cluster_weights2"]                   # [B,D,C]
+    vlad = np.matmul(act.transpose(0, 2, 1), x.reshape(B, N, D))  # [B,C,D]
+    vlad = vlad.transpose(0, 2, 1) - a                  # [B,D,C]
+    vlad = _l2_normalize(vlad, 1, 1e-12)
+    vlad = vlad.reshape(B, cluster_size * D)
+    vlad = _l2_normalize(vlad, 1, 1e-12)
+    vlad = vlad @ w["hidden1_weights"]
+    vlad = _slim_bn(vlad, w, "bn", slim_eps)
+    gates = _slim_bn(vlad @ w["gating_weights"], w, "gating_bn", slim_eps)
+    return (vlad * _sigmoid(gates)).astype(np.float32)
+
+
+def forward(points, w, detection=False, extract_global=False, knn_num=8, tp_eps=1e-5, slim_eps=1e-3,
+            knn_inds=None):
+    """core/model.py:135-210.  points [Bt,N,3] float32; returns dict of named outputs."""
+    points = np.ascontiguousarray(points, np.float32)
+    outs = {"pointclouds": points}
+    if knn_inds is not None:
+        knn_indices = np.ascontiguousarray(knn_inds.transpose(0, 2, 1))
+    else:
+        knn_indices, _ = knn_bruteforce_layer(np.ascontiguousarray(points.transpose(0, 2, 1)), knn_num)
+    outs["knn_indices"] = knn_indices
+    newpoints, localdesc = backbone_local_dilate(points, knn_indices, w, tp_eps)
+    l2n = _l2_normalize(localdesc, 2, 1e-8)
+    outs["feat"] = localdesc
+    outs["feat_l2normed"] = l2n
+    outs["xyz_feat"] = np.concatenate([newpoints, l2n], -1)
+    if detection:
+        att = detection_block(localdesc, w, tp_eps)
+        outs["attention"] = att
+        outs["xyz_feat_att"] = np.concatenate([newpoints, l2n, att], -1)
+    if extract_global:
+        _, forglobal = flex_conv_dilate(points, localdesc, 8, knn_num, [256], "global_before_assemble", w, tp_eps,
+                                        knn_indices=None, concat=False, upsample=True, add_se="")
+        gatt = globalatt_block(forglobal, w, tp_eps)
+        g = global_netvlad_block(forglobal, gatt, w, slim_eps)
+        outs["forglobal"] = forglobal
+        outs["global_att"] = gatt
+        outs["globaldesc"] = _l2_normalize(g, -1, 1e-8)
+    return outs

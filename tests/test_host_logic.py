@@ -1,0 +1,118 @@
+"""CPU: host-side logic -- configs, variable naming, losses, batch sharding, gloo all-gather (world 2)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config_presets():
+    from dh3d_amd import ConfigFactory
+    b = ConfigFactory("basic_config").getconfig()
+    g = ConfigFactory("global_config").getconfig()
+    assert b.num_points == 8192 and b.knn_num == 8 and b.featdim == 128 and not b.extract_global
+    assert g.extract_global and g.gl_dilate == 8 and g.gl_dims == [256] and g.num_neg == 8 and g.other_neg
+    assert g.some_missing_key is None  # dotdict semantics, core/configs.py:22-26
+
+
+def test_state_dict_matches_checkpoint_variable_names():
+    """Shapes from SURVEY 8(a)-0 (parsed from models/global/globalmodel.index)."""
+    from dh3d_amd import ConfigFactory
+    from dh3d_amd.model import DH3D, tf_variable_name
+    m = DH3D(ConfigFactory("global_config").getconfig())
+    sd = {tf_variable_name(k): tuple(v.shape) for k, v in m.state_dict().items()}
+    expect = {
+        "initconv/position_theta": (3, 32), "initconv/position_bias": (32,), "initconv_bn/mean/EMA": (32,),
+        "stage1/flexconv_0/position_theta": (3, 32, 64), "stage1/flexconv_1/position_bias": (64, 64),
+        "stage1/flexconv_0/feature_bias": (64, 1), "stage1/flexconv_1_bn/variance/EMA": (64,),
+        "stage1/se/f1/tfconv0/W": (1, 1, 64, 16), "stage1/se/f2/tfconv0/b": (64,),
+        "before_stage2_conv1d/tfconv0/W": (1, 1, 64, 64), "before_stage2_conv1d/tfconv0/bn/gamma": (64,),
+        "stage2/flexconv_0/position_theta": (3, 64, 128), "stage2/flexconv_1/position_theta": (3, 128, 128),
+        "stage2/se/f1/tfconv0/W": (1, 1, 128, 32), "stage2/concat_conv1d/tfconv0/W": (1, 1, 192, 128),
+        "local_stage1_shortcut/tfconv0/W": (1, 1, 64, 128), "local_stage1_shortcut/tfconv0/bn/mean/EMA": (128,),
+        "global_before_assemble/flexconv_0/position_theta": (3, 128, 256),
+        "global_before_assemble/flexconv_0/feature_bias": (256, 1),
+        "globalatt/detec_conv0/W": (1, 1, 256, 1024), "globalatt/detec_conv_fc/W": (1, 1, 1024, 1),
+        "cluster_weights": (256, 64), "cluster_weights2": (1, 256, 64), "hidden1_weights": (16384, 256),
+        "gating_weights": (256, 256), "cluster_bn/moving_mean": (64,), "bn/moving_variance": (256,),
+        "gating_bn/beta": (256,),
+    }
+    for k, shp in expect.items():
+        assert sd.get(k) == shp, (k, sd.get(k))
+    n = sum(int(np.prod(s)) for s in sd.values())
+    assert n == 4869553  # non-optimizer parameters of the global checkpoint minus 4 bookkeeping scalars
+    d = DH3D(ConfigFactory("detection_config").getconfig())
+    sdd = {tf_variable_name(k): tuple(v.shape) for k, v in d.state_dict().items()}
+    assert sdd["detection_block_reliable/detec_conv2/W"] == (1, 1, 256, 1024)
+    assert sdd["detection_block_reliable/detec_conv_fc/b"] == (1,)
+
+
+def _quad_np(desc, B, P, Ng, m1=0.5, m2=0.2):
+    D = desc.shape[1]
+    q = desc[:B]; pos = desc[B:B + P * B].reshape(B, P, D); neg = desc[B + P * B:B + P * B + Ng * B].reshape(B, Ng, D)
+    oth = desc[B + P * B + Ng * B:]
+    best = ((pos - q[:, None]) ** 2).sum(2).min(1)
+    trip = np.maximum(m1 + best[:, None] - ((neg - q[:, None]) ** 2).sum(2), 0).max(1).mean()
+    sec = np.maximum(m2 + best[:, None] - ((neg - oth[:, None]) ** 2).sum(2), 0).max(1).mean()
+    return trip, trip + sec
+
+
+def test_losses_match_restatement():
+    from dh3d_amd import losses
+    rng = np.random.default_rng(0)
+    B, P, Ng = 2, 2, 8
+    desc = rng.standard_normal((B * (1 + P + Ng + 1), 16)).astype(np.float32)
+    desc /= np.linalg.norm(desc, axis=1, keepdims=True)
+    trip, quad = _quad_np(desc.astype(np.float64), B, P, Ng)
+    t = torch.from_numpy(desc)
+    assert abs(float(losses.lazy_quadruplet_loss(t, B, P, Ng)) - quad) < 1e-5
+    assert abs(float(losses.lazy_triplet_loss(t[:B * (1 + P + Ng)], B, P, Ng)) - trip) < 1e-5
+
+
+def test_shard_plan_covers_every_cloud_once():
+    from dh3d_amd import dist as D
+    for Bt, world in ((22, 8), (32, 8), (8, 1), (5, 2), (3, 8)):
+        per, padded = D.shard_plan(Bt, world)
+        assert padded >= Bt and padded == per * world
+        seen = []
+        for r in range(world):
+            a, b = D.local_slice(Bt, r, world)
+            seen += list(range(a, b))
+        assert seen == list(range(Bt))
+    pts = torch.arange(5 * 4 * 3, dtype=torch.float32).reshape(5, 4, 3)
+    blk, mask = D.shard_batch(pts, 1, 2)
+    assert blk.shape == (3, 4, 3) and mask.tolist() == [True, True, False]
+    assert torch.equal(blk[:2], pts[3:5])
+
+
+_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, %r)
+from dh3d_amd import dist as D
+rank, world = D.init_from_env(backend="gloo")
+Bt, Dd = 5, 8
+full = torch.arange(Bt * Dd, dtype=torch.float32).reshape(Bt, Dd)
+per, _ = D.shard_plan(Bt, world)
+a, b = D.local_slice(Bt, rank, world)
+local = torch.zeros(per, Dd); local[: b - a] = full[a:b]
+out = D.all_gather_descriptors(local, Bt)
+assert torch.equal(out, full), (rank, out)
+t = D.max_over_ranks(float(rank + 1), torch.device("cpu"))
+assert t == float(world)
+D.barrier()
+print("rank", rank, "ok")
+"""
+
+
+def test_all_gather_world_size_2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29617", str(script)],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout

@@ -1,0 +1,123 @@
+"""GPU: end-to-end forward of dh3d_amd.model.DH3D vs the numpy restatement of the reference graph,
+hipGraph replay, size-independent properties at the BASELINE sizes, and single-GPU sharding glue."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _weights_np(model):
+    from dh3d_amd.model import tf_variable_name
+    return {tf_variable_name(k): v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+
+
+def _randomise_bn(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, buf in model.named_buffers():
+            if name.endswith(("mean_EMA", "moving_mean")):
+                buf.copy_(0.1 * torch.randn(buf.shape, generator=g))
+            elif name.endswith(("variance_EMA", "moving_variance")):
+                buf.copy_(0.5 + torch.rand(buf.shape, generator=g))
+        for name, p in model.named_parameters():
+            if name.endswith("gamma"):
+                p.copy_(0.75 + 0.5 * torch.rand(p.shape, generator=g))
+
+
+def _build(preset, dev, seed=0):
+    from dh3d_amd import ConfigFactory
+    from dh3d_amd.model import DH3D
+    m = DH3D(ConfigFactory(preset).getconfig()).init_synthetic(seed)
+    _randomise_bn(m, seed + 1)
+    return m.to(dev).eval().prepare()
+
+
+@pytest.mark.parametrize("preset", ["detection_config", "global_config"])
+def test_forward_vs_numpy_restatement(dev, preset):
+    from oracle import model_np
+    m = _build(preset, dev)
+    rng = np.random.default_rng(1001)
+    pts = rng.random((2, 1024, 3), dtype=np.float32)
+    with torch.no_grad():
+        outs = m(torch.from_numpy(pts).to(dev))
+    exp = model_np.forward(pts, _weights_np(m), detection=bool(m.config.detection),
+                           extract_global=bool(m.config.extract_global))
+    assert np.array_equal(outs["knn_inds"].cpu().numpy(), exp["knn_indices"].transpose(0, 2, 1))  # bit-exact ids
+    feat = outs["feat"].cpu().numpy()
+    assert np.allclose(feat, exp["feat"], rtol=1e-4, atol=1e-4 * np.abs(exp["feat"]).max())
+    assert np.allclose(outs["xyz_feat"].cpu().numpy(), exp["xyz_feat"], rtol=1e-4, atol=1e-4)  # L2-normed: abs 1e-4
+    if m.config.detection:
+        assert np.allclose(outs["xyz_feat_att"].cpu().numpy(), exp["xyz_feat_att"], rtol=1e-4, atol=1e-4)
+    if m.config.extract_global:
+        g = outs["globaldesc"].cpu().numpy()
+        assert g.shape == (2, 256) and np.allclose(g, exp["globaldesc"], rtol=1e-4, atol=1e-4)
+
+
+def test_graph_replay_matches_eager_and_is_deterministic(dev):
+    m = _build("global_config", dev, seed=3)
+    pts = torch.rand(4, 2048, 3, device=dev)
+    with torch.no_grad():
+        eager = {k: v.clone() for k, v in m(pts).items() if k in ("xyz_feat", "globaldesc")}
+        run = m.graphed(pts, outputs=("xyz_feat", "globaldesc"))
+        r1 = {k: v.clone() for k, v in run(pts).items()}
+        other = torch.rand(4, 2048, 3, device=dev)
+        run(other)
+        r2 = {k: v.clone() for k, v in run(pts).items()}
+    for k in eager:
+        assert torch.equal(eager[k], r1[k]) and torch.equal(r1[k], r2[k]), k
+
+
+def test_full_size_properties_cfg2_cfg3(dev):
+    """BASELINE sizes: cfg2 local (B=8,N=8192) and cfg3 global (B=32,N=4096).  Size-independent checks:
+    unit-norm descriptors, finite values, per-cloud independence (a cloud's result does not depend on
+    its batch neighbours) and permutation of clouds commuting with the forward."""
+    m = _build("global_config", dev, seed=5)
+    with torch.no_grad():
+        p2 = torch.rand(8, 8192, 3, device=dev)
+        o2 = m(p2)
+        xf = o2["xyz_feat"]
+        assert xf.shape == (8, 8192, 131) and torch.isfinite(xf).all()
+        assert torch.allclose(xf[:, :, 3:].norm(dim=2), torch.ones(8, 8192, device=dev), atol=1e-4)
+        assert torch.equal(xf[:, :, :3], p2)
+        solo = m(p2[5:6])
+        assert torch.equal(solo["xyz_feat"][0], xf[5])
+        p3 = torch.rand(32, 4096, 3, device=dev)
+        o3 = m(p3)
+        g = o3["globaldesc"]
+        assert g.shape == (32, 256) and torch.isfinite(g).all()
+        assert torch.allclose(g.norm(dim=1), torch.ones(32, device=dev), atol=1e-4)
+        perm = torch.randperm(32, device=dev)
+        gp = m(p3[perm])["globaldesc"]
+        assert torch.allclose(gp, g[perm], atol=1e-6)
+
+
+def test_input_knn_path_above_8192(dev):
+    """num_points > 8192: kNN indices are an input (core/model.py:148-155); cfg5 shape N=16384."""
+    from dh3d_amd import ConfigFactory, pm
+    from dh3d_amd.model import DH3D
+    cfg = ConfigFactory("basic_config").getconfig()
+    cfg.num_points = 16384
+    m = DH3D(cfg).init_synthetic(1).to(dev).eval().prepare()
+    pts = torch.rand(1, 16384, 3, device=dev)
+    with pytest.raises(ValueError):
+        m(pts)
+    nbr, _ = pm.knn_xyz(pts, 8)
+    with torch.no_grad():
+        out = m(pts, knn_inds=nbr)
+    assert out["xyz_feat"].shape == (1, 16384, 131) and torch.isfinite(out["xyz_feat"]).all()
+
+
+def test_shard_then_gather_equals_unsharded(dev):
+    """Single process emulation of the 8-rank partition: per-rank forwards + concatenation == full batch."""
+    from dh3d_amd import dist as D
+    m = _build("global_config", dev, seed=7)
+    pts = torch.rand(11, 1024, 3, device=dev)  # 11 clouds over 4 ranks -> padding on the tail rank
+    with torch.no_grad():
+        full = m(pts)["globaldesc"]
+        parts = []
+        for r in range(4):
+            blk, mask = D.shard_batch(pts, r, 4)
+            parts.append(m(blk)["globaldesc"])
+        gathered = torch.cat(parts, 0)[:11]
+    assert torch.allclose(gathered, full, atol=1e-6)

@@ -1,0 +1,208 @@
+"""GPU parity (through the C ABI): drop-in operators in the reference layouts vs the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def close(a, b, rtol=1e-4, atol=1e-6):  # reference criterion, user_ops/misc.py:89-97
+    return np.allclose(a, b, rtol=rtol, atol=atol)
+
+
+def load(name):
+    return dict(np.load(os.path.join(G, name)))
+
+
+# ------------------------------------------------------------------------------ kNN
+@pytest.mark.parametrize("B,N,K", [(2, 32, 4), (1, 4, 4), (2, 300, 8), (1, 1100, 8), (1, 2048, 16), (2, 4096, 8),
+                                   (1, 100, 50)])
+def test_knn_bitexact_vs_oracle(dev, oracle, B, N, K):
+    from dh3d_amd import ops
+    rng = np.random.default_rng(1000 + N + K)
+    pos = rng.random((B, 3, N), dtype=np.float32) * 40 - 20
+    nn, d = ops.knn_bruteforce(T(pos, dev), K)
+    enn, ed = oracle.knn_bruteforce(pos, K)
+    assert np.array_equal(nn.cpu().numpy(), enn)
+    assert np.array_equal(d.cpu().numpy(), ed)  # IEEE sqrt + explicit fma chain: bit-exact distances too
+
+
+def test_knn_golden_and_ties(dev, oracle):
+    from dh3d_amd import ops
+    c = load("fake_pointcloud.npz")
+    nn, d = ops.knn_bruteforce(T(c["position"], dev), 4)
+    assert np.array_equal(nn.cpu().numpy(), c["knn_scipy_ids"])  # scipy answer of test_knn_bruteforce.py
+    assert close(d.cpu().numpy(), c["knn_scipy_dist"], 1e-6, 1e-6)
+    t = load("knn_ties.npz")
+    for name in ("lat300", "lat1100"):
+        nn, d = ops.knn_bruteforce(T(t[name + "_pos"], dev), 8)
+        assert np.array_equal(nn.cpu().numpy(), t[name + "_nn"]), name
+        assert np.array_equal(d.cpu().numpy(), t[name + "_dist"]), name
+    # duplicates + K > N padding
+    z = np.zeros((1, 3, 300), np.float32)
+    nn, _ = ops.knn_bruteforce(T(z, dev), 8)
+    assert np.array_equal(nn.cpu().numpy(), oracle.knn_bruteforce(z, 8)[0])
+    p3 = np.random.default_rng(0).random((1, 3, 3), dtype=np.float32)
+    nn, d = ops.knn_bruteforce(T(p3, dev), 4)
+    enn, ed = oracle.knn_bruteforce(p3, 4)
+    assert np.array_equal(nn.cpu().numpy(), enn) and np.array_equal(d.cpu().numpy(), ed)
+
+
+def test_knn_full_size_properties(dev, oracle):
+    """N = 8192 (BASELINE cfg2 size): sortedness, self at rank 0, and an oracle spot check."""
+    from dh3d_amd import ops, pm
+    rng = np.random.default_rng(2002)
+    xyz = rng.random((2, 8192, 3), dtype=np.float32)
+    nn, d = pm.knn_xyz(T(xyz, dev), 8)
+    nn2, d2 = ops.knn_bruteforce(T(xyz.transpose(0, 2, 1), dev), 8)
+    assert torch.equal(nn, nn2) and torch.equal(d, d2)  # both layouts, same kernel family
+    nn, d = nn.cpu().numpy(), d.cpu().numpy()
+    assert np.all(np.diff(d, axis=2) >= 0) and np.all(d[:, :, 0] == 0)
+    assert np.array_equal(nn[:, :, 0], np.broadcast_to(np.arange(8192), (2, 8192)))
+    sub = np.ascontiguousarray(xyz[:1].transpose(0, 2, 1))
+    enn, ed = oracle.knn_bruteforce(sub, 8)  # ~1.5 s on CPU
+    assert np.array_equal(nn[:1], enn) and np.array_equal(d[:1], ed)
+
+
+def test_knn_beyond_reference_cap(dev, oracle):
+    from dh3d_amd import pm
+    xyz = np.random.default_rng(5005).random((1, 9000, 3), dtype=np.float32)
+    nn, d = pm.knn_xyz(T(xyz, dev), 12)
+    enn, ed = oracle.knn_bruteforce(np.ascontiguousarray(xyz.transpose(0, 2, 1)), 12)
+    assert np.array_equal(nn.cpu().numpy(), enn) and np.array_equal(d.cpu().numpy(), ed)
+
+
+# ------------------------------------------------------------------------------ FPS
+@pytest.mark.parametrize("B,N,m", [(2, 1024, 128), (1, 600, 64), (2, 4096, 512), (1, 8192, 1024), (1, 100, 100),
+                                   (1, 10000, 300)])
+def test_fps_bitexact_vs_oracle(dev, oracle, B, N, m):
+    from dh3d_amd import ops
+    xyz = np.random.default_rng(N + m).random((B, N, 3), dtype=np.float32)
+    idx = ops.farthest_point_sample(m, T(xyz, dev)).cpu().numpy()
+    assert np.array_equal(idx, oracle.farthest_point_sample(m, xyz))
+
+
+def test_fps_golden_and_ties(dev, oracle):
+    from dh3d_amd import ops
+    c = load("fps.npz")
+    assert np.array_equal(ops.farthest_point_sample(128, T(c["xyz"], dev)).cpu().numpy(), c["idx"])
+    assert np.array_equal(ops.farthest_point_sample(64, T(c["lat"], dev)).cpu().numpy(), c["lat_idx"])
+    z = np.zeros((1, 1500, 3), np.float32)
+    z[0, 700] = 1.0; z[0, 188] = 1.0
+    assert int(ops.farthest_point_sample(2, T(z, dev))[0, 1]) == 188
+
+
+# ------------------------------------------------------------------------------ flex ops (reference layout)
+def _case(rng, B, N, K, Din, Dout, oracle):
+    pos = rng.standard_normal((B, 3, N)).astype(np.float32)
+    nn, _ = oracle.knn_bruteforce(pos, K)
+    return dict(position=pos, neighborhood=np.ascontiguousarray(nn.transpose(0, 2, 1)),
+                features=rng.standard_normal((B, Din, N)).astype(np.float32),
+                theta=rng.standard_normal((3, Din, Dout)).astype(np.float32),
+                bias=rng.standard_normal((Din, Dout)).astype(np.float32),
+                theta_rel=rng.standard_normal((Din, Dout)).astype(np.float32),
+                bias_rel=rng.standard_normal((Dout,)).astype(np.float32),
+                topdiff=rng.standard_normal((B, Dout, N)).astype(np.float32))
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 4, 2, 6), (2, 200, 8, 16, 24), (1, 513, 8, 32, 40)])
+def test_flex_conv_fwd_bwd(dev, oracle, shape):
+    from dh3d_amd import ops
+    c = load("fake_pointcloud.npz") if shape == (2, 32, 4, 2, 6) else _case(np.random.default_rng(7), *shape, oracle)
+    f = T(c["features"], dev).requires_grad_()
+    th = T(c["theta"], dev).requires_grad_()
+    bi = T(c["bias"], dev).requires_grad_()
+    out = ops.flex_convolution(f, T(c["position"], dev), T(c["neighborhood"], dev), th, bi)
+    exp = oracle.flex_convolution(c["features"], c["position"], c["neighborhood"], c["theta"], c["bias"], True)
+    assert close(out.detach().cpu().numpy(), exp)
+    out.backward(T(c["topdiff"], dev))
+    gf, gt, gb = oracle.flex_convolution_grad(c["features"], c["position"], c["neighborhood"], c["theta"],
+                                              c["bias"], c["topdiff"])
+    # atomics / reduction order differ: the reference allows 1e-3 here (test_flex_convolution.py:120-133)
+    assert close(f.grad.cpu().numpy(), gf, 1e-3, 1e-4)
+    assert close(th.grad.cpu().numpy(), gt, 1e-3, 1e-3)
+    assert close(bi.grad.cpu().numpy(), gb, 1e-3, 1e-3)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 4, 2, 6), (2, 300, 8, 3, 32)])
+def test_conv_pointset_fwd_bwd(dev, oracle, shape):
+    from dh3d_amd import ops
+    c = load("fake_pointcloud.npz") if shape == (2, 32, 4, 2, 6) else _case(np.random.default_rng(8), *shape, oracle)
+    f = T(c["features"], dev).requires_grad_()
+    th = T(c["theta_rel"], dev).requires_grad_()
+    bi = T(c["bias_rel"], dev).requires_grad_()
+    out = ops.convolution_pointset(f, T(c["neighborhood"], dev), th, bi)
+    assert close(out.detach().cpu().numpy(), oracle.convolution_pointset(c["features"], c["neighborhood"],
+                                                                         c["theta_rel"], c["bias_rel"]))
+    out.backward(T(c["topdiff"], dev))
+    gf, gt, gb = oracle.convolution_pointset_grad(c["features"], c["neighborhood"], c["theta_rel"], c["topdiff"])
+    assert close(f.grad.cpu().numpy(), gf, 1e-3, 1e-4)
+    assert close(th.grad.cpu().numpy(), gt, 1e-3, 1e-3)
+    assert close(bi.grad.cpu().numpy(), gb, 1e-3, 1e-3)
+
+
+def test_flex_pool_exact_and_known_answer(dev, oracle):
+    from dh3d_amd import ops
+    k = load("flex_pool_kat.npz")
+    x = T(k["x"], dev).requires_grad_()
+    out, arg = ops.flex_pooling(x, T(k["nbr"], dev))
+    assert np.array_equal(out.detach().cpu().numpy(), k["out"]) and np.array_equal(arg.cpu().numpy(), k["argmax"])
+    out.sum().backward()
+    assert np.array_equal(x.grad.cpu().numpy(), k["grad"])  # all 4 units of gradient land on index 2
+    c = _case(np.random.default_rng(9), 2, 257, 8, 40, 8, oracle)
+    c["features"][0, :, 5] = c["features"][0, :, 9]  # exact value ties: first max in neighbour order wins
+    f = T(c["features"], dev).requires_grad_()
+    out, arg = ops.flex_pooling(f, T(c["neighborhood"], dev))
+    eo, ea = oracle.flex_pooling(c["features"], c["neighborhood"])
+    assert np.array_equal(out.detach().cpu().numpy(), eo) and np.array_equal(arg.cpu().numpy(), ea)
+    top = np.random.default_rng(1).standard_normal(eo.shape).astype(np.float32)
+    out.backward(T(top, dev))
+    assert close(f.grad.cpu().numpy(), oracle.flex_pooling_grad(top, ea), 1e-5, 1e-5)
+
+
+# ------------------------------------------------------------------------------ PointNet++ ops
+def test_group_point_and_interpolate_vs_reference_twin_golden(dev):
+    from dh3d_amd import ops
+    c = load("twins.npz")
+    p = T(c["points"], dev).requires_grad_()
+    out = ops.group_point(p, T(c["gidx"], dev))
+    assert np.array_equal(out.detach().cpu().numpy(), c["group"])
+    out.backward(T(c["ggrad_out"], dev))
+    assert close(p.grad.cpu().numpy(), c["group_grad"], 1e-5, 1e-5)
+    p2 = T(c["points"], dev).requires_grad_()
+    o2 = ops.three_interpolate(p2, T(c["idx3"], dev), T(c["w3"], dev))
+    assert close(o2.detach().cpu().numpy(), c["interp"], 1e-6, 1e-6)
+    o2.backward(T(c["grad_out"], dev))
+    assert close(p2.grad.cpu().numpy(), c["interp_grad"], 1e-5, 1e-5)
+    d, i = ops.three_nn(torch.zeros(2, 5, 3, device=dev), T(c["xyz2"], dev))
+    assert np.array_equal(i.cpu().numpy(), c["nn_origin_idx"]) and np.array_equal(d.cpu().numpy(), c["nn_origin_dist"])
+
+
+@pytest.mark.parametrize("b,n,m", [(2, 50, 20), (2, 4096, 512), (1, 1000, 2), (1, 3000, 1100)])
+def test_three_nn_bitexact(dev, oracle, b, n, m):
+    from dh3d_amd import ops
+    rng = np.random.default_rng(n + m)
+    x1 = rng.random((b, n, 3), dtype=np.float32)
+    x2 = rng.random((b, m, 3), dtype=np.float32)
+    d, i = ops.three_nn(T(x1, dev), T(x2, dev))
+    ed, ei = oracle.three_nn(x1, x2)
+    assert np.array_equal(i.cpu().numpy(), ei) and np.array_equal(d.cpu().numpy(), ed)
+
+
+def test_error_behaviour(dev):
+    from dh3d_amd import ops
+    with pytest.raises(ValueError):
+        ops.farthest_point_sample(0, torch.zeros(1, 8, 3, device=dev))
+    with pytest.raises(ValueError):
+        ops.farthest_point_sample(4, torch.zeros(1, 8, 2, device=dev))
+    with pytest.raises(ValueError):
+        ops.flex_pooling(torch.zeros(1, 4, 8, device=dev), torch.zeros(2, 3, 8, dtype=torch.int32, device=dev))
+    with pytest.raises(ValueError):
+        ops.knn_bruteforce(torch.zeros(1, 3, 8, device=dev, dtype=torch.float64), 2)

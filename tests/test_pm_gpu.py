@@ -1,0 +1,182 @@
+"""GPU parity: fused point-major kernels vs the CPU oracle (through layout transposes) and, for the
+dense layers, vs a plain fp32 restatement evaluated in float64 numpy."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def close(a, b, rtol=1e-4, atol=1e-5):
+    return np.allclose(a, b, rtol=rtol, atol=atol)
+
+
+def relerr(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def _cloud(rng, B, N, K, oracle):
+    xyz = rng.random((B, N, 3), dtype=np.float32)
+    nn, _ = oracle.knn_bruteforce(np.ascontiguousarray(xyz.transpose(0, 2, 1)), K)
+    return xyz, nn  # nn [B,N,K]
+
+
+def test_mfma_fragment_layout_identity_probe(dev):
+    """A = I against an ASYMMETRIC W: catches row/col swaps in the MFMA C/D mapping or the packing."""
+    from dh3d_amd import pm
+    Kd, Dout = 64, 64
+    W = (np.arange(Kd)[:, None] * 1000 + np.arange(Dout)[None, :]).astype(np.float32)
+    x = np.eye(64, Kd, dtype=np.float32)
+    out = pm.linear(T(x, dev), pm.pack_weight(T(W, dev)), Dout)
+    assert np.array_equal(out.cpu().numpy(), W)
+    x = np.random.default_rng(0).integers(-3, 4, (200, Kd)).astype(np.float32)  # exact in fp32
+    W2 = np.random.default_rng(1).integers(-3, 4, (Kd, 128)).astype(np.float32)
+    out = pm.linear(T(x, dev), pm.pack_weight(T(W2, dev)), 128)
+    assert np.array_equal(out.cpu().numpy(), x @ W2)
+
+
+@pytest.mark.parametrize("Din,Dout,N", [(32, 64, 1000), (64, 64, 777), (64, 128, 512), (128, 128, 300), (128, 256, 512)])
+def test_flex_conv_pm_vs_oracle(dev, oracle, Din, Dout, N):
+    from dh3d_amd import pm
+    rng = np.random.default_rng(Din + Dout)
+    B, K = 2, 8
+    xyz, nn = _cloud(rng, B, N, K, oracle)
+    f = rng.standard_normal((B, N, Din)).astype(np.float32)
+    theta = (rng.standard_normal((3, Din, Dout)) / np.sqrt(Din)).astype(np.float32)
+    bias = (rng.standard_normal((Din, Dout)) / np.sqrt(8 * Din)).astype(np.float32)
+    fb = rng.standard_normal(Dout).astype(np.float32)
+    sc = (0.5 + rng.random(Dout)).astype(np.float32)
+    sh = rng.standard_normal(Dout).astype(np.float32)
+    wp = pm.pack_flex_weight(T(theta, dev), T(bias, dev))
+    raw = pm.flex_conv(T(f, dev), T(xyz, dev), T(nn, dev), wp, Dout).cpu().numpy()
+    exp = oracle.flex_convolution(f.transpose(0, 2, 1), xyz.transpose(0, 2, 1), nn.transpose(0, 2, 1), theta, bias,
+                                  True).transpose(0, 2, 1)
+    assert relerr(raw, exp) < 2e-6 and close(raw, exp, 1e-4, 1e-4 * np.abs(exp).max())
+    fused = pm.flex_conv(T(f, dev), T(xyz, dev), T(nn, dev), wp, Dout, pre_bias=T(fb, dev), scale=T(sc, dev),
+                         shift=T(sh, dev), act=pm.ACT_RELU).cpu().numpy()
+    assert close(fused, np.maximum((exp + fb) * sc + sh, 0), 1e-4, 1e-4 * np.abs(exp).max())
+
+
+def test_flex_pool_pm_exact(dev, oracle):
+    from dh3d_amd import pm
+    rng = np.random.default_rng(3)
+    xyz, nn = _cloud(rng, 2, 999, 8, oracle)
+    f = rng.standard_normal((2, 999, 64)).astype(np.float32)
+    out, arg = pm.flex_pool(T(f, dev), T(nn, dev), want_argmax=True)
+    eo, ea = oracle.flex_pooling(f.transpose(0, 2, 1), nn.transpose(0, 2, 1))
+    assert np.array_equal(out.cpu().numpy(), eo.transpose(0, 2, 1))
+    assert np.array_equal(arg.cpu().numpy(), ea.transpose(0, 2, 1))
+
+
+def test_conv_pointset_pm_vs_oracle(dev, oracle):
+    from dh3d_amd import pm
+    rng = np.random.default_rng(4)
+    xyz, nn = _cloud(rng, 2, 1234, 8, oracle)
+    theta = rng.standard_normal((3, 32)).astype(np.float32)
+    bias = rng.standard_normal(32).astype(np.float32)
+    out = pm.conv_pointset_xyz(T(xyz, dev), T(nn, dev), T(theta, dev), T(bias, dev)).cpu().numpy()
+    exp = oracle.convolution_pointset(xyz.transpose(0, 2, 1), nn.transpose(0, 2, 1), theta, bias).transpose(0, 2, 1)
+    assert close(out, exp, 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("C1,C2,Dout", [(64, 0, 64), (64, 0, 128), (128, 64, 128), (128, 0, 256), (256, 0, 192)])
+def test_linear_pm_vs_fp64(dev, C1, C2, Dout):
+    from dh3d_amd import pm
+    rng = np.random.default_rng(C1 + Dout)
+    R = 1000  # not a multiple of the 64-row tile
+    x1 = rng.standard_normal((R, C1)).astype(np.float32)
+    x2 = rng.standard_normal((R, C2)).astype(np.float32) if C2 else None
+    W = (rng.standard_normal((C1 + C2, Dout)) / np.sqrt(C1 + C2)).astype(np.float32)
+    b = rng.standard_normal(Dout).astype(np.float32)
+    sc = (0.5 + rng.random(Dout)).astype(np.float32)
+    sh = rng.standard_normal(Dout).astype(np.float32)
+    res = rng.standard_normal((R, Dout)).astype(np.float32)
+    out = pm.linear(T(x1, dev), pm.pack_weight(T(W, dev)), Dout, x2=T(x2, dev) if C2 else None, pre_bias=T(b, dev),
+                    scale=T(sc, dev), shift=T(sh, dev), act=pm.ACT_RELU, residual=T(res, dev)).cpu().numpy()
+    xin = np.concatenate([x1, x2], 1) if C2 else x1
+    exp = np.maximum((xin.astype(np.float64) @ W + b) * sc + sh, 0) + res
+    assert close(out, exp, 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("C", [64, 128])
+def test_se_res_pm(dev, C):
+    from dh3d_amd import pm
+    rng = np.random.default_rng(C)
+    R = 333
+    x = rng.standard_normal((R, C)).astype(np.float32)
+    pool = rng.standard_normal((R, C)).astype(np.float32)
+    W1 = (rng.standard_normal((C, C // 4)) / 8).astype(np.float32); b1 = rng.standard_normal(C // 4).astype(np.float32)
+    W2 = (rng.standard_normal((C // 4, C)) / 4).astype(np.float32); b2 = rng.standard_normal(C).astype(np.float32)
+    out = pm.se_res(T(x, dev), T(pool, dev), T(W1, dev), T(b1, dev), T(W2, dev), T(b2, dev)).cpu().numpy()
+    h = np.maximum(pool.astype(np.float64) @ W1 + b1, 0)
+    g = 1 / (1 + np.exp(-(h @ W2 + b2)))
+    assert close(out, np.maximum(x + x * g, 0), 1e-4, 1e-5)
+
+
+def test_interpolate_idw_l2norm_and_head(dev, oracle):
+    from dh3d_amd import ops, pm
+    rng = np.random.default_rng(6)
+    xyz = rng.random((2, 800, 3), dtype=np.float32)
+    sub = xyz[:, ::8].copy()
+    pts = rng.standard_normal((2, 100, 128)).astype(np.float32)
+    d, i = ops.three_nn(T(xyz, dev), T(sub, dev))
+    out = pm.three_interpolate_idw(T(pts, dev), i, d).cpu().numpy()
+    ed, ei = oracle.three_nn(xyz, sub)
+    dist = np.maximum(ed, np.float32(1e-10))
+    w = (1.0 / dist) / np.sum(1.0 / dist, axis=2, keepdims=True)
+    assert close(out, oracle.three_interpolate(pts, ei, w.astype(np.float32)), 1e-4, 1e-5)
+    # l2norm + concat (core/model.py:177-181), incl. an all-zero row (eps rule) and a tiny row
+    x = rng.standard_normal((500, 128)).astype(np.float32)
+    x[3] = 0; x[4] *= 1e-6
+    pre = rng.standard_normal((500, 3)).astype(np.float32)
+    o = pm.l2norm_concat(T(x, dev), 1e-8, prefix=T(pre, dev)).cpu().numpy()
+    exp = x / np.sqrt(np.maximum((x.astype(np.float64) ** 2).sum(1, keepdims=True), 1e-8))
+    assert np.array_equal(o[:, :3], pre) and close(o[:, 3:], exp, 1e-4, 1e-6)
+    # MLP head: 256 -> 1024 (BN, ReLU) -> 1 -> sigmoid
+    R, C, H = 300, 256, 1024
+    h = rng.standard_normal((R, C)).astype(np.float32)
+    W = (rng.standard_normal((C, H)) / 16).astype(np.float32); b = rng.standard_normal(H).astype(np.float32)
+    sc = (0.5 + rng.random(H)).astype(np.float32); sh = rng.standard_normal(H).astype(np.float32)
+    wfc = (rng.standard_normal(H) / 32).astype(np.float32)
+    att = pm.mlp_head(T(h, dev), pm.pack_weight(T(W, dev)), H, T(wfc, dev), 0.125, pre_bias=T(b, dev),
+                      scale=T(sc, dev), shift=T(sh, dev)).cpu().numpy()
+    hid = np.maximum((h.astype(np.float64) @ W + b) * sc + sh, 0)
+    assert close(att[:, 0], 1 / (1 + np.exp(-(hid @ wfc + 0.125))), 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("B,N", [(2, 512), (3, 1000), (32, 128)])
+def test_netvlad_vs_restatement(dev, B, N):
+    from oracle import model_np
+    from dh3d_amd import pm
+    rng = np.random.default_rng(B * N)
+    D, C, O = 256, 64, 256
+    x = rng.standard_normal((B, N, D)).astype(np.float32)
+    att = rng.random((B, N, 1), dtype=np.float32)
+    w = {"cluster_weights": (rng.standard_normal((D, C)) / 16).astype(np.float32),
+         "cluster_weights2": (rng.standard_normal((1, D, C)) / 16).astype(np.float32),
+         "hidden1_weights": (rng.standard_normal((D * C, O)) / 8).astype(np.float32),
+         "gating_weights": (rng.standard_normal((O, O)) / 16).astype(np.float32)}
+    for s, n in (("cluster_bn", C), ("bn", O), ("gating_bn", O)):
+        w[s + "/gamma"] = (0.5 + rng.random(n)).astype(np.float32)
+        w[s + "/beta"] = (0.1 * rng.standard_normal(n)).astype(np.float32)
+        w[s + "/moving_mean"] = (0.1 * rng.standard_normal(n)).astype(np.float32)
+        w[s + "/moving_variance"] = (0.5 + rng.random(n)).astype(np.float32)
+    exp = model_np.global_netvlad_block(x, att, w, 1e-3)
+
+    def fold(s):
+        sc = w[s + "/gamma"] / np.sqrt(w[s + "/moving_variance"] + np.float32(1e-3))
+        return T(sc, dev), T(w[s + "/beta"] - w[s + "/moving_mean"] * sc, dev)
+    cs, ch = fold("cluster_bn"); s1, h1 = fold("bn"); s2, h2 = fold("gating_bn")
+    vlad = pm.netvlad_aggregate(T(x, dev), T(att, dev), pm.pack_weight(T(w["cluster_weights"], dev)), cs, ch,
+                                T(w["cluster_weights2"].reshape(D, C), dev))
+    out = pm.netvlad_head(vlad, T(w["hidden1_weights"], dev), s1, h1, T(w["gating_weights"], dev), s2, h2).cpu().numpy()
+    assert close(out, exp, 1e-4, 1e-5), relerr(out, exp)
+    v = vlad.cpu().numpy()
+    assert np.allclose(np.linalg.norm(v, axis=1), 1, atol=1e-5)  # whole-vector L2 norm
+    out2 = pm.netvlad_head(vlad, T(w["hidden1_weights"], dev), s1, h1, T(w["gating_weights"], dev), s2, h2,
+                           l2_eps=1e-8).cpu().numpy()
+    assert close(out2, exp / np.linalg.norm(exp, axis=1, keepdims=True), 1e-4, 1e-5)
