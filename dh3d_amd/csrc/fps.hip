@@ -4,9 +4,12 @@
 // FPS is a chain of m dependent rounds; the only outer parallelism is the batch.  One 1024-lane
 // workgroup (16 waves, one CU) owns a cloud.  Each lane keeps its PPT points AND their running
 // min-distances in registers for the whole kernel (the reference re-reads a [32,n] global scratch
-// every round), so a round is: PPT fused distance updates per lane -> wave argmax by DPP-free
-// xor-shuffles -> 16 partial winners through LDS (one barrier per round, double-buffered) ->
-// every wave re-derives the same winner and reads its coordinates from the LDS copy of the cloud.
+// every round).  A round is latency-bound, so every step is kept off the LDS where possible:
+//   packed-f32 distance update (two points per v_pk_* op) -> wave arg-max on the DPP crossbar
+//   (wave_ops.h) -> 16 partial winners through LDS (one barrier per round, double-buffered) ->
+//   16-lane DPP row reduce in every wave -> winner coordinates from the LDS copy of the cloud.
+// (The first version used ds_bpermute shuffles for both reductions: 1.5 ms for N=8192 -> 1024,
+//  profiles/r01_a.)
 //
 // Bit-exactness (compiled with -ffp-contract=off):
 //   d    = fma(dz,dz, fma(dx,dx, dy*dy))      -- nvcc/LLVM contraction of (:141); see DESIGN.md
@@ -14,11 +17,16 @@
 //   pick = max td; ties -> smallest (k % 512, k / 512): the reference's 512 threads each scan
 //          k = tid, tid+512, ... with strict '>' (:146-149) and its tree keeps the lower slot on
 //          ties (:158-161).  Encoded here as key(k) = ((k & 511) << 16) | (k >> 9), smaller wins.
+#include <limits.h>
+
 #include "common.h"
+#include "wave_ops.h"
 
 #pragma clang fp contract(off)
 
 namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / 64;
@@ -26,16 +34,17 @@ constexpr int kWaves = kThreads / 64;
 __device__ __forceinline__ int fps_key(int k) { return ((k & 511) << 16) | (k >> 9); }
 __device__ __forceinline__ int fps_unkey(int key) { return ((key & 0xffff) << 9) | (key >> 16); }
 
-// (value, key) argmax over a wave; every lane returns the winner.
-__device__ __forceinline__ void wave_argmax(float &val, int &key) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const float ov = __shfl_xor(val, off, 64);
-    const int ok = __shfl_xor(key, off, 64);
-    const bool take = (ov > val) || (ov == val && ok < key);
-    val = take ? ov : val;
-    key = take ? ok : key;
-  }
+// Single-instruction min / max3: the operands are never NaN here, so the canonicalising v_max x,x that
+// fminf/fmaxf carry under IEEE mode would only cost issue slots in a loop that is VALU-issue bound.
+__device__ __forceinline__ float vmin(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
 }
 
 template <int PPT, bool LDS_COORDS>
@@ -56,22 +65,21 @@ __global__ __launch_bounds__(kThreads) void fps_kernel(const float *__restrict__
   const float *pc = xyz + (size_t)b * N * 3;
 
   // Lane t owns k_j = (t & 511) + 512*(2j + (t >> 9)): keys increase with j, so a strict '>' scan
-  // over j keeps the smallest key among equal values.
-  float px[PPT], py[PPT], pz[PPT], md[PPT];
+  // over j keeps the smallest key among equal values.  Points are held as pairs (j = 2p, 2p+1).
+  constexpr int NP = (PPT + 1) / 2;
+  f32x2 px[NP], py[NP], pz[NP], md[NP];
   const int k0 = (tid & 511) + 512 * (tid >> 9);
+  const int key0 = fps_key(k0);
 #pragma unroll
-  for (int j = 0; j < PPT; ++j) {
+  for (int j = 0; j < 2 * NP; ++j) {
     const int k = k0 + 1024 * j;
-    if (k < N) {
-      px[j] = pc[(size_t)k * 3];
-      py[j] = pc[(size_t)k * 3 + 1];
-      pz[j] = pc[(size_t)k * 3 + 2];
-      md[j] = 1e38f;
-      if (LDS_COORDS) { s_x[k] = px[j]; s_y[k] = py[j]; s_z[k] = pz[j]; }
-    } else {
-      px[j] = py[j] = pz[j] = 0.f;
-      md[j] = -2.f;  // below the reference's initial best = -1: can never be picked
+    float x = 0.f, y = 0.f, z = 0.f, d = -2.f;  // -2: below the reference's initial best = -1, never picked
+    if (j < PPT && k < N) {
+      x = pc[(size_t)k * 3]; y = pc[(size_t)k * 3 + 1]; z = pc[(size_t)k * 3 + 2];
+      d = 1e38f;
+      if (LDS_COORDS) { s_x[k] = x; s_y[k] = y; s_z[k] = z; }
     }
+    px[j >> 1][j & 1] = x; py[j >> 1][j & 1] = y; pz[j >> 1][j & 1] = z; md[j >> 1][j & 1] = d;
   }
   if (tid == 0) out[(size_t)b * m] = 0;
   __syncthreads();
@@ -82,32 +90,39 @@ __global__ __launch_bounds__(kThreads) void fps_kernel(const float *__restrict__
     float x1, y1, z1;
     if (LDS_COORDS) { x1 = s_x[old]; y1 = s_y[old]; z1 = s_z[old]; }
     else { x1 = pc[(size_t)old * 3]; y1 = pc[(size_t)old * 3 + 1]; z1 = pc[(size_t)old * 3 + 2]; }
+    const f32x2 x2 = {x1, x1}, y2 = {y1, y1}, z2 = {z1, z1};
 
+    // running min-distance update (two points per packed op) + the lane's best VALUE only
     float best = -1.f;
-    int bestk = 0;
 #pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      const float dx = px[j] - x1, dy = py[j] - y1, dz = pz[j] - z1;
-      const float d = __fmaf_rn(dz, dz, __fmaf_rn(dx, dx, __fmul_rn(dy, dy)));
-      const float d2 = fminf(d, md[j]);
-      md[j] = d2;
-      if (d2 > best) { best = d2; bestk = k0 + 1024 * j; }
+    for (int p = 0; p < NP; ++p) {
+      const f32x2 dx = px[p] - x2, dy = py[p] - y2, dz = pz[p] - z2;
+      const f32x2 d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
+      md[p][0] = vmin(d[0], md[p][0]);
+      md[p][1] = vmin(d[1], md[p][1]);
+      best = vmax3(best, md[p][0], md[p][1]);
     }
-    int key = fps_key(bestk);
-    wave_argmax(best, key);
-    if (lane == 0) { s_val[buf * kWaves + wave] = best; s_key[buf * kWaves + wave] = key; }
+    const float wmax = wave_max_f32(best);
+    // key of the lane's first point holding wmax: key(k0 + 1024 j) = key(k0) + 2 j  (scan j downwards)
+    int jmin = 0;
+#pragma unroll
+    for (int j = 2 * NP - 1; j >= 0; --j) jmin = (md[j >> 1][j & 1] == wmax) ? j : jmin;
+    const int lkey = key0 + 2 * jmin;
+    const unsigned long long hit = __ballot(best == wmax);
+    int wkey;
+    if (__popcll(hit) == 1) wkey = __builtin_amdgcn_readlane(lkey, __builtin_ctzll(hit));
+    else wkey = wave_min_i32(best == wmax ? lkey : INT_MAX);  // several lanes tie: smallest key wins
+    if (lane == 0) { s_val[buf * kWaves + wave] = wmax; s_key[buf * kWaves + wave] = wkey; }
     __syncthreads();
-    float v = s_val[buf * kWaves + (lane & (kWaves - 1))];
-    int kk = s_key[buf * kWaves + (lane & (kWaves - 1))];
-#pragma unroll
-    for (int off = kWaves / 2; off > 0; off >>= 1) {
-      const float ov = __shfl_xor(v, off, 64);
-      const int ok = __shfl_xor(kk, off, 64);
-      const bool take = (ov > v) || (ov == v && ok < kk);
-      v = take ? ov : v;
-      kk = take ? ok : kk;
-    }
-    old = fps_unkey(kk);
+    // every wave re-derives the block winner from the 16 partials (lanes 0..15 hold one each)
+    const float v = s_val[buf * kWaves + (lane & (kWaves - 1))];
+    const int kk = s_key[buf * kWaves + (lane & (kWaves - 1))];
+    const float bmax = row16_max_f32(v);
+    const unsigned long long hit2 = __ballot(v == bmax) & 0xffffull;
+    int bkey;
+    if (__popcll(hit2) == 1) bkey = __builtin_amdgcn_readlane(kk, __builtin_ctzll(hit2));
+    else bkey = __builtin_amdgcn_readfirstlane(row16_min_i32(v == bmax ? kk : INT_MAX));
+    old = fps_unkey(bkey);
     if (tid == 0) out[(size_t)b * m + r] = old;
     buf ^= 1;
   }

@@ -2,11 +2,15 @@
 // (user_ops/kernels/knn_bruteforce_kernel_gpu.cu.cc:36-134,163-228).
 //
 // The reference sorts all N (distance, id) pairs per query with cub::BlockRadixSort and keeps K.
-// Here one lane owns one query and streams every candidate of its cloud from LDS (all 64 lanes
-// read the same float4 -> one broadcast ds_read_b128 per candidate per wave); the running top-K
-// lives in registers as a sorted list.  A candidate is first screened on the squared distance
-// against a conservative bound derived from the current K-th entry, so the IEEE sqrt and the
-// register insertion run only for the few candidates that can enter the list.
+// Here one lane owns one query and streams every candidate of its cloud from LDS (all 64 lanes read the
+// same 16 bytes -> broadcast ds_read_b128).  Per 8 candidates the hot loop is 12 packed-f32 VALU ops
+// (v_pk_add/mul/fma: two candidates per instruction) + a min tree + ONE branch: a candidate is screened
+// on its squared distance against a conservative bound derived from the lane's current K-th entry.
+// Survivors are not inserted on the spot -- with 64 independent queries per wave "some lane has a
+// survivor" is true far more often than "this lane has one", and a divergent K-deep insertion per hit
+// dominated the first version (profiles/r01_a).  They are appended to a per-lane LDS queue (3 VALU) and
+// the whole wave drains its queues only when one of them is half full: then the IEEE sqrt, the tie key
+// and the register insertion run back to back for every queued entry.
 //
 // Bit-exactness (compiled with -ffp-contract=off; every rounding below is explicit):
 //   distance  d = sqrt( fma(dz,dz, fma(dy,dy, dx*dx)) ), dx = c.x - q.x   (gpu.cu.cc:102-107 with
@@ -14,6 +18,7 @@
 //   order     ascending (d, tb), tb(x) = (x % C_THREADS)*C_VPT + x / C_THREADS  -- the rank of
 //             point x in CUB's blocked arrangement, which the stable radix sort preserves among
 //             equal keys (gpu.cu.cc:98-123); (C_THREADS, C_VPT) from the N ladder (:181-216).
+//   The list is kept as 64-bit keys (bits(d) << 32 | tb): d >= 0, so unsigned order == (d, tb) order.
 #include <float.h>
 #include <limits.h>
 
@@ -23,8 +28,12 @@
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned long long u64;
+
 constexpr int kQueriesPerBlock = 256;
-constexpr int kChunk = 1024;  // candidates staged per LDS round (16 KiB as float4)
+constexpr int kChunk = 1024;   // candidates staged per LDS round: 256 groups of 4 x 12 floats = 12 KiB
+constexpr int kQueue = 16;     // per-lane survivor queue depth (drained when any lane holds > 8)
 
 struct KnnLadder {
   int log2ct;  // log2(C_THREADS)
@@ -52,8 +61,43 @@ static KnnLadder knn_ladder(int N) {
   return l;
 }
 
-__device__ __forceinline__ bool knn_less(float d0, int t0, float d1, int t1) {
-  return d0 < d1 || (d0 == d1 && t0 < t1);
+// LDS image of 4 consecutive candidates c0..c3 (12 floats, three 16-byte reads):
+//   [x0 x1 y0 y1] [z0 z1 x2 x3] [y2 y3 z2 z3]   -> pairs feed v_pk_* directly
+__device__ __forceinline__ int cand_slot(int c, int comp) {
+  const int g = c >> 2, r = c & 3;
+  const int off = (r < 2) ? (2 * comp + r) : (4 + 2 * comp + r);  // comp 0:x 1:y 2:z
+  return g * 12 + off;
+}
+
+template <int KMAX>
+struct KnnState {
+  u64 keys[KMAX];
+  float bound;  // s > bound  =>  sqrt(s) > current K-th distance
+};
+
+template <int KMAX>
+__device__ __forceinline__ void knn_offer(KnnState<KMAX> &st, float s, int x, const KnnLadder &lad) {
+  if (s <= st.bound) {
+    const float d = sqrtf(s);  // IEEE-rounded (llvm.sqrt.f32 under -fhip-fp32-correctly-rounded-divide-sqrt)
+    const unsigned tb = (unsigned)((x & lad.ctmask) * lad.cv + (x >> lad.log2ct));
+    const u64 key = ((u64)__float_as_uint(d) << 32) | tb;
+    if (key < st.keys[KMAX - 1]) {
+      st.keys[KMAX - 1] = key;
+#pragma unroll
+      for (int i = KMAX - 1; i > 0; --i) {
+        const u64 a = st.keys[i - 1], b = st.keys[i];
+        const bool lt = b < a;
+        st.keys[i - 1] = lt ? b : a;
+        st.keys[i] = lt ? a : b;
+      }
+      const unsigned hb = (unsigned)(st.keys[KMAX - 1] >> 32);
+      if (hb <= 0x7f800000u) {
+        const float dk = __uint_as_float(hb);
+        // (1+2^-20)-inflated square of the K-th distance: any s above it has sqrt(s) > d_K.
+        st.bound = __fmul_rn(__fmul_rn(dk, dk), 1.000001f);
+      }
+    }
+  }
 }
 
 // XYZ_LAYOUT: false = positions [B,3,N] (op layout), true = xyz [B,N,3].
@@ -62,7 +106,8 @@ __global__ __launch_bounds__(kQueriesPerBlock) void knn_kernel(const float *__re
                                                               int K, KnnLadder lad,
                                                               int32_t *__restrict__ nn,
                                                               float *__restrict__ dist) {
-  __shared__ float4 s_c[kChunk];
+  __shared__ __attribute__((aligned(16))) float s_c[kChunk * 3];
+  __shared__ uint2 s_q[kQueue * kQueriesPerBlock];
   const int b = blockIdx.y;
   const int tid = threadIdx.x;
   const int y = blockIdx.x * kQueriesPerBlock + tid;
@@ -73,55 +118,85 @@ __global__ __launch_bounds__(kQueriesPerBlock) void knn_kernel(const float *__re
     if (XYZ_LAYOUT) { qx = pc[(size_t)y * 3]; qy = pc[(size_t)y * 3 + 1]; qz = pc[(size_t)y * 3 + 2]; }
     else { qx = pc[y]; qy = pc[(size_t)N + y]; qz = pc[(size_t)2 * N + y]; }
   }
+  const f32x2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
 
-  float bd[KMAX];
-  int bt[KMAX];
+  KnnState<KMAX> st;
 #pragma unroll
-  for (int i = 0; i < KMAX; ++i) { bd[i] = INFINITY; bt[i] = INT_MAX; }
-  float bound = INFINITY;  // s > bound  =>  sqrt(s) > bd[KMAX-1]
+  for (int i = 0; i < KMAX; ++i) st.keys[i] = ~0ull;
+  st.bound = INFINITY;
+  int cnt = 0;
 
   for (int base = 0; base < N; base += kChunk) {
     const int len = min(kChunk, N - base);
+    const int len8 = (len + 7) & ~7;
     __syncthreads();
     if (XYZ_LAYOUT) {
-      for (int e = tid; e < len * 3; e += kQueriesPerBlock) {
-        float v = pc[(size_t)base * 3 + e];
-        reinterpret_cast<float *>(s_c)[(e / 3) * 4 + (e % 3)] = v;
+      for (int e = tid; e < len8 * 3; e += kQueriesPerBlock) {
+        const int c = e / 3, comp = e - c * 3;
+        s_c[cand_slot(c, comp)] = c < len ? pc[(size_t)base * 3 + e] : INFINITY;
       }
     } else {
-      for (int e = tid; e < len; e += kQueriesPerBlock) {
-        s_c[e] = make_float4(pc[base + e], pc[(size_t)N + base + e], pc[(size_t)2 * N + base + e], 0.f);
+      for (int e = tid; e < len8 * 3; e += kQueriesPerBlock) {
+        const int comp = e / len8, c = e - comp * len8;
+        s_c[cand_slot(c, comp)] = c < len ? pc[(size_t)comp * N + base + c] : INFINITY;
       }
     }
     __syncthreads();
     if (y < N) {
-#pragma unroll 8
-      for (int j = 0; j < len; ++j) {
-        const float4 c = s_c[j];
-        const float dx = c.x - qx, dy = c.y - qy, dz = c.z - qz;
-        const float s = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
-        if (s <= bound) {
-          const float d = sqrtf(s);  // IEEE-rounded (llvm.sqrt.f32; -fhip-fp32-correctly-rounded-divide-sqrt default)
-          const int x = base + j;
-          const int tb = (x & lad.ctmask) * lad.cv + (x >> lad.log2ct);
-          if (knn_less(d, tb, bd[KMAX - 1], bt[KMAX - 1])) {
-            bd[KMAX - 1] = d;
-            bt[KMAX - 1] = tb;
+      for (int j = 0; j < len8; j += 8) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(s_c + (j >> 2) * 12);
+        const f32x4 a1 = *reinterpret_cast<const f32x4 *>(s_c + (j >> 2) * 12 + 4);
+        const f32x4 a2 = *reinterpret_cast<const f32x4 *>(s_c + (j >> 2) * 12 + 8);
+        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(s_c + (j >> 2) * 12 + 12);
+        const f32x4 b1 = *reinterpret_cast<const f32x4 *>(s_c + (j >> 2) * 12 + 16);
+        const f32x4 b2 = *reinterpret_cast<const f32x4 *>(s_c + (j >> 2) * 12 + 20);
+        f32x2 s[4];
+        {
+          const f32x2 dx = f32x2{a0[0], a0[1]} - qx2, dy = f32x2{a0[2], a0[3]} - qy2, dz = f32x2{a1[0], a1[1]} - qz2;
+          s[0] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+        }
+        {
+          const f32x2 dx = f32x2{a1[2], a1[3]} - qx2, dy = f32x2{a2[0], a2[1]} - qy2, dz = f32x2{a2[2], a2[3]} - qz2;
+          s[1] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+        }
+        {
+          const f32x2 dx = f32x2{b0[0], b0[1]} - qx2, dy = f32x2{b0[2], b0[3]} - qy2, dz = f32x2{b1[0], b1[1]} - qz2;
+          s[2] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+        }
+        {
+          const f32x2 dx = f32x2{b1[2], b1[3]} - qx2, dy = f32x2{b2[0], b2[1]} - qy2, dz = f32x2{b2[2], b2[3]} - qz2;
+          s[3] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+        }
+        const float m = fminf(fminf(fminf(s[0][0], s[0][1]), fminf(s[1][0], s[1][1])),
+                              fminf(fminf(s[2][0], s[2][1]), fminf(s[3][0], s[3][1])));
+        if (m <= st.bound) {
 #pragma unroll
-            for (int i = KMAX - 1; i > 0; --i) {
-              const bool lt = knn_less(bd[i], bt[i], bd[i - 1], bt[i - 1]);
-              const float d_hi = lt ? bd[i - 1] : bd[i];
-              const float d_lo = lt ? bd[i] : bd[i - 1];
-              const int t_hi = lt ? bt[i - 1] : bt[i];
-              const int t_lo = lt ? bt[i] : bt[i - 1];
-              bd[i] = d_hi; bd[i - 1] = d_lo;
-              bt[i] = t_hi; bt[i - 1] = t_lo;
+          for (int t = 0; t < 8; ++t) {
+            const float sv = s[t >> 1][t & 1];
+            const int x = base + j + t;
+            if (sv <= st.bound && x < N) {
+              s_q[cnt * kQueriesPerBlock + tid] = make_uint2(__float_as_uint(sv), (unsigned)x);
+              ++cnt;
             }
-            // (1+2^-20)-inflated square of the K-th distance: any s above it has sqrt(s) > bd[K-1].
-            bound = __fmul_rn(__fmul_rn(bd[KMAX - 1], bd[KMAX - 1]), 1.000001f);
           }
         }
+        if (__any(cnt > kQueue - 8)) {  // wave-uniform: drain every lane's queue
+          for (int i = 0; i < kQueue; ++i) {
+            if (!__any(i < cnt)) break;
+            if (i < cnt) {
+              const uint2 e = s_q[i * kQueriesPerBlock + tid];
+              knn_offer<KMAX>(st, __uint_as_float(e.x), (int)e.y, lad);
+            }
+          }
+          cnt = 0;
+        }
       }
+    }
+  }
+  for (int i = 0; i < kQueue; ++i) {  // final drain
+    if (i < cnt) {
+      const uint2 e = s_q[i * kQueriesPerBlock + tid];
+      knn_offer<KMAX>(st, __uint_as_float(e.x), (int)e.y, lad);
     }
   }
 
@@ -131,13 +206,13 @@ __global__ __launch_bounds__(kQueriesPerBlock) void knn_kernel(const float *__re
 #pragma unroll
     for (int i = 0; i < KMAX; ++i) {
       if (i < K) {
-        const int tb = bt[i];
-        if (tb == INT_MAX) {  // fewer than K points: reference pads with id -1 / FLT_MAX (:110-111)
+        const unsigned tb = (unsigned)st.keys[i];
+        if (st.keys[i] == ~0ull) {  // fewer than K points: reference pads with id -1 / FLT_MAX (:110-111)
           o_nn[i] = -1;
           o_d[i] = FLT_MAX;
         } else {
-          o_nn[i] = ((tb % lad.cv) << lad.log2ct) + tb / lad.cv;
-          o_d[i] = bd[i];
+          o_nn[i] = (int)(((tb % (unsigned)lad.cv) << lad.log2ct) + tb / (unsigned)lad.cv);
+          o_d[i] = __uint_as_float((unsigned)(st.keys[i] >> 32));
         }
       }
     }
