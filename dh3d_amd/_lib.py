@@ -50,6 +50,9 @@ _SIGNATURES = {
     "dh3d_three_nn": [c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp],
     "dh3d_three_interpolate_fwd": [c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp],
     "dh3d_three_interpolate_bwd": [c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp],
+    "dh3d_spatial_sort": [c_fp, c_int, c_int, c_fp, c_fp, c_fp],
+    "dh3d_knn_sorted": [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp],
+    "dh3d_fps_sorted": [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp],
     "dh3d_pack_weight": [c_fp, c_int, c_int, c_fp, c_fp],
     "dh3d_pack_flex_weight": [c_fp, c_fp, c_int, c_int, c_fp, c_fp],
     "dh3d_flex_conv_pm_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int,

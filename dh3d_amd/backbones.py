@@ -145,6 +145,12 @@ class Geometry(object):
         self.knn_num = knn_num
         self.nbr = nbr          # [B,N,K] int32
         self.levels = {}        # dilate -> dict(idx, xyz_s, nbr_s, nn3_dist, nn3_idx)
+        self.sorted = None      # (records [B,N,4], gbox) from pm.spatial_sort, shared by kNN and FPS
+
+    def ordered(self):
+        if self.sorted is None:
+            self.sorted = pm.spatial_sort(self.xyz)
+        return self.sorted
 
     def level(self, dilate, knn):
         key = (dilate, knn)
@@ -166,14 +172,19 @@ def gather_rows(points, idx):
 
 
 def compute_level(xyz, dilate, knn):
-    """FPS -> gather xyz -> kNN on the sampled set -> three_nn back to the full set."""
+    """FPS -> gather xyz -> kNN on the sampled set -> three_nn back to the full set.
+
+    FPS runs on the raw cloud: the ordered variant (pm.fps_sorted) measured no faster on MI355X -- the round
+    is bound by its dependent reduce/barrier chain, not by the distance updates the ordering prunes -- and
+    the raw kernel needs no sort in front of it, so the side stream can start at t = 0."""
     B, N, _ = xyz.shape
     npoint = N // dilate
     idx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
     L.check(L.lib().dh3d_farthest_point_sample(B, N, npoint, L.ptr(xyz), None, L.ptr(idx), L.stream_ptr()),
             "farthest_point_sample")
     xyz_s = gather_rows(xyz, idx)
-    nbr_s, _ = pm.knn_xyz(xyz_s, knn)
+    srt_s, gbox_s = pm.spatial_sort(xyz_s)
+    nbr_s, _ = pm.knn_sorted(srt_s, gbox_s, knn)
     d3 = torch.empty((B, N, 3), dtype=torch.float32, device=xyz.device)
     i3 = torch.empty((B, N, 3), dtype=torch.int32, device=xyz.device)
     L.check(L.lib().dh3d_three_nn(B, N, npoint, L.ptr(xyz), L.ptr(xyz_s), L.ptr(d3), L.ptr(i3), L.stream_ptr()),

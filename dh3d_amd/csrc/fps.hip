@@ -28,8 +28,13 @@ namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kThreads = 1024;
-constexpr int kWaves = kThreads / 64;
+
+#ifdef DH3D_FPS_PROBE  // dev instrumentation: cycle stamps of one round of wave 0 (tools/fps_probe.py)
+__device__ long long g_probe[16];
+#define PROBE(i) do { if (r == 300 && tid == 0 && blockIdx.x == 0) g_probe[i] = clock64(); } while (0)
+#else
+#define PROBE(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ int fps_key(int k) { return ((k & 511) << 16) | (k >> 9); }
 __device__ __forceinline__ int fps_unkey(int key) { return ((key & 0xffff) << 9) | (key >> 16); }
@@ -47,16 +52,19 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) {
   return r;
 }
 
-template <int PPT, bool LDS_COORDS>
-__global__ __launch_bounds__(kThreads) void fps_kernel(const float *__restrict__ xyz, int N, int m,
-                                                      int32_t *__restrict__ out) {
+template <int PPT, int WAVES, bool LDS_COORDS>
+__global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float *__restrict__ xyz, int N, int m,
+                                                       int32_t *__restrict__ out) {
+  constexpr int T = 64 * WAVES;
   extern __shared__ __attribute__((aligned(16))) float s_mem[];
-  // layout: [2][kWaves] vals | [2][kWaves] keys | (LDS_COORDS) x[N] y[N] z[N]
+  // layout: [2][WAVES] vals | [2][WAVES] keys | (LDS_COORDS) x[N] y[N] z[N] picks[m]
   float *s_val = s_mem;
-  int *s_key = reinterpret_cast<int *>(s_mem + 2 * kWaves);
-  float *s_x = s_mem + 4 * kWaves;
+  int *s_key = reinterpret_cast<int *>(s_mem + 2 * WAVES);
+  float *s_x = s_mem + 4 * WAVES;
   float *s_y = s_x + N;
   float *s_z = s_y + N;
+  int *s_out = reinterpret_cast<int *>(s_z + N);  // picks are buffered here: a global store per round would
+                                                  // put its write latency (vmcnt(0) before the barrier) on the chain
 
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
@@ -64,15 +72,12 @@ __global__ __launch_bounds__(kThreads) void fps_kernel(const float *__restrict__
   const int wave = tid >> 6;
   const float *pc = xyz + (size_t)b * N * 3;
 
-  // Lane t owns k_j = (t & 511) + 512*(2j + (t >> 9)): keys increase with j, so a strict '>' scan
-  // over j keeps the smallest key among equal values.  Points are held as pairs (j = 2p, 2p+1).
+  // Lane t owns k_j = t + T*j, held as pairs (j = 2p, 2p+1).  Ties are broken on key(k) explicitly.
   constexpr int NP = (PPT + 1) / 2;
   f32x2 px[NP], py[NP], pz[NP], md[NP];
-  const int k0 = (tid & 511) + 512 * (tid >> 9);
-  const int key0 = fps_key(k0);
 #pragma unroll
   for (int j = 0; j < 2 * NP; ++j) {
-    const int k = k0 + 1024 * j;
+    const int k = tid + T * j;
     float x = 0.f, y = 0.f, z = 0.f, d = -2.f;  // -2: below the reference's initial best = -1, never picked
     if (j < PPT && k < N) {
       x = pc[(size_t)k * 3]; y = pc[(size_t)k * 3 + 1]; z = pc[(size_t)k * 3 + 2];
@@ -81,17 +86,21 @@ __global__ __launch_bounds__(kThreads) void fps_kernel(const float *__restrict__
     }
     px[j >> 1][j & 1] = x; py[j >> 1][j & 1] = y; pz[j >> 1][j & 1] = z; md[j >> 1][j & 1] = d;
   }
-  if (tid == 0) out[(size_t)b * m] = 0;
+  if (tid == 0) { if (LDS_COORDS) s_out[0] = 0; else out[(size_t)b * m] = 0; }
   __syncthreads();
 
   int old = 0;
   int buf = 0;
   for (int r = 1; r < m; ++r) {
+    PROBE(0);
     float x1, y1, z1;
     if (LDS_COORDS) { x1 = s_x[old]; y1 = s_y[old]; z1 = s_z[old]; }
     else { x1 = pc[(size_t)old * 3]; y1 = pc[(size_t)old * 3 + 1]; z1 = pc[(size_t)old * 3 + 2]; }
     const f32x2 x2 = {x1, x1}, y2 = {y1, y1}, z2 = {z1, z1};
-
+#ifdef DH3D_FPS_PROBE
+    asm volatile("" :: "v"(x1), "v"(y1), "v"(z1));
+#endif
+    PROBE(1);
     // running min-distance update (two points per packed op) + the lane's best VALUE only
     float best = -1.f;
 #pragma unroll
@@ -102,47 +111,180 @@ __global__ __launch_bounds__(kThreads) void fps_kernel(const float *__restrict__
       md[p][1] = vmin(d[1], md[p][1]);
       best = vmax3(best, md[p][0], md[p][1]);
     }
+    PROBE(2);
     const float wmax = wave_max_f32(best);
-    // key of the lane's first point holding wmax: key(k0 + 1024 j) = key(k0) + 2 j  (scan j downwards)
-    int jmin = 0;
+    PROBE(3);
+    // smallest key among the lane's points that hold wmax
+    int lkey = INT_MAX;
 #pragma unroll
-    for (int j = 2 * NP - 1; j >= 0; --j) jmin = (md[j >> 1][j & 1] == wmax) ? j : jmin;
-    const int lkey = key0 + 2 * jmin;
+    for (int j = 0; j < 2 * NP; ++j) {
+      const int kj = fps_key(tid + T * j);
+      lkey = (md[j >> 1][j & 1] == wmax) ? min(lkey, kj) : lkey;
+    }
     const unsigned long long hit = __ballot(best == wmax);
     int wkey;
     if (__popcll(hit) == 1) wkey = __builtin_amdgcn_readlane(lkey, __builtin_ctzll(hit));
-    else wkey = wave_min_i32(best == wmax ? lkey : INT_MAX);  // several lanes tie: smallest key wins
-    if (lane == 0) { s_val[buf * kWaves + wave] = wmax; s_key[buf * kWaves + wave] = wkey; }
+    else wkey = wave_min_i32(lkey);  // several lanes tie: smallest key wins (non-hit lanes hold INT_MAX)
+    PROBE(4);
+    if (lane == 0) { s_val[buf * WAVES + wave] = wmax; s_key[buf * WAVES + wave] = wkey; }
     __syncthreads();
-    // every wave re-derives the block winner from the 16 partials (lanes 0..15 hold one each)
-    const float v = s_val[buf * kWaves + (lane & (kWaves - 1))];
-    const int kk = s_key[buf * kWaves + (lane & (kWaves - 1))];
+    PROBE(5);
+    // every wave re-derives the block winner from the WAVES partials (replicated along each 16-lane row)
+    const float v = s_val[buf * WAVES + (lane & (WAVES - 1))];
+    const int kk = s_key[buf * WAVES + (lane & (WAVES - 1))];
     const float bmax = row16_max_f32(v);
-    const unsigned long long hit2 = __ballot(v == bmax) & 0xffffull;
+    const unsigned long long hit2 = __ballot(v == bmax) & ((1ull << WAVES) - 1);
     int bkey;
     if (__popcll(hit2) == 1) bkey = __builtin_amdgcn_readlane(kk, __builtin_ctzll(hit2));
     else bkey = __builtin_amdgcn_readfirstlane(row16_min_i32(v == bmax ? kk : INT_MAX));
     old = fps_unkey(bkey);
-    if (tid == 0) out[(size_t)b * m + r] = old;
+    PROBE(6);
+    if (tid == 0) { if (LDS_COORDS) s_out[r] = old; else out[(size_t)b * m + r] = old; }
     buf ^= 1;
+  }
+  if (LDS_COORDS) {
+    __syncthreads();
+    for (int r = tid; r < m; r += T) out[(size_t)b * m + r] = s_out[r];
   }
 }
 
-template <int PPT>
+// ------------------------------------------------------------------------------------------------
+// FPS on a spatially ordered cloud (spatial.hip).  Same results, less work per round: lane l of wave w
+// holds one point of each of the groups w, w+16, w+32, ... (64 Morton-consecutive points each).  A
+// group's running min-distances can only change if the new sample is closer to the group's bounding box
+// than the group's current maximum, so per round a wave
+//   1. tests its PPT boxes in parallel (lane j <-> group j; 12 VALU ops + one ballot),
+//   2. re-evaluates only the hit groups (1 point per lane) and refreshes that group's cached
+//      (max, key) with one DPP wave reduction,
+//   3. reduces the PPT cached (max, key) pairs with a 16-lane DPP row reduction.
+// After the first few dozen samples a round touches a handful of the N/64 groups instead of all N points.
+// The skip test carries a 1e-5 relative margin: it may keep a group that cannot change, never the reverse.
+template <int PPT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void fps_sorted_kernel(const float4 *__restrict__ sorted,
+                                                              const float *__restrict__ gbox, int N, int m,
+                                                              int32_t *__restrict__ out) {
+  static_assert(PPT <= 64 && WAVES <= 16, "one lane per group box");
+  extern __shared__ __attribute__((aligned(16))) float s_mem[];
+  float *s_val = s_mem;
+  int *s_key = reinterpret_cast<int *>(s_mem + 2 * WAVES);
+  float *s_x = s_mem + 4 * WAVES;  // coordinates by ORIGINAL index
+  float *s_y = s_x + N;
+  float *s_z = s_y + N;
+  int *s_out = reinterpret_cast<int *>(s_z + N);  // picks, written to global memory once at the end
+
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NG = (N + 63) / 64;
+  const float4 *sc = sorted + (size_t)b * N;
+
+  float px[PPT], py[PPT], pz[PPT], md[PPT];
+  int pkey[PPT];
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    const int i = (wave + WAVES * j) * 64 + lane;
+    px[j] = py[j] = pz[j] = 0.f;
+    md[j] = -2.f;  // padding: below the reference's initial best = -1, never picked
+    pkey[j] = INT_MAX;
+    if (i < N) {
+      const float4 r = sc[i];
+      const int k = __float_as_int(r.w);
+      px[j] = r.x; py[j] = r.y; pz[j] = r.z;
+      md[j] = 1e38f;
+      pkey[j] = fps_key(k);
+      s_x[k] = r.x; s_y[k] = r.y; s_z[k] = r.z;
+    }
+  }
+  // lane j < PPT: box and cached (max, key) of this wave's group j
+  float blx = INFINITY, bly = INFINITY, blz = INFINITY, bhx = -INFINITY, bhy = -INFINITY, bhz = -INFINITY;
+  float gmax = -2.f;
+  int gkey = INT_MAX;
+  if (lane < PPT) {
+    const int g = wave + WAVES * lane;
+    if (g < NG) {
+      const float *bx = gbox + ((size_t)b * NG + g) * 8;
+      blx = bx[0]; bly = bx[1]; blz = bx[2]; bhx = bx[4]; bhy = bx[5]; bhz = bx[6];
+      gmax = 1e38f;
+    }
+  }
+  if (tid == 0) s_out[0] = 0;
+  __syncthreads();
+
+  int old = 0;
+  int buf = 0;
+  for (int r = 1; r < m; ++r) {
+    const float x1 = s_x[old], y1 = s_y[old], z1 = s_z[old];
+    // 1. which of my groups can change?  squared distance from the sample to each box (0 inside)
+    const float ex = fmaxf(fmaxf(blx - x1, x1 - bhx), 0.f);
+    const float ey = fmaxf(fmaxf(bly - y1, y1 - bhy), 0.f);
+    const float ez = fmaxf(fmaxf(blz - z1, z1 - bhz), 0.f);
+    const float bd = (ex * ex + ey * ey + ez * ez) * 0.99999f;
+    const unsigned long long need = __ballot(lane < PPT && bd <= gmax);
+    // 2. refresh the hit groups
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      if ((need >> j) & 1ull) {  // wave-uniform
+        const float dx = px[j] - x1, dy = py[j] - y1, dz = pz[j] - z1;
+        const float d = __fmaf_rn(dz, dz, __fmaf_rn(dx, dx, __fmul_rn(dy, dy)));
+        md[j] = vmin(d, md[j]);
+        const float gm = wave_max_f32(md[j]);
+        const unsigned long long hit = __ballot(md[j] == gm);
+        int gk;
+        if (__popcll(hit) == 1) gk = __builtin_amdgcn_readlane(pkey[j], __builtin_ctzll(hit));
+        else gk = wave_min_i32(md[j] == gm ? pkey[j] : INT_MAX);
+        if (lane == j) { gmax = gm; gkey = gk; }
+      }
+    }
+    // 3. wave winner over the cached groups (lanes 0..PPT-1; other lanes hold -2 / INT_MAX)
+    const float wmax = wave_max_f32(gmax);
+    const unsigned long long hitw = __ballot(gmax == wmax);
+    int wkey;
+    if (__popcll(hitw) == 1) wkey = __builtin_amdgcn_readlane(gkey, __builtin_ctzll(hitw));
+    else wkey = wave_min_i32(gmax == wmax ? gkey : INT_MAX);
+    if (lane == 0) { s_val[buf * WAVES + wave] = wmax; s_key[buf * WAVES + wave] = wkey; }
+    __syncthreads();
+    const float v = s_val[buf * WAVES + (lane & (WAVES - 1))];
+    const int kk = s_key[buf * WAVES + (lane & (WAVES - 1))];
+    const float bmax = row16_max_f32(v);
+    const unsigned long long hit2 = __ballot(v == bmax) & ((1ull << WAVES) - 1);
+    int bkey;
+    if (__popcll(hit2) == 1) bkey = __builtin_amdgcn_readlane(kk, __builtin_ctzll(hit2));
+    else bkey = __builtin_amdgcn_readfirstlane(row16_min_i32(v == bmax ? kk : INT_MAX));
+    old = fps_unkey(bkey);
+    if (tid == 0) s_out[r] = old;
+    buf ^= 1;
+  }
+  __syncthreads();
+  for (int r = tid; r < m; r += 64 * WAVES) out[(size_t)b * m + r] = s_out[r];
+}
+
+template <int PPT, int WAVES>
+int fps_sorted_launch(const float *sorted, const float *gbox, int B, int N, int m, int32_t *out, hipStream_t s) {
+  const size_t lds = sizeof(float) * (4 * WAVES + (size_t)3 * N + m);
+  if (lds > 159 * 1024) return DH3D_ERR_UNSUPPORTED;
+  DH3D_ALLOW_BIG_LDS((fps_sorted_kernel<PPT, WAVES>));
+  hipLaunchKernelGGL((fps_sorted_kernel<PPT, WAVES>), dim3(B), dim3(64 * WAVES), lds, s,
+                     reinterpret_cast<const float4 *>(sorted), gbox, N, m, out);
+  return dh3d_launch_status();
+}
+
+template <int PPT, int WAVES>
 int fps_launch(const float *xyz, int B, int N, int m, int32_t *out, hipStream_t s) {
-  const size_t red = sizeof(float) * 4 * kWaves;
-  const bool lds_coords = (size_t)N * 12 + red <= 128 * 1024;
+  const size_t red = sizeof(float) * 4 * WAVES;
+  const bool lds_coords = (size_t)N * 12 + (size_t)m * 4 + red <= 159 * 1024;
   if (lds_coords) {
-    DH3D_ALLOW_BIG_LDS((fps_kernel<PPT, true>));
-    hipLaunchKernelGGL((fps_kernel<PPT, true>), dim3(B), dim3(kThreads), red + (size_t)N * 12, s, xyz, N,
-                       m, out);
+    DH3D_ALLOW_BIG_LDS((fps_kernel<PPT, WAVES, true>));
+    hipLaunchKernelGGL((fps_kernel<PPT, WAVES, true>), dim3(B), dim3(64 * WAVES),
+                       red + (size_t)N * 12 + (size_t)m * 4, s, xyz, N, m, out);
   } else {
-    hipLaunchKernelGGL((fps_kernel<PPT, false>), dim3(B), dim3(kThreads), red, s, xyz, N, m, out);
+    hipLaunchKernelGGL((fps_kernel<PPT, WAVES, false>), dim3(B), dim3(64 * WAVES), red, s, xyz, N, m, out);
   }
   return dh3d_launch_status();
 }
 
 }  // namespace
+
+// Dev knob (tools/geo_bench.py): waves per cloud; 0 = default.
+static int g_fps_waves = 0;
+DH3D_API void dh3d_dev_set_fps_waves(int w) { g_fps_waves = w; }
 
 DH3D_API int dh3d_farthest_point_sample(int B, int N, int m, const float *inp, float *temp,
                                         int32_t *out, void *stream) {
@@ -150,9 +292,52 @@ DH3D_API int dh3d_farthest_point_sample(int B, int N, int m, const float *inp, f
   DH3D_REQUIRE(inp && out && B > 0 && N > 0 && m > 0);  // tf_sampling.cpp:100,105
   DH3D_SUPPORTED(N <= 16384);
   hipStream_t s = (hipStream_t)stream;
-  if (N <= 1024) return fps_launch<1>(inp, B, N, m, out, s);
-  if (N <= 2048) return fps_launch<2>(inp, B, N, m, out, s);
-  if (N <= 4096) return fps_launch<4>(inp, B, N, m, out, s);
-  if (N <= 8192) return fps_launch<8>(inp, B, N, m, out, s);
-  return fps_launch<16>(inp, B, N, m, out, s);
+  const int W = g_fps_waves ? g_fps_waves : (N <= 1024 ? 4 : 8);  // measured best on MI355X (tools/geo_bench.py)
+#define DH3D_FPS_CASE(WV)                                                              \
+  if (W == WV) {                                                                       \
+    const int per = 64 * WV;                                                           \
+    if (N <= per * 2) return fps_launch<2, WV>(inp, B, N, m, out, s);                  \
+    if (N <= per * 4) return fps_launch<4, WV>(inp, B, N, m, out, s);                  \
+    if (N <= per * 8) return fps_launch<8, WV>(inp, B, N, m, out, s);                  \
+    if (N <= per * 16) return fps_launch<16, WV>(inp, B, N, m, out, s);                \
+    if (N <= per * 32) return fps_launch<32, WV>(inp, B, N, m, out, s);                \
+    if (N <= per * 64) return fps_launch<64, WV>(inp, B, N, m, out, s);                \
+  }
+  DH3D_FPS_CASE(4)
+  DH3D_FPS_CASE(8)
+  DH3D_FPS_CASE(16)
+#undef DH3D_FPS_CASE
+  return DH3D_ERR_UNSUPPORTED;
 }
+
+// Dev knob (tools/geo_bench.py): waves per cloud for the ordered kernel; 0 = default.
+static int g_fps_sorted_waves = 0;
+DH3D_API void dh3d_dev_set_fps_sorted_waves(int w) { g_fps_sorted_waves = w; }
+
+DH3D_API int dh3d_fps_sorted(const float *sorted, const float *gbox, int B, int N, int m, int32_t *out,
+                             void *stream) {
+  DH3D_REQUIRE(sorted && gbox && out && B > 0 && N > 0 && m > 0);
+  DH3D_SUPPORTED(N <= 12288);  // the by-original-index coordinate table must fit LDS (12 B / point)
+  hipStream_t s = (hipStream_t)stream;
+  const int W = g_fps_sorted_waves ? g_fps_sorted_waves : 16;
+#define DH3D_FPS_CASE(WV)                                                                       \
+  if (W == WV) {                                                                                \
+    const int per = 64 * WV;                                                                    \
+    if (N <= per * 4) return fps_sorted_launch<4, WV>(sorted, gbox, B, N, m, out, s);           \
+    if (N <= per * 8) return fps_sorted_launch<8, WV>(sorted, gbox, B, N, m, out, s);           \
+    if (N <= per * 16) return fps_sorted_launch<16, WV>(sorted, gbox, B, N, m, out, s);         \
+    if (N <= per * 32) return fps_sorted_launch<32, WV>(sorted, gbox, B, N, m, out, s);         \
+    if (N <= per * 64) return fps_sorted_launch<64, WV>(sorted, gbox, B, N, m, out, s);         \
+  }
+  DH3D_FPS_CASE(4)
+  DH3D_FPS_CASE(8)
+  DH3D_FPS_CASE(16)
+#undef DH3D_FPS_CASE
+  return DH3D_ERR_UNSUPPORTED;
+}
+
+#ifdef DH3D_FPS_PROBE
+DH3D_API int dh3d_fps_probe_read(long long *host16) {
+  return hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_probe), sizeof(long long) * 16) == hipSuccess ? 0 : 3;
+}
+#endif

@@ -23,6 +23,7 @@
 #include <limits.h>
 
 #include "common.h"
+#include "wave_ops.h"
 
 #pragma clang fp contract(off)
 
@@ -219,6 +220,175 @@ __global__ __launch_bounds__(kQueriesPerBlock) void knn_kernel(const float *__re
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// kNN on a spatially ordered cloud (spatial.hip).  Still exhaustive in effect -- every candidate is either
+// evaluated or PROVEN unable to enter any list of the wave -- but most of the N^2 work disappears:
+// a wave owns one group of 64 Morton-consecutive queries and walks the candidate groups nearest-first
+// (g, g+1, g-1, g+2, ...).  A candidate group is skipped when the squared distance between the two
+// bounding boxes exceeds every lane's current screening bound (which already over-estimates the K-th
+// distance); the 1e-5 relative margin on the box distance dwarfs the rounding of the f32 distance chain,
+// so a skipped candidate would also have failed the per-candidate screen.  Evaluated groups go through
+// exactly the same screen / queue / 64-bit-key insertion as knn_kernel, so ids and distances are
+// bit-identical to it (tests).  Waves are independent: no block-level barrier.
+constexpr int kSortedWaves = 4;
+
+template <int KMAX>
+__global__ __launch_bounds__(64 * kSortedWaves) void knn_sorted_kernel(const float4 *__restrict__ sorted,
+                                                                    const float *__restrict__ gbox, int N,
+                                                                    int K, KnnLadder lad,
+                                                                    int32_t *__restrict__ nn,
+                                                                    float *__restrict__ dist) {
+  __shared__ __attribute__((aligned(16))) float s_c[kSortedWaves][64 * 3];  // pair-SoA image per wave
+  __shared__ uint2 s_q[kSortedWaves][kQueue * 64];
+  __shared__ int s_id[kSortedWaves][64];  // original ids of the staged candidates
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int NG = (N + 63) / 64;
+  const int g = blockIdx.x * kSortedWaves + wave;
+  if (g >= NG) return;  // whole wave
+  const float4 *sc = sorted + (size_t)b * N;
+  const float4 *gb = reinterpret_cast<const float4 *>(gbox) + (size_t)b * NG * 2;  // [lo.xyz,_ | hi.xyz,_]
+  float *my_c = s_c[wave];
+  uint2 *my_q = s_q[wave];
+  int *my_id = s_id[wave];
+
+  const int qi = g * 64 + lane;
+  const bool valid = qi < N;
+  const float4 pad = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(-1));
+  float4 qr = valid ? sc[qi] : pad;
+  const f32x2 qx2 = {qr.x, qr.x}, qy2 = {qr.y, qr.y}, qz2 = {qr.z, qr.z};
+  const float4 qlo = gb[g * 2], qhi = gb[g * 2 + 1];
+
+  KnnState<KMAX> st;
+#pragma unroll
+  for (int i = 0; i < KMAX; ++i) st.keys[i] = ~0ull;
+  st.bound = INFINITY;
+  int cnt = 0;
+  float wave_bound = INFINITY;  // max over the wave's valid lanes of st.bound (refreshed after each drain)
+
+  auto drain = [&]() {
+    for (int i = 0; i < kQueue; ++i) {
+      if (!__any(i < cnt)) break;
+      if (i < cnt) {
+        const uint2 e = my_q[i * 64 + lane];
+        knn_offer<KMAX>(st, __uint_as_float(e.x), (int)e.y, lad);
+      }
+    }
+    cnt = 0;
+    wave_bound = wave_max_f32(valid ? st.bound : 0.f);
+  };
+
+  // evaluate the 64 candidates of group gcc (records already in `cr`, one per lane)
+  auto scan_group = [&](int gcc, const float4 cr) {
+    my_c[cand_slot(lane, 0)] = cr.x;
+    my_c[cand_slot(lane, 1)] = cr.y;
+    my_c[cand_slot(lane, 2)] = cr.z;
+    my_id[lane] = __float_as_int(cr.w);
+    __builtin_amdgcn_wave_barrier();
+    const int clen = min(64, N - gcc * 64);
+    for (int j = 0; j < clen; j += 8) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4 *>(my_c + (j >> 2) * 12);
+      const f32x4 a1 = *reinterpret_cast<const f32x4 *>(my_c + (j >> 2) * 12 + 4);
+      const f32x4 a2 = *reinterpret_cast<const f32x4 *>(my_c + (j >> 2) * 12 + 8);
+      const f32x4 b0 = *reinterpret_cast<const f32x4 *>(my_c + (j >> 2) * 12 + 12);
+      const f32x4 b1 = *reinterpret_cast<const f32x4 *>(my_c + (j >> 2) * 12 + 16);
+      const f32x4 b2 = *reinterpret_cast<const f32x4 *>(my_c + (j >> 2) * 12 + 20);
+      f32x2 s[4];
+      {
+        const f32x2 dx = f32x2{a0[0], a0[1]} - qx2, dy = f32x2{a0[2], a0[3]} - qy2, dz = f32x2{a1[0], a1[1]} - qz2;
+        s[0] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+      }
+      {
+        const f32x2 dx = f32x2{a1[2], a1[3]} - qx2, dy = f32x2{a2[0], a2[1]} - qy2, dz = f32x2{a2[2], a2[3]} - qz2;
+        s[1] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+      }
+      {
+        const f32x2 dx = f32x2{b0[0], b0[1]} - qx2, dy = f32x2{b0[2], b0[3]} - qy2, dz = f32x2{b1[0], b1[1]} - qz2;
+        s[2] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+      }
+      {
+        const f32x2 dx = f32x2{b1[2], b1[3]} - qx2, dy = f32x2{b2[0], b2[1]} - qy2, dz = f32x2{b2[2], b2[3]} - qz2;
+        s[3] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+      }
+      const float mn = fminf(fminf(fminf(s[0][0], s[0][1]), fminf(s[1][0], s[1][1])),
+                             fminf(fminf(s[2][0], s[2][1]), fminf(s[3][0], s[3][1])));
+      if (valid && mn <= st.bound) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const float sv = s[t >> 1][t & 1];
+          if (sv <= st.bound && j + t < clen) {
+            my_q[cnt * 64 + lane] = make_uint2(__float_as_uint(sv), (unsigned)my_id[j + t]);
+            ++cnt;
+          }
+        }
+      }
+      if (__any(cnt > kQueue - 8)) drain();
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto load_group = [&](int gcc) { const int ci = gcc * 64 + lane; return ci < N ? sc[ci] : pad; };
+
+  // own group first: it fills every list and gives the first finite bounds
+  scan_group(g, qr);
+  if (__any(cnt > 0)) drain();
+
+  // other groups: lane <-> candidate group box test (64 groups per round), overlapping boxes (distance 0)
+  // first, then whatever still lies within the (tightened) bound; next group's records are prefetched.
+  for (int tier = 0; tier < 2; ++tier) {
+    for (int c0 = 0; c0 < NG; c0 += 64) {
+      const int gi = c0 + lane;
+      const bool other = gi < NG && gi != g;
+      float bd = INFINITY;
+      if (other) {
+        const float4 clo = gb[gi * 2], chi = gb[gi * 2 + 1];
+        const float ex = fmaxf(fmaxf(clo.x - qhi.x, qlo.x - chi.x), 0.f);
+        const float ey = fmaxf(fmaxf(clo.y - qhi.y, qlo.y - chi.y), 0.f);
+        const float ez = fmaxf(fmaxf(clo.z - qhi.z, qlo.z - chi.z), 0.f);
+        bd = (ex * ex + ey * ey + ez * ez) * 0.99999f;
+      }
+      unsigned long long mask =
+          tier == 0 ? __ballot(other && bd == 0.f) : __ballot(other && bd > 0.f && bd <= wave_bound);
+      if (!mask) continue;
+      int l = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      float4 nxt = load_group(c0 + l);
+      while (true) {
+        const int lcur = l;
+        const float4 cr = nxt;
+        const bool more = mask != 0;
+        if (more) {
+          l = __builtin_ctzll(mask);
+          mask &= mask - 1;
+          nxt = load_group(c0 + l);
+        }
+        const float bdl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bd), lcur));
+        if (bdl <= wave_bound) scan_group(c0 + lcur, cr);  // the bound may have tightened since the ballot
+        if (!more) break;
+      }
+    }
+  }
+  if (__any(cnt > 0)) drain();
+
+  if (valid) {
+    const int y = __float_as_int(qr.w);  // original index of this query
+    int32_t *o_nn = nn + ((size_t)b * N + y) * K;
+    float *o_d = dist + ((size_t)b * N + y) * K;
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i) {
+      if (i < K) {
+        const unsigned tb = (unsigned)st.keys[i];
+        if (st.keys[i] == ~0ull) {
+          o_nn[i] = -1;
+          o_d[i] = FLT_MAX;
+        } else {
+          o_nn[i] = (int)(((tb % (unsigned)lad.cv) << lad.log2ct) + tb / (unsigned)lad.cv);
+          o_d[i] = __uint_as_float((unsigned)(st.keys[i] >> 32));
+        }
+      }
+    }
+  }
+}
+
 template <bool XYZ>
 int knn_launch(const float *pos, int B, int N, int K, int32_t *nn, float *dist, hipStream_t s) {
   const KnnLadder lad = knn_ladder(N);
@@ -245,4 +415,21 @@ DH3D_API int dh3d_knn_bruteforce_xyz(const float *xyz, int B, int N, int K, int3
   DH3D_REQUIRE(xyz && nn && dist && B > 0 && N > 0 && K > 0);
   DH3D_SUPPORTED(K <= 64 && B <= 65535);
   return knn_launch<true>(xyz, B, N, K, nn, dist, (hipStream_t)stream);
+}
+
+DH3D_API int dh3d_knn_sorted(const float *sorted, const float *gbox, int B, int N, int K, int32_t *nn,
+                             float *dist, void *stream) {
+  DH3D_REQUIRE(sorted && gbox && nn && dist && B > 0 && N > 0 && K > 0);
+  DH3D_SUPPORTED(K <= 64 && B <= 65535);
+  const KnnLadder lad = knn_ladder(N);
+  const int NG = (N + 63) / 64;
+  dim3 grid(dh3d_cdiv(NG, kSortedWaves), B), block(64 * kSortedWaves);
+  hipStream_t s = (hipStream_t)stream;
+  const float4 *so = reinterpret_cast<const float4 *>(sorted);
+  if (K <= 4) hipLaunchKernelGGL((knn_sorted_kernel<4>), grid, block, 0, s, so, gbox, N, K, lad, nn, dist);
+  else if (K <= 8) hipLaunchKernelGGL((knn_sorted_kernel<8>), grid, block, 0, s, so, gbox, N, K, lad, nn, dist);
+  else if (K <= 16) hipLaunchKernelGGL((knn_sorted_kernel<16>), grid, block, 0, s, so, gbox, N, K, lad, nn, dist);
+  else if (K <= 32) hipLaunchKernelGGL((knn_sorted_kernel<32>), grid, block, 0, s, so, gbox, N, K, lad, nn, dist);
+  else hipLaunchKernelGGL((knn_sorted_kernel<64>), grid, block, 0, s, so, gbox, N, K, lad, nn, dist);
+  return dh3d_launch_status();
 }

@@ -45,40 +45,78 @@ __global__ __launch_bounds__(kBlock) void group_point_bwd_kernel(
 
 // ------------------------------------------------------------------ three_nn
 constexpr int kNNChunk = 1024;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// LDS image of 4 consecutive candidates (12 floats): [x0 x1 y0 y1] [z0 z1 x2 x3] [y2 y3 z2 z3]
+__device__ __forceinline__ int nn_slot(int c, int comp) {
+  const int g = c >> 2, r = c & 3;
+  return g * 12 + ((r < 2) ? (2 * comp + r) : (4 + 2 * comp + r));
+}
+
+// lane = query; 8 candidates per step as packed f32 (unfused mul/add, the reference's roundings); the
+// 3-deep insertion only runs when one of the 8 beats the lane's current third-best.
 __global__ __launch_bounds__(kBlock) void three_nn_kernel(int n, int m, const float *__restrict__ xyz1,
                                                          const float *__restrict__ xyz2,
                                                          float *__restrict__ dist,
                                                          int32_t *__restrict__ idx) {
-  __shared__ float4 s_c[kNNChunk];
+  __shared__ __attribute__((aligned(16))) float s_c[kNNChunk * 3];
   const int b = blockIdx.y;
   const int j = blockIdx.x * kBlock + threadIdx.x;
   const float *q = xyz1 + ((size_t)b * n + j) * 3;
   const float *cand = xyz2 + (size_t)b * m * 3;
   float x1 = 0.f, y1 = 0.f, z1 = 0.f;
   if (j < n) { x1 = q[0]; y1 = q[1]; z1 = q[2]; }
+  const f32x2 qx = {x1, x1}, qy = {y1, y1}, qz = {z1, z1};
   // double 1e40 of the reference: any finite float compares below it, +inf does not.
   float best1 = INFINITY, best2 = INFINITY, best3 = INFINITY;
   int bi1 = 0, bi2 = 0, bi3 = 0;
   for (int base = 0; base < m; base += kNNChunk) {
     const int len = min(kNNChunk, m - base);
+    const int len8 = (len + 7) & ~7;
     __syncthreads();
-    for (int e = threadIdx.x; e < len * 3; e += kBlock)
-      reinterpret_cast<float *>(s_c)[(e / 3) * 4 + (e % 3)] = cand[(size_t)base * 3 + e];
+    for (int e = threadIdx.x; e < len8 * 3; e += kBlock) {
+      const int c = e / 3, comp = e - c * 3;
+      s_c[nn_slot(c, comp)] = c < len ? cand[(size_t)base * 3 + e] : INFINITY;  // padding: d = inf, never < best
+    }
     __syncthreads();
     if (j < n) {
-#pragma unroll 4
-      for (int k = 0; k < len; ++k) {
-        const float4 c = s_c[k];
-        const float dx = c.x - x1, dy = c.y - y1, dz = c.z - z1;
-        const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-        const int kk = base + k;
-        if (d < best1) {
-          best3 = best2; bi3 = bi2; best2 = best1; bi2 = bi1; best1 = d; bi1 = kk;
-        } else if (d < best2) {
-          best3 = best2; bi3 = bi2; best2 = d; bi2 = kk;
-        } else if (d < best3) {
-          best3 = d; bi3 = kk;
+      for (int k = 0; k < len8; k += 8) {
+        const float *g0 = s_c + (k >> 2) * 12;
+        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(g0), a1 = *reinterpret_cast<const f32x4 *>(g0 + 4),
+                    a2 = *reinterpret_cast<const f32x4 *>(g0 + 8), b0 = *reinterpret_cast<const f32x4 *>(g0 + 12),
+                    b1 = *reinterpret_cast<const f32x4 *>(g0 + 16), b2 = *reinterpret_cast<const f32x4 *>(g0 + 20);
+        f32x2 d[4];
+        {
+          const f32x2 dx = f32x2{a0[0], a0[1]} - qx, dy = f32x2{a0[2], a0[3]} - qy, dz = f32x2{a1[0], a1[1]} - qz;
+          d[0] = (dx * dx + dy * dy) + dz * dz;
+        }
+        {
+          const f32x2 dx = f32x2{a1[2], a1[3]} - qx, dy = f32x2{a2[0], a2[1]} - qy, dz = f32x2{a2[2], a2[3]} - qz;
+          d[1] = (dx * dx + dy * dy) + dz * dz;
+        }
+        {
+          const f32x2 dx = f32x2{b0[0], b0[1]} - qx, dy = f32x2{b0[2], b0[3]} - qy, dz = f32x2{b1[0], b1[1]} - qz;
+          d[2] = (dx * dx + dy * dy) + dz * dz;
+        }
+        {
+          const f32x2 dx = f32x2{b1[2], b1[3]} - qx, dy = f32x2{b2[0], b2[1]} - qy, dz = f32x2{b2[2], b2[3]} - qz;
+          d[3] = (dx * dx + dy * dy) + dz * dz;
+        }
+        const float mn = fminf(fminf(fminf(d[0][0], d[0][1]), fminf(d[1][0], d[1][1])),
+                               fminf(fminf(d[2][0], d[2][1]), fminf(d[3][0], d[3][1])));
+        if (mn < best3) {
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {  // in index order: strict '<' keeps the first of equal distances
+            const float dv = d[t >> 1][t & 1];
+            const int kk = base + k + t;
+            if (dv < best1) {
+              best3 = best2; bi3 = bi2; best2 = best1; bi2 = bi1; best1 = dv; bi1 = kk;
+            } else if (dv < best2) {
+              best3 = best2; bi3 = bi2; best2 = dv; bi2 = kk;
+            } else if (dv < best3) {
+              best3 = dv; bi3 = kk;
+            }
+          }
         }
       }
     }

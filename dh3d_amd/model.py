@@ -136,7 +136,8 @@ class DH3D(nn.Module):
         if knn_inds is not None:
             geo.nbr = knn_inds.contiguous()
         else:
-            geo.nbr, _ = pm.knn_xyz(points, self.knn_num)  # core/model.py:157
+            srt, gbox = geo.ordered()  # Morton order + group boxes -> exact kNN with box pruning
+            geo.nbr, _ = pm.knn_sorted(srt, gbox, self.knn_num)  # core/model.py:157
         geo._side = side
         return geo
 

@@ -24,6 +24,35 @@ def knn_xyz(xyz, k):
     return nn, dist
 
 
+def spatial_sort(xyz):
+    """xyz [B,N,3] -> (sorted [B,N,4] Morton-ordered records (x,y,z,bits(orig idx)), gbox [B,ceil(N/64),8])."""
+    x = L.require_cuda_f32(xyz, "xyz", 3)
+    B, N, _ = x.shape
+    srt = torch.empty((B, N, 4), dtype=torch.float32, device=x.device)
+    gbox = torch.empty((B, (N + 63) // 64, 8), dtype=torch.float32, device=x.device)
+    L.check(L.lib().dh3d_spatial_sort(L.ptr(x), B, N, L.ptr(srt), L.ptr(gbox), L.stream_ptr()), "spatial_sort")
+    return srt, gbox
+
+
+def knn_sorted(srt, gbox, k):
+    """kNN from spatial_sort() output; same (nbr [B,N,K], dist) as knn_xyz, original indexing."""
+    B, N, _ = srt.shape
+    nn = torch.empty((B, N, k), dtype=torch.int32, device=srt.device)
+    dist = torch.empty((B, N, k), dtype=torch.float32, device=srt.device)
+    L.check(L.lib().dh3d_knn_sorted(L.ptr(srt), L.ptr(gbox), B, N, k, L.ptr(nn), L.ptr(dist), L.stream_ptr()),
+            "knn_sorted")
+    return nn, dist
+
+
+def fps_sorted(srt, gbox, npoint):
+    """FPS from spatial_sort() output; same idx [B,npoint] (original indexing) as ops.farthest_point_sample."""
+    B, N, _ = srt.shape
+    out = torch.empty((B, npoint), dtype=torch.int32, device=srt.device)
+    L.check(L.lib().dh3d_fps_sorted(L.ptr(srt), L.ptr(gbox), B, N, npoint, L.ptr(out), L.stream_ptr()),
+            "fps_sorted")
+    return out
+
+
 def pack_weight(W):
     """W [Kd, Dout] row-major -> MFMA fragment order (see mfma_gemm.h)."""
     W = L.require_cuda_f32(W, "W", 2)

@@ -148,6 +148,21 @@ int dh3d_pack_weight(const float *W, int Kd, int Dout, float *packed, void *stre
 int dh3d_pack_flex_weight(const float *theta, const float *bias, int Din, int Dout, float *packed,
                           void *stream);
 
+/* Spatial (Morton) ordering of each cloud -- a preprocessing step with no reference counterpart that
+ * changes no result; it lets kNN and FPS skip work exactly (csrc/spatial.hip).
+ * xyz [B,N,3] -> sorted [B,N,4] records (x, y, z, bits(original index)) in Morton order, and
+ * gbox [B, ceil(N/64), 8] = (min xyz, 0, max xyz, 0) of every 64 consecutive records.  N <= 16384. */
+int dh3d_spatial_sort(const float *xyz, int B, int N, float *sorted, float *gbox, void *stream);
+
+/* KnnBruteforce on an ordered cloud: identical outputs to dh3d_knn_bruteforce_xyz (ids are ORIGINAL point
+ * indices, rows are in original query order); candidate groups whose box is provably too far are skipped. */
+int dh3d_knn_sorted(const float *sorted, const float *gbox, int B, int N, int K, int32_t *nn, float *dist,
+                    void *stream);
+
+/* FarthestPointSample on an ordered cloud: identical outputs to dh3d_farthest_point_sample (original
+ * indices); per round only the 64-point groups the new sample can affect are re-evaluated.  N <= 12288. */
+int dh3d_fps_sorted(const float *sorted, const float *gbox, int B, int N, int m, int32_t *out, void *stream);
+
 /* flex_conv forward (same function as dh3d_flex_conv_fwd, Dp = 3) in the factorised form
  *   out[n,:] = [S0 | Sx | Sy | Sz][n,:] @ [bias; theta_x; theta_y; theta_z],
  *   S0[n,i] = sum_k f[nk,i],  Sd[n,i] = sum_k (p[nk,d]-p[n,d]) f[nk,i]

@@ -215,3 +215,69 @@ def test_error_behaviour(dev):
         ops.flex_pooling(torch.zeros(1, 4, 8, device=dev), torch.zeros(2, 3, 8, dtype=torch.int32, device=dev))
     with pytest.raises(ValueError):
         ops.knn_bruteforce(torch.zeros(1, 3, 8, device=dev, dtype=torch.float64), 2)
+
+
+# ------------------------------------------------------------------------------ spatially ordered variants
+@pytest.mark.parametrize("B,N,K", [(2, 64, 4), (1, 100, 8), (2, 1000, 8), (2, 4096, 8), (1, 8192, 8), (1, 8192, 16),
+                                   (1, 9000, 12), (1, 16384, 8), (3, 777, 50)])
+def test_knn_sorted_identical_to_bruteforce(dev, oracle, B, N, K):
+    from dh3d_amd import pm
+    rng = np.random.default_rng(N * 7 + K)
+    xyz = (rng.random((B, N, 3), dtype=np.float32) * 40 - 20)
+    xyz[0, N // 2:, :] *= 0.05  # strongly non-uniform density: half the cloud in a tiny blob
+    t = T(xyz, dev)
+    srt, gbox = pm.spatial_sort(t)
+    perm = srt[:, :, 3].contiguous().view(torch.int32).cpu().numpy()
+    assert all(sorted(p.tolist()) == list(range(N)) for p in perm)  # a permutation
+    assert np.array_equal(srt[:, :, :3].cpu().numpy(), np.take_along_axis(xyz, perm[:, :, None].astype(np.int64), 1))
+    nn, d = pm.knn_sorted(srt, gbox, K)
+    nn0, d0 = pm.knn_xyz(t, K)
+    assert torch.equal(nn, nn0) and torch.equal(d, d0)
+    if N <= 4096:
+        enn, ed = oracle.knn_bruteforce(np.ascontiguousarray(xyz.transpose(0, 2, 1)), K)
+        assert np.array_equal(nn.cpu().numpy(), enn) and np.array_equal(d.cpu().numpy(), ed)
+
+
+def test_knn_sorted_ties_duplicates_lattice(dev, oracle):
+    from dh3d_amd import pm
+    t = load("knn_ties.npz")
+    for name in ("lat300", "lat1100"):
+        xyz = np.ascontiguousarray(t[name + "_pos"].transpose(0, 2, 1))
+        srt, gbox = pm.spatial_sort(T(xyz, dev))
+        nn, d = pm.knn_sorted(srt, gbox, 8)
+        assert np.array_equal(nn.cpu().numpy(), t[name + "_nn"]) and np.array_equal(d.cpu().numpy(), t[name + "_dist"])
+    z = np.zeros((1, 300, 3), np.float32)  # all points identical: degenerate boxes, pure tie order
+    srt, gbox = pm.spatial_sort(T(z, dev))
+    nn, _ = pm.knn_sorted(srt, gbox, 8)
+    assert np.array_equal(nn.cpu().numpy(), oracle.knn_bruteforce(np.ascontiguousarray(z.transpose(0, 2, 1)), 8)[0])
+    p3 = np.random.default_rng(0).random((1, 3, 3), dtype=np.float32)  # K > N padding
+    srt, gbox = pm.spatial_sort(T(p3, dev))
+    nn, d = pm.knn_sorted(srt, gbox, 4)
+    enn, ed = oracle.knn_bruteforce(np.ascontiguousarray(p3.transpose(0, 2, 1)), 4)
+    assert np.array_equal(nn.cpu().numpy(), enn) and np.array_equal(d.cpu().numpy(), ed)
+
+
+@pytest.mark.parametrize("B,N,m", [(2, 1024, 128), (1, 600, 64), (2, 4096, 512), (2, 8192, 1024), (1, 100, 100),
+                                   (1, 10000, 300), (1, 12288, 1536)])
+def test_fps_sorted_identical(dev, oracle, B, N, m):
+    from dh3d_amd import ops, pm
+    rng = np.random.default_rng(N + m)
+    xyz = rng.random((B, N, 3), dtype=np.float32)
+    xyz[0, : N // 3] = xyz[0, : N // 3] * 0.02 + 0.5  # dense blob
+    t = T(xyz, dev)
+    srt, gbox = pm.spatial_sort(t)
+    idx = pm.fps_sorted(srt, gbox, m)
+    assert torch.equal(idx, ops.farthest_point_sample(m, t))
+    assert np.array_equal(idx.cpu().numpy(), oracle.farthest_point_sample(m, xyz))
+
+
+def test_fps_sorted_golden_and_ties(dev):
+    from dh3d_amd import pm
+    c = load("fps.npz")
+    for pts, m, key in ((c["xyz"], 128, "idx"), (c["lat"], 64, "lat_idx")):
+        srt, gbox = pm.spatial_sort(T(pts, dev))
+        assert np.array_equal(pm.fps_sorted(srt, gbox, m).cpu().numpy(), c[key])
+    z = np.zeros((1, 1500, 3), np.float32)
+    z[0, 700] = 1.0; z[0, 188] = 1.0
+    srt, gbox = pm.spatial_sort(T(z, dev))
+    assert int(pm.fps_sorted(srt, gbox, 2)[0, 1]) == 188
