@@ -95,10 +95,16 @@ def flex_conv_roofline(dev, B=8, N=8192, K=8, Din=64, Dout=64):
     Bc = 4.0 * (B * N * (Din + Dout + 3 + K) + 4 * Din * Dout)
     Bg = 4.0 * B * N * (K * (Din + 4) + 3 + Dout)
     F = 2.0 * B * N * 4 * Din * (K + Dout)
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "pmc_flex_conv.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+    if os.path.isfile(pmc):
+        rec = json.load(open(pmc))
+        traffic, traffic_src = rec["hbm_bytes_per_launch"], rec["source"]
     return {
+        "traffic_source": traffic_src,
         "bound": "hbm", "kernel": "flex_conv_pm_kernel<%d,%d> B=%d N=%d K=%d" % (Din, Dout, B, N, K),
         "achieved": Bc / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": Bc / t / 1e9 / HBM_PEAK_GBS,
-        "traffic": None, "launch_ms": ms, "algorithmic_bytes": Bc,
+        "traffic": traffic, "launch_ms": ms, "algorithmic_bytes": Bc,
         "gather_effective": {"achieved": Bg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": Bg / t / 1e9 / HBM_PEAK_GBS, "bytes": Bg},
         "mfma_f32": {"achieved": F / t / 1e12, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",

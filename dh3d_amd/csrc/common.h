@@ -36,6 +36,15 @@ static inline int dh3d_launch_status() {
     }                                                                                         \
   } while (0)
 
+// XCD-aware block order.  The dispatcher places block b on XCD b % 8 (observed, used for speed only --
+// MI355X_MICROARCH.md "Workgroup dispatch"); each XCD has its own 4 MiB L2.  Tiles are consecutive points of
+// a cloud and gather from that cloud's feature map, so give every XCD a CONTIGUOUS range of tiles: the
+// map's lines are then fetched into one L2 instead of all eight.  Bijective for any block count.
+__device__ __forceinline__ int dh3d_xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
 // Epilogue y = act(scale*(x+pre_bias)+shift), by value for kernels.
 struct EpilogueArgs {
   const float *pre_bias;

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void flex_conv_pm_kernel(
   using C = FlexCfg<DIN, DOUT>;
   extern __shared__ __attribute__((aligned(16))) float s_S[];  // [TM][LD]
   const int tid = threadIdx.x;
-  const long long grow0 = (long long)blockIdx.x * C::TM;
+  const long long grow0 = (long long)dh3d_xcd_remap(blockIdx.x, gridDim.x) * C::TM;
 
   // ---- phase A: gather-reduce S = [S0|Sx|Sy|Sz] for TM points
   const int r4 = (tid % C::LPR) * 4;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void flex_pool_pm_kernel(const float *__restri
                                                           int32_t *__restrict__ argmax) {
   const int cv = C / 4;
   const long long total = R * cv;
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total;
+  for (long long e = (long long)dh3d_xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x; e < total;
        e += (long long)gridDim.x * 256) {
     const long long n = e / cv;
     const int c4 = (int)(e - n * cv) * 4;
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void conv_pointset_pm_kernel(
     float *__restrict__ out) {
   const int cv = Dout / 4;
   const long long total = R * cv;
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total;
+  for (long long e = (long long)dh3d_xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x; e < total;
        e += (long long)gridDim.x * 256) {
     const long long n = e / cv;
     const int o4 = (int)(e - n * cv) * 4;
