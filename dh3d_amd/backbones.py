@@ -152,11 +152,11 @@ class Geometry(object):
             self.sorted = pm.spatial_sort(self.xyz)
         return self.sorted
 
-    def level(self, dilate, knn):
+    def level(self, dilate, knn, finish=True):
         key = (dilate, knn)
         if key not in self.levels:
             self.levels[key] = compute_level(self.xyz, dilate, knn)
-        return self.levels[key]
+        return finish_level(self.xyz, self.levels[key]) if finish else self.levels[key]
 
 
 def gather_rows(points, idx):
@@ -183,13 +183,25 @@ def compute_level(xyz, dilate, knn):
     L.check(L.lib().dh3d_farthest_point_sample(B, N, npoint, L.ptr(xyz), None, L.ptr(idx), L.stream_ptr()),
             "farthest_point_sample")
     xyz_s = gather_rows(xyz, idx)
+    ready = torch.cuda.Event()
+    ready.record()  # xyz_s exists: three_nn may start on another stream while the sampled-set kNN runs here
     srt_s, gbox_s = pm.spatial_sort(xyz_s)
     nbr_s, _ = pm.knn_sorted(srt_s, gbox_s, knn)
-    d3 = torch.empty((B, N, 3), dtype=torch.float32, device=xyz.device)
-    i3 = torch.empty((B, N, 3), dtype=torch.int32, device=xyz.device)
-    L.check(L.lib().dh3d_three_nn(B, N, npoint, L.ptr(xyz), L.ptr(xyz_s), L.ptr(d3), L.ptr(i3), L.stream_ptr()),
-            "three_nn")
-    return {"idx": idx, "xyz_s": xyz_s, "nbr_s": nbr_s, "nn3_dist": d3, "nn3_idx": i3}
+    return {"idx": idx, "xyz_s": xyz_s, "nbr_s": nbr_s, "_xyz_ready": ready}
+
+
+def finish_level(xyz, lv):
+    """three_nn of the full cloud against the sampled set (run by the consumer stream; idempotent)."""
+    if "nn3_idx" not in lv:
+        torch.cuda.current_stream().wait_event(lv["_xyz_ready"])
+        B, N, _ = xyz.shape
+        xyz_s = lv["xyz_s"]
+        d3 = torch.empty((B, N, 3), dtype=torch.float32, device=xyz.device)
+        i3 = torch.empty((B, N, 3), dtype=torch.int32, device=xyz.device)
+        L.check(L.lib().dh3d_three_nn(B, N, xyz_s.shape[1], L.ptr(xyz), L.ptr(xyz_s), L.ptr(d3), L.ptr(i3),
+                                      L.stream_ptr()), "three_nn")
+        lv["nn3_dist"], lv["nn3_idx"] = d3, i3
+    return lv
 
 
 # --------------------------------------------------------------------------- flex_conv_dilate

@@ -57,9 +57,10 @@ __global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float *__restrict
                                                        int32_t *__restrict__ out) {
   constexpr int T = 64 * WAVES;
   extern __shared__ __attribute__((aligned(16))) float s_mem[];
-  // layout: [2][WAVES] vals | [2][WAVES] keys | (LDS_COORDS) x[N] y[N] z[N] picks[m]
-  float *s_val = s_mem;
-  int *s_key = reinterpret_cast<int *>(s_mem + 2 * WAVES);
+  // layout: 3 x u64 block-best slots (+pad to 4*WAVES floats) | (LDS_COORDS) x[N] y[N] z[N] picks[m]
+  // The block arg-max is ONE 64-bit LDS atomic max per wave on (bits(value) << 32 | ~key): value >= 0 so
+  // unsigned order is (value, smaller key wins).  Slots rotate so the reset never races a reader.
+  unsigned long long *s_best = reinterpret_cast<unsigned long long *>(s_mem);
   float *s_x = s_mem + 4 * WAVES;
   float *s_y = s_x + N;
   float *s_z = s_y + N;
@@ -87,10 +88,11 @@ __global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float *__restrict
     px[j >> 1][j & 1] = x; py[j >> 1][j & 1] = y; pz[j >> 1][j & 1] = z; md[j >> 1][j & 1] = d;
   }
   if (tid == 0) { if (LDS_COORDS) s_out[0] = 0; else out[(size_t)b * m] = 0; }
+  if (tid < 3) s_best[tid] = 0ull;
   __syncthreads();
 
   int old = 0;
-  int buf = 0;
+  int buf = 1;  // slot of round r is r % 3
   for (int r = 1; r < m; ++r) {
     PROBE(0);
     float x1, y1, z1;
@@ -126,21 +128,19 @@ __global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float *__restrict
     if (__popcll(hit) == 1) wkey = __builtin_amdgcn_readlane(lkey, __builtin_ctzll(hit));
     else wkey = wave_min_i32(lkey);  // several lanes tie: smallest key wins (non-hit lanes hold INT_MAX)
     PROBE(4);
-    if (lane == 0) { s_val[buf * WAVES + wave] = wmax; s_key[buf * WAVES + wave] = wkey; }
+    if (lane == 0) {
+      const unsigned long long packed =
+          wmax >= 0.f ? (((unsigned long long)__float_as_uint(wmax) << 32) | (unsigned)~wkey) : 0ull;
+      atomicMax(&s_best[buf], packed);
+      if (wave == 0) s_best[buf == 2 ? 0 : buf + 1] = 0ull;  // next round's slot (last read two rounds ago)
+    }
     __syncthreads();
     PROBE(5);
-    // every wave re-derives the block winner from the WAVES partials (replicated along each 16-lane row)
-    const float v = s_val[buf * WAVES + (lane & (WAVES - 1))];
-    const int kk = s_key[buf * WAVES + (lane & (WAVES - 1))];
-    const float bmax = row16_max_f32(v);
-    const unsigned long long hit2 = __ballot(v == bmax) & ((1ull << WAVES) - 1);
-    int bkey;
-    if (__popcll(hit2) == 1) bkey = __builtin_amdgcn_readlane(kk, __builtin_ctzll(hit2));
-    else bkey = __builtin_amdgcn_readfirstlane(row16_min_i32(v == bmax ? kk : INT_MAX));
+    const int bkey = ~(int)(unsigned)s_best[buf];
     old = fps_unkey(bkey);
     PROBE(6);
     if (tid == 0) { if (LDS_COORDS) s_out[r] = old; else out[(size_t)b * m + r] = old; }
-    buf ^= 1;
+    buf = buf == 2 ? 0 : buf + 1;
   }
   if (LDS_COORDS) {
     __syncthreads();

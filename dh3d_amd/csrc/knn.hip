@@ -101,6 +101,35 @@ __device__ __forceinline__ void knn_offer(KnnState<KMAX> &st, float s, int x, co
   }
 }
 
+
+// Squared distances (reference rounding order) of 8 consecutive candidates of the pair-SoA LDS image.
+__device__ __forceinline__ void knn_dist8(const float *g0, const f32x2 qx2, const f32x2 qy2, const f32x2 qz2,
+                                          f32x2 (&s)[4]) {
+  const f32x4 a0 = *reinterpret_cast<const f32x4 *>(g0), a1 = *reinterpret_cast<const f32x4 *>(g0 + 4),
+              a2 = *reinterpret_cast<const f32x4 *>(g0 + 8), b0 = *reinterpret_cast<const f32x4 *>(g0 + 12),
+              b1 = *reinterpret_cast<const f32x4 *>(g0 + 16), b2 = *reinterpret_cast<const f32x4 *>(g0 + 20);
+  {
+    const f32x2 dx = f32x2{a0[0], a0[1]} - qx2, dy = f32x2{a0[2], a0[3]} - qy2, dz = f32x2{a1[0], a1[1]} - qz2;
+    s[0] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+  }
+  {
+    const f32x2 dx = f32x2{a1[2], a1[3]} - qx2, dy = f32x2{a2[0], a2[1]} - qy2, dz = f32x2{a2[2], a2[3]} - qz2;
+    s[1] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+  }
+  {
+    const f32x2 dx = f32x2{b0[0], b0[1]} - qx2, dy = f32x2{b0[2], b0[3]} - qy2, dz = f32x2{b1[0], b1[1]} - qz2;
+    s[2] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+  }
+  {
+    const f32x2 dx = f32x2{b1[2], b1[3]} - qx2, dy = f32x2{b2[0], b2[1]} - qy2, dz = f32x2{b2[2], b2[3]} - qz2;
+    s[3] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+  }
+}
+__device__ __forceinline__ float knn_min8(const f32x2 (&s)[4]) {
+  return fminf(fminf(fminf(s[0][0], s[0][1]), fminf(s[1][0], s[1][1])),
+               fminf(fminf(s[2][0], s[2][1]), fminf(s[3][0], s[3][1])));
+}
+
 // XYZ_LAYOUT: false = positions [B,3,N] (op layout), true = xyz [B,N,3].
 template <int KMAX, bool XYZ_LAYOUT>
 __global__ __launch_bounds__(kQueriesPerBlock) void knn_kernel(const float *__restrict__ pos, int N,
@@ -129,7 +158,7 @@ __global__ __launch_bounds__(kQueriesPerBlock) void knn_kernel(const float *__re
 
   for (int base = 0; base < N; base += kChunk) {
     const int len = min(kChunk, N - base);
-    const int len8 = (len + 7) & ~7;
+    const int len8 = (len + 31) & ~31;  // padded (+inf) to the 32-candidate step of the scan loop
     __syncthreads();
     if (XYZ_LAYOUT) {
       for (int e = tid; e < len8 * 3; e += kQueriesPerBlock) {
@@ -143,53 +172,44 @@ __global__ __launch_bounds__(kQueriesPerBlock) void knn_kernel(const float *__re
       }
     }
     __syncthreads();
-    if (y < N) {
-      for (int j = 0; j < len8; j += 8) {
-        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(s_c + (j >> 2) * 12);
-        const f32x4 a1 = *reinterpret_cast<const f32x4 *>(s_c + (j >> 2) * 12 + 4);
-        const f32x4 a2 = *reinterpret_cast<const f32x4 *>(s_c + (j >> 2) * 12 + 8);
-        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(s_c + (j >> 2) * 12 + 12);
-        const f32x4 b1 = *reinterpret_cast<const f32x4 *>(s_c + (j >> 2) * 12 + 16);
-        const f32x4 b2 = *reinterpret_cast<const f32x4 *>(s_c + (j >> 2) * 12 + 20);
-        f32x2 s[4];
-        {
-          const f32x2 dx = f32x2{a0[0], a0[1]} - qx2, dy = f32x2{a0[2], a0[3]} - qy2, dz = f32x2{a1[0], a1[1]} - qz2;
-          s[0] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-        }
-        {
-          const f32x2 dx = f32x2{a1[2], a1[3]} - qx2, dy = f32x2{a2[0], a2[1]} - qy2, dz = f32x2{a2[2], a2[3]} - qz2;
-          s[1] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-        }
-        {
-          const f32x2 dx = f32x2{b0[0], b0[1]} - qx2, dy = f32x2{b0[2], b0[3]} - qy2, dz = f32x2{b1[0], b1[1]} - qz2;
-          s[2] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-        }
-        {
-          const f32x2 dx = f32x2{b1[2], b1[3]} - qx2, dy = f32x2{b2[0], b2[1]} - qy2, dz = f32x2{b2[2], b2[3]} - qz2;
-          s[3] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-        }
-        const float m = fminf(fminf(fminf(s[0][0], s[0][1]), fminf(s[1][0], s[1][1])),
-                              fminf(fminf(s[2][0], s[2][1]), fminf(s[3][0], s[3][1])));
-        if (m <= st.bound) {
+    // 32 candidates per iteration: 24 broadcast LDS reads + 48 packed ops with nothing between them that
+    // depends on the lane's list, so they pipeline; ONE wave-uniform test decides whether anybody needs the
+    // slow path (a per-8 branch serialised every step behind its own LDS latency: 650-800 cycles/step
+    // measured with one wave per SIMD, tools/knn_probe.py).
+    const int len32 = (len8 + 31) & ~31;  // the image is padded with +inf up to a multiple of 32
+    for (int j = 0; j < len32; j += 32) {
+      f32x2 s[4][4];
+      float mn[4];
 #pragma unroll
-          for (int t = 0; t < 8; ++t) {
-            const float sv = s[t >> 1][t & 1];
-            const int x = base + j + t;
-            if (sv <= st.bound && x < N) {
-              s_q[cnt * kQueriesPerBlock + tid] = make_uint2(__float_as_uint(sv), (unsigned)x);
-              ++cnt;
+      for (int u = 0; u < 4; ++u) {
+        knn_dist8(s_c + ((j >> 2) + 2 * u) * 12, qx2, qy2, qz2, s[u]);
+        mn[u] = knn_min8(s[u]);
+      }
+      const float m = fminf(fminf(mn[0], mn[1]), fminf(mn[2], mn[3]));
+      if (__any(y < N && m <= st.bound)) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (y < N && mn[u] <= st.bound) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+              const float sv = s[u][t >> 1][t & 1];
+              const int x = base + j + 8 * u + t;
+              if (sv <= st.bound && x < N) {
+                s_q[cnt * kQueriesPerBlock + tid] = make_uint2(__float_as_uint(sv), (unsigned)x);
+                ++cnt;
+              }
             }
           }
-        }
-        if (__any(cnt > kQueue - 8)) {  // wave-uniform: drain every lane's queue
-          for (int i = 0; i < kQueue; ++i) {
-            if (!__any(i < cnt)) break;
-            if (i < cnt) {
-              const uint2 e = s_q[i * kQueriesPerBlock + tid];
-              knn_offer<KMAX>(st, __uint_as_float(e.x), (int)e.y, lad);
+          if (__any(cnt > kQueue - 8)) {  // wave-uniform: drain every lane's queue
+            for (int i = 0; i < kQueue; ++i) {
+              if (!__any(i < cnt)) break;
+              if (i < cnt) {
+                const uint2 e = s_q[i * kQueriesPerBlock + tid];
+                knn_offer<KMAX>(st, __uint_as_float(e.x), (int)e.y, lad);
+              }
             }
+            cnt = 0;
           }
-          cnt = 0;
         }
       }
     }
@@ -231,6 +251,9 @@ __global__ __launch_bounds__(kQueriesPerBlock) void knn_kernel(const float *__re
 // exactly the same screen / queue / 64-bit-key insertion as knn_kernel, so ids and distances are
 // bit-identical to it (tests).  Waves are independent: no block-level barrier.
 constexpr int kSortedWaves = 4;
+#ifdef DH3D_KNN_PROBE  // dev instrumentation (tools/knn_probe.py): per-wave cycle / event counters
+__device__ long long g_kprobe[8 * 512];
+#endif
 
 template <int KMAX>
 __global__ __launch_bounds__(64 * kSortedWaves) void knn_sorted_kernel(const float4 *__restrict__ sorted,
@@ -266,9 +289,20 @@ __global__ __launch_bounds__(64 * kSortedWaves) void knn_sorted_kernel(const flo
   int cnt = 0;
   float wave_bound = INFINITY;  // max over the wave's valid lanes of st.bound (refreshed after each drain)
 
+#ifdef DH3D_KNN_PROBE
+  long long pr_t0 = clock64(), pr_drain = 0;
+  int pr_ndrain = 0, pr_nslots = 0, pr_ngroups = 0;
+#endif
   auto drain = [&]() {
+#ifdef DH3D_KNN_PROBE
+    const long long d0 = clock64();
+    ++pr_ndrain;
+#endif
     for (int i = 0; i < kQueue; ++i) {
       if (!__any(i < cnt)) break;
+#ifdef DH3D_KNN_PROBE
+      ++pr_nslots;
+#endif
       if (i < cnt) {
         const uint2 e = my_q[i * 64 + lane];
         knn_offer<KMAX>(st, __uint_as_float(e.x), (int)e.y, lad);
@@ -276,53 +310,48 @@ __global__ __launch_bounds__(64 * kSortedWaves) void knn_sorted_kernel(const flo
     }
     cnt = 0;
     wave_bound = wave_max_f32(valid ? st.bound : 0.f);
+#ifdef DH3D_KNN_PROBE
+    pr_drain += clock64() - d0;
+#endif
   };
 
   // evaluate the 64 candidates of group gcc (records already in `cr`, one per lane)
   auto scan_group = [&](int gcc, const float4 cr) {
+#ifdef DH3D_KNN_PROBE
+    ++pr_ngroups;
+#endif
     my_c[cand_slot(lane, 0)] = cr.x;
     my_c[cand_slot(lane, 1)] = cr.y;
     my_c[cand_slot(lane, 2)] = cr.z;
     my_id[lane] = __float_as_int(cr.w);
     __builtin_amdgcn_wave_barrier();
     const int clen = min(64, N - gcc * 64);
-    for (int j = 0; j < clen; j += 8) {
-      const f32x4 a0 = *reinterpret_cast<const f32x4 *>(my_c + (j >> 2) * 12);
-      const f32x4 a1 = *reinterpret_cast<const f32x4 *>(my_c + (j >> 2) * 12 + 4);
-      const f32x4 a2 = *reinterpret_cast<const f32x4 *>(my_c + (j >> 2) * 12 + 8);
-      const f32x4 b0 = *reinterpret_cast<const f32x4 *>(my_c + (j >> 2) * 12 + 12);
-      const f32x4 b1 = *reinterpret_cast<const f32x4 *>(my_c + (j >> 2) * 12 + 16);
-      const f32x4 b2 = *reinterpret_cast<const f32x4 *>(my_c + (j >> 2) * 12 + 20);
-      f32x2 s[4];
-      {
-        const f32x2 dx = f32x2{a0[0], a0[1]} - qx2, dy = f32x2{a0[2], a0[3]} - qy2, dz = f32x2{a1[0], a1[1]} - qz2;
-        s[0] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-      }
-      {
-        const f32x2 dx = f32x2{a1[2], a1[3]} - qx2, dy = f32x2{a2[0], a2[1]} - qy2, dz = f32x2{a2[2], a2[3]} - qz2;
-        s[1] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-      }
-      {
-        const f32x2 dx = f32x2{b0[0], b0[1]} - qx2, dy = f32x2{b0[2], b0[3]} - qy2, dz = f32x2{b1[0], b1[1]} - qz2;
-        s[2] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-      }
-      {
-        const f32x2 dx = f32x2{b1[2], b1[3]} - qx2, dy = f32x2{b2[0], b2[1]} - qy2, dz = f32x2{b2[2], b2[3]} - qz2;
-        s[3] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-      }
-      const float mn = fminf(fminf(fminf(s[0][0], s[0][1]), fminf(s[1][0], s[1][1])),
-                             fminf(fminf(s[2][0], s[2][1]), fminf(s[3][0], s[3][1])));
-      if (valid && mn <= st.bound) {
+    // 32 candidates per iteration, one wave-uniform test (see knn_kernel); padding records are +inf
+    for (int j = 0; j < clen; j += 32) {
+      f32x2 s[4][4];
+      float mn[4];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const float sv = s[t >> 1][t & 1];
-          if (sv <= st.bound && j + t < clen) {
-            my_q[cnt * 64 + lane] = make_uint2(__float_as_uint(sv), (unsigned)my_id[j + t]);
-            ++cnt;
+      for (int u = 0; u < 4; ++u) {
+        knn_dist8(my_c + ((j >> 2) + 2 * u) * 12, qx2, qy2, qz2, s[u]);
+        mn[u] = knn_min8(s[u]);
+      }
+      const float m = fminf(fminf(mn[0], mn[1]), fminf(mn[2], mn[3]));
+      if (__any(valid && m <= st.bound)) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (valid && mn[u] <= st.bound) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+              const float sv = s[u][t >> 1][t & 1];
+              if (sv <= st.bound && j + 8 * u + t < clen) {
+                my_q[cnt * 64 + lane] = make_uint2(__float_as_uint(sv), (unsigned)my_id[j + 8 * u + t]);
+                ++cnt;
+              }
+            }
           }
+          if (__any(cnt > kQueue - 8)) drain();
         }
       }
-      if (__any(cnt > kQueue - 8)) drain();
     }
     __builtin_amdgcn_wave_barrier();
   };
@@ -368,6 +397,12 @@ __global__ __launch_bounds__(64 * kSortedWaves) void knn_sorted_kernel(const flo
     }
   }
   if (__any(cnt > 0)) drain();
+#ifdef DH3D_KNN_PROBE
+  if (lane == 0 && b == 0) {
+    long long *o = g_kprobe + (size_t)g * 8;
+    o[0] = clock64() - pr_t0; o[1] = pr_drain; o[2] = pr_ndrain; o[3] = pr_nslots; o[4] = pr_ngroups;
+  }
+#endif
 
   if (valid) {
     const int y = __float_as_int(qr.w);  // original index of this query
@@ -433,3 +468,9 @@ DH3D_API int dh3d_knn_sorted(const float *sorted, const float *gbox, int B, int 
   else hipLaunchKernelGGL((knn_sorted_kernel<64>), grid, block, 0, s, so, gbox, N, K, lad, nn, dist);
   return dh3d_launch_status();
 }
+
+#ifdef DH3D_KNN_PROBE
+DH3D_API int dh3d_knn_probe_read(long long *host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_kprobe), sizeof(long long) * n) == hipSuccess ? 0 : 3;
+}
+#endif

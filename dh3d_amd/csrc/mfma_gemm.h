@@ -25,10 +25,48 @@ __device__ __forceinline__ void wave_gemm_f32(const float *s_A, int ldA, int row
   const int lane = threadIdx.x & 63;
   const float *aptr = s_A + (size_t)(row0 + (lane & 31)) * ldA + 4 * (lane >> 5);
   const f32x4 *wp = reinterpret_cast<const f32x4 *>(wpacked) + lane;
+  // Main loop: k-blocks in groups of 4 with the NEXT group's B fragments already in flight.  The packed
+  // weight comes from L2 (~700 cycles under load); one group is 16*NT MFMAs = 1024*NT cycles of matrix
+  // pipe, which covers it.  (A 1-deep prefetch left ~450 cycles exposed per k-block: profiles/r01_c.)
+  const int KB4 = KB & ~3;
+  int kb = 0;
+  if (KB4 > 0) {
+    f32x4 nxt[4][NT];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) nxt[u][j] = wp[(size_t)((cb0 + j * cbstride) * KB + u) * 64];
+    for (; kb < KB4; kb += 4) {
+      f32x4 cur[4][NT];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) cur[u][j] = nxt[u][j];
+      if (kb + 4 < KB4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) nxt[u][j] = wp[(size_t)((cb0 + j * cbstride) * KB + kb + 4 + u) * 64];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4 *>(aptr + (kb + u) * 8);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0], cur[u][j][0], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1], cur[u][j][1], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[2], cur[u][j][2], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[3], cur[u][j][3], acc[j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (kb >= KB) return;
+  // tail (KB not a multiple of 4): one k-block at a time
   f32x4 bnext[NT];
 #pragma unroll
-  for (int j = 0; j < NT; ++j) bnext[j] = wp[(size_t)((cb0 + j * cbstride) * KB) * 64];
-  for (int kb = 0; kb < KB; ++kb) {
+  for (int j = 0; j < NT; ++j) bnext[j] = wp[(size_t)((cb0 + j * cbstride) * KB + kb) * 64];
+  for (; kb < KB; ++kb) {
     const f32x4 a4 = *reinterpret_cast<const f32x4 *>(aptr + kb * 8);
     f32x4 bcur[NT];
 #pragma unroll

@@ -72,49 +72,59 @@ __global__ __launch_bounds__(kBlock) void three_nn_kernel(int n, int m, const fl
   int bi1 = 0, bi2 = 0, bi3 = 0;
   for (int base = 0; base < m; base += kNNChunk) {
     const int len = min(kNNChunk, m - base);
-    const int len8 = (len + 7) & ~7;
+    const int len8 = (len + 31) & ~31;  // padded (+inf) to the 32-candidate step
+    const int len32 = len8;
     __syncthreads();
     for (int e = threadIdx.x; e < len8 * 3; e += kBlock) {
       const int c = e / 3, comp = e - c * 3;
       s_c[nn_slot(c, comp)] = c < len ? cand[(size_t)base * 3 + e] : INFINITY;  // padding: d = inf, never < best
     }
     __syncthreads();
-    if (j < n) {
-      for (int k = 0; k < len8; k += 8) {
-        const float *g0 = s_c + (k >> 2) * 12;
+    // 32 candidates per iteration with one wave-uniform test, so the LDS reads and packed ops pipeline
+    for (int k = 0; k < len32; k += 32) {
+      f32x2 d[4][4];
+      float mn[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float *g0 = s_c + ((k >> 2) + 2 * u) * 12;
         const f32x4 a0 = *reinterpret_cast<const f32x4 *>(g0), a1 = *reinterpret_cast<const f32x4 *>(g0 + 4),
                     a2 = *reinterpret_cast<const f32x4 *>(g0 + 8), b0 = *reinterpret_cast<const f32x4 *>(g0 + 12),
                     b1 = *reinterpret_cast<const f32x4 *>(g0 + 16), b2 = *reinterpret_cast<const f32x4 *>(g0 + 20);
-        f32x2 d[4];
         {
           const f32x2 dx = f32x2{a0[0], a0[1]} - qx, dy = f32x2{a0[2], a0[3]} - qy, dz = f32x2{a1[0], a1[1]} - qz;
-          d[0] = (dx * dx + dy * dy) + dz * dz;
+          d[u][0] = (dx * dx + dy * dy) + dz * dz;
         }
         {
           const f32x2 dx = f32x2{a1[2], a1[3]} - qx, dy = f32x2{a2[0], a2[1]} - qy, dz = f32x2{a2[2], a2[3]} - qz;
-          d[1] = (dx * dx + dy * dy) + dz * dz;
+          d[u][1] = (dx * dx + dy * dy) + dz * dz;
         }
         {
           const f32x2 dx = f32x2{b0[0], b0[1]} - qx, dy = f32x2{b0[2], b0[3]} - qy, dz = f32x2{b1[0], b1[1]} - qz;
-          d[2] = (dx * dx + dy * dy) + dz * dz;
+          d[u][2] = (dx * dx + dy * dy) + dz * dz;
         }
         {
           const f32x2 dx = f32x2{b1[2], b1[3]} - qx, dy = f32x2{b2[0], b2[1]} - qy, dz = f32x2{b2[2], b2[3]} - qz;
-          d[3] = (dx * dx + dy * dy) + dz * dz;
+          d[u][3] = (dx * dx + dy * dy) + dz * dz;
         }
-        const float mn = fminf(fminf(fminf(d[0][0], d[0][1]), fminf(d[1][0], d[1][1])),
-                               fminf(fminf(d[2][0], d[2][1]), fminf(d[3][0], d[3][1])));
-        if (mn < best3) {
+        mn[u] = fminf(fminf(fminf(d[u][0][0], d[u][0][1]), fminf(d[u][1][0], d[u][1][1])),
+                      fminf(fminf(d[u][2][0], d[u][2][1]), fminf(d[u][3][0], d[u][3][1])));
+      }
+      const float m = fminf(fminf(mn[0], mn[1]), fminf(mn[2], mn[3]));
+      if (__any(j < n && m < best3)) {
 #pragma unroll
-          for (int t = 0; t < 8; ++t) {  // in index order: strict '<' keeps the first of equal distances
-            const float dv = d[t >> 1][t & 1];
-            const int kk = base + k + t;
-            if (dv < best1) {
-              best3 = best2; bi3 = bi2; best2 = best1; bi2 = bi1; best1 = dv; bi1 = kk;
-            } else if (dv < best2) {
-              best3 = best2; bi3 = bi2; best2 = dv; bi2 = kk;
-            } else if (dv < best3) {
-              best3 = dv; bi3 = kk;
+        for (int u = 0; u < 4; ++u) {
+          if (j < n && mn[u] < best3) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {  // in index order: strict '<' keeps the first of equal distances
+              const float dv = d[u][t >> 1][t & 1];
+              const int kk = base + k + 8 * u + t;
+              if (dv < best1) {
+                best3 = best2; bi3 = bi2; best2 = best1; bi2 = bi1; best1 = dv; bi1 = kk;
+              } else if (dv < best2) {
+                best3 = best2; bi3 = bi2; best2 = dv; bi2 = kk;
+              } else if (dv < best3) {
+                best3 = dv; bi3 = kk;
+              }
             }
           }
         }

@@ -130,9 +130,11 @@ class DH3D(nn.Module):
         side = self._geo_stream
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            lv = geo.level(8, self.knn_num)  # stage2 (dilate2=8) and global (gl_dilate=8) share it
+            # stage2 (dilate2=8) and global (gl_dilate=8) share it; three_nn is left to the main stream
+            lv = geo.level(8, self.knn_num, finish=False)
             for t in lv.values():
-                t.record_stream(main)
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(main)
         if knn_inds is not None:
             geo.nbr = knn_inds.contiguous()
         else:
@@ -152,7 +154,8 @@ class DH3D(nn.Module):
         init = pm.flex_pool(init, nn_8)
         x1 = self.stage1(geo, init, nbr=nn_8)
         x2 = self.before_stage2_conv1d(x1, act=pm.ACT_RELU)
-        torch.cuda.current_stream().wait_stream(geo._side)  # FPS / kNN(N/8) / three_nn are needed from here
+        geo.level(8, self.knn_num)  # three_nn on this stream as soon as the sampled xyz exist (side: kNN(N/8))
+        torch.cuda.current_stream().wait_stream(geo._side)  # FPS / gather / kNN(N/8) are needed from here
         x2 = self.stage2(geo, x2)
         feat = self.local_stage1_shortcut(x1, act=pm.ACT_RELU, residual=x2)
         self._last_geo = geo
@@ -164,6 +167,7 @@ class DH3D(nn.Module):
         geo = outs.get("_geo")
         if geo is None:
             geo = self._geometry(points, None)
+            geo.level(8, self.knn_num)
             torch.cuda.current_stream().wait_stream(geo._side)
         forglobal = self.global_before_assemble(geo, localdesc)
         att = self.globalatt(forglobal)
