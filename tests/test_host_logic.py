@@ -108,11 +108,15 @@ print("rank", rank, "ok")
 
 
 def test_all_gather_world_size_2_gloo(tmp_path):
+    import socket
+    with socket.socket() as sk:  # a free port: a stale rendezvous from an earlier run must not collide
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
     script = tmp_path / "worker.py"
     script.write_text(_WORKER % ROOT)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29617", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
                        env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
