@@ -30,6 +30,10 @@ WORKLOADS = {
                   name="local-descriptor forward (basic_config), N=8192 K=8, batch=8 per GPU"),
     "global": dict(preset="global_config", B=32, N=4096, seed=3003, out="globaldesc",
                    name="global-descriptor forward (global_config), N=4096, 64-cluster NetVLAD, batch=32 per GPU"),
+    # BASELINE config[3]: NOT a default bench line; fixed total batch sharded over the ranks ("strong" scaling)
+    "train": dict(preset="global_config", B=22, N=4096, seed=4004, out=None,
+                  name="Siamese quadruplet training step, Oxford-shaped batch (1 anchor + 2 pos + 18 neg + 1 other-neg), "
+                       "N=4096, frozen backbone, batch sharded over ranks + RCCL all-gather of descriptors"),
 }
 
 
@@ -134,14 +138,15 @@ def cpu_baseline(workload):
     from dh3d_amd.model import DH3D
     model = DH3D(ConfigFactory(wl["preset"]).getconfig()).init_synthetic(0)
     w = {tf_variable_name(k): v.detach().numpy() for k, v in model.state_dict().items()}
-    pts = np.random.default_rng(wl["seed"]).random((1, wl["N"], 3), dtype=np.float32)
+    n = 8  # bounded sample: ~10-20 s of single-core work
+    pts = np.random.default_rng(wl["seed"]).random((n, wl["N"], 3), dtype=np.float32)
     torch.set_num_threads(1)
     t0 = time.perf_counter()
     model_np.forward(pts, w, detection=False, extract_global=(workload == "global"))
     dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "point-clouds/sec", "cores": 1, "kind": "port",
-            "sample": "1 cloud of N=%d through oracle/model_np.forward (C oracle ops + numpy dense), %.1f s" % (wl["N"], dt),
-            "host_cpus": os.cpu_count()}
+    return {"value": n / dt, "unit": "point-clouds/sec", "cores": 1, "kind": "port",
+            "sample": "%d clouds of N=%d through oracle/model_np.forward (C oracle ops, single thread + numpy dense), "
+                      "%.1f s" % (n, wl["N"], dt), "host_cpus": os.cpu_count()}
 
 
 def main():
@@ -164,7 +169,22 @@ def main():
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
 
+    def measure_train():
+        from dh3d_amd import ConfigFactory
+        from dh3d_amd.model import DH3D
+        from dh3d_amd.training import QuadrupletTrainer
+        wl = WORKLOADS["train"]
+        cfg = ConfigFactory("global_config").getconfig()
+        cfg.batch_size, cfg.num_pos, cfg.num_neg, cfg.num_points = 1, 2, 18, wl["N"]
+        model = DH3D(cfg).init_synthetic(0).to(dev).eval().prepare()
+        trainer = QuadrupletTrainer(model)
+        pts = synthetic_clouds(wl["B"], wl["N"], wl["seed"], dev, 0)  # same role-ordered batch on every rank
+        dt = time_steps(lambda p: trainer.step(p), pts, args.steps, args.warmup, dev)
+        return wl["B"] * args.steps / dt, dt / args.steps * 1e3
+
     def measure(workload):
+        if workload == "train":
+            return measure_train()
         wl = WORKLOADS[workload]
         model = build_model(wl["preset"], dev, seed=0)
         pts = synthetic_clouds(wl["B"], wl["N"], wl["seed"], dev, rank)
@@ -179,11 +199,15 @@ def main():
     line = {
         "metric": "point-clouds/sec", "value": value, "unit": "point-clouds/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "strong" if args.workload == "train" else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl["name"], "clouds_per_gpu": wl["B"], "points": wl["N"], "knn": 8,
                    "parallelism": "clouds sharded over %d GPU(s), no data-path collective" % world,
                    "weights": "random-init (no checkpoint blobs exist upstream)", "execution": "hipGraph replay"},
     }
+    if args.workload == "train":
+        line["config"]["execution"] = "eager (fused HIP backbone + autograd head)"
+        args.no_extras = True
+        args.no_cpu_baseline = True
     if rank == 0 and not args.no_extras:
         with torch.no_grad():
             line["roofline"] = flex_conv_roofline(dev)

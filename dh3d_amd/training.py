@@ -1,0 +1,196 @@
+"""Siamese training step of the global-descriptor stage (BASELINE config 4; core/model.py:135-255 with
+core/configs.py:104-144 global_config), sharded over GPUs by cloud.
+
+global_config freezes the local backbone (configs.py:112-113), so a step is:
+  1. frozen backbone + geometry on the fused HIP path (dh3d_amd.model, no autograd),
+  2. the trainable global head -- global_before_assemble flex_conv (backbones.py:178-186), attention MLP
+     (:156-173), NetVLAD + context gating (:202-320) -- with autograd: the custom ops go through the drop-in
+     operators of dh3d_amd.ops (their backward kernels are the registered gradients), the dense algebra and
+     training-mode BatchNorm are plain torch ops on the GPU,
+  3. all-gather of the [clouds_per_rank, 256] descriptors over RCCL (differentiable: backward keeps the
+     rank's own slice, every rank evaluates the identical full loss), lazy quadruplet loss
+     (core/losses.py:173-200), backward, SUM all-reduce of the head gradients, Adam with the staircase
+     exponential learning rate (core/model.py:248-255) and L2 weight decay on '.*/W' (model.py:239-243).
+
+BatchNorm statistics under sharding: per-rank (local) batch statistics by default; `sync_bn=True` all-reduces
+(sum, sum of squares, count) so the statistics equal the reference's single-GPU whole-batch statistics.
+This path favours correctness over speed: it is the parity/coverage path for config 4, not a bench line.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from . import backbones as bb
+from . import dist as D
+from . import losses, ops
+
+
+class _AllGatherKeepOwn(torch.autograd.Function):
+    """all_gather whose backward returns this rank's slice of the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, local):
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            ctx.rank, ctx.n = 0, local.shape[0]
+            return local.clone()
+        world = dist.get_world_size()
+        out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous())
+        ctx.rank, ctx.n = dist.get_rank(), local.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad[ctx.rank * ctx.n:(ctx.rank + 1) * ctx.n].contiguous()
+
+
+def _batch_norm_train(x, channel_dim, gamma, beta, run_mean, run_var, eps, momentum, sync_bn, mask=None):
+    """Training-mode BatchNorm over all dims but `channel_dim`; updates the running buffers in place.
+    `momentum` is the EMA decay (tensorpack 0.9, slim 0.999).  `mask` ([leading] bool) drops padding clouds."""
+    dims = [d for d in range(x.dim()) if d != channel_dim]
+    shape = [1] * x.dim()
+    shape[channel_dim] = -1
+    if mask is not None:
+        w = mask.to(x.dtype).reshape([-1] + [1] * (x.dim() - 1))
+        cnt = w.sum() * (x.numel() / (x.shape[0] * x.shape[channel_dim]))
+        s1 = (x * w).sum(dims)
+        s2 = (x * x * w).sum(dims)
+    else:
+        cnt = torch.tensor(float(x.numel() / x.shape[channel_dim]), device=x.device)
+        s1 = x.sum(dims)
+        s2 = (x * x).sum(dims)
+    if sync_bn and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        import torch.distributed.nn.functional as dfn
+        packed = dfn.all_reduce(torch.cat([s1, s2, cnt.reshape(1)]))
+        C = s1.numel()
+        s1, s2, cnt = packed[:C], packed[C:2 * C], packed[2 * C]
+    mean = s1 / cnt
+    var = s2 / cnt - mean * mean
+    with torch.no_grad():
+        run_mean.mul_(momentum).add_(mean.detach(), alpha=1 - momentum)
+        run_var.mul_(momentum).add_(var.detach(), alpha=1 - momentum)
+    return (x - mean.reshape(shape)) * torch.rsqrt(var.reshape(shape) + eps) * gamma.reshape(shape) + beta.reshape(shape)
+
+
+def _bn(x, channel_dim, bnmod, training, sync_bn, mask):
+    tp = isinstance(bnmod, bb.TPBatchNorm)
+    rm, rv = (bnmod.mean_EMA, bnmod.variance_EMA) if tp else (bnmod.moving_mean, bnmod.moving_variance)
+    if training:
+        return _batch_norm_train(x, channel_dim, bnmod.gamma, bnmod.beta, rm, rv, bnmod.eps, 0.9 if tp else 0.999,
+                                 sync_bn, mask)
+    shape = [1] * x.dim()
+    shape[channel_dim] = -1
+    return (x - rm.reshape(shape)) * torch.rsqrt(rv.reshape(shape) + bnmod.eps) * bnmod.gamma.reshape(shape) + \
+        bnmod.beta.reshape(shape)
+
+
+def global_head_autograd(model, points, localdesc, lv, bn_training=True, sync_bn=False, mask=None):
+    """Differentiable restatement of compute_global (core/model.py:112-133) on the parameters of `model`.
+
+    points [Bt,N,3], localdesc [Bt,N,128] (detached backbone output), lv = geometry level dict
+    (idx, xyz_s, nbr_s, nn3_dist, nn3_idx).  Returns the un-normalised global descriptor [Bt,256]."""
+    gba = model.global_before_assemble
+    fc, fbn = gba.flexconv_0, gba.flexconv_0_bn
+    feat_s = bb.gather_rows(localdesc, lv["idx"])                                   # [Bt,M,128]
+    feats_T = feat_s.transpose(1, 2).contiguous()                                   # [Bt,128,M]
+    pts_T = lv["xyz_s"].transpose(1, 2).contiguous()                                # [Bt,3,M]
+    nbr_T = lv["nbr_s"].transpose(1, 2).contiguous()                                # [Bt,K,M]
+    x = ops.flex_convolution(feats_T, pts_T, nbr_T, fc.position_theta, fc.position_bias) + fc.feature_bias
+    x = F.relu(_bn(x, 1, fbn, bn_training, sync_bn, mask))                          # tf_utils.py:60-63 (NCHW)
+    new_feat = x.transpose(1, 2).contiguous()                                       # [Bt,M,256]
+    d = torch.clamp(lv["nn3_dist"], min=1e-10)                                      # backbones.py:92-95
+    w = (1.0 / d) / (1.0 / d).sum(2, keepdim=True)
+    forglobal = ops.three_interpolate(new_feat, lv["nn3_idx"], w.contiguous())      # [Bt,N,256]
+
+    att_mod = model.globalatt
+    h = forglobal
+    for i in range(len(att_mod.conv_dims)):
+        conv = getattr(att_mod, "detec_conv%d" % i)
+        h = h @ conv.W.reshape(conv.cin, conv.cout) + conv.b
+        h = F.relu(_bn(h, 2, conv.bn, bn_training, sync_bn, mask))
+    fcw = att_mod.detec_conv_fc
+    att = torch.sigmoid(h @ fcw.W.reshape(fcw.cin, 1) + fcw.b)                      # [Bt,N,1]
+
+    nv = model._netvlad
+    Bt, N, Dm = forglobal.shape
+    xr = forglobal.reshape(-1, Dm)
+    xr = xr * torch.rsqrt(torch.clamp((xr * xr).sum(1, keepdim=True), min=1e-12))   # tf.nn.l2_normalize
+    act = xr @ nv.cluster_weights
+    pmask = mask.repeat_interleave(N) if mask is not None else None
+    act = _bn(act, 1, nv.cluster_bn, bn_training, sync_bn, pmask)
+    act = torch.softmax(act, dim=1) * att.reshape(-1, 1)
+    act = act.reshape(Bt, N, nv.C)
+    a = act.sum(1, keepdim=True) * nv.cluster_weights2                               # [Bt,D,C]
+    vlad = torch.matmul(act.transpose(1, 2), xr.reshape(Bt, N, Dm)).transpose(1, 2) - a
+    vlad = vlad * torch.rsqrt(torch.clamp((vlad * vlad).sum(1, keepdim=True), min=1e-12))
+    vlad = vlad.reshape(Bt, nv.C * Dm)
+    vlad = vlad * torch.rsqrt(torch.clamp((vlad * vlad).sum(1, keepdim=True), min=1e-12))
+    v = _bn(vlad @ nv.hidden1_weights, 1, nv.bn, bn_training, sync_bn, mask)
+    gates = _bn(v @ nv.gating_weights, 1, nv.gating_bn, bn_training, sync_bn, mask)
+    return v * torch.sigmoid(gates)
+
+
+def trainable_head_parameters(model):
+    """Parameters that global_config trains (backbone frozen: configs.py:112-113)."""
+    mods = [model.global_before_assemble, model.globalatt, model._netvlad]
+    seen, out = set(), []
+    for mod in mods:
+        for p in mod.parameters():
+            if id(p) not in seen:
+                seen.add(id(p))
+                out.append(p)
+    return out
+
+
+class QuadrupletTrainer(object):
+    """One process per GPU.  `step(points)` takes the role-ordered batch [B*(1+P+Ng+1), N, 3] (identical on
+    every rank, e.g. generated from a shared seed), runs this rank's block and returns the loss."""
+
+    def __init__(self, model, start_lr=5e-4, decay_step=20000, decay_rate=0.9, weight_decay=1e-5, sync_bn=False):
+        self.model = model
+        self.cfg = model.config
+        self.sync_bn = sync_bn
+        self.params = trainable_head_parameters(model)
+        self.wd_params = [p for n, p in model.named_parameters() if n.endswith(".W")
+                          and any(p is q for q in self.params)]
+        self.weight_decay = weight_decay
+        self.opt = torch.optim.Adam(self.params, lr=start_lr)
+        self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, lambda s: decay_rate ** (s // decay_step))
+
+    def forward_loss(self, points):
+        cfg = self.cfg
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        Bt = points.shape[0]
+        block, mask = D.shard_batch(points, rank, world)
+        self.model.eval()  # frozen backbone: fused inference path
+        with torch.no_grad():
+            geo = self.model._geometry(block, None)
+            _, localdesc = self.model.compute_local(block, _geo=geo)
+            lv = geo.level(8, self.model.knn_num)
+        desc = global_head_autograd(self.model, block, localdesc.detach(), lv, bn_training=True,
+                                    sync_bn=self.sync_bn, mask=mask if not bool(mask.all()) else None)
+        desc = desc * torch.rsqrt(torch.clamp((desc * desc).sum(1, keepdim=True), min=1e-8))  # model.py:205
+        full = _AllGatherKeepOwn.apply(desc)[:Bt]
+        loss = losses.lazy_quadruplet_loss(full, cfg.batch_size, cfg.num_pos, cfg.num_neg,
+                                           cfg.global_triplet_margin or 0.5, cfg.global_quadruplet_margin or 0.2)
+        return loss
+
+    def step(self, points):
+        # NOTE: the head trains on the raw parameters; call model.prepare() again before fused inference.
+        self.opt.zero_grad(set_to_none=True)
+        loss = self.forward_loss(points)
+        wd = sum((p * p).sum() for p in self.wd_params) * (0.5 * self.weight_decay) if self.wd_params else 0.0
+        rank0_only_wd = wd if (not dist.is_initialized() or dist.get_rank() == 0) else wd * 0.0
+        (loss + rank0_only_wd).backward()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)  # every rank holds a partial of the SAME loss
+            off = 0
+            for p in self.params:
+                n = p.numel()
+                p.grad = flat[off:off + n].reshape(p.shape).clone()
+                off += n
+        self.opt.step()
+        self.sched.step()
+        return float(loss.detach())

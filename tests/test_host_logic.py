@@ -102,8 +102,15 @@ out = D.all_gather_descriptors(local, Bt)
 assert torch.equal(out, full), (rank, out)
 t = D.max_over_ranks(float(rank + 1), torch.device("cpu"))
 assert t == float(world)
+# differentiable all-gather: backward keeps this rank's slice of the gradient
+from dh3d_amd.training import _AllGatherKeepOwn
+x = torch.full((per, Dd), float(rank + 1), requires_grad=True)
+g = _AllGatherKeepOwn.apply(x)
+w = torch.arange(g.numel(), dtype=torch.float32).reshape(g.shape)
+(g * w).sum().backward()
+assert torch.equal(x.grad, w[rank * per:(rank + 1) * per]), (rank, x.grad)
 D.barrier()
-print("rank", rank, "ok")
+open(os.path.join(%r, "rank%%d.ok" %% rank), "w").write("ok")
 """
 
 
@@ -113,10 +120,10 @@ def test_all_gather_world_size_2_gloo(tmp_path):
         sk.bind(("127.0.0.1", 0))
         port = str(sk.getsockname()[1])
     script = tmp_path / "worker.py"
-    script.write_text(_WORKER % ROOT)
+    script.write_text(_WORKER % (ROOT, str(tmp_path)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                         "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
                        env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+    assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()  # (stdout of 2 ranks interleaves)
