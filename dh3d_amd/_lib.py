@@ -67,6 +67,9 @@ _SIGNATURES = {
     "dh3d_l2norm_concat_fwd": [c_fp, c_int, c_int, c_float, c_fp, c_int, c_fp, c_fp],
     "dh3d_mlp_head_pm_fwd": [c_fp, c_int, c_int, c_fp, c_int, ctypes.POINTER(Epilogue), c_fp, c_float, c_fp,
                              c_fp],
+    "dh3d_pack_weight_x3": [c_fp, c_int, c_int, c_fp, c_fp],
+    "dh3d_mlp_head_pm_x6_fwd": [c_fp, c_int, c_int, c_fp, c_int, ctypes.POINTER(Epilogue), c_fp, c_float, c_fp,
+                                c_fp],
     "dh3d_netvlad_workspace_bytes": [c_int, c_int, c_int, c_int],
     "dh3d_netvlad_aggregate_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp,
                                    c_size_t, c_fp, c_fp],

@@ -100,50 +100,58 @@ __global__ __launch_bounds__(256) void mlp_head_pm_kernel(const float *__restric
                                                          float b_fc, long long R,
                                                          float *__restrict__ att) {
   extern __shared__ __attribute__((aligned(16))) float s_A[];
-  __shared__ float s_part[2][kTM];  // [column-half wave group][row]
+  __shared__ float s_part[4][kTM];  // [wave][row]
   const int ld = C + 4;
   const long long grow0 = (long long)blockIdx.x * kTM;
   stage_rows(h, C, h, 0, grow0, R, s_A, ld);  // (a literal nullptr here crashes hipcc 7.2's inliner)
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int row0 = (wave & 1) * 32;
   const int NB = H / 32;
-  float part[16];
+  float part[2][16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) part[r] = 0.f;
-  // wave (row block rb, column parity cp) walks column blocks cp, cp+2, ... two at a time
-  for (int cb = (wave >> 1); cb < NB; cb += 4) {
-    f32x16 acc[2];
-    zero_acc<2>(acc);
-    wave_gemm_f32<2>(s_A, ld, row0, wpacked, C / 8, cb, 2, acc);
+  for (int q = 0; q < 2; ++q)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = (cb + 2 * j) * 32 + (lane & 31);
-      float pb = 0.f, sc = 1.f, sh = 0.f;
-      if (ep.pre_bias) pb = ep.pre_bias[col];
-      if (ep.scale) sc = ep.scale[col];
-      if (ep.shift) sh = ep.shift[col];
-      const float wf = w_fc[col];
+    for (int r = 0; r < 16; ++r) part[q][r] = 0.f;
+  // wave w owns column blocks w, w+4, ... and BOTH row blocks: each weight fragment is fetched once per WG
+  for (int cb = wave; cb < NB; cb += 4) {
+    f32x16 acc[2][1];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) part[r] = fmaf(dh3d_act((acc[j][r] + pb) * sc + sh, ep.act), wf, part[r]);
-    }
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][0][r] = 0.f;
+    wave_gemm_f32_rows2<1>(s_A, ld, wpacked, C / 8, cb, 1, acc);
+    const int col = cb * 32 + (lane & 31);
+    float pb = 0.f, sc = 1.f, sh = 0.f;
+    if (ep.pre_bias) pb = ep.pre_bias[col];
+    if (ep.scale) sc = ep.scale[col];
+    if (ep.shift) sh = ep.shift[col];
+    const float wf = w_fc[col];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        part[q][r] = fmaf(dh3d_act((acc[q][0][r] + pb) * sc + sh, ep.act), wf, part[q][r]);
   }
   // reduce over the 32 columns held by the lanes of each half-wave
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
+  for (int q = 0; q < 2; ++q)
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) part[r] += __shfl_xor(part[r], off, 64);
-  }
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) part[q][r] += __shfl_xor(part[q][r], off, 64);
+    }
   if ((lane & 31) == 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s_part[wave >> 1][row0 + mfma_row(r, lane)] = part[r];
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_part[wave][q * 32 + mfma_row(r, lane)] = part[q][r];
   }
   __syncthreads();
   if (threadIdx.x < kTM) {
     const long long g = grow0 + threadIdx.x;
     if (g < R) {
-      const float logit = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + b_fc;
+      const float logit = (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]) + b_fc;
       att[g] = 1.f / (1.f + expf(-logit));
     }
   }

@@ -84,6 +84,50 @@ __device__ __forceinline__ void wave_gemm_f32(const float *s_A, int ldA, int row
   }
 }
 
+// Both 32-row blocks of a 64-row LDS tile against NTC column blocks (cb0, cb0+cbstride, ...): every packed
+// weight fragment is fetched by exactly ONE wave of the workgroup and used for two MFMA row blocks.  (With
+// the (row block, column half) split above two waves fetch each fragment; at 2 workgroups per CU that put
+// ~20 TB/s of weight traffic on the L2s and capped the wide layers at ~60 % of the matrix pipe.)
+template <int NTC>
+__device__ __forceinline__ void wave_gemm_f32_rows2(const float *s_A, int ldA, const float *__restrict__ wpacked,
+                                                    int KB, int cb0, int cbstride, f32x16 (&acc)[2][NTC]) {
+  const int lane = threadIdx.x & 63;
+  const float *aptr0 = s_A + (size_t)(lane & 31) * ldA + 4 * (lane >> 5);
+  const float *aptr1 = aptr0 + (size_t)32 * ldA;
+  const f32x4 *wp = reinterpret_cast<const f32x4 *>(wpacked) + lane;
+  f32x4 nxt[2][NTC];  // two k-blocks in flight
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int j = 0; j < NTC; ++j) nxt[u][j] = wp[(size_t)((cb0 + j * cbstride) * KB + (u < KB ? u : 0)) * 64];
+  for (int kb = 0; kb < KB; kb += 2) {
+    f32x4 cur[2][NTC];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < NTC; ++j) {
+        cur[u][j] = nxt[u][j];
+        const int kn = kb + 2 + u;
+        if (kn < KB) nxt[u][j] = wp[(size_t)((cb0 + j * cbstride) * KB + kn) * 64];
+      }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (kb + u < KB) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(aptr0 + (kb + u) * 8);
+        const f32x4 a1 = *reinterpret_cast<const f32x4 *>(aptr1 + (kb + u) * 8);
+#pragma unroll
+        for (int j = 0; j < NTC; ++j) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], cur[u][j][t], acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], cur[u][j][t], acc[1][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ int mfma_row(int reg, int lane) {
   return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
 }

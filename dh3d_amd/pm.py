@@ -186,6 +186,27 @@ def mlp_head(h, wpacked, H, w_fc, b_fc, pre_bias=None, scale=None, shift=None, a
     return out
 
 
+def pack_weight_x3(W):
+    """W [Kd, Dout] f32 -> three exact bf16 chunk planes in MFMA fragment order (csrc/dense_x6.hip)."""
+    W = L.require_cuda_f32(W, "W", 2)
+    out = torch.empty((3 * W.shape[0] * W.shape[1],), dtype=torch.int16, device=W.device)
+    L.check(L.lib().dh3d_pack_weight_x3(L.ptr(W), W.shape[0], W.shape[1], L.ptr(out), L.stream_ptr()),
+            "pack_weight_x3")
+    return out
+
+
+def mlp_head_x6(h, wpacked_x3, H, w_fc, b_fc, pre_bias=None, scale=None, shift=None, act=ACT_RELU):
+    """mlp_head with the 256 -> 1024 GEMM on the bf16 pipe at f32 accuracy (six exact-chunk products)."""
+    a = L.require_cuda_f32(h, "h")
+    C = a.shape[-1]
+    R = a.numel() // C
+    out = torch.empty(a.shape[:-1] + (1,), dtype=torch.float32, device=a.device)
+    ep = _ep(pre_bias, scale, shift, act)
+    L.check(L.lib().dh3d_mlp_head_pm_x6_fwd(L.ptr(a), R, C, L.ptr(wpacked_x3), H, ep, L.ptr(w_fc), float(b_fc),
+                                            L.ptr(out), L.stream_ptr()), "mlp_head_pm_x6")
+    return out
+
+
 def netvlad_aggregate(x, att, wc_packed, bn_scale, bn_shift, W2):
     a = L.require_cuda_f32(x, "x", 3)
     B, N, D = a.shape

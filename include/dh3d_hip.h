@@ -216,6 +216,13 @@ int dh3d_mlp_head_pm_fwd(const float *h, int R, int C, const float *wpacked, int
                          const dh3d_epilogue *ep, const float *w_fc, float b_fc, float *att,
                          void *stream);
 
+/* The same head with the GEMM on the bf16 matrix pipe at f32 accuracy ("bf16x6": every f32 operand is split
+ * exactly into three bf16 chunks, six chunk products are accumulated in f32; error <= 2^-23 per product, see
+ * csrc/dense_x6.hip).  wpacked_x3 from dh3d_pack_weight_x3 (3 * Kd * Dout * 2 bytes).  C % 16 == 0. */
+int dh3d_pack_weight_x3(const float *W, int Kd, int Dout, void *packed, void *stream);
+int dh3d_mlp_head_pm_x6_fwd(const float *h, int R, int C, const void *wpacked_x3, int H,
+                            const dh3d_epilogue *ep, const float *w_fc, float b_fc, float *att, void *stream);
+
 /* Attention-weighted NetVLAD aggregation (core/backbones.py:202-262), stage 1+2:
  *   xn = l2norm(x); a = softmax(bn(xn @ Wc)) * att;  vlad[b,d,c] = sum_n a[n,c] xn[n,d] - (sum_n a[n,c]) W2[d,c]
  *   then intra-normalise over d per cluster and L2-normalise the flattened [D*Cl] vector (d-major).

@@ -180,3 +180,31 @@ def test_netvlad_vs_restatement(dev, B, N):
     out2 = pm.netvlad_head(vlad, T(w["hidden1_weights"], dev), s1, h1, T(w["gating_weights"], dev), s2, h2,
                            l2_eps=1e-8).cpu().numpy()
     assert close(out2, exp / np.linalg.norm(exp, axis=1, keepdims=True), 1e-4, 1e-5)
+
+
+def test_mlp_head_bf16x6_is_f32_accurate(dev):
+    """The bf16x6 head against float64 and against the f32-MFMA head: same answer to f32 rounding."""
+    from dh3d_amd import pm
+    rng = np.random.default_rng(77)
+    R, C, H = 1000, 256, 1024
+    h = (rng.standard_normal((R, C)) * np.exp(rng.standard_normal((R, 1)))).astype(np.float32)  # wide dynamic range
+    W = (rng.standard_normal((C, H)) / 16).astype(np.float32)
+    b = rng.standard_normal(H).astype(np.float32)
+    sc = (0.5 + rng.random(H)).astype(np.float32); sh = rng.standard_normal(H).astype(np.float32)
+    wfc = (rng.standard_normal(H) / 32).astype(np.float32)
+    kw = dict(pre_bias=T(b, dev), scale=T(sc, dev), shift=T(sh, dev))
+    a6 = pm.mlp_head_x6(T(h, dev), pm.pack_weight_x3(T(W, dev)), H, T(wfc, dev), 0.125, **kw).cpu().numpy()[:, 0]
+    a1 = pm.mlp_head(T(h, dev), pm.pack_weight(T(W, dev)), H, T(wfc, dev), 0.125, **kw).cpu().numpy()[:, 0]
+    hid = np.maximum((h.astype(np.float64) @ W + b) * sc + sh, 0)
+    logit = hid @ wfc + 0.125
+    exp = 1 / (1 + np.exp(-logit))
+    e6, e1 = np.abs(a6 - exp).max(), np.abs(a1 - exp).max()
+    assert e6 < 2e-6 and e6 < 4 * e1 + 1e-6, (e6, e1)
+    # the pre-sigmoid sums themselves: compare a linear head (no activation, unit fc) at full relative precision
+    ones = np.ones(H, np.float32)
+    lin6 = pm.mlp_head_x6(T(h, dev), pm.pack_weight_x3(T(W, dev)), H, T(ones, dev), 0.0, act=pm.ACT_NONE).cpu().numpy()[:, 0]
+    s = (h.astype(np.float64) @ W).sum(1)
+    mag = (np.abs(h.astype(np.float64)) @ np.abs(W)).sum(1)
+    z6 = np.log(lin6 / (1 - lin6))  # undo the sigmoid
+    ok = np.abs(s) < 10
+    assert np.all(np.abs(z6[ok] - s[ok]) <= 5e-7 * mag[ok] + 1e-5)

@@ -45,3 +45,12 @@ for B, N in ((8, 8192), (32, 4096)):
         wp = pm.pack_flex_weight(torch.randn(3, Din, Dout, generator=g).to(dev), torch.randn(Din, Dout, generator=g).to(dev))
         t = ev(lambda: pm.flex_conv(f, xs, nbs, wp, Dout, act=pm.ACT_RELU))
         print("  flex_conv %3d->%3d @N/8 %7.1f us  %5.1f TF/s" % (Din, Dout, t, 2.0 * B * (N // 8) * 4 * Din * (8 + Dout) / t / 1e6))
+for R in (65536, 131072):
+    x = torch.randn(R, 256, generator=g).to(dev)
+    W = (torch.randn(256, 1024, generator=g) / 16).to(dev)
+    wfc = torch.randn(1024, generator=g).to(dev)
+    w6 = pm.pack_weight_x3(W); w1 = pm.pack_weight(W)
+    t1 = ev(lambda: pm.mlp_head(x, w1, 1024, wfc, 0.1), iters=10)
+    t6 = ev(lambda: pm.mlp_head_x6(x, w6, 1024, wfc, 0.1), iters=10)
+    print("R=%d mlp_head f32-MFMA %7.1f us (%5.1f TF/s)   bf16x6 %7.1f us (%5.1f f32-equivalent TF/s)" % (
+        R, t1, 2.0 * R * 256 * 1024 / t1 / 1e6, t6, 2.0 * R * 256 * 1024 / t6 / 1e6))
