@@ -160,78 +160,112 @@ __device__ __forceinline__ float block_sum(float v, float *s_red) {
   return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
-// grid (B), block 256: thread t owns feature d = t for all 64 clusters.
+// grid (8, B), block 256: workgroup (cg, b) finishes clusters 8*cg .. 8*cg+7 of cloud b; thread t owns
+// feature d = t.  (One workgroup per cloud left 224 CUs idle behind a 143 us serial tail: profiles/r01_c.)
+constexpr int kCG = 8;  // clusters per workgroup
 __global__ __launch_bounds__(256) void netvlad_finalize(const float *__restrict__ part_vlad,
                                                        const float *__restrict__ part_asum,
                                                        const float *__restrict__ W2 /*[D][Cl]*/,
-                                                       int chunks, float *__restrict__ vlad /*[B][D*Cl]*/) {
-  __shared__ float s_asum[kCl];
-  __shared__ float s_csq[4][kCl];
+                                                       int chunks, float *__restrict__ vlad /*[B][D*Cl]*/,
+                                                       float *__restrict__ tot /*[B][Cl/kCG]*/) {
+  __shared__ float s_csq[4][kCG];
   __shared__ float s_red[4];
-  const int b = blockIdx.x, d = threadIdx.x, lane = d & 63, wave = d >> 6;
-  if (d < kCl) {
-    float s = 0.f;
-    for (int ch = 0; ch < chunks; ++ch) s += part_asum[((size_t)b * chunks + ch) * kCl + d];
-    s_asum[d] = s;
-  }
-  __syncthreads();
-  float v[kCl];
+  const int b = blockIdx.y, c0 = blockIdx.x * kCG, d = threadIdx.x, lane = d & 63, wave = d >> 6;
+  float v[kCG];
 #pragma unroll
-  for (int c = 0; c < kCl; ++c) {
-    float s = 0.f;
-    for (int ch = 0; ch < chunks; ++ch) s += part_vlad[(((size_t)b * chunks + ch) * kCl + c) * kD + d];
-    v[c] = s - s_asum[c] * W2[(size_t)d * kCl + c];  // vlad - a_sum * cluster_weights2 (backbones.py:249-256)
+  for (int c = 0; c < kCG; ++c) {
+    float s = 0.f, as = 0.f;
+    for (int ch = 0; ch < chunks; ++ch) {  // fixed order: deterministic
+      s += part_vlad[(((size_t)b * chunks + ch) * kCl + c0 + c) * kD + d];
+      as += part_asum[((size_t)b * chunks + ch) * kCl + c0 + c];
+    }
+    v[c] = s - as * W2[(size_t)d * kCl + c0 + c];  // vlad - a_sum * cluster_weights2 (backbones.py:249-256)
   }
-  // intra-normalisation: per cluster c over the 256 features (tf.nn.l2_normalize(vlad, 1))
+  // intra-normalisation: per cluster over the 256 features (tf.nn.l2_normalize(vlad, 1))
 #pragma unroll
-  for (int c = 0; c < kCl; ++c) {
+  for (int c = 0; c < kCG; ++c) {
     float sq = v[c] * v[c];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
     if (lane == 0) s_csq[wave][c] = sq;
   }
   __syncthreads();
-  float tot = 0.f;
+  float t = 0.f;
 #pragma unroll
-  for (int c = 0; c < kCl; ++c) {
+  for (int c = 0; c < kCG; ++c) {
     const float csq = (s_csq[0][c] + s_csq[1][c]) + (s_csq[2][c] + s_csq[3][c]);
     v[c] *= rsqrtf(fmaxf(csq, 1e-12f));
-    tot = fmaf(v[c], v[c], tot);
+    t = fmaf(v[c], v[c], t);
   }
-  const float all = block_sum(tot, s_red);
-  const float inv = rsqrtf(fmaxf(all, 1e-12f));
-  float *o = vlad + (size_t)b * kD * kCl + (size_t)d * kCl;  // flatten d-major: index d*Cl + c
-#pragma unroll
-  for (int c = 0; c < kCl; c += 4)
-    *reinterpret_cast<float4 *>(o + c) = make_float4(v[c] * inv, v[c + 1] * inv, v[c + 2] * inv, v[c + 3] * inv);
+  const float all = block_sum(t, s_red);
+  if (d == 0) tot[(size_t)b * (kCl / kCG) + blockIdx.x] = all;
+  float *o = vlad + (size_t)b * kD * kCl + (size_t)d * kCl + c0;  // flatten d-major: index d*Cl + c
+  *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4 *>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
 }
 
-// Split-K projection: grid (KS, ceil(B/32)); block 256 = one thread per output column (O == 256).
-constexpr int kKSlice = 128;
+// whole-vector L2 normalisation (backbones.py:261): grid (8, B); scale = rsqrt(max(sum of the 8 partials, eps))
+__global__ __launch_bounds__(256) void netvlad_l2scale(const float *__restrict__ tot, float *__restrict__ vlad) {
+  const int b = blockIdx.y;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < kCl / kCG; ++i) s += tot[(size_t)b * (kCl / kCG) + i];
+  const float inv = rsqrtf(fmaxf(s, 1e-12f));
+  float4 *p = reinterpret_cast<float4 *>(vlad + (size_t)b * kD * kCl) + (size_t)blockIdx.x * 512 + threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float4 x = p[i * 256];
+    x.x *= inv; x.y *= inv; x.z *= inv; x.w *= inv;
+    p[i * 256] = x;
+  }
+}
+
+// Split-K projection on the f32 MFMA pipe: grid (KS, ceil(B/32)); workgroup = 32 rows x 256-deep k slice x
+// all 256 outputs.  A = vlad slice staged in LDS; B = Wh rows read in place (lanes 0..31 of a fragment are 32
+// consecutive outputs of one row: 128-byte segments), so the 16.8 MB weight streams from HBM exactly once.
+constexpr int kKSlice = 256;
 __global__ __launch_bounds__(256) void netvlad_hidden_splitk(const float *__restrict__ vlad,
                                                             const float *__restrict__ Wh, int B, int Kd,
                                                             int O, float *__restrict__ part /*[KS][B][O]*/) {
-  __shared__ float s_v[32][kKSlice + 1];
-  const int ks = blockIdx.x, b0 = blockIdx.y * 32, o = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) float s_v[32 * (kKSlice + 4)];
+  constexpr int LD = kKSlice + 4;
+  const int ks = blockIdx.x, b0 = blockIdx.y * 32;
   const int k0 = ks * kKSlice;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nb = min(32, B - b0);
-  for (int e = threadIdx.x; e < 32 * kKSlice; e += 256) {
-    const int bb = e / kKSlice, k = e % kKSlice;
-    s_v[bb][k] = (bb < nb && k0 + k < Kd) ? vlad[(size_t)(b0 + bb) * Kd + k0 + k] : 0.f;
+  for (int e = tid; e < 32 * (kKSlice / 4); e += 256) {
+    const int bb = e / (kKSlice / 4), k4 = (e % (kKSlice / 4)) * 4;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bb < nb && k0 + k4 < Kd) x = *reinterpret_cast<const float4 *>(vlad + (size_t)(b0 + bb) * Kd + k0 + k4);
+    *reinterpret_cast<float4 *>(s_v + (size_t)bb * LD + k4) = x;
   }
   __syncthreads();
-  float acc[32];
-#pragma unroll
-  for (int bb = 0; bb < 32; ++bb) acc[bb] = 0.f;
+  f32x16 acc[2];
+  zero_acc<2>(acc);
+  const float *aptr = s_v + (size_t)(lane & 31) * LD + 4 * (lane >> 5);
   const int klen = min(kKSlice, Kd - k0);
-  for (int k = 0; k < klen; ++k) {
-    const float w = Wh[(size_t)(k0 + k) * O + o];
+  for (int kb = 0; kb < klen / 8; ++kb) {
+    const f32x4 a4 = *reinterpret_cast<const f32x4 *>(aptr + kb * 8);
+    const float *wrow = Wh + (size_t)(k0 + kb * 8 + 4 * (lane >> 5)) * O + (lane & 31);
 #pragma unroll
-    for (int bb = 0; bb < 32; ++bb) acc[bb] = fmaf(s_v[bb][k], w, acc[bb]);
+    for (int j = 0; j < 2; ++j) {
+      const int o0 = (wave + 4 * j) * 32;
+      const float w0 = wrow[o0], w1 = wrow[(size_t)O + o0], w2 = wrow[(size_t)2 * O + o0], w3 = wrow[(size_t)3 * O + o0];
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0], w0, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1], w1, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[2], w2, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[3], w3, acc[j], 0, 0, 0);
+    }
   }
 #pragma unroll
-  for (int bb = 0; bb < 32; ++bb)
-    if (bb < nb) part[((size_t)ks * B + b0 + bb) * O + o] = acc[bb];
+  for (int j = 0; j < 2; ++j) {
+    const int o = (wave + 4 * j) * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int bb = mfma_row(r, lane);
+      if (bb < nb) part[((size_t)ks * B + b0 + bb) * O + o] = acc[j][r];
+    }
+  }
 }
 
 // grid (B), block 256 (O == 256): reduce split-K, BN, gating, optional final l2-normalise.
@@ -245,13 +279,27 @@ __global__ __launch_bounds__(256) void netvlad_gate(const float *__restrict__ pa
   __shared__ float s_h[256];
   __shared__ float s_red[4];
   const int b = blockIdx.x, o = threadIdx.x;
-  float h = 0.f;
-  for (int ks = 0; ks < KS; ++ks) h += part[((size_t)ks * B + b) * O + o];
+  float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;  // fixed association: deterministic
+  int ks = 0;
+  for (; ks + 3 < KS; ks += 4) {
+    h0 += part[((size_t)ks * B + b) * O + o];
+    h1 += part[((size_t)(ks + 1) * B + b) * O + o];
+    h2 += part[((size_t)(ks + 2) * B + b) * O + o];
+    h3 += part[((size_t)(ks + 3) * B + b) * O + o];
+  }
+  for (; ks < KS; ++ks) h0 += part[((size_t)ks * B + b) * O + o];
+  float h = (h0 + h1) + (h2 + h3);
   h = fmaf(h, bn1_scale[o], bn1_shift[o]);
   s_h[o] = h;
   __syncthreads();
-  float g = 0.f;
-  for (int j = 0; j < O; ++j) g = fmaf(s_h[j], Wg[(size_t)j * O + o], g);
+  float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+  for (int j = 0; j < O; j += 4) {
+    g0 = fmaf(s_h[j], Wg[(size_t)j * O + o], g0);
+    g1 = fmaf(s_h[j + 1], Wg[(size_t)(j + 1) * O + o], g1);
+    g2 = fmaf(s_h[j + 2], Wg[(size_t)(j + 2) * O + o], g2);
+    g3 = fmaf(s_h[j + 3], Wg[(size_t)(j + 3) * O + o], g3);
+  }
+  float g = (g0 + g1) + (g2 + g3);
   g = fmaf(g, bn2_scale[o], bn2_shift[o]);
   float v = h * (1.f / (1.f + expf(-g)));
   if (l2_eps > 0.f) {
@@ -266,7 +314,7 @@ __global__ __launch_bounds__(256) void netvlad_gate(const float *__restrict__ pa
 DH3D_API size_t dh3d_netvlad_workspace_bytes(int B, int N, int D, int Cl) {
   if (B <= 0 || N <= 0 || D != kD || Cl != kCl) return 0;
   const int ch = netvlad_chunks(B, N);
-  return sizeof(float) * ((size_t)B * ch * kCl * kD + (size_t)B * ch * kCl);
+  return sizeof(float) * ((size_t)B * ch * kCl * kD + (size_t)B * ch * kCl + (size_t)B * (kCl / kCG));
 }
 
 DH3D_API int dh3d_netvlad_aggregate_fwd(const float *x, const float *att, const float *wc_packed,
@@ -285,7 +333,9 @@ DH3D_API int dh3d_netvlad_aggregate_fwd(const float *x, const float *att, const 
   DH3D_ALLOW_BIG_LDS(kern);
   hipLaunchKernelGGL(kern, dim3(ch, B), dim3(256), lds, s, x, att, wc_packed, bn_scale, bn_shift, N, ch,
                      part_vlad, part_asum);
-  hipLaunchKernelGGL(netvlad_finalize, dim3(B), dim3(256), 0, s, part_vlad, part_asum, W2, ch, vlad);
+  float *tot = part_asum + (size_t)B * ch * kCl;
+  hipLaunchKernelGGL(netvlad_finalize, dim3(kCl / kCG, B), dim3(256), 0, s, part_vlad, part_asum, W2, ch, vlad, tot);
+  hipLaunchKernelGGL(netvlad_l2scale, dim3(kCl / kCG, B), dim3(256), 0, s, tot, vlad);
   return dh3d_launch_status();
 }
 
