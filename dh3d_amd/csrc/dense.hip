@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void linear_pm_kernel(const float *__restrict_
                                                        int Dout, EpilogueArgs ep,
                                                        const float *__restrict__ residual,
                                                        float *__restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float s_A[];
+  extern __shared__ __attribute__((aligned(16))) float s_A[];  // max(Kd, Dout) + 4 floats per row
   const int Kd = C1 + C2;
   const int ld = Kd + 4;
   const long long grow0 = (long long)blockIdx.x * kTM;
@@ -88,8 +88,16 @@ __global__ __launch_bounds__(256) void linear_pm_kernel(const float *__restrict_
   const int cb0 = wave >> 1;
   f32x16 acc[NT];
   zero_acc<NT>(acc);
+  EpilogueRegs er[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) er[j] = epilogue_prefetch(ep, (cb0 + 2 * j) * 32 + (threadIdx.x & 31));
   wave_gemm_f32<NT>(s_A, ld, row0, wpacked, Kd / 8, cb0, 2, acc);
-  wave_store_f32<NT>(acc, grow0, row0, cb0, 2, R, Dout, ep, residual, out);
+  // wide epilogue: tile -> LDS (A is dead) -> float4 rows (+ residual)
+  const int ldo = Dout + 4;
+  __syncthreads();
+  wave_tiles_to_lds<NT>(acc, er, ep.act, s_A, ldo, row0, cb0, 2);
+  __syncthreads();
+  block_store_rows(s_A, ldo, kTM, grow0, R, Dout, residual, out);
 }
 
 // ------------------------------------------------------------------ MLP head (wide hidden layer kept on chip)
@@ -270,7 +278,7 @@ DH3D_API int dh3d_linear_pm_fwd(const float *x1, int C1, const float *x2, int C2
   DH3D_REQUIRE(x1 && wpacked && out && R > 0 && C1 > 0 && C2 >= 0 && Dout > 0 && (C2 == 0 || x2));
   const int Kd = C1 + C2;
   DH3D_SUPPORTED(C1 % 4 == 0 && C2 % 4 == 0 && Kd % 8 == 0 && Dout % 64 == 0 && Dout <= 256 && Kd <= 512);
-  const size_t lds = sizeof(float) * kTM * (Kd + 4);
+  const size_t lds = sizeof(float) * kTM * ((Kd > Dout ? Kd : Dout) + 4);
   const EpilogueArgs e = dh3d_ep(ep);
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(dh3d_cdiv(R, kTM)), block(256);

@@ -32,7 +32,15 @@ struct FlexCfg {
   static_assert(NT >= 1 && NB * MB % 4 == 0, "tile must split over 4 waves");
 };
 
-template <int DIN, int DOUT>
+#ifdef DH3D_FLEX_PROBE  // dev instrumentation (tools/flex_probe.py): cycle stamps of a few workgroups
+__device__ long long g_fprobe[64 * 8];
+#define FPROBE(i) do { if (threadIdx.x == 0 && blockIdx.x < 64) g_fprobe[blockIdx.x * 8 + (i)] = clock64(); } while (0)
+#else
+#define FPROBE(i) do { } while (0)
+#endif
+
+// KT = compile-time neighbourhood size (8 on the DH3D path) or 0 for a run-time K.
+template <int DIN, int DOUT, int KT>
 __global__ __launch_bounds__(256) void flex_conv_pm_kernel(
     const float *__restrict__ feat, const float *__restrict__ xyz, const int32_t *__restrict__ nbr,
     const float *__restrict__ wpacked, long long R, int N, int K, EpilogueArgs ep,
@@ -43,34 +51,95 @@ __global__ __launch_bounds__(256) void flex_conv_pm_kernel(
   const long long grow0 = (long long)dh3d_xcd_remap(blockIdx.x, gridDim.x) * C::TM;
 
   // ---- phase A: gather-reduce S = [S0|Sx|Sy|Sz] for TM points
+  FPROBE(0);
   const int r4 = (tid % C::LPR) * 4;
+  if (KT > 0) {
+    // Two dependent memory round trips for the whole tile instead of ~5 per round: (1) every round's
+    // neighbour ids, (2) every neighbour row + coordinate of two rounds at a time, all in flight together.
+    // (The round-by-round form spent ~16k cycles per tile waiting on vmcnt(0): profiles/r01_e.)
+    constexpr int KK = KT > 0 ? KT : 1;
+    int nid[C::ROUNDS][KK];
+    float pxyz[C::ROUNDS][3];
+    long long cloud0[C::ROUNDS];
+    bool ok[C::ROUNDS];
 #pragma unroll
-  for (int rd = 0; rd < C::ROUNDS; ++rd) {
-    const int p = rd * C::PPR + tid / C::LPR;
-    const long long n = grow0 + p;
-    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), sx = s0, sy = s0, sz = s0;
-    if (n < R) {
-      const long long cloud0 = (n / N) * N;
-      const float px = xyz[n * 3], py = xyz[n * 3 + 1], pz = xyz[n * 3 + 2];
-      const int32_t *nb = nbr + n * K;
-#pragma unroll 4
-      for (int k = 0; k < K; ++k) {
-        const long long g = cloud0 + nb[k];
-        const float4 f = *reinterpret_cast<const float4 *>(feat + g * DIN + r4);
-        const float dx = xyz[g * 3] - px, dy = xyz[g * 3 + 1] - py, dz = xyz[g * 3 + 2] - pz;
-        s0.x += f.x; s0.y += f.y; s0.z += f.z; s0.w += f.w;
-        sx.x = fmaf(dx, f.x, sx.x); sx.y = fmaf(dx, f.y, sx.y); sx.z = fmaf(dx, f.z, sx.z); sx.w = fmaf(dx, f.w, sx.w);
-        sy.x = fmaf(dy, f.x, sy.x); sy.y = fmaf(dy, f.y, sy.y); sy.z = fmaf(dy, f.z, sy.z); sy.w = fmaf(dy, f.w, sy.w);
-        sz.x = fmaf(dz, f.x, sz.x); sz.y = fmaf(dz, f.y, sz.y); sz.z = fmaf(dz, f.z, sz.z); sz.w = fmaf(dz, f.w, sz.w);
+    for (int rd = 0; rd < C::ROUNDS; ++rd) {
+      const long long n = grow0 + rd * C::PPR + tid / C::LPR;
+      ok[rd] = n < R;
+      const long long nn = ok[rd] ? n : 0;
+      cloud0[rd] = (nn / N) * N;
+      const int4 *ip = reinterpret_cast<const int4 *>(nbr + nn * KK);
+#pragma unroll
+      for (int q = 0; q < KK / 4; ++q) {
+        const int4 v = ip[q];
+        nid[rd][4 * q] = v.x; nid[rd][4 * q + 1] = v.y; nid[rd][4 * q + 2] = v.z; nid[rd][4 * q + 3] = v.w;
+      }
+      pxyz[rd][0] = xyz[nn * 3]; pxyz[rd][1] = xyz[nn * 3 + 1]; pxyz[rd][2] = xyz[nn * 3 + 2];
+    }
+#pragma unroll
+    for (int rp = 0; rp < C::ROUNDS; rp += 2) {
+      float4 fv[2][KK];
+      float qv[2][KK][3];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int k = 0; k < KK; ++k) {
+          const long long g = cloud0[rp + h] + nid[rp + h][k];
+          fv[h][k] = *reinterpret_cast<const float4 *>(feat + g * DIN + r4);
+          qv[h][k][0] = xyz[g * 3]; qv[h][k][1] = xyz[g * 3 + 1]; qv[h][k][2] = xyz[g * 3 + 2];
+        }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int rd = rp + h;
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), sx = s0, sy = s0, sz = s0;
+#pragma unroll
+        for (int k = 0; k < KK; ++k) {
+          const float4 f = fv[h][k];
+          const float dx = qv[h][k][0] - pxyz[rd][0], dy = qv[h][k][1] - pxyz[rd][1], dz = qv[h][k][2] - pxyz[rd][2];
+          s0.x += f.x; s0.y += f.y; s0.z += f.z; s0.w += f.w;
+          sx.x = fmaf(dx, f.x, sx.x); sx.y = fmaf(dx, f.y, sx.y); sx.z = fmaf(dx, f.z, sx.z); sx.w = fmaf(dx, f.w, sx.w);
+          sy.x = fmaf(dy, f.x, sy.x); sy.y = fmaf(dy, f.y, sy.y); sy.z = fmaf(dy, f.z, sy.z); sy.w = fmaf(dy, f.w, sy.w);
+          sz.x = fmaf(dz, f.x, sz.x); sz.y = fmaf(dz, f.y, sz.y); sz.z = fmaf(dz, f.z, sz.z); sz.w = fmaf(dz, f.w, sz.w);
+        }
+        if (!ok[rd]) { s0 = make_float4(0.f, 0.f, 0.f, 0.f); sx = s0; sy = s0; sz = s0; }
+        float *row = s_S + (size_t)(rd * C::PPR + tid / C::LPR) * C::LD + r4;
+        *reinterpret_cast<float4 *>(row) = s0;
+        *reinterpret_cast<float4 *>(row + DIN) = sx;
+        *reinterpret_cast<float4 *>(row + 2 * DIN) = sy;
+        *reinterpret_cast<float4 *>(row + 3 * DIN) = sz;
       }
     }
-    float *row = s_S + (size_t)p * C::LD + r4;
-    *reinterpret_cast<float4 *>(row) = s0;
-    *reinterpret_cast<float4 *>(row + DIN) = sx;
-    *reinterpret_cast<float4 *>(row + 2 * DIN) = sy;
-    *reinterpret_cast<float4 *>(row + 3 * DIN) = sz;
+  } else {
+#pragma unroll
+    for (int rd = 0; rd < C::ROUNDS; ++rd) {
+      const int p = rd * C::PPR + tid / C::LPR;
+      const long long n = grow0 + p;
+      float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), sx = s0, sy = s0, sz = s0;
+      if (n < R) {
+        const long long cl0 = (n / N) * N;
+        const float px = xyz[n * 3], py = xyz[n * 3 + 1], pz = xyz[n * 3 + 2];
+        const int32_t *nb = nbr + n * K;
+#pragma unroll 4
+        for (int k = 0; k < K; ++k) {
+          const long long g = cl0 + nb[k];
+          const float4 f = *reinterpret_cast<const float4 *>(feat + g * DIN + r4);
+          const float dx = xyz[g * 3] - px, dy = xyz[g * 3 + 1] - py, dz = xyz[g * 3 + 2] - pz;
+          s0.x += f.x; s0.y += f.y; s0.z += f.z; s0.w += f.w;
+          sx.x = fmaf(dx, f.x, sx.x); sx.y = fmaf(dx, f.y, sx.y); sx.z = fmaf(dx, f.z, sx.z); sx.w = fmaf(dx, f.w, sx.w);
+          sy.x = fmaf(dy, f.x, sy.x); sy.y = fmaf(dy, f.y, sy.y); sy.z = fmaf(dy, f.z, sy.z); sy.w = fmaf(dy, f.w, sy.w);
+          sz.x = fmaf(dz, f.x, sz.x); sz.y = fmaf(dz, f.y, sz.y); sz.z = fmaf(dz, f.z, sz.z); sz.w = fmaf(dz, f.w, sz.w);
+        }
+      }
+      float *row = s_S + (size_t)p * C::LD + r4;
+      *reinterpret_cast<float4 *>(row) = s0;
+      *reinterpret_cast<float4 *>(row + DIN) = sx;
+      *reinterpret_cast<float4 *>(row + 2 * DIN) = sy;
+      *reinterpret_cast<float4 *>(row + 3 * DIN) = sz;
+    }
   }
+  FPROBE(1);
   __syncthreads();
+  FPROBE(2);
 
   // ---- phase B: S @ Wcat on the f32 MFMA pipe, epilogue in the store
   const int wave = tid >> 6;
@@ -79,8 +148,21 @@ __global__ __launch_bounds__(256) void flex_conv_pm_kernel(
   constexpr int cbstride = (C::MB == 2) ? 2 : 4;
   f32x16 acc[C::NT];
   zero_acc<C::NT>(acc);
+  EpilogueRegs er[C::NT];
+#pragma unroll
+  for (int j = 0; j < C::NT; ++j) er[j] = epilogue_prefetch(ep, (cb0 + j * cbstride) * 32 + (tid & 31));
   wave_gemm_f32<C::NT>(s_S, C::LD, row0, wpacked, C::KD / 8, cb0, cbstride, acc);
-  wave_store_f32<C::NT>(acc, grow0, row0, cb0, cbstride, R, DOUT, ep, nullptr, out);
+#ifdef DH3D_FLEX_PROBE
+  asm volatile("" :: "v"(acc[0][0]));
+#endif
+  FPROBE(3);
+  // wide epilogue through the (now dead) S tile: LD = 4*Din + 4 >= Dout + 4 for every supported shape
+  static_assert(C::LD >= DOUT + 4, "output tile must fit the S tile");
+  __syncthreads();
+  wave_tiles_to_lds<C::NT>(acc, er, ep.act, s_S, C::LD, row0, cb0, cbstride);
+  __syncthreads();
+  block_store_rows(s_S, C::LD, C::TM, grow0, R, DOUT, nullptr, out);
+  FPROBE(4);
 }
 
 template <int DIN, int DOUT>
@@ -89,10 +171,16 @@ int flex_conv_pm_launch(const float *feat, const float *xyz, const int32_t *nbr,
   using C = FlexCfg<DIN, DOUT>;
   const long long R = (long long)B * N;
   const size_t lds = sizeof(float) * C::TM * C::LD;
-  auto kern = flex_conv_pm_kernel<DIN, DOUT>;
-  DH3D_ALLOW_BIG_LDS(kern);
-  hipLaunchKernelGGL(kern, dim3(dh3d_cdiv(R, C::TM)), dim3(256), lds, s, feat, xyz, nbr, wpacked, R, N, K,
-                     ep, out);
+  const dim3 grid(dh3d_cdiv(R, C::TM)), block(256);
+  if (K == 8) {
+    auto kern = flex_conv_pm_kernel<DIN, DOUT, 8>;
+    DH3D_ALLOW_BIG_LDS(kern);
+    hipLaunchKernelGGL(kern, grid, block, lds, s, feat, xyz, nbr, wpacked, R, N, K, ep, out);
+  } else {
+    auto kern = flex_conv_pm_kernel<DIN, DOUT, 0>;
+    DH3D_ALLOW_BIG_LDS(kern);
+    hipLaunchKernelGGL(kern, grid, block, lds, s, feat, xyz, nbr, wpacked, R, N, K, ep, out);
+  }
   return dh3d_launch_status();
 }
 
@@ -209,3 +297,9 @@ DH3D_API int dh3d_conv_pointset_pm_fwd(const float *xyz, const int32_t *nbr, con
                      (hipStream_t)stream, xyz, nbr, theta, bias, R, N, K, Dout, dh3d_ep(ep), out);
   return dh3d_launch_status();
 }
+
+#ifdef DH3D_FLEX_PROBE
+DH3D_API int dh3d_flex_probe_read(long long *host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fprobe), sizeof(long long) * n) == hipSuccess ? 0 : 3;
+}
+#endif

@@ -166,3 +166,50 @@ __device__ __forceinline__ void wave_store_f32(const f32x16 (&acc)[NT], long lon
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Wide epilogue.  Storing an accumulator tile straight from registers is 16 global_store_dword per tile per
+// lane (256 B per instruction); measured on the flex_conv tile that store phase took as long as the GEMM
+// itself (store-issue bound, tools/flex_probe.py).  Instead: epilogue in registers -> tile into LDS (the A
+// tile is dead by then) -> the whole workgroup writes full rows with one 16-byte store per lane.
+struct EpilogueRegs {
+  float pb, sc, sh;
+};
+// fetch the per-column parameters early (before the GEMM) so their latency is off the tail
+__device__ __forceinline__ EpilogueRegs epilogue_prefetch(const EpilogueArgs &ep, int col) {
+  EpilogueRegs e{0.f, 1.f, 0.f};
+  if (ep.pre_bias) e.pb = ep.pre_bias[col];
+  if (ep.scale) e.sc = ep.scale[col];
+  if (ep.shift) e.sh = ep.shift[col];
+  return e;
+}
+template <int NT>
+__device__ __forceinline__ void wave_tiles_to_lds(const f32x16 (&acc)[NT], const EpilogueRegs (&er)[NT], int act,
+                                                  float *s_out, int ldo, int row0, int cb0, int cbstride) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = (cb0 + j * cbstride) * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      s_out[(size_t)(row0 + mfma_row(r, lane)) * ldo + col] = dh3d_act((acc[j][r] + er[j].pb) * er[j].sc + er[j].sh, act);
+  }
+}
+// all 256 threads: rows [0, TM) x Dout floats from LDS (+ residual) -> out, float4 per lane
+__device__ __forceinline__ void block_store_rows(const float *s_out, int ldo, int TM, long long grow0, long long R,
+                                                 int Dout, const float *__restrict__ residual,
+                                                 float *__restrict__ out) {
+  const int cv = Dout / 4;
+  for (int e = threadIdx.x; e < TM * cv; e += 256) {
+    const int p = e / cv, c4 = (e - p * cv) * 4;
+    const long long g = grow0 + p;
+    if (g < R) {
+      float4 v = *reinterpret_cast<const float4 *>(s_out + (size_t)p * ldo + c4);
+      if (residual) {
+        const float4 q = *reinterpret_cast<const float4 *>(residual + g * Dout + c4);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+      }
+      *reinterpret_cast<float4 *>(out + g * Dout + c4) = v;
+    }
+  }
+}
