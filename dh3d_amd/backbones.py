@@ -232,8 +232,11 @@ class FlexConvDilate(nn.Module):
             fc = getattr(self, "flexconv_%d" % i)
             bn = getattr(self, "flexconv_%d_bn" % i)
             scale, shift = [t.detach() for t in bn.fold()]
+            theta, bias = fc.position_theta.detach(), fc.position_bias.detach()
+            x6 = pm.flex_x6_supported(theta.shape[1], d, 8)  # full-resolution shapes: bf16x6 pipeline (K == 8)
             prep.append({
-                "wp": pm.pack_flex_weight(fc.position_theta.detach(), fc.position_bias.detach()),
+                "wp": pm.pack_flex_weight(theta, bias),
+                "wp3": pm.pack_flex_weight_x3(theta, bias) if x6 else None,
                 "fb": fc.feature_bias.detach().reshape(-1).contiguous(),
                 "scale": scale, "shift": shift, "dout": d,
             })
@@ -254,8 +257,10 @@ class FlexConvDilate(nn.Module):
         else:
             xyz_s, nbr_s, x = geo.xyz, (nbr if nbr is not None else geo.nbr), feat
         for p in prep:
-            x = pm.flex_conv(x, xyz_s, nbr_s, p["wp"], p["dout"], pre_bias=p["fb"], scale=p["scale"],
-                             shift=p["shift"], act=pm.ACT_RELU)
+            x6 = p["wp3"] is not None and nbr_s.shape[2] == 8
+            x = (pm.flex_conv_x6 if x6 else pm.flex_conv)(x, xyz_s, nbr_s, p["wp3"] if x6 else p["wp"], p["dout"],
+                                                          pre_bias=p["fb"], scale=p["scale"], shift=p["shift"],
+                                                          act=pm.ACT_RELU)
         if self.add_se == "max_pool":
             x = self.se(x, pm.flex_pool(x, nbr_s))
         if self.upsample and self.dilate > 1:

@@ -13,20 +13,11 @@
 // The k -> (lane group, element) slot assignment inside one v_mfma_f32_32x32x16_bf16 is the same for the A
 // and the B operand, and a dot product is invariant under a common permutation of k, so A and B fragments
 // are both filled with k = 16*kb + 8*(lane>>5) + j  (j = 0..7) and no hardware slot table is needed.
-#include "common.h"
+#include "bf16x3.h"
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kTM = 64;
-
-__device__ __forceinline__ void split3(float a, unsigned &c1, unsigned &c2, unsigned &c3) {
-  const unsigned u1 = __float_as_uint(a) & 0xFFFF0000u;
-  const float r1 = a - __uint_as_float(u1);                 // exact
-  const unsigned u2 = __float_as_uint(r1) & 0xFFFF0000u;
-  const float r2 = r1 - __uint_as_float(u2);                // exact, <= 8 significant bits left
-  c1 = u1 >> 16; c2 = u2 >> 16; c3 = __float_as_uint(r2) >> 16;
-}
 
 // W [Kd, Dout] f32 -> packed[((nb*KB + kb)*3 + plane)*64 + lane][8 bf16],
 //   element j = chunk_plane( W[16*kb + 8*(lane>>5) + j][32*nb + (lane&31)] )

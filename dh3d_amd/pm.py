@@ -89,6 +89,40 @@ def flex_conv(features, xyz, nbr, wpacked, Dout, pre_bias=None, scale=None, shif
     return out
 
 
+def flex_x6_supported(Din, Dout, K):
+    """Shapes served by the persistent bf16x6 flex_conv (csrc/flex_x6.hip)."""
+    return K == 8 and (Din, Dout) in ((32, 64), (64, 64))
+
+
+def pack_flex_weight_x3(theta, bias):
+    """[bias; theta_x; theta_y; theta_z] as three exact bf16 chunk planes in MFMA fragment order."""
+    t = L.require_cuda_f32(theta, "theta", 3)
+    b = L.require_cuda_f32(bias, "bias", 2)
+    if t.shape[0] != 3:
+        raise ValueError("point-major flex_conv needs Dp == 3")
+    Din, Dout = b.shape
+    out = torch.empty((3 * 4 * Din * Dout,), dtype=torch.int16, device=t.device)
+    L.check(L.lib().dh3d_pack_flex_weight_x3(L.ptr(t), L.ptr(b), Din, Dout, L.ptr(out), L.stream_ptr()),
+            "pack_flex_weight_x3")
+    return out
+
+
+def flex_conv_x6(features, xyz, nbr, wpacked_x3, Dout, pre_bias=None, scale=None, shift=None, act=ACT_NONE):
+    """flex_conv on the bf16 matrix pipe at f32 accuracy (full-resolution layers, K == 8)."""
+    f = L.require_cuda_f32(features, "features", 3)
+    x = L.require_cuda_f32(xyz, "xyz", 3)
+    nb = L.require_cuda_i32(nbr, "nbr", 3)
+    B, N, Din = f.shape
+    K = nb.shape[2]
+    if tuple(x.shape) != (B, N, 3) or tuple(nb.shape[:2]) != (B, N):
+        raise ValueError("flex_conv_x6: xyz/nbr do not match features [B,N,*]")
+    out = torch.empty((B, N, Dout), dtype=torch.float32, device=f.device)
+    ep = _ep(pre_bias, scale, shift, act)
+    L.check(L.lib().dh3d_flex_conv_pm_x6_fwd(L.ptr(f), L.ptr(x), L.ptr(nb), L.ptr(wpacked_x3), B, N, K, Din, Dout, ep,
+                                             L.ptr(out), L.stream_ptr()), "flex_conv_pm_x6")
+    return out
+
+
 def flex_pool(features, nbr, want_argmax=False):
     f = L.require_cuda_f32(features, "features", 3)
     nb = L.require_cuda_i32(nbr, "nbr", 3)

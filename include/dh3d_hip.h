@@ -173,6 +173,15 @@ int dh3d_flex_conv_pm_fwd(const float *features, const float *xyz, const int32_t
                           const float *wpacked, int B, int N, int K, int Din, int Dout,
                           const dh3d_epilogue *ep, float *out, void *stream);
 
+/* flex_conv of the full-resolution layers on the bf16 matrix pipe with f32 accuracy (three-way bf16 split of
+ * both operands, six products; see csrc/flex_x6.hip).  Same operands and result as dh3d_flex_conv_pm_fwd up
+ * to f32 summation order; K == 8, (Din, Dout) in {(32,64), (64,64)}.  The weight comes from
+ * dh3d_pack_flex_weight_x3 ( [bias; theta_x; theta_y; theta_z] as three bf16 planes, 6*4*Din*Dout bytes ). */
+int dh3d_pack_flex_weight_x3(const float *theta, const float *bias, int Din, int Dout, void *packed, void *stream);
+int dh3d_flex_conv_pm_x6_fwd(const float *features, const float *xyz, const int32_t *nbr, const void *wpacked_x3,
+                             int B, int N, int K, int Din, int Dout, const dh3d_epilogue *ep, float *out,
+                             void *stream);
+
 /* flex_pool forward, point-major: out[n,c] = max_k f[nbr[n,k],c], argmax may be NULL. C % 4 == 0. */
 int dh3d_flex_pool_pm_fwd(const float *features, const int32_t *nbr, int B, int N, int K, int C,
                           float *out, int32_t *argmax, void *stream);

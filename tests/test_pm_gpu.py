@@ -61,6 +61,51 @@ def test_flex_conv_pm_vs_oracle(dev, oracle, Din, Dout, N):
     assert close(fused, np.maximum((exp + fb) * sc + sh, 0), 1e-4, 1e-4 * np.abs(exp).max())
 
 
+@pytest.mark.parametrize("Din,Dout,B,N", [(32, 64, 2, 999), (64, 64, 2, 999), (64, 64, 1, 40), (32, 64, 1, 96),
+                                          (32, 64, 3, 2048), (64, 64, 3, 2048)])
+def test_flex_conv_x6_vs_oracle(dev, oracle, Din, Dout, B, N):
+    """Persistent bf16x6 flex_conv: f32-accurate against the oracle (ragged tiles, tiles straddling clouds,
+    one and several tiles per workgroup, odd tile counts)."""
+    from dh3d_amd import pm
+    rng = np.random.default_rng(Din + Dout + N)
+    K = 8
+    xyz, nn = _cloud(rng, B, N, K, oracle)
+    f = rng.standard_normal((B, N, Din)).astype(np.float32)
+    theta = (rng.standard_normal((3, Din, Dout)) / np.sqrt(Din)).astype(np.float32)
+    bias = (rng.standard_normal((Din, Dout)) / np.sqrt(8 * Din)).astype(np.float32)
+    fb = rng.standard_normal(Dout).astype(np.float32)
+    sc = (0.5 + rng.random(Dout)).astype(np.float32)
+    sh = rng.standard_normal(Dout).astype(np.float32)
+    assert pm.flex_x6_supported(Din, Dout, K)
+    wp3 = pm.pack_flex_weight_x3(T(theta, dev), T(bias, dev))
+    raw = pm.flex_conv_x6(T(f, dev), T(xyz, dev), T(nn, dev), wp3, Dout).cpu().numpy()
+    exp = oracle.flex_convolution(f.transpose(0, 2, 1), xyz.transpose(0, 2, 1), nn.transpose(0, 2, 1), theta, bias,
+                                  True).transpose(0, 2, 1)
+    assert relerr(raw, exp) < 2e-6 and close(raw, exp, 1e-4, 1e-4 * np.abs(exp).max())
+    fused = pm.flex_conv_x6(T(f, dev), T(xyz, dev), T(nn, dev), wp3, Dout, pre_bias=T(fb, dev), scale=T(sc, dev),
+                            shift=T(sh, dev), act=pm.ACT_RELU).cpu().numpy()
+    assert close(fused, np.maximum((exp + fb) * sc + sh, 0), 1e-4, 1e-4 * np.abs(exp).max())
+
+
+@pytest.mark.parametrize("Din", [32, 64])
+def test_flex_conv_x6_full_size_matches_f32_kernel(dev, Din):
+    """BASELINE shape (B=8, N=8192, K=8): eight tiles per workgroup; bf16x6 == exact-f32 MFMA kernel to rounding."""
+    from dh3d_amd import pm
+    g = torch.Generator().manual_seed(Din)
+    B, N, K, Dout = 8, 8192, 8, 64
+    xyz = torch.rand(B, N, 3, generator=g).to(dev)
+    nbr, _ = pm.knn_xyz(xyz, K)
+    f = torch.randn(B, N, Din, generator=g).to(dev)
+    theta = (torch.randn(3, Din, Dout, generator=g) / Din ** 0.5).to(dev)
+    bias = (torch.randn(Din, Dout, generator=g) / (8 * Din) ** 0.5).to(dev)
+    a = pm.flex_conv(f, xyz, nbr, pm.pack_flex_weight(theta, bias), Dout)
+    b = pm.flex_conv_x6(f, xyz, nbr, pm.pack_flex_weight_x3(theta, bias), Dout)
+    b2 = pm.flex_conv_x6(f, xyz, nbr, pm.pack_flex_weight_x3(theta, bias), Dout)
+    assert torch.equal(b, b2)  # deterministic
+    err = (a - b).abs().max().item() / a.abs().max().item()
+    assert err < 2e-6, err
+
+
 def test_flex_pool_pm_exact(dev, oracle):
     from dh3d_amd import pm
     rng = np.random.default_rng(3)

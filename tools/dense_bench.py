@@ -26,6 +26,9 @@ for B, N in ((8, 8192), (32, 4096)):
         t = ev(lambda: pm.flex_conv(f, xyz, nbr, wp, Dout, act=pm.ACT_RELU))
         F = 2.0 * B * N * 4 * Din * (8 + Dout)
         print("  flex_conv %3d->%3d  %7.1f us  %5.1f TF/s" % (Din, Dout, t, F / t / 1e6))
+        wp3 = pm.pack_flex_weight_x3(torch.randn(3, Din, Dout, generator=g).to(dev), torch.randn(Din, Dout, generator=g).to(dev))
+        t = ev(lambda: pm.flex_conv_x6(f, xyz, nbr, wp3, Dout, act=pm.ACT_RELU))
+        print("  flex_conv_x6 %3d->%3d  %7.1f us  %5.1f TF/s-equivalent" % (Din, Dout, t, F / t / 1e6))
     for C1, C2, Dout in ((64, 0, 64), (64, 0, 128), (128, 64, 128)):
         x1 = torch.randn(B * N, C1, generator=g).to(dev)
         x2 = torch.randn(B * N, C2, generator=g).to(dev) if C2 else None

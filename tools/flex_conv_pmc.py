@@ -8,12 +8,12 @@ g = torch.Generator(device="cpu").manual_seed(1)
 xyz = torch.rand(B, N, 3, generator=g).to(dev)
 f = torch.randn(B, N, Din, generator=g).to(dev)
 nbr, _ = pm.knn_xyz(xyz, K)
-wp = pm.pack_flex_weight((torch.randn(3, Din, Dout, generator=g) / 8).to(dev), (torch.randn(Din, Dout, generator=g) / 22).to(dev))
+wp = pm.pack_flex_weight_x3((torch.randn(3, Din, Dout, generator=g) / 8).to(dev), (torch.randn(Din, Dout, generator=g) / 22).to(dev))
 fb = torch.zeros(Dout, device=dev)
 # a copy kernel of known size for calibrating the counters: 64 MiB read + 64 MiB write
 cal = torch.empty(16 * 1024 * 1024, device=dev)
 for _ in range(5):
-    out = pm.flex_conv(f, xyz, nbr, wp, Dout, pre_bias=fb, scale=fb + 1, shift=fb, act=pm.ACT_RELU)
+    out = pm.flex_conv_x6(f, xyz, nbr, wp, Dout, pre_bias=fb, scale=fb + 1, shift=fb, act=pm.ACT_RELU)
     cal2 = cal.clone()
 torch.cuda.synchronize()
 print("done")

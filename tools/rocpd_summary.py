@@ -2,6 +2,7 @@
 """Summarise a rocprofv3 rocpd database (--kernel-trace --stats output) as a per-kernel table.
 
     python tools/rocpd_summary.py gpurun_out/prof/x_results.db > profiles/rNN_name.txt
+    python tools/rocpd_summary.py --pmc gpurun_out/pmc/x_results.db      (per-kernel counter values of a --pmc pass)
 """
 import re
 import sqlite3
@@ -27,5 +28,17 @@ def main(path):
                                                              100.0 * tot / total))
 
 
+def pmc(path):
+    c = sqlite3.connect(path)
+    rows = c.execute("select name, counter_name, count(*), avg(counter_value), min(counter_value), max(counter_value), "
+                     "avg(duration) from pmc_events group by name, counter_name order by 2, 4 desc").fetchall()
+    print("%-70s %-28s %6s %14s %14s %14s %10s" % ("kernel", "counter", "calls", "avg", "min", "max", "avg_dur_us"))
+    for n, cn, cnt, avg, mn, mx, dur in rows:
+        print("%-70s %-28s %6d %14.1f %14.1f %14.1f %10.2f" % (short(n)[:70], cn, cnt, avg, mn, mx, dur / 1e3))
+
+
 if __name__ == "__main__":
-    main(sys.argv[1])
+    if sys.argv[1] == "--pmc":
+        pmc(sys.argv[2])
+    else:
+        main(sys.argv[1])
