@@ -331,7 +331,10 @@ class PointMLPHead(nn.Module):
         for i in range(len(self.conv_dims)):
             getattr(self, "detec_conv%d" % i).prepare()
         self._prep = {"w_fc": self.detec_conv_fc.W.detach().reshape(-1).contiguous(),
-                      "b_fc": float(self.detec_conv_fc.b.detach().reshape(-1)[0].item())}
+                      "b_fc": float(self.detec_conv_fc.b.detach().reshape(-1)[0].item()), "wp3": None}
+        last = getattr(self, "detec_conv%d" % (len(self.conv_dims) - 1))
+        if last.cin % 32 == 0 and last.cout % 256 == 0:  # wide last layer: tiled bf16x6 GEMM (csrc/dense_x6.hip)
+            self._prep["wp3"] = pm.pack_weight_x3(last.W.detach().reshape(last.cin, last.cout).contiguous())
         return self._prep
 
     def forward(self, x):
@@ -341,6 +344,9 @@ class PointMLPHead(nn.Module):
             x = getattr(self, "detec_conv%d" % i)(x, act=pm.ACT_RELU)
         last = getattr(self, "detec_conv%d" % (n - 1))
         lp = last._prep
+        if p["wp3"] is not None:
+            return pm.mlp_head_x6(x, p["wp3"], last.cout, p["w_fc"], p["b_fc"], pre_bias=lp["b"], scale=lp["scale"],
+                                  shift=lp["shift"], act=pm.ACT_RELU)
         return pm.mlp_head(x, lp["wp"], last.cout, p["w_fc"], p["b_fc"], pre_bias=lp["b"], scale=lp["scale"],
                            shift=lp["shift"], act=pm.ACT_RELU)
 

@@ -17,7 +17,6 @@
 
 namespace {
 
-constexpr int kTM = 64;
 
 // W [Kd, Dout] f32 -> packed[((nb*KB + kb)*3 + plane)*64 + lane][8 bf16],
 //   element j = chunk_plane( W[16*kb + 8*(lane>>5) + j][32*nb + (lane&31)] )
@@ -41,101 +40,156 @@ __global__ __launch_bounds__(256) void pack_weight_x3_kernel(const float *__rest
 }
 
 // att[r] = sigmoid( sum_j act(bn(h[r,:] @ W[:,j] + b[j])) * w_fc[j] + b_fc )
-__global__ __launch_bounds__(256) void mlp_head_x6_kernel(const float *__restrict__ h, int C,
+//
+// A tiled GEMM: one workgroup owns 128 rows and walks the 1024 columns in tiles of 256; the K loop moves in
+// chunks of 32 through a double-buffered LDS stage holding the A chunk (split into its three bf16 planes as
+// it is staged) and the matching slice of the pre-split weight.  Each of the eight waves (2 x 4, two per
+// SIMD so one covers the other's waits) keeps a 64 x 64 block of f32 accumulators (four independent MFMA
+// chains); a weight fragment read from LDS feeds two row blocks and an A fragment two column blocks, and the
+// packed weight crosses L2 -> CU once per 128 rows (1.5 GB per launch at R = 131072 instead of
+// the 6.4 GB of a 64-row, weight-streaming layout -- which is what made the first version no faster than f32).
+constexpr int HTM = 128, HTN = 256, HKC = 32;
+constexpr int LDA = HKC + 8;                       // bf16 per row of a staged A plane (80 B: conflict-free b128)
+constexpr int A_STAGE = 3 * HTM * LDA;             // bf16 elements per A buffer
+constexpr int B_STAGE = (HTN / 32) * 2 * 3 * 64;   // uint4 per B buffer  [cb 8][ks 2][plane 3][lane 64]
+
+__global__ __launch_bounds__(512) void mlp_head_x6_kernel(const float *__restrict__ h, int C,
                                                          const uint4 *__restrict__ wp, int H, EpilogueArgs ep,
                                                          const float *__restrict__ w_fc, float b_fc,
                                                          long long R, float *__restrict__ att) {
-  extern __shared__ __attribute__((aligned(16))) unsigned short s_A[];  // [3][kTM][C+8] bf16 chunks
-  __shared__ float s_part[2][kTM];
-  const int LD = C + 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  unsigned short *s_A = reinterpret_cast<unsigned short *>(s_raw);                      // [2][3][HTM][LDA]
+  uint4 *s_B = reinterpret_cast<uint4 *>(s_raw + (size_t)2 * A_STAGE * 2);             // [2][B_STAGE]
+  float *s_part = reinterpret_cast<float *>(s_raw + (size_t)2 * A_STAGE * 2 + (size_t)2 * B_STAGE * 16);  // [4][HTM]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const long long grow0 = (long long)blockIdx.x * kTM;
-  // ---- stage 64 rows, splitting every f32 into its three bf16 chunks (once per element)
-  const int cv = C / 4;
-  for (int e = tid; e < kTM * cv; e += 256) {
-    const int p = e / cv, c4 = (e - p * cv) * 4;
-    const long long g = grow0 + p;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g < R) v = *reinterpret_cast<const float4 *>(h + g * C + c4);
-    unsigned a1[4], a2[4], a3[4];
-    split3(v.x, a1[0], a2[0], a3[0]); split3(v.y, a1[1], a2[1], a3[1]);
-    split3(v.z, a1[2], a2[2], a3[2]); split3(v.w, a1[3], a2[3], a3[3]);
-    unsigned short *dst = s_A + (size_t)p * LD + c4;
-    *reinterpret_cast<uint2 *>(dst) = make_uint2(a1[0] | (a1[1] << 16), a1[2] | (a1[3] << 16));
-    *reinterpret_cast<uint2 *>(dst + (size_t)kTM * LD) = make_uint2(a2[0] | (a2[1] << 16), a2[2] | (a2[3] << 16));
-    *reinterpret_cast<uint2 *>(dst + (size_t)2 * kTM * LD) = make_uint2(a3[0] | (a3[1] << 16), a3[2] | (a3[3] << 16));
-  }
-  __syncthreads();
-
-  const int row0 = (wave & 1) * 32;
-  const int KB = C / 16, NB = H / 32;
-  const unsigned short *arow = s_A + (size_t)(row0 + (lane & 31)) * LD + 8 * (lane >> 5);
-  float part[16];
+  const int wr = wave >> 2, wc = wave & 3;
+  const long long grow0 = (long long)blockIdx.x * HTM;
+  const int KB = C / 16, NCH = C / HKC, NT = H / HTN, IT = NT * NCH;
+  // staging roles: A -- thread t owns row t/4, 8 consecutive k; B -- LDS-DMA, 6 KB per wave
+  const int ar = tid >> 2, ah = tid & 3;
+  long long arow = grow0 + ar;
+  if (arow >= R) arow = R - 1;  // rows past R repeat the last row; their results are not stored
+  const float *asrc = h + arow * C + ah * 8;
+  float4 pa[2];
+  // A chunk of iteration `it` -> registers (split and written to LDS by stage_a)
+  auto prefetch_a = [&](int it) __attribute__((always_inline)) {
+    const int nt = it / NCH, ch = it - nt * NCH;
+    const float4 *ap = reinterpret_cast<const float4 *>(asrc + ch * HKC);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) part[r] = 0.f;
-
-  for (int cb = (wave >> 1); cb < NB; cb += 4) {  // this wave: column blocks cb and cb+2
-    f32x16 acc[2];
+    for (int j = 0; j < 2; ++j) pa[j] = ap[j];
+  };
+  // weight slice of iteration `it` -> LDS buffer `buf` by LDS-DMA (global_load_lds_dwordx4: no registers; each
+  // wave-instruction lands 64 x 16 B contiguously).  48 KB per chunk = 6 instructions per wave.
+  auto dma_b = [&](int it, int buf) __attribute__((always_inline)) {
+    const int nt = it / NCH, ch = it - nt * NCH;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    uint4 bn[2][3];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) bn[j][p] = wp[((size_t)((cb + 2 * j) * KB) * 3 + p) * 64 + lane];
-    for (int kb = 0; kb < KB; ++kb) {
-      uint4 bc[2][3];
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          bc[j][p] = bn[j][p];
-          if (kb + 1 < KB) bn[j][p] = wp[((size_t)((cb + 2 * j) * KB + kb + 1) * 3 + p) * 64 + lane];
-        }
-      const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(arow + kb * 16);
-      const bf16x8 a2 = *reinterpret_cast<const bf16x8 *>(arow + (size_t)kTM * LD + kb * 16);
-      const bf16x8 a3 = *reinterpret_cast<const bf16x8 *>(arow + (size_t)2 * kTM * LD + kb * 16);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const bf16x8 b1 = __builtin_bit_cast(bf16x8, bc[j][0]);
-        const bf16x8 b2 = __builtin_bit_cast(bf16x8, bc[j][1]);
-        const bf16x8 b3 = __builtin_bit_cast(bf16x8, bc[j][2]);
-        // smallest terms first
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
-      }
+    for (int j = 0; j < 6; ++j) {
+      const int e0 = (wave * 6 + j) * 64, cb = e0 / 384, rem = e0 - cb * 384 + lane;
+      const uint4 *src = wp + ((size_t)(nt * (HTN / 32) + cb) * KB + ch * 2) * 192 + rem;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)(s_B + (size_t)buf * B_STAGE + e0),
+                                       16, 0, 0);
     }
+  };
+  auto stage_a = [&](int buf) __attribute__((always_inline)) {
+    unsigned short *dst = s_A + (size_t)buf * A_STAGE + (size_t)ar * LDA + ah * 8;
+    uint2 c1[2], c2[2], c3[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = (cb + 2 * j) * 32 + (lane & 31);
+    for (int j = 0; j < 2; ++j) split3x4(pa[j], c1[j], c2[j], c3[j]);
+    *reinterpret_cast<uint4 *>(dst) = make_uint4(c1[0].x, c1[0].y, c1[1].x, c1[1].y);
+    *reinterpret_cast<uint4 *>(dst + HTM * LDA) = make_uint4(c2[0].x, c2[0].y, c2[1].x, c2[1].y);
+    *reinterpret_cast<uint4 *>(dst + 2 * HTM * LDA) = make_uint4(c3[0].x, c3[0].y, c3[1].x, c3[1].y);
+  };
+  auto stage_sync = [&]() __attribute__((always_inline)) {  // LDS-DMA counts on vmcnt
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+
+  float part[2][16];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[rb][r] = 0.f;
+
+  prefetch_a(0);
+  dma_b(0, 0);
+  stage_a(0);
+  stage_sync();
+  int it = 0;
+  for (int nt = 0; nt < NT; ++nt) {
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
+    for (int ch = 0; ch < NCH; ++ch, ++it) {
+      const int nxt = it + 1 < IT ? it + 1 : it;  // unconditional prefetch: the last one is a harmless repeat
+      prefetch_a(nxt);
+      const int buf = it & 1;
+      dma_b(nxt, buf ^ 1);                   // lands under this chunk's MFMAs (waited for in stage_sync)
+      __builtin_amdgcn_sched_barrier(0);     // keep both prefetches up here: the scheduler sinks loads to their use
+      const unsigned short *abase = s_A + (size_t)buf * A_STAGE + (size_t)(wr * 64 + (lane & 31)) * LDA + 8 * (lane >> 5);
+      const uint4 *bbase = s_B + (size_t)buf * B_STAGE + (size_t)(wc * 2) * (2 * 3 * 64) + lane;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 a[2][3], b[2][3];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            a[rb][p] = *reinterpret_cast<const bf16x8 *>(abase + (size_t)p * HTM * LDA + (size_t)rb * 32 * LDA + ks * 16);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) b[cb][p] = __builtin_bit_cast(bf16x8, bbase[((cb * 2 + ks) * 3 + p) * 64]);
+        // six products, smallest first; four independent accumulators between two uses of the same one
+#define DH3D_X6_PRODUCT(PA, PB)                                                                         \
+  _Pragma("unroll") for (int rb = 0; rb < 2; ++rb) _Pragma("unroll") for (int cb = 0; cb < 2; ++cb)     \
+      acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rb][PA], b[cb][PB], acc[rb][cb], 0, 0, 0);
+        DH3D_X6_PRODUCT(2, 0) DH3D_X6_PRODUCT(0, 2) DH3D_X6_PRODUCT(1, 1)
+        DH3D_X6_PRODUCT(1, 0) DH3D_X6_PRODUCT(0, 1) DH3D_X6_PRODUCT(0, 0)
+#undef DH3D_X6_PRODUCT
+      }
+      stage_a(buf ^ 1);
+      stage_sync();
+    }
+    // epilogue of this column tile: BN + activation, dot with w_fc, kept per lane (one column per lane)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int col = nt * HTN + (wc * 2 + cb) * 32 + (lane & 31);
       float pb = 0.f, sc = 1.f, sh = 0.f;
       if (ep.pre_bias) pb = ep.pre_bias[col];
       if (ep.scale) sc = ep.scale[col];
       if (ep.shift) sh = ep.shift[col];
       const float wf = w_fc[col];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) part[r] = fmaf(dh3d_act((acc[j][r] + pb) * sc + sh, ep.act), wf, part[r]);
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          part[rb][r] = fmaf(dh3d_act((acc[rb][cb][r] + pb) * sc + sh, ep.act), wf, part[rb][r]);
     }
   }
+  // row sums: across the 32 column lanes, then across the four column waves
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
+  for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) part[r] += __shfl_xor(part[r], off, 64);
-  }
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) part[rb][r] += __shfl_xor(part[rb][r], off, 64);
+    }
   if ((lane & 31) == 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s_part[wave >> 1][row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] = part[r];
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        s_part[wc * HTM + wr * 64 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] = part[rb][r];
   }
   __syncthreads();
-  if (tid < kTM) {
+  if (tid < HTM) {
     const long long g = grow0 + tid;
-    if (g < R) att[g] = 1.f / (1.f + expf(-(s_part[0][tid] + s_part[1][tid] + b_fc)));
+    if (g < R) att[g] = 1.f / (1.f + expf(-(((s_part[tid] + s_part[HTM + tid]) + (s_part[2 * HTM + tid] + s_part[3 * HTM + tid])) + b_fc)));
   }
 }
 
@@ -153,11 +207,11 @@ DH3D_API int dh3d_mlp_head_pm_x6_fwd(const float *h, int R, int C, const void *w
                                      const dh3d_epilogue *ep, const float *w_fc, float b_fc, float *att,
                                      void *stream) {
   DH3D_REQUIRE(h && wpacked_x3 && w_fc && att && R > 0 && C > 0 && H > 0);
-  DH3D_SUPPORTED(C % 16 == 0 && C <= 384 && H % 128 == 0);
-  const size_t lds = sizeof(unsigned short) * 3 * kTM * (C + 8);
+  DH3D_SUPPORTED(C % HKC == 0 && H % HTN == 0);
+  const size_t lds = (size_t)2 * A_STAGE * 2 + (size_t)2 * B_STAGE * 16 + sizeof(float) * 4 * HTM;
   auto kern = mlp_head_x6_kernel;
   DH3D_ALLOW_BIG_LDS(kern);
-  hipLaunchKernelGGL(kern, dim3(dh3d_cdiv(R, kTM)), dim3(256), lds, (hipStream_t)stream, h, C,
+  hipLaunchKernelGGL(kern, dim3(dh3d_cdiv(R, HTM)), dim3(512), lds, (hipStream_t)stream, h, C,
                      static_cast<const uint4 *>(wpacked_x3), H, dh3d_ep(ep), w_fc, b_fc, (long long)R, att);
   return dh3d_launch_status();
 }
