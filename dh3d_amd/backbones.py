@@ -185,8 +185,11 @@ def compute_level(xyz, dilate, knn):
     xyz_s = gather_rows(xyz, idx)
     ready = torch.cuda.Event()
     ready.record()  # xyz_s exists: three_nn may start on another stream while the sampled-set kNN runs here
-    srt_s, gbox_s = pm.spatial_sort(xyz_s)
-    nbr_s, _ = pm.knn_sorted(srt_s, gbox_s, knn)
+    if npoint <= 2048:  # small sets: the brute-force kernel beats sort + pruned search (launch/latency bound)
+        nbr_s, _ = pm.knn_xyz(xyz_s, knn)
+    else:
+        srt_s, gbox_s = pm.spatial_sort(xyz_s)
+        nbr_s, _ = pm.knn_sorted(srt_s, gbox_s, knn)
     return {"idx": idx, "xyz_s": xyz_s, "nbr_s": nbr_s, "_xyz_ready": ready}
 
 
@@ -247,8 +250,9 @@ class FlexConvDilate(nn.Module):
             self.concat_conv1d.tfconv0.prepare()
         return prep
 
-    def forward(self, geo, feat, nbr=None):
-        """geo: Geometry; feat [B,N,cin]; nbr [B,N,K] for dilate == 1 (else computed on the sampled set)."""
+    def forward(self, geo, feat, nbr=None, residual=None):
+        """geo: Geometry; feat [B,N,cin]; nbr [B,N,K] for dilate == 1 (else computed on the sampled set);
+        residual [B,N,cout]: added to the concat conv's output in its store (the caller's shortcut branch)."""
         prep = self._prep or self.prepare()
         if self.dilate > 1:
             lv = geo.level(self.dilate, self.knn)
@@ -266,7 +270,9 @@ class FlexConvDilate(nn.Module):
         if self.upsample and self.dilate > 1:
             x = pm.three_interpolate_idw(x, lv["nn3_idx"], lv["nn3_dist"])
         if self.concat:
-            x = self.concat_conv1d(x, x2=feat, act=pm.ACT_RELU)
+            x = self.concat_conv1d(x, x2=feat, act=pm.ACT_RELU, residual=residual)
+        elif residual is not None:
+            x = x + residual
         return x
 
 
@@ -308,8 +314,10 @@ class BackboneLocalDilate(nn.Module):
         init = pm.flex_pool(init, nn_8)
         x1 = self.stage1(geo, init, nbr=nn_8)
         x2 = self.before_stage2_conv1d(x1, act=pm.ACT_RELU)
-        x2 = self.stage2(geo, x2)
-        feat = self.local_stage1_shortcut(x1, act=pm.ACT_RELU, residual=x2)  # BNReLU(conv(x1)) + x2 (:123)
+        # BNReLU(conv(x1)) + stage2 (:123).  The shortcut needs only stage-1 features, so it is issued here, under
+        # the farthest-point sampling that stage 2 waits for, and the sum is folded into stage 2's last store.
+        shortcut = self.local_stage1_shortcut(x1, act=pm.ACT_RELU)
+        feat = self.stage2(geo, x2, residual=shortcut)
         return geo.xyz, feat
 
 
