@@ -156,7 +156,26 @@ class Geometry(object):
         key = (dilate, knn)
         if key not in self.levels:
             self.levels[key] = compute_level(self.xyz, dilate, knn)
-        return finish_level(self.xyz, self.levels[key]) if finish else self.levels[key]
+        return self.finish(self.levels[key]) if finish else self.levels[key]
+
+    def start_nn3(self, lv):
+        """Enqueue three_nn of a level on the CURRENT stream (the geometry side stream, behind the sampled-set
+        kNN) and leave an event for `finish`: it then overlaps the consumer's N/8 convolutions, which only need
+        lv["_level_ready"].  (A third stream would be the obvious way; hipGraph replay packs three branches
+        into two hardware queues and put the whole full-resolution chain behind three_nn -- measured.)"""
+        if "_nn3_done" in lv or "nn3_idx" in lv:
+            return
+        finish_level(self.xyz, lv, same_stream=True)
+        done = torch.cuda.Event()
+        done.record()
+        lv["_nn3_done"] = done
+
+    def finish(self, lv):
+        """Make nn3_dist / nn3_idx of a level usable on the current stream."""
+        if "_nn3_done" in lv:
+            torch.cuda.current_stream().wait_event(lv["_nn3_done"])
+            return lv
+        return finish_level(self.xyz, lv)
 
 
 def gather_rows(points, idx):
@@ -190,13 +209,17 @@ def compute_level(xyz, dilate, knn):
     else:
         srt_s, gbox_s = pm.spatial_sort(xyz_s)
         nbr_s, _ = pm.knn_sorted(srt_s, gbox_s, knn)
-    return {"idx": idx, "xyz_s": xyz_s, "nbr_s": nbr_s, "_xyz_ready": ready}
+    level_ready = torch.cuda.Event()
+    level_ready.record()  # idx / xyz_s / nbr_s exist
+    return {"idx": idx, "xyz_s": xyz_s, "nbr_s": nbr_s, "_xyz_ready": ready, "_level_ready": level_ready}
 
 
-def finish_level(xyz, lv):
-    """three_nn of the full cloud against the sampled set (run by the consumer stream; idempotent)."""
+def finish_level(xyz, lv, same_stream=False):
+    """three_nn of the full cloud against the sampled set (idempotent).  `same_stream`: the caller is on the
+    stream that produced the level, so stream order already covers lv["_xyz_ready"]."""
     if "nn3_idx" not in lv:
-        torch.cuda.current_stream().wait_event(lv["_xyz_ready"])
+        if not same_stream:
+            torch.cuda.current_stream().wait_event(lv["_xyz_ready"])
         B, N, _ = xyz.shape
         xyz_s = lv["xyz_s"]
         d3 = torch.empty((B, N, 3), dtype=torch.float32, device=xyz.device)
@@ -255,7 +278,7 @@ class FlexConvDilate(nn.Module):
         residual [B,N,cout]: added to the concat conv's output in its store (the caller's shortcut branch)."""
         prep = self._prep or self.prepare()
         if self.dilate > 1:
-            lv = geo.level(self.dilate, self.knn)
+            lv = geo.level(self.dilate, self.knn, finish=False)  # three_nn is joined only where it is consumed
             xyz_s, nbr_s = lv["xyz_s"], lv["nbr_s"]
             x = gather_rows(feat, lv["idx"])
         else:
@@ -268,6 +291,7 @@ class FlexConvDilate(nn.Module):
         if self.add_se == "max_pool":
             x = self.se(x, pm.flex_pool(x, nbr_s))
         if self.upsample and self.dilate > 1:
+            geo.finish(lv)
             x = pm.three_interpolate_idw(x, lv["nn3_idx"], lv["nn3_dist"])
         if self.concat:
             x = self.concat_conv1d(x, x2=feat, act=pm.ACT_RELU, residual=residual)

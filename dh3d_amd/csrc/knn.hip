@@ -424,9 +424,85 @@ __global__ __launch_bounds__(64 * kSortedWaves) void knn_sorted_kernel(const flo
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small clouds (N <= 2048: the N/8 sampled sets of the model).  The lane-per-query kernels above leave most of the
+// chip idle there (B*N/64 waves, each a long dependent scan).  Here a WAVE owns a query: every lane holds
+// CPL = N/64 candidates in registers (loaded once, reused for 4 queries), computes their exact keys
+// (bits(sqrt d) << 32 | tb), and the K nearest come out of K rounds of "smallest key >= last + 1" -- a per-lane
+// scan plus a two-step unsigned wave minimum on the DPP crossbar.  Keys are unique (tb is), so the strict
+// threshold replaces any bookkeeping of what was taken.  Same keys, same order, same outputs as knn_kernel.
+template <int CPL, bool XYZ>
+__global__ __launch_bounds__(256) void knn_small_kernel(const float *__restrict__ pos, int N, int K, KnnLadder lad,
+                                                       int32_t *__restrict__ nn, float *__restrict__ dist) {
+  constexpr int Q = 4;  // queries per wave
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q0 = (blockIdx.x * 4 + wave) * Q;
+  if (q0 >= N) return;
+  const float *base = pos + (size_t)b * N * 3;
+  float cx[CPL], cy[CPL], cz[CPL];
+  unsigned tbk[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int j = lane + 64 * c, jj = j < N ? j : 0;
+    cx[c] = XYZ ? base[(size_t)jj * 3] : base[jj];
+    cy[c] = XYZ ? base[(size_t)jj * 3 + 1] : base[(size_t)N + jj];
+    cz[c] = XYZ ? base[(size_t)jj * 3 + 2] : base[(size_t)2 * N + jj];
+    tbk[c] = j < N ? (unsigned)((j & lad.ctmask) * lad.cv + (j >> lad.log2ct)) : 0xFFFFFFFFu;
+  }
+  for (int qi = 0; qi < Q; ++qi) {
+    const int q = q0 + qi;
+    if (q >= N) break;
+    const float qx = XYZ ? base[(size_t)q * 3] : base[q];
+    const float qy = XYZ ? base[(size_t)q * 3 + 1] : base[(size_t)N + q];
+    const float qz = XYZ ? base[(size_t)q * 3 + 2] : base[(size_t)2 * N + q];
+    unsigned kd[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      // same roundings as knn_offer / the reference: sqrt(fma(dz,dz,fma(dy,dy,dx*dx))), :102-107
+      const float dx = qx - cx[c], dy = qy - cy[c], dz = qz - cz[c];
+      const float d = sqrtf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
+      kd[c] = tbk[c] != 0xFFFFFFFFu ? __float_as_uint(d) : 0xFFFFFFFFu;
+    }
+    u64 need = 0;  // smallest key still admissible
+    unsigned my_hi = 0xFFFFFFFFu, my_lo = 0xFFFFFFFFu;  // lane r keeps result r
+    for (int r = 0; r < K; ++r) {
+      u64 m = ~0ull;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const u64 key = ((u64)kd[c] << 32) | tbk[c];
+        m = (key >= need && key < m) ? key : m;
+      }
+      const unsigned hi = wave_min_u32((unsigned)(m >> 32));
+      const unsigned lo = wave_min_u32((unsigned)(m >> 32) == hi ? (unsigned)m : 0xFFFFFFFFu);
+      if (lane == r) { my_hi = hi; my_lo = lo; }
+      const u64 sel = ((u64)hi << 32) | lo;
+      if (sel == ~0ull) break;  // fewer than K points: the remaining slots keep the pad value
+      need = sel + 1;
+    }
+    if (lane < K) {
+      const size_t o = ((size_t)b * N + q) * K + lane;
+      if (my_hi == 0xFFFFFFFFu && my_lo == 0xFFFFFFFFu) {  // reference pads with id -1 / FLT_MAX (:110-111)
+        nn[o] = -1;
+        dist[o] = FLT_MAX;
+      } else {
+        nn[o] = (int)(((my_lo % (unsigned)lad.cv) << lad.log2ct) + my_lo / (unsigned)lad.cv);
+        dist[o] = __uint_as_float(my_hi);
+      }
+    }
+  }
+}
+
 template <bool XYZ>
 int knn_launch(const float *pos, int B, int N, int K, int32_t *nn, float *dist, hipStream_t s) {
   const KnnLadder lad = knn_ladder(N);
+  if (N <= 2048) {  // wave-per-query kernel
+    dim3 sgrid(dh3d_cdiv(N, 16), B), sblock(256);
+    if (N <= 512) hipLaunchKernelGGL((knn_small_kernel<8, XYZ>), sgrid, sblock, 0, s, pos, N, K, lad, nn, dist);
+    else if (N <= 1024) hipLaunchKernelGGL((knn_small_kernel<16, XYZ>), sgrid, sblock, 0, s, pos, N, K, lad, nn, dist);
+    else hipLaunchKernelGGL((knn_small_kernel<32, XYZ>), sgrid, sblock, 0, s, pos, N, K, lad, nn, dist);
+    return dh3d_launch_status();
+  }
   dim3 grid(dh3d_cdiv(N, kQueriesPerBlock), B), block(kQueriesPerBlock);
   if (K <= 4) hipLaunchKernelGGL((knn_kernel<4, XYZ>), grid, block, 0, s, pos, N, K, lad, nn, dist);
   else if (K <= 8) hipLaunchKernelGGL((knn_kernel<8, XYZ>), grid, block, 0, s, pos, N, K, lad, nn, dist);

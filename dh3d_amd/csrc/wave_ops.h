@@ -38,6 +38,11 @@ __device__ __forceinline__ int wave_min_i32(int v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+  asm volatile(DH3D_DPP_ROW16("v_min_u32_dpp") DH3D_DPP_ROWS("v_min_u32_dpp") : "+v"(v));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 __device__ __forceinline__ float wave_min_f32(float v) {
   asm volatile(DH3D_DPP_ROW16("v_min_f32_dpp") DH3D_DPP_ROWS("v_min_f32_dpp") : "+v"(v));
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));

@@ -130,11 +130,13 @@ class DH3D(nn.Module):
         side = self._geo_stream
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            # stage2 (dilate2=8) and global (gl_dilate=8) share it; three_nn is left to the main stream
+            # stage2 (dilate2=8) and global (gl_dilate=8) share it
             lv = geo.level(8, self.knn_num, finish=False)
+            geo.start_nn3(lv)  # three_nn behind the sampled-set kNN: overlaps the consumer's N/8 convolutions
             for t in lv.values():
                 if isinstance(t, torch.Tensor):
                     t.record_stream(main)
+        geo._lv = lv
         if knn_inds is not None:
             geo.nbr = knn_inds.contiguous()
         else:
@@ -154,10 +156,11 @@ class DH3D(nn.Module):
         init = pm.flex_pool(init, nn_8)
         x1 = self.stage1(geo, init, nbr=nn_8)
         x2 = self.before_stage2_conv1d(x1, act=pm.ACT_RELU)
-        geo.level(8, self.knn_num)  # three_nn on this stream as soon as the sampled xyz exist (side: kNN(N/8))
-        torch.cuda.current_stream().wait_stream(geo._side)  # FPS / gather / kNN(N/8) are needed from here
-        x2 = self.stage2(geo, x2)
-        feat = self.local_stage1_shortcut(x1, act=pm.ACT_RELU, residual=x2)
+        # BNReLU(conv(x1)) + stage2 (backbones.py:123): the shortcut needs stage-1 features only, so it runs under
+        # the FPS and its sum is folded into stage 2's last store
+        shortcut = self.local_stage1_shortcut(x1, act=pm.ACT_RELU)
+        torch.cuda.current_stream().wait_event(geo._lv["_level_ready"])  # FPS / gather / kNN(N/8) needed from here
+        feat = self.stage2(geo, x2, residual=shortcut)  # joins three_nn (geo.finish) at its interpolation
         self._last_geo = geo
         return points, feat
 
@@ -167,8 +170,7 @@ class DH3D(nn.Module):
         geo = outs.get("_geo")
         if geo is None:
             geo = self._geometry(points, None)
-            geo.level(8, self.knn_num)
-            torch.cuda.current_stream().wait_stream(geo._side)
+            torch.cuda.current_stream().wait_event(geo._lv["_level_ready"])
         forglobal = self.global_before_assemble(geo, localdesc)
         att = self.globalatt(forglobal)
         return self._netvlad(forglobal, att, l2_eps=l2_eps)

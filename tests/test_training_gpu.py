@@ -26,7 +26,7 @@ def _build(dev, seed=0, B=1, P=2, Ng=3):
 def test_autograd_head_matches_fused_path_in_eval_mode(dev):
     from dh3d_amd.training import global_head_autograd
     m = _build(dev)
-    pts = torch.rand(3, 1024, 3, device=dev)
+    pts = torch.rand(3, 1024, 3, generator=torch.Generator().manual_seed(101)).to(dev)
     with torch.no_grad():
         outs = m(pts)
         geo = m._geometry(pts, None)
@@ -42,7 +42,7 @@ def test_directional_gradient_of_the_head(dev):
     loss along a random direction in parameter space (f32: 2% tolerance)."""
     from dh3d_amd.training import global_head_autograd, trainable_head_parameters
     m = _build(dev, seed=3)
-    pts = torch.rand(7, 512, 3, device=dev)  # B=1: 1 anchor + 2 pos + 3 neg + 1 other-neg
+    pts = torch.rand(7, 512, 3, generator=torch.Generator().manual_seed(102)).to(dev)  # B=1: 1 anchor + 2 pos + 3 neg + 1 other-neg
     with torch.no_grad():
         geo = m._geometry(pts, None)
         _, local = m.compute_local(pts, _geo=geo)
@@ -79,7 +79,7 @@ def test_shard_partial_gradients_sum_to_full_gradient(dev):
     from dh3d_amd.training import global_head_autograd
     from dh3d_amd import dist as D, losses
     m = _build(dev, seed=5, B=1, P=2, Ng=3)
-    pts = torch.rand(7, 512, 3, device=dev)
+    pts = torch.rand(7, 512, 3, generator=torch.Generator().manual_seed(103)).to(dev)
     theta = m.global_before_assemble.flexconv_0.position_theta
     Wg = m.gating_weights
 
@@ -119,7 +119,7 @@ def test_training_steps_reduce_the_loss(dev):
     from dh3d_amd.training import QuadrupletTrainer
     m = _build(dev, seed=7, B=1, P=2, Ng=3)
     tr = QuadrupletTrainer(m, start_lr=2e-3)
-    pts = torch.rand(7, 512, 3, device=dev)
+    pts = torch.rand(7, 512, 3, generator=torch.Generator().manual_seed(104)).to(dev)
     before = [p.detach().clone() for p in tr.params[:3]]
     ls = [tr.step(pts) for _ in range(6)]
     assert all(np.isfinite(ls)) and ls[-1] < ls[0], ls
