@@ -155,7 +155,7 @@ class Geometry(object):
     def level(self, dilate, knn, finish=True):
         key = (dilate, knn)
         if key not in self.levels:
-            self.levels[key] = compute_level(self.xyz, dilate, knn)
+            self.levels[key] = compute_level(self.xyz, dilate, knn, ordered=self.sorted)
         return self.finish(self.levels[key]) if finish else self.levels[key]
 
     def start_nn3(self, lv):
@@ -190,17 +190,20 @@ def gather_rows(points, idx):
     return out
 
 
-def compute_level(xyz, dilate, knn):
-    """FPS -> gather xyz -> kNN on the sampled set -> three_nn back to the full set.
+def compute_level(xyz, dilate, knn, ordered=None):
+    """FPS -> gather xyz -> kNN on the sampled set (three_nn back to the full set: finish_level).
 
-    FPS runs on the raw cloud: the ordered variant (pm.fps_sorted) measured no faster on MI355X -- the round
-    is bound by its dependent reduce/barrier chain, not by the distance updates the ordering prunes -- and
-    the raw kernel needs no sort in front of it, so the side stream can start at t = 0."""
+    `ordered` = (records, group boxes) of pm.spatial_sort(xyz) if the caller has them: large clouds then use the
+    region-pruned FPS (csrc/fps.hip: 0.68 ms vs 0.82 ms at 8192 -> 1024; no gain at 4096 and below, where the
+    round is all synchronisation)."""
     B, N, _ = xyz.shape
     npoint = N // dilate
-    idx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
-    L.check(L.lib().dh3d_farthest_point_sample(B, N, npoint, L.ptr(xyz), None, L.ptr(idx), L.stream_ptr()),
-            "farthest_point_sample")
+    if ordered is not None and 4096 < N <= 12288:
+        idx = pm.fps_sorted(ordered[0], ordered[1], npoint)
+    else:
+        idx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
+        L.check(L.lib().dh3d_farthest_point_sample(B, N, npoint, L.ptr(xyz), None, L.ptr(idx), L.stream_ptr()),
+                "farthest_point_sample")
     xyz_s = gather_rows(xyz, idx)
     ready = torch.cuda.Event()
     ready.record()  # xyz_s exists: three_nn may start on another stream while the sampled-set kNN runs here

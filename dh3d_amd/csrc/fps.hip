@@ -31,6 +31,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #ifdef DH3D_FPS_PROBE  // dev instrumentation: cycle stamps of one round of wave 0 (tools/fps_probe.py)
 __device__ long long g_probe[16];
+__device__ unsigned long long g_fps_cnt[2];  // ordered kernel: active (wave, round) pairs, updated groups
 #define PROBE(i) do { if (r == 300 && tid == 0 && blockIdx.x == 0) g_probe[i] = clock64(); } while (0)
 #else
 #define PROBE(i) do { } while (0)
@@ -149,30 +150,36 @@ __global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// FPS on a spatially ordered cloud (spatial.hip).  Same results, less work per round: lane l of wave w
-// holds one point of each of the groups w, w+16, w+32, ... (64 Morton-consecutive points each).  A
-// group's running min-distances can only change if the new sample is closer to the group's bounding box
-// than the group's current maximum, so per round a wave
-//   1. tests its PPT boxes in parallel (lane j <-> group j; 12 VALU ops + one ballot),
-//   2. re-evaluates only the hit groups (1 point per lane) and refreshes that group's cached
-//      (max, key) with one DPP wave reduction,
-//   3. reduces the PPT cached (max, key) pairs with a 16-lane DPP row reduction.
-// After the first few dozen samples a round touches a handful of the N/64 groups instead of all N points.
+// FPS on a spatially ordered cloud (spatial.hip).  Same results, far less work per round.
+//
+// Wave w owns the Morton-consecutive groups [w*PPT, (w+1)*PPT) (64 points each: a compact region of the
+// cloud); lane l holds point l of each of them.  A point's running min-distance can only drop if the new sample
+// is closer to it than that distance, hence -- for a whole group -- only if the sample is closer to the group's
+// bounding box than the largest min-distance in the wave.  Per round every wave
+//   1. tests its PPT boxes in parallel (lane j <-> group j: ~12 VALU ops + one ballot) against its cached maximum;
+//   2. if nothing can change, re-offers its cached (max, key) -- no update, no reduction;
+//   3. otherwise updates just the hit groups (one point per lane each) and redoes ONE wave arg-max.
+// After the first few dozen samples a round touches one or two waves instead of all N points; the others spend
+// ~40 instructions.  (A first version cached a maximum per GROUP and reduced once per hit group: the
+// reductions serialised and it was no faster than the plain kernel.)
 // The skip test carries a 1e-5 relative margin: it may keep a group that cannot change, never the reverse.
 template <int PPT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void fps_sorted_kernel(const float4 *__restrict__ sorted,
                                                               const float *__restrict__ gbox, int N, int m,
                                                               int32_t *__restrict__ out) {
-  static_assert(PPT <= 64 && WAVES <= 16, "one lane per group box");
+  static_assert(PPT <= 64, "one lane per group box");
   extern __shared__ __attribute__((aligned(16))) float s_mem[];
-  float *s_val = s_mem;
-  int *s_key = reinterpret_cast<int *>(s_mem + 2 * WAVES);
-  float *s_x = s_mem + 4 * WAVES;  // coordinates by ORIGINAL index
+  // 3 rotating u64 block-best slots (as fps_kernel) | coordinates by ORIGINAL index | picks
+  // (Publishing each wave's candidate coordinates in a per-wave slot and selecting the winner's with v_readlane
+  //  -- to save the dependent table lookup -- measured SLOWER: 0.40 vs 0.36 ms of pure sync chain at 8 waves.)
+  unsigned long long *s_best = reinterpret_cast<unsigned long long *>(s_mem);
+  float *s_x = s_mem + 4 * WAVES;
   float *s_y = s_x + N;
   float *s_z = s_y + N;
   int *s_out = reinterpret_cast<int *>(s_z + N);  // picks, written to global memory once at the end
 
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NG = (N + 63) / 64;
   const float4 *sc = sorted + (size_t)b * N;
 
@@ -180,7 +187,7 @@ __global__ __launch_bounds__(64 * WAVES) void fps_sorted_kernel(const float4 *__
   int pkey[PPT];
 #pragma unroll
   for (int j = 0; j < PPT; ++j) {
-    const int i = (wave + WAVES * j) * 64 + lane;
+    const int i = (wave * PPT + j) * 64 + lane;
     px[j] = py[j] = pz[j] = 0.f;
     md[j] = -2.f;  // padding: below the reference's initial best = -1, never picked
     pkey[j] = INT_MAX;
@@ -193,23 +200,27 @@ __global__ __launch_bounds__(64 * WAVES) void fps_sorted_kernel(const float4 *__
       s_x[k] = r.x; s_y[k] = r.y; s_z[k] = r.z;
     }
   }
-  // lane j < PPT: box and cached (max, key) of this wave's group j
+  // lane j < PPT: bounding box of this wave's group j
   float blx = INFINITY, bly = INFINITY, blz = INFINITY, bhx = -INFINITY, bhy = -INFINITY, bhz = -INFINITY;
-  float gmax = -2.f;
-  int gkey = INT_MAX;
+  bool has_box = false;
   if (lane < PPT) {
-    const int g = wave + WAVES * lane;
+    const int g = wave * PPT + lane;
     if (g < NG) {
       const float *bx = gbox + ((size_t)b * NG + g) * 8;
       blx = bx[0]; bly = bx[1]; blz = bx[2]; bhx = bx[4]; bhy = bx[5]; bhz = bx[6];
-      gmax = 1e38f;
+      has_box = true;
     }
   }
   if (tid == 0) s_out[0] = 0;
+  if (tid < 3) s_best[tid] = 0ull;
   __syncthreads();
 
+  // cached wave maximum (uniform): 1e38 makes the first round update everything; a wave of pure padding
+  // offers nothing
+  float wmax = __ballot(has_box) != 0ull ? 1e38f : -2.f;
+  int wkey = INT_MAX;
   int old = 0;
-  int buf = 0;
+  int buf = 1;  // slot of round r is r % 3
   for (int r = 1; r < m; ++r) {
     const float x1 = s_x[old], y1 = s_y[old], z1 = s_z[old];
     // 1. which of my groups can change?  squared distance from the sample to each box (0 inside)
@@ -217,40 +228,48 @@ __global__ __launch_bounds__(64 * WAVES) void fps_sorted_kernel(const float4 *__
     const float ey = fmaxf(fmaxf(bly - y1, y1 - bhy), 0.f);
     const float ez = fmaxf(fmaxf(blz - z1, z1 - bhz), 0.f);
     const float bd = (ex * ex + ey * ey + ez * ez) * 0.99999f;
-    const unsigned long long need = __ballot(lane < PPT && bd <= gmax);
-    // 2. refresh the hit groups
+    const unsigned long long need = __ballot(has_box && bd <= wmax);
+#if defined(DH3D_FPS_PROBE) && DH3D_FPS_PROBE == 1
+    if (lane == 0 && need != 0ull) { atomicAdd(&g_fps_cnt[0], 1ull); atomicAdd(&g_fps_cnt[1], (unsigned long long)__popcll(need)); }
+#endif
+#if defined(DH3D_FPS_PROBE) && DH3D_FPS_PROBE == 2  // timing experiment: sync chain only (results wrong)
+    if (need != 0ull && r < 4) {
+#else
+    if (need != 0ull) {  // wave-uniform
+#endif
+      // 2. update the hit groups, then one wave arg-max over everything the wave holds
 #pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      if ((need >> j) & 1ull) {  // wave-uniform
-        const float dx = px[j] - x1, dy = py[j] - y1, dz = pz[j] - z1;
-        const float d = __fmaf_rn(dz, dz, __fmaf_rn(dx, dx, __fmul_rn(dy, dy)));
-        md[j] = vmin(d, md[j]);
-        const float gm = wave_max_f32(md[j]);
-        const unsigned long long hit = __ballot(md[j] == gm);
-        int gk;
-        if (__popcll(hit) == 1) gk = __builtin_amdgcn_readlane(pkey[j], __builtin_ctzll(hit));
-        else gk = wave_min_i32(md[j] == gm ? pkey[j] : INT_MAX);
-        if (lane == j) { gmax = gm; gkey = gk; }
+      for (int j = 0; j < PPT; ++j) {
+        if ((need >> j) & 1ull) {
+          const float dx = px[j] - x1, dy = py[j] - y1, dz = pz[j] - z1;
+          const float d = __fmaf_rn(dz, dz, __fmaf_rn(dx, dx, __fmul_rn(dy, dy)));
+          md[j] = vmin(d, md[j]);
+        }
       }
+      float best = -2.f;
+#pragma unroll
+      for (int j = 0; j + 1 < PPT; j += 2) best = vmax3(best, md[j], md[j + 1]);
+      if (PPT & 1) best = fmaxf(best, md[PPT - 1]);
+      wmax = wave_max_f32(best);
+      int lkey = INT_MAX;  // smallest key among the lane's points that hold wmax
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) lkey = (md[j] == wmax) ? min(lkey, pkey[j]) : lkey;
+      const unsigned long long hit = __ballot(best == wmax);
+      if (__popcll(hit) == 1) wkey = __builtin_amdgcn_readlane(lkey, __builtin_ctzll(hit));
+      else wkey = wave_min_i32(lkey);  // several lanes tie: smallest key wins (non-hit lanes hold INT_MAX)
     }
-    // 3. wave winner over the cached groups (lanes 0..PPT-1; other lanes hold -2 / INT_MAX)
-    const float wmax = wave_max_f32(gmax);
-    const unsigned long long hitw = __ballot(gmax == wmax);
-    int wkey;
-    if (__popcll(hitw) == 1) wkey = __builtin_amdgcn_readlane(gkey, __builtin_ctzll(hitw));
-    else wkey = wave_min_i32(gmax == wmax ? gkey : INT_MAX);
-    if (lane == 0) { s_val[buf * WAVES + wave] = wmax; s_key[buf * WAVES + wave] = wkey; }
+    // 3. block arg-max: one 64-bit LDS atomic max per wave on (bits(value) << 32 | ~key)
+    if (lane == 0) {
+      const unsigned long long packed =
+          wmax >= 0.f ? (((unsigned long long)__float_as_uint(wmax) << 32) | (unsigned)~wkey) : 0ull;
+      atomicMax(&s_best[buf], packed);
+      if (wave == 0) s_best[buf == 2 ? 0 : buf + 1] = 0ull;  // next round's slot (last read two rounds ago)
+    }
     __syncthreads();
-    const float v = s_val[buf * WAVES + (lane & (WAVES - 1))];
-    const int kk = s_key[buf * WAVES + (lane & (WAVES - 1))];
-    const float bmax = row16_max_f32(v);
-    const unsigned long long hit2 = __ballot(v == bmax) & ((1ull << WAVES) - 1);
-    int bkey;
-    if (__popcll(hit2) == 1) bkey = __builtin_amdgcn_readlane(kk, __builtin_ctzll(hit2));
-    else bkey = __builtin_amdgcn_readfirstlane(row16_min_i32(v == bmax ? kk : INT_MAX));
+    const int bkey = ~(int)(unsigned)s_best[buf];
     old = fps_unkey(bkey);
     if (tid == 0) s_out[r] = old;
-    buf ^= 1;
+    buf = buf == 2 ? 0 : buf + 1;
   }
   __syncthreads();
   for (int r = tid; r < m; r += 64 * WAVES) out[(size_t)b * m + r] = s_out[r];
@@ -319,15 +338,18 @@ DH3D_API int dh3d_fps_sorted(const float *sorted, const float *gbox, int B, int 
   DH3D_REQUIRE(sorted && gbox && out && B > 0 && N > 0 && m > 0);
   DH3D_SUPPORTED(N <= 12288);  // the by-original-index coordinate table must fit LDS (12 B / point)
   hipStream_t s = (hipStream_t)stream;
-  const int W = g_fps_sorted_waves ? g_fps_sorted_waves : 16;
-#define DH3D_FPS_CASE(WV)                                                                       \
-  if (W == WV) {                                                                                \
-    const int per = 64 * WV;                                                                    \
-    if (N <= per * 4) return fps_sorted_launch<4, WV>(sorted, gbox, B, N, m, out, s);           \
-    if (N <= per * 8) return fps_sorted_launch<8, WV>(sorted, gbox, B, N, m, out, s);           \
-    if (N <= per * 16) return fps_sorted_launch<16, WV>(sorted, gbox, B, N, m, out, s);         \
-    if (N <= per * 32) return fps_sorted_launch<32, WV>(sorted, gbox, B, N, m, out, s);         \
-    if (N <= per * 64) return fps_sorted_launch<64, WV>(sorted, gbox, B, N, m, out, s);         \
+  const int W = g_fps_sorted_waves ? g_fps_sorted_waves : 16;  // measured best on MI355X (tools/geo_bench.py)
+  const int NG = (N + 63) / 64;
+#define DH3D_FPS_CASE(WV)                                                                             \
+  if (W == WV) {                                                                                      \
+    const int gpw = (NG + WV - 1) / WV; /* groups per wave */                                         \
+    if (gpw <= 1) return fps_sorted_launch<1, WV>(sorted, gbox, B, N, m, out, s);                     \
+    if (gpw <= 2) return fps_sorted_launch<2, WV>(sorted, gbox, B, N, m, out, s);                     \
+    if (gpw <= 4) return fps_sorted_launch<4, WV>(sorted, gbox, B, N, m, out, s);                     \
+    if (gpw <= 8) return fps_sorted_launch<8, WV>(sorted, gbox, B, N, m, out, s);                     \
+    if (gpw <= 16) return fps_sorted_launch<16, WV>(sorted, gbox, B, N, m, out, s);                   \
+    if (gpw <= 32) return fps_sorted_launch<32, WV>(sorted, gbox, B, N, m, out, s);                   \
+    if (gpw <= 48) return fps_sorted_launch<48, WV>(sorted, gbox, B, N, m, out, s);                   \
   }
   DH3D_FPS_CASE(4)
   DH3D_FPS_CASE(8)
@@ -337,6 +359,11 @@ DH3D_API int dh3d_fps_sorted(const float *sorted, const float *gbox, int B, int 
 }
 
 #ifdef DH3D_FPS_PROBE
+DH3D_API int dh3d_fps_cnt_read(unsigned long long *host2, int reset) {
+  int rc = hipMemcpyFromSymbol(host2, HIP_SYMBOL(g_fps_cnt), 16) == hipSuccess ? 0 : 3;
+  if (reset) { unsigned long long z[2] = {0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fps_cnt), z, 16); }
+  return rc;
+}
 DH3D_API int dh3d_fps_probe_read(long long *host16) {
   return hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_probe), sizeof(long long) * 16) == hipSuccess ? 0 : 3;
 }

@@ -125,6 +125,8 @@ class DH3D(nn.Module):
     def _geometry(self, points, knn_inds=None):
         geo = bb.Geometry(points, self.knn_num)
         main = torch.cuda.current_stream()
+        if 4096 < points.shape[1] <= 12288:
+            geo.ordered()  # Morton order + group boxes first: shared by the kNN (here) and the pruned FPS (side)
         if self._geo_stream is None:
             self._geo_stream = torch.cuda.Stream(device=points.device)
         side = self._geo_stream
