@@ -159,13 +159,11 @@ class Geometry(object):
         return self.finish(self.levels[key]) if finish else self.levels[key]
 
     def start_nn3(self, lv):
-        """Enqueue three_nn of a level on the CURRENT stream (the geometry side stream, behind the sampled-set
-        kNN) and leave an event for `finish`: it then overlaps the consumer's N/8 convolutions, which only need
-        lv["_level_ready"].  (A third stream would be the obvious way; hipGraph replay packs three branches
-        into two hardware queues and put the whole full-resolution chain behind three_nn -- measured.)"""
+        """Enqueue three_nn of a level on the CURRENT stream (it first waits for the sampled coordinates) and leave
+        an event for `finish`; meant for a stream that runs beside the consumer's N/8 convolutions."""
         if "_nn3_done" in lv or "nn3_idx" in lv:
             return
-        finish_level(self.xyz, lv, same_stream=True)
+        finish_level(self.xyz, lv)
         done = torch.cuda.Event()
         done.record()
         lv["_nn3_done"] = done

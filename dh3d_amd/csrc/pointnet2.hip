@@ -53,15 +53,21 @@ __device__ __forceinline__ int nn_slot(int c, int comp) {
   return g * 12 + ((r < 2) ? (2 * comp + r) : (4 + 2 * comp + r));
 }
 
-// lane = query; 8 candidates per step as packed f32 (unfused mul/add, the reference's roundings); the
-// 3-deep insertion only runs when one of the 8 beats the lane's current third-best.
+// lane = query (64 per workgroup); the four waves split the candidates (32-candidate steps, interleaved) so a
+// query group keeps 4 waves per SIMD busy instead of one long scan, and their four 3-deep lists are merged
+// through LDS on (distance, index) -- the reference's strict '<' in index order = smallest index among equals.
+// 8 candidates per packed-f32 sub-step (unfused mul/add, the reference's roundings); the 3-deep insertion only
+// runs when one of them beats the lane's current third-best.
 __global__ __launch_bounds__(kBlock) void three_nn_kernel(int n, int m, const float *__restrict__ xyz1,
                                                          const float *__restrict__ xyz2,
                                                          float *__restrict__ dist,
                                                          int32_t *__restrict__ idx) {
   __shared__ __attribute__((aligned(16))) float s_c[kNNChunk * 3];
+  __shared__ float s_md[3][3][64];  // partial lists of waves 1..3: [wave-1][rank][query]
+  __shared__ int s_mi[3][3][64];
   const int b = blockIdx.y;
-  const int j = blockIdx.x * kBlock + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
   const float *q = xyz1 + ((size_t)b * n + j) * 3;
   const float *cand = xyz2 + (size_t)b * m * 3;
   float x1 = 0.f, y1 = 0.f, z1 = 0.f;
@@ -81,7 +87,7 @@ __global__ __launch_bounds__(kBlock) void three_nn_kernel(int n, int m, const fl
     }
     __syncthreads();
     // 32 candidates per iteration with one wave-uniform test, so the LDS reads and packed ops pipeline
-    for (int k = 0; k < len32; k += 32) {
+    for (int k = 32 * wave; k < len32; k += 32 * (kBlock / 64)) {
       f32x2 d[4][4];
       float mn[4];
 #pragma unroll
@@ -131,7 +137,26 @@ __global__ __launch_bounds__(kBlock) void three_nn_kernel(int n, int m, const fl
       }
     }
   }
-  if (j < n) {
+  if (wave > 0) {
+    s_md[wave - 1][0][lane] = best1; s_md[wave - 1][1][lane] = best2; s_md[wave - 1][2][lane] = best3;
+    s_mi[wave - 1][0][lane] = bi1; s_mi[wave - 1][1][lane] = bi2; s_mi[wave - 1][2][lane] = bi3;
+  }
+  __syncthreads();
+  if (wave == 0 && j < n) {
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const float dv = s_md[w][t][lane];
+        const int kk = s_mi[w][t][lane];
+        if (dv < best1 || (dv == best1 && kk < bi1)) {
+          best3 = best2; bi3 = bi2; best2 = best1; bi2 = bi1; best1 = dv; bi1 = kk;
+        } else if (dv < best2 || (dv == best2 && kk < bi2)) {
+          best3 = best2; bi3 = bi2; best2 = dv; bi2 = kk;
+        } else if (dv < best3 || (dv == best3 && kk < bi3)) {
+          best3 = dv; bi3 = kk;
+        }
+      }
     const size_t o = ((size_t)b * n + j) * 3;
     dist[o] = best1; dist[o + 1] = best2; dist[o + 2] = best3;
     idx[o] = bi1; idx[o + 1] = bi2; idx[o + 2] = bi3;
@@ -228,7 +253,7 @@ DH3D_API int dh3d_three_nn(int b, int n, int m, const float *xyz1, const float *
                            int32_t *idx, void *stream) {
   DH3D_REQUIRE(xyz1 && xyz2 && dist && idx && b > 0 && n > 0 && m > 0);
   DH3D_SUPPORTED(b <= 65535);
-  hipLaunchKernelGGL(three_nn_kernel, dim3(dh3d_cdiv(n, kBlock), b), dim3(kBlock), 0,
+  hipLaunchKernelGGL(three_nn_kernel, dim3(dh3d_cdiv(n, 64), b), dim3(kBlock), 0,
                      (hipStream_t)stream, n, m, xyz1, xyz2, dist, idx);
   return dh3d_launch_status();
 }

@@ -121,48 +121,64 @@ class DH3D(nn.Module):
         if not self._prepared:
             self.prepare()
 
-    # ------------------------------------------------------------------ geometry on a side stream
+    # ------------------------------------------------------------------ two streams
+    # The step's critical path is  sort -> FPS -> gather -> kNN(N/8) -> stage 2 -> concat conv -> ...  (FPS alone is
+    # ~70 % of the local step).  It stays on the CALLER's stream end to end; everything that only needs the full
+    # cloud (kNN(N), initconv, stage 1, the two 1x1 convs, three_nn) runs beside it on a side stream and joins
+    # where stage 2 starts.  (hipGraph replay charges ~10 us per cross-queue dependency that is last to arrive, so
+    # the critical chain must not hop between queues: the earlier arrangement -- FPS on the side stream --
+    # paid that twice per step.)
     def _geometry(self, points, knn_inds=None):
         geo = bb.Geometry(points, self.knn_num)
         main = torch.cuda.current_stream()
-        if 4096 < points.shape[1] <= 12288:
-            geo.ordered()  # Morton order + group boxes first: shared by the kNN (here) and the pruned FPS (side)
+        if knn_inds is None or 4096 < points.shape[1] <= 12288:
+            geo.ordered()  # Morton order + group boxes: shared by the kNN (side) and the pruned FPS (here)
         if self._geo_stream is None:
             self._geo_stream = torch.cuda.Stream(device=points.device)
         side = self._geo_stream
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            # stage2 (dilate2=8) and global (gl_dilate=8) share it
-            lv = geo.level(8, self.knn_num, finish=False)
-            geo.start_nn3(lv)  # three_nn behind the sampled-set kNN: overlaps the consumer's N/8 convolutions
-            for t in lv.values():
-                if isinstance(t, torch.Tensor):
-                    t.record_stream(main)
-        geo._lv = lv
-        if knn_inds is not None:
-            geo.nbr = knn_inds.contiguous()
-        else:
-            srt, gbox = geo.ordered()  # Morton order + group boxes -> exact kNN with box pruning
-            geo.nbr, _ = pm.knn_sorted(srt, gbox, self.knn_num)  # core/model.py:157
+        fork = torch.cuda.Event()
+        fork.record()  # the side stream needs the input (and the ordering) only
         geo._side = side
+        # stage2 (dilate2=8) and global (gl_dilate=8) share this level.  Enqueued BEFORE the side work: hipGraph keeps
+        # a node's first-captured successor on its queue, and the FPS chain is the one that must not hop.
+        geo._lv = geo.level(8, self.knn_num, finish=False)
+        side.wait_event(fork)
+        with torch.cuda.stream(side):
+            if knn_inds is not None:
+                geo.nbr = knn_inds.contiguous()
+            else:
+                srt, gbox = geo.ordered()  # exact kNN with box pruning
+                geo.nbr, _ = pm.knn_sorted(srt, gbox, self.knn_num)  # core/model.py:157
+            geo.nbr.record_stream(main)
         return geo
+
+    def _join_side(self, geo):
+        """Everything enqueued on the side stream so far is visible to the current stream."""
+        torch.cuda.current_stream().wait_stream(geo._side)
 
     # ------------------------------------------------------------------ reference API
     def compute_local(self, points, knn_inds=None, _geo=None):
         self._check_mode()
         geo = _geo if _geo is not None else self._geometry(points, knn_inds)
+        main = torch.cuda.current_stream()
         p = self._local._prep
-        nn_8 = geo.nbr if geo.nbr.shape[2] == 8 else geo.nbr[:, :, 0:8].contiguous()
-        init = pm.conv_pointset_xyz(geo.xyz, nn_8, p["theta"], p["bias"], scale=p["scale"], shift=p["shift"],
-                                    act=pm.ACT_RELU)
-        init = pm.flex_pool(init, nn_8)
-        x1 = self.stage1(geo, init, nbr=nn_8)
-        x2 = self.before_stage2_conv1d(x1, act=pm.ACT_RELU)
-        # BNReLU(conv(x1)) + stage2 (backbones.py:123): the shortcut needs stage-1 features only, so it runs under
-        # the FPS and its sum is folded into stage 2's last store
-        shortcut = self.local_stage1_shortcut(x1, act=pm.ACT_RELU)
-        torch.cuda.current_stream().wait_event(geo._lv["_level_ready"])  # FPS / gather / kNN(N/8) needed from here
-        feat = self.stage2(geo, x2, residual=shortcut)  # joins three_nn (geo.finish) at its interpolation
+        with torch.cuda.stream(geo._side):  # behind kNN(N), beside the FPS chain
+            nn_8 = geo.nbr if geo.nbr.shape[2] == 8 else geo.nbr[:, :, 0:8].contiguous()
+            init = pm.conv_pointset_xyz(geo.xyz, nn_8, p["theta"], p["bias"], scale=p["scale"], shift=p["shift"],
+                                        act=pm.ACT_RELU)
+            init = pm.flex_pool(init, nn_8)
+            x1 = self.stage1(geo, init, nbr=nn_8)
+            x2 = self.before_stage2_conv1d(x1, act=pm.ACT_RELU)
+            # BNReLU(conv(x1)) + stage2 (backbones.py:123): the shortcut needs stage-1 features only, so it runs
+            # here and its sum is folded into stage 2's last store
+            shortcut = self.local_stage1_shortcut(x1, act=pm.ACT_RELU)
+            stage1_done = torch.cuda.Event()
+            stage1_done.record()
+            geo.start_nn3(geo._lv)  # three_nn: waits for the sampled coordinates, overlaps the N/8 convolutions
+            for t in (x2, shortcut, geo._lv["nn3_dist"], geo._lv["nn3_idx"]):
+                t.record_stream(main)
+        main.wait_event(stage1_done)  # not the whole side stream: three_nn is joined at the interpolation (geo.finish)
+        feat = self.stage2(geo, x2, residual=shortcut)  # gather, N/8 convs, SE, interpolation, concat conv
         self._last_geo = geo
         return points, feat
 
@@ -172,7 +188,7 @@ class DH3D(nn.Module):
         geo = outs.get("_geo")
         if geo is None:
             geo = self._geometry(points, None)
-            torch.cuda.current_stream().wait_event(geo._lv["_level_ready"])
+            self._join_side(geo)
         forglobal = self.global_before_assemble(geo, localdesc)
         att = self.globalatt(forglobal)
         return self._netvlad(forglobal, att, l2_eps=l2_eps)
