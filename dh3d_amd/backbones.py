@@ -77,6 +77,8 @@ class Conv2D1x1(nn.Module):
         p = {"W2": W2, "b": self.b.detach().contiguous()}
         if self.cout % 64 == 0 and self.cin % 8 == 0:
             p["wp"] = pm.pack_weight(W2)
+        if self.cout in (128, 256) and self.cin % 32 == 0:
+            p["wp3"] = pm.pack_weight_x3(W2)  # large row counts go to the tiled bf16x6 GEMM
         if self.bn is not None:
             p["scale"], p["shift"] = [t.detach() for t in self.bn.fold()]
         else:
@@ -86,6 +88,12 @@ class Conv2D1x1(nn.Module):
 
     def forward(self, x, x2=None, act=pm.ACT_RELU, residual=None):
         p = self._prep or self.prepare()
+        # the choice depends on the points per cloud only, never on the batch: a sharded batch must reproduce the
+        # unsharded result bit for bit
+        per_cloud = x.shape[-2] if x.dim() >= 2 else 1
+        if "wp3" in p and per_cloud >= 4096 and x.shape[-1] % 32 == 0 and (x2 is None or x2.shape[-1] % 32 == 0):
+            return pm.linear_x6(x, p["wp3"], self.cout, x2=x2, pre_bias=p["b"], scale=p["scale"], shift=p["shift"],
+                                act=act, residual=residual)
         return pm.linear(x, p["wp"], self.cout, x2=x2, pre_bias=p["b"], scale=p["scale"], shift=p["shift"],
                          act=act, residual=residual)
 

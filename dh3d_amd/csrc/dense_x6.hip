@@ -193,6 +193,135 @@ __global__ __launch_bounds__(512) void mlp_head_x6_kernel(const float *__restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// out[R, Dout] = act(bn([x1 | x2] @ W + b)) (+ residual) for the wide 1x1 convs (Dout = 128 or 256), same tiling
+// and staging as the head above; NC = 32-column blocks per wave (1: Dout = 128, 2: Dout = 256).  The finished
+// 128 x Dout tile goes through LDS (the stage buffers are dead by then) so that every lane stores 16 bytes of
+// a full output row, residual added on the way.
+template <int NC>
+__global__ __launch_bounds__(512) void linear_x6_kernel(const float *__restrict__ x1, int C1,
+                                                       const float *__restrict__ x2, int C2,
+                                                       const uint4 *__restrict__ wp, EpilogueArgs ep,
+                                                       const float *__restrict__ residual, long long R,
+                                                       float *__restrict__ out) {
+  constexpr int TN = NC * 128;                      // columns of the tile = Dout
+  constexpr int BST = (TN / 32) * 2 * 3 * 64;       // uint4 per B buffer
+  constexpr int DMA = BST / 64 / 8;                 // LDS-DMA instructions per wave per chunk
+  constexpr int LDO = TN + 4;                       // leading dimension of the output tile in LDS
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  unsigned short *s_A = reinterpret_cast<unsigned short *>(s_raw);          // [2][3][HTM][LDA]
+  uint4 *s_B = reinterpret_cast<uint4 *>(s_raw + (size_t)2 * A_STAGE * 2);  // [2][BST]
+  float *s_out = reinterpret_cast<float *>(s_raw);                          // [HTM][LDO] after the K loop
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const long long grow0 = (long long)blockIdx.x * HTM;
+  const int C = C1 + C2, KB = C / 16, NCH = C / HKC;
+  const int ar = tid >> 2, ah = tid & 3;
+  long long arow = grow0 + ar;
+  if (arow >= R) arow = R - 1;  // rows past R repeat the last row; they are not stored
+  float4 pa[2];
+  auto prefetch_a = [&](int ch) __attribute__((always_inline)) {
+    const int k0 = ch * HKC + ah * 8;
+    const float *src = k0 < C1 ? x1 + arow * C1 + k0 : x2 + arow * C2 + (k0 - C1);
+    const float4 *ap = reinterpret_cast<const float4 *>(src);
+    pa[0] = ap[0]; pa[1] = ap[1];
+  };
+  auto dma_b = [&](int ch, int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < DMA; ++j) {
+      const int e0 = (wave * DMA + j) * 64, cb = e0 / 384, rem = e0 - cb * 384 + lane;
+      const uint4 *src = wp + ((size_t)cb * KB + ch * 2) * 192 + rem;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)(s_B + (size_t)buf * BST + e0), 16, 0, 0);
+    }
+  };
+  auto stage_a = [&](int buf) __attribute__((always_inline)) {
+    unsigned short *dst = s_A + (size_t)buf * A_STAGE + (size_t)ar * LDA + ah * 8;
+    uint2 c1[2], c2[2], c3[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) split3x4(pa[j], c1[j], c2[j], c3[j]);
+    *reinterpret_cast<uint4 *>(dst) = make_uint4(c1[0].x, c1[0].y, c1[1].x, c1[1].y);
+    *reinterpret_cast<uint4 *>(dst + HTM * LDA) = make_uint4(c2[0].x, c2[0].y, c2[1].x, c2[1].y);
+    *reinterpret_cast<uint4 *>(dst + 2 * HTM * LDA) = make_uint4(c3[0].x, c3[0].y, c3[1].x, c3[1].y);
+  };
+  auto stage_sync = [&]() __attribute__((always_inline)) {  // LDS-DMA counts on vmcnt
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+
+  prefetch_a(0);
+  dma_b(0, 0);
+  stage_a(0);
+  stage_sync();
+  f32x16 acc[2][NC];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < NC; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int nxt = ch + 1 < NCH ? ch + 1 : ch;  // unconditional prefetch: the last one is a harmless repeat
+    prefetch_a(nxt);
+    const int buf = ch & 1;
+    dma_b(nxt, buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned short *abase = s_A + (size_t)buf * A_STAGE + (size_t)(wr * 64 + (lane & 31)) * LDA + 8 * (lane >> 5);
+    const uint4 *bbase = s_B + (size_t)buf * BST + (size_t)(wc * NC) * (2 * 3 * 64) + lane;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[2][3], b[NC][3];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          a[rb][p] = *reinterpret_cast<const bf16x8 *>(abase + (size_t)p * HTM * LDA + (size_t)rb * 32 * LDA + ks * 16);
+#pragma unroll
+      for (int cb = 0; cb < NC; ++cb)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b[cb][p] = __builtin_bit_cast(bf16x8, bbase[((cb * 2 + ks) * 3 + p) * 64]);
+#define DH3D_X6_PRODUCT(PA, PB)                                                                          \
+  _Pragma("unroll") for (int rb = 0; rb < 2; ++rb) _Pragma("unroll") for (int cb = 0; cb < NC; ++cb)     \
+      acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rb][PA], b[cb][PB], acc[rb][cb], 0, 0, 0);
+      DH3D_X6_PRODUCT(2, 0) DH3D_X6_PRODUCT(0, 2) DH3D_X6_PRODUCT(1, 1)
+      DH3D_X6_PRODUCT(1, 0) DH3D_X6_PRODUCT(0, 1) DH3D_X6_PRODUCT(0, 0)
+#undef DH3D_X6_PRODUCT
+    }
+    stage_a(buf ^ 1);
+    stage_sync();
+  }
+  // epilogue: bias + BN + activation in registers -> tile in LDS -> full-row 16-byte stores (+ residual)
+#pragma unroll
+  for (int cb = 0; cb < NC; ++cb) {
+    const int col = (wc * NC + cb) * 32 + (lane & 31);
+    float pb = 0.f, sc = 1.f, sh = 0.f;
+    if (ep.pre_bias) pb = ep.pre_bias[col];
+    if (ep.scale) sc = ep.scale[col];
+    if (ep.shift) sh = ep.shift[col];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        s_out[(size_t)(wr * 64 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDO + col] =
+            dh3d_act((acc[rb][cb][r] + pb) * sc + sh, ep.act);
+  }
+  __syncthreads();
+  constexpr int CV = TN / 4;
+  for (int e = tid; e < HTM * CV; e += 512) {
+    const int p = e / CV, c4 = (e - p * CV) * 4;
+    const long long g = grow0 + p;
+    if (g < R) {
+      float4 v = *reinterpret_cast<const float4 *>(s_out + (size_t)p * LDO + c4);
+      if (residual) {
+        const float4 q = *reinterpret_cast<const float4 *>(residual + g * TN + c4);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+      }
+      *reinterpret_cast<float4 *>(out + g * TN + c4) = v;
+    }
+  }
+}
+
 }  // namespace
 
 DH3D_API int dh3d_pack_weight_x3(const float *W, int Kd, int Dout, void *packed, void *stream) {
@@ -213,5 +342,32 @@ DH3D_API int dh3d_mlp_head_pm_x6_fwd(const float *h, int R, int C, const void *w
   DH3D_ALLOW_BIG_LDS(kern);
   hipLaunchKernelGGL(kern, dim3(dh3d_cdiv(R, HTM)), dim3(512), lds, (hipStream_t)stream, h, C,
                      static_cast<const uint4 *>(wpacked_x3), H, dh3d_ep(ep), w_fc, b_fc, (long long)R, att);
+  return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_linear_pm_x6_fwd(const float *x1, int C1, const float *x2, int C2, const void *wpacked_x3, int R,
+                                   int Dout, const dh3d_epilogue *ep, const float *residual, float *out,
+                                   void *stream) {
+  DH3D_REQUIRE(x1 && wpacked_x3 && out && R > 0 && C1 > 0 && C2 >= 0 && Dout > 0 && (C2 == 0 || x2));
+  DH3D_SUPPORTED(C1 % HKC == 0 && C2 % HKC == 0 && (Dout == 128 || Dout == 256));
+  const EpilogueArgs e = dh3d_ep(ep);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(dh3d_cdiv(R, HTM)), block(512);
+  const uint4 *wp = static_cast<const uint4 *>(wpacked_x3);
+  if (Dout == 128) {
+    size_t lds = (size_t)2 * A_STAGE * 2 + (size_t)2 * (128 / 32) * 2 * 3 * 64 * 16;
+    const size_t tile = sizeof(float) * HTM * (128 + 4);
+    if (tile > lds) lds = tile;
+    auto kern = linear_x6_kernel<1>;
+    DH3D_ALLOW_BIG_LDS(kern);
+    hipLaunchKernelGGL(kern, grid, block, lds, s, x1, C1, x2, C2, wp, e, residual, (long long)R, out);
+  } else {
+    size_t lds = (size_t)2 * A_STAGE * 2 + (size_t)2 * (256 / 32) * 2 * 3 * 64 * 16;
+    const size_t tile = sizeof(float) * HTM * (256 + 4);
+    if (tile > lds) lds = tile;
+    auto kern = linear_x6_kernel<2>;
+    DH3D_ALLOW_BIG_LDS(kern);
+    hipLaunchKernelGGL(kern, grid, block, lds, s, x1, C1, x2, C2, wp, e, residual, (long long)R, out);
+  }
   return dh3d_launch_status();
 }

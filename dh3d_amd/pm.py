@@ -220,6 +220,29 @@ def mlp_head(h, wpacked, H, w_fc, b_fc, pre_bias=None, scale=None, shift=None, a
     return out
 
 
+def linear_x6(x1, wpacked_x3, Dout, x2=None, pre_bias=None, scale=None, shift=None, act=ACT_NONE, residual=None):
+    """linear() on the bf16 pipe at f32 accuracy (tiled bf16x6 GEMM); Dout in {128, 256}, C1/C2 multiples of 32."""
+    a = L.require_cuda_f32(x1, "x1")
+    lead = a.shape[:-1]
+    C1 = a.shape[-1]
+    R = a.numel() // C1
+    C2 = 0
+    b = None
+    if x2 is not None:
+        b = L.require_cuda_f32(x2, "x2")
+        C2 = b.shape[-1]
+        if b.shape[:-1] != lead:
+            raise ValueError("linear_x6: x1/x2 leading dims differ")
+    res = None
+    if residual is not None:
+        res = L.require_cuda_f32(residual, "residual")
+    out = torch.empty(lead + (Dout,), dtype=torch.float32, device=a.device)
+    ep = _ep(pre_bias, scale, shift, act)
+    L.check(L.lib().dh3d_linear_pm_x6_fwd(L.ptr(a), C1, L.ptr(b), C2, L.ptr(wpacked_x3), R, Dout, ep, L.ptr(res),
+                                          L.ptr(out), L.stream_ptr()), "linear_pm_x6")
+    return out
+
+
 def pack_weight_x3(W):
     """W [Kd, Dout] f32 -> three exact bf16 chunk planes in MFMA fragment order (csrc/dense_x6.hip)."""
     W = L.require_cuda_f32(W, "W", 2)

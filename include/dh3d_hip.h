@@ -225,6 +225,12 @@ int dh3d_mlp_head_pm_fwd(const float *h, int R, int C, const float *wpacked, int
                          const dh3d_epilogue *ep, const float *w_fc, float b_fc, float *att,
                          void *stream);
 
+/* dh3d_linear_pm_fwd on the bf16 matrix pipe at f32 accuracy (bf16x6, csrc/dense_x6.hip) for the wide 1x1 convs:
+ * Dout in {128, 256}, C1 and C2 multiples of 32, weight from dh3d_pack_weight_x3.  Same result up to f32
+ * summation order. */
+int dh3d_linear_pm_x6_fwd(const float *x1, int C1, const float *x2, int C2, const void *wpacked_x3, int R, int Dout,
+                          const dh3d_epilogue *ep, const float *residual, float *out, void *stream);
+
 /* The same head with the GEMM on the bf16 matrix pipe at f32 accuracy ("bf16x6": every f32 operand is split
  * exactly into three bf16 chunks, six chunk products are accumulated in f32; error <= 2^-23 per product, see
  * csrc/dense_x6.hip).  wpacked_x3 from dh3d_pack_weight_x3 (3 * Kd * Dout * 2 bytes).  C % 16 == 0. */

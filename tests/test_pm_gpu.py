@@ -147,6 +147,28 @@ def test_linear_pm_vs_fp64(dev, C1, C2, Dout):
     assert close(out, exp, 1e-4, 1e-5)
 
 
+@pytest.mark.parametrize("C1,C2,Dout,R", [(128, 64, 128, 1000), (64, 0, 128, 4097), (128, 128, 256, 777), (256, 0, 256, 128)])
+def test_linear_x6_vs_fp64(dev, C1, C2, Dout, R):
+    """Tiled bf16x6 GEMM: f32-accurate against float64 (ragged row counts, concat input, both tile widths)."""
+    from dh3d_amd import pm
+    rng = np.random.default_rng(C1 + Dout + R)
+    x1 = rng.standard_normal((R, C1)).astype(np.float32)
+    x2 = rng.standard_normal((R, C2)).astype(np.float32) if C2 else None
+    W = (rng.standard_normal((C1 + C2, Dout)) / np.sqrt(C1 + C2)).astype(np.float32)
+    b = rng.standard_normal(Dout).astype(np.float32)
+    sc = (0.5 + rng.random(Dout)).astype(np.float32)
+    sh = rng.standard_normal(Dout).astype(np.float32)
+    res = rng.standard_normal((R, Dout)).astype(np.float32)
+    kw = dict(x2=T(x2, dev) if C2 else None, pre_bias=T(b, dev), scale=T(sc, dev), shift=T(sh, dev), act=pm.ACT_RELU,
+              residual=T(res, dev))
+    out = pm.linear_x6(T(x1, dev), pm.pack_weight_x3(T(W, dev)), Dout, **kw).cpu().numpy()
+    ref32 = pm.linear(T(x1, dev), pm.pack_weight(T(W, dev)), Dout, **kw).cpu().numpy()
+    xin = np.concatenate([x1, x2], 1) if C2 else x1
+    exp = np.maximum((xin.astype(np.float64) @ W + b) * sc + sh, 0) + res
+    assert close(out, exp, 1e-5, 2e-5)
+    assert np.abs(out - exp).max() <= 2 * np.abs(ref32 - exp).max() + 1e-6  # as accurate as the exact-f32 pipe
+
+
 @pytest.mark.parametrize("C", [64, 128])
 def test_se_res_pm(dev, C):
     from dh3d_amd import pm

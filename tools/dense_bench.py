@@ -36,6 +36,10 @@ for B, N in ((8, 8192), (32, 4096)):
         t = ev(lambda: pm.linear(x1, wp, Dout, x2=x2, act=pm.ACT_RELU))
         F = 2.0 * B * N * (C1 + C2) * Dout
         print("  linear %3d+%3d->%3d %7.1f us  %5.1f TF/s  %6.1f GB/s" % (C1, C2, Dout, t, F / t / 1e6, 4.0 * B * N * (C1 + C2 + Dout) / t / 1e3))
+        if Dout in (128, 256) and C1 % 32 == 0 and C2 % 32 == 0:
+            wp3 = pm.pack_weight_x3(torch.randn(C1 + C2, Dout, generator=g).to(dev))
+            t = ev(lambda: pm.linear_x6(x1, wp3, Dout, x2=x2, act=pm.ACT_RELU))
+            print("  linear_x6 %3d+%3d->%3d %7.1f us  %5.1f TF/s-eq  %6.1f GB/s" % (C1, C2, Dout, t, F / t / 1e6, 4.0 * B * N * (C1 + C2 + Dout) / t / 1e3))
     x = torch.randn(B * N, 256, generator=g).to(dev)
     wp = pm.pack_weight((torch.randn(256, 1024, generator=g) / 16).to(dev))
     wfc = torch.randn(1024, generator=g).to(dev)
