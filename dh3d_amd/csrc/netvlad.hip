@@ -220,13 +220,15 @@ __global__ __launch_bounds__(256) void netvlad_l2scale(const float *__restrict__
   }
 }
 
-// Split-K projection on the f32 MFMA pipe: grid (KS, ceil(B/32)); workgroup = 32 rows x 256-deep k slice x
-// all 256 outputs.  A = vlad slice staged in LDS; B = Wh rows read in place (lanes 0..31 of a fragment are 32
-// consecutive outputs of one row: 128-byte segments), so the 16.8 MB weight streams from HBM exactly once.
+// Split-K projection on the f32 MFMA pipe: grid (KS, ceil(B/32), O/64); a workgroup takes 32 rows x a 256-deep k
+// slice x 64 outputs, its four waves = (32-column block) x (k half), so 4*KS*O/64 waves stream the 16.8 MB weight
+// from HBM exactly once between them (the first version put a whole slice x all 256 outputs on one workgroup:
+// 64 workgroups, 61 us of mostly exposed load latency).  A = vlad slice staged in LDS; B = Wh rows read in place
+// (lanes 0..31 of a fragment are 32 consecutive outputs of one row), one k-block ahead of the MFMAs.
 constexpr int kKSlice = 256;
 __global__ __launch_bounds__(256) void netvlad_hidden_splitk(const float *__restrict__ vlad,
                                                             const float *__restrict__ Wh, int B, int Kd,
-                                                            int O, float *__restrict__ part /*[KS][B][O]*/) {
+                                                            int O, float *__restrict__ part /*[2*KS][B][O]*/) {
   __shared__ __attribute__((aligned(16))) float s_v[32 * (kKSlice + 4)];
   constexpr int LD = kKSlice + 4;
   const int ks = blockIdx.x, b0 = blockIdx.y * 32;
@@ -240,31 +242,38 @@ __global__ __launch_bounds__(256) void netvlad_hidden_splitk(const float *__rest
     *reinterpret_cast<float4 *>(s_v + (size_t)bb * LD + k4) = x;
   }
   __syncthreads();
-  f32x16 acc[2];
-  zero_acc<2>(acc);
-  const float *aptr = s_v + (size_t)(lane & 31) * LD + 4 * (lane >> 5);
-  const int klen = min(kKSlice, Kd - k0);
-  for (int kb = 0; kb < klen / 8; ++kb) {
+  const int kh = wave >> 1;                                  // k half of the slice
+  const int o0 = blockIdx.z * 64 + (wave & 1) * 32;          // 32-column block
+  const int kbeg = kh * (kKSlice / 2);
+  int klen = min(kKSlice, Kd - k0) - kbeg;
+  klen = klen < 0 ? 0 : (klen > kKSlice / 2 ? kKSlice / 2 : klen);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const float *aptr = s_v + (size_t)(lane & 31) * LD + kbeg + 4 * (lane >> 5);
+  const float *wbase = Wh + (size_t)(k0 + kbeg + 4 * (lane >> 5)) * O + o0 + (lane & 31);
+  const int nkb = klen / 8;
+  float w[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) w[t] = nkb > 0 ? wbase[(size_t)t * O] : 0.f;
+  for (int kb = 0; kb < nkb; ++kb) {
     const f32x4 a4 = *reinterpret_cast<const f32x4 *>(aptr + kb * 8);
-    const float *wrow = Wh + (size_t)(k0 + kb * 8 + 4 * (lane >> 5)) * O + (lane & 31);
+    float wn[4];
+    const int kn = kb + 1 < nkb ? kb + 1 : kb;  // unconditional prefetch (the last repeats)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int o0 = (wave + 4 * j) * 32;
-      const float w0 = wrow[o0], w1 = wrow[(size_t)O + o0], w2 = wrow[(size_t)2 * O + o0], w3 = wrow[(size_t)3 * O + o0];
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0], w0, acc[j], 0, 0, 0);
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1], w1, acc[j], 0, 0, 0);
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[2], w2, acc[j], 0, 0, 0);
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[3], w3, acc[j], 0, 0, 0);
-    }
+    for (int t = 0; t < 4; ++t) wn[t] = wbase[(size_t)(kn * 8 + t) * O];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0], w[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1], w[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[2], w[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[3], w[3], acc, 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) w[t] = wn[t];
   }
+  const int o = o0 + (lane & 31);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int o = (wave + 4 * j) * 32 + (lane & 31);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int bb = mfma_row(r, lane);
-      if (bb < nb) part[((size_t)ks * B + b0 + bb) * O + o] = acc[j][r];
-    }
+  for (int r = 0; r < 16; ++r) {
+    const int bb = mfma_row(r, lane);
+    if (bb < nb) part[((size_t)(ks * 2 + kh) * B + b0 + bb) * O + o] = acc[r];
   }
 }
 
@@ -341,7 +350,7 @@ DH3D_API int dh3d_netvlad_aggregate_fwd(const float *x, const float *att, const 
 
 DH3D_API size_t dh3d_netvlad_head_workspace_bytes(int B, int Kd, int O) {
   if (B <= 0 || Kd <= 0 || O != 256) return 0;
-  return sizeof(float) * (size_t)dh3d_cdiv(Kd, kKSlice) * B * O;
+  return sizeof(float) * (size_t)2 * dh3d_cdiv(Kd, kKSlice) * B * O;  // two k-half partials per slice
 }
 
 DH3D_API int dh3d_netvlad_head_fwd(const float *vlad, const float *Wh, const float *bn1_scale,
@@ -355,9 +364,9 @@ DH3D_API int dh3d_netvlad_head_fwd(const float *vlad, const float *Wh, const flo
   const int KS = dh3d_cdiv(Kd, kKSlice);
   float *part = static_cast<float *>(workspace);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(netvlad_hidden_splitk, dim3(KS, dh3d_cdiv(B, 32)), dim3(256), 0, s, vlad, Wh, B, Kd, O,
+  hipLaunchKernelGGL(netvlad_hidden_splitk, dim3(KS, dh3d_cdiv(B, 32), O / 64), dim3(256), 0, s, vlad, Wh, B, Kd, O,
                      part);
-  hipLaunchKernelGGL(netvlad_gate, dim3(B), dim3(256), 0, s, part, KS, B, O, bn1_scale, bn1_shift, Wg,
+  hipLaunchKernelGGL(netvlad_gate, dim3(B), dim3(256), 0, s, part, 2 * KS, B, O, bn1_scale, bn1_shift, Wg,
                      bn2_scale, bn2_shift, l2_eps, out);
   return dh3d_launch_status();
 }

@@ -193,9 +193,13 @@ class DH3D(nn.Module):
         att = self.globalatt(forglobal)
         return self._netvlad(forglobal, att, l2_eps=l2_eps)
 
-    def forward(self, points, knn_inds=None):
+    def forward(self, points, knn_inds=None, fetch=None):
         """points [Bt, N, 3] float32 on the GPU (anchor/pos/neg already concatenated, core/model.py:139-146).
-        knn_inds [Bt, N, K] int32 is required iff num_points > 8192 (core/model.py:148-155)."""
+        knn_inds [Bt, N, K] int32 is required iff num_points > 8192 (core/model.py:148-155).
+        fetch: names of the outputs wanted (None = all).  Like a TF session fetch, tensors nobody asked for are not
+        computed: the global-descriptor extraction (globaldesc_extract.py fetches 'globaldesc' only) skips the
+        normalised per-point descriptors and the detector."""
+        want = (lambda *names: True) if fetch is None else (lambda *names: any(n in fetch for n in names))
         self._check_mode()
         cfg = self.config
         if points.dim() != 3 or points.shape[2] != 3:
@@ -207,14 +211,17 @@ class DH3D(nn.Module):
         outs["knn_inds"] = geo.nbr
         newpoints, localdesc = self.compute_local(points, _geo=geo)
         outs["feat"] = localdesc
-        xyz_feat = pm.l2norm_concat(localdesc, 1e-8, prefix=newpoints)  # l2_normalize(dim=2, eps=1e-8) + concat
-        outs["xyz_feat"] = xyz_feat
-        outs["feat_l2normed"] = xyz_feat[:, :, 3:]
-        if cfg.detection:
+        xyz_feat = None
+        if want("xyz_feat", "feat_l2normed", "xyz_feat_att"):
+            xyz_feat = pm.l2norm_concat(localdesc, 1e-8, prefix=newpoints)  # l2_normalize(dim=2, eps=1e-8) + concat
+            outs["xyz_feat"] = xyz_feat
+            outs["feat_l2normed"] = xyz_feat[:, :, 3:]
+        if cfg.detection and want("attention", "xyz_feat_att"):
             att = self.detection_block_reliable(localdesc)
             outs["attention"] = att
-            outs["xyz_feat_att"] = torch.cat([xyz_feat, att], dim=-1)
-        if cfg.extract_global:
+            if xyz_feat is not None:
+                outs["xyz_feat_att"] = torch.cat([xyz_feat, att], dim=-1)
+        if cfg.extract_global and want("globaldesc"):
             outs["_geo"] = geo
             outs["globaldesc"] = self.compute_global(outs, l2_eps=1e-8)  # model.py:205
             del outs["_geo"]
@@ -234,12 +241,12 @@ class DH3D(nn.Module):
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(warmup):
-                self.forward(static_in, static_knn)
+                self.forward(static_in, static_knn, fetch=keep)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            outs = self.forward(static_in, static_knn)
+            outs = self.forward(static_in, static_knn, fetch=keep)
         if keep is not None:
             outs = {k: v for k, v in outs.items() if k in keep}
 
