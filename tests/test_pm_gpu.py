@@ -106,6 +106,26 @@ def test_flex_conv_x6_full_size_matches_f32_kernel(dev, Din):
     assert err < 2e-6, err
 
 
+def test_flex_conv_cfg5_shape_matches_reference_formulation(dev):
+    """BASELINE config 5: one flex_conv 128 -> 128 at B=1, N=16384, K=12 (localdesc_extract.py:146,166).  The fused
+    factorised kernel (run-time K) against the drop-in kernel that keeps the reference's formulation and
+    summation order (itself checked against the oracle at small sizes)."""
+    from dh3d_amd import ops, pm
+    g = torch.Generator().manual_seed(5)
+    B, N, K, Din, Dout = 1, 16384, 12, 128, 128
+    xyz = torch.rand(B, N, 3, generator=g).to(dev)
+    nbr, _ = pm.knn_xyz(xyz, K)
+    f = torch.randn(B, N, Din, generator=g).to(dev)
+    theta = (torch.randn(3, Din, Dout, generator=g) / Din ** 0.5).to(dev)
+    bias = (torch.randn(Din, Dout, generator=g) / (K * Din) ** 0.5).to(dev)
+    fused = pm.flex_conv(f, xyz, nbr, pm.pack_flex_weight(theta, bias), Dout)
+    ref = ops.flex_convolution(f.transpose(1, 2).contiguous(), xyz.transpose(1, 2).contiguous(),
+                               nbr.transpose(1, 2).contiguous(), theta, bias).transpose(1, 2)
+    err = (fused - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 5e-6, err
+    assert nbr.shape == (B, N, K) and bool((nbr[:, :, 0] == torch.arange(N, device=dev)).all())
+
+
 def test_flex_pool_pm_exact(dev, oracle):
     from dh3d_amd import pm
     rng = np.random.default_rng(3)

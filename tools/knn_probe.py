@@ -1,7 +1,7 @@
 import ctypes, torch, numpy as np
 lib = ctypes.CDLL("tools/libknn_probe.so")
 dev = torch.device("cuda")
-for N in (1024, 8192):
+for N in (4096, 8192):
     xyz = torch.rand(8, N, 3, device=dev)
     NG = (N + 63) // 64
     srt = torch.empty(8, N, 4, device=dev); gbox = torch.empty(8, NG, 8, device=dev)
