@@ -51,6 +51,13 @@ def synthetic_clouds(B, N, seed, dev, rank=0):
 
 def time_steps(run, pts, steps, warmup, dev):
     from dh3d_amd import dist as D
+    # clock ramp: a fresh process finds the GPU in a low power state and a millisecond-scale step does not pull it
+    # up within a handful of warmup steps (measured: the same graph at 0.97 vs 0.91 ms).  ~0.2 s of untimed
+    # replays first, then the W warmup steps the contract asks for, then exactly K timed steps.
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < 0.2:
+        run(pts)
+        torch.cuda.synchronize(dev)
     for _ in range(warmup):
         run(pts)
     torch.cuda.synchronize(dev)
