@@ -53,38 +53,47 @@ constexpr int LDA = HKC + 8;                       // bf16 per row of a staged A
 constexpr int A_STAGE = 3 * HTM * LDA;             // bf16 elements per A buffer
 constexpr int B_STAGE = (HTN / 32) * 2 * 3 * 64;   // uint4 per B buffer  [cb 8][ks 2][plane 3][lane 64]
 
-__global__ __launch_bounds__(512) void mlp_head_x6_kernel(const float *__restrict__ h, int C,
-                                                         const uint4 *__restrict__ wp, int H, EpilogueArgs ep,
-                                                         const float *__restrict__ w_fc, float b_fc,
-                                                         long long R, float *__restrict__ att) {
+// WC = waves along the columns (2 rows x WC): WC = 4 -> eight waves of 64 x 64, two per SIMD; WC = 2 -> four waves
+// of 64 x 128, one per SIMD (more register reuse per LDS byte, no partner wave to cover its waits).
+template <int WC>
+__global__ __launch_bounds__(128 * WC) void mlp_head_x6_kernel(const float *__restrict__ h, int C,
+                                                              const uint4 *__restrict__ wp, int H, EpilogueArgs ep,
+                                                              const float *__restrict__ w_fc, float b_fc,
+                                                              long long R, float *__restrict__ att) {
+  constexpr int T = 128 * WC;         // threads
+  constexpr int NCW = 8 / WC;         // 32-column blocks per wave
+  constexpr int AQ = T / HTM;         // threads per staged A row
+  constexpr int NF4 = 8 / AQ;         // float4 per thread per chunk
+  constexpr int DMA = 48 / (2 * WC);  // LDS-DMA instructions per wave per chunk
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   unsigned short *s_A = reinterpret_cast<unsigned short *>(s_raw);                      // [2][3][HTM][LDA]
   uint4 *s_B = reinterpret_cast<uint4 *>(s_raw + (size_t)2 * A_STAGE * 2);             // [2][B_STAGE]
-  float *s_part = reinterpret_cast<float *>(s_raw + (size_t)2 * A_STAGE * 2 + (size_t)2 * B_STAGE * 16);  // [4][HTM]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 2, wc = wave & 3;
+  float *s_part = reinterpret_cast<float *>(s_raw + (size_t)2 * A_STAGE * 2 + (size_t)2 * B_STAGE * 16);  // [WC][HTM]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WC, wc = wave % WC;
   const long long grow0 = (long long)blockIdx.x * HTM;
   const int KB = C / 16, NCH = C / HKC, NT = H / HTN, IT = NT * NCH;
-  // staging roles: A -- thread t owns row t/4, 8 consecutive k; B -- LDS-DMA, 6 KB per wave
-  const int ar = tid >> 2, ah = tid & 3;
+  // staging roles: A -- AQ threads per row, 4*NF4 consecutive k each; B -- LDS-DMA
+  const int ar = tid / AQ, ah = tid % AQ;
   long long arow = grow0 + ar;
   if (arow >= R) arow = R - 1;  // rows past R repeat the last row; their results are not stored
-  const float *asrc = h + arow * C + ah * 8;
-  float4 pa[2];
+  const float *asrc = h + arow * C + ah * (4 * NF4);
+  float4 pa[NF4];
   // A chunk of iteration `it` -> registers (split and written to LDS by stage_a)
   auto prefetch_a = [&](int it) __attribute__((always_inline)) {
     const int nt = it / NCH, ch = it - nt * NCH;
     const float4 *ap = reinterpret_cast<const float4 *>(asrc + ch * HKC);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) pa[j] = ap[j];
+    for (int j = 0; j < NF4; ++j) pa[j] = ap[j];
   };
   // weight slice of iteration `it` -> LDS buffer `buf` by LDS-DMA (global_load_lds_dwordx4: no registers; each
-  // wave-instruction lands 64 x 16 B contiguously).  48 KB per chunk = 6 instructions per wave.
+  // wave-instruction lands 64 x 16 B contiguously).  48 KB per chunk.
   auto dma_b = [&](int it, int buf) __attribute__((always_inline)) {
     const int nt = it / NCH, ch = it - nt * NCH;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const int e0 = (wave * 6 + j) * 64, cb = e0 / 384, rem = e0 - cb * 384 + lane;
+    for (int j = 0; j < DMA; ++j) {
+      const int e0 = (wave * DMA + j) * 64, cb = e0 / 384, rem = e0 - cb * 384 + lane;
       const uint4 *src = wp + ((size_t)(nt * (HTN / 32) + cb) * KB + ch * 2) * 192 + rem;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                        (__attribute__((address_space(3))) void *)(s_B + (size_t)buf * B_STAGE + e0),
@@ -92,13 +101,16 @@ __global__ __launch_bounds__(512) void mlp_head_x6_kernel(const float *__restric
     }
   };
   auto stage_a = [&](int buf) __attribute__((always_inline)) {
-    unsigned short *dst = s_A + (size_t)buf * A_STAGE + (size_t)ar * LDA + ah * 8;
-    uint2 c1[2], c2[2], c3[2];
+    unsigned short *dst = s_A + (size_t)buf * A_STAGE + (size_t)ar * LDA + ah * (4 * NF4);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) split3x4(pa[j], c1[j], c2[j], c3[j]);
-    *reinterpret_cast<uint4 *>(dst) = make_uint4(c1[0].x, c1[0].y, c1[1].x, c1[1].y);
-    *reinterpret_cast<uint4 *>(dst + HTM * LDA) = make_uint4(c2[0].x, c2[0].y, c2[1].x, c2[1].y);
-    *reinterpret_cast<uint4 *>(dst + 2 * HTM * LDA) = make_uint4(c3[0].x, c3[0].y, c3[1].x, c3[1].y);
+    for (int j = 0; j < NF4; j += 2) {
+      uint2 c1[2], c2[2], c3[2];
+      split3x4(pa[j], c1[0], c2[0], c3[0]);
+      split3x4(pa[j + 1], c1[1], c2[1], c3[1]);
+      *reinterpret_cast<uint4 *>(dst + 4 * j) = make_uint4(c1[0].x, c1[0].y, c1[1].x, c1[1].y);
+      *reinterpret_cast<uint4 *>(dst + 4 * j + HTM * LDA) = make_uint4(c2[0].x, c2[0].y, c2[1].x, c2[1].y);
+      *reinterpret_cast<uint4 *>(dst + 4 * j + 2 * HTM * LDA) = make_uint4(c3[0].x, c3[0].y, c3[1].x, c3[1].y);
+    }
   };
   auto stage_sync = [&]() __attribute__((always_inline)) {  // LDS-DMA counts on vmcnt
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -117,11 +129,11 @@ __global__ __launch_bounds__(512) void mlp_head_x6_kernel(const float *__restric
   stage_sync();
   int it = 0;
   for (int nt = 0; nt < NT; ++nt) {
-    f32x16 acc[2][2];
+    f32x16 acc[2][NCW];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
+      for (int cb = 0; cb < NCW; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
     for (int ch = 0; ch < NCH; ++ch, ++it) {
@@ -131,23 +143,27 @@ __global__ __launch_bounds__(512) void mlp_head_x6_kernel(const float *__restric
       dma_b(nxt, buf ^ 1);                   // lands under this chunk's MFMAs (waited for in stage_sync)
       __builtin_amdgcn_sched_barrier(0);     // keep both prefetches up here: the scheduler sinks loads to their use
       const unsigned short *abase = s_A + (size_t)buf * A_STAGE + (size_t)(wr * 64 + (lane & 31)) * LDA + 8 * (lane >> 5);
-      const uint4 *bbase = s_B + (size_t)buf * B_STAGE + (size_t)(wc * 2) * (2 * 3 * 64) + lane;
+      const uint4 *bbase = s_B + (size_t)buf * B_STAGE + (size_t)(wc * NCW) * (2 * 3 * 64) + lane;
+      // the fragments of BOTH k-steps are requested before the first MFMA: one exposed LDS latency per chunk
+      bf16x8 a[2][2][3], b[2][NCW][3];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 a[2][3], b[2][3];
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
           for (int p = 0; p < 3; ++p)
-            a[rb][p] = *reinterpret_cast<const bf16x8 *>(abase + (size_t)p * HTM * LDA + (size_t)rb * 32 * LDA + ks * 16);
+            a[ks][rb][p] = *reinterpret_cast<const bf16x8 *>(abase + (size_t)p * HTM * LDA + (size_t)rb * 32 * LDA + ks * 16);
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < NCW; ++cb)
 #pragma unroll
-          for (int p = 0; p < 3; ++p) b[cb][p] = __builtin_bit_cast(bf16x8, bbase[((cb * 2 + ks) * 3 + p) * 64]);
-        // six products, smallest first; four independent accumulators between two uses of the same one
-#define DH3D_X6_PRODUCT(PA, PB)                                                                         \
-  _Pragma("unroll") for (int rb = 0; rb < 2; ++rb) _Pragma("unroll") for (int cb = 0; cb < 2; ++cb)     \
-      acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rb][PA], b[cb][PB], acc[rb][cb], 0, 0, 0);
+          for (int p = 0; p < 3; ++p) b[ks][cb][p] = __builtin_bit_cast(bf16x8, bbase[((cb * 2 + ks) * 3 + p) * 64]);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        // six products, smallest first; 2*NCW independent accumulators between two uses of the same one
+#define DH3D_X6_PRODUCT(PA, PB)                                                                           \
+  _Pragma("unroll") for (int rb = 0; rb < 2; ++rb) _Pragma("unroll") for (int cb = 0; cb < NCW; ++cb)     \
+      acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][rb][PA], b[ks][cb][PB], acc[rb][cb], 0, 0, 0);
         DH3D_X6_PRODUCT(2, 0) DH3D_X6_PRODUCT(0, 2) DH3D_X6_PRODUCT(1, 1)
         DH3D_X6_PRODUCT(1, 0) DH3D_X6_PRODUCT(0, 1) DH3D_X6_PRODUCT(0, 0)
 #undef DH3D_X6_PRODUCT
@@ -157,8 +173,8 @@ __global__ __launch_bounds__(512) void mlp_head_x6_kernel(const float *__restric
     }
     // epilogue of this column tile: BN + activation, dot with w_fc, kept per lane (one column per lane)
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-      const int col = nt * HTN + (wc * 2 + cb) * 32 + (lane & 31);
+    for (int cb = 0; cb < NCW; ++cb) {
+      const int col = nt * HTN + (wc * NCW + cb) * 32 + (lane & 31);
       float pb = 0.f, sc = 1.f, sh = 0.f;
       if (ep.pre_bias) pb = ep.pre_bias[col];
       if (ep.scale) sc = ep.scale[col];
@@ -171,7 +187,7 @@ __global__ __launch_bounds__(512) void mlp_head_x6_kernel(const float *__restric
           part[rb][r] = fmaf(dh3d_act((acc[rb][cb][r] + pb) * sc + sh, ep.act), wf, part[rb][r]);
     }
   }
-  // row sums: across the 32 column lanes, then across the four column waves
+  // row sums: across the 32 column lanes, then across the column waves
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -189,7 +205,10 @@ __global__ __launch_bounds__(512) void mlp_head_x6_kernel(const float *__restric
   __syncthreads();
   if (tid < HTM) {
     const long long g = grow0 + tid;
-    if (g < R) att[g] = 1.f / (1.f + expf(-(((s_part[tid] + s_part[HTM + tid]) + (s_part[2 * HTM + tid] + s_part[3 * HTM + tid])) + b_fc)));
+    float z = 0.f;
+#pragma unroll
+    for (int w = 0; w < WC; ++w) z += s_part[w * HTM + tid];
+    if (g < R) att[g] = 1.f / (1.f + expf(-(z + b_fc)));
   }
 }
 
@@ -332,16 +351,27 @@ DH3D_API int dh3d_pack_weight_x3(const float *W, int Kd, int Dout, void *packed,
   return dh3d_launch_status();
 }
 
+// Dev knob (tools/dense_bench.py): column waves of the head GEMM (4 = eight waves, 2 = four waves).
+static int g_head_wc = 4;
+DH3D_API void dh3d_dev_set_head_wc(int wc) { g_head_wc = wc == 2 ? 2 : 4; }
+
 DH3D_API int dh3d_mlp_head_pm_x6_fwd(const float *h, int R, int C, const void *wpacked_x3, int H,
                                      const dh3d_epilogue *ep, const float *w_fc, float b_fc, float *att,
                                      void *stream) {
   DH3D_REQUIRE(h && wpacked_x3 && w_fc && att && R > 0 && C > 0 && H > 0);
   DH3D_SUPPORTED(C % HKC == 0 && H % HTN == 0);
   const size_t lds = (size_t)2 * A_STAGE * 2 + (size_t)2 * B_STAGE * 16 + sizeof(float) * 4 * HTM;
-  auto kern = mlp_head_x6_kernel;
-  DH3D_ALLOW_BIG_LDS(kern);
-  hipLaunchKernelGGL(kern, dim3(dh3d_cdiv(R, HTM)), dim3(512), lds, (hipStream_t)stream, h, C,
-                     static_cast<const uint4 *>(wpacked_x3), H, dh3d_ep(ep), w_fc, b_fc, (long long)R, att);
+  if (g_head_wc == 2) {
+    auto kern = mlp_head_x6_kernel<2>;
+    DH3D_ALLOW_BIG_LDS(kern);
+    hipLaunchKernelGGL(kern, dim3(dh3d_cdiv(R, HTM)), dim3(256), lds, (hipStream_t)stream, h, C,
+                       static_cast<const uint4 *>(wpacked_x3), H, dh3d_ep(ep), w_fc, b_fc, (long long)R, att);
+  } else {
+    auto kern = mlp_head_x6_kernel<4>;
+    DH3D_ALLOW_BIG_LDS(kern);
+    hipLaunchKernelGGL(kern, dim3(dh3d_cdiv(R, HTM)), dim3(512), lds, (hipStream_t)stream, h, C,
+                       static_cast<const uint4 *>(wpacked_x3), H, dh3d_ep(ep), w_fc, b_fc, (long long)R, att);
+  }
   return dh3d_launch_status();
 }
 

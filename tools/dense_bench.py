@@ -61,3 +61,10 @@ for R in (65536, 131072):
     t6 = ev(lambda: pm.mlp_head_x6(x, w6, 1024, wfc, 0.1), iters=10)
     print("R=%d mlp_head f32-MFMA %7.1f us (%5.1f TF/s)   bf16x6 %7.1f us (%5.1f f32-equivalent TF/s)" % (
         R, t1, 2.0 * R * 256 * 1024 / t1 / 1e6, t6, 2.0 * R * 256 * 1024 / t6 / 1e6))
+    import ctypes
+    from dh3d_amd import _lib
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    raw.dh3d_dev_set_head_wc(2)
+    t62 = ev(lambda: pm.mlp_head_x6(x, w6, 1024, wfc, 0.1), iters=10)
+    raw.dh3d_dev_set_head_wc(4)
+    print("      bf16x6 with four 64x128 waves %7.1f us" % t62)
