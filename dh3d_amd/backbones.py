@@ -97,6 +97,18 @@ class Conv2D1x1(nn.Module):
         return pm.linear(x, p["wp"], self.cout, x2=x2, pre_bias=p["b"], scale=p["scale"], shift=p["shift"],
                          act=act, residual=residual)
 
+    def upsampled_supported(self, coarse, idx, x2):
+        """Can forward_upsampled serve this call?  (same batch-independent rule as forward's x6 choice)"""
+        p = self._prep or self.prepare()
+        return ("wp3" in p and idx.shape[1] >= 4096 and coarse.shape[-1] % 32 == 0
+                and (x2 is None or x2.shape[-1] % 32 == 0))
+
+    def forward_upsampled(self, coarse, idx, dist, x2=None, act=pm.ACT_RELU, residual=None):
+        """forward([three_interpolate_idw(coarse, idx, dist) | x2]) with the up-sampling fused into the GEMM."""
+        p = self._prep or self.prepare()
+        return pm.upsample_linear_x6(coarse, idx, dist, p["wp3"], self.cout, x2=x2, pre_bias=p["b"], scale=p["scale"],
+                                     shift=p["shift"], act=act, residual=residual)
+
 
 class FeatureConv1d(nn.Module):
     """feature_conv1d_1 (core/tf_utils.py:99-109): variable scope '<name>/tfconv0'."""
@@ -301,6 +313,11 @@ class FlexConvDilate(nn.Module):
             x = self.se(x, pm.flex_pool(x, nbr_s))
         if self.upsample and self.dilate > 1:
             geo.finish(lv)
+            conv = self.concat_conv1d.tfconv0 if self.concat else None
+            if conv is not None and conv.upsampled_supported(x, lv["nn3_idx"], feat):
+                # up-sampling fused into the concat conv's operand staging: the [B,N,C] tensor is never written
+                return conv.forward_upsampled(x, lv["nn3_idx"], lv["nn3_dist"], x2=feat, act=pm.ACT_RELU,
+                                              residual=residual)
             x = pm.three_interpolate_idw(x, lv["nn3_idx"], lv["nn3_dist"])
         if self.concat:
             x = self.concat_conv1d(x, x2=feat, act=pm.ACT_RELU, residual=residual)

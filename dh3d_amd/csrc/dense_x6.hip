@@ -217,12 +217,40 @@ __global__ __launch_bounds__(128 * WC) void mlp_head_x6_kernel(const float *__re
 // and staging as the head above; NC = 32-column blocks per wave (1: Dout = 128, 2: Dout = 256).  The finished
 // 128 x Dout tile goes through LDS (the stage buffers are dead by then) so that every lane stores 16 bytes of
 // a full output row, residual added on the way.
+// The interpolation arithmetic must round exactly like three_interp_fwd_kernel<IDW> (pointnet2.hip is compiled
+// without contraction): no fused multiply-adds in these two helpers.
+#pragma clang fp contract(off)
+__device__ __forceinline__ void idw_weights(float d1, float d2, float d3, float &w1, float &w2, float &w3) {
+  const float r1 = 1.0f / fmaxf(d1, 1e-10f), r2 = 1.0f / fmaxf(d2, 1e-10f), r3 = 1.0f / fmaxf(d3, 1e-10f);
+  const float norm = (r1 + r2) + r3;
+  w1 = r1 / norm; w2 = r2 / norm; w3 = r3 / norm;
+}
+__device__ __forceinline__ float4 idw_mix(const float4 a, const float4 b, const float4 c, float w1, float w2, float w3) {
+  float4 r;
+  r.x = (a.x * w1 + b.x * w2) + c.x * w3;
+  r.y = (a.y * w1 + b.y * w2) + c.y * w3;
+  r.z = (a.z * w1 + b.z * w2) + c.z * w3;
+  r.w = (a.w * w1 + b.w * w2) + c.w * w3;
+  return r;
+}
+#pragma clang fp contract(fast)
+
+// Up-sampling source for the x1 half (three_interpolate with inverse-distance weights, core/backbones.py:91-95,
+// fused into the A staging): x1[r, :] = sum_t w[r,t] * points[cloud(r), idx[r,t], :], exactly the arithmetic of
+// three_interp_fwd_kernel<IDW> (unfused, same association), so the fused and the two-kernel paths agree bit for bit.
+struct UpsampleSrc {
+  const float *points;   // [B, m, C1]   (null: x1 is read directly)
+  const int32_t *idx;    // [R, 3]
+  const float *dist;     // [R, 3] squared distances
+  int n, m;              // rows per cloud of the fine / coarse level
+};
+
 template <int NC>
 __global__ __launch_bounds__(512) void linear_x6_kernel(const float *__restrict__ x1, int C1,
                                                        const float *__restrict__ x2, int C2,
                                                        const uint4 *__restrict__ wp, EpilogueArgs ep,
                                                        const float *__restrict__ residual, long long R,
-                                                       float *__restrict__ out) {
+                                                       float *__restrict__ out, UpsampleSrc up) {
   constexpr int TN = NC * 128;                      // columns of the tile = Dout
   constexpr int BST = (TN / 32) * 2 * 3 * 64;       // uint4 per B buffer
   constexpr int DMA = BST / 64 / 8;                 // LDS-DMA instructions per wave per chunk
@@ -240,11 +268,29 @@ __global__ __launch_bounds__(512) void linear_x6_kernel(const float *__restrict_
   long long arow = grow0 + ar;
   if (arow >= R) arow = R - 1;  // rows past R repeat the last row; they are not stored
   float4 pa[2];
+  // up-sampling: this thread's row gathers from three coarse rows with fixed weights
+  const float *ip1 = nullptr, *ip2 = nullptr, *ip3 = nullptr;
+  float w1 = 0.f, w2 = 0.f, w3 = 0.f;
+  if (up.points) {
+    const long long bi = arow / up.n;
+    const int i1 = up.idx[arow * 3], i2 = up.idx[arow * 3 + 1], i3 = up.idx[arow * 3 + 2];
+    idw_weights(up.dist[arow * 3], up.dist[arow * 3 + 1], up.dist[arow * 3 + 2], w1, w2, w3);
+    ip1 = up.points + (bi * up.m + i1) * C1;
+    ip2 = up.points + (bi * up.m + i2) * C1;
+    ip3 = up.points + (bi * up.m + i3) * C1;
+  }
   auto prefetch_a = [&](int ch) __attribute__((always_inline)) {
     const int k0 = ch * HKC + ah * 8;
-    const float *src = k0 < C1 ? x1 + arow * C1 + k0 : x2 + arow * C2 + (k0 - C1);
-    const float4 *ap = reinterpret_cast<const float4 *>(src);
-    pa[0] = ap[0]; pa[1] = ap[1];
+    if (up.points && k0 < C1) {  // uniform per chunk
+      const float4 *a = reinterpret_cast<const float4 *>(ip1 + k0), *b = reinterpret_cast<const float4 *>(ip2 + k0),
+                   *c = reinterpret_cast<const float4 *>(ip3 + k0);
+      pa[0] = idw_mix(a[0], b[0], c[0], w1, w2, w3);
+      pa[1] = idw_mix(a[1], b[1], c[1], w1, w2, w3);
+    } else {
+      const float *src = k0 < C1 ? x1 + arow * C1 + k0 : x2 + arow * C2 + (k0 - C1);
+      const float4 *ap = reinterpret_cast<const float4 *>(src);
+      pa[0] = ap[0]; pa[1] = ap[1];
+    }
   };
   auto dma_b = [&](int ch, int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -375,10 +421,9 @@ DH3D_API int dh3d_mlp_head_pm_x6_fwd(const float *h, int R, int C, const void *w
   return dh3d_launch_status();
 }
 
-DH3D_API int dh3d_linear_pm_x6_fwd(const float *x1, int C1, const float *x2, int C2, const void *wpacked_x3, int R,
-                                   int Dout, const dh3d_epilogue *ep, const float *residual, float *out,
-                                   void *stream) {
-  DH3D_REQUIRE(x1 && wpacked_x3 && out && R > 0 && C1 > 0 && C2 >= 0 && Dout > 0 && (C2 == 0 || x2));
+static int linear_x6_launch(const float *x1, int C1, const float *x2, int C2, const void *wpacked_x3, int R, int Dout,
+                            const dh3d_epilogue *ep, const float *residual, float *out, void *stream,
+                            const UpsampleSrc &up) {
   DH3D_SUPPORTED(C1 % HKC == 0 && C2 % HKC == 0 && (Dout == 128 || Dout == 256));
   const EpilogueArgs e = dh3d_ep(ep);
   hipStream_t s = (hipStream_t)stream;
@@ -390,14 +435,32 @@ DH3D_API int dh3d_linear_pm_x6_fwd(const float *x1, int C1, const float *x2, int
     if (tile > lds) lds = tile;
     auto kern = linear_x6_kernel<1>;
     DH3D_ALLOW_BIG_LDS(kern);
-    hipLaunchKernelGGL(kern, grid, block, lds, s, x1, C1, x2, C2, wp, e, residual, (long long)R, out);
+    hipLaunchKernelGGL(kern, grid, block, lds, s, x1, C1, x2, C2, wp, e, residual, (long long)R, out, up);
   } else {
     size_t lds = (size_t)2 * A_STAGE * 2 + (size_t)2 * (256 / 32) * 2 * 3 * 64 * 16;
     const size_t tile = sizeof(float) * HTM * (256 + 4);
     if (tile > lds) lds = tile;
     auto kern = linear_x6_kernel<2>;
     DH3D_ALLOW_BIG_LDS(kern);
-    hipLaunchKernelGGL(kern, grid, block, lds, s, x1, C1, x2, C2, wp, e, residual, (long long)R, out);
+    hipLaunchKernelGGL(kern, grid, block, lds, s, x1, C1, x2, C2, wp, e, residual, (long long)R, out, up);
   }
   return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_linear_pm_x6_fwd(const float *x1, int C1, const float *x2, int C2, const void *wpacked_x3, int R,
+                                   int Dout, const dh3d_epilogue *ep, const float *residual, float *out,
+                                   void *stream) {
+  DH3D_REQUIRE(x1 && wpacked_x3 && out && R > 0 && C1 > 0 && C2 >= 0 && Dout > 0 && (C2 == 0 || x2));
+  const UpsampleSrc none{nullptr, nullptr, nullptr, 1, 1};
+  return linear_x6_launch(x1, C1, x2, C2, wpacked_x3, R, Dout, ep, residual, out, stream, none);
+}
+
+DH3D_API int dh3d_upsample_linear_pm_x6_fwd(const float *points, const int32_t *idx, const float *dist, int B, int n,
+                                            int m, int C1, const float *x2, int C2, const void *wpacked_x3, int Dout,
+                                            const dh3d_epilogue *ep, const float *residual, float *out, void *stream) {
+  DH3D_REQUIRE(points && idx && dist && wpacked_x3 && out && B > 0 && n > 0 && m > 0 && C1 > 0 && C2 >= 0 &&
+               Dout > 0 && (C2 == 0 || x2));
+  DH3D_REQUIRE((long long)B * n < (1LL << 31));
+  const UpsampleSrc up{points, idx, dist, n, m};
+  return linear_x6_launch(points, C1, x2, C2, wpacked_x3, B * n, Dout, ep, residual, out, stream, up);
 }

@@ -243,6 +243,33 @@ def linear_x6(x1, wpacked_x3, Dout, x2=None, pre_bias=None, scale=None, shift=No
     return out
 
 
+def upsample_linear_x6(points, idx, dist, wpacked_x3, Dout, x2=None, pre_bias=None, scale=None, shift=None,
+                       act=ACT_NONE, residual=None):
+    """linear_x6([three_interpolate_idw(points, idx, dist) | x2]) without materialising the up-sampled tensor.
+    points [B,m,C1], idx/dist [B,n,3], x2 [B,n,C2]."""
+    p = L.require_cuda_f32(points, "points", 3)
+    ix = L.require_cuda_i32(idx, "idx", 3)
+    d = L.require_cuda_f32(dist, "dist", 3)
+    B, m, C1 = p.shape
+    n = ix.shape[1]
+    C2 = 0
+    b = None
+    if x2 is not None:
+        b = L.require_cuda_f32(x2, "x2", 3)
+        C2 = b.shape[-1]
+        if tuple(b.shape[:2]) != (B, n):
+            raise ValueError("upsample_linear_x6: x2 must be [B,n,C2]")
+    res = None
+    if residual is not None:
+        res = L.require_cuda_f32(residual, "residual", 3)
+    out = torch.empty((B, n, Dout), dtype=torch.float32, device=p.device)
+    ep = _ep(pre_bias, scale, shift, act)
+    L.check(L.lib().dh3d_upsample_linear_pm_x6_fwd(L.ptr(p), L.ptr(ix), L.ptr(d), B, n, m, C1, L.ptr(b), C2,
+                                                   L.ptr(wpacked_x3), Dout, ep, L.ptr(res), L.ptr(out), L.stream_ptr()),
+            "upsample_linear_pm_x6")
+    return out
+
+
 def pack_weight_x3(W):
     """W [Kd, Dout] f32 -> three exact bf16 chunk planes in MFMA fragment order (csrc/dense_x6.hip)."""
     W = L.require_cuda_f32(W, "W", 2)

@@ -230,6 +230,13 @@ int dh3d_mlp_head_pm_fwd(const float *h, int R, int C, const float *wpacked, int
  * summation order. */
 int dh3d_linear_pm_x6_fwd(const float *x1, int C1, const float *x2, int C2, const void *wpacked_x3, int R, int Dout,
                           const dh3d_epilogue *ep, const float *residual, float *out, void *stream);
+/* The same GEMM with its x1 half up-sampled on the fly: x1[b,j,:] = three_interpolate(points [B,m,C1], idx [B,n,3],
+ * inverse-distance weights of dist [B,n,3]) (core/backbones.py:91-95 + tf_interpolate.cpp:107-127) -- the
+ * interpolated [B,n,C1] tensor is never written.  Bit-identical to dh3d_three_interpolate_idw_fwd followed by
+ * dh3d_linear_pm_x6_fwd. */
+int dh3d_upsample_linear_pm_x6_fwd(const float *points, const int32_t *idx, const float *dist, int B, int n, int m,
+                                   int C1, const float *x2, int C2, const void *wpacked_x3, int Dout,
+                                   const dh3d_epilogue *ep, const float *residual, float *out, void *stream);
 
 /* The same head with the GEMM on the bf16 matrix pipe at f32 accuracy ("bf16x6": every f32 operand is split
  * exactly into three bf16 chunks, six chunk products are accumulated in f32; error <= 2^-23 per product, see

@@ -189,6 +189,26 @@ def test_linear_x6_vs_fp64(dev, C1, C2, Dout, R):
     assert np.abs(out - exp).max() <= 2 * np.abs(ref32 - exp).max() + 1e-6  # as accurate as the exact-f32 pipe
 
 
+def test_upsample_linear_x6_is_interpolate_then_linear(dev, oracle):
+    """The fused up-sampling GEMM == three_interpolate (inverse-distance weights) followed by linear_x6, bit for bit."""
+    from dh3d_amd import ops, pm
+    g = torch.Generator().manual_seed(11)
+    B, n, m, C1, C2, Dout = 2, 4096, 512, 128, 64, 128
+    xyz = torch.rand(B, n, 3, generator=g).to(dev)
+    xyz_s = xyz[:, ::8].contiguous()
+    d3, i3 = ops.three_nn(xyz, xyz_s)
+    coarse = torch.randn(B, m, C1, generator=g).to(dev)
+    fine = torch.randn(B, n, C2, generator=g).to(dev)
+    W = (torch.randn(C1 + C2, Dout, generator=g) / (C1 + C2) ** 0.5).to(dev)
+    b = torch.randn(Dout, generator=g).to(dev)
+    res = torch.randn(B, n, Dout, generator=g).to(dev)
+    wp3 = pm.pack_weight_x3(W)
+    up = pm.three_interpolate_idw(coarse, i3, d3)
+    two = pm.linear_x6(up, wp3, Dout, x2=fine, pre_bias=b, act=pm.ACT_RELU, residual=res)
+    one = pm.upsample_linear_x6(coarse, i3, d3, wp3, Dout, x2=fine, pre_bias=b, act=pm.ACT_RELU, residual=res)
+    assert torch.equal(one, two)
+
+
 @pytest.mark.parametrize("C", [64, 128])
 def test_se_res_pm(dev, C):
     from dh3d_amd import pm
