@@ -29,6 +29,20 @@ __global__ __launch_bounds__(kBlock) void group_point_fwd_kernel(
   }
 }
 
+// c % 4 == 0: one 16-byte element per lane (the model's gathers: 64 / 128 channels)
+__global__ __launch_bounds__(kBlock) void group_point_fwd4_kernel(
+    long long rows, int n, int c4, int rows_per_cloud, const float4 *__restrict__ points,
+    const int32_t *__restrict__ idx, float4 *__restrict__ out) {
+  const long long total = rows * c4;
+  for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < total;
+       e += (long long)gridDim.x * kBlock) {
+    const long long row = e / c4;
+    const int l = (int)(e - row * c4);
+    const long long bi = row / rows_per_cloud;
+    out[e] = points[(bi * n + idx[row]) * c4 + l];
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void group_point_bwd_kernel(
     long long rows, int n, int c, int rows_per_cloud, const float *__restrict__ grad_out,
     const int32_t *__restrict__ idx, float *__restrict__ grad_points) {
@@ -232,8 +246,13 @@ DH3D_API int dh3d_group_point_fwd(int b, int n, int c, int m, int nsample, const
                                   const int32_t *idx, float *out, void *stream) {
   DH3D_REQUIRE(points && idx && out && b > 0 && n > 0 && c > 0 && m > 0 && nsample > 0);
   const long long rows = (long long)b * m * nsample;
-  hipLaunchKernelGGL(group_point_fwd_kernel, dim3(flat_grid(rows * c)), dim3(kBlock), 0,
-                     (hipStream_t)stream, rows, n, c, m * nsample, points, idx, out);
+  if (c % 4 == 0)
+    hipLaunchKernelGGL(group_point_fwd4_kernel, dim3(flat_grid(rows * (c / 4))), dim3(kBlock), 0, (hipStream_t)stream,
+                       rows, n, c / 4, m * nsample, reinterpret_cast<const float4 *>(points), idx,
+                       reinterpret_cast<float4 *>(out));
+  else
+    hipLaunchKernelGGL(group_point_fwd_kernel, dim3(flat_grid(rows * c)), dim3(kBlock), 0,
+                       (hipStream_t)stream, rows, n, c, m * nsample, points, idx, out);
   return dh3d_launch_status();
 }
 
