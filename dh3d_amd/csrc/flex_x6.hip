@@ -118,6 +118,10 @@ __global__ __launch_bounds__(kThreads) void flex_conv_x6_kernel(
 
   if (wave < kProducers / 64) {
     // ------------------------------------------------------------------ producers
+    // FP32 VALU work only issues in the gaps of the consumers' MFMA stream: with the producers ahead in the issue
+    // arbitration those gaps open as soon as an FP instruction is ready instead of at the end of a GEMM burst
+    // (measured 26.9 -> 25.9 us per launch)
+    __builtin_amdgcn_s_setprio(3);
     const int prow = tid >> 4, lj = tid & 15;
     const int c0 = lj * C::VEC;  // first channel of this lane
     const unsigned mrec = (unsigned)(0x100000000ULL / N);
