@@ -46,3 +46,62 @@ def lazy_quadruplet_loss(global_descs, batch_size, num_pos, num_neg, global_trip
     d_other = ((neg - other) ** 2).sum(2)
     second = torch.clamp(global_quadruplet_margin + best_pos - d_other, min=0).max(1).values.mean()
     return trip + second
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Local-descriptor and detector losses (core/losses.py:29-133): plain tensor math on the sampled keypoints of a
+# registered cloud pair [cloud 0 batch | cloud 1 batch]; the 16-NN of the detector loss runs on the kNN kernel.
+def _pairwise_sqdist(a, b):
+    """[B,n,D], [B,m,D] -> [B,n,m] sum of squared differences (core/tf_utils.py:125-136)."""
+    return ((a.unsqueeze(2) - b.unsqueeze(1)) ** 2).sum(3)
+
+
+def desc_local_loss(outs, pos_r=0.5, search_r=20, margin=0.8, neg_weight=5):
+    """n-tuple loss on sampled keypoints (core/losses.py:29-63).  outs: 'xyz_sampled' [2B,M,3], 'feat_sampled'
+    [2B,M,D], 'R' [B,3,3] (cloud 0 -> cloud 1).  Returns pos_loss + neg_weight * neg_loss."""
+    xyz0, xyz1 = torch.chunk(outs["xyz_sampled"], 2, dim=0)
+    f0, f1 = torch.chunk(outs["feat_sampled"], 2, dim=0)
+    d_xyz = torch.sqrt(_pairwise_sqdist(torch.matmul(xyz0, outs["R"]), xyz1) + 1e-10)
+    is_neg = ((d_xyz > pos_r * 2) & (d_xyz < search_r)).to(f0.dtype)
+    is_pos = (d_xyz < pos_r).to(f0.dtype)
+    d_feat = torch.sqrt(_pairwise_sqdist(f0, f1) + 1e-10)
+    pos_loss = (is_pos * d_feat).sum() / (is_pos.sum() + 1e-10)
+    neg_loss = (is_neg * torch.clamp(margin - d_feat, min=0)).sum() / (is_neg.sum() + 1e-10)
+    return pos_loss + neg_weight * neg_loss
+
+
+def local_detection_loss_nn(outs, ar_th=0.3, det_k=16, ar_nn_k=5, pos_r=0.3, use_hardest_neg=True):
+    """Detector loss (core/losses.py:66-133): for every sampled keypoint of cloud 0, the rank (among its `ar_nn_k`
+    closest-in-feature candidates) of the first candidate that lies within pos_r of the warped keypoint; candidates =
+    the det_k nearest neighbours in cloud 1 of the corresponding sample (plus those of the hardest negative).
+    outs: 'xyz' [2B,N,3], 'feat' [2B,N,D], 'sample_nodes_concat' [2B,M,1] int, 'att_sampled' [2B,M,1],
+    'xyz_sampled', 'feat_sampled', 'R'."""
+    from . import ops
+    xyz0, xyz1 = torch.chunk(outs["xyz"], 2, dim=0)
+    _, feat1 = torch.chunk(outs["feat"], 2, dim=0)
+    _, samp1 = torch.chunk(outs["sample_nodes_concat"], 2, dim=0)
+    score0, _ = torch.chunk(outs["att_sampled"], 2, dim=0)
+    xyz_s0, xyz_s1 = torch.chunk(outs["xyz_sampled"], 2, dim=0)
+    feat_s0, feat_s1 = torch.chunk(outs["feat_sampled"], 2, dim=0)
+    B, M = xyz_s0.shape[0], xyz_s0.shape[1]
+    knn1, _ = ops.knn_bruteforce(xyz1.transpose(1, 2).contiguous(), k=det_k)  # [B,N,k]
+    knn1 = knn1.long()
+    xyz0_warp = torch.matmul(xyz_s0, outs["R"])
+    bidx = torch.arange(B, device=xyz0.device).reshape(B, 1)
+    cand = knn1[bidx, samp1.reshape(B, M).long()]                           # [B,M,k]
+    if use_hardest_neg:
+        is_neg = (torch.sqrt(_pairwise_sqdist(xyz0_warp, xyz_s1) + 1e-10) > 1).to(feat_s0.dtype)
+        neg_dist = torch.sqrt(_pairwise_sqdist(feat_s0, feat_s1) + 1e-10) + (1 - is_neg) * 100
+        hardest = neg_dist.argmin(dim=2)                                     # [B,M] -- index used as in the reference
+        cand = torch.cat([cand, knn1[bidx, hardest]], dim=-1)
+    b3 = torch.arange(B, device=xyz0.device).reshape(B, 1, 1)
+    cxyz, cfeat = xyz1[b3, cand], feat1[b3, cand]                            # [B,M,k',3], [B,M,k',D]
+    d_xyz = torch.sqrt(((xyz0_warp.unsqueeze(2) - cxyz) ** 2).sum(-1))
+    d_feat = ((feat_s0.unsqueeze(2) - cfeat) ** 2).sum(-1)
+    _, order = torch.topk(-d_feat, k=ar_nn_k, dim=-1)
+    good = (torch.gather(d_xyz, 2, order) <= pos_r).to(feat_s0.dtype)
+    good = torch.cat([good, torch.ones_like(good[..., :1])], dim=-1)
+    first = good.argmax(dim=-1).to(feat_s0.dtype)                            # first index of the maximum
+    AR = (first + 1e-8) / ar_nn_k
+    s0 = score0.squeeze(2)
+    return (1 - (AR * s0 + ar_th * (1 - s0))).mean()
