@@ -215,7 +215,66 @@ __global__ __launch_bounds__(256) void flex_pool_pm_kernel(const float *__restri
 
 // ------------------------------------------------------------------ conv_pointset on coordinates
 // out[n,o] = sum_k sum_i theta[i,o]*(x[nk,i]-x[n0,i]) + bias[o]  (conv_pointset_kernel.cc:46-64), Din=3.
+// One lane per point: the K neighbour offsets are gathered ONCE (the first version used Dout/4 lanes per point,
+// each re-gathering them: 280 loads per point, load-issue bound); the 32 outputs are produced four at a time with
+// the same per-k fma chain as before, and leave through LDS so that the stores are full 128-byte rows.
+template <int KT>
 __global__ __launch_bounds__(256) void conv_pointset_pm_kernel(
+    const float *__restrict__ xyz, const int32_t *__restrict__ nbr, const float *__restrict__ theta,
+    const float *__restrict__ bias, long long R, int N, int K, int Dout, EpilogueArgs ep,
+    float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float s_o[];  // [256][Dout + 4]
+  const int LDO = Dout + 4;
+  const int tid = threadIdx.x;
+  const long long n0 = (long long)dh3d_xcd_remap(blockIdx.x, gridDim.x) * 256;
+  const long long n = n0 + tid;
+  constexpr int KK = KT > 0 ? KT : 1;
+  float dx[KK], dy[KK], dz[KK];
+  if (n < R) {
+    const long long cloud0 = (n / N) * N;
+    const int32_t *nb = nbr + n * KK;
+    const long long g0 = cloud0 + nb[0];
+    const float x0 = xyz[g0 * 3], y0 = xyz[g0 * 3 + 1], z0 = xyz[g0 * 3 + 2];
+#pragma unroll
+    for (int k = 0; k < KK; ++k) {
+      const long long g = cloud0 + nb[k];
+      dx[k] = xyz[g * 3] - x0; dy[k] = xyz[g * 3 + 1] - y0; dz[k] = xyz[g * 3 + 2] - z0;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < KK; ++k) dx[k] = dy[k] = dz[k] = 0.f;
+  }
+  for (int o4 = 0; o4 < Dout; o4 += 4) {  // theta / bias: uniform addresses -> scalar loads
+    const float4 tx = *reinterpret_cast<const float4 *>(theta + o4);
+    const float4 ty = *reinterpret_cast<const float4 *>(theta + Dout + o4);
+    const float4 tz = *reinterpret_cast<const float4 *>(theta + 2 * Dout + o4);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < KK; ++k) {
+      acc.x = fmaf(tz.x, dz[k], fmaf(ty.x, dy[k], fmaf(tx.x, dx[k], acc.x)));
+      acc.y = fmaf(tz.y, dz[k], fmaf(ty.y, dy[k], fmaf(tx.y, dx[k], acc.y)));
+      acc.z = fmaf(tz.z, dz[k], fmaf(ty.z, dy[k], fmaf(tx.z, dx[k], acc.z)));
+      acc.w = fmaf(tz.w, dz[k], fmaf(ty.w, dy[k], fmaf(tx.w, dx[k], acc.w)));
+    }
+    const float4 bq = *reinterpret_cast<const float4 *>(bias + o4);
+    float4 r;
+    r.x = dh3d_epilogue_apply(acc.x + bq.x, o4, ep);
+    r.y = dh3d_epilogue_apply(acc.y + bq.y, o4 + 1, ep);
+    r.z = dh3d_epilogue_apply(acc.z + bq.z, o4 + 2, ep);
+    r.w = dh3d_epilogue_apply(acc.w + bq.w, o4 + 3, ep);
+    *reinterpret_cast<float4 *>(s_o + (size_t)tid * LDO + o4) = r;
+  }
+  __syncthreads();
+  const int cv = Dout / 4;
+  for (int e = tid; e < 256 * cv; e += 256) {
+    const int p = e / cv, c4 = (e - p * cv) * 4;
+    if (n0 + p < R)
+      *reinterpret_cast<float4 *>(out + (n0 + p) * Dout + c4) = *reinterpret_cast<const float4 *>(s_o + (size_t)p * LDO + c4);
+  }
+}
+
+// run-time K (not the model's path): Dout/4 lanes per point
+__global__ __launch_bounds__(256) void conv_pointset_pm_anyk_kernel(
     const float *__restrict__ xyz, const int32_t *__restrict__ nbr, const float *__restrict__ theta,
     const float *__restrict__ bias, long long R, int N, int K, int Dout, EpilogueArgs ep,
     float *__restrict__ out) {
@@ -293,8 +352,16 @@ DH3D_API int dh3d_conv_pointset_pm_fwd(const float *xyz, const int32_t *nbr, con
   DH3D_REQUIRE(xyz && nbr && theta && bias && out && B > 0 && N > 0 && K > 0 && Dout > 0);
   DH3D_SUPPORTED(Dout % 4 == 0);
   const long long R = (long long)B * N;
-  hipLaunchKernelGGL(conv_pointset_pm_kernel, dim3(flat_grid(R * (Dout / 4))), dim3(256), 0,
-                     (hipStream_t)stream, xyz, nbr, theta, bias, R, N, K, Dout, dh3d_ep(ep), out);
+  if (K == 8 && Dout <= 128) {
+    const size_t lds = sizeof(float) * 256 * (Dout + 4);
+    auto kern = conv_pointset_pm_kernel<8>;
+    DH3D_ALLOW_BIG_LDS(kern);
+    hipLaunchKernelGGL(kern, dim3(dh3d_cdiv(R, 256)), dim3(256), lds, (hipStream_t)stream, xyz, nbr, theta, bias, R, N,
+                       K, Dout, dh3d_ep(ep), out);
+  } else {
+    hipLaunchKernelGGL(conv_pointset_pm_anyk_kernel, dim3(flat_grid(R * (Dout / 4))), dim3(256), 0,
+                       (hipStream_t)stream, xyz, nbr, theta, bias, R, N, K, Dout, dh3d_ep(ep), out);
+  }
   return dh3d_launch_status();
 }
 
