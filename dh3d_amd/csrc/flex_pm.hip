@@ -18,9 +18,11 @@
 namespace {
 
 // ------------------------------------------------------------------ flex_conv
-template <int DIN, int DOUT>
+template <int DIN, int DOUT, int TMSEL = 0>
 struct FlexCfg {
-  static constexpr int TM = DIN <= 64 ? 64 : 32;    // points per workgroup
+  // points per workgroup: 64 for the narrow inputs, 32 for Din = 128; TMSEL = 32 forces the small tile (launches with
+  // fewer 64-point tiles than CUs: the N/8 levels)
+  static constexpr int TM = TMSEL ? TMSEL : (DIN <= 64 ? 64 : 32);
   static constexpr int KD = 4 * DIN;                // GEMM depth
   static constexpr int LD = KD + 4;                 // LDS leading dimension (floats)
   static constexpr int MB = TM / 32;                // 32-row blocks
@@ -40,12 +42,12 @@ __device__ long long g_fprobe[64 * 8];
 #endif
 
 // KT = compile-time neighbourhood size (8 on the DH3D path) or 0 for a run-time K.
-template <int DIN, int DOUT, int KT>
+template <int DIN, int DOUT, int KT, int TMSEL = 0>
 __global__ __launch_bounds__(256) void flex_conv_pm_kernel(
     const float *__restrict__ feat, const float *__restrict__ xyz, const int32_t *__restrict__ nbr,
     const float *__restrict__ wpacked, long long R, int N, int K, EpilogueArgs ep,
     float *__restrict__ out) {
-  using C = FlexCfg<DIN, DOUT>;
+  using C = FlexCfg<DIN, DOUT, TMSEL>;
   extern __shared__ __attribute__((aligned(16))) float s_S[];  // [TM][LD]
   const int tid = threadIdx.x;
   const long long grow0 = (long long)dh3d_xcd_remap(blockIdx.x, gridDim.x) * C::TM;
@@ -170,6 +172,17 @@ int flex_conv_pm_launch(const float *feat, const float *xyz, const int32_t *nbr,
                         int B, int N, int K, const EpilogueArgs &ep, float *out, hipStream_t s) {
   using C = FlexCfg<DIN, DOUT>;
   const long long R = (long long)B * N;
+  if constexpr (DIN == 64 && DOUT >= 128) {
+    // fewer 64-point tiles than CUs (the N/8 levels): 32-point tiles keep the whole chip busy
+    if (K == 8 && R <= 64 * 256) {
+      using C32 = FlexCfg<DIN, DOUT, 32>;
+      auto kern = flex_conv_pm_kernel<DIN, DOUT, 8, 32>;
+      DH3D_ALLOW_BIG_LDS(kern);
+      hipLaunchKernelGGL(kern, dim3(dh3d_cdiv(R, 32)), dim3(256), sizeof(float) * 32 * C32::LD, s, feat, xyz, nbr,
+                         wpacked, R, N, K, ep, out);
+      return dh3d_launch_status();
+    }
+  }
   const size_t lds = sizeof(float) * C::TM * C::LD;
   const dim3 grid(dh3d_cdiv(R, C::TM)), block(256);
   if (K == 8) {

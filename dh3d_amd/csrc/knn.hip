@@ -298,14 +298,20 @@ __global__ __launch_bounds__(64 * kSortedWaves) void knn_sorted_kernel(const flo
     const long long d0 = clock64();
     ++pr_ndrain;
 #endif
+    // all queued entries are requested from LDS before the first (long) insertion: one exposed latency per drain
+    // instead of one per slot
+    const int deepest = -wave_min_i32(-cnt);
+    uint2 ent[kQueue];
+#pragma unroll
+    for (int i = 0; i < kQueue; ++i)
+      if (i < deepest) ent[i] = my_q[i * 64 + lane];
+#pragma unroll
     for (int i = 0; i < kQueue; ++i) {
-      if (!__any(i < cnt)) break;
+      if (i < deepest) {  // wave-uniform
 #ifdef DH3D_KNN_PROBE
-      ++pr_nslots;
+        ++pr_nslots;
 #endif
-      if (i < cnt) {
-        const uint2 e = my_q[i * 64 + lane];
-        knn_offer<KMAX>(st, __uint_as_float(e.x), (int)e.y, lad);
+        if (i < cnt) knn_offer<KMAX>(st, __uint_as_float(ent[i].x), (int)ent[i].y, lad);
       }
     }
     cnt = 0;
