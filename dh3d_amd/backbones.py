@@ -145,14 +145,18 @@ class SEBlock(nn.Module):
 
     def prepare(self):
         c = self.channels
-        self._prep = (self.f1.tfconv0.W.detach().reshape(c, c // 4).contiguous(),
-                      self.f1.tfconv0.b.detach().contiguous(),
-                      self.f2.tfconv0.W.detach().reshape(c // 4, c).contiguous(),
-                      self.f2.tfconv0.b.detach().contiguous())
+        W1 = self.f1.tfconv0.W.detach().reshape(c, c // 4).contiguous()
+        b1 = self.f1.tfconv0.b.detach().contiguous()
+        W2 = self.f2.tfconv0.W.detach().reshape(c // 4, c).contiguous()
+        b2 = self.f2.tfconv0.b.detach().contiguous()
+        packed = pm.se_res_pack(W1, b1, W2) + (b2,) if c in (64, 128) and c // 4 <= 32 else None
+        self._prep = (W1, b1, W2, b2, packed)
         return self._prep
 
     def forward(self, x, pool):
-        W1, b1, W2, b2 = self._prep or self.prepare()
+        W1, b1, W2, b2, packed = self._prep or self.prepare()
+        if packed is not None:
+            return pm.se_res_packed(x, pool, *packed)
         return pm.se_res(x, pool, W1, b1, W2, b2)
 
 

@@ -236,6 +236,69 @@ __global__ __launch_bounds__(256) void se_res_pm_kernel(const float *__restrict_
   }
 }
 
+// The same block on the matrix pipe.  The VALU version above issues ~1700 ds_read_b32 per lane (one per weight) and
+// needs 25-30 us per 64-row tile; here the two small GEMMs run on v_mfma_f32_32x32x2_f32 against weights packed with
+// dh3d_pack_weight (W1 padded to 32 columns, W2 to 32 rows: the padding contributes exact zeros):
+//   squeeze  [64, C] x [C, 32]   waves 0/1 = the two row blocks
+//   excite   [64, 32] x [32, C]  all four waves, C/32 column blocks
+// then out = relu(x + x * sigmoid(.)) row-wise with 16-byte accesses.
+template <int C>
+__global__ __launch_bounds__(256) void se_res_mfma_kernel(const float *__restrict__ x, const float *__restrict__ pool,
+                                                         const float *__restrict__ w1p, const float *__restrict__ b1p,
+                                                         const float *__restrict__ w2p, const float *__restrict__ b2,
+                                                         long long R, float *__restrict__ out) {
+  constexpr int LDP = C + 4;   // pooled rows, later the gate tile
+  constexpr int LDH = 32 + 4;  // hidden rows
+  __shared__ __attribute__((aligned(16))) float s_p[kTM * LDP];
+  __shared__ __attribute__((aligned(16))) float s_h[kTM * LDH];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long grow0 = (long long)blockIdx.x * kTM;
+  stage_rows(pool, C, pool, 0, grow0, R, s_p, LDP);
+  __syncthreads();
+  if (wave < 2) {  // squeeze: relu(pool @ W1 + b1)
+    f32x16 acc[1];
+    zero_acc<1>(acc);
+    wave_gemm_f32<1>(s_p, LDP, wave * 32, w1p, C / 8, 0, 1, acc);
+    const float bb = b1p[lane & 31];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = acc[0][r] + bb;
+      s_h[(size_t)(wave * 32 + mfma_row(r, lane)) * LDH + (lane & 31)] = v > 0.f ? v : 0.f;
+    }
+  }
+  __syncthreads();
+  {  // excite: sigmoid(h @ W2 + b2) -> gate tile over the (dead) pooled rows
+    constexpr int NT = C / 64;  // column blocks per wave: (row block = wave & 1, column blocks (wave >> 1) + 2 j)
+    f32x16 acc[NT];
+    zero_acc<NT>(acc);
+    wave_gemm_f32<NT>(s_h, LDH, (wave & 1) * 32, w2p, 32 / 8, wave >> 1, 2, acc);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = ((wave >> 1) + 2 * j) * 32 + (lane & 31);
+      const float bb = b2[col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        s_p[(size_t)((wave & 1) * 32 + mfma_row(r, lane)) * LDP + col] = 1.f / (1.f + expf(-(acc[j][r] + bb)));
+    }
+  }
+  __syncthreads();
+  constexpr int CV = C / 4;
+  for (int e = tid; e < kTM * CV; e += 256) {
+    const int p = e / CV, c4 = (e - p * CV) * 4;
+    const long long g = grow0 + p;
+    if (g < R) {
+      const float4 xv = *reinterpret_cast<const float4 *>(x + g * C + c4);
+      const float4 gt = *reinterpret_cast<const float4 *>(s_p + (size_t)p * LDP + c4);
+      float4 r;
+      r.x = xv.x + xv.x * gt.x; r.y = xv.y + xv.y * gt.y; r.z = xv.z + xv.z * gt.z; r.w = xv.w + xv.w * gt.w;
+      r.x = r.x > 0.f ? r.x : 0.f; r.y = r.y > 0.f ? r.y : 0.f;
+      r.z = r.z > 0.f ? r.z : 0.f; r.w = r.w > 0.f ? r.w : 0.f;
+      *reinterpret_cast<float4 *>(out + g * C + c4) = r;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ l2 normalise (+ prefix concat)
 __global__ __launch_bounds__(256) void l2norm_concat_kernel(const float *__restrict__ x, long long R, int C,
                                                            float eps, const float *__restrict__ prefix,
@@ -322,6 +385,21 @@ DH3D_API int dh3d_se_res_pm_fwd(const float *x, const float *pool, const float *
     hipLaunchKernelGGL(se_res_pm_kernel<64>, grid, block, 0, s, x, pool, W1, b1, W2, b2, (long long)R, out);
   else if (C == 128)
     hipLaunchKernelGGL(se_res_pm_kernel<128>, grid, block, 0, s, x, pool, W1, b1, W2, b2, (long long)R, out);
+  else
+    return DH3D_ERR_UNSUPPORTED;
+  return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_se_res_pm_packed_fwd(const float *x, const float *pool, const float *w1packed, const float *b1pad,
+                                       const float *w2packed, const float *b2, int R, int C, float *out,
+                                       void *stream) {
+  DH3D_REQUIRE(x && pool && w1packed && b1pad && w2packed && b2 && out && R > 0);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(dh3d_cdiv(R, kTM)), block(256);
+  if (C == 64)
+    hipLaunchKernelGGL(se_res_mfma_kernel<64>, grid, block, 0, s, x, pool, w1packed, b1pad, w2packed, b2, (long long)R, out);
+  else if (C == 128)
+    hipLaunchKernelGGL(se_res_mfma_kernel<128>, grid, block, 0, s, x, pool, w1packed, b1pad, w2packed, b2, (long long)R, out);
   else
     return DH3D_ERR_UNSUPPORTED;
   return dh3d_launch_status();

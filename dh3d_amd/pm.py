@@ -182,6 +182,30 @@ def se_res(x, pool, W1, b1, W2, b2):
     return out
 
 
+def se_res_pack(W1, b1, W2):
+    """W1 [C,C/4], b1 [C/4], W2 [C/4,C] -> (w1packed, b1pad, w2packed) for se_res_packed (zero padding to 32)."""
+    C, Cq = W1.shape
+    W1p = torch.zeros((C, 32), dtype=torch.float32, device=W1.device)
+    W1p[:, :Cq] = W1
+    b1p = torch.zeros((32,), dtype=torch.float32, device=W1.device)
+    b1p[:Cq] = b1
+    W2p = torch.zeros((32, C), dtype=torch.float32, device=W1.device)
+    W2p[:Cq] = W2
+    return pack_weight(W1p), b1p, pack_weight(W2p)
+
+
+def se_res_packed(x, pool, w1packed, b1pad, w2packed, b2):
+    """se_res on the matrix pipe (csrc/dense.hip se_res_mfma_kernel)."""
+    a = L.require_cuda_f32(x, "x")
+    p = L.require_cuda_f32(pool, "pool")
+    C = a.shape[-1]
+    R = a.numel() // C
+    out = torch.empty_like(a)
+    L.check(L.lib().dh3d_se_res_pm_packed_fwd(L.ptr(a), L.ptr(p), L.ptr(w1packed), L.ptr(b1pad), L.ptr(w2packed),
+                                              L.ptr(b2), R, C, L.ptr(out), L.stream_ptr()), "se_res_pm_packed")
+    return out
+
+
 def three_interpolate_idw(points, idx, dist):
     p = L.require_cuda_f32(points, "points", 3)
     ix = L.require_cuda_i32(idx, "idx", 3)

@@ -205,6 +205,10 @@ int dh3d_linear_pm_fwd(const float *x1, int C1, const float *x2, int C2, const f
  * x, pool [R,C]; W1 [C,C/4], W2 [C/4,C] row-major (unpacked).  C in {64,128}. */
 int dh3d_se_res_pm_fwd(const float *x, const float *pool, const float *W1, const float *b1,
                        const float *W2, const float *b2, int R, int C, float *out, void *stream);
+/* The same block on the matrix pipe: w1packed = dh3d_pack_weight of W1 zero-padded to [C,32] columns, b1pad = b1
+ * zero-padded to 32, w2packed = dh3d_pack_weight of W2 zero-padded to [32,C] rows. */
+int dh3d_se_res_pm_packed_fwd(const float *x, const float *pool, const float *w1packed, const float *b1pad,
+                              const float *w2packed, const float *b2, int R, int C, float *out, void *stream);
 
 /* three_nn + inverse-distance weights + three_interpolate (core/backbones.py:90-96) fused:
  * weight = (1/max(d,1e-10)) / sum(1/max(d,1e-10)).  idx/dist from dh3d_three_nn.

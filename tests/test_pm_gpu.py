@@ -222,6 +222,9 @@ def test_se_res_pm(dev, C):
     h = np.maximum(pool.astype(np.float64) @ W1 + b1, 0)
     g = 1 / (1 + np.exp(-(h @ W2 + b2)))
     assert close(out, np.maximum(x + x * g, 0), 1e-4, 1e-5)
+    packed = pm.se_res_pack(T(W1, dev), T(b1, dev), T(W2, dev))
+    out2 = pm.se_res_packed(T(x, dev), T(pool, dev), *packed, T(b2, dev)).cpu().numpy()
+    assert close(out2, np.maximum(x + x * g, 0), 1e-4, 1e-5)
 
 
 def test_interpolate_idw_l2norm_and_head(dev, oracle):
