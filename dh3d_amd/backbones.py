@@ -216,11 +216,11 @@ def compute_level(xyz, dilate, knn, ordered=None):
     """FPS -> gather xyz -> kNN on the sampled set (three_nn back to the full set: finish_level).
 
     `ordered` = (records, group boxes) of pm.spatial_sort(xyz) if the caller has them: large clouds then use the
-    region-pruned FPS (csrc/fps.hip: 0.68 ms vs 0.82 ms at 8192 -> 1024; no gain at 4096 and below, where the
-    round is all synchronisation)."""
+    region-pruned FPS with several picks per synchronisation (csrc/fps.hip: 0.38 ms vs 0.82 ms at 8192 -> 1024,
+    0.2 vs 0.28 ms at 4096 -> 512; no gain at 2048 and below)."""
     B, N, _ = xyz.shape
     npoint = N // dilate
-    if ordered is not None and 4096 < N <= 12288:
+    if ordered is not None and 4096 <= N <= 12288:
         idx = pm.fps_sorted(ordered[0], ordered[1], npoint)
     else:
         idx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)

@@ -30,11 +30,19 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 
 #ifdef DH3D_FPS_PROBE  // dev instrumentation: cycle stamps of one round of wave 0 (tools/fps_probe.py)
-__device__ long long g_probe[16];
+__device__ long long g_probe[32];
 __device__ unsigned long long g_fps_cnt[2];  // ordered kernel: active (wave, round) pairs, updated groups
 #define PROBE(i) do { if (r == 300 && tid == 0 && blockIdx.x == 0) g_probe[i] = clock64(); } while (0)
+// batched kernel: per-phase cycle sums of one wave of cloud 0 (DH3D_FPS_PROBE_WAVE, default 0)
+#ifndef DH3D_FPS_PROBE_WAVE
+#define DH3D_FPS_PROBE_WAVE 0
+#endif
+#define STAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); pt[i] = clock64(); } while (0)
+#define ASTAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); at[i] = clock64(); } while (0)
 #else
 #define PROBE(i) do { } while (0)
+#define STAMP(i) do { } while (0)
+#define ASTAMP(i) do { } while (0)
 #endif
 
 __device__ __forceinline__ int fps_key(int k) { return ((k & 511) << 16) | (k >> 9); }
@@ -45,6 +53,11 @@ __device__ __forceinline__ int fps_unkey(int key) { return ((key & 0xffff) << 9)
 __device__ __forceinline__ float vmin(float a, float b) {
   float r;
   asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmaxf(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
 __device__ __forceinline__ float vmax3(float a, float b, float c) {
@@ -275,6 +288,257 @@ __global__ __launch_bounds__(64 * WAVES) void fps_sorted_kernel(const float4 *__
   for (int r = tid; r < m; r += 64 * WAVES) out[(size_t)b * m + r] = s_out[r];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Batched rounds on the ordered cloud: several picks per synchronisation, same picks as the sequential rule.
+//
+// What bounds fps_sorted_kernel is not its arithmetic but the barrier + LDS chain of a round.  FPS picks are far
+// apart by construction, so consecutive picks rarely interact: after a sync every wave holds the arg-max c_w of
+// its region (value v_w, tie key) and the second-largest value s_w in the region.  Order the candidates by
+// (value, key).  The j-th candidate IS the j-th next pick of the sequential algorithm if no higher-ranked
+// candidate c_p (a) lowers its distance (d(c_p, c_j) < v_j, computed with the update's own arithmetic) or
+// (b) leaves a better point behind in its region (s_p >= v_j); everything else can only have dropped.  Each wave
+// judges its OWN candidate against the 16 published ones (16 lanes, ~10 VALU), the first bad rank is an LDS
+// atomicMin, and all candidates ranked before it are taken at once: ~3.7 picks per sync on uniform clouds
+// (tools/fps_batch_sim.py).  Two barriers per sync instead of one per pick; the box tests of up to 64/PPT picks
+// against the wave's PPT boxes run in ONE pass (lane = pick * PPT + box).
+template <int PPT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void fps_batched_kernel(const float4 *__restrict__ sorted,
+                                                               const float *__restrict__ gbox, int N, int m,
+                                                               int32_t *__restrict__ out) {
+  static_assert(PPT <= 64 && WAVES <= 16, "one lane per group box, one lane per candidate");
+  constexpr int CAP0 = PPT <= 32 ? 64 / PPT : 1;
+  constexpr int CAP = CAP0 < WAVES ? CAP0 : WAVES;  // picks per sync
+  constexpr int NP = (PPT + 1) / 2;                 // groups are held and updated in pairs (packed f32)
+  constexpr int JW = WAVES < 4 ? WAVES : 4;         // judging waves (one per SIMD), CPJ candidates each
+  constexpr int CPJ = (WAVES + JW - 1) / JW;
+  constexpr int kBig = 1 << 20;
+  extern __shared__ __attribute__((aligned(16))) float s_mem[];
+  // candidates [WAVES][8]: key lo, key hi, second value, x | y, z, index, -   | picks [16] x,y,z,index | stop[4]
+  float4 *s_ent = reinterpret_cast<float4 *>(s_mem);
+  float4 *s_pick = s_ent + 2 * WAVES;
+  int *s_jthr = reinterpret_cast<int *>(s_pick + 16);  // per judging wave: first rank it holds back
+  float *s_x = reinterpret_cast<float *>(s_jthr + 4);
+  float *s_y = s_x + N;
+  float *s_z = s_y + N;
+  int *s_out = reinterpret_cast<int *>(s_z + N);
+
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NG = (N + 63) / 64;
+  const float4 *sc = sorted + (size_t)b * N;
+
+  f32x2 px[NP], py[NP], pz[NP], md[NP];
+  int pkey[2 * NP];
+#pragma unroll
+  for (int j = 0; j < 2 * NP; ++j) {
+    const int i = (wave * PPT + j) * 64 + lane;
+    float x = 0.f, y = 0.f, z = 0.f, d = -2.f;  // padding: below the reference's initial best = -1, never picked
+    pkey[j] = INT_MAX;
+    if (j < PPT && i < N) {
+      const float4 r = sc[i];
+      const int k = __float_as_int(r.w);
+      x = r.x; y = r.y; z = r.z;
+      d = 1e38f;
+      pkey[j] = fps_key(k);
+      s_x[k] = r.x; s_y[k] = r.y; s_z[k] = r.z;
+    }
+    px[j >> 1][j & 1] = x; py[j >> 1][j & 1] = y; pz[j >> 1][j & 1] = z; md[j >> 1][j & 1] = d;
+  }
+  // lane = pick * PPT + box: every pick slot sees the wave's PPT boxes
+  const int bl = lane % PPT, pk = lane / PPT;
+  float blx = INFINITY, bly = INFINITY, blz = INFINITY, bhx = -INFINITY, bhy = -INFINITY, bhz = -INFINITY;
+  bool has_box = false;
+  if (pk < CAP) {
+    const int g = wave * PPT + bl;
+    if (g < NG) {
+      const float *bx = gbox + ((size_t)b * NG + g) * 8;
+      blx = bx[0]; bly = bx[1]; blz = bx[2]; bhx = bx[4]; bhy = bx[5]; bhz = bx[6];
+      has_box = true;
+    }
+  }
+  if (tid == 0) s_out[0] = 0;
+  if (tid < 4) s_jthr[tid] = kBig;
+  if (lane < 2) s_ent[2 * wave + lane] = make_float4(0.f, 0.f, -2.f, 0.f);  // key 0 = nothing to offer
+  __syncthreads();
+
+  // A wave executes ~1 instruction per 4.6 cycles whatever its kind (tools/fps_exp.py: the loop below is bound by the
+  // instruction count along the chain barrier -> judge -> barrier -> box test -> update -> arg-max, not by data), so
+  // every phase is written for few instructions: no per-group branches, no atomics, nothing recomputed.
+  float wmax = __ballot(has_box) != 0ull ? 1e38f : -2.f;  // cached wave maximum (uniform)
+  float qx = s_x[0], qy = s_y[0], qz = s_z[0];            // lane (pk, .): coordinates of pick pk of this sync
+  int npick = 1, r = 1;
+#ifdef DH3D_FPS_PROBE
+  long long pt[12], at[8];
+#endif
+  constexpr unsigned long long kPickMask = PPT == 64 ? ~0ull : ((1ull << (PPT & 63)) - 1ull);
+  while (true) {
+    STAMP(0);
+    // 1. every (pick, box) pair at once: can the pick change anything in the group?
+    const float ex = fmaxf(fmaxf(blx - qx, qx - bhx), 0.f);
+    const float ey = fmaxf(fmaxf(bly - qy, qy - bhy), 0.f);
+    const float ez = fmaxf(fmaxf(blz - qz, qz - bhz), 0.f);
+    const float bd = (ex * ex + ey * ey + ez * ez) * 0.99999f;
+    const unsigned long long need = __ballot(has_box && pk < npick && bd <= wmax);
+    STAMP(1);
+#if defined(DH3D_FPS_EXP) && (DH3D_FPS_EXP & 1)  // timing experiment: sync chain only (results wrong)
+    if (need != 0ull && r < 8) {
+#else
+    if (need != 0ull) {  // wave-uniform
+#endif
+      unsigned long long nd = need;
+#if defined(DH3D_FPS_EXP) && (DH3D_FPS_EXP & 4)
+      if (r < 8)
+#endif
+      do {  // the picks that reach this wave
+        const int p = __builtin_ctzll(nd) / PPT;
+        const unsigned long long nb = (nd >> (p * PPT)) & kPickMask;
+        nd &= ~(kPickMask << (p * PPT));
+        const float x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), p * PPT));
+        const float y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy), p * PPT));
+        const float z1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz), p * PPT));
+        const f32x2 x2 = {x1, x1}, y2 = {y1, y1}, z2 = {z1, z1};
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          // small waves: all groups, branch-free (an update that was not needed is harmless and a skipped pair
+          // would cost as many scalar instructions as it saves vector ones); large ones: the hit pairs only
+          if (PPT <= 8 || ((nb >> (2 * q)) & 3ull)) {
+            const f32x2 dx = px[q] - x2, dy = py[q] - y2, dz = pz[q] - z2;
+            const f32x2 d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
+            md[q][0] = __builtin_fminf(d[0], md[q][0]);
+            md[q][1] = __builtin_fminf(d[1], md[q][1]);
+          }
+        }
+      } while (nd != 0ull);
+      ASTAMP(0);
+#if defined(DH3D_FPS_EXP) && (DH3D_FPS_EXP & 8)
+      if (r < 8) {
+#else
+      {
+#endif
+      // one wave arg-max (+ runner-up value) over everything the wave holds
+      // (the key of each lane's first maximum rides along: a separate pass of compares after the wave maximum is
+      //  known costs ~270 cycles of chain, this ~40)
+      float b1 = -2.f, b2 = -2.f;
+      int lkey = INT_MAX;
+#pragma unroll
+      for (int j = 0; j < 2 * NP; ++j) {
+        const float x = md[j >> 1][j & 1];
+        lkey = x > b1 ? pkey[j] : lkey;
+        b2 = __builtin_amdgcn_fmed3f(b1, b2, x);
+        b1 = __builtin_fmaxf(b1, x);
+      }
+      asm volatile("" :: "v"(b1), "v"(b2));
+      ASTAMP(1);
+      wmax = wave_max_f32(b1);
+      ASTAMP(2);
+      const unsigned long long hit = __ballot(b1 == wmax);
+      int wl = __builtin_ctzll(hit);  // winner lane
+      float wsec = wave_max_f32(lane == wl ? b2 : b1);  // runner-up (redone below if wl changes)
+      ASTAMP(3);
+      int wkey;
+      if (__popcll(hit) == 1 && __ballot(b2 == wmax) == 0ull) {  // one point holds the maximum
+        wkey = __builtin_amdgcn_readlane(lkey, wl);
+      } else {  // ties: the smallest key wins
+        lkey = INT_MAX;
+#pragma unroll
+        for (int j = 0; j < 2 * NP; ++j) lkey = (md[j >> 1][j & 1] == wmax) ? min(lkey, pkey[j]) : lkey;
+        wkey = wave_min_i32(lkey);
+        wl = __builtin_ctzll(__ballot(lkey == wkey));
+        wsec = wave_max_f32(lane == wl ? b2 : b1);
+      }
+      ASTAMP(4);
+      const int widx = fps_unkey(wkey);
+      const float wx = s_x[widx], wy = s_y[widx], wz = s_z[widx];
+      ASTAMP(5);
+      // publish the candidate (an untouched wave's entry stays valid)
+      if (lane == 0) {
+        s_ent[2 * wave] = make_float4(__int_as_float(~wkey), wmax, wsec, wx);
+        s_ent[2 * wave + 1] = make_float4(wy, wz, __int_as_float(widx), 0.f);
+      }
+      ASTAMP(6);
+#ifdef DH3D_FPS_PROBE
+      if (tid == 64 * DH3D_FPS_PROBE_WAVE && blockIdx.x == 0) {
+        g_probe[16] += at[0] - pt[1];
+        for (int i = 0; i < 6; ++i) g_probe[17 + i] += at[i + 1] - at[i];
+      }
+#endif
+      }
+    }
+    STAMP(2);
+    if (r >= m) break;
+    __syncthreads();
+    STAMP(3);
+    // 2. judge the candidates: lane (row, p) of a judging wave compares candidate c = wave*CPJ + row with candidate p
+#if defined(DH3D_FPS_EXP) && (DH3D_FPS_EXP & 2)  // timing experiment: no judging (results wrong)
+    if (wave < JW && r < 8) {
+#else
+    if (wave < JW) {
+#endif
+      const int row = lane >> 4, p = lane & 15;
+      const int c = wave * CPJ + row;
+      const bool valid = row < CPJ && c < WAVES;
+      const float4 c0 = s_ent[2 * (c < WAVES ? c : 0)], c1 = s_ent[2 * (c < WAVES ? c : 0) + 1];
+      const float4 p0 = s_ent[2 * (p < WAVES ? p : 0)], p1 = s_ent[2 * (p < WAVES ? p : 0) + 1];
+      STAMP(7);
+      const float vc = c0.y;
+      const unsigned long long key_c = ((unsigned long long)__float_as_uint(c0.y) << 32) | __float_as_uint(c0.x);
+      const unsigned long long key_p = ((unsigned long long)__float_as_uint(p0.y) << 32) | __float_as_uint(p0.x);
+      const bool gt = valid && p < WAVES && key_p > key_c;
+      const float dx = c0.w - p0.w, dy = c1.x - p1.x, dz = c1.y - p1.y;
+      const float d = __fmaf_rn(dz, dz, __fmaf_rn(dx, dx, __fmul_rn(dy, dy)));
+      const bool aff = d < vc || p0.z >= vc;
+      const unsigned rowg = (unsigned)(__ballot(gt) >> (16 * row)) & 0xffffu;
+      const unsigned rowa = (unsigned)(__ballot(gt && aff) >> (16 * row)) & 0xffffu;
+      const int rank = __popc(rowg);
+      // first rank that must wait for the next sync: my row's, if an outranking candidate interferes with it
+      const int stop = valid && rank > 0 && (rowa != 0u || !(vc > 0.f)) ? rank : kBig;
+      STAMP(8);
+      const int stop4 = min(min(__builtin_amdgcn_readlane(stop, 0), __builtin_amdgcn_readlane(stop, 16)),
+                            min(__builtin_amdgcn_readlane(stop, 32), __builtin_amdgcn_readlane(stop, 48)));
+      if (lane == 0) s_jthr[wave] = stop4;
+      if (p == 0 && valid && key_c != 0ull && rank < CAP) s_pick[rank] = make_float4(c0.w, c1.x, c1.y, c1.z);
+    }
+    STAMP(4);
+    __syncthreads();
+    STAMP(5);
+    // 3. the accepted picks
+    {
+      const int4 jt = *reinterpret_cast<const int4 *>(s_jthr);
+      const float4 pkv = s_pick[pk < CAP ? pk : 0];
+      const int thr = min(min(jt.x, jt.y), min(jt.z, jt.w));
+#if defined(DH3D_FPS_EXP)  // timing experiments: one pick per sync whatever the judges said
+      npick = min(min(thr, 1), m - r);
+#else
+      npick = min(min(thr, CAP), m - r);
+#endif
+      qx = pkv.x; qy = pkv.y; qz = pkv.z;
+      if (wave == 0 && bl == 0 && pk < npick) s_out[r + pk] = __float_as_int(pkv.w);
+      r += npick;
+    }
+#ifdef DH3D_FPS_PROBE
+    STAMP(6);
+    if (tid == 64 * DH3D_FPS_PROBE_WAVE && blockIdx.x == 0) {
+      for (int i = 0; i < 6; ++i) g_probe[i] += pt[i + 1] - pt[i];
+      if (wave < JW) { g_probe[6] += pt[7] - pt[3]; g_probe[7] += pt[8] - pt[7]; g_probe[8] += pt[4] - pt[8]; }
+      g_probe[14] += need != 0ull;
+      g_probe[15] += 1;
+    }
+#endif
+  }
+  __syncthreads();
+  for (int i = tid; i < m; i += 64 * WAVES) out[(size_t)b * m + i] = s_out[i];
+}
+
+template <int PPT, int WAVES>
+int fps_batched_launch(const float *sorted, const float *gbox, int B, int N, int m, int32_t *out, hipStream_t s) {
+  const size_t lds = sizeof(float) * (8 * WAVES + 64 + 4 + (size_t)3 * N + m);
+  if (lds > 159 * 1024) return DH3D_ERR_UNSUPPORTED;
+  DH3D_ALLOW_BIG_LDS((fps_batched_kernel<PPT, WAVES>));
+  hipLaunchKernelGGL((fps_batched_kernel<PPT, WAVES>), dim3(B), dim3(64 * WAVES), lds, s,
+                     reinterpret_cast<const float4 *>(sorted), gbox, N, m, out);
+  return dh3d_launch_status();
+}
+
 template <int PPT, int WAVES>
 int fps_sorted_launch(const float *sorted, const float *gbox, int B, int N, int m, int32_t *out, hipStream_t s) {
   const size_t lds = sizeof(float) * (4 * WAVES + (size_t)3 * N + m);
@@ -331,7 +595,9 @@ DH3D_API int dh3d_farthest_point_sample(int B, int N, int m, const float *inp, f
 
 // Dev knob (tools/geo_bench.py): waves per cloud for the ordered kernel; 0 = default.
 static int g_fps_sorted_waves = 0;
+static int g_fps_sorted_mode = 0;  // 0 = batched rounds, 1 = one pick per round
 DH3D_API void dh3d_dev_set_fps_sorted_waves(int w) { g_fps_sorted_waves = w; }
+DH3D_API void dh3d_dev_set_fps_sorted_mode(int v) { g_fps_sorted_mode = v; }
 
 DH3D_API int dh3d_fps_sorted(const float *sorted, const float *gbox, int B, int N, int m, int32_t *out,
                              void *stream) {
@@ -343,6 +609,15 @@ DH3D_API int dh3d_fps_sorted(const float *sorted, const float *gbox, int B, int 
 #define DH3D_FPS_CASE(WV)                                                                             \
   if (W == WV) {                                                                                      \
     const int gpw = (NG + WV - 1) / WV; /* groups per wave */                                         \
+    if (g_fps_sorted_mode == 0) {                                                                     \
+      if (gpw <= 1) return fps_batched_launch<1, WV>(sorted, gbox, B, N, m, out, s);                  \
+      if (gpw <= 2) return fps_batched_launch<2, WV>(sorted, gbox, B, N, m, out, s);                  \
+      if (gpw <= 4) return fps_batched_launch<4, WV>(sorted, gbox, B, N, m, out, s);                  \
+      if (gpw <= 8) return fps_batched_launch<8, WV>(sorted, gbox, B, N, m, out, s);                  \
+      if (gpw <= 16) return fps_batched_launch<16, WV>(sorted, gbox, B, N, m, out, s);                \
+      if (gpw <= 32) return fps_batched_launch<32, WV>(sorted, gbox, B, N, m, out, s);                \
+      if (gpw <= 48) return fps_batched_launch<48, WV>(sorted, gbox, B, N, m, out, s);                \
+    }                                                                                                 \
     if (gpw <= 1) return fps_sorted_launch<1, WV>(sorted, gbox, B, N, m, out, s);                     \
     if (gpw <= 2) return fps_sorted_launch<2, WV>(sorted, gbox, B, N, m, out, s);                     \
     if (gpw <= 4) return fps_sorted_launch<4, WV>(sorted, gbox, B, N, m, out, s);                     \
@@ -365,6 +640,6 @@ DH3D_API int dh3d_fps_cnt_read(unsigned long long *host2, int reset) {
   return rc;
 }
 DH3D_API int dh3d_fps_probe_read(long long *host16) {
-  return hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_probe), sizeof(long long) * 16) == hipSuccess ? 0 : 3;
+  return hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_probe), sizeof(long long) * 32) == hipSuccess ? 0 : 3;
 }
 #endif

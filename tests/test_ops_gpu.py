@@ -271,6 +271,26 @@ def test_fps_sorted_identical(dev, oracle, B, N, m):
     assert np.array_equal(idx.cpu().numpy(), oracle.farthest_point_sample(m, xyz))
 
 
+def test_fps_sorted_batched_rounds_adversarial(dev, oracle):
+    """Several picks per synchronisation must stay the sequential picks under exact ties, duplicates and exhaustion."""
+    from dh3d_amd import ops, pm
+    rng = np.random.default_rng(5)
+    g = np.stack(np.meshgrid(*[np.arange(16, dtype=np.float32)] * 3, indexing="ij"), -1).reshape(1, -1, 3)
+    lattice = g[:, rng.permutation(4096)]                                # every distance tied many times over
+    dup = np.repeat(rng.random((1, 2500, 3), dtype=np.float32), 2, 1)    # each point twice: zero distances early
+    dup = dup[:, rng.permutation(5000)]
+    plane = rng.random((2, 6000, 3), dtype=np.float32); plane[:, :, 2] *= 1e-3
+    same = np.zeros((1, 1500, 3), np.float32)
+    for xyz, m in ((lattice, 4096), (lattice, 700), (dup, 3000), (plane, 1500), (same, 20),
+                   (rng.random((3, 70, 3), dtype=np.float32), 70), (rng.random((1, 5000, 3), dtype=np.float32), 5000)):
+        t = T(xyz, dev)
+        srt, gbox = pm.spatial_sort(t)
+        idx = pm.fps_sorted(srt, gbox, m)
+        assert torch.equal(idx, ops.farthest_point_sample(m, t))
+        if xyz.shape[1] * m <= 4096 * 1024:
+            assert np.array_equal(idx.cpu().numpy(), oracle.farthest_point_sample(m, xyz))
+
+
 def test_fps_sorted_golden_and_ties(dev):
     from dh3d_amd import pm
     c = load("fps.npz")

@@ -22,13 +22,16 @@ for B, N in ((1, 8192), (8, 8192), (32, 4096), (8, 1024), (32, 512)):
     srt, gbox = pm.spatial_sort(xyz)
     m = max(N // 8, 1)
     res = []
-    for w in (4, 8, 16):
-        raw.dh3d_dev_set_fps_sorted_waves(w)
-        try:
-            res.append("w%d %.3f" % (w, ev(lambda: pm.fps_sorted(srt, gbox, m))))
-        except Exception as e:
-            res.append("w%d n/a" % w)
+    for mode in (0, 1):  # 0 = batched rounds, 1 = one pick per round
+        raw.dh3d_dev_set_fps_sorted_mode(mode)
+        for w in (4, 8, 16):
+            raw.dh3d_dev_set_fps_sorted_waves(w)
+            try:
+                res.append("m%dw%d %.3f" % (mode, w, ev(lambda: pm.fps_sorted(srt, gbox, m))))
+            except Exception as e:
+                res.append("m%dw%d n/a" % (mode, w))
     raw.dh3d_dev_set_fps_sorted_waves(0)
+    raw.dh3d_dev_set_fps_sorted_mode(0)
     res2 = []
     for w in (4, 8, 16):
         raw.dh3d_dev_set_fps_waves(w)
