@@ -76,7 +76,8 @@ struct KnnState {
   float bound;  // s > bound  =>  sqrt(s) > current K-th distance
 };
 
-template <int KMAX>
+// KEEP_MIN: the bound may already be tighter than this list's own K-th entry (knn_split_kernel)
+template <int KMAX, bool KEEP_MIN = false>
 __device__ __forceinline__ void knn_offer(KnnState<KMAX> &st, float s, int x, const KnnLadder &lad) {
   if (s <= st.bound) {
     const float d = sqrtf(s);  // IEEE-rounded (llvm.sqrt.f32 under -fhip-fp32-correctly-rounded-divide-sqrt)
@@ -95,7 +96,8 @@ __device__ __forceinline__ void knn_offer(KnnState<KMAX> &st, float s, int x, co
       if (hb <= 0x7f800000u) {
         const float dk = __uint_as_float(hb);
         // (1+2^-20)-inflated square of the K-th distance: any s above it has sqrt(s) > d_K.
-        st.bound = __fmul_rn(__fmul_rn(dk, dk), 1.000001f);
+        const float nb = __fmul_rn(__fmul_rn(dk, dk), 1.000001f);
+        st.bound = KEEP_MIN ? fminf(st.bound, nb) : nb;
       }
     }
   }
@@ -431,6 +433,224 @@ __global__ __launch_bounds__(64 * kSortedWaves) void knn_sorted_kernel(const flo
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same search with S waves per query group.  knn_sorted_kernel has one wave per 64 queries: at the model's sizes
+// that is ONE wave per SIMD on the whole chip, each a dependent instruction stream (a wave issues ~1 instruction per
+// 4.6 cycles), and the kernel ends with its slowest group.  Here the S waves of a workgroup hold the same 64 queries and
+// split the CANDIDATE groups (group gi belongs to wave gi % S), each with its own K-lists; the lists are merged through
+// LDS at the end.  A wave alone would prune with the K-th entry of a list that saw 1/S of the candidates; instead every
+// wave publishes, per query, the distance of its ceil(K/S)-th entry: S lists hold at least K candidates within the
+// largest of those S distances, so max_w d_w bounds the true K-th distance -- as does any single wave's own K-th
+// distance; the screen uses the smallest of all of these.  Published values are only ever replaced by smaller ones, so a stale read is still valid
+// (no barrier).  Every candidate is evaluated by exactly one wave with the same arithmetic, keys are unique: the merged
+// list is the list of the one-wave kernel, bit for bit.
+template <int KMAX, int S>
+__global__ __launch_bounds__(64 * S) void knn_split_kernel(const float4 *__restrict__ sorted,
+                                                         const float *__restrict__ gbox, int N, int K,
+                                                         KnnLadder lad, int32_t *__restrict__ nn,
+                                                         float *__restrict__ dist) {
+  static_assert(KMAX * 64 * sizeof(u64) <= kQueue * 64 * sizeof(uint2), "a K-list fits its wave's survivor queue");
+  __shared__ __attribute__((aligned(16))) float s_c[S][64 * 3];  // pair-SoA image per wave
+  __shared__ uint2 s_q[S][kQueue * 64];
+  __shared__ int s_id[S][64];
+  __shared__ float s_share[S][64];  // per wave, per query: inflated square of the distance of its R-th entry
+  __shared__ float s_kth[S][64];    // ... and of its K-th entry (its own screening bound)
+  constexpr int R = (KMAX + S - 1) / S - 1;
+  const int b = blockIdx.y, g = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int NG = (N + 63) / 64;
+  const float4 *sc = sorted + (size_t)b * N;
+  const float4 *gb = reinterpret_cast<const float4 *>(gbox) + (size_t)b * NG * 2;  // [lo.xyz,_ | hi.xyz,_]
+  float *my_c = s_c[wave];
+  uint2 *my_q = s_q[wave];
+  int *my_id = s_id[wave];
+
+  const int qi = g * 64 + lane;
+  const bool valid = qi < N;
+  const float4 pad = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(-1));
+  const float4 qr = valid ? sc[qi] : pad;
+  const f32x2 qx2 = {qr.x, qr.x}, qy2 = {qr.y, qr.y}, qz2 = {qr.z, qr.z};
+  const float4 qlo = gb[g * 2], qhi = gb[g * 2 + 1];
+
+  KnnState<KMAX> st;
+#pragma unroll
+  for (int i = 0; i < KMAX; ++i) st.keys[i] = ~0ull;
+  st.bound = INFINITY;
+  int cnt = 0;
+  float wave_bound = INFINITY;
+  s_share[wave][lane] = INFINITY;
+  s_kth[wave][lane] = INFINITY;
+  __syncthreads();
+
+  // everyone's progress -> my screen: the true K-th distance is at most any wave's own K-th, and at most the largest
+  // of the S R-th distances
+  auto adopt = [&](float mx) {
+    float mk = st.bound;
+#pragma unroll
+    for (int w = 1; w < S; ++w) {
+      mx = fmaxf(mx, s_share[(wave + w) % S][lane]);
+      mk = fminf(mk, s_kth[(wave + w) % S][lane]);
+    }
+    st.bound = fminf(mk, mx);
+    wave_bound = wave_max_f32(valid ? st.bound : 0.f);
+  };
+
+  auto drain = [&]() {
+    const int deepest = -wave_min_i32(-cnt);
+    uint2 ent[kQueue];
+#pragma unroll
+    for (int i = 0; i < kQueue; ++i)
+      if (i < deepest) ent[i] = my_q[i * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < kQueue; ++i) {
+      if (i < deepest) {  // wave-uniform
+        if (i < cnt) knn_offer<KMAX, true>(st, __uint_as_float(ent[i].x), (int)ent[i].y, lad);
+      }
+    }
+    cnt = 0;
+    // publish my R-th distance, take the largest of everyone's
+    const unsigned hb = (unsigned)(st.keys[R] >> 32);
+    float mx = INFINITY;
+    if (hb <= 0x7f800000u) {
+      const float dr = __uint_as_float(hb);
+      mx = __fmul_rn(__fmul_rn(dr, dr), 1.000001f);
+    }
+    s_share[wave][lane] = mx;
+    const unsigned hk = (unsigned)(st.keys[KMAX - 1] >> 32);
+    if (hk <= 0x7f800000u) {
+      const float dk = __uint_as_float(hk);
+      s_kth[wave][lane] = __fmul_rn(__fmul_rn(dk, dk), 1.000001f);
+    }
+    adopt(mx);
+  };
+
+  auto scan_group = [&](int gcc, const float4 cr) {
+    my_c[cand_slot(lane, 0)] = cr.x;
+    my_c[cand_slot(lane, 1)] = cr.y;
+    my_c[cand_slot(lane, 2)] = cr.z;
+    my_id[lane] = __float_as_int(cr.w);
+    __builtin_amdgcn_wave_barrier();
+    const int clen = min(64, N - gcc * 64);
+    for (int j = 0; j < clen; j += 32) {
+      f32x2 sq[4][4];
+      float mn[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        knn_dist8(my_c + ((j >> 2) + 2 * u) * 12, qx2, qy2, qz2, sq[u]);
+        mn[u] = knn_min8(sq[u]);
+      }
+      const float m = fminf(fminf(mn[0], mn[1]), fminf(mn[2], mn[3]));
+      if (__any(valid && m <= st.bound)) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (valid && mn[u] <= st.bound) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+              const float sv = sq[u][t >> 1][t & 1];
+              if (sv <= st.bound && j + 8 * u + t < clen) {
+                my_q[cnt * 64 + lane] = make_uint2(__float_as_uint(sv), (unsigned)my_id[j + 8 * u + t]);
+                ++cnt;
+              }
+            }
+          }
+          if (__any(cnt > kQueue - 8)) drain();
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto load_group = [&](int gcc) { const int ci = gcc * 64 + lane; return ci < N ? sc[ci] : pad; };
+
+  if (g % S == wave) {  // the queries' own group goes first where it is owned
+    scan_group(g, qr);
+    if (__any(cnt > 0)) drain();
+  }
+  for (int tier = 0; tier < 2; ++tier) {
+    for (int c0 = 0; c0 < NG; c0 += 64) {
+      const int gi = c0 + lane;
+      const bool other = gi < NG && gi != g && gi % S == wave;
+      float bd = INFINITY;
+      if (other) {
+        const float4 clo = gb[gi * 2], chi = gb[gi * 2 + 1];
+        const float ex = fmaxf(fmaxf(clo.x - qhi.x, qlo.x - chi.x), 0.f);
+        const float ey = fmaxf(fmaxf(clo.y - qhi.y, qlo.y - chi.y), 0.f);
+        const float ez = fmaxf(fmaxf(clo.z - qhi.z, qlo.z - chi.z), 0.f);
+        bd = (ex * ex + ey * ey + ez * ez) * 0.99999f;
+      }
+      if (tier == 1) adopt(s_share[wave][lane]);  // the others have worked since the last look
+      unsigned long long mask =
+          tier == 0 ? __ballot(other && bd == 0.f) : __ballot(other && bd > 0.f && bd <= wave_bound);
+      if (!mask) continue;
+      int l = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      float4 nxt = load_group(c0 + l);
+      while (true) {
+        const int lcur = l;
+        const float4 cr = nxt;
+        const bool more = mask != 0;
+        if (more) {
+          l = __builtin_ctzll(mask);
+          mask &= mask - 1;
+          nxt = load_group(c0 + l);
+        }
+        const float bdl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bd), lcur));
+        if (bdl <= wave_bound) scan_group(c0 + lcur, cr);  // the bound may have tightened since the ballot
+        if (!more) break;
+      }
+    }
+  }
+  if (__any(cnt > 0)) drain();
+
+  // merge the S lists (tree: w <- w + step), keys are unique so plain insertion
+  for (int step = S / 2; step >= 1; step >>= 1) {
+    __syncthreads();  // the queues of the waves about to publish are drained
+    if (wave >= step && wave < 2 * step) {
+#pragma unroll
+      for (int i = 0; i < KMAX; ++i)
+        my_q[i * 64 + lane] = make_uint2((unsigned)st.keys[i], (unsigned)(st.keys[i] >> 32));
+    }
+    __syncthreads();
+    if (wave < step) {
+      const uint2 *oq = s_q[wave + step];
+#pragma unroll
+      for (int i = 0; i < KMAX; ++i) {
+        const uint2 e = oq[i * 64 + lane];
+        const u64 key = ((u64)e.y << 32) | e.x;
+        if (key < st.keys[KMAX - 1]) {
+          st.keys[KMAX - 1] = key;
+#pragma unroll
+          for (int t = KMAX - 1; t > 0; --t) {
+            const u64 a = st.keys[t - 1], c = st.keys[t];
+            const bool lt = c < a;
+            st.keys[t - 1] = lt ? c : a;
+            st.keys[t] = lt ? a : c;
+          }
+        }
+      }
+    }
+  }
+
+  if (wave == 0 && valid) {
+    const int y = __float_as_int(qr.w);  // original index of this query
+    int32_t *o_nn = nn + ((size_t)b * N + y) * K;
+    float *o_d = dist + ((size_t)b * N + y) * K;
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i) {
+      if (i < K) {
+        const unsigned tb = (unsigned)st.keys[i];
+        if (st.keys[i] == ~0ull) {
+          o_nn[i] = -1;
+          o_d[i] = FLT_MAX;
+        } else {
+          o_nn[i] = (int)(((tb % (unsigned)lad.cv) << lad.log2ct) + tb / (unsigned)lad.cv);
+          o_d[i] = __uint_as_float((unsigned)(st.keys[i] >> 32));
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Small clouds (N <= 2048: the N/8 sampled sets of the model).  The lane-per-query kernels above leave most of the
 // chip idle there (B*N/64 waves, each a long dependent scan).  Here a WAVE owns a query: every lane holds
 // CPL = N/64 candidates in registers (loaded once, reused for 4 queries), computes their exact keys
@@ -534,6 +754,10 @@ DH3D_API int dh3d_knn_bruteforce_xyz(const float *xyz, int B, int N, int K, int3
   return knn_launch<true>(xyz, B, N, K, nn, dist, (hipStream_t)stream);
 }
 
+// Dev knob (tools/geo_bench.py): waves per query group of the ordered search; -1 = default, 0 = one-wave kernel.
+static int g_knn_split = -1;
+DH3D_API void dh3d_dev_set_knn_split(int s) { g_knn_split = s; }
+
 DH3D_API int dh3d_knn_sorted(const float *sorted, const float *gbox, int B, int N, int K, int32_t *nn,
                              float *dist, void *stream) {
   DH3D_REQUIRE(sorted && gbox && nn && dist && B > 0 && N > 0 && K > 0);
@@ -543,6 +767,22 @@ DH3D_API int dh3d_knn_sorted(const float *sorted, const float *gbox, int B, int 
   dim3 grid(dh3d_cdiv(NG, kSortedWaves), B), block(64 * kSortedWaves);
   hipStream_t s = (hipStream_t)stream;
   const float4 *so = reinterpret_cast<const float4 *>(sorted);
+  // waves per query group (0 = the one-wave kernel): as many as keep the chip at <= ~4 waves per SIMD, where the
+  // search turns from latency- to issue-bound (MI355X: 8x8192 0.194 -> 0.109 ms at 4; 32x4096 0.178 -> 0.147 at 2)
+  const long long groups = (long long)NG * B;
+  const int S = g_knn_split >= 0 ? g_knn_split : groups <= 256 ? 8 : groups <= 1280 ? 4 : groups <= 4096 ? 2 : 0;
+  if (S > 0 && K <= 16) {
+    dim3 sgrid(NG, B);
+#define DH3D_SPLIT_CASE(KM, SS)                                                                               \
+  if (K <= KM && S == SS) {                                                                                  \
+    hipLaunchKernelGGL((knn_split_kernel<KM, SS>), sgrid, dim3(64 * SS), 0, s, so, gbox, N, K, lad, nn, dist); \
+    return dh3d_launch_status();                                                                             \
+  }
+    DH3D_SPLIT_CASE(4, 2) DH3D_SPLIT_CASE(4, 4)
+    DH3D_SPLIT_CASE(8, 2) DH3D_SPLIT_CASE(8, 4) DH3D_SPLIT_CASE(8, 8)
+    DH3D_SPLIT_CASE(16, 2) DH3D_SPLIT_CASE(16, 4) DH3D_SPLIT_CASE(16, 8)
+#undef DH3D_SPLIT_CASE
+  }
   if (K <= 4) hipLaunchKernelGGL((knn_sorted_kernel<4>), grid, block, 0, s, so, gbox, N, K, lad, nn, dist);
   else if (K <= 8) hipLaunchKernelGGL((knn_sorted_kernel<8>), grid, block, 0, s, so, gbox, N, K, lad, nn, dist);
   else if (K <= 16) hipLaunchKernelGGL((knn_sorted_kernel<16>), grid, block, 0, s, so, gbox, N, K, lad, nn, dist);

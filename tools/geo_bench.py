@@ -41,6 +41,12 @@ for B, N in ((1, 8192), (8, 8192), (32, 4096), (8, 1024), (32, 512)):
             res2.append("w%d n/a" % w)
     raw.dh3d_dev_set_fps_waves(0)
     print("   fps_bf by waves:", " ".join(res2))
+    res3 = []
+    for sp in (0, 2, 4, 8):  # waves per query group of the ordered kNN (0 = one-wave kernel)
+        raw.dh3d_dev_set_knn_split(sp)
+        res3.append("s%d %.3f" % (sp, ev(lambda: pm.knn_sorted(srt, gbox, 8))))
+    raw.dh3d_dev_set_knn_split(-1)
+    print("   knn_sorted by split:", " ".join(res3))
     print(B, N, "sort %.3f knn_bf %.3f knn_sorted %.3f fps_bf %.3f fps_sorted[%s] three_nn %.3f" % (
         ev(lambda: pm.spatial_sort(xyz)), ev(lambda: pm.knn_xyz(xyz, 8)), ev(lambda: pm.knn_sorted(srt, gbox, 8)),
         ev(lambda: ops.farthest_point_sample(m, xyz)), " ".join(res),
