@@ -322,6 +322,8 @@ __global__ __launch_bounds__(64 * WAVES) void fps_batched_kernel(const float4 *_
   float *s_z = s_y + N;
   int *s_out = reinterpret_cast<int *>(s_z + N);
 
+  // the kernel is a dependent chain on 1 CU per cloud while the rest of the step shares the chip: its waves go first
+  __builtin_amdgcn_s_setprio(3);
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NG = (N + 63) / 64;
