@@ -142,6 +142,14 @@ class DH3D(nn.Module):
         # stage2 (dilate2=8) and global (gl_dilate=8) share this level.  Enqueued BEFORE the side work: hipGraph keeps
         # a node's first-captured successor on its queue, and the FPS chain is the one that must not hop.
         geo._lv = geo.level(8, self.knn_num, finish=False)
+        # three_nn needs the sampled coordinates only.  It goes where there is slack: the FPS chain is ~0.05 us per
+        # point of a cloud whatever the batch, kNN(N) + stage 1 on the side stream ~2.5 us per 1000 points of the
+        # batch -- big batches of small clouds (cfg 3) leave this stream waiting for stage 1, and three_nn beside
+        # the N/8 convolutions would slow those down (42 vs 17 us for 64->128 at 32x512); a few big clouds (cfg 2)
+        # are the other way round and it runs on the side stream after stage 1 (compute_local).
+        B_, N_ = points.shape[0], points.shape[1]
+        if 80.0 + 2.5e-3 * B_ * N_ - 0.05 * N_ > 60.0:
+            bb.finish_level(points, geo._lv, same_stream=True)
         side.wait_event(fork)
         with torch.cuda.stream(side):
             if knn_inds is not None:
