@@ -135,8 +135,15 @@ def kernel_breakdown(dev, B, N):
     from dh3d_amd import pm, ops
     xyz = torch.rand(B, N, 3, device=dev)
     out = {}
+    # drop-in operators (any input order) ...
     out["knn_xyz K=8"] = event_time_ms(lambda: pm.knn_xyz(xyz, 8), iters=10, warm=2)
     out["fps N->N/8"] = event_time_ms(lambda: ops.farthest_point_sample(N // 8, xyz), iters=5, warm=1)
+    # ... and what the model runs: Morton order once, then the box-pruned search and the batched-round FPS on it
+    out["spatial_sort"] = event_time_ms(lambda: pm.spatial_sort(xyz), iters=10, warm=2)
+    srt, gbox = pm.spatial_sort(xyz)
+    out["knn_sorted K=8"] = event_time_ms(lambda: pm.knn_sorted(srt, gbox, 8), iters=10, warm=2)
+    if 4096 <= N <= 12288:
+        out["fps_sorted N->N/8"] = event_time_ms(lambda: pm.fps_sorted(srt, gbox, N // 8), iters=5, warm=1)
     sub = xyz[:, : N // 8].contiguous()
     out["three_nn"] = event_time_ms(lambda: ops.three_nn(xyz, sub), iters=10, warm=2)
     return out
