@@ -177,6 +177,9 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="local")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / breakdown / second workload")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="independent steps in flight (graph instances on separate streams, each with its own batch "
+                         "buffers): a serving loop's overlap of consecutive batches.  Default 1 = one step at a time")
     args = ap.parse_args()
 
     from dh3d_amd import dist as D
@@ -216,20 +219,21 @@ def main():
         clouds = wl["B"] * world * args.steps
         return clouds / dt, dt / args.steps * 1e3
 
-    def measure_two_in_flight(workload):
-        """Throughput with TWO independent steps in flight (two graph instances on two streams).  Informational:
-        a step of this path leaves most of the GPU idle (FPS: one CU per cloud, 75 % of the local step), so a
-        serving loop would overlap consecutive batches.  `value` stays the one-step-at-a-time number."""
+    def measure_in_flight(workload, depth=2):
+        """Throughput with `depth` independent steps in flight (graph instances on separate streams, every step still
+        one full pass over one batch).  A step of this path leaves most of the GPU idle (FPS: one CU per cloud, two
+        thirds of the local step), so a serving loop overlaps consecutive batches.  The default `value` stays the
+        one-step-at-a-time number; `--inflight` makes this the measured mode."""
         wl = WORKLOADS[workload]
         model = build_model(wl["preset"], dev, seed=0)
         pts = synthetic_clouds(wl["B"], wl["N"], wl["seed"], dev, rank)
-        streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
         with torch.no_grad():
-            runs = [model.graphed(pts, outputs=(wl["out"],)), model.graphed(pts, outputs=(wl["out"],))]
+            runs = [model.graphed(pts, outputs=(wl["out"],)) for _ in range(depth)]
             state = {"i": 0}
 
             def step(p):
-                k = state["i"] & 1
+                k = state["i"] % depth
                 state["i"] += 1
                 with torch.cuda.stream(streams[k]):
                     runs[k]()  # each instance's batch is resident in its own input buffer
@@ -239,7 +243,10 @@ def main():
             dt = time_steps(step, pts, args.steps, args.warmup, dev)
         return wl["B"] * world * args.steps / dt, dt / args.steps * 1e3
 
-    value, ms = measure(args.workload)
+    if args.inflight > 1 and args.workload != "train":
+        value, ms = measure_in_flight(args.workload, args.inflight)
+    else:
+        value, ms = measure(args.workload)
     wl = WORKLOADS[args.workload]
     line = {
         "metric": "point-clouds/sec", "value": value, "unit": "point-clouds/sec", "n_gpus": world,
@@ -247,7 +254,8 @@ def main():
         "scaling": "strong" if args.workload == "train" else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl["name"], "clouds_per_gpu": wl["B"], "points": wl["N"], "knn": 8,
                    "parallelism": "clouds sharded over %d GPU(s), no data-path collective" % world,
-                   "weights": "random-init (no checkpoint blobs exist upstream)", "execution": "hipGraph replay"},
+                   "weights": "random-init (no checkpoint blobs exist upstream)", "execution": "hipGraph replay",
+                   "steps_in_flight": args.inflight if args.workload != "train" else 1},
     }
     if args.workload == "train":
         line["config"]["execution"] = "eager (fused HIP backbone + autograd head)"
@@ -262,7 +270,7 @@ def main():
             ov, oms = measure(other)
             line["other_workload"] = {"workload": WORKLOADS[other]["name"], "value": ov,
                                       "unit": "point-clouds/sec", "ms_per_step": oms}
-            pv, pms = measure_two_in_flight(args.workload)
+            pv, pms = measure_in_flight(args.workload, 2)
             line["two_steps_in_flight"] = {"value": pv, "unit": "point-clouds/sec", "ms_per_step": pms,
                                            "note": "informational: consecutive batches overlapped on two streams; "
                                                    "`value` is measured one step at a time"}
