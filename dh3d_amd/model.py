@@ -203,7 +203,8 @@ class DH3D(nn.Module):
 
     def forward(self, points, knn_inds=None, fetch=None):
         """points [Bt, N, 3] float32 on the GPU (anchor/pos/neg already concatenated, core/model.py:139-146).
-        knn_inds [Bt, N, K] int32 is required iff num_points > 8192 (core/model.py:148-155).
+        knn_inds [Bt, N, K] int32: optional precomputed neighbours (the reference requires them for
+        num_points > 8192, core/model.py:148-155; here the device kNN serves N <= 16384).
         fetch: names of the outputs wanted (None = all).  Like a TF session fetch, tensors nobody asked for are not
         computed: the global-descriptor extraction (globaldesc_extract.py fetches 'globaldesc' only) skips the
         normalised per-point descriptors and the detector."""
@@ -212,8 +213,10 @@ class DH3D(nn.Module):
         cfg = self.config
         if points.dim() != 3 or points.shape[2] != 3:
             raise ValueError("points must be [Bt, N, 3]")
-        if self.input_knn_indices and knn_inds is None:
-            raise ValueError("num_points > 8192: pass knn_inds [Bt, N, K] (the reference feeds host kNN)")
+        if knn_inds is None and points.shape[1] > 16384:
+            raise ValueError("more than 16384 points: pass knn_inds [Bt, N, K] (the device kNN stops there)")
+        # num_points > 8192: the reference feeds host (sklearn) kNN indices because its op stops at 8192
+        # (core/model.py:38,148-155); they are still accepted, but the device search covers N <= 16384 itself.
         outs = {"pointclouds": points, "xyz": points}
         geo = self._geometry(points, knn_inds)
         outs["knn_inds"] = geo.nbr

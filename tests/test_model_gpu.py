@@ -93,19 +93,22 @@ def test_full_size_properties_cfg2_cfg3(dev):
 
 
 def test_input_knn_path_above_8192(dev):
-    """num_points > 8192: kNN indices are an input (core/model.py:148-155); cfg5 shape N=16384."""
+    """num_points > 8192: kNN indices may be an input as in the reference (core/model.py:148-155) or are computed on
+    the device (superset: the reference's op stops at 8192); cfg5 shape N=16384."""
     from dh3d_amd import ConfigFactory, pm
     from dh3d_amd.model import DH3D
     cfg = ConfigFactory("basic_config").getconfig()
     cfg.num_points = 16384
     m = DH3D(cfg).init_synthetic(1).to(dev).eval().prepare()
     pts = torch.rand(1, 16384, 3, device=dev)
-    with pytest.raises(ValueError):
-        m(pts)
     nbr, _ = pm.knn_xyz(pts, 8)
     with torch.no_grad():
         out = m(pts, knn_inds=nbr)
+        own = m(pts)
     assert out["xyz_feat"].shape == (1, 16384, 131) and torch.isfinite(out["xyz_feat"]).all()
+    assert torch.equal(own["knn_inds"], nbr) and torch.equal(own["xyz_feat"], out["xyz_feat"])
+    with pytest.raises(ValueError):
+        m(torch.rand(1, 16400, 3, device=dev))
 
 
 def test_shard_then_gather_equals_unsharded(dev):
