@@ -103,11 +103,13 @@ class Conv2D1x1(nn.Module):
         return ("wp3" in p and idx.shape[1] >= 4096 and coarse.shape[-1] % 32 == 0
                 and (x2 is None or x2.shape[-1] % 32 == 0))
 
-    def forward_upsampled(self, coarse, idx, dist, x2=None, act=pm.ACT_RELU, residual=None):
-        """forward([three_interpolate_idw(coarse, idx, dist) | x2]) with the up-sampling fused into the GEMM."""
+    def forward_upsampled(self, coarse, idx, dist, x2=None, act=pm.ACT_RELU, residual=None, l2cat=None):
+        """forward([three_interpolate_idw(coarse, idx, dist) | x2]) with the up-sampling fused into the GEMM
+        (l2cat: and the l2-normalise + xyz concat of core/model.py:177-181 fused into its store)."""
         p = self._prep or self.prepare()
         return pm.upsample_linear_x6(coarse, idx, dist, p["wp3"], self.cout, x2=x2, pre_bias=p["b"], scale=p["scale"],
-                                     shift=p["shift"], act=act, residual=residual)
+                                     shift=p["shift"], act=act, residual=residual,
+                                     l2cat=l2cat if self.cout == 128 else None)
 
 
 class FeatureConv1d(nn.Module):
@@ -298,9 +300,10 @@ class FlexConvDilate(nn.Module):
             self.concat_conv1d.tfconv0.prepare()
         return prep
 
-    def forward(self, geo, feat, nbr=None, residual=None):
+    def forward(self, geo, feat, nbr=None, residual=None, l2cat=None):
         """geo: Geometry; feat [B,N,cin]; nbr [B,N,K] for dilate == 1 (else computed on the sampled set);
-        residual [B,N,cout]: added to the concat conv's output in its store (the caller's shortcut branch)."""
+        residual [B,N,cout]: added to the concat conv's output in its store (the caller's shortcut branch);
+        l2cat = (prefix [B,N,3], eps): return [prefix | l2_normalize(output)] instead of the output."""
         prep = self._prep or self.prepare()
         if self.dilate > 1:
             lv = geo.level(self.dilate, self.knn, finish=False)  # three_nn is joined only where it is consumed
@@ -320,14 +323,16 @@ class FlexConvDilate(nn.Module):
             conv = self.concat_conv1d.tfconv0 if self.concat else None
             if conv is not None and conv.upsampled_supported(x, lv["nn3_idx"], feat):
                 # up-sampling fused into the concat conv's operand staging: the [B,N,C] tensor is never written
-                return conv.forward_upsampled(x, lv["nn3_idx"], lv["nn3_dist"], x2=feat, act=pm.ACT_RELU,
-                                              residual=residual)
+                fuse = l2cat if conv.cout == 128 else None
+                y = conv.forward_upsampled(x, lv["nn3_idx"], lv["nn3_dist"], x2=feat, act=pm.ACT_RELU,
+                                           residual=residual, l2cat=fuse)
+                return y if (l2cat is None or fuse is not None) else pm.l2norm_concat(y, l2cat[1], prefix=l2cat[0])
             x = pm.three_interpolate_idw(x, lv["nn3_idx"], lv["nn3_dist"])
         if self.concat:
             x = self.concat_conv1d(x, x2=feat, act=pm.ACT_RELU, residual=residual)
         elif residual is not None:
             x = x + residual
-        return x
+        return x if l2cat is None else pm.l2norm_concat(x, l2cat[1], prefix=l2cat[0])
 
 
 # --------------------------------------------------------------------------- local backbone

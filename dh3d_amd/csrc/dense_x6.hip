@@ -245,12 +245,20 @@ struct UpsampleSrc {
   int n, m;              // rows per cloud of the fine / coarse level
 };
 
+// Optional last step of the local path (core/model.py:177-181): out_cat[r] = [prefix[r, 0:3] | l2_normalize(y[r])]
+// written straight from the output tile (Dout == 128), instead of y: saves a pass over the [R,128] tensor.
+struct L2CatOut {
+  float *out;           // [R, 3 + 128]   (null: plain output)
+  const float *prefix;  // [R, 3]
+  float eps;            // tf.nn.l2_normalize: y * rsqrt(max(sum(y^2), eps))
+};
+
 template <int NC>
 __global__ __launch_bounds__(512) void linear_x6_kernel(const float *__restrict__ x1, int C1,
                                                        const float *__restrict__ x2, int C2,
                                                        const uint4 *__restrict__ wp, EpilogueArgs ep,
                                                        const float *__restrict__ residual, long long R,
-                                                       float *__restrict__ out, UpsampleSrc up) {
+                                                       float *__restrict__ out, UpsampleSrc up, L2CatOut l2) {
   constexpr int TN = NC * 128;                      // columns of the tile = Dout
   constexpr int BST = (TN / 32) * 2 * 3 * 64;       // uint4 per B buffer
   constexpr int DMA = BST / 64 / 8;                 // LDS-DMA instructions per wave per chunk
@@ -372,6 +380,39 @@ __global__ __launch_bounds__(512) void linear_x6_kernel(const float *__restrict_
             dh3d_act((acc[rb][cb][r] + pb) * sc + sh, ep.act);
   }
   __syncthreads();
+  if (NC == 1 && l2.out) {
+    // residual into the tile, row norms (4 threads per row), then one flat coalesced store of rows x 131 floats
+    float *s_inv = s_out + (size_t)HTM * LDO;
+    {
+      const int p = tid >> 2, q = tid & 3;
+      const long long g = grow0 + p;
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < TN / 16; ++i) {
+        const int c4 = (i * 4 + q) * 4;
+        float4 v = *reinterpret_cast<const float4 *>(s_out + (size_t)p * LDO + c4);
+        if (residual && g < R) {
+          const float4 rq = *reinterpret_cast<const float4 *>(residual + g * TN + c4);
+          v.x += rq.x; v.y += rq.y; v.z += rq.z; v.w += rq.w;
+          *reinterpret_cast<float4 *>(s_out + (size_t)p * LDO + c4) = v;
+        }
+        ss = fmaf(v.x, v.x, ss); ss = fmaf(v.y, v.y, ss); ss = fmaf(v.z, v.z, ss); ss = fmaf(v.w, v.w, ss);
+      }
+      ss += __shfl_xor(ss, 1, 64);
+      ss += __shfl_xor(ss, 2, 64);
+      if (q == 0) s_inv[p] = rsqrtf(fmaxf(ss, l2.eps));
+    }
+    __syncthreads();
+    constexpr int W = 3 + TN;
+    const long long rows = R - grow0 < HTM ? R - grow0 : HTM;
+    float *o = l2.out + grow0 * W;
+    const float *pf = l2.prefix + grow0 * 3;
+    for (int e = tid; e < (int)rows * W; e += 512) {
+      const int p = e / W, c = e - p * W;
+      o[e] = c < 3 ? pf[p * 3 + c] : s_out[(size_t)p * LDO + (c - 3)] * s_inv[p];
+    }
+    return;
+  }
   constexpr int CV = TN / 4;
   for (int e = tid; e < HTM * CV; e += 512) {
     const int p = e / CV, c4 = (e - p * CV) * 4;
@@ -423,7 +464,7 @@ DH3D_API int dh3d_mlp_head_pm_x6_fwd(const float *h, int R, int C, const void *w
 
 static int linear_x6_launch(const float *x1, int C1, const float *x2, int C2, const void *wpacked_x3, int R, int Dout,
                             const dh3d_epilogue *ep, const float *residual, float *out, void *stream,
-                            const UpsampleSrc &up) {
+                            const UpsampleSrc &up, const L2CatOut &l2 = L2CatOut{nullptr, nullptr, 0.f}) {
   DH3D_SUPPORTED(C1 % HKC == 0 && C2 % HKC == 0 && (Dout == 128 || Dout == 256));
   const EpilogueArgs e = dh3d_ep(ep);
   hipStream_t s = (hipStream_t)stream;
@@ -431,18 +472,19 @@ static int linear_x6_launch(const float *x1, int C1, const float *x2, int C2, co
   const uint4 *wp = static_cast<const uint4 *>(wpacked_x3);
   if (Dout == 128) {
     size_t lds = (size_t)2 * A_STAGE * 2 + (size_t)2 * (128 / 32) * 2 * 3 * 64 * 16;
-    const size_t tile = sizeof(float) * HTM * (128 + 4);
+    const size_t tile = sizeof(float) * HTM * (128 + 4) + sizeof(float) * HTM;  // + row norms (L2CatOut)
     if (tile > lds) lds = tile;
     auto kern = linear_x6_kernel<1>;
     DH3D_ALLOW_BIG_LDS(kern);
-    hipLaunchKernelGGL(kern, grid, block, lds, s, x1, C1, x2, C2, wp, e, residual, (long long)R, out, up);
+    hipLaunchKernelGGL(kern, grid, block, lds, s, x1, C1, x2, C2, wp, e, residual, (long long)R, out, up, l2);
   } else {
     size_t lds = (size_t)2 * A_STAGE * 2 + (size_t)2 * (256 / 32) * 2 * 3 * 64 * 16;
     const size_t tile = sizeof(float) * HTM * (256 + 4);
     if (tile > lds) lds = tile;
+    if (l2.out) return DH3D_ERR_UNSUPPORTED;
     auto kern = linear_x6_kernel<2>;
     DH3D_ALLOW_BIG_LDS(kern);
-    hipLaunchKernelGGL(kern, grid, block, lds, s, x1, C1, x2, C2, wp, e, residual, (long long)R, out, up);
+    hipLaunchKernelGGL(kern, grid, block, lds, s, x1, C1, x2, C2, wp, e, residual, (long long)R, out, up, l2);
   }
   return dh3d_launch_status();
 }
@@ -463,4 +505,20 @@ DH3D_API int dh3d_upsample_linear_pm_x6_fwd(const float *points, const int32_t *
   DH3D_REQUIRE((long long)B * n < (1LL << 31));
   const UpsampleSrc up{points, idx, dist, n, m};
   return linear_x6_launch(points, C1, x2, C2, wpacked_x3, B * n, Dout, ep, residual, out, stream, up);
+}
+
+// The same, finishing the local path in its store: out_cat [B*n, 3 + 128] = [prefix | l2_normalize(y, eps)]
+// (core/model.py:177-181); Dout == 128.  y itself is not written.
+DH3D_API int dh3d_upsample_linear_l2cat_pm_x6_fwd(const float *points, const int32_t *idx, const float *dist, int B,
+                                                  int n, int m, int C1, const float *x2, int C2,
+                                                  const void *wpacked_x3, int Dout, const dh3d_epilogue *ep,
+                                                  const float *residual, const float *prefix, float l2_eps,
+                                                  float *out_cat, void *stream) {
+  DH3D_REQUIRE(points && idx && dist && wpacked_x3 && out_cat && prefix && B > 0 && n > 0 && m > 0 && C1 > 0 &&
+               C2 >= 0 && (C2 == 0 || x2));
+  DH3D_SUPPORTED(Dout == 128);
+  DH3D_REQUIRE((long long)B * n < (1LL << 31));
+  const UpsampleSrc up{points, idx, dist, n, m};
+  const L2CatOut l2{out_cat, prefix, l2_eps};
+  return linear_x6_launch(points, C1, x2, C2, wpacked_x3, B * n, Dout, ep, residual, out_cat, stream, up, l2);
 }

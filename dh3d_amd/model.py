@@ -165,7 +165,10 @@ class DH3D(nn.Module):
         torch.cuda.current_stream().wait_stream(geo._side)
 
     # ------------------------------------------------------------------ reference API
-    def compute_local(self, points, knn_inds=None, _geo=None):
+    def compute_local(self, points, knn_inds=None, _geo=None, _l2cat_eps=None):
+        """(points, local descriptors [Bt,N,featdim]) (core/model.py:157-171).  _l2cat_eps (internal): the second item is
+        [points | l2_normalize(descriptors)] instead, written by the last conv's store (forward(fetch=...) when nothing
+        needs the raw descriptors)."""
         self._check_mode()
         geo = _geo if _geo is not None else self._geometry(points, knn_inds)
         main = torch.cuda.current_stream()
@@ -186,7 +189,8 @@ class DH3D(nn.Module):
             for t in (x2, shortcut, geo._lv["nn3_dist"], geo._lv["nn3_idx"]):
                 t.record_stream(main)
         main.wait_event(stage1_done)  # not the whole side stream: three_nn is joined at the interpolation (geo.finish)
-        feat = self.stage2(geo, x2, residual=shortcut)  # gather, N/8 convs, SE, interpolation, concat conv
+        l2cat = (points, _l2cat_eps) if _l2cat_eps is not None else None
+        feat = self.stage2(geo, x2, residual=shortcut, l2cat=l2cat)  # gather, N/8 convs, SE, interpolation, concat conv
         self._last_geo = geo
         return points, feat
 
@@ -220,6 +224,13 @@ class DH3D(nn.Module):
         outs = {"pointclouds": points, "xyz": points}
         geo = self._geometry(points, knn_inds)
         outs["knn_inds"] = geo.nbr
+        needs_raw = want("feat", "attention", "xyz_feat_att", "globaldesc")
+        if fetch is not None and not needs_raw and want("xyz_feat", "feat_l2normed"):
+            # only the normalised descriptors are asked for: the last conv writes [xyz | l2_normalize(feat)] itself
+            _, xyz_feat = self.compute_local(points, _geo=geo, _l2cat_eps=1e-8)
+            outs["xyz_feat"] = xyz_feat
+            outs["feat_l2normed"] = xyz_feat[:, :, 3:]
+            return outs
         newpoints, localdesc = self.compute_local(points, _geo=geo)
         outs["feat"] = localdesc
         xyz_feat = None

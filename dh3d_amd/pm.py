@@ -268,9 +268,10 @@ def linear_x6(x1, wpacked_x3, Dout, x2=None, pre_bias=None, scale=None, shift=No
 
 
 def upsample_linear_x6(points, idx, dist, wpacked_x3, Dout, x2=None, pre_bias=None, scale=None, shift=None,
-                       act=ACT_NONE, residual=None):
+                       act=ACT_NONE, residual=None, l2cat=None):
     """linear_x6([three_interpolate_idw(points, idx, dist) | x2]) without materialising the up-sampled tensor.
-    points [B,m,C1], idx/dist [B,n,3], x2 [B,n,C2]."""
+    points [B,m,C1], idx/dist [B,n,3], x2 [B,n,C2].  l2cat = (prefix [B,n,3], eps): return
+    [prefix | l2_normalize(result, eps)] [B,n,3+Dout] instead (Dout == 128), the result itself is not written."""
     p = L.require_cuda_f32(points, "points", 3)
     ix = L.require_cuda_i32(idx, "idx", 3)
     d = L.require_cuda_f32(dist, "dist", 3)
@@ -286,8 +287,18 @@ def upsample_linear_x6(points, idx, dist, wpacked_x3, Dout, x2=None, pre_bias=No
     res = None
     if residual is not None:
         res = L.require_cuda_f32(residual, "residual", 3)
-    out = torch.empty((B, n, Dout), dtype=torch.float32, device=p.device)
     ep = _ep(pre_bias, scale, shift, act)
+    if l2cat is not None:
+        pf = L.require_cuda_f32(l2cat[0], "prefix", 3)
+        if tuple(pf.shape) != (B, n, 3):
+            raise ValueError("upsample_linear_x6: prefix must be [B,n,3]")
+        out = torch.empty((B, n, 3 + Dout), dtype=torch.float32, device=p.device)
+        L.check(L.lib().dh3d_upsample_linear_l2cat_pm_x6_fwd(L.ptr(p), L.ptr(ix), L.ptr(d), B, n, m, C1, L.ptr(b), C2,
+                                                             L.ptr(wpacked_x3), Dout, ep, L.ptr(res), L.ptr(pf),
+                                                             float(l2cat[1]), L.ptr(out), L.stream_ptr()),
+                "upsample_linear_l2cat_pm_x6")
+        return out
+    out = torch.empty((B, n, Dout), dtype=torch.float32, device=p.device)
     L.check(L.lib().dh3d_upsample_linear_pm_x6_fwd(L.ptr(p), L.ptr(ix), L.ptr(d), B, n, m, C1, L.ptr(b), C2,
                                                    L.ptr(wpacked_x3), Dout, ep, L.ptr(res), L.ptr(out), L.stream_ptr()),
             "upsample_linear_pm_x6")

@@ -241,6 +241,12 @@ int dh3d_linear_pm_x6_fwd(const float *x1, int C1, const float *x2, int C2, cons
 int dh3d_upsample_linear_pm_x6_fwd(const float *points, const int32_t *idx, const float *dist, int B, int n, int m,
                                    int C1, const float *x2, int C2, const void *wpacked_x3, int Dout,
                                    const dh3d_epilogue *ep, const float *residual, float *out, void *stream);
+/* the same with the local path's last step fused into the store (core/model.py:177-181): out_cat [B*n, 3+128] =
+ * [prefix [B*n,3] | l2_normalize(y, l2_eps)], Dout == 128; y itself is not written */
+int dh3d_upsample_linear_l2cat_pm_x6_fwd(const float *points, const int32_t *idx, const float *dist, int B, int n,
+                                         int m, int C1, const float *x2, int C2, const void *wpacked_x3, int Dout,
+                                         const dh3d_epilogue *ep, const float *residual, const float *prefix,
+                                         float l2_eps, float *out_cat, void *stream);
 
 /* The same head with the GEMM on the bf16 matrix pipe at f32 accuracy ("bf16x6": every f32 operand is split
  * exactly into three bf16 chunks, six chunk products are accumulated in f32; error <= 2^-23 per product, see

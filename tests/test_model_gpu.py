@@ -124,3 +124,22 @@ def test_shard_then_gather_equals_unsharded(dev):
             parts.append(m(blk)["globaldesc"])
         gathered = torch.cat(parts, 0)[:11]
     assert torch.allclose(gathered, full, atol=1e-6)
+
+
+def test_fetch_only_normalised_descriptors_uses_fused_store(dev):
+    """forward(fetch=('xyz_feat',)): the concat conv writes [xyz | l2_normalize(feat)] itself; same values as the full
+    forward's separate normalisation (different summation order of the row norm: a few ulps)."""
+    from dh3d_amd import ConfigFactory
+    from dh3d_amd.model import DH3D
+    m = DH3D(ConfigFactory("basic_config").getconfig()).init_synthetic(3).to(dev).eval().prepare()
+    g = torch.Generator().manual_seed(11)
+    pts = torch.rand(2, 4096 + 64, 3, generator=g).to(dev)  # ragged last tile
+    with torch.no_grad():
+        full = m(pts)
+        only = m(pts, fetch=("xyz_feat",))
+    assert "feat" not in only and only["xyz_feat"].shape == full["xyz_feat"].shape == (2, 4160, 131)
+    assert torch.equal(only["xyz_feat"][:, :, :3], pts)
+    err = (only["xyz_feat"] - full["xyz_feat"]).abs().max().item()
+    assert err < 2e-6, err
+    nrm = only["feat_l2normed"].norm(dim=2)
+    assert torch.allclose(nrm, torch.ones_like(nrm), atol=1e-5)
