@@ -223,12 +223,12 @@ def compute_level(xyz, dilate, knn, ordered=None):
     B, N, _ = xyz.shape
     npoint = N // dilate
     if ordered is not None and 4096 <= N <= 12288:
-        idx = pm.fps_sorted(ordered[0], ordered[1], npoint)
+        idx, xyz_s = pm.fps_sorted(ordered[0], ordered[1], npoint, with_xyz=True)  # coordinates from the kernel's LDS
     else:
         idx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
         L.check(L.lib().dh3d_farthest_point_sample(B, N, npoint, L.ptr(xyz), None, L.ptr(idx), L.stream_ptr()),
                 "farthest_point_sample")
-    xyz_s = gather_rows(xyz, idx)
+        xyz_s = gather_rows(xyz, idx)
     ready = torch.cuda.Event()
     ready.record()  # xyz_s exists: three_nn may start on another stream while the sampled-set kNN runs here
     if npoint <= 2048:  # small sets: the brute-force kernel beats sort + pruned search (launch/latency bound)

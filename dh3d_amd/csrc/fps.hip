@@ -304,7 +304,8 @@ __global__ __launch_bounds__(64 * WAVES) void fps_sorted_kernel(const float4 *__
 template <int PPT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void fps_batched_kernel(const float4 *__restrict__ sorted,
                                                                const float *__restrict__ gbox, int N, int m,
-                                                               int32_t *__restrict__ out) {
+                                                               int32_t *__restrict__ out,
+                                                               float *__restrict__ xyz_out) {
   static_assert(PPT <= 64 && WAVES <= 16, "one lane per group box, one lane per candidate");
   constexpr int CAP0 = PPT <= 32 ? 64 / PPT : 1;
   constexpr int CAP = CAP0 < WAVES ? CAP0 : WAVES;  // picks per sync
@@ -529,15 +530,23 @@ __global__ __launch_bounds__(64 * WAVES) void fps_batched_kernel(const float4 *_
   }
   __syncthreads();
   for (int i = tid; i < m; i += 64 * WAVES) out[(size_t)b * m + i] = s_out[i];
+  if (xyz_out) {  // the sampled coordinates too (group_point of the xyz, core/tf_utils.py:92-95): they are in LDS
+    float *xo = xyz_out + (size_t)b * m * 3;
+    for (int e = tid; e < 3 * m; e += 64 * WAVES) {
+      const int i = e / 3, c = e - 3 * i, k = s_out[i];
+      xo[e] = c == 0 ? s_x[k] : c == 1 ? s_y[k] : s_z[k];
+    }
+  }
 }
 
 template <int PPT, int WAVES>
-int fps_batched_launch(const float *sorted, const float *gbox, int B, int N, int m, int32_t *out, hipStream_t s) {
+int fps_batched_launch(const float *sorted, const float *gbox, int B, int N, int m, int32_t *out, float *xyz_out,
+                       hipStream_t s) {
   const size_t lds = sizeof(float) * (8 * WAVES + 64 + 4 + (size_t)3 * N + m);
   if (lds > 159 * 1024) return DH3D_ERR_UNSUPPORTED;
   DH3D_ALLOW_BIG_LDS((fps_batched_kernel<PPT, WAVES>));
   hipLaunchKernelGGL((fps_batched_kernel<PPT, WAVES>), dim3(B), dim3(64 * WAVES), lds, s,
-                     reinterpret_cast<const float4 *>(sorted), gbox, N, m, out);
+                     reinterpret_cast<const float4 *>(sorted), gbox, N, m, out, xyz_out);
   return dh3d_launch_status();
 }
 
@@ -601,8 +610,8 @@ static int g_fps_sorted_mode = 0;  // 0 = batched rounds, 1 = one pick per round
 DH3D_API void dh3d_dev_set_fps_sorted_waves(int w) { g_fps_sorted_waves = w; }
 DH3D_API void dh3d_dev_set_fps_sorted_mode(int v) { g_fps_sorted_mode = v; }
 
-DH3D_API int dh3d_fps_sorted(const float *sorted, const float *gbox, int B, int N, int m, int32_t *out,
-                             void *stream) {
+static int fps_sorted_dispatch(const float *sorted, const float *gbox, int B, int N, int m, int32_t *out,
+                               float *xyz_out, void *stream) {
   DH3D_REQUIRE(sorted && gbox && out && B > 0 && N > 0 && m > 0);
   DH3D_SUPPORTED(N <= 12288);  // the by-original-index coordinate table must fit LDS (12 B / point)
   hipStream_t s = (hipStream_t)stream;
@@ -612,13 +621,13 @@ DH3D_API int dh3d_fps_sorted(const float *sorted, const float *gbox, int B, int 
   if (W == WV) {                                                                                      \
     const int gpw = (NG + WV - 1) / WV; /* groups per wave */                                         \
     if (g_fps_sorted_mode == 0) {                                                                     \
-      if (gpw <= 1) return fps_batched_launch<1, WV>(sorted, gbox, B, N, m, out, s);                  \
-      if (gpw <= 2) return fps_batched_launch<2, WV>(sorted, gbox, B, N, m, out, s);                  \
-      if (gpw <= 4) return fps_batched_launch<4, WV>(sorted, gbox, B, N, m, out, s);                  \
-      if (gpw <= 8) return fps_batched_launch<8, WV>(sorted, gbox, B, N, m, out, s);                  \
-      if (gpw <= 16) return fps_batched_launch<16, WV>(sorted, gbox, B, N, m, out, s);                \
-      if (gpw <= 32) return fps_batched_launch<32, WV>(sorted, gbox, B, N, m, out, s);                \
-      if (gpw <= 48) return fps_batched_launch<48, WV>(sorted, gbox, B, N, m, out, s);                \
+      if (gpw <= 1) return fps_batched_launch<1, WV>(sorted, gbox, B, N, m, out, xyz_out, s);         \
+      if (gpw <= 2) return fps_batched_launch<2, WV>(sorted, gbox, B, N, m, out, xyz_out, s);         \
+      if (gpw <= 4) return fps_batched_launch<4, WV>(sorted, gbox, B, N, m, out, xyz_out, s);         \
+      if (gpw <= 8) return fps_batched_launch<8, WV>(sorted, gbox, B, N, m, out, xyz_out, s);         \
+      if (gpw <= 16) return fps_batched_launch<16, WV>(sorted, gbox, B, N, m, out, xyz_out, s);       \
+      if (gpw <= 32) return fps_batched_launch<32, WV>(sorted, gbox, B, N, m, out, xyz_out, s);       \
+      if (gpw <= 48) return fps_batched_launch<48, WV>(sorted, gbox, B, N, m, out, xyz_out, s);       \
     }                                                                                                 \
     if (gpw <= 1) return fps_sorted_launch<1, WV>(sorted, gbox, B, N, m, out, s);                     \
     if (gpw <= 2) return fps_sorted_launch<2, WV>(sorted, gbox, B, N, m, out, s);                     \
@@ -628,11 +637,25 @@ DH3D_API int dh3d_fps_sorted(const float *sorted, const float *gbox, int B, int 
     if (gpw <= 32) return fps_sorted_launch<32, WV>(sorted, gbox, B, N, m, out, s);                   \
     if (gpw <= 48) return fps_sorted_launch<48, WV>(sorted, gbox, B, N, m, out, s);                   \
   }
+  if (xyz_out && g_fps_sorted_mode != 0) return DH3D_ERR_UNSUPPORTED;  // the one-pick-per-round kernel has no such output
   DH3D_FPS_CASE(4)
   DH3D_FPS_CASE(8)
   DH3D_FPS_CASE(16)
 #undef DH3D_FPS_CASE
   return DH3D_ERR_UNSUPPORTED;
+}
+
+DH3D_API int dh3d_fps_sorted(const float *sorted, const float *gbox, int B, int N, int m, int32_t *out,
+                             void *stream) {
+  return fps_sorted_dispatch(sorted, gbox, B, N, m, out, nullptr, stream);
+}
+
+// + xyz_out [B, m, 3]: the sampled coordinates (what group_point of the cloud by `out` returns), written by the same
+// kernel from its LDS copy of the cloud
+DH3D_API int dh3d_fps_sorted_xyz(const float *sorted, const float *gbox, int B, int N, int m, int32_t *out,
+                                 float *xyz_out, void *stream) {
+  DH3D_REQUIRE(xyz_out);
+  return fps_sorted_dispatch(sorted, gbox, B, N, m, out, xyz_out, stream);
 }
 
 #ifdef DH3D_FPS_PROBE

@@ -44,10 +44,16 @@ def knn_sorted(srt, gbox, k):
     return nn, dist
 
 
-def fps_sorted(srt, gbox, npoint):
-    """FPS from spatial_sort() output; same idx [B,npoint] (original indexing) as ops.farthest_point_sample."""
+def fps_sorted(srt, gbox, npoint, with_xyz=False):
+    """FPS from spatial_sort() output; same idx [B,npoint] (original indexing) as ops.farthest_point_sample.
+    with_xyz: also the sampled coordinates [B,npoint,3], written by the same kernel."""
     B, N, _ = srt.shape
     out = torch.empty((B, npoint), dtype=torch.int32, device=srt.device)
+    if with_xyz:
+        xyz_s = torch.empty((B, npoint, 3), dtype=torch.float32, device=srt.device)
+        L.check(L.lib().dh3d_fps_sorted_xyz(L.ptr(srt), L.ptr(gbox), B, N, npoint, L.ptr(out), L.ptr(xyz_s),
+                                            L.stream_ptr()), "fps_sorted_xyz")
+        return out, xyz_s
     L.check(L.lib().dh3d_fps_sorted(L.ptr(srt), L.ptr(gbox), B, N, npoint, L.ptr(out), L.stream_ptr()),
             "fps_sorted")
     return out

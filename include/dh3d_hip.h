@@ -162,6 +162,9 @@ int dh3d_knn_sorted(const float *sorted, const float *gbox, int B, int N, int K,
 /* FarthestPointSample on an ordered cloud: identical outputs to dh3d_farthest_point_sample (original
  * indices); per round only the 64-point groups the new sample can affect are re-evaluated.  N <= 12288. */
 int dh3d_fps_sorted(const float *sorted, const float *gbox, int B, int N, int m, int32_t *out, void *stream);
+/* the same + xyz_out [B,m,3] = the sampled coordinates (group_point of the cloud by `out`, core/tf_utils.py:92-95) */
+int dh3d_fps_sorted_xyz(const float *sorted, const float *gbox, int B, int N, int m, int32_t *out, float *xyz_out,
+                        void *stream);
 
 /* flex_conv forward (same function as dh3d_flex_conv_fwd, Dp = 3) in the factorised form
  *   out[n,:] = [S0 | Sx | Sy | Sz][n,:] @ [bias; theta_x; theta_y; theta_z],

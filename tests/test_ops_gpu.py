@@ -269,6 +269,9 @@ def test_fps_sorted_identical(dev, oracle, B, N, m):
     idx = pm.fps_sorted(srt, gbox, m)
     assert torch.equal(idx, ops.farthest_point_sample(m, t))
     assert np.array_equal(idx.cpu().numpy(), oracle.farthest_point_sample(m, xyz))
+    idx2, xyz_s = pm.fps_sorted(srt, gbox, m, with_xyz=True)  # + the sampled coordinates from the same kernel
+    assert torch.equal(idx2, idx)
+    assert np.array_equal(xyz_s.cpu().numpy(), np.take_along_axis(xyz, idx.cpu().numpy()[:, :, None].astype(np.int64), 1))
 
 
 def test_fps_sorted_batched_rounds_adversarial(dev, oracle):
