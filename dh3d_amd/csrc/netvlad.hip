@@ -160,20 +160,24 @@ __device__ __forceinline__ float block_sum(float v, float *s_red) {
   return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
-// grid (8, B), block 256: workgroup (cg, b) finishes clusters 8*cg .. 8*cg+7 of cloud b; thread t owns
-// feature d = t.  (One workgroup per cloud left 224 CUs idle behind a 143 us serial tail: profiles/r01_c.)
+// grid (8, B), block 1024: workgroup (cg, b) finishes clusters 8*cg .. 8*cg+7 of cloud b; thread (g, d) owns feature
+// d of clusters 8*cg + 2g, 2g+1.  (One workgroup per cloud left 224 CUs idle behind a 143 us serial tail:
+// profiles/r01_c; 256 threads with 8 clusters each was 64 dependent-ish loads per lane on 4 waves per CU: 25 us.)
 constexpr int kCG = 8;  // clusters per workgroup
-__global__ __launch_bounds__(256) void netvlad_finalize(const float *__restrict__ part_vlad,
-                                                       const float *__restrict__ part_asum,
-                                                       const float *__restrict__ W2 /*[D][Cl]*/,
-                                                       int chunks, float *__restrict__ vlad /*[B][D*Cl]*/,
-                                                       float *__restrict__ tot /*[B][Cl/kCG]*/) {
-  __shared__ float s_csq[4][kCG];
-  __shared__ float s_red[4];
-  const int b = blockIdx.y, c0 = blockIdx.x * kCG, d = threadIdx.x, lane = d & 63, wave = d >> 6;
-  float v[kCG];
+constexpr int kCT = 2;  // clusters per thread
+__global__ __launch_bounds__(1024) void netvlad_finalize(const float *__restrict__ part_vlad,
+                                                        const float *__restrict__ part_asum,
+                                                        const float *__restrict__ W2 /*[D][Cl]*/,
+                                                        int chunks, float *__restrict__ vlad /*[B][D*Cl]*/,
+                                                        float *__restrict__ tot /*[B][Cl/kCG]*/) {
+  __shared__ float s_csq[16][kCT];
+  __shared__ float s_red[16];
+  const int b = blockIdx.y, d = threadIdx.x & 255, g = threadIdx.x >> 8, lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;  // waves 4g .. 4g+3 share a cluster pair
+  const int c0 = blockIdx.x * kCG + g * kCT;
+  float v[kCT];
 #pragma unroll
-  for (int c = 0; c < kCG; ++c) {
+  for (int c = 0; c < kCT; ++c) {
     float s = 0.f, as = 0.f;
     for (int ch = 0; ch < chunks; ++ch) {  // fixed order: deterministic
       s += part_vlad[(((size_t)b * chunks + ch) * kCl + c0 + c) * kD + d];
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(256) void netvlad_finalize(const float *__restrict_
   }
   // intra-normalisation: per cluster over the 256 features (tf.nn.l2_normalize(vlad, 1))
 #pragma unroll
-  for (int c = 0; c < kCG; ++c) {
+  for (int c = 0; c < kCT; ++c) {
     float sq = v[c] * v[c];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
@@ -192,16 +196,23 @@ __global__ __launch_bounds__(256) void netvlad_finalize(const float *__restrict_
   __syncthreads();
   float t = 0.f;
 #pragma unroll
-  for (int c = 0; c < kCG; ++c) {
-    const float csq = (s_csq[0][c] + s_csq[1][c]) + (s_csq[2][c] + s_csq[3][c]);
+  for (int c = 0; c < kCT; ++c) {
+    const float csq = (s_csq[4 * g][c] + s_csq[4 * g + 1][c]) + (s_csq[4 * g + 2][c] + s_csq[4 * g + 3][c]);
     v[c] *= rsqrtf(fmaxf(csq, 1e-12f));
     t = fmaf(v[c], v[c], t);
   }
-  const float all = block_sum(t, s_red);
-  if (d == 0) tot[(size_t)b * (kCl / kCG) + blockIdx.x] = all;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+  if (lane == 0) s_red[wave] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float all = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) all += s_red[w];
+    tot[(size_t)b * (kCl / kCG) + blockIdx.x] = all;
+  }
   float *o = vlad + (size_t)b * kD * kCl + (size_t)d * kCl + c0;  // flatten d-major: index d*Cl + c
-  *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
-  *reinterpret_cast<float4 *>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  *reinterpret_cast<float2 *>(o) = make_float2(v[0], v[1]);
 }
 
 // whole-vector L2 normalisation (backbones.py:261): grid (8, B); scale = rsqrt(max(sum of the 8 partials, eps))
@@ -277,44 +288,62 @@ __global__ __launch_bounds__(256) void netvlad_hidden_splitk(const float *__rest
   }
 }
 
-// grid (B), block 256 (O == 256): reduce split-K, BN, gating, optional final l2-normalise.
-__global__ __launch_bounds__(256) void netvlad_gate(const float *__restrict__ part, int KS, int B, int O,
-                                                   const float *__restrict__ bn1_scale,
-                                                   const float *__restrict__ bn1_shift,
-                                                   const float *__restrict__ Wg,
-                                                   const float *__restrict__ bn2_scale,
-                                                   const float *__restrict__ bn2_shift, float l2_eps,
-                                                   float *__restrict__ out) {
+// grid (B), block 1024 (O == 256): reduce split-K, BN, gating, optional final l2-normalise.  Thread (q, o): quarter q
+// of the partial sums / of the gating GEMV for output o, combined through LDS in a fixed order (deterministic).  (256
+// threads walking all partials and all 256 weight rows one after the other: 27 us of load latency on 32 workgroups.)
+__global__ __launch_bounds__(1024) void netvlad_gate(const float *__restrict__ part, int KS, int B, int O,
+                                                    const float *__restrict__ bn1_scale,
+                                                    const float *__restrict__ bn1_shift,
+                                                    const float *__restrict__ Wg,
+                                                    const float *__restrict__ bn2_scale,
+                                                    const float *__restrict__ bn2_shift, float l2_eps,
+                                                    float *__restrict__ out) {
+  __shared__ float s_q[4][256];
   __shared__ float s_h[256];
   __shared__ float s_red[4];
-  const int b = blockIdx.x, o = threadIdx.x;
-  float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;  // fixed association: deterministic
-  int ks = 0;
-  for (; ks + 3 < KS; ks += 4) {
-    h0 += part[((size_t)ks * B + b) * O + o];
-    h1 += part[((size_t)(ks + 1) * B + b) * O + o];
-    h2 += part[((size_t)(ks + 2) * B + b) * O + o];
-    h3 += part[((size_t)(ks + 3) * B + b) * O + o];
+  const int b = blockIdx.x, o = threadIdx.x & 255, q = threadIdx.x >> 8;
+  {
+    const int per = (KS + 3) / 4, k0 = q * per, k1 = min(KS, k0 + per);
+    float h0 = 0.f, h1 = 0.f;
+    int ks = k0;
+    for (; ks + 1 < k1; ks += 2) {
+      h0 += part[((size_t)ks * B + b) * O + o];
+      h1 += part[((size_t)(ks + 1) * B + b) * O + o];
+    }
+    if (ks < k1) h0 += part[((size_t)ks * B + b) * O + o];
+    s_q[q][o] = h0 + h1;
   }
-  for (; ks < KS; ++ks) h0 += part[((size_t)ks * B + b) * O + o];
-  float h = (h0 + h1) + (h2 + h3);
-  h = fmaf(h, bn1_scale[o], bn1_shift[o]);
-  s_h[o] = h;
   __syncthreads();
-  float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
-  for (int j = 0; j < O; j += 4) {
-    g0 = fmaf(s_h[j], Wg[(size_t)j * O + o], g0);
-    g1 = fmaf(s_h[j + 1], Wg[(size_t)(j + 1) * O + o], g1);
-    g2 = fmaf(s_h[j + 2], Wg[(size_t)(j + 2) * O + o], g2);
-    g3 = fmaf(s_h[j + 3], Wg[(size_t)(j + 3) * O + o], g3);
+  float h = (s_q[0][o] + s_q[1][o]) + (s_q[2][o] + s_q[3][o]);
+  h = fmaf(h, bn1_scale[o], bn1_shift[o]);
+  if (q == 0) s_h[o] = h;
+  __syncthreads();
+  {
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+    const int j0 = q * (256 / 4);
+    for (int j = j0; j < j0 + 256 / 4; j += 4) {
+      g0 = fmaf(s_h[j], Wg[(size_t)j * O + o], g0);
+      g1 = fmaf(s_h[j + 1], Wg[(size_t)(j + 1) * O + o], g1);
+      g2 = fmaf(s_h[j + 2], Wg[(size_t)(j + 2) * O + o], g2);
+      g3 = fmaf(s_h[j + 3], Wg[(size_t)(j + 3) * O + o], g3);
+    }
+    __syncthreads();  // s_q is reused
+    s_q[q][o] = (g0 + g1) + (g2 + g3);
   }
-  float g = (g0 + g1) + (g2 + g3);
+  __syncthreads();
+  float g = (s_q[0][o] + s_q[1][o]) + (s_q[2][o] + s_q[3][o]);
   g = fmaf(g, bn2_scale[o], bn2_shift[o]);
-  float v = h * (1.f / (1.f + expf(-g)));
+  float v = h * (1.f / (1.f + expf(-g)));  // every quarter holds the same value
   if (l2_eps > 0.f) {
-    const float all = block_sum(v * v, s_red);
+    float sq = q == 0 ? v * v : 0.f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    if (q == 0 && (o & 63) == 0) s_red[o >> 6] = sq;
+    __syncthreads();
+    const float all = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
     v *= rsqrtf(fmaxf(all, l2_eps));
   }
+  if (q != 0) return;
   out[(size_t)b * O + o] = v;
 }
 
@@ -343,7 +372,7 @@ DH3D_API int dh3d_netvlad_aggregate_fwd(const float *x, const float *att, const 
   hipLaunchKernelGGL(kern, dim3(ch, B), dim3(256), lds, s, x, att, wc_packed, bn_scale, bn_shift, N, ch,
                      part_vlad, part_asum);
   float *tot = part_asum + (size_t)B * ch * kCl;
-  hipLaunchKernelGGL(netvlad_finalize, dim3(kCl / kCG, B), dim3(256), 0, s, part_vlad, part_asum, W2, ch, vlad, tot);
+  hipLaunchKernelGGL(netvlad_finalize, dim3(kCl / kCG, B), dim3(1024), 0, s, part_vlad, part_asum, W2, ch, vlad, tot);
   hipLaunchKernelGGL(netvlad_l2scale, dim3(kCl / kCG, B), dim3(256), 0, s, tot, vlad);
   return dh3d_launch_status();
 }
@@ -366,7 +395,7 @@ DH3D_API int dh3d_netvlad_head_fwd(const float *vlad, const float *Wh, const flo
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(netvlad_hidden_splitk, dim3(KS, dh3d_cdiv(B, 32), O / 64), dim3(256), 0, s, vlad, Wh, B, Kd, O,
                      part);
-  hipLaunchKernelGGL(netvlad_gate, dim3(B), dim3(256), 0, s, part, 2 * KS, B, O, bn1_scale, bn1_shift, Wg,
+  hipLaunchKernelGGL(netvlad_gate, dim3(B), dim3(1024), 0, s, part, 2 * KS, B, O, bn1_scale, bn1_shift, Wg,
                      bn2_scale, bn2_shift, l2_eps, out);
   return dh3d_launch_status();
 }
