@@ -264,21 +264,24 @@ __global__ __launch_bounds__(256) void netvlad_hidden_splitk(const float *__rest
   const float *aptr = s_v + (size_t)(lane & 31) * LD + kbeg + 4 * (lane >> 5);
   const float *wbase = Wh + (size_t)(k0 + kbeg + 4 * (lane >> 5)) * O + o0 + (lane & 31);
   const int nkb = klen / 8;
-  float w[4];
+  // the wave's whole weight panel (16 k-blocks x 4 rows) is requested before the first MFMA: the matrix mostly sits in
+  // the 256 MB cache between steps, so this kernel is a chain of load latencies, not of HBM bandwidth (one block of
+  // prefetch: 16 us; all in flight: see DESIGN.md)
+  constexpr int NKB = kKSlice / 2 / 8;
+  float w[NKB][4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) w[t] = nkb > 0 ? wbase[(size_t)t * O] : 0.f;
-  for (int kb = 0; kb < nkb; ++kb) {
-    const f32x4 a4 = *reinterpret_cast<const f32x4 *>(aptr + kb * 8);
-    float wn[4];
-    const int kn = kb + 1 < nkb ? kb + 1 : kb;  // unconditional prefetch (the last repeats)
+  for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) wn[t] = wbase[(size_t)(kn * 8 + t) * O];
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0], w[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1], w[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[2], w[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[3], w[3], acc, 0, 0, 0);
+    for (int t = 0; t < 4; ++t) w[kb][t] = kb < nkb ? wbase[(size_t)(kb * 8 + t) * O] : 0.f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) w[t] = wn[t];
+  for (int kb = 0; kb < NKB; ++kb) {
+    if (kb < nkb) {  // wave-uniform
+      const f32x4 a4 = *reinterpret_cast<const f32x4 *>(aptr + kb * 8);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0], w[kb][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1], w[kb][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[2], w[kb][2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[3], w[kb][3], acc, 0, 0, 0);
+    }
   }
   const int o = o0 + (lane & 31);
 #pragma unroll
