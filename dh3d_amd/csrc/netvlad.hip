@@ -51,19 +51,26 @@ __global__ __launch_bounds__(256) void netvlad_assign_accumulate(
   f32x16 vacc[4];
   zero_acc<4>(vacc);
 
+  // this thread's 64 floats of its row (4 threads per row), loaded one tile AHEAD: the next tile's HBM round trip
+  // (64 KB per workgroup, all 256 workgroups at once) hides behind the two GEMMs of the current one
+  const int sp = tid >> 2, sq = tid & 3;
+  float4 v[16];
+  auto load_tile = [&](int t) __attribute__((always_inline)) {
+    const int n = t * kTM + sp;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      v[i] = n < N ? *reinterpret_cast<const float4 *>(xb + (size_t)n * kD + (i * 4 + sq) * 4)
+                   : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  if (t_begin < t_end) load_tile(t_begin);
   for (int t = t_begin; t < t_end; ++t) {
     const int p0 = t * kTM;
     __syncthreads();  // previous tile's LDS fully consumed
-    // ---- stage + row l2-normalise: 4 threads per row, 64 floats each
+    // ---- row l2-normalise into LDS
     {
-      const int p = tid >> 2, q = tid & 3;
-      const int n = p0 + p;
-      float4 v[16];
       float ss = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        v[i] = n < N ? *reinterpret_cast<const float4 *>(xb + (size_t)n * kD + (i * 4 + q) * 4)
-                     : make_float4(0.f, 0.f, 0.f, 0.f);
         ss = fmaf(v[i].x, v[i].x, ss); ss = fmaf(v[i].y, v[i].y, ss);
         ss = fmaf(v[i].z, v[i].z, ss); ss = fmaf(v[i].w, v[i].w, ss);
       }
@@ -74,9 +81,11 @@ __global__ __launch_bounds__(256) void netvlad_assign_accumulate(
       for (int i = 0; i < 16; ++i) {
         float4 w = v[i];
         w.x *= inv; w.y *= inv; w.z *= inv; w.w *= inv;
-        *reinterpret_cast<float4 *>(s_x + (size_t)p * kLDX + (i * 4 + q) * 4) = w;
+        *reinterpret_cast<float4 *>(s_x + (size_t)sp * kLDX + (i * 4 + sq) * 4) = w;
       }
     }
+    if (t + 1 < t_end) load_tile(t + 1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the loads here, not at their first use
     __syncthreads();
     // ---- assignment logits = xn @ Wc : [64 x 256] x [256 x 64], one 32x32 tile per wave
     {
@@ -110,11 +119,17 @@ __global__ __launch_bounds__(256) void netvlad_assign_accumulate(
       for (int i = 0; i < 16; ++i) s_aT[(size_t)(i * 4 + q) * kLDA + p] = e[i] * w;
     }
     __syncthreads();
-    // ---- a_sum[c] += sum_p a[p,c]
-    if (tid < kCl) {
-      float s = 0.f;
-      for (int p = 0; p < kTM; ++p) s += s_aT[(size_t)tid * kLDA + p];
-      s_asum[tid] += s;
+    // ---- a_sum[c] += sum_p a[p,c]: 4 threads per cluster, 16 points each (one thread walking all 64 kept its wave
+    //      ~500 cycles behind the others at the next barrier)
+    {
+      const int c = tid >> 2, part = tid & 3;
+      const float4 *row = reinterpret_cast<const float4 *>(s_aT + (size_t)c * kLDA + part * 16);
+      const float4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
+      float s = ((r0.x + r0.y) + (r0.z + r0.w)) + ((r1.x + r1.y) + (r1.z + r1.w)) +
+                (((r2.x + r2.y) + (r2.z + r2.w)) + ((r3.x + r3.y) + (r3.z + r3.w)));
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      if (part == 0) s_asum[c] += s;
     }
     // ---- vladT[c,d] += sum_p aT[c,p] * xn[p,d]: A = aT (LDS, ld kLDA), B = xn read from LDS
     {
