@@ -97,16 +97,28 @@ class Conv2D1x1(nn.Module):
         return pm.linear(x, p["wp"], self.cout, x2=x2, pre_bias=p["b"], scale=p["scale"], shift=p["shift"],
                          act=act, residual=residual)
 
+    def fuse_shortcut(self, other):
+        """Let forward_upsampled(shortcut=x3) add act(BN_other(x3 W_other)) in the same kernel: the two weight matrices
+        are stacked into one packed operand (both convs must have this cout = 128 and 32-multiple inputs)."""
+        p, q = self._prep or self.prepare(), other._prep or other.prepare()
+        if self.cout == 128 and other.cout == 128 and "wp3" in p and other.cin % 32 == 0:
+            p["wp3_sc"] = pm.pack_weight_x3(torch.cat([p["W2"], q["W2"]], 0).contiguous())
+            p["sc_ep"] = (q["b"], q["scale"], q["shift"], pm.ACT_RELU)
+
     def upsampled_supported(self, coarse, idx, x2):
         """Can forward_upsampled serve this call?  (same batch-independent rule as forward's x6 choice)"""
         p = self._prep or self.prepare()
         return ("wp3" in p and idx.shape[1] >= 4096 and coarse.shape[-1] % 32 == 0
                 and (x2 is None or x2.shape[-1] % 32 == 0))
 
-    def forward_upsampled(self, coarse, idx, dist, x2=None, act=pm.ACT_RELU, residual=None, l2cat=None):
+    def forward_upsampled(self, coarse, idx, dist, x2=None, act=pm.ACT_RELU, residual=None, l2cat=None, shortcut=None):
         """forward([three_interpolate_idw(coarse, idx, dist) | x2]) with the up-sampling fused into the GEMM
-        (l2cat: and the l2-normalise + xyz concat of core/model.py:177-181 fused into its store)."""
+        (l2cat: and the l2-normalise + xyz concat of core/model.py:177-181 fused into its store; shortcut = x3:
+        + the conv given to fuse_shortcut applied to x3, instead of `residual`)."""
         p = self._prep or self.prepare()
+        if shortcut is not None:
+            return pm.upsample_linear_shortcut_x6(coarse, idx, dist, p["wp3_sc"], self.cout, x2, shortcut,
+                                                  (p["b"], p["scale"], p["shift"], act), p["sc_ep"], l2cat=l2cat)
         return pm.upsample_linear_x6(coarse, idx, dist, p["wp3"], self.cout, x2=x2, pre_bias=p["b"], scale=p["scale"],
                                      shift=p["shift"], act=act, residual=residual,
                                      l2cat=l2cat if self.cout == 128 else None)
@@ -300,7 +312,14 @@ class FlexConvDilate(nn.Module):
             self.concat_conv1d.tfconv0.prepare()
         return prep
 
-    def forward(self, geo, feat, nbr=None, residual=None, l2cat=None):
+    def shortcut_fusable(self, n_points):
+        """forward(shortcut_src=...) available: the concat conv takes the fused path at this cloud size and holds the
+        stacked weights (Conv2D1x1.fuse_shortcut)."""
+        conv = self.concat_conv1d.tfconv0 if self.concat else None
+        return (conv is not None and self.upsample and self.dilate > 1 and n_points >= 4096
+                and "wp3_sc" in (conv._prep or conv.prepare()))
+
+    def forward(self, geo, feat, nbr=None, residual=None, l2cat=None, shortcut_src=None):
         """geo: Geometry; feat [B,N,cin]; nbr [B,N,K] for dilate == 1 (else computed on the sampled set);
         residual [B,N,cout]: added to the concat conv's output in its store (the caller's shortcut branch);
         l2cat = (prefix [B,N,3], eps): return [prefix | l2_normalize(output)] instead of the output."""
@@ -325,7 +344,7 @@ class FlexConvDilate(nn.Module):
                 # up-sampling fused into the concat conv's operand staging: the [B,N,C] tensor is never written
                 fuse = l2cat if conv.cout == 128 else None
                 y = conv.forward_upsampled(x, lv["nn3_idx"], lv["nn3_dist"], x2=feat, act=pm.ACT_RELU,
-                                           residual=residual, l2cat=fuse)
+                                           residual=residual, l2cat=fuse, shortcut=shortcut_src)
                 return y if (l2cat is None or fuse is not None) else pm.l2norm_concat(y, l2cat[1], prefix=l2cat[0])
             x = pm.three_interpolate_idw(x, lv["nn3_idx"], lv["nn3_dist"])
         if self.concat:
@@ -363,6 +382,7 @@ class BackboneLocalDilate(nn.Module):
         self.before_stage2_conv1d.tfconv0.prepare()
         self.stage2.prepare()
         self.local_stage1_shortcut.tfconv0.prepare()
+        self.stage2.concat_conv1d.tfconv0.fuse_shortcut(self.local_stage1_shortcut.tfconv0)
         return self._prep
 
     def forward(self, geo):

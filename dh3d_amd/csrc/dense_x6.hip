@@ -253,12 +253,23 @@ struct L2CatOut {
   float eps;            // tf.nn.l2_normalize: y * rsqrt(max(sum(y^2), eps))
 };
 
-template <int NC>
+// Optional second 1x1 conv summed into the output: out = act(BN([x1|x2] W)) + act_sc(BN_sc(x3 W_sc)) -- the local
+// backbone's shortcut branch (core/backbones.py:123), whose [R,128] result would otherwise be written by one kernel and
+// read back by this one (134 MB at 131 k rows).  x3's K-chunks follow the main ones in the same pipeline (the packed
+// weight is the two matrices stacked) and feed a second accumulator set.
+struct ShortcutSrc {
+  const float *x3;  // [R, C3]   (null: none)
+  int C3;
+  EpilogueArgs ep;
+};
+
+template <int NC, bool SC>
 __global__ __launch_bounds__(512) void linear_x6_kernel(const float *__restrict__ x1, int C1,
                                                        const float *__restrict__ x2, int C2,
                                                        const uint4 *__restrict__ wp, EpilogueArgs ep,
                                                        const float *__restrict__ residual, long long R,
-                                                       float *__restrict__ out, UpsampleSrc up, L2CatOut l2) {
+                                                       float *__restrict__ out, UpsampleSrc up, L2CatOut l2,
+                                                       ShortcutSrc sc) {
   constexpr int TN = NC * 128;                      // columns of the tile = Dout
   constexpr int BST = (TN / 32) * 2 * 3 * 64;       // uint4 per B buffer
   constexpr int DMA = BST / 64 / 8;                 // LDS-DMA instructions per wave per chunk
@@ -271,7 +282,8 @@ __global__ __launch_bounds__(512) void linear_x6_kernel(const float *__restrict_
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const long long grow0 = (long long)blockIdx.x * HTM;
-  const int C = C1 + C2, KB = C / 16, NCH = C / HKC;
+  const int C3 = SC ? sc.C3 : 0;
+  const int C = C1 + C2 + C3, KB = C / 16, NCH = C / HKC, NCH_MAIN = (C1 + C2) / HKC;
   const int ar = tid >> 2, ah = tid & 3;
   long long arow = grow0 + ar;
   if (arow >= R) arow = R - 1;  // rows past R repeat the last row; they are not stored
@@ -295,7 +307,9 @@ __global__ __launch_bounds__(512) void linear_x6_kernel(const float *__restrict_
       pa[0] = idw_mix(a[0], b[0], c[0], w1, w2, w3);
       pa[1] = idw_mix(a[1], b[1], c[1], w1, w2, w3);
     } else {
-      const float *src = k0 < C1 ? x1 + arow * C1 + k0 : x2 + arow * C2 + (k0 - C1);
+      const float *src = k0 < C1 ? x1 + arow * C1 + k0
+                         : (!SC || k0 < C1 + C2) ? x2 + arow * C2 + (k0 - C1)
+                                                 : sc.x3 + arow * C3 + (k0 - C1 - C2);
       const float4 *ap = reinterpret_cast<const float4 *>(src);
       pa[0] = ap[0]; pa[1] = ap[1];
     }
@@ -327,19 +341,17 @@ __global__ __launch_bounds__(512) void linear_x6_kernel(const float *__restrict_
   dma_b(0, 0);
   stage_a(0);
   stage_sync();
-  f32x16 acc[2][NC];
+  f32x16 acc[2][NC], acc2[SC ? 2 : 1][SC ? NC : 1];
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
     for (int cb = 0; cb < NC; ++cb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
-  for (int ch = 0; ch < NCH; ++ch) {
-    const int nxt = ch + 1 < NCH ? ch + 1 : ch;  // unconditional prefetch: the last one is a harmless repeat
-    prefetch_a(nxt);
-    const int buf = ch & 1;
-    dma_b(nxt, buf ^ 1);
-    __builtin_amdgcn_sched_barrier(0);
+      for (int r = 0; r < 16; ++r) {
+        acc[rb][cb][r] = 0.f;
+        if (SC) acc2[rb][cb][r] = 0.f;
+      }
+  auto mfma_chunk = [&](int buf, f32x16 (&ac)[2][NC]) __attribute__((always_inline)) {
     const unsigned short *abase = s_A + (size_t)buf * A_STAGE + (size_t)(wr * 64 + (lane & 31)) * LDA + 8 * (lane >> 5);
     const uint4 *bbase = s_B + (size_t)buf * BST + (size_t)(wc * NC) * (2 * 3 * 64) + lane;
 #pragma unroll
@@ -356,10 +368,23 @@ __global__ __launch_bounds__(512) void linear_x6_kernel(const float *__restrict_
         for (int p = 0; p < 3; ++p) b[cb][p] = __builtin_bit_cast(bf16x8, bbase[((cb * 2 + ks) * 3 + p) * 64]);
 #define DH3D_X6_PRODUCT(PA, PB)                                                                          \
   _Pragma("unroll") for (int rb = 0; rb < 2; ++rb) _Pragma("unroll") for (int cb = 0; cb < NC; ++cb)     \
-      acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rb][PA], b[cb][PB], acc[rb][cb], 0, 0, 0);
+      ac[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rb][PA], b[cb][PB], ac[rb][cb], 0, 0, 0);
       DH3D_X6_PRODUCT(2, 0) DH3D_X6_PRODUCT(0, 2) DH3D_X6_PRODUCT(1, 1)
       DH3D_X6_PRODUCT(1, 0) DH3D_X6_PRODUCT(0, 1) DH3D_X6_PRODUCT(0, 0)
 #undef DH3D_X6_PRODUCT
+    }
+  };
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int nxt = ch + 1 < NCH ? ch + 1 : ch;  // unconditional prefetch: the last one is a harmless repeat
+    prefetch_a(nxt);
+    const int buf = ch & 1;
+    dma_b(nxt, buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SC) {
+      if (ch < NCH_MAIN) mfma_chunk(buf, acc);
+      else mfma_chunk(buf, acc2);
+    } else {
+      mfma_chunk(buf, acc);
     }
     stage_a(buf ^ 1);
     stage_sync();
@@ -368,16 +393,23 @@ __global__ __launch_bounds__(512) void linear_x6_kernel(const float *__restrict_
 #pragma unroll
   for (int cb = 0; cb < NC; ++cb) {
     const int col = (wc * NC + cb) * 32 + (lane & 31);
-    float pb = 0.f, sc = 1.f, sh = 0.f;
+    float pb = 0.f, scl = 1.f, sh = 0.f, pb2 = 0.f, scl2 = 1.f, sh2 = 0.f;
     if (ep.pre_bias) pb = ep.pre_bias[col];
-    if (ep.scale) sc = ep.scale[col];
+    if (ep.scale) scl = ep.scale[col];
     if (ep.shift) sh = ep.shift[col];
+    if (SC) {
+      if (sc.ep.pre_bias) pb2 = sc.ep.pre_bias[col];
+      if (sc.ep.scale) scl2 = sc.ep.scale[col];
+      if (sc.ep.shift) sh2 = sc.ep.shift[col];
+    }
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        s_out[(size_t)(wr * 64 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDO + col] =
-            dh3d_act((acc[rb][cb][r] + pb) * sc + sh, ep.act);
+      for (int r = 0; r < 16; ++r) {
+        float y = dh3d_act((acc[rb][cb][r] + pb) * scl + sh, ep.act);
+        if (SC) y += dh3d_act((acc2[rb][cb][r] + pb2) * scl2 + sh2, sc.ep.act);
+        s_out[(size_t)(wr * 64 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDO + col] = y;
+      }
   }
   __syncthreads();
   if (NC == 1 && l2.out) {
@@ -464,8 +496,9 @@ DH3D_API int dh3d_mlp_head_pm_x6_fwd(const float *h, int R, int C, const void *w
 
 static int linear_x6_launch(const float *x1, int C1, const float *x2, int C2, const void *wpacked_x3, int R, int Dout,
                             const dh3d_epilogue *ep, const float *residual, float *out, void *stream,
-                            const UpsampleSrc &up, const L2CatOut &l2 = L2CatOut{nullptr, nullptr, 0.f}) {
-  DH3D_SUPPORTED(C1 % HKC == 0 && C2 % HKC == 0 && (Dout == 128 || Dout == 256));
+                            const UpsampleSrc &up, const L2CatOut &l2 = L2CatOut{nullptr, nullptr, 0.f},
+                            const ShortcutSrc &sc = ShortcutSrc{nullptr, 0, EpilogueArgs{nullptr, nullptr, nullptr, 0}}) {
+  DH3D_SUPPORTED(C1 % HKC == 0 && C2 % HKC == 0 && sc.C3 % HKC == 0 && (Dout == 128 || Dout == 256));
   const EpilogueArgs e = dh3d_ep(ep);
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(dh3d_cdiv(R, HTM)), block(512);
@@ -474,17 +507,23 @@ static int linear_x6_launch(const float *x1, int C1, const float *x2, int C2, co
     size_t lds = (size_t)2 * A_STAGE * 2 + (size_t)2 * (128 / 32) * 2 * 3 * 64 * 16;
     const size_t tile = sizeof(float) * HTM * (128 + 4) + sizeof(float) * HTM;  // + row norms (L2CatOut)
     if (tile > lds) lds = tile;
-    auto kern = linear_x6_kernel<1>;
-    DH3D_ALLOW_BIG_LDS(kern);
-    hipLaunchKernelGGL(kern, grid, block, lds, s, x1, C1, x2, C2, wp, e, residual, (long long)R, out, up, l2);
+    if (sc.x3) {
+      auto kern = linear_x6_kernel<1, true>;
+      DH3D_ALLOW_BIG_LDS(kern);
+      hipLaunchKernelGGL(kern, grid, block, lds, s, x1, C1, x2, C2, wp, e, residual, (long long)R, out, up, l2, sc);
+    } else {
+      auto kern = linear_x6_kernel<1, false>;
+      DH3D_ALLOW_BIG_LDS(kern);
+      hipLaunchKernelGGL(kern, grid, block, lds, s, x1, C1, x2, C2, wp, e, residual, (long long)R, out, up, l2, sc);
+    }
   } else {
     size_t lds = (size_t)2 * A_STAGE * 2 + (size_t)2 * (256 / 32) * 2 * 3 * 64 * 16;
     const size_t tile = sizeof(float) * HTM * (256 + 4);
     if (tile > lds) lds = tile;
-    if (l2.out) return DH3D_ERR_UNSUPPORTED;
-    auto kern = linear_x6_kernel<2>;
+    if (l2.out || sc.x3) return DH3D_ERR_UNSUPPORTED;
+    auto kern = linear_x6_kernel<2, false>;
     DH3D_ALLOW_BIG_LDS(kern);
-    hipLaunchKernelGGL(kern, grid, block, lds, s, x1, C1, x2, C2, wp, e, residual, (long long)R, out, up, l2);
+    hipLaunchKernelGGL(kern, grid, block, lds, s, x1, C1, x2, C2, wp, e, residual, (long long)R, out, up, l2, sc);
   }
   return dh3d_launch_status();
 }
@@ -521,4 +560,23 @@ DH3D_API int dh3d_upsample_linear_l2cat_pm_x6_fwd(const float *points, const int
   const UpsampleSrc up{points, idx, dist, n, m};
   const L2CatOut l2{out_cat, prefix, l2_eps};
   return linear_x6_launch(points, C1, x2, C2, wpacked_x3, B * n, Dout, ep, residual, out_cat, stream, up, l2);
+}
+
+// out = act(BN([upsample(points) | x2] W)) + act_sc(BN_sc(x3 W_sc)): the up-sampling concat conv with the backbone's
+// shortcut conv (core/backbones.py:123) computed in the same kernel instead of written and read back.  wpacked_x3 =
+// dh3d_pack_weight_x3 of [W; W_sc] stacked ([C1 + C2 + C3, Dout]), Dout == 128.  prefix != NULL: `out` is
+// [B*n, 3 + 128] = [prefix | l2_normalize(sum, l2_eps)] as in dh3d_upsample_linear_l2cat_pm_x6_fwd.
+DH3D_API int dh3d_upsample_linear_shortcut_pm_x6_fwd(const float *points, const int32_t *idx, const float *dist, int B,
+                                                     int n, int m, int C1, const float *x2, int C2, const float *x3,
+                                                     int C3, const void *wpacked_x3, int Dout,
+                                                     const dh3d_epilogue *ep, const dh3d_epilogue *ep_shortcut,
+                                                     const float *prefix, float l2_eps, float *out, void *stream) {
+  DH3D_REQUIRE(points && idx && dist && wpacked_x3 && out && x3 && B > 0 && n > 0 && m > 0 && C1 > 0 && C2 >= 0 &&
+               C3 > 0 && (C2 == 0 || x2));
+  DH3D_SUPPORTED(Dout == 128);
+  DH3D_REQUIRE((long long)B * n < (1LL << 31));
+  const UpsampleSrc up{points, idx, dist, n, m};
+  const L2CatOut l2{prefix ? out : nullptr, prefix, l2_eps};
+  const ShortcutSrc sc{x3, C3, dh3d_ep(ep_shortcut)};
+  return linear_x6_launch(points, C1, x2, C2, wpacked_x3, B * n, Dout, ep, nullptr, out, stream, up, l2, sc);
 }

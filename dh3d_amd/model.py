@@ -147,8 +147,7 @@ class DH3D(nn.Module):
         # batch -- big batches of small clouds (cfg 3) leave this stream waiting for stage 1, and three_nn beside
         # the N/8 convolutions would slow those down (42 vs 17 us for 64->128 at 32x512); a few big clouds (cfg 2)
         # are the other way round and it runs on the side stream after stage 1 (compute_local).
-        B_, N_ = points.shape[0], points.shape[1]
-        if 80.0 + 2.5e-3 * B_ * N_ - 0.05 * N_ > 60.0:
+        if self._side_is_critical(points):
             bb.finish_level(points, geo._lv, same_stream=True)
         side.wait_event(fork)
         with torch.cuda.stream(side):
@@ -159,6 +158,13 @@ class DH3D(nn.Module):
                 geo.nbr, _ = pm.knn_sorted(srt, gbox, self.knn_num)  # core/model.py:157
             geo.nbr.record_stream(main)
         return geo
+
+    @staticmethod
+    def _side_is_critical(points):
+        """Which of the step's two chains ends last (measured model, MI355X): the FPS chain costs ~0.05 us per point of
+        a cloud whatever the batch, kNN(N) + stage 1 on the side stream ~2.5 us per 1000 points of the batch."""
+        B, N = points.shape[0], points.shape[1]
+        return 80.0 + 2.5e-3 * B * N - 0.05 * N > 60.0
 
     def _join_side(self, geo):
         """Everything enqueued on the side stream so far is visible to the current stream."""
@@ -180,17 +186,26 @@ class DH3D(nn.Module):
             init = pm.flex_pool(init, nn_8)
             x1 = self.stage1(geo, init, nbr=nn_8)
             x2 = self.before_stage2_conv1d(x1, act=pm.ACT_RELU)
-            # BNReLU(conv(x1)) + stage2 (backbones.py:123): the shortcut needs stage-1 features only, so it runs
-            # here and its sum is folded into stage 2's last store
-            shortcut = self.local_stage1_shortcut(x1, act=pm.ACT_RELU)
+            # BNReLU(conv(x1)) + stage2 (backbones.py:123).  Large clouds: the shortcut conv runs INSIDE stage 2's last
+            # conv (its input x1 is just more K for that GEMM, with its own accumulators and epilogue), so its
+            # [Bt,N,128] result is never written or read back.  Otherwise it runs here, beside the FPS chain, and its
+            # sum is folded into stage 2's last store.
+            # (only for clouds of <= 4096 points, where this stream tends to be the step's critical chain: beside a
+            #  longer FPS chain the separate conv is free and the fusion just adds K to the critical tail -- same-box
+            #  A/B: cfg 3 -23 us, cfg 2 +6 us.  The rule looks at the points per cloud only, never at the batch: the
+            #  two forms differ in the rounding of the final sum and a sharded batch must reproduce the unsharded
+            #  result bit for bit.)
+            fuse_sc = points.shape[1] <= 4096 and self.stage2.shortcut_fusable(points.shape[1])
+            shortcut = None if fuse_sc else self.local_stage1_shortcut(x1, act=pm.ACT_RELU)
             stage1_done = torch.cuda.Event()
             stage1_done.record()
             geo.start_nn3(geo._lv)  # three_nn: waits for the sampled coordinates, overlaps the N/8 convolutions
-            for t in (x2, shortcut, geo._lv["nn3_dist"], geo._lv["nn3_idx"]):
+            for t in (x2, x1 if fuse_sc else shortcut, geo._lv["nn3_dist"], geo._lv["nn3_idx"]):
                 t.record_stream(main)
         main.wait_event(stage1_done)  # not the whole side stream: three_nn is joined at the interpolation (geo.finish)
         l2cat = (points, _l2cat_eps) if _l2cat_eps is not None else None
-        feat = self.stage2(geo, x2, residual=shortcut, l2cat=l2cat)  # gather, N/8 convs, SE, interpolation, concat conv
+        feat = self.stage2(geo, x2, residual=shortcut, l2cat=l2cat,  # gather, N/8 convs, SE, interpolation, concat conv
+                           shortcut_src=x1 if fuse_sc else None)
         self._last_geo = geo
         return points, feat
 

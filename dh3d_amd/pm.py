@@ -311,6 +311,34 @@ def upsample_linear_x6(points, idx, dist, wpacked_x3, Dout, x2=None, pre_bias=No
     return out
 
 
+def upsample_linear_shortcut_x6(points, idx, dist, wstacked_x3, Dout, x2, x3, ep_main, ep_shortcut, l2cat=None):
+    """act(BN([three_interpolate_idw(points, idx, dist) | x2] W)) + act_sc(BN_sc(x3 W_sc)) in one kernel (Dout == 128);
+    wstacked_x3 = pack_weight_x3([W; W_sc]); ep_* = (pre_bias, scale, shift, act).  l2cat as in upsample_linear_x6."""
+    p = L.require_cuda_f32(points, "points", 3)
+    ix = L.require_cuda_i32(idx, "idx", 3)
+    d = L.require_cuda_f32(dist, "dist", 3)
+    B, m, C1 = p.shape
+    n = ix.shape[1]
+    b = L.require_cuda_f32(x2, "x2", 3)
+    c = L.require_cuda_f32(x3, "x3", 3)
+    if tuple(b.shape[:2]) != (B, n) or tuple(c.shape[:2]) != (B, n):
+        raise ValueError("upsample_linear_shortcut_x6: x2 / x3 must be [B,n,*]")
+    pf = None
+    width = Dout
+    if l2cat is not None:
+        pf = L.require_cuda_f32(l2cat[0], "prefix", 3)
+        if tuple(pf.shape) != (B, n, 3):
+            raise ValueError("upsample_linear_shortcut_x6: prefix must be [B,n,3]")
+        width = 3 + Dout
+    out = torch.empty((B, n, width), dtype=torch.float32, device=p.device)
+    e1, e2 = _ep(*ep_main), _ep(*ep_shortcut)
+    L.check(L.lib().dh3d_upsample_linear_shortcut_pm_x6_fwd(
+        L.ptr(p), L.ptr(ix), L.ptr(d), B, n, m, C1, L.ptr(b), b.shape[-1], L.ptr(c), c.shape[-1], L.ptr(wstacked_x3),
+        Dout, e1, e2, L.ptr(pf), float(l2cat[1]) if l2cat is not None else 0.0, L.ptr(out), L.stream_ptr()),
+        "upsample_linear_shortcut_pm_x6")
+    return out
+
+
 def pack_weight_x3(W):
     """W [Kd, Dout] f32 -> three exact bf16 chunk planes in MFMA fragment order (csrc/dense_x6.hip)."""
     W = L.require_cuda_f32(W, "W", 2)

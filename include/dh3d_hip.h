@@ -250,6 +250,14 @@ int dh3d_upsample_linear_l2cat_pm_x6_fwd(const float *points, const int32_t *idx
                                          int m, int C1, const float *x2, int C2, const void *wpacked_x3, int Dout,
                                          const dh3d_epilogue *ep, const float *residual, const float *prefix,
                                          float l2_eps, float *out_cat, void *stream);
+/* out = act(BN([upsample(points) | x2] W)) + act_sc(BN_sc(x3 W_sc)): the concat conv with the local backbone's shortcut
+ * conv (core/backbones.py:123) in one kernel; wpacked_x3 = dh3d_pack_weight_x3 of [W; W_sc] ([C1+C2+C3, Dout]),
+ * Dout == 128; prefix != NULL: out is [B*n, 3+128] = [prefix | l2_normalize(sum, l2_eps)] */
+int dh3d_upsample_linear_shortcut_pm_x6_fwd(const float *points, const int32_t *idx, const float *dist, int B, int n,
+                                            int m, int C1, const float *x2, int C2, const float *x3, int C3,
+                                            const void *wpacked_x3, int Dout, const dh3d_epilogue *ep,
+                                            const dh3d_epilogue *ep_shortcut, const float *prefix, float l2_eps,
+                                            float *out, void *stream);
 
 /* The same head with the GEMM on the bf16 matrix pipe at f32 accuracy ("bf16x6": every f32 operand is split
  * exactly into three bf16 chunks, six chunk products are accumulated in f32; error <= 2^-23 per product, see

@@ -318,3 +318,34 @@ def test_mlp_head_bf16x6_is_f32_accurate(dev):
     z6 = np.log(lin6 / (1 - lin6))  # undo the sigmoid
     ok = np.abs(s) < 10
     assert np.all(np.abs(z6[ok] - s[ok]) <= 5e-7 * mag[ok] + 1e-5)
+
+
+@pytest.mark.parametrize("B,n,l2", [(2, 4096, False), (1, 4100, True), (3, 4160, True)])
+def test_upsample_linear_shortcut_fused_matches_two_kernels(dev, B, n, l2):
+    """Concat conv + shortcut conv in one kernel == shortcut conv, then concat conv with the residual added in its
+    store (same bf16x6 products, same epilogue arithmetic: equal to rounding of the final sum), with and without
+    the fused l2-normalise + xyz concat."""
+    from dh3d_amd import pm, ops
+    g = torch.Generator().manual_seed(n)
+    m, C1, C2, C3, Dout = n // 8, 128, 64, 64, 128
+    fine = torch.rand(B, n, 3, generator=g).to(dev)
+    coarse_xyz = fine[:, :m].contiguous()
+    d3, i3 = ops.three_nn(fine, coarse_xyz)
+    pts = torch.randn(B, m, C1, generator=g).to(dev)
+    x2 = torch.randn(B, n, C2, generator=g).to(dev)
+    x3 = torch.randn(B, n, C3, generator=g).to(dev)
+    W = (torch.randn(C1 + C2, Dout, generator=g) / (C1 + C2) ** 0.5).to(dev)
+    Ws = (torch.randn(C3, Dout, generator=g) / C3 ** 0.5).to(dev)
+    mk = lambda: [torch.randn(Dout, generator=g).to(dev), (0.5 + torch.rand(Dout, generator=g)).to(dev),
+                  torch.randn(Dout, generator=g).to(dev)]
+    e1, e2 = mk(), mk()
+    sc = pm.linear_x6(x3, pm.pack_weight_x3(Ws), Dout, pre_bias=e2[0], scale=e2[1], shift=e2[2], act=pm.ACT_RELU)
+    l2cat = (fine, 1e-8) if l2 else None
+    ref = pm.upsample_linear_x6(pts, i3, d3, pm.pack_weight_x3(W), Dout, x2=x2, pre_bias=e1[0], scale=e1[1],
+                                shift=e1[2], act=pm.ACT_RELU, residual=sc, l2cat=l2cat)
+    got = pm.upsample_linear_shortcut_x6(pts, i3, d3, pm.pack_weight_x3(torch.cat([W, Ws], 0).contiguous()), Dout, x2,
+                                         x3, (e1[0], e1[1], e1[2], pm.ACT_RELU), (e2[0], e2[1], e2[2], pm.ACT_RELU),
+                                         l2cat=l2cat)
+    assert got.shape == ref.shape
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 1e-6, err
