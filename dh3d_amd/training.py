@@ -84,6 +84,48 @@ def _bn(x, channel_dim, bnmod, training, sync_bn, mask):
         bnmod.beta.reshape(shape)
 
 
+class _FlexConvFactorised(torch.autograd.Function):
+    """flex_conv for the training step, point-major, in its factorised form
+        out = [S0 | Sx | Sy | Sz] @ [bias; theta_x; theta_y; theta_z],  S0 = sum_k f[n_k],  Sd = sum_k dp_d(k) f[n_k]
+    (the form the fused inference kernel runs; the drop-in op `ops.flex_convolution` keeps the reference's
+    9*K*Din*Dout-flop formulation and its atomics backward: 21 of the 32 ms of a 22-cloud step).  Forward = the fused
+    HIP kernel; backward = the same factorisation differentiated: dW = S^T dOut, dS = dOut W^T, and dS scattered back
+    over the neighbour lists.  Gradients w.r.t. features, theta and bias (positions are data).  Centre = the point
+    itself (the GPU forward's rule, flex_conv_kernel_gpu.cu.cc:77-79; identical to the backward's rank-0-neighbour
+    rule under exact kNN)."""
+
+    @staticmethod
+    def forward(ctx, feat, xyz, nbr, theta, bias):
+        from . import pm
+        out = pm.flex_conv(feat, xyz, nbr, pm.pack_flex_weight(theta.detach(), bias.detach()), theta.shape[2])
+        ctx.save_for_backward(feat, xyz, nbr, theta, bias)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        feat, xyz, nbr, theta, bias = ctx.saved_tensors
+        B, M, Din = feat.shape
+        K, Dout = nbr.shape[2], theta.shape[2]
+        R = B * M
+        flat = (nbr.long() + (torch.arange(B, device=nbr.device) * M).view(B, 1, 1)).reshape(R, K)
+        f2, p2 = feat.reshape(R, Din), xyz.reshape(R, 3)
+        fn = f2[flat]                                        # [R,K,Din]
+        dp = p2[flat] - p2[:, None, :]                       # [R,K,3]
+        S = torch.cat([fn.sum(1, keepdim=True), torch.einsum("rkd,rkc->rdc", dp, fn)], 1)   # [R,4,Din]
+        g = dout.reshape(R, Dout)
+        dW = S.reshape(R, 4 * Din).t() @ g                   # [4*Din, Dout]
+        W = torch.cat([bias[None], theta], 0).reshape(4 * Din, Dout)
+        dS = (g @ W.t()).reshape(R, 4, Din)
+        dfn = dS[:, 0:1] + torch.einsum("rkd,rdc->rkc", dp, dS[:, 1:])                      # [R,K,Din]
+        dfeat = torch.zeros_like(f2).index_add_(0, flat.reshape(-1), dfn.reshape(-1, Din))
+        return dfeat.reshape(B, M, Din), None, None, dW[Din:].reshape(3, Din, Dout), dW[:Din]
+
+
+def flex_conv_factorised(feat, xyz, nbr, theta, bias):
+    """feat [B,M,Din], xyz [B,M,3], nbr [B,M,K] int32, theta [3,Din,Dout], bias [Din,Dout] -> [B,M,Dout]."""
+    return _FlexConvFactorised.apply(feat.contiguous(), xyz.contiguous(), nbr.contiguous(), theta, bias)
+
+
 def global_head_autograd(model, points, localdesc, lv, bn_training=True, sync_bn=False, mask=None):
     """Differentiable restatement of compute_global (core/model.py:112-133) on the parameters of `model`.
 
@@ -92,12 +134,9 @@ def global_head_autograd(model, points, localdesc, lv, bn_training=True, sync_bn
     gba = model.global_before_assemble
     fc, fbn = gba.flexconv_0, gba.flexconv_0_bn
     feat_s = bb.gather_rows(localdesc, lv["idx"])                                   # [Bt,M,128]
-    feats_T = feat_s.transpose(1, 2).contiguous()                                   # [Bt,128,M]
-    pts_T = lv["xyz_s"].transpose(1, 2).contiguous()                                # [Bt,3,M]
-    nbr_T = lv["nbr_s"].transpose(1, 2).contiguous()                                # [Bt,K,M]
-    x = ops.flex_convolution(feats_T, pts_T, nbr_T, fc.position_theta, fc.position_bias) + fc.feature_bias
-    x = F.relu(_bn(x, 1, fbn, bn_training, sync_bn, mask))                          # tf_utils.py:60-63 (NCHW)
-    new_feat = x.transpose(1, 2).contiguous()                                       # [Bt,M,256]
+    x = flex_conv_factorised(feat_s, lv["xyz_s"], lv["nbr_s"], fc.position_theta, fc.position_bias)
+    x = x + fc.feature_bias.reshape(1, 1, -1)                                       # layers.py:330-331
+    new_feat = F.relu(_bn(x, 2, fbn, bn_training, sync_bn, mask)).contiguous()      # tf_utils.py:60-63; [Bt,M,256]
     d = torch.clamp(lv["nn3_dist"], min=1e-10)                                      # backbones.py:92-95
     w = (1.0 / d) / (1.0 / d).sum(2, keepdim=True)
     forglobal = ops.three_interpolate(new_feat, lv["nn3_idx"], w.contiguous())      # [Bt,N,256]

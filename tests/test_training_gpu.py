@@ -128,3 +128,27 @@ def test_training_steps_reduce_the_loss(dev):
     with torch.no_grad():
         out = m(pts)["globaldesc"]
     assert torch.isfinite(out).all()
+
+
+def test_factorised_flex_conv_grads_match_the_drop_in_op(dev):
+    """Training-path flex_conv (fused forward + factorised backward) against ops.flex_convolution (reference
+    formulation, atomics backward): same outputs and the same gradients for features, theta, bias."""
+    from dh3d_amd import ops, pm
+    from dh3d_amd.training import flex_conv_factorised
+    g = torch.Generator().manual_seed(21)
+    B, M, K, Din, Dout = 3, 300, 8, 64, 128
+    xyz = torch.rand(B, M, 3, generator=g).to(dev)
+    nbr, _ = pm.knn_xyz(xyz, K)
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev).requires_grad_(True)
+    f1, t1, b1 = mk(B, M, Din), mk(3, Din, Dout, sc=Din ** -0.5), mk(Din, Dout, sc=(8 * Din) ** -0.5)
+    f2, t2, b2 = [v.detach().clone().requires_grad_(True) for v in (f1, t1, b1)]
+    wgt = torch.randn(B, M, Dout, generator=g).to(dev)
+    y1 = flex_conv_factorised(f1, xyz, nbr, t1, b1)
+    y2 = ops.flex_convolution(f2.transpose(1, 2).contiguous(), xyz.transpose(1, 2).contiguous(),
+                              nbr.transpose(1, 2).contiguous(), t2, b2).transpose(1, 2)
+    assert (y1 - y2).abs().max().item() < 1e-5 * y2.abs().max().item()
+    (y1 * wgt).sum().backward()
+    (y2 * wgt).sum().backward()
+    for a, b, name in ((f1.grad, f2.grad, "features"), (t1.grad, t2.grad, "theta"), (b1.grad, b2.grad, "bias")):
+        err = (a - b).abs().max().item() / b.abs().max().item()
+        assert err < 2e-5, (name, err)
