@@ -338,6 +338,7 @@ class FlexConvDilate(nn.Module):
         if self.add_se == "max_pool":
             x = self.se(x, pm.flex_pool(x, nbr_s))
         if self.upsample and self.dilate > 1:
+            self._last_coarse = (x, lv)  # the level's features before up-sampling (PointMLPHead.forward_interpolated)
             geo.finish(lv)
             conv = self.concat_conv1d.tfconv0 if self.concat else None
             if conv is not None and conv.upsampled_supported(x, lv["nn3_idx"], feat):
@@ -421,8 +422,27 @@ class PointMLPHead(nn.Module):
                       "b_fc": float(self.detec_conv_fc.b.detach().reshape(-1)[0].item()), "wp3": None}
         last = getattr(self, "detec_conv%d" % (len(self.conv_dims) - 1))
         if last.cin % 32 == 0 and last.cout % 256 == 0:  # wide last layer: tiled bf16x6 GEMM (csrc/dense_x6.hip)
-            self._prep["wp3"] = pm.pack_weight_x3(last.W.detach().reshape(last.cin, last.cout).contiguous())
+            W2 = last.W.detach().reshape(last.cin, last.cout)
+            self._prep["wp3"] = pm.pack_weight_x3(W2.contiguous())
+            if len(self.conv_dims) == 1 and last.cout <= 1024:  # single wide layer: can be commuted through an up-sampling
+                self._prep["wslices"] = torch.cat([pm.pack_weight_x3(W2[:, j:j + 256].contiguous())
+                                                   for j in range(0, last.cout, 256)])
         return self._prep
+
+    def interpolated_supported(self, coarse, idx):
+        """forward_interpolated available (same batch-independent kind of rule as the convs': cloud size only)."""
+        p = self._prep or self.prepare()
+        return "wslices" in p and coarse.shape[-1] % 32 == 0 and idx.shape[1] >= 4096
+
+    def forward_interpolated(self, coarse, idx, dist):
+        """forward(three_interpolate_idw(coarse, idx, dist)) without running the wide conv on the up-sampled rows: the
+        conv is linear and the interpolation weights sum to one, so it is applied to the coarse rows and its output
+        interpolated (csrc/dense_x6.hip interp_head_kernel)."""
+        p = self._prep or self.prepare()
+        last = getattr(self, "detec_conv0")
+        lp = last._prep
+        return pm.interp_head(coarse, idx, dist, p["wslices"], last.cout, p["w_fc"], p["b_fc"], pre_bias=lp["b"],
+                              scale=lp["scale"], shift=lp["shift"], act=pm.ACT_RELU)
 
     def forward(self, x):
         p = self._prep or self.prepare()

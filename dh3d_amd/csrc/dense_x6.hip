@@ -269,7 +269,10 @@ __global__ __launch_bounds__(512) void linear_x6_kernel(const float *__restrict_
                                                        const uint4 *__restrict__ wp, EpilogueArgs ep,
                                                        const float *__restrict__ residual, long long R,
                                                        float *__restrict__ out, UpsampleSrc up, L2CatOut l2,
-                                                       ShortcutSrc sc) {
+                                                       ShortcutSrc sc, long long wslice, long long oslice) {
+  // blockIdx.y = column slice of a wider layer: its own packed weight and output plane (dh3d_linear_slices_pm_x6_fwd)
+  wp += (size_t)blockIdx.y * wslice;
+  out += (size_t)blockIdx.y * oslice;
   constexpr int TN = NC * 128;                      // columns of the tile = Dout
   constexpr int BST = (TN / 32) * 2 * 3 * 64;       // uint4 per B buffer
   constexpr int DMA = BST / 64 / 8;                 // LDS-DMA instructions per wave per chunk
@@ -460,6 +463,88 @@ __global__ __launch_bounds__(512) void linear_x6_kernel(const float *__restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The attention head on an UP-SAMPLED input, with the wide 1x1 conv commuted through the interpolation.
+// globalatt_block (core/backbones.py:156-173) is  sigmoid(w_fc . relu(BN(W x + b)) + b_fc)  on x = the 3-NN inverse-
+// distance interpolation of the N/8-level features (backbones.py:91-95).  Interpolation and conv are both linear and
+// the weights sum to one, so  W interp(x) + b = interp(W x) + b:  the 256 -> 1024 GEMM -- the largest dense op of the
+// global path -- runs on the m = n/8 coarse rows (8x fewer flops; linear_x6 slices H[j] = x W[:, 256 j : 256 j + 256])
+// and this kernel interpolates the 1024-wide rows instead: a wave per fine point, lane l = channels 4 l .. 4 l + 3 of
+// each 256-slice, three gathered rows (12 KB per point from L2 -- a cloud's H is 2 MB), bias + BN + ReLU + the dot with
+// w_fc in registers, one wave reduction.  Same value up to the rounding of a different association.
+__global__ __launch_bounds__(256) void interp_head_kernel(const float *__restrict__ H, int NS, long long Rc,
+                                                         const int32_t *__restrict__ idx,
+                                                         const float *__restrict__ dist, int n, int m, EpilogueArgs ep,
+                                                         const float *__restrict__ w_fc, float b_fc, long long R,
+                                                         float *__restrict__ att) {
+  constexpr int MAXS = 4;  // 256-channel slices (hidden width <= 1024)
+  const int lane = threadIdx.x & 63;
+  const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long long)gridDim.x * 4;
+  // this lane's channels: slice j, columns 4*lane .. 4*lane+3
+  float4 pb[MAXS], sc[MAXS], sh[MAXS], wf[MAXS];
+#pragma unroll
+  for (int j = 0; j < MAXS; ++j) {
+    const int c = j * 256 + lane * 4;
+    pb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    sc[j] = make_float4(1.f, 1.f, 1.f, 1.f);
+    sh[j] = pb[j];
+    wf[j] = pb[j];
+    if (j < NS) {
+      if (ep.pre_bias) pb[j] = *reinterpret_cast<const float4 *>(ep.pre_bias + c);
+      if (ep.scale) sc[j] = *reinterpret_cast<const float4 *>(ep.scale + c);
+      if (ep.shift) sh[j] = *reinterpret_cast<const float4 *>(ep.shift + c);
+      wf[j] = *reinterpret_cast<const float4 *>(w_fc + c);
+    }
+  }
+  // Workgroups are dispatched round-robin over the 8 XCDs, each with its own 4 MB L2, and a cloud's H is 2 MB: XCD x
+  // takes clouds x, x + 8, ... one after the other, all its waves on the same cloud at a time (with waves simply walking
+  // the rows in order, every L2 saw eight clouds at once and the gathers went to the far cache: 176 us).
+  const int xcd = blockIdx.x & 7;
+  const long long wx = (long long)(blockIdx.x >> 3) * 4 + (threadIdx.x >> 6), nwx = (long long)(gridDim.x >> 3) * 4;
+  const int B = (int)(R / n);
+  const int per = (int)((n + nwx - 1) / nwx);
+  (void)wid; (void)nw;
+  for (int bi = xcd; bi < B; bi += 8) {
+    const int q0 = (int)(wx * per), q1 = q0 + per < n ? q0 + per : n;
+    if (q0 >= n) continue;
+    long long r = (long long)bi * n + q0;
+    int i1 = idx[r * 3], i2 = idx[r * 3 + 1], i3 = idx[r * 3 + 2];
+    float d1 = dist[r * 3], d2 = dist[r * 3 + 1], d3 = dist[r * 3 + 2];
+    for (int q = q0; q < q1; ++q, ++r) {
+    const float *p1 = H + ((long long)bi * m + i1) * 256 + lane * 4;
+    const float *p2 = H + ((long long)bi * m + i2) * 256 + lane * 4;
+    const float *p3 = H + ((long long)bi * m + i3) * 256 + lane * 4;
+    float w1, w2, w3;
+    idw_weights(d1, d2, d3, w1, w2, w3);
+    float4 a[MAXS], b[MAXS], c[MAXS];
+#pragma unroll
+    for (int j = 0; j < MAXS; ++j)
+      if (j < NS) {
+        a[j] = *reinterpret_cast<const float4 *>(p1 + (size_t)j * Rc * 256);
+        b[j] = *reinterpret_cast<const float4 *>(p2 + (size_t)j * Rc * 256);
+        c[j] = *reinterpret_cast<const float4 *>(p3 + (size_t)j * Rc * 256);
+      }
+    if (q + 1 < q1) {  // the next point's indices ride behind this point's rows
+      i1 = idx[(r + 1) * 3]; i2 = idx[(r + 1) * 3 + 1]; i3 = idx[(r + 1) * 3 + 2];
+      d1 = dist[(r + 1) * 3]; d2 = dist[(r + 1) * 3 + 1]; d3 = dist[(r + 1) * 3 + 2];
+    }
+    float z = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXS; ++j)
+      if (j < NS) {
+        const float4 v = idw_mix(a[j], b[j], c[j], w1, w2, w3);
+        z = fmaf(dh3d_act((v.x + pb[j].x) * sc[j].x + sh[j].x, ep.act), wf[j].x, z);
+        z = fmaf(dh3d_act((v.y + pb[j].y) * sc[j].y + sh[j].y, ep.act), wf[j].y, z);
+        z = fmaf(dh3d_act((v.z + pb[j].z) * sc[j].z + sh[j].z, ep.act), wf[j].z, z);
+        z = fmaf(dh3d_act((v.w + pb[j].w) * sc[j].w + sh[j].w, ep.act), wf[j].w, z);
+      }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off, 64);
+    if (lane == 0) att[r] = 1.f / (1.f + expf(-(z + b_fc)));
+    }
+  }
+}
+
 }  // namespace
 
 DH3D_API int dh3d_pack_weight_x3(const float *W, int Kd, int Dout, void *packed, void *stream) {
@@ -497,12 +582,15 @@ DH3D_API int dh3d_mlp_head_pm_x6_fwd(const float *h, int R, int C, const void *w
 static int linear_x6_launch(const float *x1, int C1, const float *x2, int C2, const void *wpacked_x3, int R, int Dout,
                             const dh3d_epilogue *ep, const float *residual, float *out, void *stream,
                             const UpsampleSrc &up, const L2CatOut &l2 = L2CatOut{nullptr, nullptr, 0.f},
-                            const ShortcutSrc &sc = ShortcutSrc{nullptr, 0, EpilogueArgs{nullptr, nullptr, nullptr, 0}}) {
+                            const ShortcutSrc &sc = ShortcutSrc{nullptr, 0, EpilogueArgs{nullptr, nullptr, nullptr, 0}},
+                            int slices = 1) {
   DH3D_SUPPORTED(C1 % HKC == 0 && C2 % HKC == 0 && sc.C3 % HKC == 0 && (Dout == 128 || Dout == 256));
   const EpilogueArgs e = dh3d_ep(ep);
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid(dh3d_cdiv(R, HTM)), block(512);
+  const dim3 grid(dh3d_cdiv(R, HTM), slices), block(512);
   const uint4 *wp = static_cast<const uint4 *>(wpacked_x3);
+  const long long wslice = (long long)3 * (C1 + C2 + sc.C3) * Dout * 2 / 16;  // uint4 per packed slice
+  const long long oslice = (long long)R * Dout;
   if (Dout == 128) {
     size_t lds = (size_t)2 * A_STAGE * 2 + (size_t)2 * (128 / 32) * 2 * 3 * 64 * 16;
     const size_t tile = sizeof(float) * HTM * (128 + 4) + sizeof(float) * HTM;  // + row norms (L2CatOut)
@@ -510,11 +598,13 @@ static int linear_x6_launch(const float *x1, int C1, const float *x2, int C2, co
     if (sc.x3) {
       auto kern = linear_x6_kernel<1, true>;
       DH3D_ALLOW_BIG_LDS(kern);
-      hipLaunchKernelGGL(kern, grid, block, lds, s, x1, C1, x2, C2, wp, e, residual, (long long)R, out, up, l2, sc);
+      hipLaunchKernelGGL(kern, grid, block, lds, s, x1, C1, x2, C2, wp, e, residual, (long long)R, out, up, l2, sc, wslice,
+                         oslice);
     } else {
       auto kern = linear_x6_kernel<1, false>;
       DH3D_ALLOW_BIG_LDS(kern);
-      hipLaunchKernelGGL(kern, grid, block, lds, s, x1, C1, x2, C2, wp, e, residual, (long long)R, out, up, l2, sc);
+      hipLaunchKernelGGL(kern, grid, block, lds, s, x1, C1, x2, C2, wp, e, residual, (long long)R, out, up, l2, sc, wslice,
+                         oslice);
     }
   } else {
     size_t lds = (size_t)2 * A_STAGE * 2 + (size_t)2 * (256 / 32) * 2 * 3 * 64 * 16;
@@ -523,7 +613,8 @@ static int linear_x6_launch(const float *x1, int C1, const float *x2, int C2, co
     if (l2.out || sc.x3) return DH3D_ERR_UNSUPPORTED;
     auto kern = linear_x6_kernel<2, false>;
     DH3D_ALLOW_BIG_LDS(kern);
-    hipLaunchKernelGGL(kern, grid, block, lds, s, x1, C1, x2, C2, wp, e, residual, (long long)R, out, up, l2, sc);
+    hipLaunchKernelGGL(kern, grid, block, lds, s, x1, C1, x2, C2, wp, e, residual, (long long)R, out, up, l2, sc, wslice,
+                         oslice);
   }
   return dh3d_launch_status();
 }
@@ -579,4 +670,32 @@ DH3D_API int dh3d_upsample_linear_shortcut_pm_x6_fwd(const float *points, const 
   const L2CatOut l2{prefix ? out : nullptr, prefix, l2_eps};
   const ShortcutSrc sc{x3, C3, dh3d_ep(ep_shortcut)};
   return linear_x6_launch(points, C1, x2, C2, wpacked_x3, B * n, Dout, ep, nullptr, out, stream, up, l2, sc);
+}
+
+// A layer wider than 256 as `slices` column slices of 256 in ONE launch: out [slices][R][256] = x1 @ W[:, 256 j : 256 j + 256],
+// wpacked_x3 = the dh3d_pack_weight_x3 images of the slices one after the other.  No epilogue, no residual.
+DH3D_API int dh3d_linear_slices_pm_x6_fwd(const float *x1, int C1, const void *wpacked_x3, int R, int slices,
+                                          float *out, void *stream) {
+  DH3D_REQUIRE(x1 && wpacked_x3 && out && R > 0 && C1 > 0 && slices > 0);
+  DH3D_SUPPORTED(slices <= 65535);
+  const UpsampleSrc none{nullptr, nullptr, nullptr, 1, 1};
+  return linear_x6_launch(x1, C1, nullptr, 0, wpacked_x3, R, 256, nullptr, nullptr, out, stream, none,
+                          L2CatOut{nullptr, nullptr, 0.f},
+                          ShortcutSrc{nullptr, 0, EpilogueArgs{nullptr, nullptr, nullptr, 0}}, slices);
+}
+
+// att [B*n] = sigmoid(w_fc . act(BN(interp(H) + pre_bias)) + b_fc), H = the hidden layer WITHOUT bias computed on the
+// coarse level: [Hd/256][B*m][256] (one dh3d_linear_pm_x6_fwd per 256-column slice of the weight), idx / dist [B*n, 3]
+// from dh3d_three_nn (squared distances), Hd in {256, 512, 768, 1024}.
+DH3D_API int dh3d_interp_head_fwd(const float *H, int Hd, const int32_t *idx, const float *dist, int B, int n, int m,
+                                  const dh3d_epilogue *ep, const float *w_fc, float b_fc, float *att, void *stream) {
+  DH3D_REQUIRE(H && idx && dist && w_fc && att && B > 0 && n > 0 && m > 0 && Hd > 0);
+  DH3D_SUPPORTED(Hd % 256 == 0 && Hd <= 1024);
+  const long long R = (long long)B * n;
+  int grid = (int)((R + 3) / 4);
+  if (grid > 256 * 16) grid = 256 * 16;
+  grid = (grid + 7) & ~7;  // whole rounds of the 8 XCDs
+  hipLaunchKernelGGL(interp_head_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, H, Hd / 256,
+                     (long long)B * m, idx, dist, n, m, dh3d_ep(ep), w_fc, b_fc, R, att);
+  return dh3d_launch_status();
 }

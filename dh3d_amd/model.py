@@ -217,7 +217,12 @@ class DH3D(nn.Module):
             geo = self._geometry(points, None)
             self._join_side(geo)
         forglobal = self.global_before_assemble(geo, localdesc)
-        att = self.globalatt(forglobal)
+        coarse, lv = getattr(self.global_before_assemble, "_last_coarse", (None, None))
+        if coarse is not None and "nn3_idx" in lv and self.globalatt.interpolated_supported(coarse, lv["nn3_idx"]):
+            # the attention MLP's 256 -> 1024 conv commutes with the up-sampling: it runs on the N/8 level
+            att = self.globalatt.forward_interpolated(coarse, lv["nn3_idx"], lv["nn3_dist"])
+        else:
+            att = self.globalatt(forglobal)
         return self._netvlad(forglobal, att, l2_eps=l2_eps)
 
     def forward(self, points, knn_inds=None, fetch=None):

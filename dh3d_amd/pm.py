@@ -360,6 +360,27 @@ def mlp_head_x6(h, wpacked_x3, H, w_fc, b_fc, pre_bias=None, scale=None, shift=N
     return out
 
 
+def interp_head(coarse, idx, dist, wslices_x3, Hd, w_fc, b_fc, pre_bias=None, scale=None, shift=None, act=ACT_RELU):
+    """mlp_head_x6(three_interpolate_idw(coarse, idx, dist), ...) with the wide conv commuted through the interpolation:
+    the [C, Hd] GEMM runs on the coarse rows (its 256-column slices in one launch, `wslices_x3` = their packed images
+    back to back), a gather kernel
+    interpolates the Hd-wide rows and finishes bias + BN + act + w_fc + sigmoid.  coarse [B,m,C], idx/dist [B,n,3]."""
+    x = L.require_cuda_f32(coarse, "coarse", 3)
+    ix = L.require_cuda_i32(idx, "idx", 3)
+    d = L.require_cuda_f32(dist, "dist", 3)
+    B, m, C = x.shape
+    n = ix.shape[1]
+    ns = Hd // 256
+    H = torch.empty((ns, B * m, 256), dtype=torch.float32, device=x.device)
+    L.check(L.lib().dh3d_linear_slices_pm_x6_fwd(L.ptr(x), C, L.ptr(wslices_x3), B * m, ns, L.ptr(H), L.stream_ptr()),
+            "linear_slices_pm_x6")
+    out = torch.empty((B, n, 1), dtype=torch.float32, device=x.device)
+    ep = _ep(pre_bias, scale, shift, act)
+    L.check(L.lib().dh3d_interp_head_fwd(L.ptr(H), Hd, L.ptr(ix), L.ptr(d), B, n, m, ep, L.ptr(w_fc), float(b_fc),
+                                         L.ptr(out), L.stream_ptr()), "interp_head")
+    return out
+
+
 def netvlad_aggregate(x, att, wc_packed, bn_scale, bn_shift, W2):
     a = L.require_cuda_f32(x, "x", 3)
     B, N, D = a.shape

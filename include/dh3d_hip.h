@@ -266,6 +266,17 @@ int dh3d_pack_weight_x3(const float *W, int Kd, int Dout, void *packed, void *st
 int dh3d_mlp_head_pm_x6_fwd(const float *h, int R, int C, const void *wpacked_x3, int H,
                             const dh3d_epilogue *ep, const float *w_fc, float b_fc, float *att, void *stream);
 
+/* The same head on an up-sampled input with the wide conv commuted through the (linear, weights sum to 1) 3-NN
+ * interpolation of core/backbones.py:91-95:  att = sigmoid(w_fc . act(BN(interp(H) + pre_bias)) + b_fc),  H = x_coarse W
+ * computed on the m coarse rows, layout [Hd/256][B*m][256] (one dh3d_linear_pm_x6_fwd per 256-column weight slice);
+ * idx / dist [B*n,3] from dh3d_three_nn.  8x fewer GEMM flops than running the head on the up-sampled rows. */
+int dh3d_interp_head_fwd(const float *H, int Hd, const int32_t *idx, const float *dist, int B, int n, int m,
+                         const dh3d_epilogue *ep, const float *w_fc, float b_fc, float *att, void *stream);
+/* a layer wider than 256 as `slices` column slices of 256 in one launch: out [slices][R][256] = x1 @ W[:, 256 j ..],
+ * wpacked_x3 = the dh3d_pack_weight_x3 images of the slices back to back (the H operand of dh3d_interp_head_fwd) */
+int dh3d_linear_slices_pm_x6_fwd(const float *x1, int C1, const void *wpacked_x3, int R, int slices, float *out,
+                                 void *stream);
+
 /* Attention-weighted NetVLAD aggregation (core/backbones.py:202-262), stage 1+2:
  *   xn = l2norm(x); a = softmax(bn(xn @ Wc)) * att;  vlad[b,d,c] = sum_n a[n,c] xn[n,d] - (sum_n a[n,c]) W2[d,c]
  *   then intra-normalise over d per cluster and L2-normalise the flattened [D*Cl] vector (d-major).

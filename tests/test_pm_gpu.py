@@ -349,3 +349,29 @@ def test_upsample_linear_shortcut_fused_matches_two_kernels(dev, B, n, l2):
     assert got.shape == ref.shape
     err = (got - ref).abs().max().item() / ref.abs().max().item()
     assert err < 1e-6, err
+
+
+@pytest.mark.parametrize("B,n", [(2, 4096), (1, 4100), (3, 5000)])
+def test_interp_head_equals_head_on_upsampled_rows(dev, B, n):
+    """The attention head with its wide conv commuted through the 3-NN interpolation == the head run on the
+    materialised up-sampled tensor (same weights; a different association of the same sums)."""
+    from dh3d_amd import pm, ops
+    g = torch.Generator().manual_seed(n + B)
+    m, C, Hd = n // 8, 256, 1024
+    fine = torch.rand(B, n, 3, generator=g).to(dev)
+    d3, i3 = ops.three_nn(fine, fine[:, :m].contiguous())
+    coarse = torch.randn(B, m, C, generator=g).to(dev)
+    W = (torch.randn(C, Hd, generator=g) / C ** 0.5).to(dev)
+    wfc = (torch.randn(Hd, generator=g) / Hd ** 0.5).to(dev)
+    b = torch.randn(Hd, generator=g).to(dev); sc = (0.5 + torch.rand(Hd, generator=g)).to(dev); sh = torch.randn(Hd, generator=g).to(dev)
+    up = pm.three_interpolate_idw(coarse, i3, d3)
+    ref = pm.mlp_head_x6(up, pm.pack_weight_x3(W), Hd, wfc, 0.2, pre_bias=b, scale=sc, shift=sh, act=pm.ACT_RELU)
+    slices = torch.cat([pm.pack_weight_x3(W[:, j:j + 256].contiguous()) for j in range(0, Hd, 256)])
+    got = pm.interp_head(coarse, i3, d3, slices, Hd, wfc, 0.2, pre_bias=b, scale=sc, shift=sh, act=pm.ACT_RELU)
+    assert got.shape == ref.shape == (B, n, 1)
+    assert (got - ref).abs().max().item() < 2e-6
+    # and against float64
+    w = 1.0 / d3.double().clamp_min(1e-10); w = w / w.sum(2, keepdim=True)
+    upd = (torch.gather(coarse.double(), 1, i3.long().reshape(B, -1, 1).expand(-1, -1, C)).reshape(B, n, 3, C) * w[..., None]).sum(2)
+    z = torch.relu((upd @ W.double() + b.double()) * sc.double() + sh.double()) @ wfc.double() + 0.2
+    assert (got.double().squeeze(-1) - torch.sigmoid(z)).abs().max().item() < 2e-6
