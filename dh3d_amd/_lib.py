@@ -45,6 +45,7 @@ _SIGNATURES = {
     "dh3d_conv_pointset_bwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp,
                                c_fp],
     "dh3d_farthest_point_sample": [c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp],
+    "dh3d_farthest_point_sample_mode": [c_int, c_int, c_int, c_fp, c_fp, c_fp, c_int, c_fp],
     "dh3d_group_point_fwd": [c_int, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp],
     "dh3d_group_point_bwd": [c_int, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp],
     "dh3d_three_nn": [c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp],

@@ -178,7 +178,8 @@ class SEBlock(nn.Module):
 class Geometry(object):
     """Everything the forward needs that depends on coordinates only."""
 
-    def __init__(self, xyz, knn_num, nbr=None):
+    def __init__(self, xyz, knn_num, nbr=None, fps_contract=None):
+        self.fps_contract = fps_contract
         self.xyz = xyz
         self.knn_num = knn_num
         self.nbr = nbr          # [B,N,K] int32
@@ -193,7 +194,8 @@ class Geometry(object):
     def level(self, dilate, knn, finish=True):
         key = (dilate, knn)
         if key not in self.levels:
-            self.levels[key] = compute_level(self.xyz, dilate, knn, ordered=self.sorted)
+            self.levels[key] = compute_level(self.xyz, dilate, knn, ordered=self.sorted,
+                                             fps_contract=self.fps_contract)
         return self.finish(self.levels[key]) if finish else self.levels[key]
 
     def start_nn3(self, lv):
@@ -226,20 +228,21 @@ def gather_rows(points, idx):
     return out
 
 
-def compute_level(xyz, dilate, knn, ordered=None):
+def compute_level(xyz, dilate, knn, ordered=None, fps_contract=None):
     """FPS -> gather xyz -> kNN on the sampled set (three_nn back to the full set: finish_level).
 
     `ordered` = (records, group boxes) of pm.spatial_sort(xyz) if the caller has them: large clouds then use the
     region-pruned FPS with several picks per synchronisation (csrc/fps.hip: 0.38 ms vs 0.82 ms at 8192 -> 1024,
-    0.2 vs 0.28 ms at 4096 -> 512; no gain at 2048 and below)."""
+    0.2 vs 0.28 ms at 4096 -> 512; no gain at 2048 and below).
+    fps_contract: None = default kernels; 0 / 1 forces the any-N kernel with that distance rounding
+    (ops.farthest_point_sample)."""
     B, N, _ = xyz.shape
     npoint = N // dilate
-    if ordered is not None and 4096 <= N <= 12288:
+    if ordered is not None and 4096 <= N <= 12288 and fps_contract is None:
         idx, xyz_s = pm.fps_sorted(ordered[0], ordered[1], npoint, with_xyz=True)  # coordinates from the kernel's LDS
     else:
-        idx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
-        L.check(L.lib().dh3d_farthest_point_sample(B, N, npoint, L.ptr(xyz), None, L.ptr(idx), L.stream_ptr()),
-                "farthest_point_sample")
+        from . import ops
+        idx = ops.farthest_point_sample(npoint, xyz, contract=fps_contract)  # any N (scratch distances above 16384)
         xyz_s = gather_rows(xyz, idx)
     ready = torch.cuda.Event()
     ready.record()  # xyz_s exists: three_nn may start on another stream while the sampled-set kNN runs here
@@ -348,6 +351,10 @@ class FlexConvDilate(nn.Module):
                                            residual=residual, l2cat=fuse, shortcut=shortcut_src)
                 return y if (l2cat is None or fuse is not None) else pm.l2norm_concat(y, l2cat[1], prefix=l2cat[0])
             x = pm.three_interpolate_idw(x, lv["nn3_idx"], lv["nn3_dist"])
+        if shortcut_src is not None:
+            raise RuntimeError("shortcut_src was given but the fused up-sample + concat conv path is not available "
+                               "for this shape: the caller must check shortcut_fusable() (the stage-1 shortcut "
+                               "would be dropped silently otherwise)")
         if self.concat:
             x = self.concat_conv1d(x, x2=feat, act=pm.ACT_RELU, residual=residual)
         elif residual is not None:

@@ -150,7 +150,7 @@ def load_tf_checkpoint(model, prefix, strict=True):
     arrays = read_checkpoint(prefix, names=sorted(set(found.values())))
     new = {k: torch.from_numpy(np.array(arrays[v])).to(dtype=sd[k].dtype) for k, v in found.items()}
     model.load_state_dict(new, strict=False)
-    if hasattr(model, "_prepared"):
-        model._prepared = False  # packed / folded copies of the weights are rebuilt on the next forward
+    if hasattr(model, "invalidate"):
+        model.invalidate()  # packed / folded copies of the weights are rebuilt on the next forward
     used = set(found.values())
     return missing, sorted(n for n in entries if n not in used)

@@ -574,17 +574,77 @@ int fps_launch(const float *xyz, int B, int N, int m, int32_t *out, hipStream_t 
   return dh3d_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Any-N kernel with the running min-distances in the caller's `temp` scratch, as the reference keeps them
+// (tf_sampling_g.cu:112-145: temp[blockIdx.x*n+k]); serves (a) clouds of more than 16384 points, which the
+// register-resident kernels above do not hold, and (b) the UNCONTRACTED distance arithmetic
+// ((dx*dx + dy*dy) + dz*dz, what nvcc -fmad=false would build) for integrators whose reference binary
+// was compiled that way -- CONTRACT selects between the two roundings, everything else (1e38 start,
+// min, strict '>' in index order per 512-stride lane, lower slot on tree ties) is the same rule.
+// One 1024-lane workgroup per cloud; a lane scans k = tid, tid+1024, ...; the block arg-max is one 64-bit
+// LDS atomicMax per wave on (bits(value) << 32 | ~key(k)), slots rotating over three rounds.
+template <bool CONTRACT>
+__global__ __launch_bounds__(1024) void fps_anyn_kernel(const float *__restrict__ xyz, int N, int m,
+                                                        float *__restrict__ temp, int32_t *__restrict__ out) {
+  __shared__ unsigned long long s_best[3];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float *pc = xyz + (size_t)b * N * 3;
+  float *td = temp + (size_t)b * N;
+  for (int k = tid; k < N; k += 1024) td[k] = 1e38f;
+  if (tid == 0) out[(size_t)b * m] = 0;
+  if (tid < 3) s_best[tid] = 0ull;
+  __syncthreads();
+  int old = 0;
+  for (int r = 1; r < m; ++r) {
+    const float x1 = pc[(size_t)old * 3], y1 = pc[(size_t)old * 3 + 1], z1 = pc[(size_t)old * 3 + 2];
+    float best = -1.f;
+    int bkey = INT_MAX;
+    for (int k = tid; k < N; k += 1024) {
+      const float dx = pc[(size_t)k * 3] - x1, dy = pc[(size_t)k * 3 + 1] - y1, dz = pc[(size_t)k * 3 + 2] - z1;
+      const float d = CONTRACT ? __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy)) : (dx * dx + dy * dy) + dz * dz;
+      const float t0 = td[k];
+      const float d2 = d < t0 ? d : t0;
+      if (d2 != t0) td[k] = d2;
+      const int key = fps_key(k);
+      if (d2 > best || (d2 == best && key < bkey)) { best = d2; bkey = key; }
+    }
+    if (best >= 0.f) {
+      const unsigned long long v =
+          ((unsigned long long)(unsigned)__float_as_int(best) << 32) | (unsigned)(~bkey);
+      atomicMax(&s_best[r % 3], v);
+    }
+    __syncthreads();
+    const unsigned long long w = s_best[r % 3];
+    // slot (r+2)%3 == (r-1)%3 was last read before this round's barrier and is written again only after the
+    // next one: safe to clear here
+    if (tid == 0) s_best[(r + 2) % 3] = 0ull;
+    old = fps_unkey(~(int)(unsigned)(w & 0xffffffffu));
+    if (tid == 0) out[(size_t)b * m + r] = old;
+  }
+}
+
 }  // namespace
 
 // Dev knob (tools/geo_bench.py): waves per cloud; 0 = default.
 static int g_fps_waves = 0;
 DH3D_API void dh3d_dev_set_fps_waves(int w) { g_fps_waves = w; }
 
+DH3D_API int dh3d_farthest_point_sample_mode(int B, int N, int m, const float *inp, float *temp, int32_t *out,
+                                             int contract, void *stream) {
+  DH3D_REQUIRE(inp && out && temp && B > 0 && N > 0 && m > 0 && (contract == 0 || contract == 1));
+  hipStream_t s = (hipStream_t)stream;
+  if (contract) hipLaunchKernelGGL(fps_anyn_kernel<true>, dim3(B), dim3(1024), 0, s, inp, N, m, temp, out);
+  else hipLaunchKernelGGL(fps_anyn_kernel<false>, dim3(B), dim3(1024), 0, s, inp, N, m, temp, out);
+  return dh3d_launch_status();
+}
+
 DH3D_API int dh3d_farthest_point_sample(int B, int N, int m, const float *inp, float *temp,
                                         int32_t *out, void *stream) {
-  (void)temp;
   DH3D_REQUIRE(inp && out && B > 0 && N > 0 && m > 0);  // tf_sampling.cpp:100,105
-  DH3D_SUPPORTED(N <= 16384);
+  if (N > 16384) {  // beyond the register-resident kernels: distances in the caller's scratch, as upstream
+    DH3D_SUPPORTED(temp != nullptr);
+    return dh3d_farthest_point_sample_mode(B, N, m, inp, temp, out, 1, stream);
+  }
   hipStream_t s = (hipStream_t)stream;
   const int W = g_fps_waves ? g_fps_waves : (N <= 1024 ? 4 : 8);  // measured best on MI355X (tools/geo_bench.py)
 #define DH3D_FPS_CASE(WV)                                                              \

@@ -56,7 +56,7 @@ def _pairwise_sqdist(a, b):
     return ((a.unsqueeze(2) - b.unsqueeze(1)) ** 2).sum(3)
 
 
-def desc_local_loss(outs, pos_r=0.5, search_r=20, margin=0.8, neg_weight=5):
+def desc_local_loss(outs, pos_r=0.5, search_r=20, margin=0.8, neg_weight=5, **unused):
     """n-tuple loss on sampled keypoints (core/losses.py:29-63).  outs: 'xyz_sampled' [2B,M,3], 'feat_sampled'
     [2B,M,D], 'R' [B,3,3] (cloud 0 -> cloud 1).  Returns pos_loss + neg_weight * neg_loss."""
     xyz0, xyz1 = torch.chunk(outs["xyz_sampled"], 2, dim=0)
@@ -70,7 +70,7 @@ def desc_local_loss(outs, pos_r=0.5, search_r=20, margin=0.8, neg_weight=5):
     return pos_loss + neg_weight * neg_loss
 
 
-def local_detection_loss_nn(outs, ar_th=0.3, det_k=16, ar_nn_k=5, pos_r=0.3, use_hardest_neg=True):
+def local_detection_loss_nn(outs, ar_th=0.3, det_k=16, ar_nn_k=5, pos_r=0.3, use_hardest_neg=True, **unused):
     """Detector loss (core/losses.py:66-133): for every sampled keypoint of cloud 0, the rank (among its `ar_nn_k`
     closest-in-feature candidates) of the first candidate that lies within pos_r of the warped keypoint; candidates =
     the det_k nearest neighbours in cloud 1 of the corresponding sample (plus those of the hardest negative).
@@ -105,3 +105,28 @@ def local_detection_loss_nn(outs, ar_th=0.3, det_k=16, ar_nn_k=5, pos_r=0.3, use
     AR = (first + 1e-8) / ar_nn_k
     s0 = score0.squeeze(2)
     return (1 - (AR * s0 + ar_th * (1 - s0))).mean()
+
+
+def compute_loss(outs, config):
+    """The reference's loss assembly (core/model.py:212-237): every loss is called with **config (so the config's
+    margin / pos_r / ar_th / ... override the function defaults, as upstream) and scaled by its *_loss_weight.
+    outs: the forward's named outputs (+ the sampled-keypoint tensors the local losses need); the global descriptor
+    is read from 'global_desc' (the reference's key, model.py:206) or 'globaldesc' (the fetch name).
+    Weight decay on '.*/W' (model.py:239-243) is the optimiser's part: training.QuadrupletTrainer."""
+    import sys
+    mod = sys.modules[__name__]
+
+    def weight(key):
+        return config.get(key) if config.get(key) is not None else 1.0
+    total = 0.0
+    if config.get("extract_global"):
+        desc = outs["global_desc"] if "global_desc" in outs else outs["globaldesc"]
+        fn = getattr(mod, config.get("global_loss") or "lazy_quadruplet_loss")
+        total = total + fn(global_descs=desc, **config) * weight("global_loss_weight")
+    if config.get("add_local_loss"):
+        fn = getattr(mod, config.get("local_loss") or "desc_local_loss")
+        total = total + fn(outs, **config) * weight("local_loss_weight")
+    if config.get("detection") and config.get("add_det_loss"):
+        fn = getattr(mod, config.get("detection_loss") or "local_detection_loss_nn")
+        total = total + fn(outs, **config) * weight("det_loss_weight")
+    return total

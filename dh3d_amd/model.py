@@ -73,6 +73,8 @@ class DH3D(nn.Module):
         object.__setattr__(self, "_local", local)
         self._geo_stream = None
         self._prepared = False
+        self._head_prepared = False
+        self.validate_knn_inds = True  # range-check caller-provided neighbour ids (one device sync per eager call)
 
     # ------------------------------------------------------------------ weights
     @torch.no_grad()
@@ -99,20 +101,52 @@ class DH3D(nn.Module):
                 p.copy_(torch.randn(p.shape, generator=g) / (p.shape[-2] ** 0.5))
             elif leaf == "hidden1_weights":
                 p.copy_(torch.randn(p.shape, generator=g) / 8.0)
-        self._prepared = False
+        self.invalidate()
         return self
 
     def prepare(self):
-        """Fold BatchNorm and pack weights for the kernels.  Call after loading / moving weights."""
+        """Fold BatchNorm and pack weights for the kernels.  Called lazily by the forward; explicit calls are
+        allowed (and harmless) after loading / moving weights."""
         self._local.prepare()
         if self.config.detection:
             self.detection_block_reliable.prepare()
+        self._prepared = True
+        self._prepare_head()
+        return self
+
+    def _prepare_head(self):
         if self.config.extract_global:
             self.global_before_assemble.prepare()
             self.globalatt.prepare()
             self._netvlad.prepare()
-        self._prepared = True
-        return self
+        self._head_prepared = True
+
+    def invalidate(self, head_only=False):
+        """Drop the folded / packed copies of the weights (rebuilt by the next forward): called whenever parameters
+        may have changed -- load_state_dict, .to()/.cuda()/.float() (_apply), init_synthetic, an optimiser step
+        (head_only: the global head that global_config trains; the frozen backbone's copies stay)."""
+        self._head_prepared = False
+        mods = []
+        if self.config.extract_global:
+            for top in (self.global_before_assemble, self.globalatt, self.__dict__.get("_netvlad")):
+                mods += [top] + (list(top.modules()) if top is not None else [])
+        if not head_only:
+            self._prepared = False
+            mods += list(self.modules()) + [self.__dict__.get("_local"), self.__dict__.get("_netvlad")]
+        for m in mods:
+            if m is not None and getattr(m, "_prep", None) is not None:
+                m._prep = None
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        if "_prepared" in self.__dict__:
+            self.invalidate()
+        return out
 
     def _check_mode(self):
         if self.training:
@@ -120,6 +154,8 @@ class DH3D(nn.Module):
                 "training-mode BatchNorm is not implemented on the fused path; call model.eval()")
         if not self._prepared:
             self.prepare()
+        elif not self._head_prepared:
+            self._prepare_head()
 
     # ------------------------------------------------------------------ two streams
     # The step's critical path is  sort -> FPS -> gather -> kNN(N/8) -> stage 2 -> concat conv -> ...  (FPS alone is
@@ -129,9 +165,9 @@ class DH3D(nn.Module):
     # the critical chain must not hop between queues: the earlier arrangement -- FPS on the side stream --
     # paid that twice per step.)
     def _geometry(self, points, knn_inds=None):
-        geo = bb.Geometry(points, self.knn_num)
+        geo = bb.Geometry(points, self.knn_num, fps_contract=self.config.fps_contract)
         main = torch.cuda.current_stream()
-        if knn_inds is None or 4096 <= points.shape[1] <= 12288:
+        if knn_inds is None or (4096 <= points.shape[1] <= 12288 and self.config.fps_contract is None):
             geo.ordered()  # Morton order + group boxes: shared by the kNN (side) and the pruned FPS (here)
         if self._geo_stream is None:
             self._geo_stream = torch.cuda.Stream(device=points.device)
@@ -239,6 +275,19 @@ class DH3D(nn.Module):
             raise ValueError("points must be [Bt, N, 3]")
         if knn_inds is None and points.shape[1] > 16384:
             raise ValueError("more than 16384 points: pass knn_inds [Bt, N, K] (the device kNN stops there)")
+        if points.shape[1] > 131072:
+            raise ValueError("more than 131072 points per cloud are not supported (sampled-set kNN: N/8 <= 16384)")
+        if knn_inds is not None:
+            # the kernels never bounds-check neighbour ids (nor does the reference): do it here
+            if (knn_inds.dim() != 3 or knn_inds.shape[0] != points.shape[0] or knn_inds.shape[1] != points.shape[1]
+                    or knn_inds.shape[2] < 8 or knn_inds.dtype != torch.int32 or knn_inds.device != points.device):
+                raise ValueError("knn_inds must be int32 [Bt, N, K>=8] on the device of points, got %s %s"
+                                 % (tuple(knn_inds.shape), knn_inds.dtype))
+            if self.validate_knn_inds and not torch.cuda.is_current_stream_capturing():
+                lo, hi = int(knn_inds.min()), int(knn_inds.max())  # one sync; switch off with validate_knn_inds=False
+                if lo < 0 or hi >= points.shape[1]:
+                    raise ValueError("knn_inds out of range [0, %d): min %d max %d (kNN pads with -1 when N < K)"
+                                     % (points.shape[1], lo, hi))
         # num_points > 8192: the reference feeds host (sklearn) kNN indices because its op stops at 8192
         # (core/model.py:38,148-155); they are still accepted, but the device search covers N <= 16384 itself.
         outs = {"pointclouds": points, "xyz": points}

@@ -165,8 +165,12 @@ def convolution_pointset(features, neighborhood, theta, bias, name=None):
 
 
 # --------------------------------------------------------------------------- PointNet++ ops
-def farthest_point_sample(npoint, inp):
-    """inp [B,N,3] -> idx [B,npoint] int32 (tf_sampling.py:63-71); not differentiable."""
+def farthest_point_sample(npoint, inp, contract=None):
+    """inp [B,N,3] -> idx [B,npoint] int32 (tf_sampling.py:63-71); not differentiable.
+
+    contract (extension): None = the default kernels (distance rounded as fma(dz,dz,fma(dx,dx,dy*dy)), the LLVM/NVVM
+    contraction of tf_sampling_g.cu:141); 1 / 0 = the any-N kernel with that contraction / the uncontracted
+    (dx*dx+dy*dy)+dz*dz of an -fmad=false build (dh3d_farthest_point_sample_mode)."""
     x = L.require_cuda_f32(inp, "inp", 3)
     if x.shape[2] != 3:
         raise ValueError("FarthestPointSample expects (batch_size,num_points,3) inp shape")  # tf_sampling.cpp:105
@@ -175,8 +179,14 @@ def farthest_point_sample(npoint, inp):
     B, N, _ = x.shape
     out = torch.empty((B, int(npoint)), dtype=torch.int32, device=x.device)
     with torch.cuda.device(x.device):
-        L.check(L.lib().dh3d_farthest_point_sample(B, N, int(npoint), L.ptr(x), None, L.ptr(out), L.stream_ptr()),
-                "farthest_point_sample")
+        if contract is None and N <= 16384:
+            L.check(L.lib().dh3d_farthest_point_sample(B, N, int(npoint), L.ptr(x), None, L.ptr(out),
+                                                       L.stream_ptr()), "farthest_point_sample")
+        else:  # running min-distances in scratch, as the reference's allocate_temp (tf_sampling.cpp:115)
+            temp = torch.empty((B, N), dtype=torch.float32, device=x.device)
+            L.check(L.lib().dh3d_farthest_point_sample_mode(B, N, int(npoint), L.ptr(x), L.ptr(temp), L.ptr(out),
+                                                            1 if contract is None else int(bool(contract)),
+                                                            L.stream_ptr()), "farthest_point_sample")
     return out
 
 

@@ -12,8 +12,8 @@ global_config freezes the local backbone (configs.py:112-113), so a step is:
      (core/losses.py:173-200), backward, SUM all-reduce of the head gradients, Adam with the staircase
      exponential learning rate (core/model.py:248-255) and L2 weight decay on '.*/W' (model.py:239-243).
 
-BatchNorm statistics under sharding: per-rank (local) batch statistics by default; `sync_bn=True` all-reduces
-(sum, sum of squares, count) so the statistics equal the reference's single-GPU whole-batch statistics.
+BatchNorm statistics under sharding: `sync_bn=True` (default) all-reduces (sum, sum of squares, count) so the
+statistics equal the reference's single-GPU whole-batch statistics; `sync_bn=False` uses per-rank statistics.
 This path favours correctness over speed: it is the parity/coverage path for config 4, not a bench line.
 """
 import torch
@@ -64,11 +64,17 @@ def _batch_norm_train(x, channel_dim, gamma, beta, run_mean, run_var, eps, momen
         packed = dfn.all_reduce(torch.cat([s1, s2, cnt.reshape(1)]))
         C = s1.numel()
         s1, s2, cnt = packed[:C], packed[C:2 * C], packed[2 * C]
+    # a rank that holds only padding clouds (e.g. 22 clouds over 12 or 16 ranks) has cnt == 0 without sync_bn: its
+    # statistics are 0/0.  Guard the division and leave its running buffers alone -- every row of x is masked out of
+    # the loss there, so its gradients are exact zeros instead of NaN that the SUM all-reduce would spread.
+    empty = cnt <= 0
+    cnt = cnt.clamp_min(1.0)
     mean = s1 / cnt
-    var = s2 / cnt - mean * mean
+    var = (s2 / cnt - mean * mean).clamp_min(0.0)
     with torch.no_grad():
-        run_mean.mul_(momentum).add_(mean.detach(), alpha=1 - momentum)
-        run_var.mul_(momentum).add_(var.detach(), alpha=1 - momentum)
+        keep = empty.to(mean.dtype)  # 1 -> buffers unchanged
+        run_mean.copy_(keep * run_mean + (1 - keep) * (momentum * run_mean + (1 - momentum) * mean.detach()))
+        run_var.copy_(keep * run_var + (1 - keep) * (momentum * run_var + (1 - momentum) * var.detach()))
     return (x - mean.reshape(shape)) * torch.rsqrt(var.reshape(shape) + eps) * gamma.reshape(shape) + beta.reshape(shape)
 
 
@@ -185,9 +191,19 @@ class QuadrupletTrainer(object):
     """One process per GPU.  `step(points)` takes the role-ordered batch [B*(1+P+Ng+1), N, 3] (identical on
     every rank, e.g. generated from a shared seed), runs this rank's block and returns the loss."""
 
-    def __init__(self, model, start_lr=5e-4, decay_step=20000, decay_rate=0.9, weight_decay=1e-5, sync_bn=False):
+    def __init__(self, model, start_lr=None, decay_step=None, decay_rate=None, weight_decay=None, sync_bn=True):
+        """Schedule / weight decay default to the model's config (core/configs.py:50-54,115-117).  sync_bn=True (the
+        default) reproduces the reference's whole-batch BatchNorm statistics under sharding -- and keeps the running
+        buffers identical on every rank; sync_bn=False normalises with per-rank statistics (a few clouds of one role
+        each under the contiguous role-ordered partition) and lets the buffers diverge."""
         self.model = model
         self.cfg = model.config
+        c = self.cfg
+        start_lr = start_lr if start_lr is not None else (c.start_lr or 5e-4)
+        decay_step = decay_step if decay_step is not None else (c.decay_step or 20000)
+        decay_rate = decay_rate if decay_rate is not None else (c.decay_rate or 0.9)
+        if weight_decay is None:
+            weight_decay = (c.train_weight_decay or 1e-5) if c.add_weight_decay is not False else 0.0
         self.sync_bn = sync_bn
         self.params = trainable_head_parameters(model)
         self.wd_params = [p for n, p in model.named_parameters() if n.endswith(".W")
@@ -216,7 +232,6 @@ class QuadrupletTrainer(object):
         return loss
 
     def step(self, points):
-        # NOTE: the head trains on the raw parameters; call model.prepare() again before fused inference.
         self.opt.zero_grad(set_to_none=True)
         loss = self.forward_loss(points)
         wd = sum((p * p).sum() for p in self.wd_params) * (0.5 * self.weight_decay) if self.wd_params else 0.0
@@ -232,4 +247,5 @@ class QuadrupletTrainer(object):
                 off += n
         self.opt.step()
         self.sched.step()
+        self.model.invalidate(head_only=True)  # the packed / folded weight copies of the fused inference path are stale now
         return float(loss.detach())

@@ -98,10 +98,18 @@ int dh3d_conv_pointset_bwd(const float *features, const float *theta,
 
 /* FarthestPointSample -- replaces farthestpointsamplingLauncher (tf_ops/sampling/tf_sampling.cpp:94,
  * tf_sampling_g.cu:105-170,203-205).  inp [B,N,3] -> out [B,m] int32, first pick 0, bit-exact tie
- * order.  `temp` is the reference's [32,N] scratch: accepted for signature parity, unused (the
- * running min-distances live in registers); may be NULL.  N <= 16384. */
+ * order.  `temp` is the reference's scratch (tf_sampling.cpp:115 allocates [32,N]): for N <= 16384 the
+ * running min-distances live in registers and it may be NULL; above that it must hold B*N floats. */
 int dh3d_farthest_point_sample(int B, int N, int m, const float *inp, float *temp, int32_t *out,
                                void *stream);
+
+/* Same op with the rounding of d = (x2-x1)^2+(y2-y1)^2+(z2-z1)^2 (tf_sampling_g.cu:141) selectable:
+ * contract = 1: fma(dz,dz,fma(dx,dx,dy*dy)) -- the LLVM/NVVM contraction, what the kernels above compute;
+ * contract = 0: (dx*dx+dy*dy)+dz*dz -- an nvcc -fmad=false build.  Which one a given reference binary
+ * used cannot be checked without nvcc (parity unpinned); an integrator who can check picks here.
+ * Any N; temp [B*N] floats is REQUIRED (the running min-distances, as upstream). */
+int dh3d_farthest_point_sample_mode(int B, int N, int m, const float *inp, float *temp, int32_t *out,
+                                    int contract, void *stream);
 
 /* GroupPoint / GroupPointGrad -- replace groupPointLauncher / groupPointGradLauncher
  * (tf_ops/grouping/tf_grouping.cpp:208-274, tf_grouping_g.cu:94-132).

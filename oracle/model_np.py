@@ -79,17 +79,22 @@ def subsample(points, feat, targetnum):
 
 
 def flex_conv_dilate(xyz, feat, dilate, knn, outdims, scope, w, eps, knn_indices=None, concat=True,
-                     add_se="max_pool", upsample=True):
-    """core/backbones.py:58-101."""
+                     add_se="max_pool", upsample=True, trace=None):
+    """core/backbones.py:58-101.  trace (dict or None): receives the block's integer intermediates
+    ('<scope>/fps_idx' [B,m], '<scope>/knn' [B,K,m], '<scope>/nn3_idx' [B,N,3], '<scope>/nn3_dist')."""
     N = xyz.shape[1]
     if dilate > 1:
-        points_s, feat_s, _ = subsample(xyz, feat, N // dilate)
+        points_s, feat_s, kp = subsample(xyz, feat, N // dilate)
+        if trace is not None:
+            trace[scope + "/fps_idx"] = kp[:, :, 0]
     else:
         points_s, feat_s = xyz, feat
     feats_T = np.ascontiguousarray(feat_s.transpose(0, 2, 1))
     points_T = np.ascontiguousarray(points_s.transpose(0, 2, 1))
     if knn_indices is None:
         knn_indices, _ = knn_bruteforce_layer(points_T, knn)
+        if trace is not None:
+            trace[scope + "/knn"] = knn_indices
     x = feats_T
     for i, d in enumerate(outdims):
         x = flexconv_bn(x, points_T, knn_indices, w, "%s/flexconv_%d" % (scope, i), eps)
@@ -99,6 +104,8 @@ def flex_conv_dilate(xyz, feat, dilate, knn, outdims, scope, w, eps, knn_indices
     new_feat = np.ascontiguousarray(x.transpose(0, 2, 1))
     if upsample and dilate > 1:
         dist, idx = O.three_nn(xyz, points_s)
+        if trace is not None:
+            trace[scope + "/nn3_idx"], trace[scope + "/nn3_dist"] = idx, dist.copy()
         dist = np.maximum(dist, np.float32(1e-10))
         norm = np.sum(np.float32(1.0) / dist, axis=2, keepdims=True)
         weight = (np.float32(1.0) / dist) / norm
@@ -109,7 +116,7 @@ def flex_conv_dilate(xyz, feat, dilate, knn, outdims, scope, w, eps, knn_indices
     return xyz, new_feat
 
 
-def backbone_local_dilate(points, knn_ind, w, eps):
+def backbone_local_dilate(points, knn_ind, w, eps, trace=None):
     """core/backbones.py:104-127."""
     nn_8 = np.ascontiguousarray(knn_ind[:, 0:8, :])
     pts_T = np.ascontiguousarray(points.transpose(0, 2, 1))
@@ -119,7 +126,8 @@ def backbone_local_dilate(points, knn_ind, w, eps):
     init = np.ascontiguousarray(init.transpose(0, 2, 1))
     _, x1 = flex_conv_dilate(points, init, 1, 8, [64, 64], "stage1", w, eps, knn_indices=nn_8, concat=False)
     x2 = _conv1x1(x1, w, "before_stage2_conv1d/tfconv0", bn_eps=eps, act=_relu)
-    _, x2 = flex_conv_dilate(points, x2, 8, 8, [128, 128], "stage2", w, eps, knn_indices=None, concat=True)
+    _, x2 = flex_conv_dilate(points, x2, 8, 8, [128, 128], "stage2", w, eps, knn_indices=None, concat=True,
+                             trace=trace)
     feat = _conv1x1(x1, w, "local_stage1_shortcut/tfconv0", bn_eps=eps, act=_relu) + x2
     return points, feat.astype(np.float32)
 
@@ -163,8 +171,9 @@ def global_netvlad_block(features, att, w, slim_eps, cluster_size=64):
 
 
 def forward(points, w, detection=False, extract_global=False, knn_num=8, tp_eps=1e-5, slim_eps=1e-3,
-            knn_inds=None):
-    """core/model.py:135-210.  points [Bt,N,3] float32; returns dict of named outputs."""
+            knn_inds=None, trace=None):
+    """core/model.py:135-210.  points [Bt,N,3] float32; returns dict of named outputs.
+    trace (dict or None) collects the integer intermediates of the sampled levels (see flex_conv_dilate)."""
     points = np.ascontiguousarray(points, np.float32)
     outs = {"pointclouds": points}
     if knn_inds is not None:
@@ -172,7 +181,7 @@ def forward(points, w, detection=False, extract_global=False, knn_num=8, tp_eps=
     else:
         knn_indices, _ = knn_bruteforce_layer(np.ascontiguousarray(points.transpose(0, 2, 1)), knn_num)
     outs["knn_indices"] = knn_indices
-    newpoints, localdesc = backbone_local_dilate(points, knn_indices, w, tp_eps)
+    newpoints, localdesc = backbone_local_dilate(points, knn_indices, w, tp_eps, trace=trace)
     l2n = _l2_normalize(localdesc, 2, 1e-8)
     outs["feat"] = localdesc
     outs["feat_l2normed"] = l2n
@@ -183,7 +192,8 @@ def forward(points, w, detection=False, extract_global=False, knn_num=8, tp_eps=
         outs["xyz_feat_att"] = np.concatenate([newpoints, l2n, att], -1)
     if extract_global:
         _, forglobal = flex_conv_dilate(points, localdesc, 8, knn_num, [256], "global_before_assemble", w, tp_eps,
-                                        knn_indices=None, concat=False, upsample=True, add_se="")
+                                        knn_indices=None, concat=False, upsample=True, add_se="",
+                                        trace=trace)
         gatt = globalatt_block(forglobal, w, tp_eps)
         g = global_netvlad_block(forglobal, gatt, w, slim_eps)
         outs["forglobal"] = forglobal
