@@ -1,19 +1,29 @@
 #!/usr/bin/env python
 """Benchmark of the DH3D hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload local|global] [--no-cpu-baseline]
+    python bench.py --gpus N --steps K --warmup W [--workload local|global|cfg5|train] [--scaling weak|strong]
 
-A "step" is one forward of the hot path over one batch of synthetic clouds already resident in HBM:
-  local  (default, BASELINE config[1]): local-descriptor forward, basic_config, N=8192 K=8, batch 8 / GPU
-  global (BASELINE config[2])         : global-descriptor forward, global_config, N=4096, batch 32 / GPU
-One process per GPU (torchrun env), weak scaling over clouds, no data-path collective (clouds are
-independent); the timed region is bracketed by barrier + synchronize and the max over ranks is taken.
-Rank 0 prints ONE JSON line.  The step is a hipGraph replay of dh3d_amd.model.DH3D.forward.
+A "step" is one pass of the hot path over one batch of synthetic clouds already resident in HBM:
+  local  (default, BASELINE config[1]): local-descriptor forward, basic_config, N=8192 K=8, batch 8
+  global (BASELINE config[2])         : global-descriptor forward, global_config, N=4096, batch 32
+  cfg5   (BASELINE config[4])         : save_all dense feature map, detection_config, N=16384, batch 4
+                                        (localdesc_extract.py:65,146,166) + the flex_conv 128->128 K=12 kernel line
+  train  (BASELINE config[3])         : Siamese quadruplet training step, 1+2+18+1 clouds of N=4096
+One process per GPU over RCCL.  `--gpus N` with no torchrun environment re-launches itself under
+`python -m torch.distributed.run --nproc-per-node N` (127.0.0.1 rendezvous); under torchrun WORLD_SIZE must equal N.
+  --scaling weak   (default): the batch above PER GPU, clouds are independent -> no data-path collective;
+  --scaling strong          : the batch above IN TOTAL, ceil(B/N) clouds per GPU (SURVEY 8e "Expected scaling");
+  train is always strong (one role-ordered Siamese batch sharded over the ranks + descriptor all-gather).
+The timed region is bracketed by barrier + synchronize, the max over ranks is taken, rank 0 prints ONE JSON line.
+The forward step is a hipGraph replay of dh3d_amd.model.DH3D.forward.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -24,23 +34,47 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md)
 F32_MFMA_PEAK_TF = 157.3  # dense f32 MFMA = f32 vector peak
+BF16_MFMA_PEAK_TF = 2500.0
 
 WORKLOADS = {
     "local": dict(preset="basic_config", B=8, N=8192, seed=2002, out="xyz_feat",
-                  name="local-descriptor forward (basic_config), N=8192 K=8, batch=8 per GPU"),
+                  name="local-descriptor forward (basic_config), N=8192 K=8, batch=8"),
     "global": dict(preset="global_config", B=32, N=4096, seed=3003, out="globaldesc",
-                   name="global-descriptor forward (global_config), N=4096, 64-cluster NetVLAD, batch=32 per GPU"),
-    # BASELINE config[3]: NOT a default bench line; fixed total batch sharded over the ranks ("strong" scaling)
+                   name="global-descriptor forward (global_config), N=4096, 64-cluster NetVLAD, batch=32"),
+    "cfg5": dict(preset="detection_config", B=4, N=16384, seed=5005, out="xyz_feat_att",
+                 name="dense local feature map (save_all path, detection_config), N=16384 K=8, batch=4, device kNN"),
     "train": dict(preset="global_config", B=22, N=4096, seed=4004, out=None,
                   name="Siamese quadruplet training step, Oxford-shaped batch (1 anchor + 2 pos + 18 neg + 1 other-neg), "
                        "N=4096, frozen backbone, batch sharded over ranks + RCCL all-gather of descriptors"),
 }
 
 
-def build_model(preset, dev, seed=0):
+# --------------------------------------------------------------------------------------------- launch
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` without a torchrun environment: become the launcher (one rank per GPU)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execvpe(cmd[0], cmd, env)
+
+
+# --------------------------------------------------------------------------------------------- helpers
+def build_model(preset, dev, seed=0, num_points=None):
     from dh3d_amd import ConfigFactory
     from dh3d_amd.model import DH3D
-    m = DH3D(ConfigFactory(preset).getconfig()).init_synthetic(seed)
+    cfg = ConfigFactory(preset).getconfig()
+    if num_points:
+        cfg.num_points = num_points
+    m = DH3D(cfg).init_synthetic(seed)
     return m.to(dev).eval().prepare()
 
 
@@ -85,12 +119,17 @@ def event_time_ms(fn, iters=50, warm=5):
     return e0.elapsed_time(e1) / iters
 
 
-def flex_conv_roofline(dev, B=8, N=8192, K=8, Din=64, Dout=64):
-    """The kernel BASELINE.json names: flex_conv at N=8192, K=8 (stage-1 layer 64->64, batch 8).
-    Algorithmic figures per launch:
+# --------------------------------------------------------------------------------------------- roofline
+def flex_figures(B, N, K, Din, Dout):
+    """Algorithmic figures per launch:
       Bc = 4*[B*N*(Din+Dout+3+K) + 4*Din*Dout]   compulsory HBM bytes
       Bg = 4*B*N*[K*(Din+4)+3+Dout]              bytes requested by the gather (cache hierarchy)
       F  = 2*B*N*4*Din*(K+Dout)                  flops of the factorised form (gather-reduce + GEMM)"""
+    return (4.0 * (B * N * (Din + Dout + 3 + K) + 4 * Din * Dout), 4.0 * B * N * (K * (Din + 4) + 3 + Dout),
+            2.0 * B * N * 4 * Din * (K + Dout))
+
+
+def _flex_inputs(dev, B, N, K, Din, Dout):
     from dh3d_amd import pm
     g = torch.Generator(device="cpu").manual_seed(1)
     xyz = torch.rand(B, N, 3, generator=g).to(dev)
@@ -98,6 +137,71 @@ def flex_conv_roofline(dev, B=8, N=8192, K=8, Din=64, Dout=64):
     nbr, _ = pm.knn_xyz(xyz, K)
     theta = (torch.randn(3, Din, Dout, generator=g) / Din ** 0.5).to(dev)
     bias = (torch.randn(Din, Dout, generator=g) / (8 * Din) ** 0.5).to(dev)
+    return xyz, f, nbr, theta, bias
+
+
+def three_fractions(ms, B, N, K, Din, Dout):
+    Bc, Bg, F = flex_figures(B, N, K, Din, Dout)
+    t = ms * 1e-3
+    return {"launch_ms": ms, "algorithmic_bytes": Bc,
+            "strict_hbm": {"achieved": Bc / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": Bc / t / 1e9 / HBM_PEAK_GBS},
+            "gather_effective": {"achieved": Bg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": Bg / t / 1e9 / HBM_PEAK_GBS, "bytes": Bg},
+            "f32_equivalent_flops": {"achieved": F / t / 1e12, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                                     "frac": F / t / 1e12 / F32_MFMA_PEAK_TF, "flops": F}}
+
+
+def live_pmc_traffic(timeout=240):
+    """HBM bytes per launch of the roofline kernel from rocprofv3 PMC counters, collected NOW on this box: two separate
+    --pmc passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only, the guide's recipe) over tools/flex_conv_pmc.py, the
+    FETCH correction calibrated on a 64 MiB device copy in the same run (gfx950 tallies wide streaming reads at 1/2).
+    Returns (bytes or None, source string)."""
+    import shutil
+    import sqlite3
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 not on PATH"
+    vals, cal = {}, {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="dh3d_pmc_", dir="/tmp")
+            env = dict(os.environ, PYTHONPATH=ROOT, TMPDIR="/tmp")
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)
+            subprocess.run(["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", d, "-o", "p", "--",
+                            sys.executable, os.path.join(ROOT, "tools", "flex_conv_pmc.py")],
+                           cwd="/tmp", env=env, timeout=timeout, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            db = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
+            if not db:
+                return None, "rocprofv3 --pmc %s produced no database" % counter
+            c = sqlite3.connect(db[0])
+            rows = c.execute("select name, avg(counter_value), max(counter_value) from pmc_events where counter_name=? "
+                             "group by name", (counter,)).fetchall()
+            for name, avg, mx in rows:
+                if "flex_conv_x6_kernel" in name:
+                    vals[counter] = avg
+                if "copyBuffer" in name:
+                    cal[counter] = mx
+            shutil.rmtree(d, ignore_errors=True)
+        if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+            return None, "kernel not found in the PMC tables"
+        fcorr = 65536.0 / cal["FETCH_SIZE"] if cal.get("FETCH_SIZE") else 2.0
+        wcorr = 65536.0 / cal["WRITE_SIZE"] if cal.get("WRITE_SIZE") else 1.0
+        if not (1.8 < fcorr < 2.2):
+            fcorr = 2.0
+        if not (0.9 < wcorr < 1.1):
+            wcorr = 1.0
+        total = (vals["FETCH_SIZE"] * fcorr + vals["WRITE_SIZE"] * wcorr) * 1024.0
+        return total, ("live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) in this "
+                       "run; raw %.1f KB x %.2f + %.1f KB x %.2f (corrections calibrated on a 64 MiB copy)"
+                       % (vals["FETCH_SIZE"], fcorr, vals["WRITE_SIZE"], wcorr))
+    except Exception as e:  # noqa: BLE001  (measurement aid: never fail the bench line)
+        return None, "live PMC failed: %r" % (e,)
+
+
+def flex_conv_roofline(dev, in_step_ms=None, pmc=True, B=8, N=8192, K=8, Din=64, Dout=64):
+    """The kernel BASELINE.json names: flex_conv at N=8192, K=8 (stage-1 layer 64->64, batch 8)."""
+    from dh3d_amd import pm
+    xyz, f, nbr, theta, bias = _flex_inputs(dev, B, N, K, Din, Dout)
     wp = pm.pack_flex_weight(theta, bias)
     wp3 = pm.pack_flex_weight_x3(theta, bias)
     fb = torch.zeros(Dout, device=dev)
@@ -107,27 +211,72 @@ def flex_conv_roofline(dev, B=8, N=8192, K=8, Din=64, Dout=64):
                                                act=pm.ACT_RELU))
     ms_f32 = event_time_ms(lambda: pm.flex_conv(f, xyz, nbr, wp, Dout, pre_bias=fb, scale=fb + 1, shift=fb,
                                                 act=pm.ACT_RELU))
-    t = ms * 1e-3
-    Bc = 4.0 * (B * N * (Din + Dout + 3 + K) + 4 * Din * Dout)
-    Bg = 4.0 * B * N * (K * (Din + 4) + 3 + Dout)
-    F = 2.0 * B * N * 4 * Din * (K + Dout)
-    traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "pmc_flex_conv.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-    if os.path.isfile(pmc):
-        rec = json.load(open(pmc))
-        traffic, traffic_src = rec["hbm_bytes_per_launch"], rec["source"]
-    return {
-        "traffic_source": traffic_src,
+    fr = three_fractions(ms, B, N, K, Din, Dout)
+    traffic, src = (None, "skipped (--no-pmc)")
+    if pmc:
+        traffic, src = live_pmc_traffic()
+    if traffic is None:
+        static = os.path.join(ROOT, "profiles", "pmc_flex_conv.json")
+        if os.path.isfile(static):
+            rec = json.load(open(static))
+            traffic, src = rec["hbm_bytes_per_launch"], "STATIC (%s); live attempt: %s" % (rec["source"], src)
+    out = {
         "bound": "hbm", "kernel": "flex_conv_x6_kernel<%d,%d> B=%d N=%d K=%d" % (Din, Dout, B, N, K),
+        "achieved": fr["strict_hbm"]["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fr["strict_hbm"]["frac"],
+        "traffic": traffic, "traffic_source": src, "launch_ms": ms, "algorithmic_bytes": fr["algorithmic_bytes"],
         "launch_ms_f32_mfma_kernel": ms_f32,
-        "achieved": Bc / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": Bc / t / 1e9 / HBM_PEAK_GBS,
-        "traffic": traffic, "launch_ms": ms, "algorithmic_bytes": Bc,
-        "gather_effective": {"achieved": Bg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": Bg / t / 1e9 / HBM_PEAK_GBS, "bytes": Bg},
-        "f32_equivalent_flops": {"achieved": F / t / 1e12, "unit": "TFLOP/s", "flops": F,
-                                 "note": "factorised-form flops / time; runs as 6 bf16 MFMA products per f32 product"},
-        "binding_roof": "SIMD issue + FP32-VALU/MFMA exclusion (DESIGN.md: measured with tools/coissue_probe.hip)",
+        "gather_effective": fr["gather_effective"], "f32_equivalent_flops": fr["f32_equivalent_flops"],
+        "binding_roof": "SIMD issue + FP32-VALU/MFMA exclusion (DESIGN.md 3.1)",
     }
+    if in_step_ms is not None:
+        Bc = fr["algorithmic_bytes"]
+        out["in_step"] = {"launch_ms": in_step_ms, "frac": Bc / (in_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "note": "the same kernel timed with HIP events on its own stream inside the local forward "
+                                  "(FPS running beside it on the other stream)"}
+    return out
+
+
+def flex_in_step_ms(dev, reps=10):
+    """Duration of the stage-1 flex_conv 64->64 launch INSIDE the local forward (events on the stream it runs on)."""
+    from dh3d_amd import pm
+    wl = WORKLOADS["local"]
+    model = build_model(wl["preset"], dev, seed=0)
+    pts = synthetic_clouds(wl["B"], wl["N"], wl["seed"], dev)
+    orig = pm.flex_conv_x6
+    rec = []
+
+    def timed(features, *a, **kw):
+        if features.shape[-1] == 64 and features.shape[1] == wl["N"]:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig(features, *a, **kw)
+            e1.record()
+            rec.append((e0, e1))
+            return out
+        return orig(features, *a, **kw)
+    pm.flex_conv_x6 = timed
+    try:
+        with torch.no_grad():
+            for _ in range(reps + 2):
+                model(pts, fetch=(wl["out"],))
+        torch.cuda.synchronize(dev)
+    finally:
+        pm.flex_conv_x6 = orig
+    ts = [a.elapsed_time(b) for a, b in rec[2:]]
+    return sum(ts) / max(len(ts), 1)
+
+
+def cfg5_kernel_line(dev):
+    """BASELINE config[4]'s kernel: flex_conv 128->128 at B=1, N=16384, K=12 (three fractions)."""
+    from dh3d_amd import pm
+    B, N, K, Din, Dout = 1, 16384, 12, 128, 128
+    xyz, f, nbr, theta, bias = _flex_inputs(dev, B, N, K, Din, Dout)
+    wp = pm.pack_flex_weight(theta, bias)
+    fb = torch.zeros(Dout, device=dev)
+    ms = event_time_ms(lambda: pm.flex_conv(f, xyz, nbr, wp, Dout, pre_bias=fb, scale=fb + 1, shift=fb, act=pm.ACT_RELU))
+    out = three_fractions(ms, B, N, K, Din, Dout)
+    out["kernel"] = "flex_conv_pm_kernel<128,128> B=1 N=16384 K=12 (exact-f32 MFMA)"
+    return out
 
 
 def kernel_breakdown(dev, B, N):
@@ -135,10 +284,8 @@ def kernel_breakdown(dev, B, N):
     from dh3d_amd import pm, ops
     xyz = torch.rand(B, N, 3, device=dev)
     out = {}
-    # drop-in operators (any input order) ...
     out["knn_xyz K=8"] = event_time_ms(lambda: pm.knn_xyz(xyz, 8), iters=10, warm=2)
     out["fps N->N/8"] = event_time_ms(lambda: ops.farthest_point_sample(N // 8, xyz), iters=5, warm=1)
-    # ... and what the model runs: Morton order once, then the box-pruned search and the batched-round FPS on it
     out["spatial_sort"] = event_time_ms(lambda: pm.spatial_sort(xyz), iters=10, warm=2)
     srt, gbox = pm.spatial_sort(xyz)
     out["knn_sorted K=8"] = event_time_ms(lambda: pm.knn_sorted(srt, gbox, 8), iters=10, warm=2)
@@ -149,48 +296,120 @@ def kernel_breakdown(dev, B, N):
     return out
 
 
+def dropin_ops_line(dev):
+    """The reference-signature operators (section A of the C ABI, channels-first [B,C,N]) at the roofline shape, beside
+    the fused point-major kernel: what a TF-side integrator following INTEGRATION.md gets."""
+    from dh3d_amd import ops, pm
+    B, N, K, Din, Dout = 8, 8192, 8, 64, 64
+    xyz, f, nbr, theta, bias = _flex_inputs(dev, B, N, K, Din, Dout)
+    f_cf, p_cf = f.transpose(1, 2).contiguous(), xyz.transpose(1, 2).contiguous()
+    nbr_cf = nbr.transpose(1, 2).contiguous()
+    out = {}
+    with torch.no_grad():
+        out["ops.flex_convolution 64->64 fwd"] = event_time_ms(
+            lambda: ops.flex_convolution(f_cf, p_cf, nbr_cf, theta, bias), iters=10, warm=2)
+        out["ops.flex_pooling D=64 fwd"] = event_time_ms(lambda: ops.flex_pooling(f_cf, nbr_cf), iters=10, warm=2)
+        th0, b0 = torch.randn(3, 32, device=dev), torch.randn(32, device=dev)
+        out["ops.convolution_pointset 3->32 fwd"] = event_time_ms(
+            lambda: ops.convolution_pointset(p_cf, nbr_cf, th0, b0), iters=10, warm=2)
+        wp3 = pm.pack_flex_weight_x3(theta, bias)
+        out["pm.flex_conv_x6 64->64 fwd"] = event_time_ms(lambda: pm.flex_conv_x6(f, xyz, nbr, wp3, Dout), iters=20)
+    return out
+
+
+# --------------------------------------------------------------------------------------------- CPU baseline
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(workload):
-    """The CPU oracle (numpy graph + C ops, oracle/) on ONE cloud of the workload, one core."""
-    from oracle import model_np
-    from dh3d_amd.model import tf_variable_name
-    wl = WORKLOADS[workload]
+    """The CPU oracle (numpy graph + C ops, oracle/) on the workload's clouds: single thread, and one single-threaded
+    process per host core.  A reported baseline ("port"), never the thing measured as `value`."""
     from dh3d_amd import ConfigFactory
-    from dh3d_amd.model import DH3D
+    from dh3d_amd.model import DH3D, tf_variable_name
+    wl = WORKLOADS[workload]
     model = DH3D(ConfigFactory(wl["preset"]).getconfig()).init_synthetic(0)
     w = {tf_variable_name(k): v.detach().numpy() for k, v in model.state_dict().items()}
-    n = 8  # bounded sample: ~10-20 s of single-core work
-    pts = np.random.default_rng(wl["seed"]).random((n, wl["N"], 3), dtype=np.float32)
-    torch.set_num_threads(1)
+    tmp = tempfile.mkdtemp(prefix="dh3d_cpu_", dir="/tmp")
+    path = os.path.join(tmp, "w.npz")
+    np.savez(path, **w)
+    glob = "1" if workload == "global" else "0"
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+
+    def worker(count, seed):
+        return subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", path, str(wl["N"]), str(count), str(seed), glob],
+                                cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    n1 = 4  # bounded sample: ~10-20 s of single-core work
+    p = worker(n1, wl["seed"])
+    t1 = float(p.communicate()[0].strip() or "nan")
+    cores = os.cpu_count() or 1
     t0 = time.perf_counter()
-    model_np.forward(pts, w, detection=False, extract_global=(workload == "global"))
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "point-clouds/sec", "cores": 1, "kind": "port",
-            "sample": "%d clouds of N=%d through oracle/model_np.forward (C oracle ops, single thread + numpy dense), "
-                      "%.1f s" % (n, wl["N"], dt), "host_cpus": os.cpu_count()}
+    procs = [worker(1, wl["seed"] + 1 + i) for i in range(cores)]
+    inner = [float(q.communicate()[0].strip() or "nan") for q in procs]
+    wall = time.perf_counter() - t0
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    return {"value": n1 / t1, "unit": "point-clouds/sec", "cores": 1, "kind": "port",
+            "sample": "%d clouds of N=%d through oracle/model_np.forward (C oracle ops + numpy dense, one thread), %.1f s"
+                      % (n1, wl["N"], t1),
+            "all_cores": {"value": cores / wall, "unit": "point-clouds/sec", "cores": cores,
+                          "sample": "one single-threaded oracle process per host core, one cloud each, wall %.1f s "
+                                    "(process start included; slowest worker's compute %.1f s)" % (wall, np.nanmax(inner))},
+            "cpu_model": cpu_model_string(), "host_cpus": cores}
 
 
+# --------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="local")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--batch", type=int, default=0, help="override the workload's batch (clouds)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip roofline / breakdown / second workload")
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline / breakdown / other workloads")
+    ap.add_argument("--no-pmc", action="store_true", help="do not collect live PMC traffic for the roofline kernel")
     ap.add_argument("--inflight", type=int, default=1,
                     help="independent steps in flight (graph instances on separate streams, each with its own batch "
                          "buffers): a serving loop's overlap of consecutive batches.  Default 1 = one step at a time")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        relaunch_under_torchrun(args.gpus)  # does not return
 
     from dh3d_amd import dist as D
     rank, world = D.init_from_env()
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or drop the torchrun "
+                         "environment and let bench.py spawn the ranks itself)" % (args.gpus, world, args.gpus))
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d has no GPU (device_count=%d)" % (local_rank, torch.cuda.device_count()))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+    ranks_seen = 1
+    if world > 1:
+        one = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(one)  # over RCCL: every rank is alive on its own GPU
+        ranks_seen = int(one.item())
+    strong = args.scaling == "strong" or args.workload == "train"
+
+    def per_rank_batch(B):
+        if not strong:
+            return B, B * world
+        per = (B + world - 1) // world
+        return per, B
 
     def measure_train():
         from dh3d_amd import ConfigFactory
@@ -203,30 +422,31 @@ def main():
         trainer = QuadrupletTrainer(model)
         pts = synthetic_clouds(wl["B"], wl["N"], wl["seed"], dev, 0)  # same role-ordered batch on every rank
         dt = time_steps(lambda p: trainer.step(p), pts, args.steps, args.warmup, dev)
-        return wl["B"] * args.steps / dt, dt / args.steps * 1e3
+        extra = {"phases_ms": trainer.phase_times_ms()} if hasattr(trainer, "phase_times_ms") else {}
+        return wl["B"] * args.steps / dt, dt / args.steps * 1e3, extra
 
-    def measure(workload):
+    def measure(workload, batch=None):
         if workload == "train":
             return measure_train()
         wl = WORKLOADS[workload]
-        model = build_model(wl["preset"], dev, seed=0)
-        pts = synthetic_clouds(wl["B"], wl["N"], wl["seed"], dev, rank)
+        per, total = per_rank_batch(batch or (args.batch if workload == args.workload and args.batch else wl["B"]))
+        model = build_model(wl["preset"], dev, seed=0, num_points=wl["N"])
+        pts = synthetic_clouds(per, wl["N"], wl["seed"], dev, rank)
         with torch.no_grad():
             run = model.graphed(pts, outputs=(wl["out"],))
             # the batch is resident in the graph's input buffer (where a loader's H2D copy would put it)
             run.static_input.copy_(pts)
             dt = time_steps(run, run.static_input, args.steps, args.warmup, dev)
-        clouds = wl["B"] * world * args.steps
-        return clouds / dt, dt / args.steps * 1e3
+        return total * args.steps / dt, dt / args.steps * 1e3, {"clouds_per_gpu": per}
 
     def measure_in_flight(workload, depth=2):
         """Throughput with `depth` independent steps in flight (graph instances on separate streams, every step still
-        one full pass over one batch).  A step of this path leaves most of the GPU idle (FPS: one CU per cloud, two
-        thirds of the local step), so a serving loop overlaps consecutive batches.  The default `value` stays the
-        one-step-at-a-time number; `--inflight` makes this the measured mode."""
+        one full pass over one batch).  A step of this path leaves most of the GPU idle (FPS: a few CUs per cloud), so a
+        serving loop overlaps consecutive batches.  The default `value` stays the one-step-at-a-time number."""
         wl = WORKLOADS[workload]
-        model = build_model(wl["preset"], dev, seed=0)
-        pts = synthetic_clouds(wl["B"], wl["N"], wl["seed"], dev, rank)
+        per, total = per_rank_batch(wl["B"])
+        model = build_model(wl["preset"], dev, seed=0, num_points=wl["N"])
+        pts = synthetic_clouds(per, wl["N"], wl["seed"], dev, rank)
         streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
         with torch.no_grad():
             runs = [model.graphed(pts, outputs=(wl["out"],)) for _ in range(depth)]
@@ -241,44 +461,74 @@ def main():
             for st in streams:
                 st.wait_stream(torch.cuda.current_stream())
             dt = time_steps(step, pts, args.steps, args.warmup, dev)
-        return wl["B"] * world * args.steps / dt, dt / args.steps * 1e3
+        return total * args.steps / dt, dt / args.steps * 1e3
 
     if args.inflight > 1 and args.workload != "train":
         value, ms = measure_in_flight(args.workload, args.inflight)
+        info = {}
     else:
-        value, ms = measure(args.workload)
+        value, ms, info = measure(args.workload)
     wl = WORKLOADS[args.workload]
+    per, total = per_rank_batch(args.batch or wl["B"])
     line = {
         "metric": "point-clouds/sec", "value": value, "unit": "point-clouds/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-        "scaling": "strong" if args.workload == "train" else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": wl["name"], "clouds_per_gpu": wl["B"], "points": wl["N"], "knn": 8,
+        "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "ranks_seen": ranks_seen,
+        "config": {"workload": wl["name"], "clouds_per_gpu": per, "clouds_total": total, "points": wl["N"], "knn": 8,
                    "parallelism": "clouds sharded over %d GPU(s), no data-path collective" % world,
                    "weights": "random-init (no checkpoint blobs exist upstream)", "execution": "hipGraph replay",
                    "steps_in_flight": args.inflight if args.workload != "train" else 1},
     }
     if args.workload == "train":
-        line["config"]["execution"] = "eager (fused HIP backbone + autograd head)"
-        args.no_extras = True
-        args.no_cpu_baseline = True
-    if rank == 0 and not args.no_extras:
+        line["config"]["execution"] = "eager: fused HIP backbone (no grad) + trainable global head fwd/bwd"
+        line["config"]["parallelism"] = ("one role-ordered batch sharded over %d GPU(s); all-gather of [clouds,256] "
+                                         "descriptors + SUM all-reduce of head gradients over RCCL" % world)
+        line.update(info)
+    extras = rank == 0 and not args.no_extras and args.workload in ("local", "global")
+    if extras:
         with torch.no_grad():
-            line["roofline"] = flex_conv_roofline(dev)
+            in_step = flex_in_step_ms(dev)
+            line["roofline"] = flex_conv_roofline(dev, in_step_ms=in_step, pmc=(not args.no_pmc and world == 1))
             line["kernels_ms"] = kernel_breakdown(dev, wl["B"], wl["N"])
-        if world == 1:
-            other = "global" if args.workload == "local" else "local"
-            ov, oms = measure(other)
-            line["other_workload"] = {"workload": WORKLOADS[other]["name"], "value": ov,
-                                      "unit": "point-clouds/sec", "ms_per_step": oms}
-            pv, pms = measure_in_flight(args.workload, 2)
-            line["two_steps_in_flight"] = {"value": pv, "unit": "point-clouds/sec", "ms_per_step": pms,
-                                           "note": "informational: consecutive batches overlapped on two streams; "
-                                                   "`value` is measured one step at a time"}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            if world == 1:
+                line["dropin_ops_ms"] = dropin_ops_line(dev)
+    if extras and world == 1:
+        others = []
+        for other in ("local", "global", "cfg5", "train"):
+            if other == args.workload:
+                continue
+            ov, oms, oinfo = measure(other, batch=WORKLOADS[other]["B"])
+            rec = {"workload": WORKLOADS[other]["name"], "key": other, "value": ov, "unit": "point-clouds/sec",
+                   "ms_per_step": oms}
+            rec.update(oinfo)
+            if other == "cfg5":
+                with torch.no_grad():
+                    rec["kernel_roofline"] = cfg5_kernel_line(dev)
+            others.append(rec)
+        line["other_workloads"] = others
+        line["other_workload"] = others[0]  # round-1 key, kept for the driver's diff
+        pv, pms = measure_in_flight(args.workload, 2)
+        line["two_steps_in_flight"] = {"value": pv, "unit": "point-clouds/sec", "ms_per_step": pms,
+                                       "note": "informational: consecutive batches overlapped on two streams; "
+                                               "`value` is measured one step at a time"}
+        # per-GPU throughput against the local batch: what `--scaling strong` gives each GPU at 8 / 4 / 2 GPUs
+        # (SURVEY 8e "Expected scaling": the FPS / kNN latency chain does not shrink with the batch)
+        sweep = []
+        for b in (wl["B"], wl["B"] // 2, wl["B"] // 4, wl["B"] // 8):
+            if b >= 1:
+                v, m_, _ = measure(args.workload, batch=b)
+                sweep.append({"clouds_per_gpu": b, "value": v, "ms_per_step": m_})
+        line["batch_sweep_1gpu"] = {"workload": args.workload, "points": sweep,
+                                    "predicted_strong_scaling_8gpu": (8 * sweep[-1]["value"] / sweep[0]["value"])
+                                    if len(sweep) == 4 else None}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("local", "global"):
         line["cpu_baseline"] = cpu_baseline(args.workload)
     D.barrier()
     if rank == 0:
         print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -77,17 +77,34 @@ class Conv2D1x1(nn.Module):
         p = {"W2": W2, "b": self.b.detach().contiguous()}
         if self.cout % 64 == 0 and self.cin % 8 == 0:
             p["wp"] = pm.pack_weight(W2)
+        elif self.cin % 8 == 0 and self.cout > 1:
+            # narrow outputs (final_fc with featdim < 128, backbones.py:125-126): the GEMM runs on zero-padded columns
+            # and the caller's view drops them
+            pad = (-self.cout) % 64
+            p["pad"] = pad
+            p["wp"] = pm.pack_weight(torch.cat([W2, W2.new_zeros(self.cin, pad)], 1).contiguous())
         if self.cout in (128, 256) and self.cin % 32 == 0:
             p["wp3"] = pm.pack_weight_x3(W2)  # large row counts go to the tiled bf16x6 GEMM
         if self.bn is not None:
             p["scale"], p["shift"] = [t.detach() for t in self.bn.fold()]
         else:
             p["scale"], p["shift"] = None, None
+        if p.get("pad"):
+            z = W2.new_zeros(p["pad"])
+            p["b"] = torch.cat([p["b"], z])
+            if p["scale"] is not None:
+                p["scale"], p["shift"] = torch.cat([p["scale"], z + 1]), torch.cat([p["shift"], z])
         self._prep = p
         return p
 
     def forward(self, x, x2=None, act=pm.ACT_RELU, residual=None):
         p = self._prep or self.prepare()
+        if p.get("pad"):
+            if residual is not None:
+                raise NotImplementedError("residual with a padded 1x1 conv")
+            y = pm.linear(x, p["wp"], self.cout + p["pad"], x2=x2, pre_bias=p["b"], scale=p["scale"],
+                          shift=p["shift"], act=act)
+            return y[..., :self.cout].contiguous()
         # the choice depends on the points per cloud only, never on the batch: a sharded batch must reproduce the
         # unsharded result bit for bit
         per_cloud = x.shape[-2] if x.dim() >= 2 else 1
@@ -279,8 +296,9 @@ class FlexConvDilate(nn.Module):
     def __init__(self, cin, outdims, dilate, knn=8, concat=True, add_se="max_pool", upsample=True,
                  bn_eps=1e-5):
         super().__init__()
-        if add_se not in ("max_pool", ""):
-            raise NotImplementedError("add_se=%r: only 'max_pool' / '' are used by the shipped backbones" % add_se)
+        if add_se not in ("max_pool", "avg_pool", ""):
+            raise ValueError("add_se=%r (core/backbones.py:76-86 knows 'max_pool', 'avg_pool', anything else = none)"
+                             % add_se)
         self.cin, self.outdims, self.dilate, self.knn = cin, list(outdims), dilate, knn
         self.concat, self.add_se, self.upsample = concat, add_se, upsample
         c = cin
@@ -288,7 +306,7 @@ class FlexConvDilate(nn.Module):
             setattr(self, "flexconv_%d" % i, FlexConvParams(c, d))
             setattr(self, "flexconv_%d_bn" % i, TPBatchNorm(d, bn_eps))
             c = d
-        if add_se == "max_pool":
+        if add_se in ("max_pool", "avg_pool"):
             self.se = SEBlock(outdims[-1])
         if concat:
             self.concat_conv1d = FeatureConv1d(outdims[-1] + cin, outdims[-1], bn=True, bn_eps=bn_eps)
@@ -309,7 +327,7 @@ class FlexConvDilate(nn.Module):
                 "scale": scale, "shift": shift, "dout": d,
             })
         self._prep = prep
-        if self.add_se == "max_pool":
+        if self.add_se in ("max_pool", "avg_pool"):
             self.se.prepare()
         if self.concat:
             self.concat_conv1d.tfconv0.prepare()
@@ -340,6 +358,8 @@ class FlexConvDilate(nn.Module):
                                                           act=pm.ACT_RELU)
         if self.add_se == "max_pool":
             x = self.se(x, pm.flex_pool(x, nbr_s))
+        elif self.add_se == "avg_pool":  # flex_avg (theta 0, bias eye: the neighbour sum) * 1/knn, backbones.py:80-83
+            x = self.se(x, pm.flex_avg(x, nbr_s, 1.0 / self.knn))
         if self.upsample and self.dilate > 1:
             self._last_coarse = (x, lv)  # the level's features before up-sampling (PointMLPHead.forward_interpolated)
             geo.finish(lv)
@@ -368,8 +388,10 @@ class BackboneLocalDilate(nn.Module):
 
     def __init__(self, featdim=128, dilate2=8, bn_eps=1e-5):
         super().__init__()
-        if featdim != 128:
-            raise NotImplementedError("featdim < 128 ('final_fc') is not used by the shipped configs")
+        if featdim > 128 or featdim < 4 or featdim % 4:
+            raise ValueError("featdim must be a multiple of 4 in [4, 128] (core/backbones.py:125: featdim < 128 adds "
+                             "'final_fc', larger values leave the 128-d descriptor as it is upstream)")
+        self.featdim = featdim
         self.initconv = nn.Module()
         limit = math.sqrt(6.0 / (3 + 32))
         self.initconv.position_theta = nn.Parameter(torch.empty(3, 32).uniform_(-limit, limit))
@@ -380,6 +402,8 @@ class BackboneLocalDilate(nn.Module):
         self.stage2 = FlexConvDilate(64, [128, 128], dilate=dilate2, knn=8, concat=True, add_se="max_pool",
                                      bn_eps=bn_eps)
         self.local_stage1_shortcut = FeatureConv1d(64, 128, bn=True, bn_eps=bn_eps)
+        if featdim < 128:  # backbones.py:125-126: feature_conv1d_1(feat, featdim, 'final_fc') -- Conv2D + BNReLU
+            self.final_fc = FeatureConv1d(128, featdim, bn=True, bn_eps=bn_eps)
         self._prep = None
 
     def prepare(self):
@@ -391,6 +415,8 @@ class BackboneLocalDilate(nn.Module):
         self.stage2.prepare()
         self.local_stage1_shortcut.tfconv0.prepare()
         self.stage2.concat_conv1d.tfconv0.fuse_shortcut(self.local_stage1_shortcut.tfconv0)
+        if self.featdim < 128:
+            self.final_fc.tfconv0.prepare()
         return self._prep
 
     def forward(self, geo):
@@ -405,6 +431,8 @@ class BackboneLocalDilate(nn.Module):
         # the farthest-point sampling that stage 2 waits for, and the sum is folded into stage 2's last store.
         shortcut = self.local_stage1_shortcut(x1, act=pm.ACT_RELU)
         feat = self.stage2(geo, x2, residual=shortcut)
+        if self.featdim < 128:
+            feat = self.final_fc(feat, act=pm.ACT_RELU)
         return geo.xyz, feat
 
 
@@ -471,29 +499,44 @@ class NetVLAD(nn.Module):
     def __init__(self, feature_size=256, cluster_size=64, output_dim=256, add_batch_norm=True, gating=True,
                  slim_bn_eps=1e-3):
         super().__init__()
-        if not (add_batch_norm and gating):
-            raise NotImplementedError("shipped configs use add_batch_norm=True, gating=True")
         D, C, O = feature_size, cluster_size, output_dim
         self.D, self.C, self.O = D, C, O
+        self.add_batch_norm, self.gating = bool(add_batch_norm), bool(gating)
         self.cluster_weights = nn.Parameter(torch.randn(D, C) / math.sqrt(D))
-        self.cluster_bn = SlimBatchNorm(C, slim_bn_eps)
+        if add_batch_norm:
+            self.cluster_bn = SlimBatchNorm(C, slim_bn_eps)
+        else:  # backbones.py:224-229
+            self.cluster_biases = nn.Parameter(torch.randn(C) / math.sqrt(D))
         self.cluster_weights2 = nn.Parameter(torch.randn(1, D, C) / math.sqrt(D))
         self.hidden1_weights = nn.Parameter(torch.randn(C * D, O) / math.sqrt(C))
-        self.bn = SlimBatchNorm(O, slim_bn_eps)
-        self.gating_weights = nn.Parameter(torch.randn(O, O) / math.sqrt(O))
-        self.gating_bn = SlimBatchNorm(O, slim_bn_eps)
+        self.bn = SlimBatchNorm(O, slim_bn_eps)  # 'bn' is applied whatever add_batch_norm says (backbones.py:270-274)
+        if gating:
+            self.gating_weights = nn.Parameter(torch.randn(O, O) / math.sqrt(O))
+            if add_batch_norm:
+                self.gating_bn = SlimBatchNorm(O, slim_bn_eps)
+            else:  # backbones.py:310-314
+                self.gating_biases = nn.Parameter(torch.randn(O) / math.sqrt(O))
         self._prep = None
 
     def prepare(self):
-        cs, ch = [t.detach() for t in self.cluster_bn.fold()]
+        if self.add_batch_norm:
+            cs, ch = [t.detach() for t in self.cluster_bn.fold()]
+        else:  # "+ bias" is the folded form with unit scale
+            cs, ch = torch.ones_like(self.cluster_biases.detach()), self.cluster_biases.detach().contiguous()
         s1, h1 = [t.detach() for t in self.bn.fold()]
-        s2, h2 = [t.detach() for t in self.gating_bn.fold()]
+        Wg = s2 = h2 = None
+        if self.gating:
+            Wg = self.gating_weights.detach().contiguous()
+            if self.add_batch_norm:
+                s2, h2 = [t.detach() for t in self.gating_bn.fold()]
+            else:
+                s2, h2 = torch.ones_like(self.gating_biases.detach()), self.gating_biases.detach().contiguous()
         self._prep = {
             "wc": pm.pack_weight(self.cluster_weights.detach().contiguous()),
             "cs": cs, "ch": ch,
             "W2": self.cluster_weights2.detach().reshape(self.D, self.C).contiguous(),
             "Wh": self.hidden1_weights.detach().contiguous(), "s1": s1, "h1": h1,
-            "Wg": self.gating_weights.detach().contiguous(), "s2": s2, "h2": h2,
+            "Wg": Wg, "s2": s2, "h2": h2,
         }
         return self._prep
 

@@ -226,6 +226,32 @@ __global__ __launch_bounds__(256) void flex_pool_pm_kernel(const float *__restri
   }
 }
 
+// ------------------------------------------------------------------ flex_avg (neighbour sum)
+// Flex_Avg (core/layers.py:342-436) is flex_conv with theta = 0 (non-trainable) and bias = eye(Dout): every other
+// term of FlexConv's sum is an exact 0*f, what is left is out[n,c] = sum_k f[nbr[n,k],c] in neighbour order; the
+// caller's factor (backbones.py:82: 1/knn) is applied to the finished sum, as upstream.
+__global__ __launch_bounds__(256) void flex_avg_pm_kernel(const float *__restrict__ feat,
+                                                         const int32_t *__restrict__ nbr, long long R, int N,
+                                                         int K, int C, float scale, float *__restrict__ out) {
+  const int cv = C / 4;
+  const long long total = R * cv;
+  for (long long e = (long long)dh3d_xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x; e < total;
+       e += (long long)gridDim.x * 256) {
+    const long long n = e / cv;
+    const int c4 = (int)(e - n * cv) * 4;
+    const long long cloud0 = (n / N) * N;
+    const int32_t *nb = nbr + n * K;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int k = 0; k < K; ++k) {
+      const float4 v = *reinterpret_cast<const float4 *>(feat + (cloud0 + nb[k]) * C + c4);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
+    *reinterpret_cast<float4 *>(out + n * C + c4) = acc;
+  }
+}
+
 // ------------------------------------------------------------------ conv_pointset on coordinates
 // out[n,o] = sum_k sum_i theta[i,o]*(x[nk,i]-x[n0,i]) + bias[o]  (conv_pointset_kernel.cc:46-64), Din=3.
 // One lane per point: the K neighbour offsets are gathered ONCE (the first version used Dout/4 lanes per point,
@@ -356,6 +382,16 @@ DH3D_API int dh3d_flex_pool_pm_fwd(const float *features, const int32_t *nbr, in
   const long long R = (long long)B * N;
   hipLaunchKernelGGL(flex_pool_pm_kernel, dim3(flat_grid(R * (C / 4))), dim3(256), 0, (hipStream_t)stream,
                      features, nbr, R, N, K, C, out, argmax);
+  return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_flex_avg_pm_fwd(const float *features, const int32_t *nbr, int B, int N, int K, int C,
+                                  float scale, float *out, void *stream) {
+  DH3D_REQUIRE(features && nbr && out && B > 0 && N > 0 && K > 0 && C > 0);
+  DH3D_SUPPORTED(C % 4 == 0);
+  const long long R = (long long)B * N;
+  hipLaunchKernelGGL(flex_avg_pm_kernel, dim3(flat_grid(R * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                     features, nbr, R, N, K, C, scale, out);
   return dh3d_launch_status();
 }
 

@@ -336,7 +336,8 @@ __global__ __launch_bounds__(1024) void netvlad_gate(const float *__restrict__ p
   h = fmaf(h, bn1_scale[o], bn1_shift[o]);
   if (q == 0) s_h[o] = h;
   __syncthreads();
-  {
+  float v = h;
+  if (Wg) {  // context gating (backbones.py:276-277,282-320); Wg == nullptr: gating=False
     float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
     const int j0 = q * (256 / 4);
     for (int j = j0; j < j0 + 256 / 4; j += 4) {
@@ -347,11 +348,11 @@ __global__ __launch_bounds__(1024) void netvlad_gate(const float *__restrict__ p
     }
     __syncthreads();  // s_q is reused
     s_q[q][o] = (g0 + g1) + (g2 + g3);
+    __syncthreads();
+    float g = (s_q[0][o] + s_q[1][o]) + (s_q[2][o] + s_q[3][o]);
+    g = fmaf(g, bn2_scale[o], bn2_shift[o]);
+    v = h * (1.f / (1.f + expf(-g)));  // every quarter holds the same value
   }
-  __syncthreads();
-  float g = (s_q[0][o] + s_q[1][o]) + (s_q[2][o] + s_q[3][o]);
-  g = fmaf(g, bn2_scale[o], bn2_shift[o]);
-  float v = h * (1.f / (1.f + expf(-g)));  // every quarter holds the same value
   if (l2_eps > 0.f) {
     float sq = q == 0 ? v * v : 0.f;
 #pragma unroll
@@ -404,7 +405,8 @@ DH3D_API int dh3d_netvlad_head_fwd(const float *vlad, const float *Wh, const flo
                                    const float *bn1_shift, const float *Wg, const float *bn2_scale,
                                    const float *bn2_shift, int B, int Kd, int O, float l2_eps,
                                    void *workspace, size_t workspace_bytes, float *out, void *stream) {
-  DH3D_REQUIRE(vlad && Wh && bn1_scale && bn1_shift && Wg && bn2_scale && bn2_shift && workspace && out);
+  DH3D_REQUIRE(vlad && Wh && bn1_scale && bn1_shift && workspace && out);
+  DH3D_REQUIRE(!Wg || (bn2_scale && bn2_shift));  // Wg == NULL: no context gating (gating=False, backbones.py:276)
   DH3D_REQUIRE(B > 0 && Kd > 0);
   DH3D_SUPPORTED(O == 256 && B <= 65535);
   DH3D_REQUIRE(workspace_bytes >= dh3d_netvlad_head_workspace_bytes(B, Kd, O));

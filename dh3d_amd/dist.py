@@ -56,6 +56,36 @@ def shard_batch(points, rank, world):
     return out, mask
 
 
+def _staged(t):
+    """gloo moves CUDA tensors only for broadcast / all_reduce; everything else is staged through the host there
+    (the CPU-test / single-GPU multi-process path -- RCCL takes device tensors directly)."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def all_gather_rows(local):
+    """local [n, ...] (same n on every rank) -> [world*n, ...] in rank order."""
+    world = dist.get_world_size()
+    if _staged(local):
+        host = local.detach().cpu().contiguous()
+        out = torch.empty((world * host.shape[0],) + tuple(host.shape[1:]), dtype=host.dtype)
+        dist.all_gather_into_tensor(out, host)
+        return out.to(local.device)
+    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous())
+    return out
+
+
+def all_reduce_sum_(t):
+    """In-place SUM all-reduce (device tensors over RCCL; host-staged under gloo)."""
+    if _staged(t):
+        host = t.detach().cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
 def all_gather_descriptors(local_desc, num_clouds):
     """local_desc [per_rank, D] -> [num_clouds, D] in the original role order on every rank.
 
@@ -63,11 +93,7 @@ def all_gather_descriptors(local_desc, num_clouds):
     bound, no reduction.  With world == 1 this is the identity."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return local_desc[:num_clouds]
-    world = dist.get_world_size()
-    gathered = torch.empty((world * local_desc.shape[0],) + tuple(local_desc.shape[1:]), dtype=local_desc.dtype,
-                           device=local_desc.device)
-    dist.all_gather_into_tensor(gathered, local_desc.contiguous())
-    return gathered[:num_clouds]
+    return all_gather_rows(local_desc)[:num_clouds]
 
 
 def barrier():
@@ -79,6 +105,6 @@ def max_over_ranks(value, device):
     """Scalar max over ranks (bench timing contract)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if dist.get_backend() != "gloo" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

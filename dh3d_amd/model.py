@@ -48,11 +48,23 @@ class DH3D(nn.Module):
         self._local_names = [n for n, _ in local.named_children()]
 
         if cfg.detection:
-            self.detection_block_reliable = bb.PointMLPHead(128, [128, 256, 1024], fc_bias_init=1.0 / 8,
+            self.detection_block_reliable = bb.PointMLPHead(cfg.featdim or 128, [128, 256, 1024], fc_bias_init=1.0 / 8,
                                                             bn_eps=tp_eps)
         if cfg.extract_global:
             if cfg.global_backbone not in (None, "global_before_assemble"):
-                raise NotImplementedError("global_backbone %r" % cfg.global_backbone)
+                raise NotImplementedError("global_backbone %r: only 'global_before_assemble' (core/backbones.py:178-186, "
+                                          "the shipped global_config) is built; 'global_before_assemble_conv1d' "
+                                          "(:189-197) is not" % cfg.global_backbone)
+            if cfg.concat_xyz:
+                raise NotImplementedError("concat_xyz=True (core/backbones.py:180-181: 131 input channels to the "
+                                          "global flex_conv) is not built; the shipped global_config sets False")
+            if cfg.global_subsample and cfg.global_subsample > 0:
+                raise NotImplementedError("global_subsample > 0 (core/model.py:120-122) is not built; the shipped "
+                                          "global_config sets -1")
+            if (cfg.featdim or 128) != 128:
+                raise NotImplementedError("extract_global with featdim < 128 is not built: the global flex_conv and "
+                                          "attention kernels are instantiated for the 128-d descriptor of the "
+                                          "shipped configs (core/configs.py:58)")
             gl_dims = list(cfg.gl_dims or [256])
             self.global_before_assemble = bb.FlexConvDilate(128, gl_dims, dilate=cfg.gl_dilate or 8,
                                                             knn=self.knn_num, concat=False, add_se="",
@@ -62,13 +74,10 @@ class DH3D(nn.Module):
             nv = bb.NetVLAD(gl_dims[-1], 64, 256, add_batch_norm=cfg.add_batch_norm is not False,
                             slim_bn_eps=slim_eps)
             # NetVLAD variables are created at the root variable scope (backbones.py:212-276)
-            self.cluster_weights = nv.cluster_weights
-            self.cluster_bn = nv.cluster_bn
-            self.cluster_weights2 = nv.cluster_weights2
-            self.hidden1_weights = nv.hidden1_weights
-            self.bn = nv.bn
-            self.gating_weights = nv.gating_weights
-            self.gating_bn = nv.gating_bn
+            for vname in ("cluster_weights", "cluster_bn", "cluster_biases", "cluster_weights2", "hidden1_weights", "bn",
+                          "gating_weights", "gating_bn", "gating_biases"):
+                if hasattr(nv, vname):
+                    setattr(self, vname, getattr(nv, vname))
             object.__setattr__(self, "_netvlad", nv)  # not registered twice
         object.__setattr__(self, "_local", local)
         self._geo_stream = None
@@ -85,7 +94,7 @@ class DH3D(nn.Module):
             leaf = name.split(".")[-1]
             if leaf in ("gamma",):
                 p.fill_(1.0)
-            elif leaf in ("beta", "b", "feature_bias"):
+            elif leaf in ("beta", "b", "feature_bias", "cluster_biases", "gating_biases"):
                 p.copy_(0.1 * torch.randn(p.shape, generator=g))
             elif leaf == "position_theta" and p.dim() == 3:
                 p.copy_(torch.randn(p.shape, generator=g) / (p.shape[1] ** 0.5))
@@ -242,6 +251,8 @@ class DH3D(nn.Module):
         l2cat = (points, _l2cat_eps) if _l2cat_eps is not None else None
         feat = self.stage2(geo, x2, residual=shortcut, l2cat=l2cat,  # gather, N/8 convs, SE, interpolation, concat conv
                            shortcut_src=x1 if fuse_sc else None)
+        if self._local.featdim < 128:  # core/backbones.py:125-126
+            feat = self.final_fc(feat, act=pm.ACT_RELU)
         self._last_geo = geo
         return points, feat
 
@@ -294,7 +305,7 @@ class DH3D(nn.Module):
         geo = self._geometry(points, knn_inds)
         outs["knn_inds"] = geo.nbr
         needs_raw = want("feat", "attention", "xyz_feat_att", "globaldesc")
-        if fetch is not None and not needs_raw and want("xyz_feat", "feat_l2normed"):
+        if fetch is not None and not needs_raw and want("xyz_feat", "feat_l2normed") and self._local.featdim == 128:
             # only the normalised descriptors are asked for: the last conv writes [xyz | l2_normalize(feat)] itself
             _, xyz_feat = self.compute_local(points, _geo=geo, _l2cat_eps=1e-8)
             outs["xyz_feat"] = xyz_feat

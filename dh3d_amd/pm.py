@@ -141,6 +141,17 @@ def flex_pool(features, nbr, want_argmax=False):
     return (out, argmax) if want_argmax else out
 
 
+def flex_avg(features, nbr, scale=1.0):
+    """Flex_Avg (core/layers.py:342-436): scale * sum_k features[nbr[n,k]]; backbones.py:80-82 uses scale = 1/knn."""
+    f = L.require_cuda_f32(features, "features", 3)
+    nb = L.require_cuda_i32(nbr, "nbr", 3)
+    B, N, C = f.shape
+    out = torch.empty_like(f)
+    L.check(L.lib().dh3d_flex_avg_pm_fwd(L.ptr(f), L.ptr(nb), B, N, nb.shape[2], C, float(scale), L.ptr(out),
+                                         L.stream_ptr()), "flex_avg_pm")
+    return out
+
+
 def conv_pointset_xyz(xyz, nbr, theta, bias, pre_bias=None, scale=None, shift=None, act=ACT_NONE):
     x = L.require_cuda_f32(xyz, "xyz", 3)
     nb = L.require_cuda_i32(nbr, "nbr", 3)

@@ -33,15 +33,25 @@ class _AllGatherKeepOwn(torch.autograd.Function):
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             ctx.rank, ctx.n = 0, local.shape[0]
             return local.clone()
-        world = dist.get_world_size()
-        out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local.contiguous())
         ctx.rank, ctx.n = dist.get_rank(), local.shape[0]
-        return out
+        return D.all_gather_rows(local)
 
     @staticmethod
     def backward(ctx, grad):
         return grad[ctx.rank * ctx.n:(ctx.rank + 1) * ctx.n].contiguous()
+
+
+class _AllReduceSum(torch.autograd.Function):
+    """SUM all-reduce with the matching backward (every rank's output depends on every rank's input: the gradient
+    of the sum is the sum of the gradients)."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return D.all_reduce_sum_(t.clone())
+
+    @staticmethod
+    def backward(ctx, grad):
+        return D.all_reduce_sum_(grad.clone())
 
 
 def _batch_norm_train(x, channel_dim, gamma, beta, run_mean, run_var, eps, momentum, sync_bn, mask=None):
@@ -60,8 +70,7 @@ def _batch_norm_train(x, channel_dim, gamma, beta, run_mean, run_var, eps, momen
         s1 = x.sum(dims)
         s2 = (x * x).sum(dims)
     if sync_bn and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        import torch.distributed.nn.functional as dfn
-        packed = dfn.all_reduce(torch.cat([s1, s2, cnt.reshape(1)]))
+        packed = _AllReduceSum.apply(torch.cat([s1, s2, cnt.reshape(1)]))
         C = s1.numel()
         s1, s2, cnt = packed[:C], packed[C:2 * C], packed[2 * C]
     # a rank that holds only padding clouds (e.g. 22 clouds over 12 or 16 ranks) has cnt == 0 without sync_bn: its
@@ -239,7 +248,7 @@ class QuadrupletTrainer(object):
         (loss + rank0_only_wd).backward()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)  # every rank holds a partial of the SAME loss
+            D.all_reduce_sum_(flat)  # every rank holds a partial of the SAME loss
             off = 0
             for p in self.params:
                 n = p.numel()

@@ -197,6 +197,11 @@ int dh3d_flex_conv_pm_x6_fwd(const float *features, const float *xyz, const int3
 int dh3d_flex_pool_pm_fwd(const float *features, const int32_t *nbr, int B, int N, int K, int C,
                           float *out, int32_t *argmax, void *stream);
 
+/* Flex_Avg forward (core/layers.py:342-436 = flex_conv with theta 0, bias eye), point-major:
+ * out[n,c] = scale * sum_k f[nbr[n,k],c]  (backbones.py:80-82 passes scale = 1/knn).  C % 4 == 0. */
+int dh3d_flex_avg_pm_fwd(const float *features, const int32_t *nbr, int B, int N, int K, int C,
+                         float scale, float *out, void *stream);
+
 /* conv_pointset forward on coordinates (Din = 3), point-major, + epilogue:
  * xyz [B,N,3], theta [3,Dout], bias [Dout] -> out [B,N,Dout].  Dout % 4 == 0, Dout <= 128. */
 int dh3d_conv_pointset_pm_fwd(const float *xyz, const int32_t *nbr, const float *theta,

@@ -101,6 +101,12 @@ def flex_conv_dilate(xyz, feat, dilate, knn, outdims, scope, w, eps, knn_indices
     if add_se == "max_pool":
         x_pool, _ = O.flex_pooling(x, knn_indices)
         x = se_res_bottleneck(x, x_pool, w, scope + "/se")
+    elif add_se == "avg_pool":  # backbones.py:80-83: flex_avg = FlexConv(theta=0, bias=eye) (layers.py:379-386), * 1/knn
+        d = outdims[-1]
+        x_pool = O.flex_convolution(x, points_T, knn_indices, np.zeros((3, d, d), np.float32), np.eye(d, dtype=np.float32),
+                                    center_self=True)
+        x_pool = (x_pool * np.float32(1.0 / knn)).astype(np.float32)
+        x = se_res_bottleneck(x, x_pool, w, scope + "/se")
     new_feat = np.ascontiguousarray(x.transpose(0, 2, 1))
     if upsample and dilate > 1:
         dist, idx = O.three_nn(xyz, points_s)
@@ -116,19 +122,22 @@ def flex_conv_dilate(xyz, feat, dilate, knn, outdims, scope, w, eps, knn_indices
     return xyz, new_feat
 
 
-def backbone_local_dilate(points, knn_ind, w, eps, trace=None):
-    """core/backbones.py:104-127."""
+def backbone_local_dilate(points, knn_ind, w, eps, trace=None, featdim=128, add_se="max_pool"):
+    """core/backbones.py:104-127 (add_se is 'max_pool' upstream; a parameter here to exercise :80-83)."""
     nn_8 = np.ascontiguousarray(knn_ind[:, 0:8, :])
     pts_T = np.ascontiguousarray(points.transpose(0, 2, 1))
     init = O.convolution_pointset(pts_T, nn_8, w["initconv/position_theta"], w["initconv/position_bias"])
     init = _relu(_bn(init, w, "initconv_bn", 1, eps)).astype(np.float32)
     init, _ = O.flex_pooling(init, nn_8)
     init = np.ascontiguousarray(init.transpose(0, 2, 1))
-    _, x1 = flex_conv_dilate(points, init, 1, 8, [64, 64], "stage1", w, eps, knn_indices=nn_8, concat=False)
+    _, x1 = flex_conv_dilate(points, init, 1, 8, [64, 64], "stage1", w, eps, knn_indices=nn_8, concat=False,
+                             add_se=add_se)
     x2 = _conv1x1(x1, w, "before_stage2_conv1d/tfconv0", bn_eps=eps, act=_relu)
     _, x2 = flex_conv_dilate(points, x2, 8, 8, [128, 128], "stage2", w, eps, knn_indices=None, concat=True,
-                             trace=trace)
+                             trace=trace, add_se=add_se)
     feat = _conv1x1(x1, w, "local_stage1_shortcut/tfconv0", bn_eps=eps, act=_relu) + x2
+    if featdim < 128:  # :125-126
+        feat = _conv1x1(feat, w, "final_fc/tfconv0", bn_eps=eps, act=_relu)
     return points, feat.astype(np.float32)
 
 
@@ -146,12 +155,12 @@ def globalatt_block(features, w, eps, scope="globalatt"):
     return _sigmoid(_conv1x1(x, w, scope + "/detec_conv_fc"))
 
 
-def global_netvlad_block(features, att, w, slim_eps, cluster_size=64):
+def global_netvlad_block(features, att, w, slim_eps, cluster_size=64, add_batch_norm=True, gating=True):
     """core/backbones.py:202-279 + context_gating :282-320."""
     B, N, D = features.shape
     x = _l2_normalize(features.reshape(-1, D), 1, 1e-12)
     act = x @ w["cluster_weights"]
-    act = _slim_bn(act, w, "cluster_bn", slim_eps)
+    act = _slim_bn(act, w, "cluster_bn", slim_eps) if add_batch_norm else act + w["cluster_biases"]
     act = act - act.max(axis=1, keepdims=True)
     act = np.exp(act)
     act = (act / act.sum(axis=1, keepdims=True)).astype(np.float32)
@@ -166,12 +175,15 @@ def global_netvlad_block(features, att, w, slim_eps, cluster_size=64):
     vlad = _l2_normalize(vlad, 1, 1e-12)
     vlad = vlad @ w["hidden1_weights"]
     vlad = _slim_bn(vlad, w, "bn", slim_eps)
-    gates = _slim_bn(vlad @ w["gating_weights"], w, "gating_bn", slim_eps)
+    if not gating:
+        return vlad.astype(np.float32)
+    gates = vlad @ w["gating_weights"]
+    gates = _slim_bn(gates, w, "gating_bn", slim_eps) if add_batch_norm else gates + w["gating_biases"]
     return (vlad * _sigmoid(gates)).astype(np.float32)
 
 
 def forward(points, w, detection=False, extract_global=False, knn_num=8, tp_eps=1e-5, slim_eps=1e-3,
-            knn_inds=None, trace=None):
+            knn_inds=None, trace=None, featdim=128, add_batch_norm=True, add_se="max_pool"):
     """core/model.py:135-210.  points [Bt,N,3] float32; returns dict of named outputs.
     trace (dict or None) collects the integer intermediates of the sampled levels (see flex_conv_dilate)."""
     points = np.ascontiguousarray(points, np.float32)
@@ -181,7 +193,8 @@ def forward(points, w, detection=False, extract_global=False, knn_num=8, tp_eps=
     else:
         knn_indices, _ = knn_bruteforce_layer(np.ascontiguousarray(points.transpose(0, 2, 1)), knn_num)
     outs["knn_indices"] = knn_indices
-    newpoints, localdesc = backbone_local_dilate(points, knn_indices, w, tp_eps, trace=trace)
+    newpoints, localdesc = backbone_local_dilate(points, knn_indices, w, tp_eps, trace=trace, featdim=featdim,
+                                                  add_se=add_se)
     l2n = _l2_normalize(localdesc, 2, 1e-8)
     outs["feat"] = localdesc
     outs["feat_l2normed"] = l2n
@@ -195,7 +208,7 @@ def forward(points, w, detection=False, extract_global=False, knn_num=8, tp_eps=
                                         knn_indices=None, concat=False, upsample=True, add_se="",
                                         trace=trace)
         gatt = globalatt_block(forglobal, w, tp_eps)
-        g = global_netvlad_block(forglobal, gatt, w, slim_eps)
+        g = global_netvlad_block(forglobal, gatt, w, slim_eps, add_batch_norm=add_batch_norm)
         outs["forglobal"] = forglobal
         outs["global_att"] = gatt
         outs["globaldesc"] = _l2_normalize(g, -1, 1e-8)

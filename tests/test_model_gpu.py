@@ -143,3 +143,61 @@ def test_fetch_only_normalised_descriptors_uses_fused_store(dev):
     assert err < 2e-6, err
     nrm = only["feat_l2normed"].norm(dim=2)
     assert torch.allclose(nrm, torch.ones_like(nrm), atol=1e-5)
+
+
+def test_config_reachable_branches_vs_oracle(dev):
+    """Branches no shipped preset selects but a reference config key / call can reach: featdim < 128 ('final_fc',
+    core/backbones.py:125-126), NetVLAD without BatchNorm (cluster_biases / gating_biases, :224-229,310-314) and
+    without context gating (:276), SE on the neighbour average (flex_avg, :80-83)."""
+    from oracle import model_np
+    from dh3d_amd import ConfigFactory, backbones as bb, pm
+    from dh3d_amd.model import DH3D
+    rng = np.random.default_rng(77)
+    pts = rng.random((2, 1024, 3), dtype=np.float32)
+    # featdim = 64 with the detector head on top
+    cfg = ConfigFactory("detection_config").getconfig()
+    cfg.featdim = 64
+    m = DH3D(cfg).init_synthetic(4)
+    _randomise_bn(m, 5)
+    m = m.to(dev).eval()
+    with torch.no_grad():
+        outs = m(torch.from_numpy(pts).to(dev))
+    exp = model_np.forward(pts, _weights_np(m), detection=True, featdim=64)
+    assert outs["feat"].shape == (2, 1024, 64) and outs["xyz_feat_att"].shape == (2, 1024, 68)
+    assert np.allclose(outs["xyz_feat_att"].cpu().numpy(), exp["xyz_feat_att"], rtol=1e-4, atol=1e-4)
+    # add_batch_norm = False on the global path
+    cfg = ConfigFactory("global_config").getconfig()
+    cfg.add_batch_norm = False
+    m = DH3D(cfg).init_synthetic(6)
+    _randomise_bn(m, 7)
+    m = m.to(dev).eval()
+    assert "cluster_biases" in m.state_dict() and "gating_biases" in m.state_dict() and "cluster_bn.gamma" not in m.state_dict()
+    with torch.no_grad():
+        g = m(torch.from_numpy(pts).to(dev))["globaldesc"].cpu().numpy()
+    exp = model_np.forward(pts, _weights_np(m), extract_global=True, add_batch_norm=False)
+    assert np.allclose(g, exp["globaldesc"], rtol=1e-4, atol=1e-4)
+    # gating = False (a call-level argument upstream)
+    nv = bb.NetVLAD(256, 64, 256, add_batch_norm=True, gating=False).to(dev)
+    x = torch.randn(2, 300, 256, device=dev); att = torch.rand(2, 300, 1, device=dev)
+    w = {k.replace(".", "/"): v.detach().cpu().numpy() for k, v in nv.state_dict().items()}
+    got = nv(x, att).cpu().numpy()
+    ref = model_np.global_netvlad_block(x.cpu().numpy(), att.cpu().numpy(), w, 1e-3, gating=False)
+    assert np.allclose(got, ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+    # add_se = 'avg_pool'
+    blk = bb.FlexConvDilate(32, [64, 64], dilate=1, knn=8, concat=False, add_se="avg_pool").to(dev)
+    geo = bb.Geometry(torch.from_numpy(pts).to(dev), 8)
+    geo.nbr, _ = pm.knn_xyz(geo.xyz, 8)
+    f = torch.randn(2, 1024, 32, device=dev)
+    got = blk(geo, f, nbr=geo.nbr).cpu().numpy()
+    w = {"stage1/" + k.replace(".", "/").replace("mean_EMA", "mean/EMA").replace("variance_EMA", "variance/EMA"):
+         v.detach().cpu().numpy() for k, v in blk.state_dict().items()}
+    _, ref = model_np.flex_conv_dilate(pts, f.cpu().numpy(), 1, 8, [64, 64], "stage1", w, 1e-5,
+                                       knn_indices=np.ascontiguousarray(geo.nbr.cpu().numpy().transpose(0, 2, 1)),
+                                       concat=False, add_se="avg_pool")
+    assert np.allclose(got, ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+    # and the branches that stay unbuilt say so, citing the reference
+    for key, val in (("global_backbone", "global_before_assemble_conv1d"), ("concat_xyz", True), ("global_subsample", 256)):
+        cfg = ConfigFactory("global_config").getconfig()
+        cfg[key] = val
+        with pytest.raises(NotImplementedError, match="core/"):
+            DH3D(cfg)

@@ -304,3 +304,36 @@ def test_fps_sorted_golden_and_ties(dev):
     z[0, 700] = 1.0; z[0, 188] = 1.0
     srt, gbox = pm.spatial_sort(T(z, dev))
     assert int(pm.fps_sorted(srt, gbox, 2)[0, 1]) == 188
+
+
+@pytest.mark.parametrize("contract", [1, 0])
+@pytest.mark.parametrize("B,N,m", [(2, 777, 100), (1, 4096, 512), (1, 20000, 300)])
+def test_fps_mode_any_n_both_contractions(dev, oracle, B, N, m, contract):
+    """dh3d_farthest_point_sample_mode: the any-N kernel (running distances in scratch, as upstream) in both
+    roundings of tf_sampling_g.cu:141 -- each bit-equal to the oracle in the same mode; N > 16384 included."""
+    from dh3d_amd import ops
+    rng = np.random.default_rng(N + contract)
+    xyz = rng.random((B, N, 3), dtype=np.float32) * 30 - 15
+    got = ops.farthest_point_sample(m, T(xyz, dev), contract=contract).cpu().numpy()
+    assert np.array_equal(got, oracle.farthest_point_sample(m, xyz, contract=bool(contract)))
+    if contract == 1 and N <= 16384:  # the default kernels compute the contracted form
+        assert np.array_equal(got, ops.farthest_point_sample(m, T(xyz, dev)).cpu().numpy())
+
+
+def test_fps_modes_differ_somewhere_and_ties(dev, oracle):
+    """The two roundings are not the same function (otherwise the switch would be untestable), and the tie rule
+    holds in the any-N kernel: lattice clouds where many points share the maximum."""
+    from dh3d_amd import ops
+    rng = np.random.default_rng(99)
+    differ = 0
+    for s in range(6):
+        xyz = (rng.random((1, 3000, 3), dtype=np.float32) * 50 - 25)
+        a = ops.farthest_point_sample(400, T(xyz, dev), contract=1).cpu().numpy()
+        b = ops.farthest_point_sample(400, T(xyz, dev), contract=0).cpu().numpy()
+        differ += int(not np.array_equal(a, b))
+    lat = np.stack(np.meshgrid(np.arange(12), np.arange(12), np.arange(12), indexing="ij"), -1).reshape(1, -1, 3)
+    lat = lat.astype(np.float32)[:, rng.permutation(1728)]
+    for c in (0, 1):
+        assert np.array_equal(ops.farthest_point_sample(200, T(lat, dev), contract=c).cpu().numpy(),
+                              oracle.farthest_point_sample(200, lat, contract=bool(c)))
+    print("clouds on which the two FPS roundings pick differently: %d / 6" % differ)

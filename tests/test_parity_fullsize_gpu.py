@@ -186,3 +186,34 @@ def test_netvlad_cfg3_shape_vs_restatement(dev):
     outn = pm.netvlad_head(vlad, T(w["hidden1_weights"]), s1, h1, T(w["gating_weights"]), s2, h2,
                            l2_eps=1e-8).cpu().numpy()
     assert np.abs(outn - exp / np.linalg.norm(exp, axis=1, keepdims=True)).max() < 1e-4
+
+
+def test_forward_above_16384_points_with_host_knn_vs_oracle(dev):
+    """num_points > 16384: the reference takes any such size with host kNN indices (core/model.py:38,148-155); here the
+    FPS then keeps its running distances in scratch (any-N kernel).  N = 18000 against the oracle."""
+    m = _build("basic_config", dev, seed=41, num_points=18000)
+    pts = np.random.default_rng(18000).random((1, 18000, 3), dtype=np.float32)
+    from oracle import cpu as O
+    nn, _ = O.knn_bruteforce(np.ascontiguousarray(pts.transpose(0, 2, 1)), 8)
+    nbr = torch.from_numpy(nn).to(dev)
+    _run_and_compare(m, pts, dev, knn_inds=nbr)
+    with pytest.raises(ValueError):
+        m(torch.from_numpy(pts).to(dev))                      # no device kNN above 16384
+    bad = nbr.clone(); bad[0, 5, 3] = 18000
+    with pytest.raises(ValueError):
+        m(torch.from_numpy(pts).to(dev), knn_inds=bad)       # out-of-range ids are refused, not dereferenced
+    with pytest.raises(ValueError):
+        m(torch.from_numpy(pts).to(dev), knn_inds=nbr[:, :100])
+
+
+def test_fps_contract_switch_reaches_the_model(dev):
+    """config.fps_contract = 0: the whole forward on the uncontracted FPS rounding (integrator's switch), against the
+    oracle run in the same mode."""
+    from oracle import cpu as O
+    m = _build("basic_config", dev, seed=43)
+    m.config.fps_contract = 0
+    pts = (np.random.default_rng(43).random((1, 4096, 3), dtype=np.float32) * 40 - 20)
+    with torch.no_grad():
+        m(torch.from_numpy(pts).to(dev))
+    got = m._last_geo._lv["idx"].cpu().numpy()
+    assert np.array_equal(got, O.farthest_point_sample(512, pts, contract=False))

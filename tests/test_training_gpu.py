@@ -152,3 +152,88 @@ def test_factorised_flex_conv_grads_match_the_drop_in_op(dev):
     for a, b, name in ((f1.grad, f2.grad, "features"), (t1.grad, t2.grad, "theta"), (b1.grad, b2.grad, "bias")):
         err = (a - b).abs().max().item() / b.abs().max().item()
         assert err < 2e-5, (name, err)
+
+
+_WORLD2 = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch
+from dh3d_amd import ConfigFactory, dist as D
+from dh3d_amd.model import DH3D
+from dh3d_amd.training import QuadrupletTrainer
+
+sync_bn = bool(int(sys.argv[1]))
+dev = torch.device("cuda", 0)            # both ranks share the one GPU; collectives are host-staged over gloo
+torch.cuda.set_device(dev)
+
+def build():
+    cfg = ConfigFactory("global_config").getconfig()
+    cfg.batch_size, cfg.num_pos, cfg.num_neg = 1, 2, 3          # 1 + 2 + 3 + 1 = 7 clouds -> 4 + 3(+1 padding)
+    return DH3D(cfg).init_synthetic(5).to(dev).eval()
+
+pts = torch.from_numpy(np.random.default_rng(77).random((7, 1024, 3), dtype=np.float32)).to(dev)
+# single-process reference (no process group yet): whole-batch statistics, as the reference's one GPU
+ref = build()
+tr = QuadrupletTrainer(ref, sync_bn=False)
+ref_losses = [tr.step(pts) for _ in range(2)]
+ref_params = [p.detach().clone() for p in tr.params]
+ref_bufs = {k: v.detach().clone() for k, v in ref.named_buffers()}
+
+rank, world = D.init_from_env(backend="gloo")
+assert world == 2
+m = build()
+t2 = QuadrupletTrainer(m, sync_bn=sync_bn)
+losses = [t2.step(pts) for _ in range(2)]
+assert all(np.isfinite(losses)), losses
+# every rank must end with the same parameters (same gathered loss, SUM-reduced gradients)
+flat = torch.cat([p.detach().reshape(-1) for p in t2.params])
+both = D.all_gather_rows(flat[None])
+assert torch.equal(both[0], both[1]), "ranks diverged"
+if sync_bn:
+    # sync-BN + sharding == the single-process step (summation order differs: tolerance, not equality)
+    assert abs(losses[0] - ref_losses[0]) < 1e-5 and abs(losses[1] - ref_losses[1]) < 1e-4, (losses, ref_losses)
+    for p, q in zip(t2.params, ref_params):
+        assert torch.allclose(p, q, rtol=1e-3, atol=2e-5), float((p - q).abs().max())
+    for k, v in m.named_buffers():
+        assert torch.allclose(v, ref_bufs[k], rtol=1e-4, atol=1e-5), k
+else:
+    assert abs(losses[0] - ref_losses[0]) < 0.5   # per-rank statistics: a different (legal) normalisation
+D.barrier()
+open(os.path.join(%(out)r, "rank%%d_%%d.ok" %% (rank, int(sync_bn))), "w").write("ok")
+"""
+
+
+@pytest.mark.parametrize("sync_bn", [1, 0])
+def test_trainer_step_world_size_2_matches_single_process(dev, tmp_path, sync_bn):
+    """QuadrupletTrainer.step with two ranks (gloo, collectives staged through the host, both ranks on this GPU):
+    shard + masked padding + descriptor all-gather + sync-BN + gradient all-reduce == the single-process step."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    script = tmp_path / "w2.py"
+    script.write_text(_WORLD2 % {"root": root, "out": str(tmp_path)})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script), str(sync_bn)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert (tmp_path / ("rank0_%d.ok" % sync_bn)).exists() and (tmp_path / ("rank1_%d.ok" % sync_bn)).exists()
+
+
+def test_trainer_survives_a_rank_with_only_padding_clouds(dev):
+    """22 clouds over 12 or 16 ranks leave tail ranks with an all-False mask: statistics of zero rows must not turn
+    into NaN (which the SUM all-reduce would spread) and must leave the running buffers alone."""
+    from dh3d_amd.training import _batch_norm_train
+    x = torch.randn(2, 16, 8, device=dev, requires_grad=True)
+    mask = torch.zeros(2, dtype=torch.bool, device=dev)
+    rm, rv = torch.zeros(8, device=dev), torch.ones(8, device=dev)
+    y = _batch_norm_train(x, 2, torch.ones(8, device=dev), torch.zeros(8, device=dev), rm, rv, 1e-5, 0.9, False, mask)
+    (y * 0.0).sum().backward()
+    assert torch.isfinite(y).all() and torch.isfinite(x.grad).all()
+    assert torch.equal(rm, torch.zeros(8, device=dev)) and torch.equal(rv, torch.ones(8, device=dev))
