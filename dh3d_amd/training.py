@@ -207,6 +207,7 @@ class QuadrupletTrainer(object):
         each under the contiguous role-ordered partition) and lets the buffers diverge."""
         self.model = model
         self.cfg = model.config
+        self.keep_grads, self.last_grads = False, None
         c = self.cfg
         start_lr = start_lr if start_lr is not None else (c.start_lr or 5e-4)
         decay_step = decay_step if decay_step is not None else (c.decay_step or 20000)
@@ -254,6 +255,8 @@ class QuadrupletTrainer(object):
                 n = p.numel()
                 p.grad = flat[off:off + n].reshape(p.shape).clone()
                 off += n
+        if self.keep_grads:  # tests: the reduced gradient of this step (Adam's m/sqrt(v) is sign-like in the first
+            self.last_grads = [p.grad.detach().clone() for p in self.params]  # steps: parameters are ill-conditioned)
         self.opt.step()
         self.sched.step()
         self.model.invalidate(head_only=True)  # the packed / folded weight copies of the fused inference path are stale now
