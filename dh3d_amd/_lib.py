@@ -44,6 +44,21 @@ _SIGNATURES = {
     "dh3d_conv_pointset_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp],
     "dh3d_conv_pointset_bwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp,
                                c_fp],
+    "dh3d_flex_conv_fwd_workspace_bytes": [c_int, c_int, c_int, c_int, c_int, c_int],
+    "dh3d_flex_conv_fwd_ws": [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp,
+                              c_size_t, c_fp],
+    "dh3d_flex_conv_bwd_workspace_bytes": [c_int, c_int, c_int, c_int, c_int, c_int],
+    "dh3d_flex_conv_bwd_ws": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp,
+                              c_fp, c_fp, c_fp, c_size_t, c_fp],
+    "dh3d_flex_pool_fwd_workspace_bytes": [c_int, c_int, c_int, c_int],
+    "dh3d_flex_pool_fwd_ws": [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_size_t, c_fp],
+    "dh3d_flex_conv_pm_bwd_workspace_bytes": [c_int, c_int, c_int, c_int],
+    "dh3d_flex_conv_pm_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp,
+                              c_size_t, c_fp, c_fp, c_fp, c_fp],
+    "dh3d_gemm_tn_f32": [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp],
+    "dh3d_gemm_nn_f32": [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp],
+    "dh3d_transpose32": [c_fp, c_int, c_int, c_int, c_fp, c_fp],
+    "dh3d_colsum_f32": [c_fp, ctypes.c_longlong, c_int, c_int, c_fp, c_fp],
     "dh3d_farthest_point_sample": [c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp],
     "dh3d_farthest_point_sample_mode": [c_int, c_int, c_int, c_fp, c_fp, c_fp, c_int, c_fp],
     "dh3d_group_point_fwd": [c_int, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp],
@@ -100,6 +115,10 @@ _RESTYPES = {
     "dh3d_status_string": ctypes.c_char_p,
     "dh3d_netvlad_workspace_bytes": c_size_t,
     "dh3d_netvlad_head_workspace_bytes": c_size_t,
+    "dh3d_flex_conv_fwd_workspace_bytes": c_size_t,
+    "dh3d_flex_conv_bwd_workspace_bytes": c_size_t,
+    "dh3d_flex_pool_fwd_workspace_bytes": c_size_t,
+    "dh3d_flex_conv_pm_bwd_workspace_bytes": c_size_t,
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -18,6 +18,11 @@ __all__ = [
 ]
 
 
+# The reference-layout operators run on the fused MFMA kernels whenever the shape is one they serve (every DH3D
+# layer); False forces the reference formulation (csrc/flex_generic.hip) -- the tests compare the two.
+FAST_PATH = True
+
+
 def _same(a, b, what):
     if a != b:
         raise ValueError("%s mismatch: %s vs %s" % (what, a, b))
@@ -59,8 +64,15 @@ class _FlexConv(torch.autograd.Function):
         _same(tuple(p.shape), (B, Dp, N), "position shape")
         out = torch.empty((B, Dout, N), dtype=torch.float32, device=f.device)
         with torch.cuda.device(f.device):
-            L.check(L.lib().dh3d_flex_conv_fwd(L.ptr(f), L.ptr(t), L.ptr(bi), L.ptr(nb), L.ptr(p), B, N, K, Dp,
-                                               Din, Dout, L.ptr(out), L.stream_ptr()), "flex_convolution")
+            ws_bytes = L.lib().dh3d_flex_conv_fwd_workspace_bytes(B, N, K, Dp, Din, Dout) if FAST_PATH else 0
+            if ws_bytes:  # the DH3D shapes: fused MFMA kernels behind the reference signature (section A' of the ABI)
+                ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=f.device)
+                L.check(L.lib().dh3d_flex_conv_fwd_ws(L.ptr(f), L.ptr(t), L.ptr(bi), L.ptr(nb), L.ptr(p), B, N, K, Dp,
+                                                      Din, Dout, L.ptr(out), L.ptr(ws), ws_bytes, L.stream_ptr()),
+                        "flex_convolution")
+            else:       # any other shape: the reference formulation (csrc/flex_generic.hip)
+                L.check(L.lib().dh3d_flex_conv_fwd(L.ptr(f), L.ptr(t), L.ptr(bi), L.ptr(nb), L.ptr(p), B, N, K, Dp,
+                                                   Din, Dout, L.ptr(out), L.stream_ptr()), "flex_convolution")
         ctx.save_for_backward(f, t, bi, nb, p)
         return out
 
@@ -73,9 +85,16 @@ class _FlexConv(torch.autograd.Function):
         K = nb.shape[1]
         gf, gt, gb = torch.empty_like(f), torch.empty_like(t), torch.empty_like(bi)
         with torch.cuda.device(f.device):
-            L.check(L.lib().dh3d_flex_conv_bwd(L.ptr(f), L.ptr(t), L.ptr(bi), L.ptr(nb), L.ptr(p), L.ptr(td), B,
-                                               N, K, Dp, Din, Dout, L.ptr(gf), L.ptr(gt), L.ptr(gb),
-                                               L.stream_ptr()), "flex_convolution_grad")
+            ws_bytes = L.lib().dh3d_flex_conv_bwd_workspace_bytes(B, N, K, Dp, Din, Dout) if FAST_PATH else 0
+            if ws_bytes:  # factorised backward on the MFMA pipe + atomics scatter (csrc/flex_bwd.hip)
+                ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=f.device)
+                L.check(L.lib().dh3d_flex_conv_bwd_ws(L.ptr(f), L.ptr(t), L.ptr(bi), L.ptr(nb), L.ptr(p), L.ptr(td), B,
+                                                      N, K, Dp, Din, Dout, L.ptr(gf), L.ptr(gt), L.ptr(gb), L.ptr(ws),
+                                                      ws_bytes, L.stream_ptr()), "flex_convolution_grad")
+            else:
+                L.check(L.lib().dh3d_flex_conv_bwd(L.ptr(f), L.ptr(t), L.ptr(bi), L.ptr(nb), L.ptr(p), L.ptr(td), B,
+                                                   N, K, Dp, Din, Dout, L.ptr(gf), L.ptr(gt), L.ptr(gb),
+                                                   L.stream_ptr()), "flex_convolution_grad")
         return gf, gt, gb, None, None
 
 
@@ -97,8 +116,14 @@ class _FlexPool(torch.autograd.Function):
         out = torch.empty_like(f)
         argmax = torch.empty((B, D, N), dtype=torch.int32, device=f.device)
         with torch.cuda.device(f.device):
-            L.check(L.lib().dh3d_flex_pool_fwd(L.ptr(f), L.ptr(nb), B, N, K, D, L.ptr(out), L.ptr(argmax),
-                                               L.stream_ptr()), "flex_pooling")
+            ws_bytes = L.lib().dh3d_flex_pool_fwd_workspace_bytes(B, N, K, D) if FAST_PATH else 0
+            if ws_bytes:
+                ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=f.device)
+                L.check(L.lib().dh3d_flex_pool_fwd_ws(L.ptr(f), L.ptr(nb), B, N, K, D, L.ptr(out), L.ptr(argmax),
+                                                      L.ptr(ws), ws_bytes, L.stream_ptr()), "flex_pooling")
+            else:
+                L.check(L.lib().dh3d_flex_pool_fwd(L.ptr(f), L.ptr(nb), B, N, K, D, L.ptr(out), L.ptr(argmax),
+                                                   L.stream_ptr()), "flex_pooling")
         ctx.save_for_backward(argmax)
         ctx.mark_non_differentiable(argmax)
         return out, argmax

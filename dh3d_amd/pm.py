@@ -421,3 +421,78 @@ def netvlad_head(vlad, Wh, bn1_scale, bn1_shift, Wg, bn2_scale, bn2_shift, l2_ep
                                           L.ptr(bn2_scale), L.ptr(bn2_shift), B, Kd, O, float(l2_eps), L.ptr(ws),
                                           ws_bytes, L.ptr(out), L.stream_ptr()), "netvlad_head")
     return out
+
+
+# --------------------------------------------------------------------------------------------- backward / training
+def flex_conv_bwd(features, xyz, nbr, theta, bias, grad_out, center_rank0=False, need_grad_features=True):
+    """Factorised flex_conv backward (csrc/flex_bwd.hip): features [B,N,Din], xyz [B,N,3], nbr [B,N,K] int32,
+    theta [3,Din,Dout], bias [Din,Dout], grad_out [B,N,Dout] -> (grad_features [B,N,Din] or None, grad_theta, grad_bias)."""
+    f = L.require_cuda_f32(features, "features", 3)
+    x = L.require_cuda_f32(xyz, "xyz", 3)
+    nb = L.require_cuda_i32(nbr, "nbr", 3)
+    t = L.require_cuda_f32(theta, "theta", 3)
+    bi = L.require_cuda_f32(bias, "bias", 2)
+    g = L.require_cuda_f32(grad_out, "grad_out", 3)
+    B, N, Din = f.shape
+    K, Dout = nb.shape[2], t.shape[2]
+    if t.shape[0] != 3 or tuple(bi.shape) != (Din, Dout) or tuple(g.shape) != (B, N, Dout):
+        raise ValueError("flex_conv_bwd: inconsistent shapes")
+    ws_bytes = L.lib().dh3d_flex_conv_pm_bwd_workspace_bytes(B, N, Din, Dout)
+    if ws_bytes == 0:
+        raise ValueError("flex_conv_bwd: Din and Dout must be multiples of 4")
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=f.device)
+    gf = torch.empty_like(f) if need_grad_features else None
+    gt, gb = torch.empty_like(t), torch.empty_like(bi)
+    L.check(L.lib().dh3d_flex_conv_pm_bwd(L.ptr(f), L.ptr(x), L.ptr(nb), L.ptr(t), L.ptr(bi), L.ptr(g), B, N, K, Din,
+                                          Dout, 1 if center_rank0 else 0, L.ptr(ws), ws_bytes, L.ptr(gf), L.ptr(gt),
+                                          L.ptr(gb), L.stream_ptr()), "flex_conv_pm_bwd")
+    return gf, gt, gb
+
+
+def gemm_tn(A, B, out=None, accumulate=False):
+    """C[M,N] (+)= A[K,M]^T @ B[K,N] on the exact-f32 MFMA pipe (weight gradients: the reduction runs over rows)."""
+    A = L.require_cuda_f32(A, "A", 2)
+    B = L.require_cuda_f32(B, "B", 2)
+    K, M = A.shape
+    if B.shape[0] != K:
+        raise ValueError("gemm_tn: row counts differ")
+    N = B.shape[1]
+    C = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=A.device)
+    L.check(L.lib().dh3d_gemm_tn_f32(L.ptr(A), L.ptr(B), K, M, N, 1 if accumulate else 0, L.ptr(C), L.stream_ptr()),
+            "gemm_tn")
+    return C
+
+
+def gemm_nn(A, B, out=None, accumulate=False):
+    """C[M,N] (+)= A[M,K] @ B[K,N] on the exact-f32 MFMA pipe."""
+    A = L.require_cuda_f32(A, "A", 2)
+    B = L.require_cuda_f32(B, "B", 2)
+    M, K = A.shape
+    if B.shape[0] != K:
+        raise ValueError("gemm_nn: inner dimensions differ")
+    N = B.shape[1]
+    C = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=A.device)
+    L.check(L.lib().dh3d_gemm_nn_f32(L.ptr(A), L.ptr(B), M, K, N, 1 if accumulate else 0, L.ptr(C), L.stream_ptr()),
+            "gemm_nn")
+    return C
+
+
+def transpose_last2(x):
+    """[..., R, C] -> [..., C, R] (32-bit elements) through LDS tiles."""
+    if not x.is_cuda or x.element_size() != 4:
+        raise ValueError("transpose_last2: 32-bit GPU tensors only")
+    x = x.contiguous()
+    R, C = x.shape[-2], x.shape[-1]
+    Bt = x.numel() // (R * C)
+    out = torch.empty(tuple(x.shape[:-2]) + (C, R), dtype=x.dtype, device=x.device)
+    L.check(L.lib().dh3d_transpose32(L.ptr(x), Bt, R, C, L.ptr(out), L.stream_ptr()), "transpose32")
+    return out
+
+
+def colsum(x, out=None, accumulate=False):
+    """x [R, C] -> [C] column sums (bias gradients)."""
+    x = L.require_cuda_f32(x, "x", 2)
+    R, C = x.shape
+    o = out if out is not None else torch.empty((C,), dtype=torch.float32, device=x.device)
+    L.check(L.lib().dh3d_colsum_f32(L.ptr(x), R, C, 1 if accumulate else 0, L.ptr(o), L.stream_ptr()), "colsum")
+    return o

@@ -104,8 +104,8 @@ class _FlexConvFactorised(torch.autograd.Function):
         out = [S0 | Sx | Sy | Sz] @ [bias; theta_x; theta_y; theta_z],  S0 = sum_k f[n_k],  Sd = sum_k dp_d(k) f[n_k]
     (the form the fused inference kernel runs; the drop-in op `ops.flex_convolution` keeps the reference's
     9*K*Din*Dout-flop formulation and its atomics backward: 21 of the 32 ms of a 22-cloud step).  Forward = the fused
-    HIP kernel; backward = the same factorisation differentiated: dW = S^T dOut, dS = dOut W^T, and dS scattered back
-    over the neighbour lists.  Gradients w.r.t. features, theta and bias (positions are data).  Centre = the point
+    HIP kernel; backward = the same factorisation differentiated, also in HIP (pm.flex_conv_bwd): dW = S^T dOut and
+    dS = dOut W^T on the MFMA pipe, dS scattered back over the neighbour lists with f32 atomics.  Gradients w.r.t. features, theta and bias (positions are data).  Centre = the point
     itself (the GPU forward's rule, flex_conv_kernel_gpu.cu.cc:77-79; identical to the backward's rank-0-neighbour
     rule under exact kNN)."""
 
@@ -118,22 +118,13 @@ class _FlexConvFactorised(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        from . import pm
         feat, xyz, nbr, theta, bias = ctx.saved_tensors
-        B, M, Din = feat.shape
-        K, Dout = nbr.shape[2], theta.shape[2]
-        R = B * M
-        flat = (nbr.long() + (torch.arange(B, device=nbr.device) * M).view(B, 1, 1)).reshape(R, K)
-        f2, p2 = feat.reshape(R, Din), xyz.reshape(R, 3)
-        fn = f2[flat]                                        # [R,K,Din]
-        dp = p2[flat] - p2[:, None, :]                       # [R,K,3]
-        S = torch.cat([fn.sum(1, keepdim=True), torch.einsum("rkd,rkc->rdc", dp, fn)], 1)   # [R,4,Din]
-        g = dout.reshape(R, Dout)
-        dW = S.reshape(R, 4 * Din).t() @ g                   # [4*Din, Dout]
-        W = torch.cat([bias[None], theta], 0).reshape(4 * Din, Dout)
-        dS = (g @ W.t()).reshape(R, 4, Din)
-        dfn = dS[:, 0:1] + torch.einsum("rkd,rdc->rkc", dp, dS[:, 1:])                      # [R,K,Din]
-        dfeat = torch.zeros_like(f2).index_add_(0, flat.reshape(-1), dfn.reshape(-1, Din))
-        return dfeat.reshape(B, M, Din), None, None, dW[Din:].reshape(3, Din, Dout), dW[:Din]
+        # dWcat = S^T dOut and dS = dOut Wcat^T on the f32 MFMA pipe, dS scattered over the neighbour lists with
+        # hardware f32 atomics (csrc/flex_bwd.hip)
+        dfeat, dtheta, dbias = pm.flex_conv_bwd(feat, xyz, nbr, theta.detach(), bias.detach(), dout.contiguous(),
+                                                center_rank0=False, need_grad_features=ctx.needs_input_grad[0])
+        return dfeat, None, None, dtheta, dbias
 
 
 def flex_conv_factorised(feat, xyz, nbr, theta, bias):

@@ -132,6 +132,28 @@ int dh3d_three_interpolate_bwd(int b, int n, int c, int m, const float *grad_out
                                const int32_t *idx, const float *weight, float *grad_points,
                                void *stream);
 
+/* ---- A'. The same operators on the fast kernels (reference layouts, caller-provided workspace) ----
+ * FlexConv / FlexConvGrad / FlexPool with the signatures above + (workspace, workspace_bytes): the channels-first
+ * tensors are transposed through LDS tiles into the workspace, the fused point-major MFMA kernels of section B run
+ * (flex_conv: the bf16x6 pipeline for K = 8, Dout = 64, Din in {32, 64}; the exact-f32 MFMA kernel for the other
+ * DH3D shapes), and the result is transposed back.  Same function as the section-A entry (forward centres on
+ * point n, backward on the rank-0 neighbour); summation order differs (factorised form), within the reference's own
+ * CPU-vs-GPU tolerance.  *_workspace_bytes returns 0 when the shape is not served -- use the section-A entry then.
+ * The backward is  dWcat = S^T dOut,  dS = dOut Wcat^T  on the f32 MFMA pipe + an atomics scatter of dS over the
+ * neighbour lists (the reference's feature gradient is atomics too, flex_conv_kernel_gpu.cu.cc:250-385). */
+size_t dh3d_flex_conv_fwd_workspace_bytes(int B, int N, int K, int Dp, int Din, int Dout);
+int dh3d_flex_conv_fwd_ws(const float *features, const float *theta, const float *bias,
+                          const int32_t *neighborhood, const float *positions, int B, int N, int K, int Dp,
+                          int Din, int Dout, float *output, void *workspace, size_t workspace_bytes, void *stream);
+size_t dh3d_flex_conv_bwd_workspace_bytes(int B, int N, int K, int Dp, int Din, int Dout);
+int dh3d_flex_conv_bwd_ws(const float *features, const float *theta, const float *bias,
+                          const int32_t *neighborhood, const float *positions, const float *topdiff, int B, int N,
+                          int K, int Dp, int Din, int Dout, float *grad_features, float *grad_theta,
+                          float *grad_bias, void *workspace, size_t workspace_bytes, void *stream);
+size_t dh3d_flex_pool_fwd_workspace_bytes(int B, int N, int K, int D);
+int dh3d_flex_pool_fwd_ws(const float *features, const int32_t *neighborhood, int B, int N, int K, int D,
+                          float *output, int32_t *argmax, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ===================================================================================== *
  * B. Fused point-major kernels (model path)
  *    Activations are [B,N,C] (C contiguous).  Neighbourhoods are [B,N,K] (the kNN op's native
@@ -310,6 +332,30 @@ int dh3d_netvlad_head_fwd(const float *vlad, const float *Wh, const float *bn1_s
                           const float *bn1_shift, const float *Wg, const float *bn2_scale,
                           const float *bn2_shift, int B, int Kd, int O, float l2_eps,
                           void *workspace, size_t workspace_bytes, float *out, void *stream);
+
+/* ===================================================================================== *
+ * C. Backward / training kernels (point-major)
+ * ===================================================================================== */
+
+/* flex_conv backward, factorised (csrc/flex_bwd.hip): features [B,N,Din], xyz [B,N,3], nbr [B,N,K], theta [3,Din,Dout],
+ * bias [Din,Dout], grad_out [B,N,Dout] -> grad_features [B,N,Din] (may be NULL: weights only), grad_theta, grad_bias.
+ * center_rank0: offsets relative to the rank-0 neighbour (the reference backward's rule) instead of the point itself.
+ * Zeroes its outputs.  workspace: dh3d_flex_conv_pm_bwd_workspace_bytes.  Din % 4 == 0, Dout % 4 == 0. */
+size_t dh3d_flex_conv_pm_bwd_workspace_bytes(int B, int N, int Din, int Dout);
+int dh3d_flex_conv_pm_bwd(const float *features, const float *xyz, const int32_t *nbr, const float *theta,
+                          const float *bias, const float *grad_out, int B, int N, int K, int Din, int Dout,
+                          int center_rank0, void *workspace, size_t workspace_bytes, float *grad_features,
+                          float *grad_theta, float *grad_bias, void *stream);
+
+/* Exact-f32 MFMA GEMMs of the backward passes (csrc/gemm.hip), all row-major:
+ *   tn: C[M,N] (+)= A[K,M]^T B[K,N]  (weight gradients: reduction over rows, split over workgroups + f32 atomics)
+ *   nn: C[M,N] (+)= A[M,K]   B[K,N]  (input gradients with W^T materialised)
+ * accumulate = 0 overwrites C.  M, N (tn) / K, N (nn) multiples of 4. */
+int dh3d_gemm_tn_f32(const float *A, const float *B, int K, int M, int N, int accumulate, float *C, void *stream);
+int dh3d_gemm_nn_f32(const float *A, const float *B, int M, int K, int N, int accumulate, float *C, void *stream);
+/* [Bt,R,C] -> [Bt,C,R] of 32-bit elements; out[c] (+)= sum_r x[r,c]. */
+int dh3d_transpose32(const void *in, int Bt, int R, int C, void *out, void *stream);
+int dh3d_colsum_f32(const float *x, long long R, int C, int accumulate, float *out, void *stream);
 
 #ifdef __cplusplus
 }

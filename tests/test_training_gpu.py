@@ -199,7 +199,10 @@ if sync_bn:
     # sync-BN + sharding == the single-process step (summation order differs: tolerance, not equality)
     assert abs(losses[0] - ref_losses[0]) < 1e-5, (losses, ref_losses)
     for g, q in zip(grads, ref_grads):   # the reduced gradient of the first step (parameters after Adam are sign-like)
-        tol = 1e-3 * float(q.abs().max()) + 1e-7
+        # f32 sums in another order through three chained batch norms (variance as E[x^2] - E[x]^2), atomics in the
+        # flex_conv backward: a few 1e-3 of the largest entry; a sharding bug (padding in the statistics, a lost
+        # slice) shows up at 1e-1
+        tol = 5e-3 * float(q.abs().max()) + 1e-7
         assert float((g - q).abs().max()) <= tol, (float((g - q).abs().max()), float(q.abs().max()))
     for k, v in bufs1.items():
         assert torch.allclose(v, ref_bufs[k], rtol=1e-4, atol=1e-5), k
