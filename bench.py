@@ -422,7 +422,11 @@ def main():
         trainer = QuadrupletTrainer(model)
         pts = synthetic_clouds(wl["B"], wl["N"], wl["seed"], dev, 0)  # same role-ordered batch on every rank
         dt = time_steps(lambda p: trainer.step(p), pts, args.steps, args.warmup, dev)
-        extra = {"phases_ms": trainer.phase_times_ms()} if hasattr(trainer, "phase_times_ms") else {}
+        trainer.time_phases(True)   # five more (untimed) steps with events around the phases
+        for _ in range(5):
+            trainer.step(pts)
+        extra = {"phases_ms": trainer.phase_times_ms(), "head_implementation": trainer.impl}
+        trainer.time_phases(False)
         return wl["B"] * args.steps / dt, dt / args.steps * 1e3, extra
 
     def measure(workload, batch=None):

@@ -21,6 +21,7 @@ c_fp = ctypes.c_void_p  # device pointers travel as void*
 c_int = ctypes.c_int
 c_size_t = ctypes.c_size_t
 c_float = ctypes.c_float
+c_ll = ctypes.c_longlong
 
 
 class Epilogue(ctypes.Structure):
@@ -56,9 +57,23 @@ _SIGNATURES = {
     "dh3d_flex_conv_pm_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp,
                               c_size_t, c_fp, c_fp, c_fp, c_fp],
     "dh3d_gemm_tn_f32": [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp],
-    "dh3d_gemm_nn_f32": [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp],
+    "dh3d_gemm_nn_f32": [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp],
+    "dh3d_gemm_tn_f32_batched": [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp],
+    "dh3d_gemm_nn_f32_batched": [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp],
+    "dh3d_bn_colstats": [c_fp, c_ll, c_int, c_fp, c_int, c_fp, c_fp, c_fp],
+    "dh3d_bn_finalize": [c_fp, c_fp, c_fp, c_fp, c_fp, c_float, c_float, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp],
+    "dh3d_scale_shift_act": [c_fp, c_ll, c_int, c_fp, c_fp, c_int, c_fp, c_fp],
+    "dh3d_row_logit_sigmoid": [c_fp, c_ll, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp],
+    "dh3d_bn_bwd_sums": [c_fp, c_fp, c_fp, c_fp, c_ll, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_int,
+                         c_fp, c_fp, c_fp, c_fp],
+    "dh3d_bn_bwd_finalize": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_fp],
+    "dh3d_bn_bwd_apply": [c_fp, c_fp, c_fp, c_fp, c_ll, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_int,
+                          c_fp, c_fp],
+    "dh3d_netvlad_assign_rows": [c_fp, c_ll, c_int, c_fp, c_fp, c_fp, c_fp, c_fp],
+    "dh3d_netvlad_assign_rows_bwd": [c_fp, c_ll, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp],
+    "dh3d_l2norm_rows_bwd": [c_fp, c_fp, c_ll, c_int, c_float, c_fp, c_fp],
     "dh3d_transpose32": [c_fp, c_int, c_int, c_int, c_fp, c_fp],
-    "dh3d_colsum_f32": [c_fp, ctypes.c_longlong, c_int, c_int, c_fp, c_fp],
+    "dh3d_colsum_f32": [c_fp, c_ll, c_int, c_int, c_fp, c_fp],
     "dh3d_farthest_point_sample": [c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp],
     "dh3d_farthest_point_sample_mode": [c_int, c_int, c_int, c_fp, c_fp, c_fp, c_int, c_fp],
     "dh3d_group_point_fwd": [c_int, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp],

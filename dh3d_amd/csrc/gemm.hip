@@ -26,7 +26,9 @@ template <bool TA, int WM, int WN>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__ A, int lda,
                                                       const float *__restrict__ B, int ldb, float *__restrict__ C,
                                                       int ldc, int M, int N, int K, int kchunk, int atomic,
-                                                      float *__restrict__ C1, int rows0) {
+                                                      float *__restrict__ C1, int rows0,
+                                                      const float *__restrict__ colbias, int chunks, long long sA,
+                                                      long long sB, long long sC, long long sBias) {
   constexpr int BM = 64 * WM, BN = 64 * WN, LA = BM + 4, LB = BN + 4;
   constexpr int NA = kKC * BM / 4 / 256, NBv = kKC * BN / 4 / 256;  // float4 per thread per stage
   static_assert(NA >= 1 && NBv >= 1, "tile too small for 256 threads");
@@ -34,8 +36,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
   __shared__ __attribute__((aligned(16))) float s_B[2][kKC * LB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
-  const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+  const int bz = blockIdx.z / chunks;  // batch entry (strides sA / sB / sC / sBias elements), then reduction chunk
+  const int kbeg = (blockIdx.z - bz * chunks) * kchunk, kend = min(K, kbeg + kchunk);
   if (kbeg >= kend) return;
+  A += (size_t)bz * sA; B += (size_t)bz * sB; C += (size_t)bz * sC;
+  if (colbias) colbias += (size_t)bz * sBias;
 
   float4 ra[NA], rb[NBv];
   auto load = [&](int k0) {
@@ -132,13 +137,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
       const int n = n0 + (wave >> 1) * 32 * WN + 32 * j + (lane & 31);
+      const float cb = (colbias && n < N) ? colbias[n] : 0.f;  // only with a single, non-atomic reduction chunk
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + (wave & 1) * 32 * WM + 32 * i + mfma_row(r, lane);
         if (m < M && n < N) {
           float *dst = (C1 && m >= rows0) ? C1 + (size_t)(m - rows0) * ldc + n : C + (size_t)m * ldc + n;
           if (atomic) unsafeAtomicAdd(dst, acc[i][j][r]);
-          else *dst = acc[i][j][r];
+          else *dst = acc[i][j][r] + cb;
         }
       }
     }
@@ -179,36 +185,41 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x
   if (q == 0 && c < Cc) unsafeAtomicAdd(out + c, (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]));
 }
 
+struct GemmBatch { int n; long long sA, sB, sC, sBias; };
+
 int gemm_launch(bool ta, const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N, int K,
-                float *C1, int rows0, bool accumulate, hipStream_t s) {
-  // tile: 128 x 128 (or 128 x 64 for narrow N); reduction split so that ~3 workgroups per CU exist
+                float *C1, int rows0, bool accumulate, hipStream_t s, const float *colbias = nullptr,
+                GemmBatch bt = GemmBatch{1, 0, 0, 0, 0}) {
+  // tile: 128 x 128 (or 128 x 64 for narrow N); the reduction is split so that ~3 workgroups per CU exist
   const bool narrow = N <= 64;
   const int BM = 128, BN = narrow ? 64 : 128;
   const int gm = dh3d_cdiv(M, BM), gn = dh3d_cdiv(N, BN);
-  int chunks = 1;
-  if (ta) {
-    chunks = dh3d_cdiv(768, gm * gn);
-    const int maxc = dh3d_cdiv(K, 64);
-    chunks = chunks > maxc ? maxc : chunks;
-    if (chunks < 1) chunks = 1;
-  }
+  int chunks = dh3d_cdiv(768, gm * gn * bt.n);
+  const int maxc = dh3d_cdiv(K, ta ? 64 : 256);  // [M,K] operands: only long reductions are worth the atomics
+  chunks = chunks > maxc ? maxc : chunks;
+  if (chunks < 1 || colbias) chunks = 1;
   int kchunk = dh3d_cdiv(K, chunks);
   kchunk = (kchunk + kKC - 1) / kKC * kKC;  // multiple of 16: float4 loads of the [M,K] operand stay aligned
   chunks = dh3d_cdiv(K, kchunk);
   const int atomic = (chunks > 1 || accumulate) ? 1 : 0;
+  if (colbias && atomic) return DH3D_ERR_UNSUPPORTED;
+  if ((long long)chunks * bt.n > 65535) return DH3D_ERR_UNSUPPORTED;
   if (atomic && !accumulate) {  // the split partials add into zeros
     if (C1) {
       if (hipMemsetAsync(C, 0, sizeof(float) * (size_t)rows0 * ldc, s) != hipSuccess) return DH3D_ERR_LAUNCH;
       if (hipMemsetAsync(C1, 0, sizeof(float) * (size_t)(M - rows0) * ldc, s) != hipSuccess) return DH3D_ERR_LAUNCH;
-    } else if (ldc == N) {
-      if (hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N, s) != hipSuccess) return DH3D_ERR_LAUNCH;
-    } else {
+    } else if (ldc == N && (bt.n == 1 || bt.sC == (long long)M * N)) {
+      if (hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N * bt.n, s) != hipSuccess) return DH3D_ERR_LAUNCH;
+    } else if (bt.n == 1) {
       if (hipMemset2DAsync(C, sizeof(float) * ldc, 0, sizeof(float) * N, M, s) != hipSuccess) return DH3D_ERR_LAUNCH;
+    } else {
+      return DH3D_ERR_UNSUPPORTED;
     }
   }
-  const dim3 grid(gn, gm, chunks), block(256);
-#define DH3D_GEMM(TAV, WNV) \
-  hipLaunchKernelGGL((gemm_f32_kernel<TAV, 2, WNV>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, kchunk, atomic, C1, rows0)
+  const dim3 grid(gn, gm, chunks * bt.n), block(256);
+#define DH3D_GEMM(TAV, WNV)                                                                                          \
+  hipLaunchKernelGGL((gemm_f32_kernel<TAV, 2, WNV>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, kchunk, atomic, \
+                     C1, rows0, colbias, chunks, bt.sA, bt.sB, bt.sC, bt.sBias)
   if (ta) { if (narrow) DH3D_GEMM(true, 1); else DH3D_GEMM(true, 2); }
   else { if (narrow) DH3D_GEMM(false, 1); else DH3D_GEMM(false, 2); }
 #undef DH3D_GEMM
@@ -237,11 +248,29 @@ DH3D_API int dh3d_gemm_tn_f32(const float *A, const float *B, int K, int M, int 
   return gemm_launch(true, A, M, B, N, C, N, M, N, K, nullptr, 0, accumulate != 0, (hipStream_t)stream);
 }
 
-DH3D_API int dh3d_gemm_nn_f32(const float *A, const float *B, int M, int K, int N, int accumulate, float *C,
-                              void *stream) {
-  DH3D_REQUIRE(A && B && C && K > 0 && M > 0 && N > 0);
+DH3D_API int dh3d_gemm_nn_f32(const float *A, const float *B, const float *colbias, int M, int K, int N,
+                              int accumulate, float *C, void *stream) {
+  DH3D_REQUIRE(A && B && C && K > 0 && M > 0 && N > 0 && !(colbias && accumulate));
   DH3D_SUPPORTED(K % 4 == 0 && N % 4 == 0 && dh3d_cdiv(M, 128) <= 65535);
-  return gemm_launch(false, A, K, B, N, C, N, M, N, K, nullptr, 0, accumulate != 0, (hipStream_t)stream);
+  return gemm_launch(false, A, K, B, N, C, N, M, N, K, nullptr, 0, accumulate != 0, (hipStream_t)stream, colbias);
+}
+
+// batched forms: `batch` independent products, operands of entry b at A + b*K*M etc. (dense, back to back);
+// colbias (nn only) [batch, N]
+DH3D_API int dh3d_gemm_tn_f32_batched(const float *A, const float *B, int batch, int K, int M, int N, float *C,
+                                      void *stream) {
+  DH3D_REQUIRE(A && B && C && batch > 0 && K > 0 && M > 0 && N > 0);
+  DH3D_SUPPORTED(M % 4 == 0 && N % 4 == 0 && M / 128 <= 65535);
+  return gemm_launch(true, A, M, B, N, C, N, M, N, K, nullptr, 0, false, (hipStream_t)stream, nullptr,
+                     GemmBatch{batch, (long long)K * M, (long long)K * N, (long long)M * N, 0});
+}
+
+DH3D_API int dh3d_gemm_nn_f32_batched(const float *A, const float *B, const float *colbias, int batch, int M, int K,
+                                      int N, float *C, void *stream) {
+  DH3D_REQUIRE(A && B && C && batch > 0 && K > 0 && M > 0 && N > 0);
+  DH3D_SUPPORTED(K % 4 == 0 && N % 4 == 0 && dh3d_cdiv(M, 128) <= 65535);
+  return gemm_launch(false, A, K, B, N, C, N, M, N, K, nullptr, 0, false, (hipStream_t)stream, colbias,
+                     GemmBatch{batch, (long long)M * K, (long long)K * N, (long long)M * N, N});
 }
 
 DH3D_API int dh3d_transpose32(const void *in, int Bt, int R, int Cc, void *out, void *stream) {

@@ -1,0 +1,370 @@
+// Training-mode BatchNorm and the attention head's element-wise passes for the Siamese training step (gfx950).
+//
+// The reference trains with batch statistics (tensorpack BatchNorm / slim batch_norm with is_training,
+// core/tf_utils.py:60-63, core/backbones.py:145-173,218-223,271-274): TF runs one fused_batch_norm / moments +
+// batchnorm pair per site, forward and backward.  Here every site is two HBM-bound passes per direction:
+//   forward   column statistics (sum, sum of squares; f32 per thread, f64 hardware atomics across workgroups, so that
+//             var = E[x^2] - E[x]^2 is formed from exact-ish sums)  ->  [host: mean / rstd / folded scale, shift; under
+//             sync-BN the all-reduce of (sum, sumsq, count) sits here]  ->  y = act(x * scale + shift)
+//   backward  S1 = sum dz, S2 = sum dz * xhat  (dz = dy through the ReLU mask, recomputed from x)  ->  [all-reduce under
+//             sync-BN]  ->  dx = gamma * rstd * (dz - S1/n - xhat * S2/n);   dgamma = S2, dbeta = S1.
+// The attention head (core/backbones.py:156-173: 256 -> 1024 BNReLU -> 1, sigmoid) never materialises its
+// [R, 1024] activation gradient before the BatchNorm: dy[n,c] = dlogit[n] * w_fc[c] is rank one, so both backward passes
+// take (dlogit, w_fc) instead of dy, the first one also accumulates the gradient of w_fc, and the second one overwrites
+// the saved pre-activation in place with its gradient.
+// Rows of padding clouds (sharded batches, dh3d_amd/dist.py) are excluded through a per-cloud mask.
+#include "common.h"
+
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace {
+
+__device__ __forceinline__ bool row_live(const unsigned char *mask, long long r, int rows_per_cloud) {
+  return !mask || mask[r / rows_per_cloud] != 0;
+}
+
+// grid (ceil(C/64), chunks); 256 threads = 4 row lanes x 64 columns
+__global__ __launch_bounds__(256) void colstats_kernel(const float *__restrict__ x, long long R, int C, int rows_per,
+                                                      const unsigned char *__restrict__ mask, int rows_per_cloud,
+                                                      double *__restrict__ sum, double *__restrict__ sumsq) {
+  __shared__ float s1[4][64], s2[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  const long long r0 = (long long)blockIdx.y * rows_per, r1 = min(R, r0 + rows_per);
+  float a = 0.f, b = 0.f;
+  if (c < C)
+    for (long long r = r0 + q; r < r1; r += 4)
+      if (row_live(mask, r, rows_per_cloud)) { const float v = x[r * C + c]; a += v; b = fmaf(v, v, b); }
+  s1[q][threadIdx.x & 63] = a; s2[q][threadIdx.x & 63] = b;
+  __syncthreads();
+  if (q == 0 && c < C) {
+    const int t = threadIdx.x;
+    unsafeAtomicAdd(sum + c, ((double)s1[0][t] + s1[1][t]) + ((double)s1[2][t] + s1[3][t]));
+    unsafeAtomicAdd(sumsq + c, ((double)s2[0][t] + s2[1][t]) + ((double)s2[2][t] + s2[3][t]));
+  }
+}
+
+// y = act(x * scale[c] + shift[c]), float4 per lane
+__global__ __launch_bounds__(256) void scale_shift_act_kernel(const float *__restrict__ x, long long R, int C,
+                                                             const float *__restrict__ scale,
+                                                             const float *__restrict__ shift, int relu,
+                                                             float *__restrict__ y) {
+  const int cv = C / 4;
+  const long long total = R * cv;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int c4 = (int)(e % cv) * 4;
+    const float4 v = reinterpret_cast<const float4 *>(x)[e];
+    const float4 sc = *reinterpret_cast<const float4 *>(scale + c4), sh = *reinterpret_cast<const float4 *>(shift + c4);
+    float4 o;
+    o.x = fmaf(v.x, sc.x, sh.x); o.y = fmaf(v.y, sc.y, sh.y); o.z = fmaf(v.z, sc.z, sh.z); o.w = fmaf(v.w, sc.w, sh.w);
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    reinterpret_cast<float4 *>(y)[e] = o;
+  }
+}
+
+// att[n] = sigmoid(sum_c relu(h[n,c] * scale[c] + shift[c]) * w[c] + b): one wave per row
+__global__ __launch_bounds__(256) void row_logit_kernel(const float *__restrict__ h, long long R, int C,
+                                                       const float *__restrict__ scale, const float *__restrict__ shift,
+                                                       const float *__restrict__ w, const float *__restrict__ bptr,
+                                                       float *__restrict__ att) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  float acc = 0.f;
+  for (int c4 = lane * 4; c4 < C; c4 += 256) {
+    const float4 v = *reinterpret_cast<const float4 *>(h + row * C + c4);
+    const float4 sc = *reinterpret_cast<const float4 *>(scale + c4), sh = *reinterpret_cast<const float4 *>(shift + c4);
+    const float4 ww = *reinterpret_cast<const float4 *>(w + c4);
+    acc = fmaf(fmaxf(fmaf(v.x, sc.x, sh.x), 0.f), ww.x, acc);
+    acc = fmaf(fmaxf(fmaf(v.y, sc.y, sh.y), 0.f), ww.y, acc);
+    acc = fmaf(fmaxf(fmaf(v.z, sc.z, sh.z), 0.f), ww.z, acc);
+    acc = fmaf(fmaxf(fmaf(v.w, sc.w, sh.w), 0.f), ww.w, acc);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0) att[row] = 1.f / (1.f + expf(-(acc + bptr[0])));
+}
+
+// backward sums.  dy == nullptr: dy[n,c] = rowscale[n] * colvec[c] (attention head) and S3[c] += rowscale[n] * y[n,c].
+// xhat = (x - mean) * rstd;  y = xhat * gamma + beta;  dz = relu ? dy * [y > 0] : dy
+__global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                         const float *__restrict__ rowscale,
+                                                         const float *__restrict__ colvec, long long R, int C,
+                                                         int rows_per, const float *__restrict__ mean,
+                                                         const float *__restrict__ rstd, const float *__restrict__ gamma,
+                                                         const float *__restrict__ beta, int relu,
+                                                         const unsigned char *__restrict__ mask, int rows_per_cloud,
+                                                         double *__restrict__ S1, double *__restrict__ S2,
+                                                         double *__restrict__ S3) {
+  __shared__ float s[3][4][64];
+  const int t = threadIdx.x & 63, c = blockIdx.x * 64 + t, q = threadIdx.x >> 6;
+  const long long r0 = (long long)blockIdx.y * rows_per, r1 = min(R, r0 + rows_per);
+  float a = 0.f, b = 0.f, d = 0.f;
+  if (c < C) {
+    const float mu = mean[c], rs = rstd[c], g = gamma[c], be = beta[c], cvv = colvec ? colvec[c] : 0.f;
+    for (long long r = r0 + q; r < r1; r += 4) {
+      if (!row_live(mask, r, rows_per_cloud)) continue;
+      const float xh = (x[r * C + c] - mu) * rs;
+      const float y = fmaf(xh, g, be);
+      float dz = dy ? dy[r * C + c] : rowscale[r] * cvv;
+      if (relu && !(y > 0.f)) dz = 0.f;
+      a += dz; b = fmaf(dz, xh, b);
+      if (!dy) d = fmaf(rowscale[r], relu ? fmaxf(y, 0.f) : y, d);
+    }
+  }
+  s[0][q][t] = a; s[1][q][t] = b; s[2][q][t] = d;
+  __syncthreads();
+  if (q == 0 && c < C) {
+    unsafeAtomicAdd(S1 + c, ((double)s[0][0][t] + s[0][1][t]) + ((double)s[0][2][t] + s[0][3][t]));
+    unsafeAtomicAdd(S2 + c, ((double)s[1][0][t] + s[1][1][t]) + ((double)s[1][2][t] + s[1][3][t]));
+    if (S3) unsafeAtomicAdd(S3 + c, ((double)s[2][0][t] + s[2][1][t]) + ((double)s[2][2][t] + s[2][3][t]));
+  }
+}
+
+// dx = gamma*rstd*(dz - S1/n - xhat*S2/n) with everything per-column folded by bn_bwd_finalize:
+//   dx = k1[c]*dz - k2[c] - k3[c]*x,   dz = relu ? dy*[x*scale[c] + shift[c] > 0] : dy
+// (k1 = scale = gamma*rstd, k3 = gamma*rstd^2*S2/n, k2 = gamma*rstd*S1/n - k3*mean).  dx may alias x or dy (in place).
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *x, const float *dy,
+                                                          const float *__restrict__ rowscale,
+                                                          const float *__restrict__ colvec, long long R, int C,
+                                                          const float *__restrict__ scale, const float *__restrict__ shift,
+                                                          const float *__restrict__ k2, const float *__restrict__ k3,
+                                                          int relu, const unsigned char *__restrict__ mask,
+                                                          int rows_per_cloud, float *dx) {
+  const int cv = C / 4;
+  // one workgroup walks whole rows: the column of a lane is fixed, its coefficients live in registers
+  const int c4 = (threadIdx.x % cv) * 4;
+  const int rpb = 256 / cv > 0 ? 256 / cv : 1;      // rows per block pass (cv <= 256)
+  const int rl = threadIdx.x / cv;
+  if (rl >= rpb) return;
+  const float4 sc = *reinterpret_cast<const float4 *>(scale + c4), sh = *reinterpret_cast<const float4 *>(shift + c4);
+  const float4 q2 = *reinterpret_cast<const float4 *>(k2 + c4), q3 = *reinterpret_cast<const float4 *>(k3 + c4);
+  float4 cvv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!dy) cvv = *reinterpret_cast<const float4 *>(colvec + c4);
+  for (long long r = (long long)blockIdx.x * rpb + rl; r < R; r += (long long)gridDim.x * rpb) {
+    const size_t e = (size_t)r * cv + c4 / 4;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row_live(mask, r, rows_per_cloud)) {
+      const float4 xv = reinterpret_cast<const float4 *>(x)[e];
+      float4 dv;
+      if (dy) dv = reinterpret_cast<const float4 *>(dy)[e];
+      else { const float rsn = rowscale[r]; dv = make_float4(rsn * cvv.x, rsn * cvv.y, rsn * cvv.z, rsn * cvv.w); }
+      if (relu) {
+        if (!(fmaf(xv.x, sc.x, sh.x) > 0.f)) dv.x = 0.f;
+        if (!(fmaf(xv.y, sc.y, sh.y) > 0.f)) dv.y = 0.f;
+        if (!(fmaf(xv.z, sc.z, sh.z) > 0.f)) dv.z = 0.f;
+        if (!(fmaf(xv.w, sc.w, sh.w) > 0.f)) dv.w = 0.f;
+      }
+      o.x = fmaf(sc.x, dv.x, -q2.x) - q3.x * xv.x; o.y = fmaf(sc.y, dv.y, -q2.y) - q3.y * xv.y;
+      o.z = fmaf(sc.z, dv.z, -q2.z) - q3.z * xv.z; o.w = fmaf(sc.w, dv.w, -q2.w) - q3.w * xv.w;
+    }
+    reinterpret_cast<float4 *>(dx)[e] = o;
+  }
+}
+
+// One launch instead of ~15 tiny tensor ops per BatchNorm site and direction.
+// forward: (sum, sumsq, count) f64 -> mean, rstd, folded scale/shift; running buffers updated with decay `momentum`
+// (left alone when count == 0: a rank that holds only padding clouds).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double *__restrict__ sum, const double *__restrict__ sumsq,
+                                                         const double *__restrict__ cnt, const float *__restrict__ gamma,
+                                                         const float *__restrict__ beta, float eps, float momentum,
+                                                         float *__restrict__ run_mean, float *__restrict__ run_var, int C,
+                                                         float *__restrict__ mean, float *__restrict__ rstd,
+                                                         float *__restrict__ scale, float *__restrict__ shift) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const double n = cnt[0] > 1.0 ? cnt[0] : 1.0;
+  const double mu = sum[c] / n;
+  double var = sumsq[c] / n - mu * mu;
+  var = var > 0.0 ? var : 0.0;
+  const float rs = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[c] * rs;
+  mean[c] = (float)mu; rstd[c] = rs; scale[c] = sc; shift[c] = beta[c] - (float)mu * sc;
+  if (cnt[0] > 0.0) {
+    run_mean[c] = momentum * run_mean[c] + (1.f - momentum) * (float)mu;
+    run_var[c] = momentum * run_var[c] + (1.f - momentum) * (float)var;
+  }
+}
+// backward: (S1, S2, count) f64 (+ mean, rstd, gamma) -> k2, k3 of bn_bwd_apply
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double *__restrict__ S1, const double *__restrict__ S2,
+                                                             const double *__restrict__ cnt, const float *__restrict__ mean,
+                                                             const float *__restrict__ rstd, const float *__restrict__ gamma,
+                                                             int C, float *__restrict__ k2, float *__restrict__ k3) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const double n = cnt[0] > 1.0 ? cnt[0] : 1.0;
+  const float m1 = (float)(S1[c] / n), m2 = (float)(S2[c] / n);
+  const float q3 = gamma[c] * rstd[c] * rstd[c] * m2;
+  k3[c] = q3;
+  k2[c] = gamma[c] * rstd[c] * m1 - q3 * mean[c];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// NetVLAD soft assignment (core/backbones.py:214-238), one wave per row of s = xn @ Wc (64 clusters = 64 lanes):
+//   z = s*scale + shift (training: folded batch statistics);  p = softmax(z);  a = p * att[n]
+// backward given da = dL/da:  datt[n] = sum_c da*p;  dp = da*att;  dz = p * (dp - sum_c dp*p)
+template <bool BWD>
+__global__ __launch_bounds__(256) void netvlad_assign_rows_kernel(const float *__restrict__ sm, long long R,
+                                                                 const float *__restrict__ scale,
+                                                                 const float *__restrict__ shift,
+                                                                 const float *__restrict__ att,
+                                                                 const float *__restrict__ da, float *__restrict__ out,
+                                                                 float *__restrict__ datt) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const float z = fmaf(sm[row * 64 + lane], scale[lane], shift[lane]);
+  float m = z;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  const float e = expf(z - m);
+  float den = e;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) den += __shfl_xor(den, off, 64);
+  const float p = e / den, w = att[row];
+  if (!BWD) { out[row * 64 + lane] = p * w; return; }
+  const float g = da[row * 64 + lane];
+  float d1 = g * p;           // -> datt
+  float d2 = g * w * p;       // -> sum_c dp * p
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { d1 += __shfl_xor(d1, off, 64); d2 += __shfl_xor(d2, off, 64); }
+  out[row * 64 + lane] = p * (g * w - d2);
+  if (lane == 0) datt[row] = d1;
+}
+
+// backward of xn = x * rsqrt(max(sum x^2, eps)) (tf.nn.l2_normalize), one wave per row
+__global__ __launch_bounds__(256) void l2norm_rows_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dxn,
+                                                             long long R, int C, float eps, float *__restrict__ dx) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  float ss = 0.f, dot = 0.f;
+  for (int c = lane; c < C; c += 64) { const float v = x[row * C + c]; ss = fmaf(v, v, ss); dot = fmaf(v, dxn[row * C + c], dot); }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { ss += __shfl_xor(ss, off, 64); dot += __shfl_xor(dot, off, 64); }
+  const float inv = rsqrtf(fmaxf(ss, eps));
+  // d/dx [x * inv]: inv * dxn - x * inv^3 * (x . dxn) where the norm is active, inv * dxn where it is clamped
+  const float k = ss > eps ? inv * inv * inv * dot : 0.f;
+  for (int c = lane; c < C; c += 64) dx[row * C + c] = fmaf(-x[row * C + c], k, inv * dxn[row * C + c]);
+}
+
+inline int flat_grid(long long work) {
+  long long g = (work + 255) / 256;
+  return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
+}
+inline int row_chunks(long long R, int *rows_per) {
+  int chunks = dh3d_cdiv(R, 128);
+  chunks = chunks > 1024 ? 1024 : chunks;
+  *rows_per = dh3d_cdiv(R, chunks);
+  return dh3d_cdiv(R, *rows_per);
+}
+
+}  // namespace
+
+DH3D_API int dh3d_bn_colstats(const float *x, long long R, int C, const unsigned char *mask, int rows_per_cloud,
+                              double *sum, double *sumsq, void *stream) {
+  DH3D_REQUIRE(x && sum && sumsq && R > 0 && C > 0 && (!mask || rows_per_cloud > 0));
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(sum, 0, sizeof(double) * C, s) != hipSuccess) return DH3D_ERR_LAUNCH;
+  if (hipMemsetAsync(sumsq, 0, sizeof(double) * C, s) != hipSuccess) return DH3D_ERR_LAUNCH;
+  int rows_per;
+  const int chunks = row_chunks(R, &rows_per);
+  hipLaunchKernelGGL(colstats_kernel, dim3(dh3d_cdiv(C, 64), chunks), dim3(256), 0, s, x, R, C, rows_per, mask,
+                     rows_per_cloud > 0 ? rows_per_cloud : 1, sum, sumsq);
+  return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_scale_shift_act(const float *x, long long R, int C, const float *scale, const float *shift, int relu,
+                                  float *y, void *stream) {
+  DH3D_REQUIRE(x && scale && shift && y && R > 0 && C > 0);
+  DH3D_SUPPORTED(C % 4 == 0);
+  hipLaunchKernelGGL(scale_shift_act_kernel, dim3(flat_grid(R * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, R, C,
+                     scale, shift, relu, y);
+  return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_row_logit_sigmoid(const float *h, long long R, int C, const float *scale, const float *shift,
+                                    const float *w, const float *b, float *att, void *stream) {
+  DH3D_REQUIRE(h && scale && shift && w && b && att && R > 0 && C > 0);
+  DH3D_SUPPORTED(C % 4 == 0);
+  hipLaunchKernelGGL(row_logit_kernel, dim3(dh3d_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, h, R, C, scale, shift,
+                     w, b, att);
+  return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_bn_bwd_sums(const float *x, const float *dy, const float *rowscale, const float *colvec, long long R,
+                              int C, const float *mean, const float *rstd, const float *gamma, const float *beta,
+                              int relu, const unsigned char *mask, int rows_per_cloud, double *S1, double *S2,
+                              double *S3, void *stream) {
+  DH3D_REQUIRE(x && mean && rstd && gamma && beta && S1 && S2 && R > 0 && C > 0);
+  DH3D_REQUIRE(dy || (rowscale && colvec && S3));
+  DH3D_REQUIRE(!mask || rows_per_cloud > 0);
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(S1, 0, sizeof(double) * C, s) != hipSuccess) return DH3D_ERR_LAUNCH;
+  if (hipMemsetAsync(S2, 0, sizeof(double) * C, s) != hipSuccess) return DH3D_ERR_LAUNCH;
+  if (!dy && hipMemsetAsync(S3, 0, sizeof(double) * C, s) != hipSuccess) return DH3D_ERR_LAUNCH;
+  int rows_per;
+  const int chunks = row_chunks(R, &rows_per);
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(dh3d_cdiv(C, 64), chunks), dim3(256), 0, s, x, dy, rowscale, colvec, R, C,
+                     rows_per, mean, rstd, gamma, beta, relu, mask, rows_per_cloud > 0 ? rows_per_cloud : 1, S1, S2,
+                     dy ? nullptr : S3);
+  return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_bn_bwd_apply(const float *x, const float *dy, const float *rowscale, const float *colvec,
+                               long long R, int C, const float *scale, const float *shift, const float *k2,
+                               const float *k3, int relu, const unsigned char *mask, int rows_per_cloud, float *dx,
+                               void *stream) {
+  DH3D_REQUIRE(x && scale && shift && k2 && k3 && dx && R > 0 && C > 0);
+  DH3D_REQUIRE(dy || (rowscale && colvec));
+  DH3D_REQUIRE(!mask || rows_per_cloud > 0);
+  DH3D_SUPPORTED(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0);
+  const int rpb = 256 / (C / 4);
+  long long g = (R + rpb - 1) / rpb;
+  g = g > 4096 ? 4096 : g;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, x, dy, rowscale, colvec, R, C,
+                     scale, shift, k2, k3, relu, mask, rows_per_cloud > 0 ? rows_per_cloud : 1, dx);
+  return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_bn_finalize(const double *sum, const double *sumsq, const double *count, const float *gamma,
+                              const float *beta, float eps, float momentum, float *run_mean, float *run_var, int C,
+                              float *mean, float *rstd, float *scale, float *shift, void *stream) {
+  DH3D_REQUIRE(sum && sumsq && count && gamma && beta && run_mean && run_var && mean && rstd && scale && shift && C > 0);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(dh3d_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sum, sumsq, count,
+                     gamma, beta, eps, momentum, run_mean, run_var, C, mean, rstd, scale, shift);
+  return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_bn_bwd_finalize(const double *S1, const double *S2, const double *count, const float *mean,
+                                  const float *rstd, const float *gamma, int C, float *k2, float *k3, void *stream) {
+  DH3D_REQUIRE(S1 && S2 && count && mean && rstd && gamma && k2 && k3 && C > 0);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dh3d_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, S1, S2, count,
+                     mean, rstd, gamma, C, k2, k3);
+  return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_netvlad_assign_rows(const float *s, long long R, int Cl, const float *scale, const float *shift,
+                                      const float *att, float *a, void *stream) {
+  DH3D_REQUIRE(s && scale && shift && att && a && R > 0);
+  DH3D_SUPPORTED(Cl == 64);
+  hipLaunchKernelGGL(netvlad_assign_rows_kernel<false>, dim3(dh3d_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, s, R,
+                     scale, shift, att, nullptr, a, nullptr);
+  return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_netvlad_assign_rows_bwd(const float *s, long long R, int Cl, const float *scale, const float *shift,
+                                          const float *att, const float *da, float *dz, float *datt, void *stream) {
+  DH3D_REQUIRE(s && scale && shift && att && da && dz && datt && R > 0);
+  DH3D_SUPPORTED(Cl == 64);
+  hipLaunchKernelGGL(netvlad_assign_rows_kernel<true>, dim3(dh3d_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, s, R,
+                     scale, shift, att, da, dz, datt);
+  return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_l2norm_rows_bwd(const float *x, const float *dxn, long long R, int C, float eps, float *dx,
+                                  void *stream) {
+  DH3D_REQUIRE(x && dxn && dx && R > 0 && C > 0);
+  hipLaunchKernelGGL(l2norm_rows_bwd_kernel, dim3(dh3d_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, x, dxn, R, C, eps,
+                     dx);
+  return dh3d_launch_status();
+}

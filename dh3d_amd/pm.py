@@ -463,8 +463,8 @@ def gemm_tn(A, B, out=None, accumulate=False):
     return C
 
 
-def gemm_nn(A, B, out=None, accumulate=False):
-    """C[M,N] (+)= A[M,K] @ B[K,N] on the exact-f32 MFMA pipe."""
+def gemm_nn(A, B, out=None, accumulate=False, bias=None):
+    """C[M,N] (+)= A[M,K] @ B[K,N] (+ bias[N]) on the exact-f32 MFMA pipe."""
     A = L.require_cuda_f32(A, "A", 2)
     B = L.require_cuda_f32(B, "B", 2)
     M, K = A.shape
@@ -472,8 +472,8 @@ def gemm_nn(A, B, out=None, accumulate=False):
         raise ValueError("gemm_nn: inner dimensions differ")
     N = B.shape[1]
     C = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=A.device)
-    L.check(L.lib().dh3d_gemm_nn_f32(L.ptr(A), L.ptr(B), M, K, N, 1 if accumulate else 0, L.ptr(C), L.stream_ptr()),
-            "gemm_nn")
+    L.check(L.lib().dh3d_gemm_nn_f32(L.ptr(A), L.ptr(B), L.ptr(bias), M, K, N, 1 if accumulate else 0, L.ptr(C),
+                                     L.stream_ptr()), "gemm_nn")
     return C
 
 
@@ -496,3 +496,132 @@ def colsum(x, out=None, accumulate=False):
     o = out if out is not None else torch.empty((C,), dtype=torch.float32, device=x.device)
     L.check(L.lib().dh3d_colsum_f32(L.ptr(x), R, C, 1 if accumulate else 0, L.ptr(o), L.stream_ptr()), "colsum")
     return o
+
+
+def _mask_u8(mask):
+    return None if mask is None else mask.to(torch.uint8).contiguous()
+
+
+def bn_colstats(x, mask=None, rows_per_cloud=0, out=None):
+    """x [R,C] -> (sum [C], sumsq [C]) float64 (views of `out` [>= 2C] if given); mask [clouds] bool excludes padding
+    clouds of rows_per_cloud rows."""
+    x = L.require_cuda_f32(x, "x", 2)
+    R, C = x.shape
+    buf = out if out is not None else torch.empty((2 * C,), dtype=torch.float64, device=x.device)
+    s1, s2 = buf[:C], buf[C:2 * C]
+    m = _mask_u8(mask)
+    L.check(L.lib().dh3d_bn_colstats(L.ptr(x), R, C, L.ptr(m), int(rows_per_cloud), L.ptr(s1), L.ptr(s2),
+                                     L.stream_ptr()), "bn_colstats")
+    return s1, s2
+
+
+def bn_finalize(s1, s2, cnt, gamma, beta, eps, momentum, run_mean, run_var):
+    """(sum, sumsq, count) -> [mean, rstd, scale, shift] as rows of one [4, C] float32 tensor; running buffers updated."""
+    C = gamma.numel()
+    o = torch.empty((4, C), dtype=torch.float32, device=gamma.device)
+    L.check(L.lib().dh3d_bn_finalize(L.ptr(s1), L.ptr(s2), L.ptr(cnt), L.ptr(gamma), L.ptr(beta), float(eps),
+                                     float(momentum), L.ptr(run_mean), L.ptr(run_var), C, L.ptr(o[0]), L.ptr(o[1]),
+                                     L.ptr(o[2]), L.ptr(o[3]), L.stream_ptr()), "bn_finalize")
+    return o
+
+
+def bn_bwd_finalize(S1, S2, cnt, mean, rstd, gamma):
+    """-> [k2, k3] rows of a [2, C] tensor (coefficients of bn_bwd_apply)."""
+    C = gamma.numel()
+    o = torch.empty((2, C), dtype=torch.float32, device=gamma.device)
+    L.check(L.lib().dh3d_bn_bwd_finalize(L.ptr(S1), L.ptr(S2), L.ptr(cnt), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), C,
+                                         L.ptr(o[0]), L.ptr(o[1]), L.stream_ptr()), "bn_bwd_finalize")
+    return o
+
+
+def scale_shift_act(x, scale, shift, relu, out=None):
+    x = L.require_cuda_f32(x, "x", 2)
+    R, C = x.shape
+    y = out if out is not None else torch.empty_like(x)
+    L.check(L.lib().dh3d_scale_shift_act(L.ptr(x), R, C, L.ptr(scale), L.ptr(shift), 1 if relu else 0, L.ptr(y),
+                                         L.stream_ptr()), "scale_shift_act")
+    return y
+
+
+def row_logit_sigmoid(h, scale, shift, w, b):
+    """att[r] = sigmoid(sum_c relu(h*scale+shift)[r,c]*w[c] + b); b: device tensor holding the scalar."""
+    h = L.require_cuda_f32(h, "h", 2)
+    R, C = h.shape
+    att = torch.empty((R,), dtype=torch.float32, device=h.device)
+    L.check(L.lib().dh3d_row_logit_sigmoid(L.ptr(h), R, C, L.ptr(scale), L.ptr(shift), L.ptr(w), L.ptr(b), L.ptr(att),
+                                           L.stream_ptr()), "row_logit_sigmoid")
+    return att
+
+
+def bn_bwd_sums(x, mean, rstd, gamma, beta, relu, dy=None, rowscale=None, colvec=None, mask=None, rows_per_cloud=0):
+    """-> S [3, C] float64: S[0] = sum dz, S[1] = sum dz*xhat, S[2] = sum rowscale*y (rank-one form only; else unused)."""
+    x = L.require_cuda_f32(x, "x", 2)
+    R, C = x.shape
+    S = torch.empty((3, C), dtype=torch.float64, device=x.device)
+    m = _mask_u8(mask)
+    L.check(L.lib().dh3d_bn_bwd_sums(L.ptr(x), L.ptr(dy), L.ptr(rowscale), L.ptr(colvec), R, C, L.ptr(mean), L.ptr(rstd),
+                                     L.ptr(gamma), L.ptr(beta), 1 if relu else 0, L.ptr(m), int(rows_per_cloud),
+                                     L.ptr(S[0]), L.ptr(S[1]), L.ptr(S[2]), L.stream_ptr()), "bn_bwd_sums")
+    return S
+
+
+def bn_bwd_apply(x, scale, shift, k2, k3, relu, dy=None, rowscale=None, colvec=None, mask=None, rows_per_cloud=0,
+                 out=None):
+    """dx = scale*dz - k2 - k3*x (see include/dh3d_hip.h); out may be x (in place)."""
+    x = L.require_cuda_f32(x, "x", 2)
+    R, C = x.shape
+    dx = out if out is not None else torch.empty_like(x)
+    m = _mask_u8(mask)
+    L.check(L.lib().dh3d_bn_bwd_apply(L.ptr(x), L.ptr(dy), L.ptr(rowscale), L.ptr(colvec), R, C, L.ptr(scale),
+                                      L.ptr(shift), L.ptr(k2), L.ptr(k3), 1 if relu else 0, L.ptr(m),
+                                      int(rows_per_cloud), L.ptr(dx), L.stream_ptr()), "bn_bwd_apply")
+    return dx
+
+
+def netvlad_assign_rows(s, scale, shift, att):
+    s = L.require_cuda_f32(s, "s", 2)
+    a = torch.empty_like(s)
+    L.check(L.lib().dh3d_netvlad_assign_rows(L.ptr(s), s.shape[0], s.shape[1], L.ptr(scale), L.ptr(shift), L.ptr(att),
+                                             L.ptr(a), L.stream_ptr()), "netvlad_assign_rows")
+    return a
+
+
+def netvlad_assign_rows_bwd(s, scale, shift, att, da):
+    s = L.require_cuda_f32(s, "s", 2)
+    dz = torch.empty_like(s)
+    datt = torch.empty((s.shape[0],), dtype=torch.float32, device=s.device)
+    L.check(L.lib().dh3d_netvlad_assign_rows_bwd(L.ptr(s), s.shape[0], s.shape[1], L.ptr(scale), L.ptr(shift),
+                                                 L.ptr(att), L.ptr(da), L.ptr(dz), L.ptr(datt), L.stream_ptr()),
+            "netvlad_assign_rows_bwd")
+    return dz, datt
+
+
+def l2norm_rows_bwd(x, dxn, eps):
+    x = L.require_cuda_f32(x, "x", 2)
+    dx = torch.empty_like(x)
+    L.check(L.lib().dh3d_l2norm_rows_bwd(L.ptr(x), L.ptr(dxn), x.shape[0], x.shape[1], float(eps), L.ptr(dx),
+                                         L.stream_ptr()), "l2norm_rows_bwd")
+    return dx
+
+
+def gemm_tn_batched(A, B):
+    """A [b,K,M], B [b,K,N] -> C [b,M,N] = A^T B per batch entry."""
+    A = L.require_cuda_f32(A, "A", 3)
+    B = L.require_cuda_f32(B, "B", 3)
+    b, K, M = A.shape
+    N = B.shape[2]
+    C = torch.empty((b, M, N), dtype=torch.float32, device=A.device)
+    L.check(L.lib().dh3d_gemm_tn_f32_batched(L.ptr(A), L.ptr(B), b, K, M, N, L.ptr(C), L.stream_ptr()), "gemm_tn_batched")
+    return C
+
+
+def gemm_nn_batched(A, B, bias=None):
+    """A [b,M,K], B [b,K,N] (+ bias [b,N]) -> C [b,M,N]."""
+    A = L.require_cuda_f32(A, "A", 3)
+    B = L.require_cuda_f32(B, "B", 3)
+    b, M, K = A.shape
+    N = B.shape[2]
+    C = torch.empty((b, M, N), dtype=torch.float32, device=A.device)
+    L.check(L.lib().dh3d_gemm_nn_f32_batched(L.ptr(A), L.ptr(B), L.ptr(bias), b, M, K, N, L.ptr(C), L.stream_ptr()),
+            "gemm_nn_batched")
+    return C

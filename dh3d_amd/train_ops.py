@@ -1,0 +1,218 @@
+"""Autograd nodes of the training step whose forward AND backward are hand-written HIP kernels (csrc/train.hip,
+csrc/gemm.hip, csrc/flex_bwd.hip) -- the counterparts of the TF graph's fused_batch_norm / MatMul / custom-op gradient
+nodes that core/model.py:135-255 builds for the trainable global head:
+
+    BatchNormTrain   training-mode BatchNorm (+ReLU) on [R, C] rows (tensorpack BatchNorm, slim batch_norm with
+                     is_training; core/tf_utils.py:60-63, core/backbones.py:218-223,271-274,304-309)
+    Linear           y = x W (+ b): exact-f32 MFMA GEMMs in both directions (dW = x^T dy, dx = dy W^T)
+    AttentionHead    globalatt_block (core/backbones.py:156-173): 256 -> 1024 BNReLU -> 1 -> sigmoid, the rank-one
+                     activation gradient never materialised, the pre-activation overwritten by its gradient in place
+    NetVLADAssign    rows of NetVLAD (core/backbones.py:207-255): l2-normalise, soft assignment with batch-norm,
+                     attention weighting, VLAD contraction -- returns (sum_n a x^T per cloud, sum_n a per cloud)
+
+Sharded batches: `mask` ([clouds] bool) marks this rank's real clouds, padding rows take no part in statistics and
+get zero gradients; `sync` all-reduces the statistics (sum, sum of squares, count) and the backward sums over the ranks
+so that they equal the reference's single-GPU whole-batch BatchNorm.  Parameter gradients are this rank's partials
+(the trainer SUM-all-reduces them).
+"""
+import torch
+import torch.distributed as dist
+
+from . import dist as D
+from . import pm
+
+
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+_CNT = {}
+
+
+def _count(R, mask, rows_per_cloud, device):
+    """Rows that take part in the statistics, as a float64 device scalar (cached: no host round trip per call)."""
+    if mask is None:
+        key = (str(device), int(R))
+        if key not in _CNT:
+            _CNT[key] = torch.tensor([float(R)], dtype=torch.float64, device=device)
+        return _CNT[key]
+    return (mask.sum().to(torch.float64) * float(rows_per_cloud)).reshape(1)
+
+
+class _BNState(object):
+    """Forward statistics of one BatchNorm site: [mean, rstd, scale, shift] rows + the row count."""
+    __slots__ = ("stats", "cnt")
+
+
+def _forward_stats(x, gamma, beta, run_mean, run_var, eps, momentum, mask, rows_per_cloud, sync):
+    """Two launches (+ the all-reduce under sync-BN): column sums, then the finalize kernel."""
+    C = x.shape[1]
+    packed = torch.empty((2 * C + 1,), dtype=torch.float64, device=x.device)
+    s1, s2 = pm.bn_colstats(x, mask, rows_per_cloud, out=packed)
+    cnt = _count(x.shape[0], mask, rows_per_cloud, x.device)
+    if sync and _world() > 1:
+        packed[2 * C:] = cnt
+        D.all_reduce_sum_(packed)
+        cnt = packed[2 * C:]
+    st = _BNState()
+    st.stats = pm.bn_finalize(s1, s2, cnt, gamma, beta, eps, momentum, run_mean, run_var)
+    st.cnt = cnt
+    return st
+
+
+def _backward_coeffs(S, st, gamma, sync):
+    """S [3, C] f64 local sums -> (local dgamma, dbeta as float32, [k2, k3]) with the all-reduce under sync-BN."""
+    local = S[:2].float()                       # this rank's partials: dbeta = S1, dgamma = S2
+    if sync and _world() > 1:
+        S = S.clone()
+        D.all_reduce_sum_(S[:2])
+    k = pm.bn_bwd_finalize(S[0], S[1], st.cnt, st.stats[0], st.stats[1], gamma)
+    return local[1], local[0], k
+
+
+class _BatchNormTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, run_mean, run_var, eps, momentum, relu, sync, mask, rows_per_cloud):
+        x = x.contiguous()
+        g, be = gamma.detach().contiguous(), beta.detach().contiguous()
+        st = _forward_stats(x, g, be, run_mean, run_var, eps, momentum, mask, rows_per_cloud, sync)
+        y = pm.scale_shift_act(x, st.stats[2], st.stats[3], relu)
+        ctx.save_for_backward(x, g, be)
+        ctx.cfg = (bool(relu), bool(sync), mask, int(rows_per_cloud), st)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, be = ctx.saved_tensors
+        relu, sync, mask, rpc, st = ctx.cfg
+        dy = dy.contiguous()
+        S = pm.bn_bwd_sums(x, st.stats[0], st.stats[1], g, be, relu, dy=dy, mask=mask, rows_per_cloud=rpc)
+        dgamma, dbeta, k = _backward_coeffs(S, st, g, sync)
+        dx = pm.bn_bwd_apply(x, st.stats[2], st.stats[3], k[0], k[1], relu, dy=dy, mask=mask, rows_per_cloud=rpc)
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+def batch_norm_train(x, bnmod, relu, sync=False, mask=None, rows_per_cloud=0, momentum=None):
+    """x [R, C] -> act(BN_train(x)); bnmod: backbones.TPBatchNorm / SlimBatchNorm (running buffers updated in place:
+    decay 0.9 / 0.999 like tensorpack / slim).  mask [clouds] bool with rows_per_cloud rows each, or None."""
+    from . import backbones as bb
+    tp = isinstance(bnmod, bb.TPBatchNorm)
+    rm, rv = (bnmod.mean_EMA, bnmod.variance_EMA) if tp else (bnmod.moving_mean, bnmod.moving_variance)
+    mom = momentum if momentum is not None else (0.9 if tp else 0.999)
+    return _BatchNormTrain.apply(x, bnmod.gamma, bnmod.beta, rm, rv, bnmod.eps, mom, relu, sync, mask, rows_per_cloud)
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, b):
+        x = x.contiguous()
+        y = pm.gemm_nn(x, W.detach().contiguous(), bias=None if b is None else b.detach().contiguous())
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = pm.gemm_nn(dy, pm.transpose_last2(W.detach())) if ctx.needs_input_grad[0] else None
+        dW = pm.gemm_tn(x, dy) if ctx.needs_input_grad[1] else None
+        db = pm.colsum(dy) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dW, db
+
+
+def linear(x, W, b=None):
+    """x [R, Cin] @ W [Cin, Cout] (+ b) with hand-written GEMMs in both directions (Cin, Cout multiples of 4)."""
+    return _Linear.apply(x, W, b)
+
+
+class _AttentionHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, W, b, gamma, beta, run_mean, run_var, eps, momentum, wfc, bfc, sync, mask, rows_per_cloud):
+        X = X.contiguous()
+        h = pm.gemm_nn(X, W.detach().contiguous(), bias=b.detach().contiguous())          # [R, H] pre-activation
+        g, be = gamma.detach().contiguous(), beta.detach().contiguous()
+        st = _forward_stats(h, g, be, run_mean, run_var, eps, momentum, mask, rows_per_cloud, sync)
+        att = pm.row_logit_sigmoid(h, st.stats[2], st.stats[3], wfc.detach().reshape(-1).contiguous(),
+                                   bfc.detach().reshape(-1).contiguous())
+        ctx.save_for_backward(X, W, h, g, be, wfc, att)
+        ctx.cfg = (bool(sync), mask, int(rows_per_cloud), st)
+        return att
+
+    @staticmethod
+    def backward(ctx, datt):
+        X, W, h, g, be, wfc, att = ctx.saved_tensors
+        sync, mask, rpc, st = ctx.cfg
+        dlogit = (datt * att * (1.0 - att)).contiguous()                                # sigmoid
+        if mask is not None:
+            dlogit = dlogit * mask.repeat_interleave(rpc).to(dlogit.dtype)
+        wv = wfc.detach().reshape(-1).contiguous()
+        S = pm.bn_bwd_sums(h, st.stats[0], st.stats[1], g, be, True, rowscale=dlogit, colvec=wv, mask=mask,
+                           rows_per_cloud=rpc)
+        dwfc = S[2].float().reshape(wfc.shape)
+        dbfc = dlogit.sum().reshape(1)
+        dgamma, dbeta, k = _backward_coeffs(S, st, g, sync)
+        dh = pm.bn_bwd_apply(h, st.stats[2], st.stats[3], k[0], k[1], True, rowscale=dlogit, colvec=wv, mask=mask,
+                             rows_per_cloud=rpc, out=h)                                  # in place: h is dead after this
+        dW = pm.gemm_tn(X, dh)
+        # d/db: the BatchNorm that follows removes any per-channel constant, the exact gradient is 0 (the column sums
+        # of dh are rounding noise)
+        db = torch.zeros_like(g)
+        dX = pm.gemm_nn(dh, pm.transpose_last2(W.detach())) if ctx.needs_input_grad[0] else None
+        return dX, dW, db, dgamma, dbeta, None, None, None, None, dwfc, dbfc, None, None, None
+
+
+def attention_head(X, conv, wfc, bfc, sync=False, mask=None, rows_per_cloud=0):
+    """globalatt_block on rows X [R, Cin]: conv = backbones.Conv2D1x1 (W, b, bn), wfc [H,1] / bfc [1] the final layer.
+    Returns att [R]."""
+    bn = conv.bn
+    return _AttentionHead.apply(X, conv.W.reshape(conv.cin, conv.cout), conv.b, bn.gamma, bn.beta, bn.mean_EMA,
+                                bn.variance_EMA, bn.eps, 0.9, wfc, bfc, sync, mask, rows_per_cloud)
+
+
+class _NetVLADAssign(torch.autograd.Function):
+    """x [Bt, N, D] rows, att [Bt*N] -> (V [Bt, Cl, D] = sum_n a[n,c] xn[n,d],  asum [Bt, Cl] = sum_n a[n,c])."""
+
+    @staticmethod
+    def forward(ctx, x, att, Wc, gamma, beta, run_mean, run_var, eps, momentum, sync, mask):
+        Bt, N, Dm = x.shape
+        x2 = x.reshape(Bt * N, Dm).contiguous()
+        xn = pm.l2norm_concat(x2, 1e-12)                                   # tf.nn.l2_normalize(reshaped_input, 1)
+        s = pm.gemm_nn(xn, Wc.detach().contiguous())                       # [R, Cl]
+        g, be = gamma.detach().contiguous(), beta.detach().contiguous()
+        st = _forward_stats(s, g, be, run_mean, run_var, eps, momentum, mask, N, sync)
+        scale, shift = st.stats[2], st.stats[3]
+        att = att.contiguous()
+        a = pm.netvlad_assign_rows(s, scale, shift, att)                   # softmax(bn(s)) * att
+        Cl = a.shape[1]
+        V = pm.gemm_tn_batched(a.reshape(Bt, N, Cl), xn.reshape(Bt, N, Dm))   # [Bt, Cl, D]
+        asum = a.reshape(Bt, N, Cl).sum(1)
+        ctx.save_for_backward(x2, xn, s, a, att, Wc, g, be)
+        ctx.cfg = (Bt, N, bool(sync), mask, st)
+        return V, asum
+
+    @staticmethod
+    def backward(ctx, dV, dasum):
+        x2, xn, s, a, att, Wc, g, be = ctx.saved_tensors
+        Bt, N, sync, mask, st = ctx.cfg
+        scale, shift = st.stats[2], st.stats[3]
+        Dm, Cl = xn.shape[1], a.shape[1]
+        dV = dV.contiguous()
+        # da[n,c] = sum_d dV[c,d] xn[n,d] + dasum[c];   dxn[n,d] = sum_c a[n,c] dV[c,d]
+        da = pm.gemm_nn_batched(xn.reshape(Bt, N, Dm), pm.transpose_last2(dV), bias=dasum.contiguous())
+        dxn = pm.gemm_nn_batched(a.reshape(Bt, N, Cl), dV).reshape(Bt * N, Dm)
+        dz, datt = pm.netvlad_assign_rows_bwd(s, scale, shift, att, da.reshape(Bt * N, Cl))
+        S = pm.bn_bwd_sums(s, st.stats[0], st.stats[1], g, be, False, dy=dz, mask=mask, rows_per_cloud=N)
+        dgamma, dbeta, k = _backward_coeffs(S, st, g, sync)
+        ds = pm.bn_bwd_apply(s, scale, shift, k[0], k[1], False, dy=dz, mask=mask, rows_per_cloud=N, out=dz)
+        dWc = pm.gemm_tn(xn, ds)
+        pm.gemm_nn(ds, pm.transpose_last2(Wc.detach()), out=dxn, accumulate=True)
+        dx = pm.l2norm_rows_bwd(x2, dxn, 1e-12).reshape(Bt, N, Dm)
+        if mask is not None:
+            datt = datt * mask.repeat_interleave(N).to(datt.dtype)
+        return dx, datt, dWc, dgamma, dbeta, None, None, None, None, None, None
+
+
+def netvlad_assign(x, att, Wc, bnmod, sync=False, mask=None):
+    return _NetVLADAssign.apply(x, att, Wc, bnmod.gamma, bnmod.beta, bnmod.moving_mean, bnmod.moving_variance, bnmod.eps,
+                                0.999, sync, mask)

@@ -175,6 +175,39 @@ def global_head_autograd(model, points, localdesc, lv, bn_training=True, sync_bn
     return v * torch.sigmoid(gates)
 
 
+def global_head_hip(model, points, localdesc, lv, sync_bn=False, mask=None):
+    """compute_global (core/model.py:112-133) in training mode with every row-level operator -- flex_conv, the three
+    training-mode BatchNorms on rows, three_interpolate, the attention MLP, NetVLAD's assignment / aggregation -- as a
+    hand-written HIP kernel in BOTH directions (dh3d_amd.train_ops, csrc/train.hip / gemm.hip / flex_bwd.hip); what is
+    left to torch are [Bt, 256]- and [Bt, 16384]-sized per-cloud element-wise ops (microseconds).  Same function as
+    global_head_autograd(bn_training=True), which is kept as the plain-torch reference the tests compare with."""
+    from . import train_ops as T
+    gba, att_mod, nv = model.global_before_assemble, model.globalatt, model._netvlad
+    if len(att_mod.conv_dims) != 1 or len(gba.outdims) != 1 or not (nv.add_batch_norm and nv.gating):
+        return global_head_autograd(model, points, localdesc, lv, True, sync_bn, mask)
+    fc, fbn = gba.flexconv_0, gba.flexconv_0_bn
+    Bt, N = points.shape[0], points.shape[1]
+    M = lv["xyz_s"].shape[1]
+    feat_s = bb.gather_rows(localdesc, lv["idx"])                                   # [Bt,M,128]
+    x = flex_conv_factorised(feat_s, lv["xyz_s"], lv["nbr_s"], fc.position_theta, fc.position_bias)
+    x = x + fc.feature_bias.reshape(1, 1, -1)                                       # layers.py:330-331
+    Dg = x.shape[2]
+    new_feat = T.batch_norm_train(x.reshape(Bt * M, Dg), fbn, True, sync_bn, mask, M).reshape(Bt, M, Dg)
+    d = torch.clamp(lv["nn3_dist"], min=1e-10)                                      # backbones.py:92-95
+    w = (1.0 / d) / (1.0 / d).sum(2, keepdim=True)
+    forglobal = ops.three_interpolate(new_feat, lv["nn3_idx"], w.contiguous())      # [Bt,N,256]
+    fcw = att_mod.detec_conv_fc
+    att = T.attention_head(forglobal.reshape(Bt * N, Dg), att_mod.detec_conv0, fcw.W, fcw.b, sync_bn, mask, N)
+    V, asum = T.netvlad_assign(forglobal, att, nv.cluster_weights, nv.cluster_bn, sync_bn, mask)   # [Bt,C,D], [Bt,C]
+    vlad = V.transpose(1, 2) - asum.unsqueeze(1) * nv.cluster_weights2              # [Bt,D,C]  (backbones.py:241-256)
+    vlad = vlad * torch.rsqrt(torch.clamp((vlad * vlad).sum(1, keepdim=True), min=1e-12))
+    vlad = vlad.reshape(Bt, nv.C * Dg)
+    vlad = vlad * torch.rsqrt(torch.clamp((vlad * vlad).sum(1, keepdim=True), min=1e-12))
+    v = T.batch_norm_train(T.linear(vlad, nv.hidden1_weights), nv.bn, False, sync_bn, mask, 1)
+    gates = T.batch_norm_train(T.linear(v, nv.gating_weights), nv.gating_bn, False, sync_bn, mask, 1)
+    return v * torch.sigmoid(gates)
+
+
 def trainable_head_parameters(model):
     """Parameters that global_config trains (backbone frozen: configs.py:112-113)."""
     mods = [model.global_before_assemble, model.globalatt, model._netvlad]
@@ -191,14 +224,17 @@ class QuadrupletTrainer(object):
     """One process per GPU.  `step(points)` takes the role-ordered batch [B*(1+P+Ng+1), N, 3] (identical on
     every rank, e.g. generated from a shared seed), runs this rank's block and returns the loss."""
 
-    def __init__(self, model, start_lr=None, decay_step=None, decay_rate=None, weight_decay=None, sync_bn=True):
+    def __init__(self, model, start_lr=None, decay_step=None, decay_rate=None, weight_decay=None, sync_bn=True,
+                 impl="hip"):
         """Schedule / weight decay default to the model's config (core/configs.py:50-54,115-117).  sync_bn=True (the
         default) reproduces the reference's whole-batch BatchNorm statistics under sharding -- and keeps the running
         buffers identical on every rank; sync_bn=False normalises with per-rank statistics (a few clouds of one role
         each under the contiguous role-ordered partition) and lets the buffers diverge."""
         self.model = model
         self.cfg = model.config
+        self.impl = impl          # "hip": train_ops kernels; "torch": the plain-torch restatement (test reference)
         self.keep_grads, self.last_grads = False, None
+        self._ev = None
         c = self.cfg
         start_lr = start_lr if start_lr is not None else (c.start_lr or 5e-4)
         decay_step = decay_step if decay_step is not None else (c.decay_step or 20000)
@@ -224,20 +260,56 @@ class QuadrupletTrainer(object):
             geo = self.model._geometry(block, None)
             _, localdesc = self.model.compute_local(block, _geo=geo)
             lv = geo.level(8, self.model.knn_num)
-        desc = global_head_autograd(self.model, block, localdesc.detach(), lv, bn_training=True,
-                                    sync_bn=self.sync_bn, mask=mask if not bool(mask.all()) else None)
+        self._mark(1)
+        m = mask if not bool(mask.all()) else None
+        if self.impl == "hip":
+            desc = global_head_hip(self.model, block, localdesc.detach(), lv, sync_bn=self.sync_bn, mask=m)
+        else:
+            desc = global_head_autograd(self.model, block, localdesc.detach(), lv, bn_training=True,
+                                        sync_bn=self.sync_bn, mask=m)
         desc = desc * torch.rsqrt(torch.clamp((desc * desc).sum(1, keepdim=True), min=1e-8))  # model.py:205
         full = _AllGatherKeepOwn.apply(desc)[:Bt]
         loss = losses.lazy_quadruplet_loss(full, cfg.batch_size, cfg.num_pos, cfg.num_neg,
                                            cfg.global_triplet_margin or 0.5, cfg.global_quadruplet_margin or 0.2)
         return loss
 
+    # phase timing (bench.py --workload train): events on the current stream around the four phases of a step
+    def time_phases(self, on=True):
+        self._ev = [] if on else None
+
+    def _mark(self, k):
+        if self._ev is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._ev.append((k, e))
+
+    def phase_times_ms(self):
+        """Mean ms of [frozen backbone fwd, head fwd + loss, backward, grad all-reduce + Adam] over the timed steps."""
+        if not self._ev:
+            return None
+        torch.cuda.synchronize()
+        names = ["backbone_fwd", "head_fwd_loss", "backward", "allreduce_adam"]
+        tot, cnt = [0.0] * 4, [0] * 4
+        for (k0, e0), (k1, e1) in zip(self._ev[:-1], self._ev[1:]):
+            if k1 == k0 + 1:
+                tot[k0] += e0.elapsed_time(e1)
+                cnt[k0] += 1
+        return {n: (t / c if c else None) for n, t, c in zip(names, tot, cnt)}
+
     def step(self, points):
         self.opt.zero_grad(set_to_none=True)
+        self._mark(0)
         loss = self.forward_loss(points)
-        wd = sum((p * p).sum() for p in self.wd_params) * (0.5 * self.weight_decay) if self.wd_params else 0.0
-        rank0_only_wd = wd if (not dist.is_initialized() or dist.get_rank() == 0) else wd * 0.0
-        (loss + rank0_only_wd).backward()
+        self._mark(2)
+        loss.backward()
+        # L2 weight decay on '.*/W' (regularize_cost, core/model.py:239-243): d/dp [wd/2 * sum p^2] = wd * p, added to the
+        # gradients directly (one multi-tensor launch) by rank 0 only -- the SUM all-reduce below then counts it once
+        if self.wd_params and self.weight_decay and (not dist.is_initialized() or dist.get_rank() == 0):
+            gs = [p.grad for p in self.wd_params if p.grad is not None]
+            ps = [p.detach() for p in self.wd_params if p.grad is not None]
+            if gs:
+                torch._foreach_add_(gs, ps, alpha=self.weight_decay)
+        self._mark(3)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params])
             D.all_reduce_sum_(flat)  # every rank holds a partial of the SAME loss
@@ -250,5 +322,6 @@ class QuadrupletTrainer(object):
             self.last_grads = [p.grad.detach().clone() for p in self.params]  # steps: parameters are ill-conditioned)
         self.opt.step()
         self.sched.step()
+        self._mark(4)
         self.model.invalidate(head_only=True)  # the packed / folded weight copies of the fused inference path are stale now
         return float(loss.detach())

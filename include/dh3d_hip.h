@@ -349,13 +349,59 @@ int dh3d_flex_conv_pm_bwd(const float *features, const float *xyz, const int32_t
 
 /* Exact-f32 MFMA GEMMs of the backward passes (csrc/gemm.hip), all row-major:
  *   tn: C[M,N] (+)= A[K,M]^T B[K,N]  (weight gradients: reduction over rows, split over workgroups + f32 atomics)
- *   nn: C[M,N] (+)= A[M,K]   B[K,N]  (input gradients with W^T materialised)
+ *   nn: C[M,N] (+)= A[M,K]   B[K,N] (+ colbias[N], may be NULL; not with accumulate)  (linear layers of the
+ *       training step, input gradients with W^T materialised)
  * accumulate = 0 overwrites C.  M, N (tn) / K, N (nn) multiples of 4. */
 int dh3d_gemm_tn_f32(const float *A, const float *B, int K, int M, int N, int accumulate, float *C, void *stream);
-int dh3d_gemm_nn_f32(const float *A, const float *B, int M, int K, int N, int accumulate, float *C, void *stream);
+int dh3d_gemm_nn_f32(const float *A, const float *B, const float *colbias, int M, int K, int N, int accumulate,
+                     float *C, void *stream);
 /* [Bt,R,C] -> [Bt,C,R] of 32-bit elements; out[c] (+)= sum_r x[r,c]. */
 int dh3d_transpose32(const void *in, int Bt, int R, int C, void *out, void *stream);
 int dh3d_colsum_f32(const float *x, long long R, int C, int accumulate, float *out, void *stream);
+
+/* Training-mode BatchNorm in two HBM-bound passes per direction and the attention head's element-wise passes
+ * (csrc/train.hip; tensorpack BatchNorm / slim batch_norm with is_training -- core/tf_utils.py:60-63,
+ * core/backbones.py:145-173,218-223,271-274).  x [R,C] row-major; mask (may be NULL): one byte per cloud of
+ * rows_per_cloud rows, 0 = padding cloud, excluded.  Sums are f64 (f32 per thread, f64 atomics across workgroups).
+ *   colstats       : sum[c] = sum_r x, sumsq[c] = sum_r x^2                         (zeroes its outputs)
+ *   scale_shift_act: y = act(x*scale[c] + shift[c])   (relu = 0/1; y may alias x)
+ *   row_logit_sigmoid: att[r] = sigmoid(sum_c relu(h*scale+shift)[r,c] w[c] + b)    (attention head, backbones.py:170-173)
+ *   bn_bwd_sums    : S1 = sum dz, S2 = sum dz*xhat with xhat = (x-mean)*rstd, dz = dy masked by relu(xhat*gamma+beta) > 0;
+ *                    dy == NULL: dy[r,c] = rowscale[r]*colvec[c] (rank one) and S3[c] = sum_r rowscale[r]*y[r,c]
+ *   bn_finalize    : (sum, sumsq, count) -> mean, rstd, scale = gamma*rstd, shift = beta - mean*scale; running buffers
+ *                    <- momentum*old + (1-momentum)*batch statistic (untouched when count == 0)
+ *   bn_bwd_finalize: (S1, S2, count) -> k2, k3 of bn_bwd_apply
+ *   bn_bwd_apply   : dx = scale*dz - k2[c] - k3[c]*x  == gamma*rstd*(dz - S1/n - xhat*S2/n)   (dx may alias x) */
+int dh3d_bn_colstats(const float *x, long long R, int C, const unsigned char *mask, int rows_per_cloud, double *sum,
+                     double *sumsq, void *stream);
+int dh3d_scale_shift_act(const float *x, long long R, int C, const float *scale, const float *shift, int relu,
+                         float *y, void *stream);
+int dh3d_row_logit_sigmoid(const float *h, long long R, int C, const float *scale, const float *shift, const float *w,
+                           const float *b /* device scalar */, float *att, void *stream);
+int dh3d_bn_bwd_sums(const float *x, const float *dy, const float *rowscale, const float *colvec, long long R, int C,
+                     const float *mean, const float *rstd, const float *gamma, const float *beta, int relu,
+                     const unsigned char *mask, int rows_per_cloud, double *S1, double *S2, double *S3, void *stream);
+int dh3d_bn_bwd_apply(const float *x, const float *dy, const float *rowscale, const float *colvec, long long R, int C,
+                      const float *scale, const float *shift, const float *k2, const float *k3, int relu,
+                      const unsigned char *mask, int rows_per_cloud, float *dx, void *stream);
+int dh3d_bn_finalize(const double *sum, const double *sumsq, const double *count /* device scalar */,
+                     const float *gamma, const float *beta, float eps, float momentum, float *run_mean, float *run_var,
+                     int C, float *mean, float *rstd, float *scale, float *shift, void *stream);
+int dh3d_bn_bwd_finalize(const double *S1, const double *S2, const double *count, const float *mean, const float *rstd,
+                         const float *gamma, int C, float *k2, float *k3, void *stream);
+
+/* NetVLAD soft assignment rows (core/backbones.py:214-238; Cl = 64, one wave per row):
+ *   a[r,:] = softmax(s[r,:]*scale + shift) * att[r];   backward: da -> dz (gradient at the BatchNorm output), datt.
+ * l2norm_rows_bwd: backward of xn = x * rsqrt(max(sum x^2, eps)) (tf.nn.l2_normalize). */
+int dh3d_netvlad_assign_rows(const float *s, long long R, int Cl, const float *scale, const float *shift,
+                             const float *att, float *a, void *stream);
+int dh3d_netvlad_assign_rows_bwd(const float *s, long long R, int Cl, const float *scale, const float *shift,
+                                 const float *att, const float *da, float *dz, float *datt, void *stream);
+int dh3d_l2norm_rows_bwd(const float *x, const float *dxn, long long R, int C, float eps, float *dx, void *stream);
+/* batched GEMMs: `batch` independent products on operands stored back to back; colbias [batch, N] (nn only). */
+int dh3d_gemm_tn_f32_batched(const float *A, const float *B, int batch, int K, int M, int N, float *C, void *stream);
+int dh3d_gemm_nn_f32_batched(const float *A, const float *B, const float *colbias, int batch, int M, int K, int N,
+                             float *C, void *stream);
 
 #ifdef __cplusplus
 }

@@ -206,8 +206,8 @@ if sync_bn:
         assert float((g - q).abs().max()) <= tol, (float((g - q).abs().max()), float(q.abs().max()))
     for k, v in bufs1.items():
         assert torch.allclose(v, ref_bufs[k], rtol=1e-4, atol=1e-5), k
-else:
-    assert abs(losses[0] - ref_losses[0]) < 0.5   # per-rank statistics: a different (legal) normalisation
+# sync_bn off: per-rank statistics over 4 / 3 clouds are a different (legal) normalisation -- nothing to compare with
+# the whole-batch step beyond finiteness and the ranks agreeing with each other (checked above)
 D.barrier()
 open(os.path.join(%(out)r, "rank%%d_%%d.ok" %% (rank, int(sync_bn))), "w").write("ok")
 """
@@ -246,3 +246,80 @@ def test_trainer_survives_a_rank_with_only_padding_clouds(dev):
     (y * 0.0).sum().backward()
     assert torch.isfinite(y).all() and torch.isfinite(x.grad).all()
     assert torch.equal(rm, torch.zeros(8, device=dev)) and torch.equal(rv, torch.ones(8, device=dev))
+
+
+def test_bn_train_kernels_match_torch(dev):
+    """train_ops.batch_norm_train (HIP statistics / apply / backward sums / backward apply) against torch autograd on
+    the textbook formula, with and without ReLU and padding mask."""
+    from dh3d_amd import backbones as bb, train_ops as T
+    g = torch.Generator().manual_seed(3)
+    for (clouds, rpc, C, relu, use_mask) in [(3, 700, 256, True, False), (4, 512, 64, False, True), (5, 1, 256, False, True),
+                                             (2, 4096, 1024, True, False)]:
+        R = clouds * rpc
+        x = (torch.randn(R, C, generator=g) * 2 + 0.5).to(dev)
+        mask = None
+        if use_mask:
+            mask = torch.ones(clouds, dtype=torch.bool, device=dev); mask[-1] = False
+        bn = bb.TPBatchNorm(C).to(dev)
+        with torch.no_grad():
+            bn.gamma.copy_(0.5 + torch.rand(C, generator=g).to(dev)); bn.beta.copy_(torch.randn(C, generator=g).to(dev))
+        dy = torch.randn(R, C, generator=g).to(dev)
+        x1 = x.clone().requires_grad_()
+        y = T.batch_norm_train(x1, bn, relu, False, mask, rpc)
+        y.backward(dy)
+        g1, b1 = bn.gamma.grad.clone(), bn.beta.grad.clone()
+        rm1, rv1 = bn.mean_EMA.clone(), bn.variance_EMA.clone()
+        # torch restatement in float64
+        bn.gamma.grad = None; bn.beta.grad = None
+        x2 = x.double().clone().requires_grad_()
+        live = torch.ones(R, dtype=torch.bool, device=dev) if mask is None else mask.repeat_interleave(rpc)
+        xs = x2[live]
+        mean, var = xs.mean(0), xs.var(0, unbiased=False)
+        gam, bet = bn.gamma.double().detach().requires_grad_(), bn.beta.double().detach().requires_grad_()
+        yy = (x2 - mean) * torch.rsqrt(var + bn.eps) * gam + bet
+        if relu:
+            yy = torch.relu(yy)
+        yy = yy * live[:, None]
+        (yy * dy.double()).sum().backward()
+        assert torch.allclose(y[live], yy[live].float(), rtol=1e-5, atol=1e-5)
+        for a, b in ((x1.grad, x2.grad), (g1, gam.grad), (b1, bet.grad)):
+            assert float((a.double() - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7
+        assert torch.allclose(rm1, (0.1 * mean).float(), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(rv1, (0.9 + 0.1 * var).float(), rtol=1e-5, atol=1e-6)
+
+
+def test_hip_head_matches_torch_head_forward_and_gradients(dev):
+    """global_head_hip (hand-written kernels in both directions) == global_head_autograd (plain torch) on the same
+    batch: descriptors, every trainable gradient, BatchNorm running buffers; with and without a padding cloud."""
+    from dh3d_amd.training import global_head_autograd, global_head_hip, trainable_head_parameters
+    for use_mask in (False, True):
+        res = []
+        for impl in (global_head_hip, global_head_autograd):
+            m = _build(dev, seed=11)
+            pts = torch.rand(4, 4096, 3, generator=torch.Generator().manual_seed(5)).to(dev)
+            mask = None
+            if use_mask:
+                mask = torch.tensor([True, True, True, False], device=dev)
+            with torch.no_grad():
+                geo = m._geometry(pts, None)
+                _, local = m.compute_local(pts, _geo=geo)
+                lv = geo.level(8, 8)
+            if impl is global_head_hip:
+                desc = impl(m, pts, local.detach(), lv, sync_bn=False, mask=mask)
+            else:
+                desc = impl(m, pts, local.detach(), lv, bn_training=True, sync_bn=False, mask=mask)
+            live = desc if mask is None else desc[mask]
+            wgt = torch.randn(live.shape, generator=torch.Generator().manual_seed(9)).to(dev)
+            (live * wgt).sum().backward()
+            params = trainable_head_parameters(m)
+            res.append((live.detach(), [p.grad.clone() for p in params], {k: v.clone() for k, v in m.named_buffers()},
+                        [n for n, p in m.named_parameters() if any(p is q for q in params)]))
+        (d0, g0, b0, names), (d1, g1, b1, _) = res
+        assert float((d0 - d1).abs().max()) <= 1e-4 * float(d1.abs().max()), float((d0 - d1).abs().max())
+        for n, a, b in zip(names, g0, g1):
+            # (biases in front of a BatchNorm have an exactly-zero gradient in theory: both sides hold ~1e-8 of rounding
+            #  noise there, hence the absolute floor)
+            tol = 2e-3 * float(b.abs().max()) + 1e-6
+            assert float((a - b).abs().max()) <= tol, (n, float((a - b).abs().max()), float(b.abs().max()))
+        for k in b0:
+            assert torch.allclose(b0[k], b1[k], rtol=1e-4, atol=1e-5), k
