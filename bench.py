@@ -293,6 +293,10 @@ def kernel_breakdown(dev, B, N):
         out["fps_sorted N->N/8"] = event_time_ms(lambda: pm.fps_sorted(srt, gbox, N // 8), iters=5, warm=1)
     sub = xyz[:, : N // 8].contiguous()
     out["three_nn"] = event_time_ms(lambda: ops.three_nn(xyz, sub), iters=10, warm=2)
+    if N // 8 >= 256:
+        out["spatial_sort N/8"] = event_time_ms(lambda: pm.spatial_sort(sub), iters=10, warm=2)
+        ss, gs = pm.spatial_sort(sub)
+        out["three_nn_sorted"] = event_time_ms(lambda: pm.three_nn_sorted(srt, gbox, ss, gs), iters=10, warm=2)
     return out
 
 

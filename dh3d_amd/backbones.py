@@ -270,7 +270,12 @@ def compute_level(xyz, dilate, knn, ordered=None, fps_contract=None):
         nbr_s, _ = pm.knn_sorted(srt_s, gbox_s, knn)
     level_ready = torch.cuda.Event()
     level_ready.record()  # idx / xyz_s / nbr_s exist
-    return {"idx": idx, "xyz_s": xyz_s, "nbr_s": nbr_s, "_xyz_ready": ready, "_level_ready": level_ready}
+    lv = {"idx": idx, "xyz_s": xyz_s, "nbr_s": nbr_s, "_xyz_ready": ready, "_level_ready": level_ready}
+    if ordered is not None:
+        lv["_ordered"] = ordered            # Morton records + boxes of the full cloud: the pruned three_nn uses them
+        if npoint > 2048:
+            lv["_ordered_s"] = (srt_s, gbox_s)
+    return lv
 
 
 def finish_level(xyz, lv, same_stream=False):
@@ -281,10 +286,18 @@ def finish_level(xyz, lv, same_stream=False):
             torch.cuda.current_stream().wait_event(lv["_xyz_ready"])
         B, N, _ = xyz.shape
         xyz_s = lv["xyz_s"]
-        d3 = torch.empty((B, N, 3), dtype=torch.float32, device=xyz.device)
-        i3 = torch.empty((B, N, 3), dtype=torch.int32, device=xyz.device)
-        L.check(L.lib().dh3d_three_nn(B, N, xyz_s.shape[1], L.ptr(xyz), L.ptr(xyz_s), L.ptr(d3), L.ptr(i3),
-                                      L.stream_ptr()), "three_nn")
+        if "_ordered" in lv and 256 <= xyz_s.shape[1] <= 16384:
+            # both sets in Morton order: a wave's 64 queries are a compact region and its scan starts at the matching
+            # place of the sampled set's order, so the 3-deep lists settle within the first ~128 candidates and the
+            # rest of the scan is the bare distance test (bit-identical outputs, csrc/pointnet2.hip
+            # three_nn_sorted_kernel); the sampled set is sorted here unless the level's kNN already did
+            srt_s, gbox_s = lv["_ordered_s"] if "_ordered_s" in lv else pm.spatial_sort(xyz_s)
+            d3, i3 = pm.three_nn_sorted(lv["_ordered"][0], lv["_ordered"][1], srt_s, gbox_s)
+        else:
+            d3 = torch.empty((B, N, 3), dtype=torch.float32, device=xyz.device)
+            i3 = torch.empty((B, N, 3), dtype=torch.int32, device=xyz.device)
+            L.check(L.lib().dh3d_three_nn(B, N, xyz_s.shape[1], L.ptr(xyz), L.ptr(xyz_s), L.ptr(d3), L.ptr(i3),
+                                          L.stream_ptr()), "three_nn")
         lv["nn3_dist"], lv["nn3_idx"] = d3, i3
     return lv
 

@@ -6,7 +6,10 @@
 //   three_interpolate(+grad)  replaces tf_interpolate.cpp:107-153.
 //   three_interpolate_idw     fuses the weight computation of core/backbones.py:92-95.
 // Arithmetic that decides integer outputs (three_nn) is written with explicit, unfused roundings.
+#include <limits.h>
+
 #include "common.h"
+#include "wave_ops.h"
 
 #pragma clang fp contract(off)
 
@@ -177,6 +180,122 @@ __global__ __launch_bounds__(kBlock) void three_nn_kernel(int n, int m, const fl
   }
 }
 
+// ------------------------------------------------------------------ three_nn on ordered clouds
+// Same outputs as three_nn_kernel from the Morton-ordered records of both sets (spatial.hip: float4 (x, y, z,
+// bits(original index))).  What the brute-force kernel spends its time on is not the 8 flop per pair but the 3-deep
+// insertion: with queries and candidates in arbitrary order SOME lane of the wave improves its list in nearly every
+// 8-candidate sub-step (P ~ 64 * 8 * 3/k until k > 1536), so the branch is taken all the way through.  Here a wave
+// holds 64 CONSECUTIVE queries of the Morton order (a compact region) and starts its candidate scan at the position
+// of the sampled set's own Morton order that corresponds to that region (farthest-point samples spread evenly over
+// the cloud, so rank-proportional is close), wrapping around: the lists are nearly final after the first 128
+// candidates and the rest of the scan is the bare distance test.  Every candidate is still visited -- no pruning
+// structure, nothing to get wrong -- and equal distances resolve to the smallest candidate index explicitly, so ids
+// and distances are bit-identical to three_nn_kernel whatever the visiting order (tf_interpolate.cpp:66-96).
+__global__ __launch_bounds__(kBlock) void three_nn_sorted_kernel(int n, int m, const float4 *__restrict__ qs,
+                                                                const float4 *__restrict__ cs,
+                                                                float *__restrict__ dist, int32_t *__restrict__ idx) {
+  __shared__ __attribute__((aligned(16))) float s_c[kNNChunk * 3];
+  __shared__ int s_k[kNNChunk];
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
+  const bool valid = j < n;
+  const float4 q = qs[(size_t)b * n + (valid ? j : blockIdx.x * 64)];
+  const float4 *cand = cs + (size_t)b * m;
+  const f32x2 qx = {q.x, q.x}, qy = {q.y, q.y}, qz = {q.z, q.z};
+  // The 3-deep list as 64-bit keys (bits(d) << 32 | index): d >= 0, so unsigned order is (distance, index) -- the
+  // smallest index among equal distances, i.e. the reference's strict '<' in index order -- and an insertion is three
+  // compares + selects with no branch (the branchy form was ~5x the cost of the distance arithmetic per visit).
+  // Start: (+inf, 0), the reference's 1e40 / index 0.
+  const unsigned long long kInf = (unsigned long long)__float_as_uint(INFINITY) << 32;
+  unsigned long long k1 = kInf, k2 = kInf, k3 = kInf;
+  // rank-proportional start, 64 candidates before the centre of this query group's image, aligned to the 32-step
+  const int nchunks = (m + kNNChunk - 1) / kNNChunk;
+  long long c0 = ((long long)blockIdx.x * 64 + 32) * m / n - 64;
+  c0 = c0 < 0 ? 0 : c0;
+  const int chunk0 = (int)(c0 / kNNChunk);
+  for (int ci = 0; ci < nchunks; ++ci) {
+    const int base = ((chunk0 + ci) % nchunks) * kNNChunk;
+    const int len = min(kNNChunk, m - base);
+    const int len32 = (len + 31) & ~31;  // padded (+inf) to the 32-candidate step
+    int k0 = ci == 0 ? ((int)(c0 - base) & ~31) : 0;
+    k0 = k0 < len32 ? k0 : 0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < len32; e += kBlock) {
+      float4 r = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(INT_MAX));  // padding: d = inf, never taken
+      if (e < len) r = cand[base + e];
+      s_c[nn_slot(e, 0)] = r.x; s_c[nn_slot(e, 1)] = r.y; s_c[nn_slot(e, 2)] = r.z;
+      s_k[e] = __float_as_int(r.w);
+    }
+    __syncthreads();
+    for (int kr = 32 * wave; kr < len32; kr += 32 * (kBlock / 64)) {
+      int k = k0 + kr;
+      k = k >= len32 ? k - len32 : k;  // wrap around inside the chunk
+      f32x2 d[4][4];
+      float mn[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float *g0 = s_c + ((k >> 2) + 2 * u) * 12;
+        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(g0), a1 = *reinterpret_cast<const f32x4 *>(g0 + 4),
+                    a2 = *reinterpret_cast<const f32x4 *>(g0 + 8), b0 = *reinterpret_cast<const f32x4 *>(g0 + 12),
+                    b1 = *reinterpret_cast<const f32x4 *>(g0 + 16), b2 = *reinterpret_cast<const f32x4 *>(g0 + 20);
+        {
+          const f32x2 dx = f32x2{a0[0], a0[1]} - qx, dy = f32x2{a0[2], a0[3]} - qy, dz = f32x2{a1[0], a1[1]} - qz;
+          d[u][0] = (dx * dx + dy * dy) + dz * dz;
+        }
+        {
+          const f32x2 dx = f32x2{a1[2], a1[3]} - qx, dy = f32x2{a2[0], a2[1]} - qy, dz = f32x2{a2[2], a2[3]} - qz;
+          d[u][1] = (dx * dx + dy * dy) + dz * dz;
+        }
+        {
+          const f32x2 dx = f32x2{b0[0], b0[1]} - qx, dy = f32x2{b0[2], b0[3]} - qy, dz = f32x2{b1[0], b1[1]} - qz;
+          d[u][2] = (dx * dx + dy * dy) + dz * dz;
+        }
+        {
+          const f32x2 dx = f32x2{b1[2], b1[3]} - qx, dy = f32x2{b2[0], b2[1]} - qy, dz = f32x2{b2[2], b2[3]} - qz;
+          d[u][3] = (dx * dx + dy * dy) + dz * dz;
+        }
+        mn[u] = fminf(fminf(fminf(d[u][0][0], d[u][0][1]), fminf(d[u][1][0], d[u][1][1])),
+                      fminf(fminf(d[u][2][0], d[u][2][1]), fminf(d[u][3][0], d[u][3][1])));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        // '<=': an equal distance with a smaller index must still be seen
+        if (__any(valid && mn[u] <= __uint_as_float((unsigned)(k3 >> 32)))) {
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            const unsigned long long x = ((unsigned long long)__float_as_uint(d[u][t >> 1][t & 1]) << 32) |
+                                         (unsigned)s_k[k + 8 * u + t];
+            const bool l1 = x < k1, l2 = x < k2, l3 = x < k3;
+            k3 = l2 ? k2 : (l3 ? x : k3);
+            k2 = l1 ? k1 : (l2 ? x : k2);
+            k1 = l1 ? x : k1;
+          }
+        }
+      }
+    }
+  }
+  __shared__ unsigned long long s_mk[3][3][64];  // partial lists of waves 1..3
+  if (wave > 0) { s_mk[wave - 1][0][lane] = k1; s_mk[wave - 1][1][lane] = k2; s_mk[wave - 1][2][lane] = k3; }
+  __syncthreads();
+  if (wave == 0 && valid) {
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const unsigned long long x = s_mk[w][t][lane];
+        const bool l1 = x < k1, l2 = x < k2, l3 = x < k3;
+        k3 = l2 ? k2 : (l3 ? x : k3);
+        k2 = l1 ? k1 : (l2 ? x : k2);
+        k1 = l1 ? x : k1;
+      }
+    const size_t o = ((size_t)b * n + __float_as_int(q.w)) * 3;
+    dist[o] = __uint_as_float((unsigned)(k1 >> 32)); dist[o + 1] = __uint_as_float((unsigned)(k2 >> 32));
+    dist[o + 2] = __uint_as_float((unsigned)(k3 >> 32));
+    idx[o] = (int)(unsigned)k1; idx[o + 1] = (int)(unsigned)k2; idx[o + 2] = (int)(unsigned)k3;
+  }
+}
+
 // ------------------------------------------------------------------ three_interpolate
 // IDW: weights derived from squared distances (core/backbones.py:92-95); else read from `weight`.
 template <bool IDW, int VEC>
@@ -274,6 +393,17 @@ DH3D_API int dh3d_three_nn(int b, int n, int m, const float *xyz1, const float *
   DH3D_SUPPORTED(b <= 65535);
   hipLaunchKernelGGL(three_nn_kernel, dim3(dh3d_cdiv(n, 64), b), dim3(kBlock), 0,
                      (hipStream_t)stream, n, m, xyz1, xyz2, dist, idx);
+  return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_three_nn_sorted(int b, int n, int m, const float *sorted1, const float *gbox1,
+                                  const float *sorted2, const float *gbox2, float *dist, int32_t *idx,
+                                  void *stream) {
+  (void)gbox1; (void)gbox2;  // accepted for symmetry with the other ordered kernels; the scan needs the order only
+  DH3D_REQUIRE(sorted1 && sorted2 && dist && idx && b > 0 && n > 0 && m > 0);
+  DH3D_SUPPORTED(b <= 65535);
+  hipLaunchKernelGGL(three_nn_sorted_kernel, dim3(dh3d_cdiv(n, 64), b), dim3(kBlock), 0, (hipStream_t)stream, n, m,
+                     reinterpret_cast<const float4 *>(sorted1), reinterpret_cast<const float4 *>(sorted2), dist, idx);
   return dh3d_launch_status();
 }
 

@@ -59,6 +59,18 @@ def fps_sorted(srt, gbox, npoint, with_xyz=False):
     return out
 
 
+def three_nn_sorted(srt1, gbox1, srt2, gbox2):
+    """three_nn from spatial_sort() outputs of the query cloud and of the candidate set: same (dist [B,n,3] squared,
+    idx [B,n,3]) as ops.three_nn, original indexing on both sides."""
+    B, n, _ = srt1.shape
+    m = srt2.shape[1]
+    d3 = torch.empty((B, n, 3), dtype=torch.float32, device=srt1.device)
+    i3 = torch.empty((B, n, 3), dtype=torch.int32, device=srt1.device)
+    L.check(L.lib().dh3d_three_nn_sorted(B, n, m, L.ptr(srt1), L.ptr(gbox1), L.ptr(srt2), L.ptr(gbox2), L.ptr(d3),
+                                         L.ptr(i3), L.stream_ptr()), "three_nn_sorted")
+    return d3, i3
+
+
 def pack_weight(W):
     """W [Kd, Dout] row-major -> MFMA fragment order (see mfma_gemm.h)."""
     W = L.require_cuda_f32(W, "W", 2)

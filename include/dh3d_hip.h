@@ -189,6 +189,14 @@ int dh3d_spatial_sort(const float *xyz, int B, int N, float *sorted, float *gbox
 int dh3d_knn_sorted(const float *sorted, const float *gbox, int B, int N, int K, int32_t *nn, float *dist,
                     void *stream);
 
+/* ThreeNN on ordered clouds: identical dist / idx to dh3d_three_nn (original indexing on both sides) from the
+ * dh3d_spatial_sort outputs of the query cloud (sorted1 [b,n,4], gbox1) and of the candidate set (sorted2 [b,m,4],
+ * gbox2; the boxes are not needed by the current kernel and may be NULL).  Every candidate is still visited; the
+ * ordering makes the 3-deep insertion rare (a wave's queries are a compact region and its scan starts at the matching
+ * place of the candidates' order). */
+int dh3d_three_nn_sorted(int b, int n, int m, const float *sorted1, const float *gbox1, const float *sorted2,
+                         const float *gbox2, float *dist, int32_t *idx, void *stream);
+
 /* FarthestPointSample on an ordered cloud: identical outputs to dh3d_farthest_point_sample (original
  * indices); per round only the 64-point groups the new sample can affect are re-evaluated.  N <= 12288. */
 int dh3d_fps_sorted(const float *sorted, const float *gbox, int B, int N, int m, int32_t *out, void *stream);

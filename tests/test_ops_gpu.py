@@ -337,3 +337,26 @@ def test_fps_modes_differ_somewhere_and_ties(dev, oracle):
         assert np.array_equal(ops.farthest_point_sample(200, T(lat, dev), contract=c).cpu().numpy(),
                               oracle.farthest_point_sample(200, lat, contract=bool(c)))
     print("clouds on which the two FPS roundings pick differently: %d / 6" % differ)
+
+
+@pytest.mark.parametrize("b,n,m", [(2, 8192, 1024), (3, 4096, 512), (1, 5000, 700), (1, 16384, 2048), (2, 300, 256), (1, 1000, 2)])
+def test_three_nn_sorted_identical_to_bruteforce(dev, oracle, b, n, m):
+    """The box-pruned three_nn on Morton-ordered sets: ids and (squared) distances bit-equal to the brute-force op and
+    to the oracle, incl. a sampled set that is a subset of the cloud (distance-0 hits) and exact ties on a lattice."""
+    from dh3d_amd import ops, pm
+    rng = np.random.default_rng(n + m)
+    xyz1 = (rng.random((b, n, 3), dtype=np.float32) * 30 - 15)
+    sel = np.stack([rng.choice(n, m, replace=False) for _ in range(b)])
+    xyz2 = np.take_along_axis(xyz1, sel[:, :, None], 1)            # the model's case: samples of the cloud itself
+    for (a1, a2) in ((xyz1, xyz2), (np.round(xyz1), np.round(xyz2))):   # second: integer lattice -> many exact ties
+        t1, t2 = T(a1, dev), T(a2, dev)
+        d0, i0 = ops.three_nn(t1, t2)
+        s1, g1 = pm.spatial_sort(t1)
+        s2, g2 = pm.spatial_sort(t2)
+        d1, i1 = pm.three_nn_sorted(s1, g1, s2, g2)
+        assert torch.equal(i0, i1) and torch.equal(d0, d1)
+    if n <= 5000:
+        de, ie = oracle.three_nn(xyz1, xyz2)
+        s1, g1 = pm.spatial_sort(T(xyz1, dev)); s2, g2 = pm.spatial_sort(T(xyz2, dev))
+        dd, ii = pm.three_nn_sorted(s1, g1, s2, g2)
+        assert np.array_equal(ii.cpu().numpy(), ie) and np.array_equal(dd.cpu().numpy(), de)
