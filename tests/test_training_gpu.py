@@ -321,7 +321,9 @@ def test_hip_head_matches_torch_head_forward_and_gradients(dev):
             #  noise there, hence the absolute floor)
             # (a single-element gradient -- the fc bias: a sum of 16k signed terms -- is compared relative to itself,
             #  not to a tensor's largest entry: cancellation leaves it ~3e-3 of relative rounding)
-            tol = (2e-3 if b.numel() > 1 else 1e-2) * float(b.abs().max()) + 1e-6
+            # (5e-3 of the largest entry: f32 sums in another order through three chained batch norms and f32 atomics
+            #  in the scatter / split-K kernels -- run-to-run jitter of the HIP side alone is ~1e-3)
+            tol = (5e-3 if b.numel() > 1 else 1e-2) * float(b.abs().max()) + 1e-6
             assert float((a - b).abs().max()) <= tol, (n, float((a - b).abs().max()), float(b.abs().max()))
         for k in b0:
             assert torch.allclose(b0[k], b1[k], rtol=1e-4, atol=1e-5), k
