@@ -289,8 +289,9 @@ def kernel_breakdown(dev, B, N):
     out["spatial_sort"] = event_time_ms(lambda: pm.spatial_sort(xyz), iters=10, warm=2)
     srt, gbox = pm.spatial_sort(xyz)
     out["knn_sorted K=8"] = event_time_ms(lambda: pm.knn_sorted(srt, gbox, 8), iters=10, warm=2)
-    if 4096 <= N <= 12288:
-        out["fps_sorted N->N/8"] = event_time_ms(lambda: pm.fps_sorted(srt, gbox, N // 8), iters=5, warm=1)
+    if 4096 <= N <= 16384:
+        out["fps_sorted N->N/8"] = event_time_ms(lambda: pm.fps_sorted(srt, gbox, N // 8, xyz=xyz if N > 12288 else None),
+                                                 iters=5, warm=1)
     sub = xyz[:, : N // 8].contiguous()
     out["three_nn"] = event_time_ms(lambda: ops.three_nn(xyz, sub), iters=10, warm=2)
     if N // 8 >= 256:
@@ -513,6 +514,7 @@ def main():
             if other == "cfg5":
                 with torch.no_grad():
                     rec["kernel_roofline"] = cfg5_kernel_line(dev)
+                    rec["kernels_ms"] = kernel_breakdown(dev, WORKLOADS[other]["B"], WORKLOADS[other]["N"])
             others.append(rec)
         line["other_workloads"] = others
         line["other_workload"] = others[0]  # round-1 key, kept for the driver's diff

@@ -86,6 +86,7 @@ _SIGNATURES = {
     "dh3d_fps_sorted": [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp],
     "dh3d_three_nn_sorted": [c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp],
     "dh3d_fps_sorted_xyz": [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp],
+    "dh3d_fps_sorted_cloud": [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp],
     "dh3d_pack_weight": [c_fp, c_int, c_int, c_fp, c_fp],
     "dh3d_pack_flex_weight": [c_fp, c_fp, c_int, c_int, c_fp, c_fp],
     "dh3d_flex_conv_pm_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int,

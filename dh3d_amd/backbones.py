@@ -255,8 +255,9 @@ def compute_level(xyz, dilate, knn, ordered=None, fps_contract=None):
     (ops.farthest_point_sample)."""
     B, N, _ = xyz.shape
     npoint = N // dilate
-    if ordered is not None and 4096 <= N <= 12288 and fps_contract is None:
-        idx, xyz_s = pm.fps_sorted(ordered[0], ordered[1], npoint, with_xyz=True)  # coordinates from the kernel's LDS
+    if ordered is not None and 4096 <= N <= 16384 and fps_contract is None:
+        # (above 12288 points the kernel has no room for its LDS coordinate table and reads winners from the cloud)
+        idx, xyz_s = pm.fps_sorted(ordered[0], ordered[1], npoint, with_xyz=True, xyz=xyz if N > 12288 else None)
     else:
         from . import ops
         idx = ops.farthest_point_sample(npoint, xyz, contract=fps_contract)  # any N (scratch distances above 16384)

@@ -301,11 +301,15 @@ __global__ __launch_bounds__(64 * WAVES) void fps_sorted_kernel(const float4 *__
 // atomicMin, and all candidates ranked before it are taken at once: ~3.7 picks per sync on uniform clouds
 // (tools/fps_batch_sim.py).  Two barriers per sync instead of one per pick; the box tests of up to 64/PPT picks
 // against the wave's PPT boxes run in ONE pass (lane = pick * PPT + box).
-template <int PPT, int WAVES>
+// TABLE: the by-original-index coordinate table lives in LDS (12 B per point: clouds of up to ~12 k points).  Larger
+// clouds (TABLE = false) read the winner's coordinates from the cloud itself (`xyz`, L2-resident) instead -- one global
+// round trip on the active wave's chain per sync, still far ahead of the one-pick-per-round kernel at 16384 points.
+template <int PPT, int WAVES, bool TABLE>
 __global__ __launch_bounds__(64 * WAVES) void fps_batched_kernel(const float4 *__restrict__ sorted,
                                                                const float *__restrict__ gbox, int N, int m,
                                                                int32_t *__restrict__ out,
-                                                               float *__restrict__ xyz_out) {
+                                                               float *__restrict__ xyz_out,
+                                                               const float *__restrict__ xyz) {
   static_assert(PPT <= 64 && WAVES <= 16, "one lane per group box, one lane per candidate");
   constexpr int CAP0 = PPT <= 32 ? 64 / PPT : 1;
   constexpr int CAP = CAP0 < WAVES ? CAP0 : WAVES;  // picks per sync
@@ -319,9 +323,10 @@ __global__ __launch_bounds__(64 * WAVES) void fps_batched_kernel(const float4 *_
   float4 *s_pick = s_ent + 2 * WAVES;
   int *s_jthr = reinterpret_cast<int *>(s_pick + 16);  // per judging wave: first rank it holds back
   float *s_x = reinterpret_cast<float *>(s_jthr + 4);
-  float *s_y = s_x + N;
-  float *s_z = s_y + N;
-  int *s_out = reinterpret_cast<int *>(s_z + N);
+  float *s_y = s_x + (TABLE ? N : 0);
+  float *s_z = s_y + (TABLE ? N : 0);
+  int *s_out = reinterpret_cast<int *>(s_z + (TABLE ? N : 0));
+  const float *pc = TABLE ? nullptr : xyz + (size_t)blockIdx.x * N * 3;
 
   // the kernel is a dependent chain on 1 CU per cloud while the rest of the step shares the chip: its waves go first
   __builtin_amdgcn_s_setprio(3);
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(64 * WAVES) void fps_batched_kernel(const float4 *_
       x = r.x; y = r.y; z = r.z;
       d = 1e38f;
       pkey[j] = fps_key(k);
-      s_x[k] = r.x; s_y[k] = r.y; s_z[k] = r.z;
+      if (TABLE) { s_x[k] = r.x; s_y[k] = r.y; s_z[k] = r.z; }
     }
     px[j >> 1][j & 1] = x; py[j >> 1][j & 1] = y; pz[j >> 1][j & 1] = z; md[j >> 1][j & 1] = d;
   }
@@ -368,7 +373,9 @@ __global__ __launch_bounds__(64 * WAVES) void fps_batched_kernel(const float4 *_
   // instruction count along the chain barrier -> judge -> barrier -> box test -> update -> arg-max, not by data), so
   // every phase is written for few instructions: no per-group branches, no atomics, nothing recomputed.
   float wmax = __ballot(has_box) != 0ull ? 1e38f : -2.f;  // cached wave maximum (uniform)
-  float qx = s_x[0], qy = s_y[0], qz = s_z[0];            // lane (pk, .): coordinates of pick pk of this sync
+  float qx, qy, qz;                                         // lane (pk, .): coordinates of pick pk of this sync
+  if (TABLE) { qx = s_x[0]; qy = s_y[0]; qz = s_z[0]; }
+  else { qx = pc[0]; qy = pc[1]; qz = pc[2]; }
   int npick = 1, r = 1;
 #ifdef DH3D_FPS_PROBE
   long long pt[12], at[8];
@@ -451,7 +458,9 @@ __global__ __launch_bounds__(64 * WAVES) void fps_batched_kernel(const float4 *_
       }
       ASTAMP(4);
       const int widx = fps_unkey(wkey);
-      const float wx = s_x[widx], wy = s_y[widx], wz = s_z[widx];
+      float wx, wy, wz;
+      if (TABLE) { wx = s_x[widx]; wy = s_y[widx]; wz = s_z[widx]; }
+      else { wx = pc[(size_t)widx * 3]; wy = pc[(size_t)widx * 3 + 1]; wz = pc[(size_t)widx * 3 + 2]; }
       ASTAMP(5);
       // publish the candidate (an untouched wave's entry stays valid)
       if (lane == 0) {
@@ -534,19 +543,26 @@ __global__ __launch_bounds__(64 * WAVES) void fps_batched_kernel(const float4 *_
     float *xo = xyz_out + (size_t)b * m * 3;
     for (int e = tid; e < 3 * m; e += 64 * WAVES) {
       const int i = e / 3, c = e - 3 * i, k = s_out[i];
-      xo[e] = c == 0 ? s_x[k] : c == 1 ? s_y[k] : s_z[k];
+      xo[e] = TABLE ? (c == 0 ? s_x[k] : c == 1 ? s_y[k] : s_z[k]) : pc[(size_t)k * 3 + c];
     }
   }
 }
 
 template <int PPT, int WAVES>
 int fps_batched_launch(const float *sorted, const float *gbox, int B, int N, int m, int32_t *out, float *xyz_out,
-                       hipStream_t s) {
-  const size_t lds = sizeof(float) * (8 * WAVES + 64 + 4 + (size_t)3 * N + m);
-  if (lds > 159 * 1024) return DH3D_ERR_UNSUPPORTED;
-  DH3D_ALLOW_BIG_LDS((fps_batched_kernel<PPT, WAVES>));
-  hipLaunchKernelGGL((fps_batched_kernel<PPT, WAVES>), dim3(B), dim3(64 * WAVES), lds, s,
-                     reinterpret_cast<const float4 *>(sorted), gbox, N, m, out, xyz_out);
+                       const float *xyz, hipStream_t s) {
+  const size_t small = sizeof(float) * (8 * WAVES + 64 + 4 + (size_t)m);
+  const size_t lds = small + sizeof(float) * (size_t)3 * N;
+  if (lds <= 159 * 1024) {
+    DH3D_ALLOW_BIG_LDS((fps_batched_kernel<PPT, WAVES, true>));
+    hipLaunchKernelGGL((fps_batched_kernel<PPT, WAVES, true>), dim3(B), dim3(64 * WAVES), lds, s,
+                       reinterpret_cast<const float4 *>(sorted), gbox, N, m, out, xyz_out, nullptr);
+  } else {
+    if (!xyz || small > 159 * 1024) return DH3D_ERR_UNSUPPORTED;  // no LDS table: the cloud itself is needed
+    DH3D_ALLOW_BIG_LDS((fps_batched_kernel<PPT, WAVES, false>));
+    hipLaunchKernelGGL((fps_batched_kernel<PPT, WAVES, false>), dim3(B), dim3(64 * WAVES), small, s,
+                       reinterpret_cast<const float4 *>(sorted), gbox, N, m, out, xyz_out, xyz);
+  }
   return dh3d_launch_status();
 }
 
@@ -671,9 +687,10 @@ DH3D_API void dh3d_dev_set_fps_sorted_waves(int w) { g_fps_sorted_waves = w; }
 DH3D_API void dh3d_dev_set_fps_sorted_mode(int v) { g_fps_sorted_mode = v; }
 
 static int fps_sorted_dispatch(const float *sorted, const float *gbox, int B, int N, int m, int32_t *out,
-                               float *xyz_out, void *stream) {
+                               float *xyz_out, const float *xyz, void *stream) {
   DH3D_REQUIRE(sorted && gbox && out && B > 0 && N > 0 && m > 0);
-  DH3D_SUPPORTED(N <= 12288);  // the by-original-index coordinate table must fit LDS (12 B / point)
+  // the by-original-index coordinate table must fit LDS (12 B / point) unless the cloud itself is given
+  DH3D_SUPPORTED(N <= 12288 || (xyz && N <= 16384 && g_fps_sorted_mode == 0));
   hipStream_t s = (hipStream_t)stream;
   const int W = g_fps_sorted_waves ? g_fps_sorted_waves : 16;  // measured best on MI355X (tools/geo_bench.py)
   const int NG = (N + 63) / 64;
@@ -681,13 +698,13 @@ static int fps_sorted_dispatch(const float *sorted, const float *gbox, int B, in
   if (W == WV) {                                                                                      \
     const int gpw = (NG + WV - 1) / WV; /* groups per wave */                                         \
     if (g_fps_sorted_mode == 0) {                                                                     \
-      if (gpw <= 1) return fps_batched_launch<1, WV>(sorted, gbox, B, N, m, out, xyz_out, s);         \
-      if (gpw <= 2) return fps_batched_launch<2, WV>(sorted, gbox, B, N, m, out, xyz_out, s);         \
-      if (gpw <= 4) return fps_batched_launch<4, WV>(sorted, gbox, B, N, m, out, xyz_out, s);         \
-      if (gpw <= 8) return fps_batched_launch<8, WV>(sorted, gbox, B, N, m, out, xyz_out, s);         \
-      if (gpw <= 16) return fps_batched_launch<16, WV>(sorted, gbox, B, N, m, out, xyz_out, s);       \
-      if (gpw <= 32) return fps_batched_launch<32, WV>(sorted, gbox, B, N, m, out, xyz_out, s);       \
-      if (gpw <= 48) return fps_batched_launch<48, WV>(sorted, gbox, B, N, m, out, xyz_out, s);       \
+      if (gpw <= 1) return fps_batched_launch<1, WV>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);         \
+      if (gpw <= 2) return fps_batched_launch<2, WV>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);         \
+      if (gpw <= 4) return fps_batched_launch<4, WV>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);         \
+      if (gpw <= 8) return fps_batched_launch<8, WV>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);         \
+      if (gpw <= 16) return fps_batched_launch<16, WV>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);       \
+      if (gpw <= 32) return fps_batched_launch<32, WV>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);       \
+      if (gpw <= 48) return fps_batched_launch<48, WV>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);       \
     }                                                                                                 \
     if (gpw <= 1) return fps_sorted_launch<1, WV>(sorted, gbox, B, N, m, out, s);                     \
     if (gpw <= 2) return fps_sorted_launch<2, WV>(sorted, gbox, B, N, m, out, s);                     \
@@ -707,7 +724,7 @@ static int fps_sorted_dispatch(const float *sorted, const float *gbox, int B, in
 
 DH3D_API int dh3d_fps_sorted(const float *sorted, const float *gbox, int B, int N, int m, int32_t *out,
                              void *stream) {
-  return fps_sorted_dispatch(sorted, gbox, B, N, m, out, nullptr, stream);
+  return fps_sorted_dispatch(sorted, gbox, B, N, m, out, nullptr, nullptr, stream);
 }
 
 // + xyz_out [B, m, 3]: the sampled coordinates (what group_point of the cloud by `out` returns), written by the same
@@ -715,7 +732,15 @@ DH3D_API int dh3d_fps_sorted(const float *sorted, const float *gbox, int B, int 
 DH3D_API int dh3d_fps_sorted_xyz(const float *sorted, const float *gbox, int B, int N, int m, int32_t *out,
                                  float *xyz_out, void *stream) {
   DH3D_REQUIRE(xyz_out);
-  return fps_sorted_dispatch(sorted, gbox, B, N, m, out, xyz_out, stream);
+  return fps_sorted_dispatch(sorted, gbox, B, N, m, out, xyz_out, nullptr, stream);
+}
+
+// + xyz [B, N, 3]: the cloud the records were sorted from.  Lifts the 12288-point limit of the LDS coordinate table
+// to the 16384 of the ordering itself (the winner's coordinates are then read from `xyz`); xyz_out may be NULL.
+DH3D_API int dh3d_fps_sorted_cloud(const float *sorted, const float *gbox, const float *xyz, int B, int N, int m,
+                                   int32_t *out, float *xyz_out, void *stream) {
+  DH3D_REQUIRE(xyz);
+  return fps_sorted_dispatch(sorted, gbox, B, N, m, out, xyz_out, xyz, stream);
 }
 
 #ifdef DH3D_FPS_PROBE

@@ -176,7 +176,7 @@ class DH3D(nn.Module):
     def _geometry(self, points, knn_inds=None):
         geo = bb.Geometry(points, self.knn_num, fps_contract=self.config.fps_contract)
         main = torch.cuda.current_stream()
-        if knn_inds is None or (4096 <= points.shape[1] <= 12288 and self.config.fps_contract is None):
+        if knn_inds is None or (4096 <= points.shape[1] <= 16384 and self.config.fps_contract is None):
             geo.ordered()  # Morton order + group boxes: shared by the kNN (side) and the pruned FPS (here)
         if self._geo_stream is None:
             self._geo_stream = torch.cuda.Stream(device=points.device)

@@ -44,19 +44,24 @@ def knn_sorted(srt, gbox, k):
     return nn, dist
 
 
-def fps_sorted(srt, gbox, npoint, with_xyz=False):
+def fps_sorted(srt, gbox, npoint, with_xyz=False, xyz=None):
     """FPS from spatial_sort() output; same idx [B,npoint] (original indexing) as ops.farthest_point_sample.
-    with_xyz: also the sampled coordinates [B,npoint,3], written by the same kernel."""
+    with_xyz: also the sampled coordinates [B,npoint,3], written by the same kernel.
+    xyz: the cloud the records came from -- required above 12288 points (no room for the LDS coordinate table)."""
     B, N, _ = srt.shape
     out = torch.empty((B, npoint), dtype=torch.int32, device=srt.device)
-    if with_xyz:
-        xyz_s = torch.empty((B, npoint, 3), dtype=torch.float32, device=srt.device)
+    xyz_s = torch.empty((B, npoint, 3), dtype=torch.float32, device=srt.device) if with_xyz else None
+    if xyz is not None:
+        x = L.require_cuda_f32(xyz, "xyz", 3)
+        L.check(L.lib().dh3d_fps_sorted_cloud(L.ptr(srt), L.ptr(gbox), L.ptr(x), B, N, npoint, L.ptr(out), L.ptr(xyz_s),
+                                              L.stream_ptr()), "fps_sorted_cloud")
+    elif with_xyz:
         L.check(L.lib().dh3d_fps_sorted_xyz(L.ptr(srt), L.ptr(gbox), B, N, npoint, L.ptr(out), L.ptr(xyz_s),
                                             L.stream_ptr()), "fps_sorted_xyz")
-        return out, xyz_s
-    L.check(L.lib().dh3d_fps_sorted(L.ptr(srt), L.ptr(gbox), B, N, npoint, L.ptr(out), L.stream_ptr()),
-            "fps_sorted")
-    return out
+    else:
+        L.check(L.lib().dh3d_fps_sorted(L.ptr(srt), L.ptr(gbox), B, N, npoint, L.ptr(out), L.stream_ptr()),
+                "fps_sorted")
+    return (out, xyz_s) if with_xyz else out
 
 
 def three_nn_sorted(srt1, gbox1, srt2, gbox2):

@@ -203,6 +203,10 @@ int dh3d_fps_sorted(const float *sorted, const float *gbox, int B, int N, int m,
 /* the same + xyz_out [B,m,3] = the sampled coordinates (group_point of the cloud by `out`, core/tf_utils.py:92-95) */
 int dh3d_fps_sorted_xyz(const float *sorted, const float *gbox, int B, int N, int m, int32_t *out, float *xyz_out,
                         void *stream);
+/* Same with the cloud itself (xyz [B,N,3], what dh3d_spatial_sort was given): clouds of up to 16384 points (above
+ * 12288 the by-index coordinate table no longer fits the LDS and the kernel reads winners from xyz).  xyz_out may be NULL. */
+int dh3d_fps_sorted_cloud(const float *sorted, const float *gbox, const float *xyz, int B, int N, int m, int32_t *out,
+                          float *xyz_out, void *stream);
 
 /* flex_conv forward (same function as dh3d_flex_conv_fwd, Dp = 3) in the factorised form
  *   out[n,:] = [S0 | Sx | Sy | Sz][n,:] @ [bias; theta_x; theta_y; theta_z],

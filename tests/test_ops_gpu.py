@@ -360,3 +360,21 @@ def test_three_nn_sorted_identical_to_bruteforce(dev, oracle, b, n, m):
         s1, g1 = pm.spatial_sort(T(xyz1, dev)); s2, g2 = pm.spatial_sort(T(xyz2, dev))
         dd, ii = pm.three_nn_sorted(s1, g1, s2, g2)
         assert np.array_equal(ii.cpu().numpy(), ie) and np.array_equal(dd.cpu().numpy(), de)
+
+
+@pytest.mark.parametrize("B,N,m", [(1, 12289, 1536), (2, 16384, 2048), (1, 13000, 700)])
+def test_fps_sorted_above_the_lds_table_limit(dev, oracle, B, N, m):
+    """Clouds of 12289..16384 points: the batched-round FPS without its LDS coordinate table (winners read from the
+    cloud) -- same picks as the plain op, and as the oracle."""
+    from dh3d_amd import ops, pm
+    rng = np.random.default_rng(N)
+    xyz = rng.random((B, N, 3), dtype=np.float32) * 40 - 20
+    t = T(xyz, dev)
+    srt, gbox = pm.spatial_sort(t)
+    idx, xyz_s = pm.fps_sorted(srt, gbox, m, with_xyz=True, xyz=t)
+    assert torch.equal(idx, ops.farthest_point_sample(m, t))
+    assert torch.equal(xyz_s, torch.gather(t, 1, idx.long()[:, :, None].expand(-1, -1, 3)))
+    if B == 1:
+        assert np.array_equal(idx.cpu().numpy(), oracle.farthest_point_sample(m, xyz))
+    with pytest.raises(ValueError):
+        pm.fps_sorted(srt, gbox, m)          # no cloud given: the table does not fit
