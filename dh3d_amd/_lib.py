@@ -103,6 +103,8 @@ _SIGNATURES = {
     "dh3d_upsample_linear_shortcut_pm_x6_fwd": [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_int, c_fp, c_int,
                                                 c_fp, c_int, ctypes.POINTER(Epilogue), ctypes.POINTER(Epilogue),
                                                 c_fp, c_float, c_fp, c_fp],
+    "dh3d_interp_combine_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, ctypes.POINTER(Epilogue), c_fp, c_fp,
+                                c_float, c_fp, c_fp],
     "dh3d_linear_slices_pm_x6_fwd": [c_fp, c_int, c_fp, c_int, c_int, c_fp, c_fp],
     "dh3d_interp_head_fwd": [c_fp, c_int, c_fp, c_fp, c_int, c_int, c_int, ctypes.POINTER(Epilogue), c_fp, c_float,
                              c_fp, c_fp],

@@ -122,6 +122,32 @@ class Conv2D1x1(nn.Module):
             p["wp3_sc"] = pm.pack_weight_x3(torch.cat([p["W2"], q["W2"]], 0).contiguous())
             p["sc_ep"] = (q["b"], q["scale"], q["shift"], pm.ACT_RELU)
 
+    def commuted_supported(self, c_top):
+        """forward_commuted available: the conv splits into an upper block applied to c_top up-sampled channels and a
+        lower block applied to the full-resolution input (cout = 128, both blocks GEMM-able)."""
+        p = self._prep or self.prepare()
+        if "wp_top" not in p and self.cout == 128 and 0 < c_top < self.cin and c_top % 8 == 0 and (self.cin - c_top) % 8 == 0:
+            p["c_top"] = c_top
+            p["wp_top"] = pm.pack_weight(p["W2"][:c_top].contiguous())
+            p["wp_bot"] = pm.pack_weight(p["W2"][c_top:].contiguous())
+        return p.get("c_top") == c_top
+
+    def lower_partial(self, x2):
+        """x2 @ W[c_top:] (no bias / BN / activation): the part of a commuted concat conv that needs the full-resolution
+        input only -- the caller runs it off the critical chain."""
+        p = self._prep
+        return pm.linear(x2, p["wp_bot"], self.cout)
+
+    def forward_commuted(self, coarse, idx, dist, partial, act=pm.ACT_RELU, residual=None, l2cat=None):
+        """forward([three_interpolate_idw(coarse) | x2]) with the upper weight block applied to the COARSE rows (the
+        interpolation is linear and acts on rows, so it commutes with the conv) and `partial` = lower_partial(x2):
+        a [B*M, c_top] x [c_top, 128] GEMM + one gather / epilogue kernel behind the sampled level instead of the
+        [B*N, cin] x [cin, 128] GEMM with the up-sampling fused into its staging."""
+        p = self._prep
+        cw = pm.linear(coarse, p["wp_top"], self.cout)
+        return pm.interp_combine(cw, idx, dist, partial, pre_bias=p["b"], scale=p["scale"], shift=p["shift"], act=act,
+                                 residual=residual, l2cat=l2cat)
+
     def upsampled_supported(self, coarse, idx, x2):
         """Can forward_upsampled serve this call?  (same batch-independent rule as forward's x6 choice)"""
         p = self._prep or self.prepare()
@@ -354,10 +380,21 @@ class FlexConvDilate(nn.Module):
         return (conv is not None and self.upsample and self.dilate > 1 and n_points >= 4096
                 and "wp3_sc" in (conv._prep or conv.prepare()))
 
-    def forward(self, geo, feat, nbr=None, residual=None, l2cat=None, shortcut_src=None):
+    def commuted_partial(self, feat):
+        """The part of this block's concat conv that needs `feat` only (Conv2D1x1.lower_partial), or None when the
+        commuted form does not apply: clouds of more than 4096 points, where the sampling chain is the critical one and
+        whatever can run beside it should (rule on the points per cloud only, never on the batch)."""
+        conv = self.concat_conv1d.tfconv0 if self.concat else None
+        if (conv is None or not (self.upsample and self.dilate > 1) or feat.shape[1] <= 4096
+                or not conv.commuted_supported(self.outdims[-1])):
+            return None
+        return conv.lower_partial(feat)
+
+    def forward(self, geo, feat, nbr=None, residual=None, l2cat=None, shortcut_src=None, lower_partial=None):
         """geo: Geometry; feat [B,N,cin]; nbr [B,N,K] for dilate == 1 (else computed on the sampled set);
         residual [B,N,cout]: added to the concat conv's output in its store (the caller's shortcut branch);
-        l2cat = (prefix [B,N,3], eps): return [prefix | l2_normalize(output)] instead of the output."""
+        l2cat = (prefix [B,N,3], eps): return [prefix | l2_normalize(output)] instead of the output;
+        lower_partial: commuted_partial(feat), computed earlier by the caller."""
         prep = self._prep or self.prepare()
         if self.dilate > 1:
             lv = geo.level(self.dilate, self.knn, finish=False)  # three_nn is joined only where it is consumed
@@ -382,6 +419,9 @@ class FlexConvDilate(nn.Module):
             self._last_coarse = (x, lv)  # the level's features before up-sampling (PointMLPHead.forward_interpolated)
             geo.finish(lv)
             conv = self.concat_conv1d.tfconv0 if self.concat else None
+            if conv is not None and lower_partial is not None and shortcut_src is None:
+                return conv.forward_commuted(x, lv["nn3_idx"], lv["nn3_dist"], lower_partial, act=pm.ACT_RELU,
+                                             residual=residual, l2cat=l2cat)
             if conv is not None and conv.upsampled_supported(x, lv["nn3_idx"], feat):
                 # up-sampling fused into the concat conv's operand staging: the [B,N,C] tensor is never written
                 fuse = l2cat if conv.cout == 128 else None

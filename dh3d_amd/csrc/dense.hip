@@ -316,7 +316,78 @@ __global__ __launch_bounds__(256) void l2norm_concat_kernel(const float *__restr
   for (int c = sub; c < C; c += 32) o[P + c] = x[row * C + c] * inv;
 }
 
+// ------------------------------------------------------------------ commuted concat conv: gather + epilogue
+// The concat conv behind an up-sampling, y = act(BN([interp(coarse) | x2] W + b)) (core/backbones.py:89-100), is linear
+// in its two inputs and the three interpolation weights act on rows:  interp(coarse) W_top = interp(coarse W_top).  So
+// the GEMM against W_top runs on the COARSE rows (N/8 of them) and the one against W_bot on x2 as soon as x2 exists
+// (beside the farthest-point sampling, off the critical chain); what is left behind the sampled level is this kernel:
+//   v = w0*Cw[i0] + w1*Cw[i1] + w2*Cw[i2] + P[n] + b  ->  BN, activation  ->  + residual  ->  out / [prefix | l2norm(v)]
+// 32 lanes x float4 per row (C == 128), a wave = two rows; the l2-normalisation's row sum is a 32-lane DPP-free
+// shuffle reduction.  HBM: P + residual + out rows (~1.5 KB per point), the coarse rows come from L2.
+__global__ __launch_bounds__(256) void interp_combine_kernel(const float *__restrict__ cw, const int32_t *__restrict__ idx,
+                                                            const float *__restrict__ dist,
+                                                            const float *__restrict__ part, long long rows, int n, int m,
+                                                            EpilogueArgs ep, const float *__restrict__ residual,
+                                                            const float *__restrict__ prefix, float l2_eps,
+                                                            float *__restrict__ out) {
+  constexpr int C = 128;
+  const int sub = threadIdx.x & 31, c4 = sub * 4;
+  float4 pb = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = pb;
+  if (ep.pre_bias) pb = *reinterpret_cast<const float4 *>(ep.pre_bias + c4);
+  if (ep.scale) sc = *reinterpret_cast<const float4 *>(ep.scale + c4);
+  if (ep.shift) sh = *reinterpret_cast<const float4 *>(ep.shift + c4);
+  for (long long row = (long long)blockIdx.x * 8 + (threadIdx.x >> 5); row < rows; row += (long long)gridDim.x * 8) {
+    const long long bi = row / n;
+    const int i1 = idx[row * 3], i2 = idx[row * 3 + 1], i3 = idx[row * 3 + 2];
+    // the inverse-distance weights of core/backbones.py:92-95, same arithmetic as three_interp_fwd_kernel<true>
+    const float r1 = 1.0f / fmaxf(dist[row * 3], 1e-10f), r2 = 1.0f / fmaxf(dist[row * 3 + 1], 1e-10f),
+                r3 = 1.0f / fmaxf(dist[row * 3 + 2], 1e-10f);
+    const float norm = (r1 + r2) + r3;
+    const float w1 = r1 / norm, w2 = r2 / norm, w3 = r3 / norm;
+    const float4 a = *reinterpret_cast<const float4 *>(cw + (bi * m + i1) * C + c4);
+    const float4 bq = *reinterpret_cast<const float4 *>(cw + (bi * m + i2) * C + c4);
+    const float4 cq = *reinterpret_cast<const float4 *>(cw + (bi * m + i3) * C + c4);
+    float4 v;
+    v.x = (a.x * w1 + bq.x * w2) + cq.x * w3; v.y = (a.y * w1 + bq.y * w2) + cq.y * w3;
+    v.z = (a.z * w1 + bq.z * w2) + cq.z * w3; v.w = (a.w * w1 + bq.w * w2) + cq.w * w3;
+    if (part) {
+      const float4 p = *reinterpret_cast<const float4 *>(part + row * C + c4);
+      v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    v.x = dh3d_act((v.x + pb.x) * sc.x + sh.x, ep.act); v.y = dh3d_act((v.y + pb.y) * sc.y + sh.y, ep.act);
+    v.z = dh3d_act((v.z + pb.z) * sc.z + sh.z, ep.act); v.w = dh3d_act((v.w + pb.w) * sc.w + sh.w, ep.act);
+    if (residual) {
+      const float4 q = *reinterpret_cast<const float4 *>(residual + row * C + c4);
+      v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+    }
+    if (prefix) {  // [xyz | l2_normalize(v)] (core/model.py:177-181)
+      float ss = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+      const float inv = rsqrtf(fmaxf(ss, l2_eps));
+      float *o = out + row * (C + 3);
+      if (sub < 3) o[sub] = prefix[row * 3 + sub];
+      o[3 + c4] = v.x * inv; o[4 + c4] = v.y * inv; o[5 + c4] = v.z * inv; o[6 + c4] = v.w * inv;
+    } else {
+      *reinterpret_cast<float4 *>(out + row * C + c4) = v;
+    }
+  }
+}
+
 }  // namespace
+
+DH3D_API int dh3d_interp_combine_fwd(const float *coarse_w, const int32_t *idx, const float *dist, const float *partial,
+                                     int B, int N, int M, int C, const dh3d_epilogue *ep, const float *residual,
+                                     const float *prefix, float l2_eps, float *out, void *stream) {
+  DH3D_REQUIRE(coarse_w && idx && dist && out && B > 0 && N > 0 && M > 0);
+  DH3D_SUPPORTED(C == 128);
+  const long long rows = (long long)B * N;
+  long long g = (rows + 7) / 8;
+  g = g > 16384 ? 16384 : g;
+  hipLaunchKernelGGL(interp_combine_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, coarse_w, idx, dist, partial,
+                     rows, N, M, dh3d_ep(ep), residual, prefix, l2_eps, out);
+  return dh3d_launch_status();
+}
 
 DH3D_API int dh3d_pack_weight(const float *W, int Kd, int Dout, float *packed, void *stream) {
   DH3D_REQUIRE(W && packed && Kd > 0 && Dout > 0);

@@ -246,15 +246,20 @@ class DH3D(nn.Module):
             #  result bit for bit.)
             fuse_sc = points.shape[1] <= 4096 and self.stage2.shortcut_fusable(points.shape[1])
             shortcut = None if fuse_sc else self.local_stage1_shortcut(x1, act=pm.ACT_RELU)
+            # larger clouds: stage 2's concat conv is commuted through its up-sampling -- its lower weight block meets
+            # x2 here, beside the sampling chain; behind the sampled level only a GEMM on the N/8 rows and one
+            # gather / epilogue kernel are left (backbones.Conv2D1x1.forward_commuted)
+            lower = None if fuse_sc else self.stage2.commuted_partial(x2)
             stage1_done = torch.cuda.Event()
             stage1_done.record()
             geo.start_nn3(geo._lv)  # three_nn: waits for the sampled coordinates, overlaps the N/8 convolutions
-            for t in (x2, x1 if fuse_sc else shortcut, geo._lv["nn3_dist"], geo._lv["nn3_idx"]):
-                t.record_stream(main)
+            for t in (x2, x1 if fuse_sc else shortcut, geo._lv["nn3_dist"], geo._lv["nn3_idx"], lower):
+                if t is not None:
+                    t.record_stream(main)
         main.wait_event(stage1_done)  # not the whole side stream: three_nn is joined at the interpolation (geo.finish)
         l2cat = (points, _l2cat_eps) if _l2cat_eps is not None else None
         feat = self.stage2(geo, x2, residual=shortcut, l2cat=l2cat,  # gather, N/8 convs, SE, interpolation, concat conv
-                           shortcut_src=x1 if fuse_sc else None)
+                           shortcut_src=x1 if fuse_sc else None, lower_partial=lower)
         if self._local.featdim < 128:  # core/backbones.py:125-126
             feat = self.final_fc(feat, act=pm.ACT_RELU)
         self._last_geo = geo

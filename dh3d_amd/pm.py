@@ -369,6 +369,24 @@ def upsample_linear_shortcut_x6(points, idx, dist, wstacked_x3, Dout, x2, x3, ep
     return out
 
 
+def interp_combine(coarse_w, idx, dist, partial=None, pre_bias=None, scale=None, shift=None, act=ACT_NONE, residual=None,
+                   l2cat=None):
+    """act(BN(interp3(coarse_w) + partial + pre_bias)) + residual -> [B,N,128]; l2cat = (prefix [B,N,3], eps) returns
+    [prefix | l2_normalize(.)] [B,N,131] instead (the tail of a concat conv commuted through the up-sampling)."""
+    cw = L.require_cuda_f32(coarse_w, "coarse_w", 3)
+    ix = L.require_cuda_i32(idx, "idx", 3)
+    d = L.require_cuda_f32(dist, "dist", 3)
+    B, M, C = cw.shape
+    N = ix.shape[1]
+    pf, eps = (L.require_cuda_f32(l2cat[0], "prefix", 3), float(l2cat[1])) if l2cat is not None else (None, 0.0)
+    out = torch.empty((B, N, C + (3 if pf is not None else 0)), dtype=torch.float32, device=cw.device)
+    ep = _ep(pre_bias, scale, shift, act)
+    L.check(L.lib().dh3d_interp_combine_fwd(L.ptr(cw), L.ptr(ix), L.ptr(d), L.ptr(partial), B, N, M, C, ep,
+                                            L.ptr(residual), L.ptr(pf), eps, L.ptr(out), L.stream_ptr()),
+            "interp_combine")
+    return out
+
+
 def pack_weight_x3(W):
     """W [Kd, Dout] f32 -> three exact bf16 chunk planes in MFMA fragment order (csrc/dense_x6.hip)."""
     W = L.require_cuda_f32(W, "W", 2)

@@ -327,6 +327,15 @@ int dh3d_mlp_head_pm_x6_fwd(const float *h, int R, int C, const void *wpacked_x3
  * idx / dist [B*n,3] from dh3d_three_nn.  8x fewer GEMM flops than running the head on the up-sampled rows. */
 int dh3d_interp_head_fwd(const float *H, int Hd, const int32_t *idx, const float *dist, int B, int n, int m,
                          const dh3d_epilogue *ep, const float *w_fc, float b_fc, float *att, void *stream);
+/* The tail of a concat conv commuted through the up-sampling (C = 128):
+ *   out[n] = act(BN(interp3(coarse_w)[n] + partial[n] + pre_bias)) + residual[n]     (or [prefix | l2_normalize(.)])
+ * coarse_w [B,M,C] = coarse rows already multiplied by the conv's upper weight block, partial [B,N,C] = the lower block
+ * applied to the full-resolution input (may be NULL), idx/dist [B,N,3] from three_nn (inverse-distance weights as
+ * core/backbones.py:92-95), residual / prefix ([B,N,3]) may be NULL. */
+int dh3d_interp_combine_fwd(const float *coarse_w, const int32_t *idx, const float *dist, const float *partial, int B,
+                            int N, int M, int C, const dh3d_epilogue *ep, const float *residual, const float *prefix,
+                            float l2_eps, float *out, void *stream);
+
 /* a layer wider than 256 as `slices` column slices of 256 in one launch: out [slices][R][256] = x1 @ W[:, 256 j ..],
  * wpacked_x3 = the dh3d_pack_weight_x3 images of the slices back to back (the H operand of dh3d_interp_head_fwd) */
 int dh3d_linear_slices_pm_x6_fwd(const float *x1, int C1, const void *wpacked_x3, int R, int slices, float *out,
