@@ -7,6 +7,8 @@ Fixtures are DATA (inputs + expected outputs):
                         with np.random.seed(42) (user_ops/misc.py:27,31-68; the recipe needs only
                         numpy + scipy), the scipy kNN answer its test compares against
                         (user_ops/test_knn_bruteforce.py:32-40), and the oracle's outputs frozen.
+  twins_nn_lattice.npz  three_nn of lattice queries away from the origin through the reference twin (pre-translated
+                        candidates: exact arithmetic)
   twins.npz             outputs of the REFERENCE's stand-alone twins (oracle/_ref, compiled from
                         tf_ops/interpolation/interpolate.cpp and tf_ops/grouping/test/query_ball_point.cpp).
   flex_pool_kat.npz     the hand-made 4-point known-answer test (user_ops/test_flex_pooling.py:76-98).
@@ -71,6 +73,21 @@ def main():
              interp_grad=O.ref_three_interpolate_grad(pts.shape, idx3, w3, go),
              group=O.ref_group_point(pts, gidx), group_grad=O.ref_group_point_grad(pts.shape, gidx, ggo),
              nn_origin_dist=d0, nn_origin_idx=i0)
+
+    # three_nn with the query away from the origin, still pinned by the reference twin: the twin measures |xyz2|^2 (it
+    # drops xyz1, interpolate.cpp:34), so it is handed xyz2 - q -- on an integer lattice that subtraction, and every
+    # product / sum of the distance, is exact in float32, i.e. twin(xyz2 - q) IS tf_interpolate.cpp's three_nn(q, xyz2)
+    # bit for bit, ties (many on a lattice) included.
+    lrng = np.random.default_rng(1111)
+    lat1 = lrng.integers(-8, 9, (2, 48, 3)).astype(np.float32)
+    lat2 = lrng.integers(-8, 9, (2, 300, 3)).astype(np.float32)
+    nd = np.empty((2, 48, 3), np.float32)
+    ni = np.empty((2, 48, 3), np.int32)
+    for b in range(2):
+        for j in range(48):
+            d1, i1 = O.ref_three_nn_origin((lat2[b:b + 1] - lat1[b, j]).astype(np.float32), 1)
+            nd[b, j], ni[b, j] = d1[0, 0], i1[0, 0]
+    np.savez(os.path.join(HERE, "twins_nn_lattice.npz"), xyz1=lat1, xyz2=lat2, dist=nd, idx=ni)
 
     x = np.array([[[1], [2], [5], [3]]], np.float32).transpose(0, 2, 1)
     n = np.array([[[0, 1, 2, 3], [1, 2, 3, 0], [2, 3, 0, 1], [3, 0, 1, 2]]]).transpose(0, 2, 1).astype(np.int32)

@@ -378,3 +378,15 @@ def test_fps_sorted_above_the_lds_table_limit(dev, oracle, B, N, m):
         assert np.array_equal(idx.cpu().numpy(), oracle.farthest_point_sample(m, xyz))
     with pytest.raises(ValueError):
         pm.fps_sorted(srt, gbox, m)          # no cloud given: the table does not fit
+
+
+def test_three_nn_vs_reference_twin_lattice_golden(dev):
+    """Both device kernels against outputs of the reference's own twin (queries away from the origin, exact ties)."""
+    from dh3d_amd import ops, pm
+    c = load("twins_nn_lattice.npz")
+    t1, t2 = T(c["xyz1"], dev), T(c["xyz2"], dev)
+    d, i = ops.three_nn(t1, t2)
+    assert np.array_equal(d.cpu().numpy(), c["dist"]) and np.array_equal(i.cpu().numpy(), c["idx"])
+    s1, g1 = pm.spatial_sort(t1); s2, g2 = pm.spatial_sort(t2)
+    d2, i2 = pm.three_nn_sorted(s1, g1, s2, g2)
+    assert np.array_equal(d2.cpu().numpy(), c["dist"]) and np.array_equal(i2.cpu().numpy(), c["idx"])

@@ -172,6 +172,15 @@ def test_pointnet2_ops_vs_reference_twin_outputs(oracle):
     assert np.array_equal(d, c["nn_origin_dist"]) and np.array_equal(i, c["nn_origin_idx"])
 
 
+def test_three_nn_vs_reference_twin_away_from_the_origin(oracle):
+    """tests/golden/twins_nn_lattice.npz: the reference twin on pre-translated lattice candidates (exact arithmetic) ==
+    tf_interpolate.cpp's three_nn for queries anywhere, ties (dozens on a 17^3 lattice) included."""
+    c = load("twins_nn_lattice.npz")
+    d, i = oracle.three_nn(c["xyz1"], c["xyz2"])
+    assert np.array_equal(d, c["dist"]) and np.array_equal(i, c["idx"])
+    assert int((c["dist"][:, :, 0] == c["dist"][:, :, 1]).sum()) > 10   # the fixture does exercise the tie rule
+
+
 def test_live_reference_twins_if_built(oracle):
     if not oracle.have_ref():
         pytest.skip("oracle/_ref not built (no /root/reference)")
