@@ -108,6 +108,8 @@ _SIGNATURES = {
     "dh3d_linear_slices_pm_x6_fwd": [c_fp, c_int, c_fp, c_int, c_int, c_fp, c_fp],
     "dh3d_interp_head_fwd": [c_fp, c_int, c_fp, c_fp, c_int, c_int, c_int, ctypes.POINTER(Epilogue), c_fp, c_float,
                              c_fp, c_fp],
+    "dh3d_interp_head_sorted_fwd": [c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, ctypes.POINTER(Epilogue), c_fp,
+                                    c_float, c_fp, c_fp],
     "dh3d_linear_pm_x6_fwd": [c_fp, c_int, c_fp, c_int, c_fp, c_int, c_int, ctypes.POINTER(Epilogue), c_fp, c_fp, c_fp],
     "dh3d_se_res_pm_packed_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp],
     "dh3d_flex_pool_pm_fwd": [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp],

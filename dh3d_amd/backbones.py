@@ -527,7 +527,7 @@ class PointMLPHead(nn.Module):
         p = self._prep or self.prepare()
         return "wslices" in p and coarse.shape[-1] % 32 == 0 and idx.shape[1] >= 4096
 
-    def forward_interpolated(self, coarse, idx, dist):
+    def forward_interpolated(self, coarse, idx, dist, order=None):
         """forward(three_interpolate_idw(coarse, idx, dist)) without running the wide conv on the up-sampled rows: the
         conv is linear and the interpolation weights sum to one, so it is applied to the coarse rows and its output
         interpolated (csrc/dense_x6.hip interp_head_kernel)."""
@@ -535,7 +535,7 @@ class PointMLPHead(nn.Module):
         last = getattr(self, "detec_conv0")
         lp = last._prep
         return pm.interp_head(coarse, idx, dist, p["wslices"], last.cout, p["w_fc"], p["b_fc"], pre_bias=lp["b"],
-                              scale=lp["scale"], shift=lp["shift"], act=pm.ACT_RELU)
+                              scale=lp["scale"], shift=lp["shift"], act=pm.ACT_RELU, order=order)
 
     def forward(self, x):
         p = self._prep or self.prepare()

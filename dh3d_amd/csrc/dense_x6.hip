@@ -14,6 +14,7 @@
 // and the B operand, and a dot product is invariant under a common permutation of k, so A and B fragments
 // are both filled with k = 16*kb + 8*(lane>>5) + j  (j = 0..7) and no hardware slot table is needed.
 #include "bf16x3.h"
+#include "wave_ops.h"
 
 namespace {
 
@@ -687,6 +688,178 @@ DH3D_API int dh3d_linear_slices_pm_x6_fwd(const float *x1, int C1, const void *w
 // att [B*n] = sigmoid(w_fc . act(BN(interp(H) + pre_bias)) + b_fc), H = the hidden layer WITHOUT bias computed on the
 // coarse level: [Hd/256][B*m][256] (one dh3d_linear_pm_x6_fwd per 256-column slice of the weight), idx / dist [B*n, 3]
 // from dh3d_three_nn (squared distances), Hd in {256, 512, 768, 1024}.
+// ---------------------------------------------------------------------------------------------------------------
+// The same head with the fine points walked in MORTON order and the coarse rows staged in LDS (round 2).
+// interp_head_kernel moves 12 KB per fine point through the L2 (1.6 GB per cfg-3 step, 11.6 TB/s: L2-bound).  128
+// consecutive points of the Morton order are a compact region whose 384 neighbour references hit only ~35-45 DISTINCT
+// coarse rows: a workgroup finds them with a bitmap (one bit per coarse row of the cloud, prefix popcounts = slots),
+// and for each 256-channel slice stages those rows ONCE (1 KB each, <= 48 slots = 48 KB, so three workgroups share a CU)
+// and lets its four waves read them from LDS -- ~10x less L2 traffic.  The 64 lane partials of a point and slice are
+// summed right away (two points per butterfly) into a per-point logit in LDS: a plain loop over the points, small code
+// and few registers (keeping 32 per-lane partials in registers across the slices, fully unrolled, cost 296-512 VGPRs
+// and, with the generic activation inlined 256 times, twice the instruction cache).  (The first attempt,
+// DESIGN.md dead end (j), staged whole 4 KB rows: 32 slots did not hold a block's rows and one workgroup filled a CU.)
+// Rows beyond the slot capacity (never seen on uniform clouds) are read from global memory like before.
+constexpr int kIHP = 128;    // fine points per workgroup
+constexpr int kIHCap = 48;   // staged coarse rows per slice (48 KB: three workgroups per CU; a block touches ~35-45)
+constexpr int kIHPW = kIHP / 4;  // points per wave
+
+__global__ __launch_bounds__(256) void interp_head_lds_kernel(const float *__restrict__ H, int NS, long long Rc,
+                                                             const int32_t *__restrict__ idx,
+                                                             const float *__restrict__ dist,
+                                                             const float4 *__restrict__ order, int B, int n, int m,
+                                                             int nblk, EpilogueArgs ep, const float *__restrict__ w_fc,
+                                                             float b_fc, float *__restrict__ att) {
+  extern __shared__ __attribute__((aligned(16))) float s_ih[];
+  float *s_rows = s_ih;                                   // [kIHCap][256]   (reused as the partial-sum area at the end)
+  int *s_slot = reinterpret_cast<int *>(s_rows + kIHCap * 256);   // [kIHP][4] slot (or -1 - coarse row)
+  float *s_w = reinterpret_cast<float *>(s_slot + kIHP * 4);      // [kIHP][4] interpolation weights
+  int *s_orig = reinterpret_cast<int *>(s_w + kIHP * 4);          // [kIHP] original index of the fine point (-1: none)
+  unsigned *s_bits = reinterpret_cast<unsigned *>(s_orig + kIHP); // [32] bitmap over the cloud's coarse rows
+  int *s_pre = reinterpret_cast<int *>(s_bits + 32);              // [33] popcount prefix
+  int *s_row = s_pre + 33;                                        // [kIHCap] slot -> coarse row
+  float *s_z = reinterpret_cast<float *>(s_row + kIHCap);         // [kIHP] logits
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // XCD x takes clouds x, x + 8, ...: a cloud's H (2 MB) stays in one L2
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int bi = xcd + 8 * (seq / nblk), blk = seq % nblk;
+  if (bi >= B) return;
+  if (tid < 32) s_bits[tid] = 0u;
+  __syncthreads();
+  // ---- the block's points, their neighbours and weights; mark the coarse rows they touch
+  int my_i[3] = {0, 0, 0};
+  if (tid < kIHP) {
+    const int q = blk * kIHP + tid;
+    int orig = -1;
+    if (q < n) {
+      orig = order ? __float_as_int(order[(size_t)bi * n + q].w) : q;
+      const long long r = (long long)bi * n + orig;
+      float w1, w2, w3;
+      idw_weights(dist[r * 3], dist[r * 3 + 1], dist[r * 3 + 2], w1, w2, w3);
+      *reinterpret_cast<float4 *>(s_w + tid * 4) = make_float4(w1, w2, w3, 0.f);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        my_i[t] = idx[r * 3 + t];
+        atomicOr(&s_bits[my_i[t] >> 5], 1u << (my_i[t] & 31));
+      }
+    }
+    s_orig[tid] = orig;
+    if (orig < 0) {  // padding point of the last block: harmless reads of slot 0 with zero weights
+      *reinterpret_cast<float4 *>(s_w + tid * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<int4 *>(s_slot + tid * 4) = make_int4(0, 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {  // exclusive prefix of the 32 word popcounts (one wave, shuffle scan)
+    int c = tid < 32 ? __popc(s_bits[tid]) : 0, v = c;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+      const int o = __shfl_up(v, off, 64);
+      if ((tid & 63) >= off) v += o;
+    }
+    if (tid < 32) s_pre[tid] = v - c;
+    if (tid == 31) s_pre[32] = v;
+  }
+  __syncthreads();
+  if (tid < kIHP && s_orig[tid] >= 0) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int j = my_i[t];
+      const int slot = s_pre[j >> 5] + __popc(s_bits[j >> 5] & ((1u << (j & 31)) - 1u));
+      s_slot[tid * 4 + t] = slot < kIHCap ? slot : -1 - j;
+    }
+  }
+  for (int j = tid; j < m; j += 256) {  // slot -> coarse row
+    if ((s_bits[j >> 5] >> (j & 31)) & 1u) {
+      const int slot = s_pre[j >> 5] + __popc(s_bits[j >> 5] & ((1u << (j & 31)) - 1u));
+      if (slot < kIHCap) s_row[slot] = j;
+    }
+  }
+  __syncthreads();
+  const int nd = min(s_pre[32], kIHCap);
+  const float lo = ep.act == DH3D_ACT_RELU ? 0.f : -__builtin_inff();  // ReLU as a clamp, or no activation
+  if (tid < kIHP) s_z[tid] = 0.f;
+  for (int sl = 0; sl < NS; ++sl) {
+    const float *Hs = H + ((size_t)sl * Rc + (size_t)bi * m) * 256;
+    // ---- stage the distinct rows of this slice: wave w takes slots w, w + 4, ...; every load of the wave is in flight
+    // before the first LDS store (a load-store loop would pay the L2 latency once per row).  (Requesting the NEXT
+    // slice's rows before computing the current one -- a register double buffer -- was slower, 139 vs 100 us: the
+    // compute phase's overflow path shares the in-order load counter with them.)
+    {
+      float4 rg[kIHCap / 4];
+#pragma unroll
+      for (int u = 0; u < kIHCap / 4; ++u) {
+        const int r = wave + 4 * u;
+        rg[u] = *reinterpret_cast<const float4 *>(Hs + (size_t)s_row[r < nd ? r : 0] * 256 + lane * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < kIHCap / 4; ++u) {
+        const int r = wave + 4 * u;
+        if (r < nd) *reinterpret_cast<float4 *>(s_rows + (size_t)r * 256 + lane * 4) = rg[u];
+      }
+    }
+    const int c = sl * 256 + lane * 4;
+    float4 pb = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = pb;
+    if (ep.pre_bias) pb = *reinterpret_cast<const float4 *>(ep.pre_bias + c);
+    if (ep.scale) sc = *reinterpret_cast<const float4 *>(ep.scale + c);
+    if (ep.shift) sh = *reinterpret_cast<const float4 *>(ep.shift + c);
+    const float4 wf = *reinterpret_cast<const float4 *>(w_fc + c);
+    __syncthreads();
+    // ---- the wave's 32 points, two at a time (a plain loop: small code, bounded registers).  Slots and weights are
+    // wave-uniform: through the scalar unit, so a row address is scalar base + lane offset and the rare overflow test
+    // (a row beyond the slot capacity: read from global memory) is a scalar branch.
+    for (int p = 0; p < kIHPW; p += 4) {
+      float part[4];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const int pt = wave * kIHPW + p + h;
+        const int4 si = *reinterpret_cast<const int4 *>(s_slot + pt * 4);
+        const float4 sw = *reinterpret_cast<const float4 *>(s_w + pt * 4);
+        const int s0 = __builtin_amdgcn_readfirstlane(si.x), s1 = __builtin_amdgcn_readfirstlane(si.y),
+                  s2 = __builtin_amdgcn_readfirstlane(si.z);
+        const float4 r0 = s0 >= 0 ? *reinterpret_cast<const float4 *>(s_rows + (size_t)s0 * 256 + lane * 4)
+                                  : *reinterpret_cast<const float4 *>(Hs + (size_t)(-1 - s0) * 256 + lane * 4);
+        const float4 r1 = s1 >= 0 ? *reinterpret_cast<const float4 *>(s_rows + (size_t)s1 * 256 + lane * 4)
+                                  : *reinterpret_cast<const float4 *>(Hs + (size_t)(-1 - s1) * 256 + lane * 4);
+        const float4 r2 = s2 >= 0 ? *reinterpret_cast<const float4 *>(s_rows + (size_t)s2 * 256 + lane * 4)
+                                  : *reinterpret_cast<const float4 *>(Hs + (size_t)(-1 - s2) * 256 + lane * 4);
+        const float4 v = idw_mix(r0, r1, r2, sw.x, sw.y, sw.z);  // padding points: slot 0, weight 0 -> never stored
+        float a = fmaxf((v.x + pb.x) * sc.x + sh.x, lo) * wf.x;
+        a = fmaf(fmaxf((v.y + pb.y) * sc.y + sh.y, lo), wf.y, a);
+        a = fmaf(fmaxf((v.z + pb.z) * sc.z + sh.z, lo), wf.z, a);
+        a = fmaf(fmaxf((v.w + pb.w) * sc.w + sh.w, lo), wf.w, a);
+        part[h] = a;
+      }
+      // row sums of two points per reduction: one half-swap + five DPP adds, no LDS crossbar (wave_ops.h)
+      const float t01 = pair_wave_sum_f32(part[0], part[1]), t23 = pair_wave_sum_f32(part[2], part[3]);
+      if ((lane & 31) == 16) {
+        s_z[wave * kIHPW + p + (lane >> 5)] += t01;
+        s_z[wave * kIHPW + p + 2 + (lane >> 5)] += t23;
+      }
+    }
+    __syncthreads();  // the rows are overwritten by the next slice
+  }
+  if (tid < kIHP && s_orig[tid] >= 0) att[(size_t)bi * n + s_orig[tid]] = 1.f / (1.f + expf(-(s_z[tid] + b_fc)));
+}
+
+// `order` (may be NULL): the dh3d_spatial_sort records [B,n,4] of the FINE cloud; with it the points are walked in Morton
+// order and the coarse rows are staged in LDS (m <= 1024); results equal dh3d_interp_head_fwd up to the summation order
+// of the 1024-term row dot.
+DH3D_API int dh3d_interp_head_sorted_fwd(const float *H, int Hd, const int32_t *idx, const float *dist,
+                                         const float *order, int B, int n, int m, const dh3d_epilogue *ep,
+                                         const float *w_fc, float b_fc, float *att, void *stream) {
+  DH3D_REQUIRE(H && idx && dist && w_fc && att && B > 0 && n > 0 && m > 0 && Hd > 0);
+  DH3D_SUPPORTED(Hd % 256 == 0 && Hd <= 1024 && m <= 1024 && (!ep || ep->act != DH3D_ACT_SIGMOID));
+  const int nblk = dh3d_cdiv(n, kIHP);
+  const int per_xcd = dh3d_cdiv(B, 8) * nblk;
+  const size_t lds = sizeof(float) * ((size_t)kIHCap * 256 + kIHP * 4 * 2 + kIHP + 32 + 33 + kIHCap + kIHP);
+  DH3D_ALLOW_BIG_LDS(interp_head_lds_kernel);
+  hipLaunchKernelGGL(interp_head_lds_kernel, dim3(8 * per_xcd), dim3(256), lds, (hipStream_t)stream, H, Hd / 256,
+                     (long long)B * m, idx, dist, reinterpret_cast<const float4 *>(order), B, n, m, nblk, dh3d_ep(ep),
+                     w_fc, b_fc, att);
+  return dh3d_launch_status();
+}
+
 DH3D_API int dh3d_interp_head_fwd(const float *H, int Hd, const int32_t *idx, const float *dist, int B, int n, int m,
                                   const dh3d_epilogue *ep, const float *w_fc, float b_fc, float *att, void *stream) {
   DH3D_REQUIRE(H && idx && dist && w_fc && att && B > 0 && n > 0 && m > 0 && Hd > 0);

@@ -51,3 +51,19 @@ __device__ __forceinline__ float row16_min_f32(float v) {
   asm volatile(DH3D_DPP_ROW16("v_min_f32_dpp") "s_nop 1\n\t" : "+v"(v));
   return v;
 }
+
+// Sums (not idempotent, but every step pairs DISJOINT partial groups, so nothing is counted twice):
+// after the four row steps every lane of a 16-lane row holds the row's sum; row_bcast:15 adds row 0's (2's) sum into
+// row 1 (3).  Result: lanes 16..31 hold the sum of lanes 0..31, lanes 48..63 the sum of lanes 32..63.
+__device__ __forceinline__ float half32_sum_f32(float v) {
+  asm volatile(DH3D_DPP_ROW16("v_add_f32_dpp")
+               "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+               : "+v"(v));
+  return v;
+}
+// Two per-lane partial sums a, b (one value per lane each) -> lanes 16..31: sum of a over the wave, lanes 48..63: sum
+// of b over the wave.  v_permlane32_swap (gfx950) exchanges a's upper half with b's lower half in one instruction.
+__device__ __forceinline__ float pair_wave_sum_f32(float a, float b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return half32_sum_f32(__uint_as_float(r[0]) + __uint_as_float(r[1]));
+}

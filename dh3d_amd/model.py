@@ -276,7 +276,8 @@ class DH3D(nn.Module):
         coarse, lv = getattr(self.global_before_assemble, "_last_coarse", (None, None))
         if coarse is not None and "nn3_idx" in lv and self.globalatt.interpolated_supported(coarse, lv["nn3_idx"]):
             # the attention MLP's 256 -> 1024 conv commutes with the up-sampling: it runs on the N/8 level
-            att = self.globalatt.forward_interpolated(coarse, lv["nn3_idx"], lv["nn3_dist"])
+            order = lv["_ordered"][0] if "_ordered" in lv else None  # Morton records of the full cloud
+            att = self.globalatt.forward_interpolated(coarse, lv["nn3_idx"], lv["nn3_dist"], order=order)
         else:
             att = self.globalatt(forglobal)
         return self._netvlad(forglobal, att, l2_eps=l2_eps)

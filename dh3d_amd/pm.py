@@ -408,11 +408,13 @@ def mlp_head_x6(h, wpacked_x3, H, w_fc, b_fc, pre_bias=None, scale=None, shift=N
     return out
 
 
-def interp_head(coarse, idx, dist, wslices_x3, Hd, w_fc, b_fc, pre_bias=None, scale=None, shift=None, act=ACT_RELU):
+def interp_head(coarse, idx, dist, wslices_x3, Hd, w_fc, b_fc, pre_bias=None, scale=None, shift=None, act=ACT_RELU,
+                order=None):
     """mlp_head_x6(three_interpolate_idw(coarse, idx, dist), ...) with the wide conv commuted through the interpolation:
     the [C, Hd] GEMM runs on the coarse rows (its 256-column slices in one launch, `wslices_x3` = their packed images
     back to back), a gather kernel
-    interpolates the Hd-wide rows and finishes bias + BN + act + w_fc + sigmoid.  coarse [B,m,C], idx/dist [B,n,3]."""
+    interpolates the Hd-wide rows and finishes bias + BN + act + w_fc + sigmoid.  coarse [B,m,C], idx/dist [B,n,3].
+    order: spatial_sort records [B,n,4] of the fine cloud -> the LDS-staged kernel (m <= 1024)."""
     x = L.require_cuda_f32(coarse, "coarse", 3)
     ix = L.require_cuda_i32(idx, "idx", 3)
     d = L.require_cuda_f32(dist, "dist", 3)
@@ -424,6 +426,12 @@ def interp_head(coarse, idx, dist, wslices_x3, Hd, w_fc, b_fc, pre_bias=None, sc
             "linear_slices_pm_x6")
     out = torch.empty((B, n, 1), dtype=torch.float32, device=x.device)
     ep = _ep(pre_bias, scale, shift, act)
+    if order is not None and m <= 1024:
+        # fine points in Morton order (`order` = spatial_sort records of the fine cloud), coarse rows staged in LDS
+        L.check(L.lib().dh3d_interp_head_sorted_fwd(L.ptr(H), Hd, L.ptr(ix), L.ptr(d), L.ptr(order), B, n, m, ep,
+                                                    L.ptr(w_fc), float(b_fc), L.ptr(out), L.stream_ptr()),
+                "interp_head_sorted")
+        return out
     L.check(L.lib().dh3d_interp_head_fwd(L.ptr(H), Hd, L.ptr(ix), L.ptr(d), B, n, m, ep, L.ptr(w_fc), float(b_fc),
                                          L.ptr(out), L.stream_ptr()), "interp_head")
     return out

@@ -327,6 +327,13 @@ int dh3d_mlp_head_pm_x6_fwd(const float *h, int R, int C, const void *wpacked_x3
  * idx / dist [B*n,3] from dh3d_three_nn.  8x fewer GEMM flops than running the head on the up-sampled rows. */
 int dh3d_interp_head_fwd(const float *H, int Hd, const int32_t *idx, const float *dist, int B, int n, int m,
                          const dh3d_epilogue *ep, const float *w_fc, float b_fc, float *att, void *stream);
+/* Same head with the fine points walked in the Morton order of `order` (the dh3d_spatial_sort records [B,n,4] of the
+ * fine cloud; NULL = index order) and the distinct coarse rows of 128 consecutive points staged in LDS, one 256-channel
+ * slice at a time: ~10x less L2 traffic.  m <= 1024.  Equal to dh3d_interp_head_fwd up to the summation order of the
+ * row dot. */
+int dh3d_interp_head_sorted_fwd(const float *H, int Hd, const int32_t *idx, const float *dist, const float *order, int B,
+                                int n, int m, const dh3d_epilogue *ep, const float *w_fc, float b_fc, float *att,
+                                void *stream);
 /* The tail of a concat conv commuted through the up-sampling (C = 128):
  *   out[n] = act(BN(interp3(coarse_w)[n] + partial[n] + pre_bias)) + residual[n]     (or [prefix | l2_normalize(.)])
  * coarse_w [B,M,C] = coarse rows already multiplied by the conv's upper weight block, partial [B,N,C] = the lower block

@@ -134,3 +134,37 @@ def test_import_round_trip(tmp_path):
         load_tf_checkpoint(DH3D(cfg), prefix)
     missing, _ = load_tf_checkpoint(DH3D(cfg), prefix, strict=False)
     assert sorted(tf_variable_name(k) for k in missing) == sorted(n for n in del_keys if not n.endswith("/Adam"))
+
+
+@pytest.mark.gpu
+def test_checkpoint_import_on_the_device_reproduces_the_descriptors(tmp_path):
+    """The GPU leg of the import path (what localdesc_extract.py:120-127 / globaldesc_extract.py:85-91 do with
+    SaverRestore): a TensorFlow-format bundle -> load_tf_checkpoint into a model that already lives on the GPU and has
+    already run (stale packed weights must be rebuilt) -> same descriptors as the model the bundle was written from,
+    and both equal to the oracle fed the bundle's tensors by their TensorFlow names."""
+    from dh3d_amd import ConfigFactory
+    from dh3d_amd.checkpoint import load_tf_checkpoint, read_checkpoint
+    from dh3d_amd.model import DH3D, tf_variable_name
+    from oracle import model_np
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    dev = torch.device("cuda:0")
+    cfg = ConfigFactory("global_config").getconfig()
+    src = DH3D(cfg).init_synthetic(12).to(dev).eval()
+    pts = torch.rand(2, 1024, 3, generator=torch.Generator().manual_seed(3)).to(dev)
+    with torch.no_grad():
+        want = {k: v.clone() for k, v in src(pts).items() if k in ("xyz_feat", "globaldesc")}
+    prefix = str(tmp_path / "model-7")
+    write_bundle(prefix, {tf_variable_name(k): v.cpu().numpy() for k, v in src.state_dict().items()})
+    dst = DH3D(cfg).init_synthetic(99).to(dev).eval()
+    with torch.no_grad():
+        before = dst(pts)["globaldesc"].clone()          # runs once with other weights: packed copies now exist
+        missing, unused = load_tf_checkpoint(dst, prefix)
+        got = dst(pts)
+    assert missing == [] and unused == []
+    assert not torch.allclose(before, want["globaldesc"])
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    exp = model_np.forward(pts.cpu().numpy(), read_checkpoint(prefix), extract_global=True)
+    assert np.abs(got["globaldesc"].cpu().numpy() - exp["globaldesc"]).max() < 1e-4
+    assert np.abs(got["xyz_feat"].cpu().numpy() - exp["xyz_feat"]).max() < 1e-4

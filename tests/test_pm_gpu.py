@@ -375,3 +375,33 @@ def test_interp_head_equals_head_on_upsampled_rows(dev, B, n):
     upd = (torch.gather(coarse.double(), 1, i3.long().reshape(B, -1, 1).expand(-1, -1, C)).reshape(B, n, 3, C) * w[..., None]).sum(2)
     z = torch.relu((upd @ W.double() + b.double()) * sc.double() + sh.double()) @ wfc.double() + 0.2
     assert (got.double().squeeze(-1) - torch.sigmoid(z)).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("B,n,clustered", [(2, 4096, False), (3, 5000, False), (9, 4096, False), (1, 8192, False), (2, 4100, True)])
+def test_interp_head_lds_staged_equals_gather_kernel(dev, B, n, clustered):
+    """interp_head with the fine points walked in Morton order and the distinct coarse rows staged in LDS (per
+    256-channel slice) == the plain gather kernel: same per-element arithmetic, only the 1024-term row dot is summed in
+    another order.  `clustered`: a cloud squeezed into a thin slab, where a block of 128 points can touch more distinct
+    coarse rows than the 64 LDS slots hold (the overflow path reads them from global memory)."""
+    from dh3d_amd import pm, ops
+    g = torch.Generator().manual_seed(n + B)
+    m, C, Hd = n // 8, 256, 1024
+    fine = torch.rand(B, n, 3, generator=g)
+    if clustered:
+        fine[:, :, 2] *= 1e-3
+        fine[:, :, 1] *= 0.05
+    fine = fine.to(dev)
+    samp = ops.farthest_point_sample(m, fine)
+    coarse_xyz = torch.gather(fine, 1, samp.long()[:, :, None].expand(-1, -1, 3)).contiguous()
+    d3, i3 = ops.three_nn(fine, coarse_xyz)
+    coarse = torch.randn(B, m, C, generator=g).to(dev)
+    W = (torch.randn(C, Hd, generator=g) / C ** 0.5).to(dev)
+    wfc = (torch.randn(Hd, generator=g) / Hd ** 0.5).to(dev)
+    b = torch.randn(Hd, generator=g).to(dev); sc = (0.5 + torch.rand(Hd, generator=g)).to(dev); sh = torch.randn(Hd, generator=g).to(dev)
+    slices = torch.cat([pm.pack_weight_x3(W[:, j:j + 256].contiguous()) for j in range(0, Hd, 256)])
+    kw = dict(pre_bias=b, scale=sc, shift=sh, act=pm.ACT_RELU)
+    ref = pm.interp_head(coarse, i3, d3, slices, Hd, wfc, 0.2, **kw)
+    srt, _ = pm.spatial_sort(fine)
+    got = pm.interp_head(coarse, i3, d3, slices, Hd, wfc, 0.2, order=srt, **kw)
+    assert got.shape == ref.shape == (B, n, 1)
+    assert (got - ref).abs().max().item() < 1e-6, (got - ref).abs().max().item()
