@@ -89,6 +89,8 @@ _SIGNATURES = {
     "dh3d_fps_sorted_cloud": [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp],
     "dh3d_pack_weight": [c_fp, c_int, c_int, c_fp, c_fp],
     "dh3d_pack_flex_weight": [c_fp, c_fp, c_int, c_int, c_fp, c_fp],
+    "dh3d_flex_conv_pm_gather_fwd": [c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int,
+                                     ctypes.POINTER(Epilogue), c_fp, c_fp],
     "dh3d_flex_conv_pm_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int,
                               ctypes.POINTER(Epilogue), c_fp, c_fp],
     "dh3d_pack_flex_weight_x3": [c_fp, c_fp, c_int, c_int, c_fp, c_fp],
@@ -130,6 +132,9 @@ _SIGNATURES = {
     "dh3d_netvlad_aggregate_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp,
                                    c_size_t, c_fp, c_fp],
     "dh3d_netvlad_head_workspace_bytes": [c_int, c_int, c_int],
+    "dh3d_netvlad_fused_workspace_bytes": [c_int, c_int, c_int, c_int, c_int],
+    "dh3d_netvlad_fused_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int,
+                               c_int, c_int, c_float, c_fp, c_size_t, c_fp, c_fp],
     "dh3d_netvlad_head_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_float, c_fp,
                               c_size_t, c_fp, c_fp],
 }
@@ -138,6 +143,7 @@ _RESTYPES = {
     "dh3d_status_string": ctypes.c_char_p,
     "dh3d_netvlad_workspace_bytes": c_size_t,
     "dh3d_netvlad_head_workspace_bytes": c_size_t,
+    "dh3d_netvlad_fused_workspace_bytes": c_size_t,
     "dh3d_flex_conv_fwd_workspace_bytes": c_size_t,
     "dh3d_flex_conv_bwd_workspace_bytes": c_size_t,
     "dh3d_flex_pool_fwd_workspace_bytes": c_size_t,

@@ -399,18 +399,23 @@ class FlexConvDilate(nn.Module):
         if self.dilate > 1:
             lv = geo.level(self.dilate, self.knn, finish=False)  # three_nn is joined only where it is consumed
             xyz_s, nbr_s = lv["xyz_s"], lv["nbr_s"]
-            x = gather_rows(feat, lv["idx"])
+            # group_point (core/tf_utils.py:92-95) as its own tiny kernel: fusing it into the first flex_conv's neighbour
+            # gather (pm.flex_conv remap=, bit-identical) was measured and is NOT used -- the 8-fold re-read of every
+            # sampled row then goes to the scattered rows of the full map instead of a compact, cache-resident copy
+            # (64->128 at 8x1024: 15.6 + 10.8 us -> 29.5 us)
+            x, remap = gather_rows(feat, lv["idx"]), None
         else:
-            xyz_s, nbr_s, x = geo.xyz, (nbr if nbr is not None else geo.nbr), feat
+            xyz_s, nbr_s, x, remap = geo.xyz, (nbr if nbr is not None else geo.nbr), feat, None
         for p in prep:
-            x6 = p["wp3"] is not None and nbr_s.shape[2] == 8
+            x6 = p["wp3"] is not None and nbr_s.shape[2] == 8 and remap is None
             if x6:
                 x = pm.flex_conv_x6(x, xyz_s, nbr_s, p["wp3"], p["dout"], pre_bias=p["fb"], scale=p["scale"],
                                     shift=p["shift"], act=pm.ACT_RELU,
                                     reserve_cus_per_xcd=getattr(geo, "busy_cus_per_xcd", 0))
             else:
                 x = pm.flex_conv(x, xyz_s, nbr_s, p["wp"], p["dout"], pre_bias=p["fb"], scale=p["scale"],
-                                 shift=p["shift"], act=pm.ACT_RELU)
+                                 shift=p["shift"], act=pm.ACT_RELU, remap=remap)
+            remap = None
         if self.add_se == "max_pool":
             x = self.se(x, pm.flex_pool(x, nbr_s))
         elif self.add_se == "avg_pool":  # flex_avg (theta 0, bias eye: the neighbour sum) * 1/knn, backbones.py:80-83
@@ -602,5 +607,5 @@ class NetVLAD(nn.Module):
         """features [B,N,256], att [B,N,1] -> [B,256] ('final_global'); l2_eps > 0 also applies
         tf.nn.l2_normalize(dim=-1, epsilon=l2_eps) (core/model.py:205)."""
         p = self._prep or self.prepare()
-        vlad = pm.netvlad_aggregate(features, att, p["wc"], p["cs"], p["ch"], p["W2"])
-        return pm.netvlad_head(vlad, p["Wh"], p["s1"], p["h1"], p["Wg"], p["s2"], p["h2"], l2_eps=l2_eps)
+        return pm.netvlad_fused(features, att, p["wc"], p["cs"], p["ch"], p["W2"], p["Wh"], p["s1"], p["h1"], p["Wg"],
+                                p["s2"], p["h2"], l2_eps=l2_eps)

@@ -46,7 +46,10 @@ template <int DIN, int DOUT, int KT, int TMSEL = 0>
 __global__ __launch_bounds__(256) void flex_conv_pm_kernel(
     const float *__restrict__ feat, const float *__restrict__ xyz, const int32_t *__restrict__ nbr,
     const float *__restrict__ wpacked, long long R, int N, int K, EpilogueArgs ep,
-    float *__restrict__ out) {
+    float *__restrict__ out, const int32_t *__restrict__ remap, int Nsrc) {
+  // remap (may be NULL): the features are rows of a LARGER per-cloud map [B, Nsrc, DIN] and point j of this level is
+  // row remap[b*N + j] of it -- group_point (the sampled level's feature gather, core/tf_utils.py:92-95) fused into the
+  // neighbour gather: one more dependent index load instead of a kernel + its dependency gap
   using C = FlexCfg<DIN, DOUT, TMSEL>;
   extern __shared__ __attribute__((aligned(16))) float s_S[];  // [TM][LD]
   const int tid = threadIdx.x;
@@ -82,12 +85,20 @@ __global__ __launch_bounds__(256) void flex_conv_pm_kernel(
     for (int rp = 0; rp < C::ROUNDS; rp += 2) {
       float4 fv[2][KK];
       float qv[2][KK][3];
+      long long gf[2][KK];
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int k = 0; k < KK; ++k) {
           const long long g = cloud0[rp + h] + nid[rp + h][k];
-          fv[h][k] = *reinterpret_cast<const float4 *>(feat + g * DIN + r4);
+          gf[h][k] = remap ? (cloud0[rp + h] / N) * Nsrc + remap[g] : g;
+        }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int k = 0; k < KK; ++k) {
+          const long long g = cloud0[rp + h] + nid[rp + h][k];
+          fv[h][k] = *reinterpret_cast<const float4 *>(feat + gf[h][k] * DIN + r4);
           qv[h][k][0] = xyz[g * 3]; qv[h][k][1] = xyz[g * 3 + 1]; qv[h][k][2] = xyz[g * 3 + 2];
         }
 #pragma unroll
@@ -124,7 +135,8 @@ __global__ __launch_bounds__(256) void flex_conv_pm_kernel(
 #pragma unroll 4
         for (int k = 0; k < K; ++k) {
           const long long g = cl0 + nb[k];
-          const float4 f = *reinterpret_cast<const float4 *>(feat + g * DIN + r4);
+          const long long gfk = remap ? (cl0 / N) * Nsrc + remap[g] : g;
+          const float4 f = *reinterpret_cast<const float4 *>(feat + gfk * DIN + r4);
           const float dx = xyz[g * 3] - px, dy = xyz[g * 3 + 1] - py, dz = xyz[g * 3 + 2] - pz;
           s0.x += f.x; s0.y += f.y; s0.z += f.z; s0.w += f.w;
           sx.x = fmaf(dx, f.x, sx.x); sx.y = fmaf(dx, f.y, sx.y); sx.z = fmaf(dx, f.z, sx.z); sx.w = fmaf(dx, f.w, sx.w);
@@ -169,7 +181,8 @@ __global__ __launch_bounds__(256) void flex_conv_pm_kernel(
 
 template <int DIN, int DOUT>
 int flex_conv_pm_launch(const float *feat, const float *xyz, const int32_t *nbr, const float *wpacked,
-                        int B, int N, int K, const EpilogueArgs &ep, float *out, hipStream_t s) {
+                        int B, int N, int K, const EpilogueArgs &ep, float *out, hipStream_t s,
+                        const int32_t *remap, int Nsrc) {
   using C = FlexCfg<DIN, DOUT>;
   const long long R = (long long)B * N;
   if constexpr (DIN == 64 && DOUT >= 128) {
@@ -179,7 +192,7 @@ int flex_conv_pm_launch(const float *feat, const float *xyz, const int32_t *nbr,
       auto kern = flex_conv_pm_kernel<DIN, DOUT, 8, 32>;
       DH3D_ALLOW_BIG_LDS(kern);
       hipLaunchKernelGGL(kern, dim3(dh3d_cdiv(R, 32)), dim3(256), sizeof(float) * 32 * C32::LD, s, feat, xyz, nbr,
-                         wpacked, R, N, K, ep, out);
+                         wpacked, R, N, K, ep, out, remap, Nsrc);
       return dh3d_launch_status();
     }
   }
@@ -188,11 +201,11 @@ int flex_conv_pm_launch(const float *feat, const float *xyz, const int32_t *nbr,
   if (K == 8) {
     auto kern = flex_conv_pm_kernel<DIN, DOUT, 8>;
     DH3D_ALLOW_BIG_LDS(kern);
-    hipLaunchKernelGGL(kern, grid, block, lds, s, feat, xyz, nbr, wpacked, R, N, K, ep, out);
+    hipLaunchKernelGGL(kern, grid, block, lds, s, feat, xyz, nbr, wpacked, R, N, K, ep, out, remap, Nsrc);
   } else {
     auto kern = flex_conv_pm_kernel<DIN, DOUT, 0>;
     DH3D_ALLOW_BIG_LDS(kern);
-    hipLaunchKernelGGL(kern, grid, block, lds, s, feat, xyz, nbr, wpacked, R, N, K, ep, out);
+    hipLaunchKernelGGL(kern, grid, block, lds, s, feat, xyz, nbr, wpacked, R, N, K, ep, out, remap, Nsrc);
   }
   return dh3d_launch_status();
 }
@@ -356,14 +369,15 @@ inline int flat_grid(long long total) {
 
 }  // namespace
 
-DH3D_API int dh3d_flex_conv_pm_fwd(const float *features, const float *xyz, const int32_t *nbr,
-                                   const float *wpacked, int B, int N, int K, int Din, int Dout,
-                                   const dh3d_epilogue *ep, float *out, void *stream) {
-  DH3D_REQUIRE(features && xyz && nbr && wpacked && out && B > 0 && N > 0 && K > 0);
+DH3D_API int dh3d_flex_conv_pm_gather_fwd(const float *features, const int32_t *remap, int Nsrc, const float *xyz,
+                                          const int32_t *nbr, const float *wpacked, int B, int N, int K, int Din,
+                                          int Dout, const dh3d_epilogue *ep, float *out, void *stream) {
+  DH3D_REQUIRE(features && xyz && nbr && wpacked && out && B > 0 && N > 0 && K > 0 && (!remap || Nsrc > 0));
   const EpilogueArgs e = dh3d_ep(ep);
   hipStream_t s = (hipStream_t)stream;
 #define DH3D_FLEX_CASE(DI, DO) \
-  if (Din == DI && Dout == DO) return flex_conv_pm_launch<DI, DO>(features, xyz, nbr, wpacked, B, N, K, e, out, s)
+  if (Din == DI && Dout == DO)  \
+  return flex_conv_pm_launch<DI, DO>(features, xyz, nbr, wpacked, B, N, K, e, out, s, remap, Nsrc)
   DH3D_FLEX_CASE(32, 64);
   DH3D_FLEX_CASE(32, 128);
   DH3D_FLEX_CASE(64, 64);
@@ -373,6 +387,12 @@ DH3D_API int dh3d_flex_conv_pm_fwd(const float *features, const float *xyz, cons
   DH3D_FLEX_CASE(128, 256);
 #undef DH3D_FLEX_CASE
   return DH3D_ERR_UNSUPPORTED;
+}
+
+DH3D_API int dh3d_flex_conv_pm_fwd(const float *features, const float *xyz, const int32_t *nbr,
+                                   const float *wpacked, int B, int N, int K, int Din, int Dout,
+                                   const dh3d_epilogue *ep, float *out, void *stream) {
+  return dh3d_flex_conv_pm_gather_fwd(features, nullptr, 0, xyz, nbr, wpacked, B, N, K, Din, Dout, ep, out, stream);
 }
 
 DH3D_API int dh3d_flex_pool_pm_fwd(const float *features, const int32_t *nbr, int B, int N, int K, int C,

@@ -315,7 +315,9 @@ __global__ __launch_bounds__(1024) void netvlad_gate(const float *__restrict__ p
                                                     const float *__restrict__ Wg,
                                                     const float *__restrict__ bn2_scale,
                                                     const float *__restrict__ bn2_shift, float l2_eps,
-                                                    float *__restrict__ out) {
+                                                    const float *__restrict__ tot, float *__restrict__ out) {
+  // tot (may be NULL): the 8 partial square sums of cloud b's intra-normalised VLAD vector, when the caller skipped the
+  // whole-vector L2 normalisation kernel (backbones.py:261): (v * inv) @ Wh == inv * (v @ Wh), applied here
   __shared__ float s_q[4][256];
   __shared__ float s_h[256];
   __shared__ float s_red[4];
@@ -333,6 +335,12 @@ __global__ __launch_bounds__(1024) void netvlad_gate(const float *__restrict__ p
   }
   __syncthreads();
   float h = (s_q[0][o] + s_q[1][o]) + (s_q[2][o] + s_q[3][o]);
+  if (tot) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < kCl / kCG; ++i) t += tot[(size_t)b * (kCl / kCG) + i];
+    h *= rsqrtf(fmaxf(t, 1e-12f));
+  }
   h = fmaf(h, bn1_scale[o], bn1_shift[o]);
   if (q == 0) s_h[o] = h;
   __syncthreads();
@@ -416,6 +424,49 @@ DH3D_API int dh3d_netvlad_head_fwd(const float *vlad, const float *Wh, const flo
   hipLaunchKernelGGL(netvlad_hidden_splitk, dim3(KS, dh3d_cdiv(B, 32), O / 64), dim3(256), 0, s, vlad, Wh, B, Kd, O,
                      part);
   hipLaunchKernelGGL(netvlad_gate, dim3(B), dim3(1024), 0, s, part, 2 * KS, B, O, bn1_scale, bn1_shift, Wg,
-                     bn2_scale, bn2_shift, l2_eps, out);
+                     bn2_scale, bn2_shift, l2_eps, static_cast<const float *>(nullptr), out);
+  return dh3d_launch_status();
+}
+
+// Aggregation + projection + gating in one call (the model path): same result as dh3d_netvlad_aggregate_fwd followed by
+// dh3d_netvlad_head_fwd up to the rounding of one multiplication per output -- the whole-vector L2 normalisation is not
+// a kernel of its own (a pass over [B, 16384] + a dependency gap), its factor multiplies the projected vector instead.
+// workspace: dh3d_netvlad_workspace_bytes + dh3d_netvlad_head_workspace_bytes + 4*B*D*Cl bytes.
+DH3D_API size_t dh3d_netvlad_fused_workspace_bytes(int B, int N, int D, int Cl, int O) {
+  const size_t a = dh3d_netvlad_workspace_bytes(B, N, D, Cl), h = dh3d_netvlad_head_workspace_bytes(B, D * Cl, O);
+  if (!a || !h) return 0;
+  return ((a + 255) & ~(size_t)255) + ((h + 255) & ~(size_t)255) + sizeof(float) * (size_t)B * D * Cl;
+}
+
+DH3D_API int dh3d_netvlad_fused_fwd(const float *x, const float *att, const float *wc_packed, const float *bn_scale,
+                                    const float *bn_shift, const float *W2, const float *Wh, const float *bn1_scale,
+                                    const float *bn1_shift, const float *Wg, const float *bn2_scale,
+                                    const float *bn2_shift, int B, int N, int D, int Cl, int O, float l2_eps,
+                                    void *workspace, size_t workspace_bytes, float *out, void *stream) {
+  DH3D_REQUIRE(x && att && wc_packed && bn_scale && bn_shift && W2 && Wh && bn1_scale && bn1_shift && workspace && out);
+  DH3D_REQUIRE(B > 0 && N > 0 && (!Wg || (bn2_scale && bn2_shift)));
+  DH3D_SUPPORTED(D == kD && Cl == kCl && O == 256 && B <= 65535);
+  DH3D_REQUIRE(workspace_bytes >= dh3d_netvlad_fused_workspace_bytes(B, N, D, Cl, O));
+  const size_t a = (dh3d_netvlad_workspace_bytes(B, N, D, Cl) + 255) & ~(size_t)255;
+  const size_t hb = (dh3d_netvlad_head_workspace_bytes(B, D * Cl, O) + 255) & ~(size_t)255;
+  char *w = static_cast<char *>(workspace);
+  float *vlad = reinterpret_cast<float *>(w + a + hb);
+  const int ch = netvlad_chunks(B, N);
+  float *part_vlad = reinterpret_cast<float *>(w);
+  float *part_asum = part_vlad + (size_t)B * ch * kCl * kD;
+  float *tot = part_asum + (size_t)B * ch * kCl;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = sizeof(float) * (kTM * kLDX + kCl * kLDA + kCl);
+  auto kern = netvlad_assign_accumulate;
+  DH3D_ALLOW_BIG_LDS(kern);
+  hipLaunchKernelGGL(kern, dim3(ch, B), dim3(256), lds, s, x, att, wc_packed, bn_scale, bn_shift, N, ch, part_vlad,
+                     part_asum);
+  hipLaunchKernelGGL(netvlad_finalize, dim3(kCl / kCG, B), dim3(1024), 0, s, part_vlad, part_asum, W2, ch, vlad, tot);
+  const int Kd = D * Cl, KS = dh3d_cdiv(Kd, kKSlice);
+  float *part = reinterpret_cast<float *>(w + a);
+  hipLaunchKernelGGL(netvlad_hidden_splitk, dim3(KS, dh3d_cdiv(B, 32), O / 64), dim3(256), 0, s, vlad, Wh, B, Kd, O,
+                     part);
+  hipLaunchKernelGGL(netvlad_gate, dim3(B), dim3(1024), 0, s, part, 2 * KS, B, O, bn1_scale, bn1_shift, Wg, bn2_scale,
+                     bn2_shift, l2_eps, static_cast<const float *>(tot), out);
   return dh3d_launch_status();
 }

@@ -97,18 +97,28 @@ def pack_flex_weight(theta, bias):
     return out
 
 
-def flex_conv(features, xyz, nbr, wpacked, Dout, pre_bias=None, scale=None, shift=None, act=ACT_NONE):
+def flex_conv(features, xyz, nbr, wpacked, Dout, pre_bias=None, scale=None, shift=None, act=ACT_NONE, remap=None):
+    """Fused factorised flex_conv (exact-f32 MFMA).  remap [B,N] int32 (optional): `features` is the [B,Nsrc,Din] map of
+    the level above and point j of this level is its row remap[b,j] -- group_point fused into the neighbour gather."""
     f = L.require_cuda_f32(features, "features", 3)
     x = L.require_cuda_f32(xyz, "xyz", 3)
     nb = L.require_cuda_i32(nbr, "nbr", 3)
-    B, N, Din = f.shape
+    B, N = x.shape[0], x.shape[1]
+    Din = f.shape[2]
     K = nb.shape[2]
-    if tuple(x.shape) != (B, N, 3) or tuple(nb.shape[:2]) != (B, N):
+    rm = None
+    if remap is not None:
+        rm = L.require_cuda_i32(remap, "remap", 2)
+        if tuple(rm.shape) != (B, N) or f.shape[0] != B:
+            raise ValueError("flex_conv: remap must be [B,N] and features [B,Nsrc,Din]")
+    elif tuple(f.shape[:2]) != (B, N):
         raise ValueError("flex_conv: xyz/nbr do not match features [B,N,*]")
+    if tuple(x.shape) != (B, N, 3) or tuple(nb.shape[:2]) != (B, N):
+        raise ValueError("flex_conv: xyz/nbr do not match [B,N,*]")
     out = torch.empty((B, N, Dout), dtype=torch.float32, device=f.device)
     ep = _ep(pre_bias, scale, shift, act)
-    L.check(L.lib().dh3d_flex_conv_pm_fwd(L.ptr(f), L.ptr(x), L.ptr(nb), L.ptr(wpacked), B, N, K, Din, Dout, ep,
-                                          L.ptr(out), L.stream_ptr()), "flex_conv_pm")
+    L.check(L.lib().dh3d_flex_conv_pm_gather_fwd(L.ptr(f), L.ptr(rm), f.shape[1], L.ptr(x), L.ptr(nb), L.ptr(wpacked), B,
+                                                 N, K, Din, Dout, ep, L.ptr(out), L.stream_ptr()), "flex_conv_pm")
     return out
 
 
@@ -451,6 +461,25 @@ def netvlad_aggregate(x, att, wc_packed, bn_scale, bn_shift, W2):
                                                L.ptr(bn_shift), L.ptr(W2), B, N, D, Cl, L.ptr(ws), ws_bytes,
                                                L.ptr(vlad), L.stream_ptr()), "netvlad_aggregate")
     return vlad
+
+
+def netvlad_fused(x, att, wc_packed, bn_scale, bn_shift, W2, Wh, bn1_scale, bn1_shift, Wg, bn2_scale, bn2_shift,
+                  l2_eps=0.0):
+    """netvlad_head(netvlad_aggregate(...), ...) in one C call, without the separate whole-vector normalisation kernel."""
+    xx = L.require_cuda_f32(x, "x", 3)
+    B, N, D = xx.shape
+    Cl, O = W2.shape[1], Wh.shape[1]
+    a = L.require_cuda_f32(att, "att").reshape(B, N).contiguous()
+    ws_bytes = L.lib().dh3d_netvlad_fused_workspace_bytes(B, N, D, Cl, O)
+    if ws_bytes == 0:
+        raise ValueError("netvlad_fused: unsupported shape D=%d Cl=%d O=%d" % (D, Cl, O))
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=xx.device)
+    out = torch.empty((B, O), dtype=torch.float32, device=xx.device)
+    L.check(L.lib().dh3d_netvlad_fused_fwd(L.ptr(xx), L.ptr(a), L.ptr(wc_packed), L.ptr(bn_scale), L.ptr(bn_shift),
+                                           L.ptr(W2), L.ptr(Wh), L.ptr(bn1_scale), L.ptr(bn1_shift), L.ptr(Wg),
+                                           L.ptr(bn2_scale), L.ptr(bn2_shift), B, N, D, Cl, O, float(l2_eps), L.ptr(ws),
+                                           ws_bytes, L.ptr(out), L.stream_ptr()), "netvlad_fused")
+    return out
 
 
 def netvlad_head(vlad, Wh, bn1_scale, bn1_shift, Wg, bn2_scale, bn2_shift, l2_eps=0.0):

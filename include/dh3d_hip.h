@@ -217,6 +217,12 @@ int dh3d_fps_sorted_cloud(const float *sorted, const float *gbox, const float *x
 int dh3d_flex_conv_pm_fwd(const float *features, const float *xyz, const int32_t *nbr,
                           const float *wpacked, int B, int N, int K, int Din, int Dout,
                           const dh3d_epilogue *ep, float *out, void *stream);
+/* Same with group_point fused in: `features` is the [B, Nsrc, Din] map of the level above and point j of this level
+ * (xyz / nbr / out are [B, N, ...]) is its row remap[b*N + j] (remap = the farthest-point-sampling picks).  Equal to
+ * dh3d_flex_conv_pm_fwd(group_point(features, remap), ...) bit for bit. */
+int dh3d_flex_conv_pm_gather_fwd(const float *features, const int32_t *remap, int Nsrc, const float *xyz,
+                                 const int32_t *nbr, const float *wpacked, int B, int N, int K, int Din, int Dout,
+                                 const dh3d_epilogue *ep, float *out, void *stream);
 
 /* flex_conv of the full-resolution layers on the bf16 matrix pipe with f32 accuracy (three-way bf16 split of
  * both operands, six products; see csrc/flex_x6.hip).  Same operands and result as dh3d_flex_conv_pm_fwd up
@@ -438,6 +444,16 @@ int dh3d_l2norm_rows_bwd(const float *x, const float *dxn, long long R, int C, f
 int dh3d_gemm_tn_f32_batched(const float *A, const float *B, int batch, int K, int M, int N, float *C, void *stream);
 int dh3d_gemm_nn_f32_batched(const float *A, const float *B, const float *colbias, int batch, int M, int K, int N,
                              float *C, void *stream);
+
+/* NetVLAD aggregation + projection + gating in one call (what the model runs): dh3d_netvlad_aggregate_fwd followed by
+ * dh3d_netvlad_head_fwd, without the separate whole-vector L2-normalisation kernel (its factor is applied to the
+ * projected vector).  Wg may be NULL (no gating).  workspace: dh3d_netvlad_fused_workspace_bytes. */
+size_t dh3d_netvlad_fused_workspace_bytes(int B, int N, int D, int Cl, int O);
+int dh3d_netvlad_fused_fwd(const float *x, const float *att, const float *wc_packed, const float *bn_scale,
+                           const float *bn_shift, const float *W2, const float *Wh, const float *bn1_scale,
+                           const float *bn1_shift, const float *Wg, const float *bn2_scale, const float *bn2_shift, int B,
+                           int N, int D, int Cl, int O, float l2_eps, void *workspace, size_t workspace_bytes, float *out,
+                           void *stream);
 
 #ifdef __cplusplus
 }

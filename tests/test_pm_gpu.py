@@ -405,3 +405,46 @@ def test_interp_head_lds_staged_equals_gather_kernel(dev, B, n, clustered):
     got = pm.interp_head(coarse, i3, d3, slices, Hd, wfc, 0.2, order=srt, **kw)
     assert got.shape == ref.shape == (B, n, 1)
     assert (got - ref).abs().max().item() < 1e-6, (got - ref).abs().max().item()
+
+
+def test_flex_conv_with_fused_group_point_is_bit_identical(dev):
+    """pm.flex_conv(full_map, ..., remap=idx) == pm.flex_conv(group_point(full_map, idx), ...): the sampled level's
+    feature gather fused into the neighbour gather (compile-time K = 8 and run-time K paths, both tile sizes)."""
+    from dh3d_amd import pm, ops
+    from dh3d_amd.backbones import gather_rows
+    g = torch.Generator().manual_seed(5)
+    for (B, N, Din, Dout, K) in [(3, 4096, 64, 128, 8), (2, 2048, 128, 256, 8), (2, 1000, 128, 128, 12), (1, 8192, 64, 128, 8)]:
+        M = N // 8
+        xyz = torch.rand(B, N, 3, generator=g).to(dev)
+        feat = torch.randn(B, N, Din, generator=g).to(dev)
+        idx = ops.farthest_point_sample(M, xyz)
+        xyz_s = gather_rows(xyz, idx)
+        nbr_s, _ = pm.knn_xyz(xyz_s, K)
+        wp = pm.pack_flex_weight((torch.randn(3, Din, Dout, generator=g) / Din ** 0.5).to(dev),
+                                 (torch.randn(Din, Dout, generator=g) / (8 * Din) ** 0.5).to(dev))
+        fb = torch.randn(Dout, generator=g).to(dev)
+        kw = dict(pre_bias=fb, scale=fb * 0 + 1.5, shift=fb, act=pm.ACT_RELU)
+        a = pm.flex_conv(gather_rows(feat, idx), xyz_s, nbr_s, wp, Dout, **kw)
+        b = pm.flex_conv(feat, xyz_s, nbr_s, wp, Dout, remap=idx, **kw)
+        assert torch.equal(a, b), (B, N, Din, Dout, K)
+
+
+@pytest.mark.parametrize("B,N", [(2, 512), (32, 4096), (3, 1000)])
+def test_netvlad_fused_equals_two_calls(dev, B, N):
+    """dh3d_netvlad_fused_fwd (no separate whole-vector normalisation kernel) == aggregate + head."""
+    from dh3d_amd import pm
+    g = torch.Generator().manual_seed(B + N)
+    D, C, O = 256, 64, 256
+    x = torch.randn(B, N, D, generator=g).to(dev); att = torch.rand(B, N, 1, generator=g).to(dev)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)
+    wc = pm.pack_weight((r(D, C) / 16).contiguous()); W2 = (r(D, C) / 16).contiguous()
+    Wh, Wg = (r(D * C, O) / 8).contiguous(), (r(O, O) / 16).contiguous()
+    cs, ch, s1, h1, s2, h2 = [0.5 + torch.rand(n, generator=g).to(dev) if i % 2 == 0 else 0.1 * r(n)
+                              for i, n in enumerate((C, C, O, O, O, O))]
+    for l2 in (0.0, 1e-8):
+        two = pm.netvlad_head(pm.netvlad_aggregate(x, att, wc, cs, ch, W2), Wh, s1, h1, Wg, s2, h2, l2_eps=l2)
+        one = pm.netvlad_fused(x, att, wc, cs, ch, W2, Wh, s1, h1, Wg, s2, h2, l2_eps=l2)
+        assert float((one - two).abs().max()) <= 2e-6 * float(two.abs().max()), float((one - two).abs().max())
+    nog = pm.netvlad_fused(x, att, wc, cs, ch, W2, Wh, s1, h1, None, None, None)
+    ref = pm.netvlad_head(pm.netvlad_aggregate(x, att, wc, cs, ch, W2), Wh, s1, h1, None, None, None)
+    assert float((nog - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
