@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdh3d_hip.so")
+LIB_PATH = os.environ.get("DH3D_HIP_LIB") or os.path.join(_HERE, "libdh3d_hip.so")  # (env: dev builds of the library)
 
 DH3D_OK = 0
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
@@ -132,6 +132,11 @@ _SIGNATURES = {
     "dh3d_netvlad_aggregate_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp,
                                    c_size_t, c_fp, c_fp],
     "dh3d_netvlad_head_workspace_bytes": [c_int, c_int, c_int],
+    "dh3d_global_tail_fwd": [c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, ctypes.POINTER(Epilogue), c_fp,
+                             c_float, c_fp, c_fp, c_fp, c_fp, c_fp],
+    "dh3d_netvlad_tail_workspace_bytes": [c_int, c_int, c_int, c_int],
+    "dh3d_netvlad_tail_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_float,
+                              c_fp, c_size_t, c_fp, c_fp],
     "dh3d_netvlad_fused_workspace_bytes": [c_int, c_int, c_int, c_int, c_int],
     "dh3d_netvlad_fused_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int,
                                c_int, c_int, c_float, c_fp, c_size_t, c_fp, c_fp],
@@ -144,6 +149,7 @@ _RESTYPES = {
     "dh3d_netvlad_workspace_bytes": c_size_t,
     "dh3d_netvlad_head_workspace_bytes": c_size_t,
     "dh3d_netvlad_fused_workspace_bytes": c_size_t,
+    "dh3d_netvlad_tail_workspace_bytes": c_size_t,
     "dh3d_flex_conv_fwd_workspace_bytes": c_size_t,
     "dh3d_flex_conv_bwd_workspace_bytes": c_size_t,
     "dh3d_flex_pool_fwd_workspace_bytes": c_size_t,

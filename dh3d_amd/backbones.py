@@ -390,7 +390,8 @@ class FlexConvDilate(nn.Module):
             return None
         return conv.lower_partial(feat)
 
-    def forward(self, geo, feat, nbr=None, residual=None, l2cat=None, shortcut_src=None, lower_partial=None):
+    def forward(self, geo, feat, nbr=None, residual=None, l2cat=None, shortcut_src=None, lower_partial=None,
+                coarse_only=False):
         """geo: Geometry; feat [B,N,cin]; nbr [B,N,K] for dilate == 1 (else computed on the sampled set);
         residual [B,N,cout]: added to the concat conv's output in its store (the caller's shortcut branch);
         l2cat = (prefix [B,N,3], eps): return [prefix | l2_normalize(output)] instead of the output;
@@ -423,6 +424,8 @@ class FlexConvDilate(nn.Module):
         if self.upsample and self.dilate > 1:
             self._last_coarse = (x, lv)  # the level's features before up-sampling (PointMLPHead.forward_interpolated)
             geo.finish(lv)
+            if coarse_only:  # the caller commutes the up-sampling through whatever consumes it (model.compute_global)
+                return x
             conv = self.concat_conv1d.tfconv0 if self.concat else None
             if conv is not None and lower_partial is not None and shortcut_src is None:
                 return conv.forward_commuted(x, lv["nn3_idx"], lv["nn3_dist"], lower_partial, act=pm.ACT_RELU,

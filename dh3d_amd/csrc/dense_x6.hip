@@ -13,8 +13,13 @@
 // The k -> (lane group, element) slot assignment inside one v_mfma_f32_32x32x16_bf16 is the same for the A
 // and the B operand, and a dot product is invariant under a common permutation of k, so A and B fragments
 // are both filled with k = 16*kb + 8*(lane>>5) + j  (j = 0..7) and no hardware slot table is needed.
+#include <type_traits>
+
 #include "bf16x3.h"
 #include "wave_ops.h"
+#include "internal.h"
+
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace {
 
@@ -693,7 +698,7 @@ DH3D_API int dh3d_linear_slices_pm_x6_fwd(const float *x1, int C1, const void *w
 // interp_head_kernel moves 12 KB per fine point through the L2 (1.6 GB per cfg-3 step, 11.6 TB/s: L2-bound).  128
 // consecutive points of the Morton order are a compact region whose 384 neighbour references hit only ~35-45 DISTINCT
 // coarse rows: a workgroup finds them with a bitmap (one bit per coarse row of the cloud, prefix popcounts = slots),
-// and for each 256-channel slice stages those rows ONCE (1 KB each, <= 48 slots = 48 KB, so three workgroups share a CU)
+// and for each 256-channel slice stages those rows ONCE (1 KB each, <= 64 slots = 64 KB, so two workgroups share a CU)
 // and lets its four waves read them from LDS -- ~10x less L2 traffic.  The 64 lane partials of a point and slice are
 // summed right away (two points per butterfly) into a per-point logit in LDS: a plain loop over the points, small code
 // and few registers (keeping 32 per-lane partials in registers across the slices, fully unrolled, cost 296-512 VGPRs
@@ -701,15 +706,45 @@ DH3D_API int dh3d_linear_slices_pm_x6_fwd(const float *x1, int C1, const void *w
 // DESIGN.md dead end (j), staged whole 4 KB rows: 32 slots did not hold a block's rows and one workgroup filled a CU.)
 // Rows beyond the slot capacity (never seen on uniform clouds) are read from global memory like before.
 constexpr int kIHP = 128;    // fine points per workgroup
-constexpr int kIHCap = 48;   // staged coarse rows per slice (48 KB: three workgroups per CU; a block touches ~35-45)
+constexpr int kIHCap = 64;   // staged coarse rows per slice: a 128-point block touches 46 distinct rows on average, 62 at most (uniform clouds); 48 slots overflowed in 1/3-2/3 of the blocks
 constexpr int kIHPW = kIHP / 4;  // points per wave
 
+// VLAD (the global descriptor path): the same walk continues into NetVLAD's soft assignment
+// (core/backbones.py:207-255) -- the up-sampled feature map is never built.  With x[n] = sum_t w_t c[i_t] (c = the
+// coarse rows) and xn = x / |x|:
+//   logits   s[n,:] = xn[n] Wc = (1/|x[n]|) * sum_t w_t (c Wc)[i_t]        -> interpolate the rows of  cw = c Wc  (64 wide)
+//   VLAD     V[k,d] = sum_n a[n,k] xn[n,d] = sum_j A'[j,k] c[j,d],   A'[j,k] = sum_{(n,t): i_t = j} a[n,k] w_t / |x[n]|
+// so after the attention logit of a point the kernel (a) mixes the point's three coarse rows once more for |x|,
+// (b) mixes three cw rows for the logits, BatchNorm + softmax over the 64 lanes, times the attention just computed,
+// (c) adds a * w_t / |x| into A' rows -- in LDS for the staged rows, flushed with 64-lane f32 atomics at the end -- and
+// the caller finishes with a [m x 64]^T [m x 256] GEMM per cloud on the COARSE rows.  Replaces three_interpolate (134
+// MB written and read back at cfg 3) and the per-point part of netvlad_assign_accumulate; the f32 atomics make the
+// global descriptor reproducible to ~1e-7 instead of bit for bit.
+// a staged row (slot >= 0) from LDS, or -- only in blocks that exceeded the slot capacity (OVF) -- row -1-slot from
+// global memory.  The common case has no branch at all: a taken scalar branch costs ~35 cycles and there would be
+// three per point and slice.
+template <bool OVF>
+__device__ __forceinline__ float4 ih_row4(const float *s_rows, const float *gbase, int slot, int lane) {
+  if (OVF && slot < 0) return *reinterpret_cast<const float4 *>(gbase + (size_t)(-1 - slot) * 256 + lane * 4);
+  return *reinterpret_cast<const float4 *>(s_rows + (size_t)slot * 256 + lane * 4);
+}
+
+struct VladTail {
+  const float *coarse;    // [B, m, 256]
+  const float *cw;        // [B, m, 64] = coarse @ cluster_weights
+  const float *cl_scale;  // [64] folded cluster BatchNorm
+  const float *cl_shift;
+  float *apart;           // [B, m, 64]  A' (zeroed by the launcher)
+  float *asum;            // [B, 64]     sum_n a[n,:] (zeroed by the launcher)
+};
+
+template <bool VLAD>
 __global__ __launch_bounds__(256) void interp_head_lds_kernel(const float *__restrict__ H, int NS, long long Rc,
                                                              const int32_t *__restrict__ idx,
                                                              const float *__restrict__ dist,
                                                              const float4 *__restrict__ order, int B, int n, int m,
                                                              int nblk, EpilogueArgs ep, const float *__restrict__ w_fc,
-                                                             float b_fc, float *__restrict__ att) {
+                                                             float b_fc, float *__restrict__ att, VladTail vt) {
   extern __shared__ __attribute__((aligned(16))) float s_ih[];
   float *s_rows = s_ih;                                   // [kIHCap][256]   (reused as the partial-sum area at the end)
   int *s_slot = reinterpret_cast<int *>(s_rows + kIHCap * 256);   // [kIHP][4] slot (or -1 - coarse row)
@@ -777,6 +812,7 @@ __global__ __launch_bounds__(256) void interp_head_lds_kernel(const float *__res
   }
   __syncthreads();
   const int nd = min(s_pre[32], kIHCap);
+  const bool overflow = s_pre[32] > kIHCap;  // block-uniform: some rows are not staged
   const float lo = ep.act == DH3D_ACT_RELU ? 0.f : -__builtin_inff();  // ReLU as a clamp, or no activation
   if (tid < kIHP) s_z[tid] = 0.f;
   for (int sl = 0; sl < NS; ++sl) {
@@ -808,43 +844,187 @@ __global__ __launch_bounds__(256) void interp_head_lds_kernel(const float *__res
     // ---- the wave's 32 points, two at a time (a plain loop: small code, bounded registers).  Slots and weights are
     // wave-uniform: through the scalar unit, so a row address is scalar base + lane offset and the rare overflow test
     // (a row beyond the slot capacity: read from global memory) is a scalar branch.
-    for (int p = 0; p < kIHPW; p += 4) {
-      float part[4];
+    auto slice_points = [&](auto ovf) __attribute__((always_inline)) {
+      constexpr bool OVF = decltype(ovf)::value;
+      for (int p = 0; p < kIHPW; p += 4) {
+        float part[4];
 #pragma unroll
-      for (int h = 0; h < 4; ++h) {
-        const int pt = wave * kIHPW + p + h;
-        const int4 si = *reinterpret_cast<const int4 *>(s_slot + pt * 4);
-        const float4 sw = *reinterpret_cast<const float4 *>(s_w + pt * 4);
-        const int s0 = __builtin_amdgcn_readfirstlane(si.x), s1 = __builtin_amdgcn_readfirstlane(si.y),
-                  s2 = __builtin_amdgcn_readfirstlane(si.z);
-        const float4 r0 = s0 >= 0 ? *reinterpret_cast<const float4 *>(s_rows + (size_t)s0 * 256 + lane * 4)
-                                  : *reinterpret_cast<const float4 *>(Hs + (size_t)(-1 - s0) * 256 + lane * 4);
-        const float4 r1 = s1 >= 0 ? *reinterpret_cast<const float4 *>(s_rows + (size_t)s1 * 256 + lane * 4)
-                                  : *reinterpret_cast<const float4 *>(Hs + (size_t)(-1 - s1) * 256 + lane * 4);
-        const float4 r2 = s2 >= 0 ? *reinterpret_cast<const float4 *>(s_rows + (size_t)s2 * 256 + lane * 4)
-                                  : *reinterpret_cast<const float4 *>(Hs + (size_t)(-1 - s2) * 256 + lane * 4);
-        const float4 v = idw_mix(r0, r1, r2, sw.x, sw.y, sw.z);  // padding points: slot 0, weight 0 -> never stored
-        float a = fmaxf((v.x + pb.x) * sc.x + sh.x, lo) * wf.x;
-        a = fmaf(fmaxf((v.y + pb.y) * sc.y + sh.y, lo), wf.y, a);
-        a = fmaf(fmaxf((v.z + pb.z) * sc.z + sh.z, lo), wf.z, a);
-        a = fmaf(fmaxf((v.w + pb.w) * sc.w + sh.w, lo), wf.w, a);
-        part[h] = a;
+        for (int h = 0; h < 4; ++h) {
+          const int pt = wave * kIHPW + p + h;
+          const int4 si = *reinterpret_cast<const int4 *>(s_slot + pt * 4);
+          const float4 sw = *reinterpret_cast<const float4 *>(s_w + pt * 4);
+          const int s0 = __builtin_amdgcn_readfirstlane(si.x), s1 = __builtin_amdgcn_readfirstlane(si.y),
+                    s2 = __builtin_amdgcn_readfirstlane(si.z);
+          const float4 v = idw_mix(ih_row4<OVF>(s_rows, Hs, s0, lane), ih_row4<OVF>(s_rows, Hs, s1, lane),
+                                   ih_row4<OVF>(s_rows, Hs, s2, lane), sw.x, sw.y, sw.z);  // padding: weight 0
+          float a = fmaxf((v.x + pb.x) * sc.x + sh.x, lo) * wf.x;
+          a = fmaf(fmaxf((v.y + pb.y) * sc.y + sh.y, lo), wf.y, a);
+          a = fmaf(fmaxf((v.z + pb.z) * sc.z + sh.z, lo), wf.z, a);
+          a = fmaf(fmaxf((v.w + pb.w) * sc.w + sh.w, lo), wf.w, a);
+          part[h] = a;
+        }
+        // row sums of two points per reduction: one half-swap + five DPP adds, no LDS crossbar (wave_ops.h)
+        const float t01 = pair_wave_sum_f32(part[0], part[1]), t23 = pair_wave_sum_f32(part[2], part[3]);
+        if ((lane & 31) == 16) {
+          s_z[wave * kIHPW + p + (lane >> 5)] += t01;
+          s_z[wave * kIHPW + p + 2 + (lane >> 5)] += t23;
+        }
       }
-      // row sums of two points per reduction: one half-swap + five DPP adds, no LDS crossbar (wave_ops.h)
-      const float t01 = pair_wave_sum_f32(part[0], part[1]), t23 = pair_wave_sum_f32(part[2], part[3]);
-      if ((lane & 31) == 16) {
-        s_z[wave * kIHPW + p + (lane >> 5)] += t01;
-        s_z[wave * kIHPW + p + 2 + (lane >> 5)] += t23;
-      }
-    }
+    };
+    if (overflow) slice_points(std::true_type{}); else slice_points(std::false_type{});
     __syncthreads();  // the rows are overwritten by the next slice
   }
-  if (tid < kIHP && s_orig[tid] >= 0) att[(size_t)bi * n + s_orig[tid]] = 1.f / (1.f + expf(-(s_z[tid] + b_fc)));
+  if (tid < kIHP) {
+    const float a = s_orig[tid] >= 0 ? 1.f / (1.f + expf(-(s_z[tid] + b_fc))) : 0.f;  // padding points weigh nothing
+    if (s_orig[tid] >= 0 && att) att[(size_t)bi * n + s_orig[tid]] = a;
+    if (VLAD) s_z[tid] = a;
+  }
+  if (!VLAD) return;
+  // ================= NetVLAD assignment on the same block =================
+  float *s_inv = s_z + kIHP;                 // [kIHP] 1 / |x|
+  float *s_asum = s_inv + kIHP;              // [64]
+  float *s_a = s_rows + 16 * 256;            // [kIHP][64]  a[n, k] = softmax * attention of the block's points (behind the cw rows)
+  // ---- (a) |x|: the coarse feature rows, staged like a slice
+  {
+    const float *Cs = vt.coarse + (size_t)bi * m * 256;
+    float4 rg[kIHCap / 4];
+#pragma unroll
+    for (int u = 0; u < kIHCap / 4; ++u) {
+      const int r = wave + 4 * u;
+      rg[u] = *reinterpret_cast<const float4 *>(Cs + (size_t)s_row[r < nd ? r : 0] * 256 + lane * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < kIHCap / 4; ++u) {
+      const int r = wave + 4 * u;
+      if (r < nd) *reinterpret_cast<float4 *>(s_rows + (size_t)r * 256 + lane * 4) = rg[u];
+    }
+    __syncthreads();
+    auto norm_points = [&](auto ovf) __attribute__((always_inline)) {
+      constexpr bool OVF = decltype(ovf)::value;
+      for (int p = 0; p < kIHPW; p += 4) {
+        float part[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          const int pt = wave * kIHPW + p + h;
+          const int4 si = *reinterpret_cast<const int4 *>(s_slot + pt * 4);
+          const float4 sw = *reinterpret_cast<const float4 *>(s_w + pt * 4);
+          const int s0 = __builtin_amdgcn_readfirstlane(si.x), s1 = __builtin_amdgcn_readfirstlane(si.y),
+                    s2 = __builtin_amdgcn_readfirstlane(si.z);
+          const float4 v = idw_mix(ih_row4<OVF>(s_rows, Cs, s0, lane), ih_row4<OVF>(s_rows, Cs, s1, lane),
+                                   ih_row4<OVF>(s_rows, Cs, s2, lane), sw.x, sw.y, sw.z);
+          part[h] = fmaf(v.w, v.w, fmaf(v.z, v.z, fmaf(v.y, v.y, v.x * v.x)));
+        }
+        const float t01 = pair_wave_sum_f32(part[0], part[1]), t23 = pair_wave_sum_f32(part[2], part[3]);
+        if ((lane & 31) == 16) {  // tf.nn.l2_normalize: x * rsqrt(max(sum x^2, 1e-12))
+          s_inv[wave * kIHPW + p + (lane >> 5)] = rsqrtf(fmaxf(t01, 1e-12f));
+          s_inv[wave * kIHPW + p + 2 + (lane >> 5)] = rsqrtf(fmaxf(t23, 1e-12f));
+        }
+      }
+    };
+#if !defined(DH3D_GT_SKIP) || !(DH3D_GT_SKIP & 2)   // dev timing knob (tools/gt_bench.py): results wrong when set
+    if (overflow) norm_points(std::true_type{}); else norm_points(std::false_type{});
+#endif
+    __syncthreads();
+  }
+  // ---- (b, c): cw rows (64 floats each) at the head of the row buffer, A' behind them
+  const float *Ws = vt.cw + (size_t)bi * m * 64;
+  for (int e = tid; e < nd * 16; e += 256) {
+    const int r = e >> 4, q = e & 15;
+    *reinterpret_cast<float4 *>(s_rows + r * 64 + q * 4) = *reinterpret_cast<const float4 *>(Ws + (size_t)s_row[r] * 64 + q * 4);
+  }
+  if (tid < 64) s_asum[tid] = 0.f;
+  __syncthreads();
+  {
+    const float csc = vt.cl_scale[lane], csh = vt.cl_shift[lane];
+    float *Ab = vt.apart + (size_t)bi * m * 64;
+    float asum_acc = 0.f;
+    auto assign_points = [&](auto ovf) __attribute__((always_inline)) {
+      constexpr bool OVF = decltype(ovf)::value;
+      for (int p = 0; p < kIHPW; p += 2) {
+        float e2[2];
+        int sl_[2][3];
+        float cf[2][3];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int pt = wave * kIHPW + p + h;
+          const int4 si = *reinterpret_cast<const int4 *>(s_slot + pt * 4);
+          const float4 sw = *reinterpret_cast<const float4 *>(s_w + pt * 4);
+          const float inv = s_inv[pt];
+          sl_[h][0] = __builtin_amdgcn_readfirstlane(si.x); sl_[h][1] = __builtin_amdgcn_readfirstlane(si.y);
+          sl_[h][2] = __builtin_amdgcn_readfirstlane(si.z);
+          cf[h][0] = sw.x * inv; cf[h][1] = sw.y * inv; cf[h][2] = sw.z * inv;
+          float mixv = 0.f;
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            const int sq = sl_[h][t];
+            const float cv = (OVF && sq < 0) ? Ws[(size_t)(-1 - sq) * 64 + lane] : s_rows[sq * 64 + lane];
+            mixv = fmaf(cf[h][t], cv, mixv);                     // (1/|x|) * sum_t w_t cw[i_t, lane]
+          }
+          const float z = fmaf(mixv, csc, csh);                  // cluster BatchNorm (folded)
+          e2[h] = __expf(z - wave_max_f32(z));
+        }
+        const float hs = pair_wave_sum_f32(e2[0], e2[1]);
+        const float sum0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hs), 16));
+        const float sum1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hs), 48));
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int pt = wave * kIHPW + p + h;
+          const float a = e2[h] * (s_z[pt] * __frcp_rn(h == 0 ? sum0 : sum1));  // softmax * attention (0: padding)
+          asum_acc += a;
+          s_a[pt * 64 + lane] = a;
+          if (OVF) {  // rows that did not fit the staging area: straight to memory
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+              if (sl_[h][t] < 0) unsafeAtomicAdd(&Ab[(size_t)(-1 - sl_[h][t]) * 64 + lane], a * cf[h][t]);
+          }
+        }
+      }
+    };
+#if !defined(DH3D_GT_SKIP) || !(DH3D_GT_SKIP & 1)
+    if (overflow) assign_points(std::true_type{}); else assign_points(std::false_type{});
+#endif
+    unsafeAtomicAdd(&s_asum[lane], asum_acc);
+    __syncthreads();
+#if !defined(DH3D_GT_SKIP) || !(DH3D_GT_SKIP & 4)
+    // A'[slot, k] = sum_n S[n, slot] * a[n, k] with S[n, slot_t(n)] = w_t(n) / |x_n|: a [64 x 128] x [128 x 64] product on
+    // the matrix cores, S built in registers from the slot table (an LDS float atomic per (point, t, cluster) cost 115 us:
+    // ds_add_f32 retires roughly one lane every 2.4 cycles).  Wave = one 32x32 tile: slots 32*(wave>>1).., clusters
+    // 32*(wave&1)..
+    {
+      const int ti = wave >> 1, tj = wave & 1;
+      if (ti * 32 < nd) {  // block-uniform per wave pair
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const int jrow = ti * 32 + (lane & 31), kk = lane >> 5;
+#pragma unroll 4
+        for (int st = 0; st < kIHP / 2; ++st) {
+          const int pt = 2 * st + kk;
+          const int4 si = *reinterpret_cast<const int4 *>(s_slot + pt * 4);
+          const float4 sw = *reinterpret_cast<const float4 *>(s_w + pt * 4);
+          const float inv = s_inv[pt];
+          const float sv = (si.x == jrow ? sw.x : 0.f) + (si.y == jrow ? sw.y : 0.f) + (si.z == jrow ? sw.z : 0.f);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sv * inv, s_a[pt * 64 + tj * 32 + (lane & 31)], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;  // 32x32 accumulator layout
+          if (j < nd) unsafeAtomicAdd(&Ab[(size_t)s_row[j] * 64 + tj * 32 + (lane & 31)], acc[r]);
+        }
+      }
+    }
+#endif
+    if (tid < 64) unsafeAtomicAdd(&vt.asum[(size_t)bi * 64 + tid], s_asum[tid]);
+  }
 }
 
 // `order` (may be NULL): the dh3d_spatial_sort records [B,n,4] of the FINE cloud; with it the points are walked in Morton
 // order and the coarse rows are staged in LDS (m <= 1024); results equal dh3d_interp_head_fwd up to the summation order
 // of the 1024-term row dot.
+static size_t interp_head_lds_bytes() {
+  return sizeof(float) * ((size_t)kIHCap * 256 + kIHP * 4 * 2 + kIHP + 32 + 33 + kIHCap + kIHP /*s_z*/ + kIHP /*s_inv*/ + 64);
+}
+
 DH3D_API int dh3d_interp_head_sorted_fwd(const float *H, int Hd, const int32_t *idx, const float *dist,
                                          const float *order, int B, int n, int m, const dh3d_epilogue *ep,
                                          const float *w_fc, float b_fc, float *att, void *stream) {
@@ -852,12 +1032,37 @@ DH3D_API int dh3d_interp_head_sorted_fwd(const float *H, int Hd, const int32_t *
   DH3D_SUPPORTED(Hd % 256 == 0 && Hd <= 1024 && m <= 1024 && (!ep || ep->act != DH3D_ACT_SIGMOID));
   const int nblk = dh3d_cdiv(n, kIHP);
   const int per_xcd = dh3d_cdiv(B, 8) * nblk;
-  const size_t lds = sizeof(float) * ((size_t)kIHCap * 256 + kIHP * 4 * 2 + kIHP + 32 + 33 + kIHCap + kIHP);
-  DH3D_ALLOW_BIG_LDS(interp_head_lds_kernel);
-  hipLaunchKernelGGL(interp_head_lds_kernel, dim3(8 * per_xcd), dim3(256), lds, (hipStream_t)stream, H, Hd / 256,
-                     (long long)B * m, idx, dist, reinterpret_cast<const float4 *>(order), B, n, m, nblk, dh3d_ep(ep),
-                     w_fc, b_fc, att);
+  DH3D_ALLOW_BIG_LDS(interp_head_lds_kernel<false>);
+  hipLaunchKernelGGL(interp_head_lds_kernel<false>, dim3(8 * per_xcd), dim3(256), interp_head_lds_bytes(),
+                     (hipStream_t)stream, H, Hd / 256, (long long)B * m, idx, dist, reinterpret_cast<const float4 *>(order),
+                     B, n, m, nblk, dh3d_ep(ep), w_fc, b_fc, att, VladTail{});
   return dh3d_launch_status();
+}
+
+// Attention head + NetVLAD soft assignment in one walk over the fine points (see VladTail above).  Outputs: att
+// [B,n] (may be NULL) and `accum` = [ apart B*m*64 | asum B*64 | V B*64*256 ] floats, zeroed here in one fill: apart =
+// A', asum its column sums, V[b] = apart[b]^T coarse[b] (exact-f32 MFMA GEMM, accumulating).  The caller finishes
+// with dh3d_netvlad_tail_fwd(V, asum, ...).
+DH3D_API int dh3d_global_tail_fwd(const float *H, int Hd, const float *coarse, const float *cw, const int32_t *idx,
+                                  const float *dist, const float *order, int B, int n, int m, const dh3d_epilogue *ep,
+                                  const float *w_fc, float b_fc, const float *cl_scale, const float *cl_shift, float *att,
+                                  float *accum, void *stream) {
+  DH3D_REQUIRE(H && coarse && cw && idx && dist && w_fc && cl_scale && cl_shift && accum);
+  DH3D_REQUIRE(B > 0 && n > 0 && m > 0 && Hd > 0);
+  DH3D_SUPPORTED(Hd % 256 == 0 && Hd <= 1024 && m <= 1024 && (!ep || ep->act != DH3D_ACT_SIGMOID));
+  hipStream_t s = (hipStream_t)stream;
+  float *apart = accum, *asum = apart + (size_t)B * m * 64, *V = asum + (size_t)B * 64;
+  if (hipMemsetAsync(accum, 0, sizeof(float) * ((size_t)B * m * 64 + (size_t)B * 64 + (size_t)B * 64 * 256), s) != hipSuccess)
+    return DH3D_ERR_LAUNCH;
+  const int nblk = dh3d_cdiv(n, kIHP);
+  const int per_xcd = dh3d_cdiv(B, 8) * nblk;
+  DH3D_ALLOW_BIG_LDS(interp_head_lds_kernel<true>);
+  hipLaunchKernelGGL(interp_head_lds_kernel<true>, dim3(8 * per_xcd), dim3(256), interp_head_lds_bytes(), s, H, Hd / 256,
+                     (long long)B * m, idx, dist, reinterpret_cast<const float4 *>(order), B, n, m, nblk, dh3d_ep(ep),
+                     w_fc, b_fc, att, VladTail{coarse, cw, cl_scale, cl_shift, apart, asum});
+  const int st = dh3d_launch_status();
+  if (st != DH3D_OK) return st;
+  return dh3d_internal_gemm_tn_batched(apart, coarse, B, m, 64, 256, V, true, s);
 }
 
 DH3D_API int dh3d_interp_head_fwd(const float *H, int Hd, const int32_t *idx, const float *dist, int B, int n, int m,

@@ -265,6 +265,12 @@ DH3D_API int dh3d_gemm_tn_f32_batched(const float *A, const float *B, int batch,
                      GemmBatch{batch, (long long)K * M, (long long)K * N, (long long)M * N, 0});
 }
 
+int dh3d_internal_gemm_tn_batched(const float *A, const float *B, int batch, int K, int M, int N, float *C,
+                                  bool accumulate, hipStream_t s) {
+  return gemm_launch(true, A, M, B, N, C, N, M, N, K, nullptr, 0, accumulate, s, nullptr,
+                     GemmBatch{batch, (long long)K * M, (long long)K * N, (long long)M * N, 0});
+}
+
 DH3D_API int dh3d_gemm_nn_f32_batched(const float *A, const float *B, const float *colbias, int batch, int M, int K,
                                       int N, float *C, void *stream) {
   DH3D_REQUIRE(A && B && C && batch > 0 && K > 0 && M > 0 && N > 0);

@@ -9,3 +9,6 @@ int dh3d_internal_gemm(bool ta, const float *A, int lda, const float *B, int ldb
 // [Bt][R][Cc] -> [Bt][Cc][R] (32-bit elements); ldo != 0: output row stride ldo and batch stride obs (elements)
 int dh3d_internal_transpose32(const void *in, void *out, int Bt, int R, int Cc, long long ldo, long long obs,
                               hipStream_t s);
+// `batch` independent C[b] (+)= A[b]^T B[b]: A [batch,K,M], B [batch,K,N], C [batch,M,N], stored back to back
+int dh3d_internal_gemm_tn_batched(const float *A, const float *B, int batch, int K, int M, int N, float *C,
+                                  bool accumulate, hipStream_t s);

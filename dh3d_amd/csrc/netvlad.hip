@@ -428,6 +428,38 @@ DH3D_API int dh3d_netvlad_head_fwd(const float *vlad, const float *Wh, const flo
   return dh3d_launch_status();
 }
 
+// The tail behind the commuted aggregation (dense_x6.hip, dh3d_global_tail_fwd): V [B, Cl, D] = A'^T coarse per cloud and
+// asum [B, Cl] are given; subtract asum * W2, intra-normalise, flatten, project, gate.  workspace:
+// dh3d_netvlad_tail_workspace_bytes.
+DH3D_API size_t dh3d_netvlad_tail_workspace_bytes(int B, int D, int Cl, int O) {
+  const size_t h = dh3d_netvlad_head_workspace_bytes(B, D * Cl, O);
+  if (!h || D != kD || Cl != kCl) return 0;
+  return ((h + 255) & ~(size_t)255) + sizeof(float) * ((size_t)B * D * Cl + (size_t)B * (kCl / kCG));
+}
+
+DH3D_API int dh3d_netvlad_tail_fwd(const float *V, const float *asum, const float *W2, const float *Wh,
+                                   const float *bn1_scale, const float *bn1_shift, const float *Wg,
+                                   const float *bn2_scale, const float *bn2_shift, int B, int D, int Cl, int O,
+                                   float l2_eps, void *workspace, size_t workspace_bytes, float *out, void *stream) {
+  DH3D_REQUIRE(V && asum && W2 && Wh && bn1_scale && bn1_shift && workspace && out && B > 0);
+  DH3D_REQUIRE(!Wg || (bn2_scale && bn2_shift));
+  DH3D_SUPPORTED(D == kD && Cl == kCl && O == 256 && B <= 65535);
+  DH3D_REQUIRE(workspace_bytes >= dh3d_netvlad_tail_workspace_bytes(B, D, Cl, O));
+  const size_t hb = (dh3d_netvlad_head_workspace_bytes(B, D * Cl, O) + 255) & ~(size_t)255;
+  char *w = static_cast<char *>(workspace);
+  float *part = reinterpret_cast<float *>(w);
+  float *vlad = reinterpret_cast<float *>(w + hb);
+  float *tot = vlad + (size_t)B * D * Cl;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(netvlad_finalize, dim3(kCl / kCG, B), dim3(1024), 0, s, V, asum, W2, 1, vlad, tot);
+  const int Kd = D * Cl, KS = dh3d_cdiv(Kd, kKSlice);
+  hipLaunchKernelGGL(netvlad_hidden_splitk, dim3(KS, dh3d_cdiv(B, 32), O / 64), dim3(256), 0, s, vlad, Wh, B, Kd, O,
+                     part);
+  hipLaunchKernelGGL(netvlad_gate, dim3(B), dim3(1024), 0, s, part, 2 * KS, B, O, bn1_scale, bn1_shift, Wg, bn2_scale,
+                     bn2_shift, l2_eps, static_cast<const float *>(tot), out);
+  return dh3d_launch_status();
+}
+
 // Aggregation + projection + gating in one call (the model path): same result as dh3d_netvlad_aggregate_fwd followed by
 // dh3d_netvlad_head_fwd up to the rounding of one multiplication per output -- the whole-vector L2 normalisation is not
 // a kernel of its own (a pass over [B, 16384] + a dependency gap), its factor multiplies the projected vector instead.

@@ -272,6 +272,22 @@ class DH3D(nn.Module):
         if geo is None:
             geo = self._geometry(points, None)
             self._join_side(geo)
+        lv = geo.level(self.global_before_assemble.dilate, self.knn_num, finish=False)
+        nv, ga = self._netvlad, self.globalatt
+        m = lv["xyz_s"].shape[1]
+        if ("_ordered" in lv and points.shape[1] >= 4096 and m <= 1024 and nv.add_batch_norm
+                and self.global_before_assemble.outdims[-1] == 256
+                and "wslices" in (ga._prep or ga.prepare())):
+            # Both consumers of the up-sampled map -- the attention MLP and NetVLAD's soft assignment / aggregation --
+            # are reached through the interpolation's linearity: the fine points are walked once (Morton order, coarse
+            # rows staged in LDS), the [Bt, N, 256] map is never built (rule on the points per cloud only).
+            coarse = self.global_before_assemble(geo, localdesc, coarse_only=True)
+            last = ga.detec_conv0
+            lp, gp, p = last._prep, ga._prep, nv._prep or nv.prepare()
+            return pm.global_tail(coarse, lv["nn3_idx"], lv["nn3_dist"], lv["_ordered"][0], gp["wslices"], last.cout,
+                                  gp["w_fc"], gp["b_fc"], (lp["b"], lp["scale"], lp["shift"], pm.ACT_RELU), p["wc"],
+                                  p["cs"], p["ch"], p["W2"], p["Wh"], p["s1"], p["h1"], p["Wg"], p["s2"], p["h2"],
+                                  l2_eps=l2_eps)
         forglobal = self.global_before_assemble(geo, localdesc)
         coarse, lv = getattr(self.global_before_assemble, "_last_coarse", (None, None))
         if coarse is not None and "nn3_idx" in lv and self.globalatt.interpolated_supported(coarse, lv["nn3_idx"]):

@@ -482,6 +482,42 @@ def netvlad_fused(x, att, wc_packed, bn_scale, bn_shift, W2, Wh, bn1_scale, bn1_
     return out
 
 
+def global_tail(coarse, idx, dist, order, wslices_x3, Hd, w_fc, b_fc, att_ep, wc_packed, cl_scale, cl_shift, W2, Wh,
+                bn1_scale, bn1_shift, Wg, bn2_scale, bn2_shift, l2_eps=0.0, want_att=False):
+    """three_interpolate -> attention head -> NetVLAD + gating, with the up-sampling commuted through both consumers: the
+    fine points are walked once (csrc/dense_x6.hip VladTail), everything else runs on the coarse rows.
+    coarse [B,m,256], idx/dist [B,n,3], order = spatial_sort records [B,n,4] of the fine cloud, att_ep =
+    (pre_bias, scale, shift, act) of the attention's hidden layer.  Returns the descriptor [B,O] (, att [B,n,1])."""
+    x = L.require_cuda_f32(coarse, "coarse", 3)
+    ix = L.require_cuda_i32(idx, "idx", 3)
+    d = L.require_cuda_f32(dist, "dist", 3)
+    B, m, C = x.shape
+    n = ix.shape[1]
+    ns = Hd // 256
+    H = torch.empty((ns, B * m, 256), dtype=torch.float32, device=x.device)
+    L.check(L.lib().dh3d_linear_slices_pm_x6_fwd(L.ptr(x), C, L.ptr(wslices_x3), B * m, ns, L.ptr(H), L.stream_ptr()),
+            "linear_slices_pm_x6")
+    cw = linear(x, wc_packed, 64)                                                  # coarse @ cluster_weights
+    att = torch.empty((B, n, 1), dtype=torch.float32, device=x.device) if want_att else None
+    accum = torch.empty((B * m * 64 + B * 64 + B * 64 * 256,), dtype=torch.float32, device=x.device)
+    ep = _ep(*att_ep)
+    L.check(L.lib().dh3d_global_tail_fwd(L.ptr(H), Hd, L.ptr(x), L.ptr(cw), L.ptr(ix), L.ptr(d), L.ptr(order), B, n, m,
+                                         ep, L.ptr(w_fc), float(b_fc), L.ptr(cl_scale), L.ptr(cl_shift), L.ptr(att),
+                                         L.ptr(accum), L.stream_ptr()), "global_tail")
+    asum = accum[B * m * 64:B * m * 64 + B * 64]
+    V = accum[B * m * 64 + B * 64:]                                                # [B, 64, 256] = A'^T coarse
+    O = Wh.shape[1]
+    ws_bytes = L.lib().dh3d_netvlad_tail_workspace_bytes(B, C, 64, O)
+    if ws_bytes == 0:
+        raise ValueError("global_tail: unsupported NetVLAD shape")
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
+    out = torch.empty((B, O), dtype=torch.float32, device=x.device)
+    L.check(L.lib().dh3d_netvlad_tail_fwd(L.ptr(V), L.ptr(asum), L.ptr(W2), L.ptr(Wh), L.ptr(bn1_scale), L.ptr(bn1_shift),
+                                          L.ptr(Wg), L.ptr(bn2_scale), L.ptr(bn2_shift), B, C, 64, O, float(l2_eps),
+                                          L.ptr(ws), ws_bytes, L.ptr(out), L.stream_ptr()), "netvlad_tail")
+    return (out, att) if want_att else out
+
+
 def netvlad_head(vlad, Wh, bn1_scale, bn1_shift, Wg, bn2_scale, bn2_shift, l2_eps=0.0):
     v = L.require_cuda_f32(vlad, "vlad", 2)
     B, Kd = v.shape

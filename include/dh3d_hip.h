@@ -445,6 +445,24 @@ int dh3d_gemm_tn_f32_batched(const float *A, const float *B, int batch, int K, i
 int dh3d_gemm_nn_f32_batched(const float *A, const float *B, const float *colbias, int batch, int M, int K, int N,
                              float *C, void *stream);
 
+/* The global-descriptor tail with the up-sampling commuted through BOTH consumers of the up-sampled map (attention MLP
+ * and NetVLAD; csrc/dense_x6.hip VladTail): dh3d_global_tail_fwd walks the fine points once (Morton order of `order`,
+ * coarse rows staged in LDS) from H = the 256-column slices of coarse @ W_att (dh3d_linear_slices_pm_x6_fwd), coarse
+ * [B,m,256] and cw = coarse @ cluster_weights [B,m,64], and produces att [B,n] (may be NULL) and
+ * accum = [ apart B*m*64 | asum B*64 | V B*64*256 ] floats (zeroed by the call): apart = A' (softmax * attention
+ * scattered onto the coarse rows, f32 atomics), asum its per-cluster sums, V[b] = apart[b]^T coarse[b].
+ * dh3d_netvlad_tail_fwd(V, asum, ...) finishes (subtract asum*W2, intra-normalise, project, gate).  Same function as
+ * three_interpolate -> attention head -> dh3d_netvlad_fused_fwd, reassociated; m <= 1024. */
+int dh3d_global_tail_fwd(const float *H, int Hd, const float *coarse, const float *cw, const int32_t *idx,
+                         const float *dist, const float *order, int B, int n, int m, const dh3d_epilogue *ep,
+                         const float *w_fc, float b_fc, const float *cl_scale, const float *cl_shift, float *att,
+                         float *accum, void *stream);
+size_t dh3d_netvlad_tail_workspace_bytes(int B, int D, int Cl, int O);
+int dh3d_netvlad_tail_fwd(const float *V, const float *asum, const float *W2, const float *Wh, const float *bn1_scale,
+                          const float *bn1_shift, const float *Wg, const float *bn2_scale, const float *bn2_shift, int B,
+                          int D, int Cl, int O, float l2_eps, void *workspace, size_t workspace_bytes, float *out,
+                          void *stream);
+
 /* NetVLAD aggregation + projection + gating in one call (what the model runs): dh3d_netvlad_aggregate_fwd followed by
  * dh3d_netvlad_head_fwd, without the separate whole-vector L2-normalisation kernel (its factor is applied to the
  * projected vector).  Wg may be NULL (no gating).  workspace: dh3d_netvlad_fused_workspace_bytes. */

@@ -448,3 +448,42 @@ def test_netvlad_fused_equals_two_calls(dev, B, N):
     nog = pm.netvlad_fused(x, att, wc, cs, ch, W2, Wh, s1, h1, None, None, None)
     ref = pm.netvlad_head(pm.netvlad_aggregate(x, att, wc, cs, ch, W2), Wh, s1, h1, None, None, None)
     assert float((nog - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("B,n,clustered", [(2, 4096, False), (9, 4096, False), (3, 5000, False), (1, 8192, False), (2, 4100, True)])
+def test_global_tail_equals_upsample_attention_netvlad(dev, B, n, clustered):
+    """pm.global_tail (one walk over the fine points, everything else on the coarse rows) == three_interpolate ->
+    attention head -> NetVLAD + gating on the materialised up-sampled map; same math reassociated (f32 atomics: the
+    result is reproducible to ~1e-7, compared at 2e-6 of the descriptor's largest entry), attention weights too."""
+    from dh3d_amd import pm, ops
+    g = torch.Generator().manual_seed(n * 3 + B)
+    m, C, Hd, Cl, O = n // 8, 256, 1024, 64, 256
+    fine = torch.rand(B, n, 3, generator=g)
+    if clustered:
+        fine[:, :, 2] *= 1e-3
+        fine[:, :, 1] *= 0.05
+    fine = fine.to(dev)
+    samp = ops.farthest_point_sample(m, fine)
+    cxyz = torch.gather(fine, 1, samp.long()[:, :, None].expand(-1, -1, 3)).contiguous()
+    d3, i3 = ops.three_nn(fine, cxyz)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)
+    coarse = r(B, m, C)
+    W = (r(C, Hd) / C ** 0.5).contiguous(); wfc = r(Hd) / Hd ** 0.5
+    b, sc, sh = r(Hd), (0.5 + torch.rand(Hd, generator=g)).to(dev), r(Hd)
+    slices = torch.cat([pm.pack_weight_x3(W[:, j:j + 256].contiguous()) for j in range(0, Hd, 256)])
+    Wc = (r(C, Cl) / 16).contiguous(); wc = pm.pack_weight(Wc); W2 = (r(C, Cl) / 16).contiguous()
+    Wh, Wg = (r(C * Cl, O) / 8).contiguous(), (r(O, O) / 16).contiguous()
+    cs, ch = (0.5 + torch.rand(Cl, generator=g)).to(dev), 0.1 * r(Cl)
+    s1, h1, s2, h2 = (0.5 + torch.rand(O, generator=g)).to(dev), 0.1 * r(O), (0.5 + torch.rand(O, generator=g)).to(dev), 0.1 * r(O)
+    srt, _ = pm.spatial_sort(fine)
+    # reference: materialised up-sampling
+    up = pm.three_interpolate_idw(coarse, i3, d3)
+    att_ref = pm.interp_head(coarse, i3, d3, slices, Hd, wfc, 0.2, pre_bias=b, scale=sc, shift=sh, act=pm.ACT_RELU)
+    ref = pm.netvlad_fused(up, att_ref, wc, cs, ch, W2, Wh, s1, h1, Wg, s2, h2, l2_eps=1e-8)
+    got, att = pm.global_tail(coarse, i3, d3, srt, slices, Hd, wfc, 0.2, (b, sc, sh, pm.ACT_RELU), wc, cs, ch, W2, Wh, s1,
+                              h1, Wg, s2, h2, l2_eps=1e-8, want_att=True)
+    assert float((att - att_ref).abs().max()) < 1e-6
+    assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) + 1e-7, float((got - ref).abs().max())
+    again = pm.global_tail(coarse, i3, d3, srt, slices, Hd, wfc, 0.2, (b, sc, sh, pm.ACT_RELU), wc, cs, ch, W2, Wh, s1, h1,
+                           Wg, s2, h2, l2_eps=1e-8)
+    assert float((again - got).abs().max()) <= 1e-6 * float(got.abs().max())
