@@ -226,7 +226,7 @@ __global__ __launch_bounds__(kThreads) void flex_conv_x6_kernel(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         XPROBE(0, gg, 1);
-#if !defined(DH3D_X6_PROBE) || DH3D_X6_PROBE != 3   // probe 3: producers only load (timing experiment)
+#if (!defined(DH3D_X6_PROBE) || DH3D_X6_PROBE != 3) && !(defined(DH3D_X6_EXP) && (DH3D_X6_EXP & 4))   // probe 3 / exp 4: producers only load (timing experiment)
         compute(s, gg);
 #else
         asm volatile("" :: "v"(reinterpret_cast<const float *>(&fv[s][0])[0]), "v"(reinterpret_cast<const float *>(&fv[s][7])[1]),
@@ -256,7 +256,8 @@ __global__ __launch_bounds__(kThreads) void flex_conv_x6_kernel(
     if (ep.pre_bias) pb = *reinterpret_cast<const float4 *>(ep.pre_bias + c4);
     if (ep.scale) sc = *reinterpret_cast<const float4 *>(ep.scale + c4);
     if (ep.shift) sh = *reinterpret_cast<const float4 *>(ep.shift + c4);
-    const float lo = ep.act == DH3D_ACT_RELU ? 0.f : -__builtin_inff();
+    sh.x = fmaf(pb.x, sc.x, sh.x); sh.y = fmaf(pb.y, sc.y, sh.y); sh.z = fmaf(pb.z, sc.z, sh.z); sh.w = fmaf(pb.w, sc.w, sh.w);
+    const int lo = ep.act == DH3D_ACT_RELU ? 0 : INT_MIN;
     // GEMM of tile i: this wave's K-half x column block.  The six products of a k-block go to two independent
     // accumulator chains (a dependent MFMA would wait ~12 cycles on its predecessor), small terms first.  The
     // trailing scheduling hints pin the issue order: chains alternating, the A fragments of the next k-block
@@ -267,14 +268,19 @@ __global__ __launch_bounds__(kThreads) void flex_conv_x6_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
 #pragma unroll
-#if defined(DH3D_X6_PROBE) && DH3D_X6_PROBE == 4      // probe 4: consumers skip the MFMAs (timing experiment)
+#if (defined(DH3D_X6_PROBE) && DH3D_X6_PROBE == 4) || (defined(DH3D_X6_EXP) && (DH3D_X6_EXP & 8))     // probe 4 / exp 8: consumers skip the MFMAs (timing experiment)
       for (int kb = 0; kb < 0; ++kb) {
 #else
       for (int kb = 0; kb < C::KBH; ++kb) {
 #endif
-        const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(abase + kb * 16);
-        const bf16x8 a2 = *reinterpret_cast<const bf16x8 *>(abase + kTM * C::LD + kb * 16);
-        const bf16x8 a3 = *reinterpret_cast<const bf16x8 *>(abase + 2 * kTM * C::LD + kb * 16);
+#if defined(DH3D_X6_EXP) && (DH3D_X6_EXP & 1)   // timing experiment: one set of A fragments per tile (results wrong)
+        const int kbo = 0;
+#else
+        const int kbo = kb * 16;
+#endif
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(abase + kbo);
+        const bf16x8 a2 = *reinterpret_cast<const bf16x8 *>(abase + kTM * C::LD + kbo);
+        const bf16x8 a3 = *reinterpret_cast<const bf16x8 *>(abase + 2 * kTM * C::LD + kbo);
         const bf16x8 b1 = __builtin_bit_cast(bf16x8, breg[kb][0]), b2 = __builtin_bit_cast(bf16x8, breg[kb][1]),
                      b3 = __builtin_bit_cast(bf16x8, breg[kb][2]);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc0, 0, 0, 0);
@@ -295,9 +301,13 @@ __global__ __launch_bounds__(kThreads) void flex_conv_x6_kernel(
     };
     auto write_partial = [&](int i, const f32x16 &acc0, const f32x16 &acc1) {
       float *part = s_P + (size_t)(i & 1) * C::P_FLOATS + (size_t)kh * kTM * C::PLD + cb * 32 + (lane & 31);
+      // packed adds: an FP32 VALU instruction holds up the SIMD's matrix pipe (see above), so half as many of them
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        part[(size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * C::PLD] = acc0[r] + acc1[r];
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 sum = f32x2{acc0[r], acc0[r + 1]} + f32x2{acc1[r], acc1[r + 1]};
+        part[(size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * C::PLD] = sum[0];
+        part[(size_t)(((r + 1) & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * C::PLD] = sum[1];
+      }
     };
     // sum of the two K-half partial tiles of tile i, epilogue, 16-byte stores
     auto reduce_store = [&](int i) {
@@ -308,12 +318,16 @@ __global__ __launch_bounds__(kThreads) void flex_conv_x6_kernel(
         const float *q = s_P + (size_t)(i & 1) * C::P_FLOATS + (size_t)p * C::PLD + c4;
         const float4 v0 = *reinterpret_cast<const float4 *>(q);
         const float4 v1 = *reinterpret_cast<const float4 *>(q + kTM * C::PLD);
-        float4 v;  // relu as a clamp (no branch in this block; sigmoid is not offered by this kernel)
-        v.x = fmaxf(((v0.x + v1.x) + pb.x) * sc.x + sh.x, lo);
-        v.y = fmaxf(((v0.y + v1.y) + pb.y) * sc.y + sh.y, lo);
-        v.z = fmaxf(((v0.z + v1.z) + pb.z) * sc.z + sh.z, lo);
-        v.w = fmaxf(((v0.w + v1.w) + pb.w) * sc.w + sh.w, lo);
-        if (!RAGGED || grow0 + p < R) *reinterpret_cast<float4 *>(out + (size_t)(grow0 + p) * DOUT + c4) = v;
+        // four packed FP instructions per row segment (the pre-bias is folded into the shift); relu / no activation
+        // as an INTEGER max on the bit patterns (max(bits, 0) clamps negative floats to +0, max(bits, INT_MIN) is the
+        // identity): integer VALU work does overlap the matrix pipe
+        const f32x2 t0 = f32x2{v0.x, v0.y} + f32x2{v1.x, v1.y}, t1 = f32x2{v0.z, v0.w} + f32x2{v1.z, v1.w};
+        const f32x2 r0 = __builtin_elementwise_fma(t0, f32x2{sc.x, sc.y}, f32x2{sh.x, sh.y});
+        const f32x2 r1 = __builtin_elementwise_fma(t1, f32x2{sc.z, sc.w}, f32x2{sh.z, sh.w});
+        int4 vi;
+        vi.x = max(__float_as_int(r0[0]), lo); vi.y = max(__float_as_int(r0[1]), lo);
+        vi.z = max(__float_as_int(r1[0]), lo); vi.w = max(__float_as_int(r1[1]), lo);
+        if (!RAGGED || grow0 + p < R) *reinterpret_cast<int4 *>(out + (size_t)(grow0 + p) * DOUT + c4) = vi;
       }
     };
     // The reduce + store of tile i-1 is issued in the shadow of tile i's MFMAs (an MFMA holds the matrix pipe
@@ -328,9 +342,14 @@ __global__ __launch_bounds__(kThreads) void flex_conv_x6_kernel(
     XPROBE(1, 0, 2);
     for (int i = 1; i < cnt; ++i) {
       XPROBE(1, i, 0);
+#if defined(DH3D_X6_EXP) && (DH3D_X6_EXP & 2)   // timing experiment: no partial tiles, no reduce + store (results wrong)
+      gemm(i, acc0, acc1);
+      asm volatile("" :: "v"(acc0), "v"(acc1));
+#else
       reduce_store(i - 1);
       gemm(i, acc0, acc1);
       write_partial(i, acc0, acc1);
+#endif
       XPROBE(1, i, 1);
       wg_barrier(i + 1);  // partials of tile i complete, tile i+1 staged
       XPROBE(1, i, 2);
