@@ -14,7 +14,16 @@ wp3 = pm.pack_flex_weight_x3(theta, bias); out = torch.empty(B, N, Dout, device=
 p = lambda t: ctypes.c_void_p(t.data_ptr())
 libs = [("shipped", "dh3d_amd/libdh3d_hip.so")] + sorted(
     (("exp %2d" % int(re.search(r"exp(\d+)", x).group(1)), x) for x in glob.glob("tools/libx6_exp*.so")), key=lambda t: int(t[0][4:]))
-for name, path in libs:
+if len(sys.argv) < 2:  # one subprocess per library: a variant that deadlocks costs 20 s, not the whole call
+    import subprocess
+    for name, path in libs:
+        try:
+            r = subprocess.run([sys.executable, __file__, name, path], capture_output=True, text=True, timeout=20)
+            print(r.stdout.strip() or r.stderr.strip()[-200:])
+        except subprocess.TimeoutExpired:
+            print("%-8s HUNG" % name)
+    sys.exit(0)
+for name, path in [(sys.argv[1], sys.argv[2])]:
     lib = ctypes.CDLL(path)
     fn = lib.dh3d_flex_conv_pm_x6_fwd
     for _ in range(3):
