@@ -387,7 +387,7 @@ def test_interp_head_lds_staged_equals_gather_kernel(dev, B, n, clustered):
     g = torch.Generator().manual_seed(n + B)
     m, C, Hd = n // 8, 256, 1024
     fine = torch.rand(B, n, 3, generator=g)
-    if clustered:
+    if clustered is True:
         fine[:, :, 2] *= 1e-3
         fine[:, :, 1] *= 0.05
     fine = fine.to(dev)
@@ -450,7 +450,8 @@ def test_netvlad_fused_equals_two_calls(dev, B, N):
     assert float((nog - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
 
 
-@pytest.mark.parametrize("B,n,clustered", [(2, 4096, False), (9, 4096, False), (3, 5000, False), (1, 8192, False), (2, 4100, True)])
+@pytest.mark.parametrize("B,n,clustered", [(2, 4096, False), (9, 4096, False), (3, 5000, False), (1, 8192, False), (2, 4100, True),
+                                           (2, 4096, "scrambled")])
 def test_global_tail_equals_upsample_attention_netvlad(dev, B, n, clustered):
     """pm.global_tail (one walk over the fine points, everything else on the coarse rows) == three_interpolate ->
     attention head -> NetVLAD + gating on the materialised up-sampled map; same math reassociated (f32 atomics: the
@@ -466,6 +467,9 @@ def test_global_tail_equals_upsample_attention_netvlad(dev, B, n, clustered):
     samp = ops.farthest_point_sample(m, fine)
     cxyz = torch.gather(fine, 1, samp.long()[:, :, None].expand(-1, -1, 3)).contiguous()
     d3, i3 = ops.three_nn(fine, cxyz)
+    if clustered == "scrambled":  # neighbours with no spatial coherence: a 128-point block touches ~350 coarse rows,
+        # far more than the 64 staged in LDS -- every block takes the overflow path (rows read from / added to memory)
+        i3 = torch.randint(0, m, (B, n, 3), generator=g, dtype=torch.int32).to(dev)
     r = lambda *s: torch.randn(*s, generator=g).to(dev)
     coarse = r(B, m, C)
     W = (r(C, Hd) / C ** 0.5).contiguous(); wfc = r(Hd) / Hd ** 0.5

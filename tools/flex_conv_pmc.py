@@ -12,7 +12,7 @@ wp = pm.pack_flex_weight_x3((torch.randn(3, Din, Dout, generator=g) / 8).to(dev)
 fb = torch.zeros(Dout, device=dev)
 # a copy kernel of known size for calibrating the counters: 64 MiB read + 64 MiB write
 cal = torch.empty(16 * 1024 * 1024, device=dev)
-for _ in range(5):
+for _ in range(24):
     out = pm.flex_conv_x6(f, xyz, nbr, wp, Dout, pre_bias=fb, scale=fb + 1, shift=fb, act=pm.ACT_RELU)
     cal2 = cal.clone()
 torch.cuda.synchronize()
