@@ -112,6 +112,13 @@ _SIGNATURES = {
                              c_fp, c_fp],
     "dh3d_interp_head_sorted_fwd": [c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, ctypes.POINTER(Epilogue), c_fp,
                                     c_float, c_fp, c_fp],
+    "dh3d_interp_head_sorted_fwd_dev": [c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, ctypes.POINTER(Epilogue), c_fp,
+                                        c_fp, c_fp, c_fp],
+    "dh3d_interp_bn_colstats": [c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp],
+    "dh3d_interp_bn_bwd_sums": [c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
+                                c_fp, c_fp, c_fp, c_fp, c_fp],
+    "dh3d_interp_bn_bwd_apply": [c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
+                                 c_fp, c_fp, c_fp],
     "dh3d_linear_pm_x6_fwd": [c_fp, c_int, c_fp, c_int, c_fp, c_int, c_int, ctypes.POINTER(Epilogue), c_fp, c_fp, c_fp],
     "dh3d_se_res_pm_packed_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp],
     "dh3d_flex_pool_pm_fwd": [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp],

@@ -736,6 +736,7 @@ struct VladTail {
   const float *cl_shift;
   float *apart;           // [B, m, 64]  A' (zeroed by the launcher)
   float *asum;            // [B, 64]     sum_n a[n,:] (zeroed by the launcher)
+  const float *b_dev;     // (either instantiation) the fc bias as a device scalar, added to b_fc; may be NULL
 };
 
 template <bool VLAD>
@@ -875,7 +876,8 @@ __global__ __launch_bounds__(256) void interp_head_lds_kernel(const float *__res
     __syncthreads();  // the rows are overwritten by the next slice
   }
   if (tid < kIHP) {
-    const float a = s_orig[tid] >= 0 ? 1.f / (1.f + expf(-(s_z[tid] + b_fc))) : 0.f;  // padding points weigh nothing
+    const float bias = b_fc + (vt.b_dev ? vt.b_dev[0] : 0.f);
+    const float a = s_orig[tid] >= 0 ? 1.f / (1.f + expf(-(s_z[tid] + bias))) : 0.f;  // padding points weigh nothing
     if (s_orig[tid] >= 0 && att) att[(size_t)bi * n + s_orig[tid]] = a;
     if (VLAD) s_z[tid] = a;
   }
@@ -1036,6 +1038,23 @@ DH3D_API int dh3d_interp_head_sorted_fwd(const float *H, int Hd, const int32_t *
   hipLaunchKernelGGL(interp_head_lds_kernel<false>, dim3(8 * per_xcd), dim3(256), interp_head_lds_bytes(),
                      (hipStream_t)stream, H, Hd / 256, (long long)B * m, idx, dist, reinterpret_cast<const float4 *>(order),
                      B, n, m, nblk, dh3d_ep(ep), w_fc, b_fc, att, VladTail{});
+  return dh3d_launch_status();
+}
+
+// Same with the fc bias read from device memory (a trainable parameter: no host round trip in the training step).
+DH3D_API int dh3d_interp_head_sorted_fwd_dev(const float *H, int Hd, const int32_t *idx, const float *dist,
+                                             const float *order, int B, int n, int m, const dh3d_epilogue *ep,
+                                             const float *w_fc, const float *b_fc_dev, float *att, void *stream) {
+  DH3D_REQUIRE(H && idx && dist && w_fc && b_fc_dev && att && B > 0 && n > 0 && m > 0 && Hd > 0);
+  DH3D_SUPPORTED(Hd % 256 == 0 && Hd <= 1024 && m <= 1024 && (!ep || ep->act != DH3D_ACT_SIGMOID));
+  const int nblk = dh3d_cdiv(n, kIHP);
+  const int per_xcd = dh3d_cdiv(B, 8) * nblk;
+  DH3D_ALLOW_BIG_LDS(interp_head_lds_kernel<false>);
+  VladTail vt{};
+  vt.b_dev = b_fc_dev;
+  hipLaunchKernelGGL(interp_head_lds_kernel<false>, dim3(8 * per_xcd), dim3(256), interp_head_lds_bytes(),
+                     (hipStream_t)stream, H, Hd / 256, (long long)B * m, idx, dist, reinterpret_cast<const float4 *>(order),
+                     B, n, m, nblk, dh3d_ep(ep), w_fc, 0.f, att, vt);
   return dh3d_launch_status();
 }
 

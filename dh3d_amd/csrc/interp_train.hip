@@ -1,0 +1,394 @@
+// Training-mode attention head with its 256 -> 1024 convolution commuted through the up-sampling (gfx950).
+//
+// globalatt_block (core/backbones.py:156-173) runs  conv 256->1024 -> BatchNorm (batch statistics) -> ReLU -> fc 1024->1
+// -> sigmoid  on the three_interpolate'd rows (core/backbones.py:89-100).  The interpolation is linear and acts on rows,
+// the convolution is linear and acts on channels, so  conv(interp(c)) = interp(conv(c)):  the three 47-GFLOP exact-f32
+// GEMMs of the training step (forward, dX, dW on Bt*N = 90 k rows) become 6-GFLOP ones on the Bt*N/8 sampled rows, and
+// the [90 k x 1024] pre-activation h = interp(G), G = c W + b, is never written: every pass that needs it walks the fine
+// points in Morton order (records of dh3d_spatial_sort), 128 points per workgroup, finds the <= 64 distinct coarse rows
+// the block touches with a bitmap, stages them in LDS one 256-channel slice at a time and mixes three of them per point
+// -- the walk of interp_head_lds_kernel (dense_x6.hip), which stays the forward pass proper (its BatchNorm epilogue
+// takes the batch statistics).  The three passes here:
+//   MODE 0  column statistics of h:          sum_n h[n,c], sum_n h[n,c]^2                      (forward, before the head)
+//   MODE 1  BatchNorm backward sums:         S1 = sum dz, S2 = sum dz * xhat, S3 = sum dlogit * relu(y) (= d w_fc)
+//   MODE 2  dh = k1 dz - k2 - k3 h  scattered back through the interpolation:  dG[i_t(n), c] += w_t(n) dh[n, c]
+// with dz[n,c] = dlogit[n] * w_fc[c] * [y > 0] (the rank-one gradient of train.hip's attention head).  The scatter of
+// MODE 2 is a product on the matrix cores: per 32 points, dG_tile[slot, c] += sum_n S[n, slot] dh[n, c] with S built in
+// registers from the slot table (S[n, slot_t(n)] = w_t(n)) -- LDS float atomics retire about one lane per 2.4 cycles
+// and three_interp_bwd's global atomics take 218 us for a quarter of the channels; the staged tile is added to memory
+// once per block and slice (f32 atomics on <= 64 rows).  Rows of padding clouds (mask) take no part.
+#include "common.h"
+#include "wave_ops.h"
+
+#include <type_traits>
+
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace {
+
+constexpr int kP = 128;    // fine points per workgroup
+constexpr int kCap = 64;   // staged coarse rows per slice (a 128-point block touches 46 on average, 62 at most)
+constexpr int kPW = kP / 4;
+// MODE 2 keeps a chunk of dh rows next to the staged rows; 56 slots + 16 points x 272 floats leave room for two
+// workgroups per CU (79.6 KB each; with 64 + 32 x 288 only one fitted and the pass took 375 instead of ~300 us).
+constexpr int kCap2 = 56;  // staged rows in MODE 2 (blocks touching more take the overflow path for the excess)
+constexpr int kCH = 16;    // points per dh chunk
+constexpr int kLDH = 272;  // row stride of the dh chunk (floats)
+
+// must round like three_interp_fwd_kernel<IDW> / interp_head_lds_kernel (no contraction)
+#pragma clang fp contract(off)
+__device__ __forceinline__ void idw3(float d1, float d2, float d3, float &w1, float &w2, float &w3) {
+  const float r1 = 1.0f / fmaxf(d1, 1e-10f), r2 = 1.0f / fmaxf(d2, 1e-10f), r3 = 1.0f / fmaxf(d3, 1e-10f);
+  const float norm = (r1 + r2) + r3;
+  w1 = r1 / norm; w2 = r2 / norm; w3 = r3 / norm;
+}
+__device__ __forceinline__ float4 mix3(const float4 a, const float4 b, const float4 c, float w1, float w2, float w3) {
+  float4 r;
+  r.x = (a.x * w1 + b.x * w2) + c.x * w3;
+  r.y = (a.y * w1 + b.y * w2) + c.y * w3;
+  r.z = (a.z * w1 + b.z * w2) + c.z * w3;
+  r.w = (a.w * w1 + b.w * w2) + c.w * w3;
+  return r;
+}
+#pragma clang fp contract(fast)
+
+template <bool OVF>
+__device__ __forceinline__ float4 row4(const float *s_rows, const float *gbase, int slot, int lane) {
+  if (OVF && slot < 0) return *reinterpret_cast<const float4 *>(gbase + (size_t)(-1 - slot) * 256 + lane * 4);
+  return *reinterpret_cast<const float4 *>(s_rows + (size_t)slot * 256 + lane * 4);
+}
+
+struct InterpBnArgs {
+  const float *G;            // [NS][Rc][256] slices of coarse @ W + b
+  int NS;
+  long long Rc;              // B * m
+  const int32_t *idx;        // [B, n, 3]
+  const float *dist;         // [B, n, 3]
+  const float4 *order;       // [B, n] spatial_sort records of the fine cloud
+  int B, n, m, nblk;
+  const unsigned char *mask; // [B] or null
+  const float *dlogit;       // [B * n] by original point index (MODE 1, 2)
+  const float *wfc;          // [NS * 256]
+  const float *v0, *v1, *v2, *v3;  // MODE 1: mean, rstd, gamma, beta;  MODE 2: scale, shift, k2, k3
+  double *s0, *s1, *s2;      // MODE 0: sum, sumsq;  MODE 1: S1, S2, S3
+  float *dG;                 // MODE 2: [NS][Rc][256]
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void interp_bn_kernel(const InterpBnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float s_mem[];
+  constexpr int CAP = MODE == 2 ? kCap2 : kCap;
+  float *s_rows = s_mem;                                           // [CAP][256]
+  int *s_slot = reinterpret_cast<int *>(s_rows + CAP * 256);       // [kP][4] slots (or -1 - coarse row), .w = point valid
+  float *s_w = reinterpret_cast<float *>(s_slot + kP * 4);         // [kP][4] weights, .w = dlogit (0: padding)
+  unsigned *s_bits = reinterpret_cast<unsigned *>(s_w + kP * 4);   // [32]
+  int *s_pre = reinterpret_cast<int *>(s_bits + 32);               // [33]
+  int *s_row = s_pre + 33;                                         // [kCap]
+  float *s_x = reinterpret_cast<float *>(s_row + kCap + 3);        // MODE 2: [kCH][kLDH] dh chunk
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int bi = xcd + 8 * (seq / a.nblk), blk = seq % a.nblk;
+  if (bi >= a.B) return;
+  if (a.mask && !a.mask[bi]) return;  // a padding cloud: no statistics, zero gradients
+  const int n = a.n, m = a.m;
+  if (tid < 32) s_bits[tid] = 0u;
+  __syncthreads();
+  int my_i[3] = {0, 0, 0};
+  bool have = false;
+  if (tid < kP) {
+    const int q = blk * kP + tid;
+    if (q < n) {
+      const int orig = a.order ? __float_as_int(a.order[(size_t)bi * n + q].w) : q;
+      const long long r = (long long)bi * n + orig;
+      float w1, w2, w3;
+      idw3(a.dist[r * 3], a.dist[r * 3 + 1], a.dist[r * 3 + 2], w1, w2, w3);
+      *reinterpret_cast<float4 *>(s_w + tid * 4) = make_float4(w1, w2, w3, MODE == 0 ? 0.f : a.dlogit[r]);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        my_i[t] = a.idx[r * 3 + t];
+        atomicOr(&s_bits[my_i[t] >> 5], 1u << (my_i[t] & 31));
+      }
+      have = true;
+    } else {  // padding point of the last block: slot 0 with zero weights, flagged invalid
+      *reinterpret_cast<float4 *>(s_w + tid * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<int4 *>(s_slot + tid * 4) = make_int4(0, 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    int c = tid < 32 ? __popc(s_bits[tid]) : 0, v = c;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+      const int o = __shfl_up(v, off, 64);
+      if ((tid & 63) >= off) v += o;
+    }
+    if (tid < 32) s_pre[tid] = v - c;
+    if (tid == 31) s_pre[32] = v;
+  }
+  __syncthreads();
+  if (have) {
+    int sl3[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int j = my_i[t];
+      const int slot = s_pre[j >> 5] + __popc(s_bits[j >> 5] & ((1u << (j & 31)) - 1u));
+      sl3[t] = slot < CAP ? slot : -1 - j;
+    }
+    *reinterpret_cast<int4 *>(s_slot + tid * 4) = make_int4(sl3[0], sl3[1], sl3[2], 1);
+  }
+  for (int j = tid; j < m; j += 256) {
+    if ((s_bits[j >> 5] >> (j & 31)) & 1u) {
+      const int slot = s_pre[j >> 5] + __popc(s_bits[j >> 5] & ((1u << (j & 31)) - 1u));
+      if (slot < CAP) s_row[slot] = j;
+    }
+  }
+  __syncthreads();
+  const int nd = min(s_pre[32], CAP);
+  const bool overflow = s_pre[32] > CAP;
+
+  for (int sl = 0; sl < a.NS; ++sl) {
+    const float *Gs = a.G + (size_t)sl * a.Rc * 256 + (size_t)bi * m * 256;
+    {
+      float4 rg[CAP / 4];
+#pragma unroll
+      for (int u = 0; u < CAP / 4; ++u) {
+        const int r = wave + 4 * u;
+        rg[u] = *reinterpret_cast<const float4 *>(Gs + (size_t)s_row[r < nd ? r : 0] * 256 + lane * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < CAP / 4; ++u) {
+        const int r = wave + 4 * u;
+        if (r < nd) *reinterpret_cast<float4 *>(s_rows + (size_t)r * 256 + lane * 4) = rg[u];
+      }
+    }
+    const int c = sl * 256 + lane * 4;
+    float4 q0 = {}, q1 = {}, q2 = {}, q3 = {}, wf = {};
+    if (MODE != 0) {
+      q0 = *reinterpret_cast<const float4 *>(a.v0 + c); q1 = *reinterpret_cast<const float4 *>(a.v1 + c);
+      q2 = *reinterpret_cast<const float4 *>(a.v2 + c); q3 = *reinterpret_cast<const float4 *>(a.v3 + c);
+      wf = *reinterpret_cast<const float4 *>(a.wfc + c);
+    }
+    __syncthreads();
+
+    if (MODE == 0 || MODE == 1) {
+      float4 A1 = {}, A2 = {}, A3 = {};
+      auto points = [&](auto ovf) __attribute__((always_inline)) {
+        constexpr bool OVF = decltype(ovf)::value;
+#pragma unroll 4
+        for (int p = 0; p < kPW; ++p) {
+          const int pt = wave * kPW + p;
+          const int4 si = *reinterpret_cast<const int4 *>(s_slot + pt * 4);
+          const float4 sw = *reinterpret_cast<const float4 *>(s_w + pt * 4);
+          const int s0 = __builtin_amdgcn_readfirstlane(si.x), s1 = __builtin_amdgcn_readfirstlane(si.y),
+                    s2 = __builtin_amdgcn_readfirstlane(si.z);
+          const float4 h = mix3(row4<OVF>(s_rows, Gs, s0, lane), row4<OVF>(s_rows, Gs, s1, lane),
+                                row4<OVF>(s_rows, Gs, s2, lane), sw.x, sw.y, sw.z);
+          if (MODE == 0) {
+            const float f = si.w ? 1.f : 0.f;  // padding points: h = 0 anyway (zero weights)
+            A1.x += h.x; A1.y += h.y; A1.z += h.z; A1.w += h.w;
+            A2.x = fmaf(h.x, h.x, A2.x); A2.y = fmaf(h.y, h.y, A2.y); A2.z = fmaf(h.z, h.z, A2.z); A2.w = fmaf(h.w, h.w, A2.w);
+            (void)f;
+          } else {
+            // xhat = (h - mean) rstd; y = xhat gamma + beta; dz = dlogit w_fc [y > 0]   (dlogit = 0 on padding points)
+            const float dl = sw.w;
+#define DH3D_IB_SUMS(X)                                                                         \
+  {                                                                                             \
+    const float xh = (h.X - q0.X) * q1.X;                                                       \
+    const float y = fmaf(xh, q2.X, q3.X);                                                       \
+    const float dz = y > 0.f ? dl * wf.X : 0.f;                                                 \
+    A1.X += dz; A2.X = fmaf(dz, xh, A2.X); A3.X = fmaf(dl, fmaxf(y, 0.f), A3.X);               \
+  }
+            DH3D_IB_SUMS(x) DH3D_IB_SUMS(y) DH3D_IB_SUMS(z) DH3D_IB_SUMS(w)
+#undef DH3D_IB_SUMS
+          }
+        }
+      };
+      if (overflow) points(std::true_type{}); else points(std::false_type{});
+      // the four waves hold different points of the same channels: through LDS (the row buffer is dead by now), then
+      // one f64 atomic per channel
+      __syncthreads();
+      float *red = s_rows;
+      *reinterpret_cast<float4 *>(red + (0 * 4 + wave) * 256 + lane * 4) = A1;
+      *reinterpret_cast<float4 *>(red + (1 * 4 + wave) * 256 + lane * 4) = A2;
+      if (MODE == 1) *reinterpret_cast<float4 *>(red + (2 * 4 + wave) * 256 + lane * 4) = A3;
+      __syncthreads();
+      {
+        const int ch = sl * 256 + tid;
+#pragma unroll
+        for (int k = 0; k < (MODE == 1 ? 3 : 2); ++k) {
+          const double v = ((double)red[(k * 4 + 0) * 256 + tid] + red[(k * 4 + 1) * 256 + tid]) +
+                           ((double)red[(k * 4 + 2) * 256 + tid] + red[(k * 4 + 3) * 256 + tid]);
+          unsafeAtomicAdd((k == 0 ? a.s0 : k == 1 ? a.s1 : a.s2) + ch, v);
+        }
+      }
+      __syncthreads();  // rows and partial sums are overwritten by the next slice
+    } else {
+      // ---- MODE 2: dh per point into LDS 32 points at a time, scattered onto the staged rows by an MFMA product
+      float *s_dh = s_x;
+      float *dGs = a.dG + (size_t)sl * a.Rc * 256 + (size_t)bi * m * 256;
+      const int nrt = nd > 32 ? 2 : 1;  // 32-slot row tiles in use (block-uniform)
+      f32x16 acc[2][2];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.f;
+      for (int q = 0; q < kP / kCH; ++q) {
+        auto points = [&](auto ovf) __attribute__((always_inline)) {
+          constexpr bool OVF = decltype(ovf)::value;
+#pragma unroll
+          for (int j = 0; j < kCH / 4; ++j) {
+            const int pl = wave * (kCH / 4) + j, pt = q * kCH + pl;
+            const int4 si = *reinterpret_cast<const int4 *>(s_slot + pt * 4);
+            const float4 sw = *reinterpret_cast<const float4 *>(s_w + pt * 4);
+            const int s0 = __builtin_amdgcn_readfirstlane(si.x), s1 = __builtin_amdgcn_readfirstlane(si.y),
+                      s2 = __builtin_amdgcn_readfirstlane(si.z);
+            const float4 h = mix3(row4<OVF>(s_rows, Gs, s0, lane), row4<OVF>(s_rows, Gs, s1, lane),
+                                  row4<OVF>(s_rows, Gs, s2, lane), sw.x, sw.y, sw.z);
+            const float dl = sw.w, live = si.w ? 1.f : 0.f;
+            float4 dh;
+            // dh = k1 dz - k2 - k3 h,  dz = dlogit w_fc [h scale + shift > 0]   (0 on padding points)
+#define DH3D_IB_DH(X)                                                                           \
+  {                                                                                             \
+    const float dz = fmaf(h.X, q0.X, q1.X) > 0.f ? dl * wf.X : 0.f;                             \
+    dh.X = live * ((fmaf(q0.X, dz, -q2.X)) - q3.X * h.X);                                       \
+  }
+            DH3D_IB_DH(x) DH3D_IB_DH(y) DH3D_IB_DH(z) DH3D_IB_DH(w)
+#undef DH3D_IB_DH
+            *reinterpret_cast<float4 *>(s_dh + pl * kLDH + lane * 4) = dh;
+            if (OVF) {  // rows that did not fit the staging area: straight to memory
+              const int st[3] = {s0, s1, s2};
+              const float wt[3] = {sw.x, sw.y, sw.z};
+#pragma unroll
+              for (int t = 0; t < 3; ++t)
+                if (st[t] < 0) {
+                  float *dst = dGs + (size_t)(-1 - st[t]) * 256 + lane * 4;
+                  unsafeAtomicAdd(dst, wt[t] * dh.x); unsafeAtomicAdd(dst + 1, wt[t] * dh.y);
+                  unsafeAtomicAdd(dst + 2, wt[t] * dh.z); unsafeAtomicAdd(dst + 3, wt[t] * dh.w);
+                }
+            }
+          }
+        };
+        if (overflow) points(std::true_type{}); else points(std::false_type{});
+        __syncthreads();
+        // dG_tile[slot, c] += sum_p S[p, slot] dh[p, c]: wave w owns channels 64 w .. 64 w + 63 (two 32-column tiles)
+        const int kk = lane >> 5, col = wave * 64 + (lane & 31);
+#pragma unroll 4
+        for (int st = 0; st < kCH / 2; ++st) {
+          const int pl = 2 * st + kk, pt = q * kCH + pl;
+          const int4 si = *reinterpret_cast<const int4 *>(s_slot + pt * 4);
+          const float4 sw = *reinterpret_cast<const float4 *>(s_w + pt * 4);
+          const float b0 = s_dh[pl * kLDH + col], b1 = s_dh[pl * kLDH + col + 32];
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt) {
+            if (rt < nrt) {
+              const int jrow = rt * 32 + (lane & 31);
+              const float sv = (si.x == jrow ? sw.x : 0.f) + (si.y == jrow ? sw.y : 0.f) + (si.z == jrow ? sw.z : 0.f);
+#if defined(DH3D_IB_EXP) && (DH3D_IB_EXP & 1)   // timing experiment: no MFMAs (results wrong)
+              asm volatile("" :: "v"(sv), "v"(b0), "v"(b1));
+#else
+              acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv, b0, acc[rt][0], 0, 0, 0);
+              acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv, b1, acc[rt][1], 0, 0, 0);
+#endif
+            }
+          }
+        }
+        __syncthreads();  // the chunk buffer is rewritten
+      }
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        if (rt < nrt) {
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int j = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);  // 32x32 accumulator layout
+#if defined(DH3D_IB_EXP) && (DH3D_IB_EXP & 2)   // timing experiment: plain stores instead of atomics (results wrong)
+              if (j < nd) dGs[(size_t)s_row[j] * 256 + wave * 64 + ct * 32 + (lane & 31)] = acc[rt][ct][r];
+#elif defined(DH3D_IB_EXP) && (DH3D_IB_EXP & 4)   // timing experiment: no flush at all
+              if (j < nd && acc[rt][ct][r] == 123.456f) dGs[0] = 1.f;
+#else
+              if (j < nd) unsafeAtomicAdd(dGs + (size_t)s_row[j] * 256 + wave * 64 + ct * 32 + (lane & 31), acc[rt][ct][r]);
+#endif
+            }
+        }
+      }
+      // (the next slice's staging writes s_rows only after every wave passed the last barrier above)
+    }
+  }
+}
+
+size_t interp_bn_lds(int mode) {
+  const size_t base = sizeof(float) * ((size_t)(mode == 2 ? kCap2 : kCap) * 256 + kP * 4 * 2 + 32 + 33 + kCap + 3);
+  return base + sizeof(float) * (mode == 2 ? (size_t)kCH * kLDH : 0);  // 70 / 79.6 KB: two workgroups per CU
+}
+
+template <int MODE>
+int launch(const InterpBnArgs &a, hipStream_t s) {
+  auto kern = interp_bn_kernel<MODE>;
+  DH3D_ALLOW_BIG_LDS(kern);
+  const int per_xcd = dh3d_cdiv(a.B, 8) * a.nblk;
+  hipLaunchKernelGGL(kern, dim3(8 * per_xcd), dim3(256), interp_bn_lds(MODE), s, a);
+  return dh3d_launch_status();
+}
+
+bool shape_ok(int Hd, int m) { return Hd % 256 == 0 && Hd >= 256 && Hd <= 1024 && m <= 1024; }
+
+}  // namespace
+
+// G: the 256-column slices [Hd/256][B*m][256] of coarse @ W + b; idx / dist: three_nn of the fine points [B,n,3];
+// order: dh3d_spatial_sort records of the fine cloud [B,n,4] (may be NULL: points in index order, correct but slower);
+// mask [B] bytes (may be NULL).  sum / sumsq [Hd] f64 are zeroed here.
+DH3D_API int dh3d_interp_bn_colstats(const float *G, int Hd, const int32_t *idx, const float *dist, const float *order,
+                                     int B, int n, int m, const unsigned char *mask, double *sum, double *sumsq,
+                                     void *stream) {
+  DH3D_REQUIRE(G && idx && dist && sum && sumsq && B > 0 && n > 0 && m > 0);
+  DH3D_SUPPORTED(shape_ok(Hd, m));
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(sum, 0, sizeof(double) * Hd, s) != hipSuccess) return DH3D_ERR_LAUNCH;
+  if (hipMemsetAsync(sumsq, 0, sizeof(double) * Hd, s) != hipSuccess) return DH3D_ERR_LAUNCH;
+  InterpBnArgs a{};
+  a.G = G; a.NS = Hd / 256; a.Rc = (long long)B * m; a.idx = idx; a.dist = dist;
+  a.order = reinterpret_cast<const float4 *>(order); a.B = B; a.n = n; a.m = m; a.nblk = dh3d_cdiv(n, kP); a.mask = mask;
+  a.s0 = sum; a.s1 = sumsq;
+  return launch<0>(a, s);
+}
+
+// S1, S2, S3 [Hd] f64 (zeroed here): the sums of dh3d_bn_bwd_sums for the rank-one gradient dy = dlogit x w_fc on the
+// virtual rows h = interp(G);  dlogit [B*n] by original point index.
+DH3D_API int dh3d_interp_bn_bwd_sums(const float *G, int Hd, const int32_t *idx, const float *dist, const float *order,
+                                     int B, int n, int m, const unsigned char *mask, const float *dlogit,
+                                     const float *w_fc, const float *mean, const float *rstd, const float *gamma,
+                                     const float *beta, double *S1, double *S2, double *S3, void *stream) {
+  DH3D_REQUIRE(G && idx && dist && dlogit && w_fc && mean && rstd && gamma && beta && S1 && S2 && S3);
+  DH3D_REQUIRE(B > 0 && n > 0 && m > 0);
+  DH3D_SUPPORTED(shape_ok(Hd, m));
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(S1, 0, sizeof(double) * Hd, s) != hipSuccess) return DH3D_ERR_LAUNCH;
+  if (hipMemsetAsync(S2, 0, sizeof(double) * Hd, s) != hipSuccess) return DH3D_ERR_LAUNCH;
+  if (hipMemsetAsync(S3, 0, sizeof(double) * Hd, s) != hipSuccess) return DH3D_ERR_LAUNCH;
+  InterpBnArgs a{};
+  a.G = G; a.NS = Hd / 256; a.Rc = (long long)B * m; a.idx = idx; a.dist = dist;
+  a.order = reinterpret_cast<const float4 *>(order); a.B = B; a.n = n; a.m = m; a.nblk = dh3d_cdiv(n, kP); a.mask = mask;
+  a.dlogit = dlogit; a.wfc = w_fc; a.v0 = mean; a.v1 = rstd; a.v2 = gamma; a.v3 = beta;
+  a.s0 = S1; a.s1 = S2; a.s2 = S3;
+  return launch<1>(a, s);
+}
+
+// dG [Hd/256][B*m][256] (zeroed here) = interp^T(dh),  dh = scale dz - k2 - k3 h  (the coefficients of
+// dh3d_bn_bwd_finalize; dz = dlogit w_fc [h scale + shift > 0]); f32 atomics.
+DH3D_API int dh3d_interp_bn_bwd_apply(const float *G, int Hd, const int32_t *idx, const float *dist, const float *order,
+                                      int B, int n, int m, const unsigned char *mask, const float *dlogit,
+                                      const float *w_fc, const float *scale, const float *shift, const float *k2,
+                                      const float *k3, float *dG, void *stream) {
+  DH3D_REQUIRE(G && idx && dist && dlogit && w_fc && scale && shift && k2 && k3 && dG && B > 0 && n > 0 && m > 0);
+  DH3D_SUPPORTED(shape_ok(Hd, m));
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(dG, 0, sizeof(float) * (size_t)B * m * Hd, s) != hipSuccess) return DH3D_ERR_LAUNCH;
+  InterpBnArgs a{};
+  a.G = G; a.NS = Hd / 256; a.Rc = (long long)B * m; a.idx = idx; a.dist = dist;
+  a.order = reinterpret_cast<const float4 *>(order); a.B = B; a.n = n; a.m = m; a.nblk = dh3d_cdiv(n, kP); a.mask = mask;
+  a.dlogit = dlogit; a.wfc = w_fc; a.v0 = scale; a.v1 = shift; a.v2 = k2; a.v3 = k3; a.dG = dG;
+  return launch<2>(a, s);
+}

@@ -688,6 +688,57 @@ def bn_bwd_apply(x, scale, shift, k2, k3, relu, dy=None, rowscale=None, colvec=N
     return dx
 
 
+# ---- attention head, training mode, conv commuted through the up-sampling (csrc/interp_train.hip)
+def interp_bn_colstats(G, idx, dist, order, mask=None, out=None):
+    """G [ns, B*m, 256] slices of coarse @ W + b; idx/dist [B,n,3]; order = spatial_sort records [B,n,4] or None ->
+    (sum, sumsq) [Hd] float64 of the virtual rows three_interpolate(G)."""
+    ns, Rc, _ = G.shape
+    B, n = idx.shape[0], idx.shape[1]
+    Hd = ns * 256
+    buf = out if out is not None else torch.empty((2 * Hd,), dtype=torch.float64, device=G.device)
+    s1, s2 = buf[:Hd], buf[Hd:2 * Hd]
+    L.check(L.lib().dh3d_interp_bn_colstats(L.ptr(G), Hd, L.ptr(idx), L.ptr(dist), L.ptr(order), B, n, Rc // B,
+                                            L.ptr(_mask_u8(mask)), L.ptr(s1), L.ptr(s2), L.stream_ptr()),
+            "interp_bn_colstats")
+    return s1, s2
+
+
+def interp_head_rows(G, idx, dist, order, scale, shift, w_fc, b_fc_dev):
+    """att [B*n] = sigmoid(relu(three_interpolate(G) * scale + shift) . w_fc + b_fc), b_fc a device scalar."""
+    ns, Rc, _ = G.shape
+    B, n = idx.shape[0], idx.shape[1]
+    out = torch.empty((B * n,), dtype=torch.float32, device=G.device)
+    ep = _ep(None, scale, shift, ACT_RELU)
+    L.check(L.lib().dh3d_interp_head_sorted_fwd_dev(L.ptr(G), ns * 256, L.ptr(idx), L.ptr(dist), L.ptr(order), B, n,
+                                                    Rc // B, ep, L.ptr(w_fc), L.ptr(b_fc_dev), L.ptr(out),
+                                                    L.stream_ptr()), "interp_head_sorted_dev")
+    return out
+
+
+def interp_bn_bwd_sums(G, idx, dist, order, dlogit, w_fc, mean, rstd, gamma, beta, mask=None):
+    ns, Rc, _ = G.shape
+    B, n = idx.shape[0], idx.shape[1]
+    Hd = ns * 256
+    S = torch.empty((3, Hd), dtype=torch.float64, device=G.device)
+    L.check(L.lib().dh3d_interp_bn_bwd_sums(L.ptr(G), Hd, L.ptr(idx), L.ptr(dist), L.ptr(order), B, n, Rc // B,
+                                            L.ptr(_mask_u8(mask)), L.ptr(dlogit), L.ptr(w_fc), L.ptr(mean), L.ptr(rstd),
+                                            L.ptr(gamma), L.ptr(beta), L.ptr(S[0]), L.ptr(S[1]), L.ptr(S[2]),
+                                            L.stream_ptr()), "interp_bn_bwd_sums")
+    return S
+
+
+def interp_bn_bwd_apply(G, idx, dist, order, dlogit, w_fc, scale, shift, k2, k3, mask=None):
+    """-> dG [ns, B*m, 256] = interp^T(scale*dz - k2 - k3*h)."""
+    ns, Rc, _ = G.shape
+    B, n = idx.shape[0], idx.shape[1]
+    dG = torch.empty_like(G)
+    L.check(L.lib().dh3d_interp_bn_bwd_apply(L.ptr(G), ns * 256, L.ptr(idx), L.ptr(dist), L.ptr(order), B, n, Rc // B,
+                                             L.ptr(_mask_u8(mask)), L.ptr(dlogit), L.ptr(w_fc), L.ptr(scale),
+                                             L.ptr(shift), L.ptr(k2), L.ptr(k3), L.ptr(dG), L.stream_ptr()),
+            "interp_bn_bwd_apply")
+    return dG
+
+
 def netvlad_assign_rows(s, scale, shift, att):
     s = L.require_cuda_f32(s, "s", 2)
     a = torch.empty_like(s)

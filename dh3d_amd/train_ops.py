@@ -170,6 +170,78 @@ def attention_head(X, conv, wfc, bfc, sync=False, mask=None, rows_per_cloud=0):
                                 bn.variance_EMA, bn.eps, 0.9, wfc, bfc, sync, mask, rows_per_cloud)
 
 
+class _AttentionHeadCommuted(torch.autograd.Function):
+    """The same head on the up-sampled rows three_interpolate(C) WITHOUT building them: conv(interp(C)) = interp(conv(C)),
+    so the three big GEMMs run on the sampled rows C [Bt*M, Cin] and the [Bt*N, H] pre-activation only exists inside
+    the kernels of csrc/interp_train.hip (statistics, forward, backward sums, backward apply + scatter)."""
+
+    @staticmethod
+    def forward(ctx, C, W, b, gamma, beta, run_mean, run_var, eps, momentum, wfc, bfc, sync, mask, idx, dist, order):
+        C = C.contiguous()
+        Wd, bd = W.detach(), b.detach()
+        H = Wd.shape[1]
+        ns = H // 256
+        G = torch.empty((ns, C.shape[0], 256), dtype=torch.float32, device=C.device)
+        Wt = Wd.reshape(Wd.shape[0], ns, 256).transpose(0, 1).contiguous()              # [ns, Cin, 256]
+        for j in range(ns):
+            pm.gemm_nn(C, Wt[j], bias=bd[j * 256:(j + 1) * 256].contiguous(), out=G[j])
+        Bt, N = idx.shape[0], idx.shape[1]
+        g, be = gamma.detach().contiguous(), beta.detach().contiguous()
+        packed = torch.empty((2 * H + 1,), dtype=torch.float64, device=C.device)
+        s1, s2 = pm.interp_bn_colstats(G, idx, dist, order, mask, out=packed)
+        cnt = _count(Bt * N, mask, N, C.device)
+        if sync and _world() > 1:
+            packed[2 * H:] = cnt
+            D.all_reduce_sum_(packed)
+            cnt = packed[2 * H:]
+        st = _BNState()
+        st.stats = pm.bn_finalize(s1, s2, cnt, g, be, eps, momentum, run_mean, run_var)
+        st.cnt = cnt
+        wv = wfc.detach().reshape(-1).contiguous()
+        att = pm.interp_head_rows(G, idx, dist, order, st.stats[2], st.stats[3], wv, bfc.detach().reshape(-1).contiguous())
+        ctx.save_for_backward(C, Wt, G, g, be, wv, att)
+        ctx.cfg = (bool(sync), mask, idx, dist, order, st, W.shape, wfc.shape)
+        return att
+
+    @staticmethod
+    def backward(ctx, datt):
+        C, Wt, G, g, be, wv, att = ctx.saved_tensors
+        sync, mask, idx, dist, order, st, wshape, wfcshape = ctx.cfg
+        N = idx.shape[1]
+        dlogit = (datt * att * (1.0 - att)).contiguous()
+        if mask is not None:
+            dlogit = dlogit * mask.repeat_interleave(N).to(dlogit.dtype)
+        S = pm.interp_bn_bwd_sums(G, idx, dist, order, dlogit, wv, st.stats[0], st.stats[1], g, be, mask)
+        dwfc = S[2].float().reshape(wfcshape)
+        dbfc = dlogit.sum().reshape(1)
+        dgamma, dbeta, k = _backward_coeffs(S, st, g, sync)
+        dG = pm.interp_bn_bwd_apply(G, idx, dist, order, dlogit, wv, st.stats[2], st.stats[3], k[0], k[1], mask)
+        ns = G.shape[0]
+        dW = torch.empty((ns, C.shape[1], 256), dtype=torch.float32, device=C.device)
+        dC = torch.empty_like(C) if ctx.needs_input_grad[0] else None
+        Wtt = pm.transpose_last2(Wt)                                                     # [ns, 256, Cin]
+        for j in range(ns):
+            pm.gemm_tn(C, dG[j], out=dW[j])
+            if dC is not None:
+                pm.gemm_nn(dG[j], Wtt[j], out=dC, accumulate=(j > 0))
+        dW = dW.transpose(0, 1).reshape(wshape)
+        db = torch.zeros_like(g)   # the BatchNorm removes any per-channel constant: exact gradient 0
+        return dC, dW, db, dgamma, dbeta, None, None, None, None, dwfc, dbfc, None, None, None, None, None
+
+
+def attention_head_commuted(coarse, conv, wfc, bfc, idx, dist, order, sync=False, mask=None):
+    """globalatt_block on the rows three_interpolate(coarse [Bt*M, Cin]) (inverse-distance weights of `dist`), never
+    materialised.  idx / dist [Bt,N,3] int32 / float32, order = spatial_sort records of the fine clouds [Bt,N,4].
+    Returns att [Bt*N]."""
+    bn = conv.bn
+    return _AttentionHeadCommuted.apply(coarse, conv.W.reshape(conv.cin, conv.cout), conv.b, bn.gamma, bn.beta,
+                                        bn.mean_EMA, bn.variance_EMA, bn.eps, 0.9, wfc, bfc, sync, mask, idx, dist, order)
+
+
+def attention_commute_supported(conv, M):
+    return conv.cout % 256 == 0 and 256 <= conv.cout <= 1024 and conv.cin % 4 == 0 and M <= 1024
+
+
 class _NetVLADAssign(torch.autograd.Function):
     """x [Bt, N, D] rows, att [Bt*N] -> (V [Bt, Cl, D] = sum_n a[n,c] xn[n,d],  asum [Bt, Cl] = sum_n a[n,c])."""
 

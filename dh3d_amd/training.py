@@ -175,7 +175,7 @@ def global_head_autograd(model, points, localdesc, lv, bn_training=True, sync_bn
     return v * torch.sigmoid(gates)
 
 
-def global_head_hip(model, points, localdesc, lv, sync_bn=False, mask=None):
+def global_head_hip(model, points, localdesc, lv, sync_bn=False, mask=None, commute_attention=True):
     """compute_global (core/model.py:112-133) in training mode with every row-level operator -- flex_conv, the three
     training-mode BatchNorms on rows, three_interpolate, the attention MLP, NetVLAD's assignment / aggregation -- as a
     hand-written HIP kernel in BOTH directions (dh3d_amd.train_ops, csrc/train.hip / gemm.hip / flex_bwd.hip); what is
@@ -197,7 +197,16 @@ def global_head_hip(model, points, localdesc, lv, sync_bn=False, mask=None):
     w = (1.0 / d) / (1.0 / d).sum(2, keepdim=True)
     forglobal = ops.three_interpolate(new_feat, lv["nn3_idx"], w.contiguous())      # [Bt,N,256]
     fcw = att_mod.detec_conv_fc
-    att = T.attention_head(forglobal.reshape(Bt * N, Dg), att_mod.detec_conv0, fcw.W, fcw.b, sync_bn, mask, N)
+    if commute_attention and T.attention_commute_supported(att_mod.detec_conv0, M):
+        # conv(interp(c)) = interp(conv(c)): the head's GEMMs on the Bt*M sampled rows, its [Bt*N, 1024] pre-activation
+        # never written (csrc/interp_train.hip); the fine clouds' Morton records come from the geometry level if it has
+        # them (compute_level stores them for N >= 4096)
+        from . import pm
+        order = lv["_ordered"][0] if "_ordered" in lv else pm.spatial_sort(points)[0]
+        att = T.attention_head_commuted(new_feat.reshape(Bt * M, Dg), att_mod.detec_conv0, fcw.W, fcw.b, lv["nn3_idx"],
+                                        lv["nn3_dist"], order, sync_bn, mask)
+    else:
+        att = T.attention_head(forglobal.reshape(Bt * N, Dg), att_mod.detec_conv0, fcw.W, fcw.b, sync_bn, mask, N)
     V, asum = T.netvlad_assign(forglobal, att, nv.cluster_weights, nv.cluster_bn, sync_bn, mask)   # [Bt,C,D], [Bt,C]
     vlad = V.transpose(1, 2) - asum.unsqueeze(1) * nv.cluster_weights2              # [Bt,D,C]  (backbones.py:241-256)
     vlad = vlad * torch.rsqrt(torch.clamp((vlad * vlad).sum(1, keepdim=True), min=1e-12))

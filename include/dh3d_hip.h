@@ -340,6 +340,10 @@ int dh3d_interp_head_fwd(const float *H, int Hd, const int32_t *idx, const float
 int dh3d_interp_head_sorted_fwd(const float *H, int Hd, const int32_t *idx, const float *dist, const float *order, int B,
                                 int n, int m, const dh3d_epilogue *ep, const float *w_fc, float b_fc, float *att,
                                 void *stream);
+/* the same with the fc bias in device memory (a trainable parameter) */
+int dh3d_interp_head_sorted_fwd_dev(const float *H, int Hd, const int32_t *idx, const float *dist, const float *order,
+                                    int B, int n, int m, const dh3d_epilogue *ep, const float *w_fc,
+                                    const float *b_fc_dev, float *att, void *stream);
 /* The tail of a concat conv commuted through the up-sampling (C = 128):
  *   out[n] = act(BN(interp3(coarse_w)[n] + partial[n] + pre_bias)) + residual[n]     (or [prefix | l2_normalize(.)])
  * coarse_w [B,M,C] = coarse rows already multiplied by the conv's upper weight block, partial [B,N,C] = the lower block
@@ -440,6 +444,25 @@ int dh3d_netvlad_assign_rows(const float *s, long long R, int Cl, const float *s
 int dh3d_netvlad_assign_rows_bwd(const float *s, long long R, int Cl, const float *scale, const float *shift,
                                  const float *att, const float *da, float *dz, float *datt, void *stream);
 int dh3d_l2norm_rows_bwd(const float *x, const float *dxn, long long R, int C, float eps, float *dx, void *stream);
+/* Training-mode attention head with its convolution commuted through the up-sampling (csrc/interp_train.hip): the
+ * pre-activation h = three_interpolate(G) of globalatt_block (core/backbones.py:89-100,156-173), G = the 256-column slices
+ * [Hd/256][B*m][256] of coarse @ W + b, is never materialised.  idx / dist [B,n,3] = three_nn of the fine points, order =
+ * dh3d_spatial_sort records [B,n,4] of the fine cloud (NULL: index order), mask [B] bytes (NULL: all clouds live).
+ *   colstats : sum, sumsq [Hd] f64 of h over the live rows (zeroed by the call) -> dh3d_bn_finalize
+ *   forward  : dh3d_interp_head_sorted_fwd with the folded batch statistics as its epilogue
+ *   bwd_sums : S1, S2, S3 [Hd] f64 of dh3d_bn_bwd_sums for dy = dlogit x w_fc (dlogit [B*n] by original point index)
+ *   bwd_apply: dG [Hd/256][B*m][256] = interp^T(scale dz - k2 - k3 h) (zeroed by the call, f32 atomics), from which
+ *              dW = coarse^T dG and dcoarse = dG W^T are GEMMs on B*m rows.  Hd <= 1024, m <= 1024. */
+int dh3d_interp_bn_colstats(const float *G, int Hd, const int32_t *idx, const float *dist, const float *order, int B,
+                            int n, int m, const unsigned char *mask, double *sum, double *sumsq, void *stream);
+int dh3d_interp_bn_bwd_sums(const float *G, int Hd, const int32_t *idx, const float *dist, const float *order, int B,
+                            int n, int m, const unsigned char *mask, const float *dlogit, const float *w_fc,
+                            const float *mean, const float *rstd, const float *gamma, const float *beta, double *S1,
+                            double *S2, double *S3, void *stream);
+int dh3d_interp_bn_bwd_apply(const float *G, int Hd, const int32_t *idx, const float *dist, const float *order, int B,
+                             int n, int m, const unsigned char *mask, const float *dlogit, const float *w_fc,
+                             const float *scale, const float *shift, const float *k2, const float *k3, float *dG,
+                             void *stream);
 /* batched GEMMs: `batch` independent products on operands stored back to back; colbias [batch, N] (nn only). */
 int dh3d_gemm_tn_f32_batched(const float *A, const float *B, int batch, int K, int M, int N, float *C, void *stream);
 int dh3d_gemm_nn_f32_batched(const float *A, const float *B, const float *colbias, int batch, int M, int K, int N,

@@ -327,3 +327,57 @@ def test_hip_head_matches_torch_head_forward_and_gradients(dev):
             assert float((a - b).abs().max()) <= tol, (n, float((a - b).abs().max()), float(b.abs().max()))
         for k in b0:
             assert torch.allclose(b0[k], b1[k], rtol=1e-4, atol=1e-5), k
+
+
+@pytest.mark.parametrize("N,use_mask", [(4096, False), (4096, True), (5000, False)])
+def test_commuted_attention_head_matches_the_materialised_one(dev, N, use_mask):
+    """train_ops.attention_head_commuted (conv commuted through three_interpolate, pre-activation never written,
+    csrc/interp_train.hip) == train_ops.attention_head on the materialised up-sampled rows: attention weights, the
+    gradients of every parameter and of the sampled features, BatchNorm running buffers.  Same math reassociated; the
+    scatter and the statistics use f32 / f64 atomics (run-to-run jitter ~1e-6)."""
+    from dh3d_amd import ops, pm, train_ops as T
+    g = torch.Generator().manual_seed(N + use_mask)
+    Bt, M, Cin = 3, N // 8, 256
+    pts = torch.rand(Bt, N, 3, generator=g).to(dev)
+    samp = ops.farthest_point_sample(M, pts)
+    cxyz = torch.gather(pts, 1, samp.long()[:, :, None].expand(-1, -1, 3)).contiguous()
+    d3, i3 = ops.three_nn(pts, cxyz)
+    order = pm.spatial_sort(pts)[0]
+    mask = torch.tensor([True, False, True], device=dev) if use_mask else None
+    res = []
+    for commuted in (True, False):
+        m = _build(dev, seed=3)
+        conv, fcw = m.globalatt.detec_conv0, m.globalatt.detec_conv_fc
+        with torch.no_grad():
+            conv.bn.gamma.copy_(0.5 + torch.rand(conv.cout, generator=torch.Generator().manual_seed(1)).to(dev))
+            conv.bn.beta.copy_(0.3 * torch.randn(conv.cout, generator=torch.Generator().manual_seed(2)).to(dev))
+        coarse = torch.randn(Bt, M, Cin, generator=torch.Generator().manual_seed(7)).to(dev).requires_grad_(True)
+        if commuted:
+            att = T.attention_head_commuted(coarse.reshape(Bt * M, Cin), conv, fcw.W, fcw.b, i3, d3, order, False, mask)
+        else:
+            dd = torch.clamp(d3, min=1e-10)
+            w = (1.0 / dd) / (1.0 / dd).sum(2, keepdim=True)
+            up = ops.three_interpolate(coarse, i3, w.contiguous())
+            att = T.attention_head(up.reshape(Bt * N, Cin), conv, fcw.W, fcw.b, False, mask, N)
+        wgt = torch.randn(Bt * N, generator=torch.Generator().manual_seed(9)).to(dev)
+        if mask is not None:
+            wgt = wgt * mask.repeat_interleave(N).float()
+        (att * wgt).sum().backward()
+        ps = [conv.W, conv.bn.gamma, conv.bn.beta, fcw.W, fcw.b]
+        res.append((att.detach(), coarse.grad.clone(), [p.grad.clone() for p in ps],
+                    (conv.bn.mean_EMA.clone(), conv.bn.variance_EMA.clone())))
+    (a0, c0, g0, b0), (a1, c1, g1, b1) = res
+    live = slice(None) if mask is None else mask.repeat_interleave(N)
+    assert float((a0[live] - a1[live]).abs().max()) < 2e-6
+    # The two sides compute the pre-activation with different roundings (interp of a GEMM vs GEMM of an interp, ~1e-6
+    # apart): of the 12 M ReLU inputs a handful lie that close to zero and take the other branch, which moves the
+    # gradient entries they feed by up to ~1 % of the largest one.  So: the bulk must agree tightly (norm-wise), single
+    # entries within 2 %.
+    def agree(x, y, name):
+        rel = float((x - y).norm() / (y.norm() + 1e-30))
+        assert rel <= 2e-3, (name, rel)
+        assert float((x - y).abs().max()) <= 2e-2 * float(y.abs().max()) + 1e-7, (name, float((x - y).abs().max()))
+    agree(c0, c1, "dcoarse")
+    for name, x, y in zip(("W", "gamma", "beta", "wfc", "bfc"), g0, g1):
+        agree(x, y, name)
+    assert torch.allclose(b0[0], b1[0], rtol=1e-5, atol=1e-6) and torch.allclose(b0[1], b1[1], rtol=1e-5, atol=1e-6)

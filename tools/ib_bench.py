@@ -1,0 +1,28 @@
+"""Timing of the commuted attention head's passes (csrc/interp_train.hip) at the training shape (22 x 4096 -> 512)."""
+import torch, sys
+from dh3d_amd import ops, pm
+dev = torch.device("cuda")
+g = torch.Generator().manual_seed(1)
+Bt, N = 22, 4096
+M = N // 8
+pts = torch.rand(Bt, N, 3, generator=g).to(dev)
+samp = ops.farthest_point_sample(M, pts)
+cxyz = torch.gather(pts, 1, samp.long()[:, :, None].expand(-1, -1, 3)).contiguous()
+d3, i3 = ops.three_nn(pts, cxyz)
+order = pm.spatial_sort(pts)[0]
+G = torch.randn(4, Bt * M, 256, generator=g).to(dev)
+H = 1024
+v = [torch.randn(H, generator=g).to(dev) for _ in range(6)]
+sc = (0.5 + torch.rand(H, generator=g)).to(dev)
+dl = torch.randn(Bt * N, generator=g).to(dev)
+def t(fn, reps=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+print("colstats  %.1f us" % t(lambda: pm.interp_bn_colstats(G, i3, d3, order)))
+print("bwd_sums  %.1f us" % t(lambda: pm.interp_bn_bwd_sums(G, i3, d3, order, dl, v[0], v[1], sc, sc, v[2])))
+print("bwd_apply %.1f us" % t(lambda: pm.interp_bn_bwd_apply(G, i3, d3, order, dl, v[0], sc, v[3], v[4], v[5])))
