@@ -170,6 +170,40 @@ def attention_head(X, conv, wfc, bfc, sync=False, mask=None, rows_per_cloud=0):
                                 bn.variance_EMA, bn.eps, 0.9, wfc, bfc, sync, mask, rows_per_cloud)
 
 
+class _ThreeInterpolateSorted(torch.autograd.Function):
+    """ops.three_interpolate with the backward on the Morton order of the fine cloud (csrc/interp_train.hip MODE 3)."""
+
+    @staticmethod
+    def forward(ctx, points, idx, weight, order):
+        from . import _lib as L
+        p = points.contiguous()
+        b, m, c = p.shape
+        n = idx.shape[1]
+        out = torch.empty((b, n, c), dtype=torch.float32, device=p.device)
+        L.check(L.lib().dh3d_three_interpolate_fwd(b, m, c, n, L.ptr(p), L.ptr(idx), L.ptr(weight), L.ptr(out),
+                                                   L.stream_ptr()), "three_interpolate")
+        ctx.save_for_backward(idx, weight, order)
+        ctx.pshape = (b, m, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from . import _lib as L
+        idx, weight, order = ctx.saved_tensors
+        b, m, c = ctx.pshape
+        go = grad_out.contiguous()
+        gp = torch.empty((b, m, c), dtype=torch.float32, device=go.device)
+        L.check(L.lib().dh3d_three_interpolate_bwd_sorted(b, idx.shape[1], c, m, L.ptr(go), L.ptr(idx), L.ptr(weight),
+                                                          L.ptr(order), L.ptr(gp), L.stream_ptr()),
+                "three_interpolate_bwd_sorted")
+        return gp, None, None, None
+
+
+def three_interpolate_sorted(points, idx, weight, order):
+    """points [b,m,256], idx / weight [b,n,3], order = spatial_sort records of the fine cloud [b,n,4] -> [b,n,256]."""
+    return _ThreeInterpolateSorted.apply(points, idx.contiguous(), weight.contiguous(), order.contiguous())
+
+
 class _AttentionHeadCommuted(torch.autograd.Function):
     """The same head on the up-sampled rows three_interpolate(C) WITHOUT building them: conv(interp(C)) = interp(conv(C)),
     so the three big GEMMs run on the sampled rows C [Bt*M, Cin] and the [Bt*N, H] pre-activation only exists inside

@@ -195,14 +195,19 @@ def global_head_hip(model, points, localdesc, lv, sync_bn=False, mask=None, comm
     new_feat = T.batch_norm_train(x.reshape(Bt * M, Dg), fbn, True, sync_bn, mask, M).reshape(Bt, M, Dg)
     d = torch.clamp(lv["nn3_dist"], min=1e-10)                                      # backbones.py:92-95
     w = (1.0 / d) / (1.0 / d).sum(2, keepdim=True)
-    forglobal = ops.three_interpolate(new_feat, lv["nn3_idx"], w.contiguous())      # [Bt,N,256]
     fcw = att_mod.detec_conv_fc
-    if commute_attention and T.attention_commute_supported(att_mod.detec_conv0, M):
-        # conv(interp(c)) = interp(conv(c)): the head's GEMMs on the Bt*M sampled rows, its [Bt*N, 1024] pre-activation
-        # never written (csrc/interp_train.hip); the fine clouds' Morton records come from the geometry level if it has
-        # them (compute_level stores them for N >= 4096)
+    sorted_walks = commute_attention and T.attention_commute_supported(att_mod.detec_conv0, M) and Dg == 256
+    if sorted_walks:
+        # the fine clouds' Morton records: from the geometry level if it has them (compute_level stores them for
+        # N >= 4096); three_interpolate's backward and the attention head walk the points in that order
         from . import pm
         order = lv["_ordered"][0] if "_ordered" in lv else pm.spatial_sort(points)[0]
+        forglobal = T.three_interpolate_sorted(new_feat, lv["nn3_idx"], w, order)   # [Bt,N,256]
+    else:
+        forglobal = ops.three_interpolate(new_feat, lv["nn3_idx"], w.contiguous())
+    if sorted_walks:
+        # conv(interp(c)) = interp(conv(c)): the head's GEMMs on the Bt*M sampled rows, its [Bt*N, 1024] pre-activation
+        # never written (csrc/interp_train.hip)
         att = T.attention_head_commuted(new_feat.reshape(Bt * M, Dg), att_mod.detec_conv0, fcw.W, fcw.b, lv["nn3_idx"],
                                         lv["nn3_dist"], order, sync_bn, mask)
     else:

@@ -463,6 +463,13 @@ int dh3d_interp_bn_bwd_apply(const float *G, int Hd, const int32_t *idx, const f
                              int n, int m, const unsigned char *mask, const float *dlogit, const float *w_fc,
                              const float *scale, const float *shift, const float *k2, const float *k3, float *dG,
                              void *stream);
+/* three_interpolate's backward (threeinterpolate_grad_cpu, tf_interpolate.cpp:131-153) on the Morton order of the fine
+ * cloud (order = dh3d_spatial_sort records [b,n,4], NULL: index order): the rows of a 128-point block are scattered onto
+ * the <= 56 coarse rows it touches by an MFMA product in LDS, then added to grad_points [b,m,c] (zeroed by the call) with
+ * one f32 atomic per (block, row, channel).  c == 256, m <= 1024; same result as dh3d_three_interpolate_bwd up to the
+ * summation order. */
+int dh3d_three_interpolate_bwd_sorted(int b, int n, int c, int m, const float *grad_out, const int32_t *idx,
+                                      const float *weight, const float *order, float *grad_points, void *stream);
 /* batched GEMMs: `batch` independent products on operands stored back to back; colbias [batch, N] (nn only). */
 int dh3d_gemm_tn_f32_batched(const float *A, const float *B, int batch, int K, int M, int N, float *C, void *stream);
 int dh3d_gemm_nn_f32_batched(const float *A, const float *B, const float *colbias, int batch, int M, int K, int N,

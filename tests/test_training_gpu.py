@@ -381,3 +381,33 @@ def test_commuted_attention_head_matches_the_materialised_one(dev, N, use_mask):
     for name, x, y in zip(("W", "gamma", "beta", "wfc", "bfc"), g0, g1):
         agree(x, y, name)
     assert torch.allclose(b0[0], b1[0], rtol=1e-5, atol=1e-6) and torch.allclose(b0[1], b1[1], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,N,scrambled", [(3, 4096, False), (2, 5000, False), (2, 4096, True)])
+def test_three_interpolate_sorted_backward_matches_the_drop_in_op(dev, B, N, scrambled):
+    """train_ops.three_interpolate_sorted: same forward kernel, backward on the Morton order (MFMA scatter in LDS, one
+    atomic per block, row and channel) == ops.three_interpolate's backward (threeinterpolate_grad_cpu,
+    tf_interpolate.cpp:131-153) up to the summation order.  `scrambled`: neighbours without spatial coherence -- every
+    block exceeds the 56 staged rows and takes the overflow path."""
+    from dh3d_amd import ops, pm, train_ops as T
+    g = torch.Generator().manual_seed(N + B)
+    M, C = N // 8, 256
+    pts = torch.rand(B, N, 3, generator=g).to(dev)
+    samp = ops.farthest_point_sample(M, pts)
+    cxyz = torch.gather(pts, 1, samp.long()[:, :, None].expand(-1, -1, 3)).contiguous()
+    d3, i3 = ops.three_nn(pts, cxyz)
+    if scrambled:
+        i3 = torch.randint(0, M, (B, N, 3), generator=g, dtype=torch.int32).to(dev)
+    dd = torch.clamp(d3, min=1e-10)
+    w = ((1.0 / dd) / (1.0 / dd).sum(2, keepdim=True)).contiguous()
+    order = pm.spatial_sort(pts)[0]
+    go = torch.randn(B, N, C, generator=g).to(dev)
+    outs = []
+    for fn in (lambda p: T.three_interpolate_sorted(p, i3, w, order), lambda p: ops.three_interpolate(p, i3, w)):
+        p = torch.randn(B, M, C, generator=torch.Generator().manual_seed(4)).to(dev).requires_grad_(True)
+        y = fn(p)
+        y.backward(go)
+        outs.append((y.detach(), p.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    err = float((outs[0][1] - outs[1][1]).abs().max())
+    assert err <= 2e-5 * float(outs[1][1].abs().max()), err
