@@ -690,21 +690,40 @@ __global__ __launch_bounds__(256) void knn_small_kernel(const float *__restrict_
       const float d = sqrtf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
       kd[c] = tbk[c] != 0xFFFFFFFFu ? __float_as_uint(d) : 0xFFFFFFFFu;
     }
+    // Every lane caches its two smallest admissible keys (m1 < m2): a round is then two wave minima and a pop in the
+    // winning lane; the per-lane scan over all CPL keys -- most of a round before -- is redone only when some lane has
+    // used up both (it won three of the rounds so far: rare, the K nearest spread over the 64 lanes).
     u64 need = 0;  // smallest key still admissible
     unsigned my_hi = 0xFFFFFFFFu, my_lo = 0xFFFFFFFFu;  // lane r keeps result r
-    for (int r = 0; r < K; ++r) {
-      u64 m = ~0ull;
+    u64 m1 = ~0ull, m2 = ~0ull;
+    bool more = false;  // this lane may hold admissible keys beyond m2
+    auto rescan = [&]() {
+      m1 = ~0ull; m2 = ~0ull;
+      int cnt = 0;
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
         const u64 key = ((u64)kd[c] << 32) | tbk[c];
-        m = (key >= need && key < m) ? key : m;
+        const bool ok = key >= need && key != ~0ull;
+        const bool c1 = ok && key < m1, c2 = ok && key < m2;
+        m2 = c1 ? m1 : (c2 ? key : m2);
+        m1 = c1 ? key : m1;
+        cnt += ok ? 1 : 0;
       }
-      const unsigned hi = wave_min_u32((unsigned)(m >> 32));
-      const unsigned lo = wave_min_u32((unsigned)(m >> 32) == hi ? (unsigned)m : 0xFFFFFFFFu);
+      more = cnt > 2;
+    };
+    rescan();
+    for (int r = 0; r < K; ++r) {
+      const unsigned hi = wave_min_u32((unsigned)(m1 >> 32));
+      const unsigned lo = wave_min_u32((unsigned)(m1 >> 32) == hi ? (unsigned)m1 : 0xFFFFFFFFu);
       if (lane == r) { my_hi = hi; my_lo = lo; }
       const u64 sel = ((u64)hi << 32) | lo;
       if (sel == ~0ull) break;  // fewer than K points: the remaining slots keep the pad value
       need = sel + 1;
+      const bool won = m1 == sel;
+      const bool dry = won && m2 == ~0ull && more;  // both cached keys used, more behind them
+      m1 = won ? m2 : m1;
+      m2 = won ? ~0ull : m2;
+      if (__ballot(dry) != 0ull) rescan();  // wave-uniform
     }
     if (lane < K) {
       const size_t o = ((size_t)b * N + q) * K + lane;
