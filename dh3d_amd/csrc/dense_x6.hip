@@ -816,25 +816,38 @@ __global__ __launch_bounds__(256) void interp_head_lds_kernel(const float *__res
   const bool overflow = s_pre[32] > kIHCap;  // block-uniform: some rows are not staged
   const float lo = ep.act == DH3D_ACT_RELU ? 0.f : -__builtin_inff();  // ReLU as a clamp, or no activation
   if (tid < kIHP) s_z[tid] = 0.f;
+  // ---- staging: wave w takes slots w, w + 4, ...; the rows of slice sl + 1 are requested BEFORE the points of slice
+  // sl are worked on and parked in registers until the buffer is free (staging and per-point work took about the same
+  // time when they ran one after the other).  The parked rows are ONE 64-float vector value: as a float4 array the
+  // compiler kept them in scratch, stored behind every load and reloaded -- which is why the first attempt at this
+  // double buffer measured slower (139 vs 100 us).
+  typedef float f32x64 __attribute__((ext_vector_type(64)));
+  static_assert(kIHCap / 4 <= 16, "parked rows: one f32x64");
+  int rowoff[kIHCap / 4];
+#pragma unroll
+  for (int u = 0; u < kIHCap / 4; ++u) {
+    const int r = wave + 4 * u;
+    rowoff[u] = (bi * m + s_row[r < nd ? r : 0]) * 256 + lane * 4;
+  }
+  f32x64 rg;
+#define DH3D_IH_REQUEST(SL)                                                                     \
+  {                                                                                             \
+    const float *Hn = H + (size_t)(SL) * Rc * 256;                                              \
+    _Pragma("unroll") for (int u = 0; u < kIHCap / 4; ++u) {                                    \
+      const float4 v = *reinterpret_cast<const float4 *>(Hn + rowoff[u]);                       \
+      rg[4 * u] = v.x; rg[4 * u + 1] = v.y; rg[4 * u + 2] = v.z; rg[4 * u + 3] = v.w;           \
+    }                                                                                           \
+  }
+  DH3D_IH_REQUEST(0)
   for (int sl = 0; sl < NS; ++sl) {
     const float *Hs = H + ((size_t)sl * Rc + (size_t)bi * m) * 256;
-    // ---- stage the distinct rows of this slice: wave w takes slots w, w + 4, ...; every load of the wave is in flight
-    // before the first LDS store (a load-store loop would pay the L2 latency once per row).  (Requesting the NEXT
-    // slice's rows before computing the current one -- a register double buffer -- was slower, 139 vs 100 us: the
-    // compute phase's overflow path shares the in-order load counter with them.)
-    {
-      float4 rg[kIHCap / 4];
 #pragma unroll
-      for (int u = 0; u < kIHCap / 4; ++u) {
-        const int r = wave + 4 * u;
-        rg[u] = *reinterpret_cast<const float4 *>(Hs + (size_t)s_row[r < nd ? r : 0] * 256 + lane * 4);
-      }
-#pragma unroll
-      for (int u = 0; u < kIHCap / 4; ++u) {
-        const int r = wave + 4 * u;
-        if (r < nd) *reinterpret_cast<float4 *>(s_rows + (size_t)r * 256 + lane * 4) = rg[u];
-      }
+    for (int u = 0; u < kIHCap / 4; ++u) {  // all slots, used or not: no branch between the loads and these stores
+      const int r = wave + 4 * u;
+      *reinterpret_cast<float4 *>(s_rows + (size_t)r * 256 + lane * 4) =
+          make_float4(rg[4 * u], rg[4 * u + 1], rg[4 * u + 2], rg[4 * u + 3]);
     }
+    DH3D_IH_REQUEST(sl + 1 < NS ? sl + 1 : sl)  // (unconditional -- the last slice once more)
     const int c = sl * 256 + lane * 4;
     float4 pb = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = pb;
     if (ep.pre_bias) pb = *reinterpret_cast<const float4 *>(ep.pre_bias + c);

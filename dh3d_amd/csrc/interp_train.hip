@@ -60,6 +60,20 @@ __device__ __forceinline__ float4 row4(const float *s_rows, const float *gbase, 
   return *reinterpret_cast<const float4 *>(s_rows + (size_t)slot * 256 + lane * 4);
 }
 
+// The parked rows live in ONE 64-float vector value (an SSA value: a float4 array of the same size was kept in scratch
+// -- stored right behind every load and reloaded -- whatever the control flow around it looked like).
+typedef float f32x64 __attribute__((ext_vector_type(64)));
+template <int NR>
+__device__ __forceinline__ f32x64 request_rows(const float *Gslice, const int (&rowoff)[NR]) {
+  f32x64 rg;
+#pragma unroll
+  for (int u = 0; u < NR; ++u) {
+    const float4 v = *reinterpret_cast<const float4 *>(Gslice + rowoff[u]);
+    rg[4 * u] = v.x; rg[4 * u + 1] = v.y; rg[4 * u + 2] = v.z; rg[4 * u + 3] = v.w;
+  }
+  return rg;
+}
+
 struct InterpBnArgs {
   const float *G;            // [NS][Rc][256] slices of coarse @ W + b
   int NS;
@@ -72,7 +86,7 @@ struct InterpBnArgs {
   const float *dlogit;       // [B * n] by original point index (MODE 1, 2)
   const float *wfc;          // [NS * 256]
   const float *v0, *v1, *v2, *v3;  // MODE 1: mean, rstd, gamma, beta;  MODE 2: scale, shift, k2, k3
-  double *s0, *s1, *s2;      // MODE 0: sum, sumsq;  MODE 1: S1, S2, S3
+  double *s0, *s1, *s2;      // MODE 0: sum, sumsq;  MODE 1: S1, S2, S3 -- one partial row [Hd] per cloud
   float *dG;                 // MODE 2: [NS][Rc][256]
   const float *dY;           // MODE 3: [B * n, 256] gradient rows by original point index
   const float *weight;       // MODE 3: [B, n, 3] interpolation weights (instead of dist)
@@ -153,21 +167,37 @@ __global__ __launch_bounds__(256) void interp_bn_kernel(const InterpBnArgs a) {
   const int nd = min(s_pre[32], CAP);
   const bool overflow = s_pre[32] > CAP;
 
+  // The rows of slice sl + 1 are requested BEFORE the points of slice sl are worked on and parked in registers (CAP / 4
+  // float4 per lane) until the buffer is free: staging and per-point work each took ~32 us of the 97 us statistics
+  // pass when they ran one after the other.
+  static_assert(CAP / 4 <= 16, "parked rows: one f32x64");
+  f32x64 rg = {};
+  int rowoff[CAP / 4];  // this lane's float offset into a slice for each of its rows
+#pragma unroll
+  for (int u = 0; u < CAP / 4; ++u) {
+    const int r = wave + 4 * u;
+    rowoff[u] = (bi * m + s_row[r < nd ? r : 0]) * 256 + lane * 4;
+  }
+  // (not in MODE 2: 64 more registers would leave one wave per SIMD there)
+  constexpr bool PREFETCH = MODE != 2;
+#if !defined(DH3D_IB_EXP) || !(DH3D_IB_EXP & 16)   // exp 16: no staging (results wrong)
+  if (MODE != 3 && PREFETCH) rg = request_rows<CAP / 4>(a.G, rowoff);
+#endif
   for (int sl = 0; sl < a.NS; ++sl) {
     const float *Gs = MODE == 3 ? nullptr : a.G + (size_t)sl * a.Rc * 256 + (size_t)bi * m * 256;
+#if !defined(DH3D_IB_EXP) || !(DH3D_IB_EXP & 16)
     if (MODE != 3) {
-      float4 rg[CAP / 4];
+      if (!PREFETCH) rg = request_rows<CAP / 4>(a.G + (size_t)sl * a.Rc * 256, rowoff);
 #pragma unroll
-      for (int u = 0; u < CAP / 4; ++u) {
+      for (int u = 0; u < CAP / 4; ++u) {  // all CAP slots, used or not: no branch between the loads and these stores
         const int r = wave + 4 * u;
-        rg[u] = *reinterpret_cast<const float4 *>(Gs + (size_t)s_row[r < nd ? r : 0] * 256 + lane * 4);
+        *reinterpret_cast<float4 *>(s_rows + (size_t)r * 256 + lane * 4) =
+            make_float4(rg[4 * u], rg[4 * u + 1], rg[4 * u + 2], rg[4 * u + 3]);
       }
-#pragma unroll
-      for (int u = 0; u < CAP / 4; ++u) {
-        const int r = wave + 4 * u;
-        if (r < nd) *reinterpret_cast<float4 *>(s_rows + (size_t)r * 256 + lane * 4) = rg[u];
-      }
+      // (unconditional -- the last slice once more: a load under a branch would be merged through memory)
+      if (PREFETCH) rg = request_rows<CAP / 4>(a.G + (size_t)(sl + 1 < a.NS ? sl + 1 : sl) * a.Rc * 256, rowoff);
     }
+#endif
     const int c = sl * 256 + lane * 4;
     float4 q0 = {}, q1 = {}, q2 = {}, q3 = {}, wf = {};
     if (MODE == 1 || MODE == 2) {
@@ -210,7 +240,9 @@ __global__ __launch_bounds__(256) void interp_bn_kernel(const InterpBnArgs a) {
           }
         }
       };
+#if !defined(DH3D_IB_EXP) || !(DH3D_IB_EXP & 32)   // exp 32: no per-point work (results wrong)
       if (overflow) points(std::true_type{}); else points(std::false_type{});
+#endif
       // the four waves hold different points of the same channels: through LDS (the row buffer is dead by now), then
       // one f64 atomic per channel
       __syncthreads();
@@ -220,12 +252,16 @@ __global__ __launch_bounds__(256) void interp_bn_kernel(const InterpBnArgs a) {
       if (MODE == 1) *reinterpret_cast<float4 *>(red + (2 * 4 + wave) * 256 + lane * 4) = A3;
       __syncthreads();
       {
-        const int ch = sl * 256 + tid;
+        const size_t ch = (size_t)bi * (a.NS * 256) + sl * 256 + tid;  // this cloud's partial row
 #pragma unroll
         for (int k = 0; k < (MODE == 1 ? 3 : 2); ++k) {
           const double v = ((double)red[(k * 4 + 0) * 256 + tid] + red[(k * 4 + 1) * 256 + tid]) +
                            ((double)red[(k * 4 + 2) * 256 + tid] + red[(k * 4 + 3) * 256 + tid]);
+#if defined(DH3D_IB_EXP) && (DH3D_IB_EXP & 8)   // timing experiment: no statistics atomics (results wrong)
+          if (v == 123.456) a.s0[0] = v;
+#else
           unsafeAtomicAdd((k == 0 ? a.s0 : k == 1 ? a.s1 : a.s2) + ch, v);
+#endif
         }
       }
       __syncthreads();  // rows and partial sums are overwritten by the next slice
@@ -353,40 +389,38 @@ bool shape_ok(int Hd, int m) { return Hd % 256 == 0 && Hd >= 256 && Hd <= 1024 &
 
 // G: the 256-column slices [Hd/256][B*m][256] of coarse @ W + b; idx / dist: three_nn of the fine points [B,n,3];
 // order: dh3d_spatial_sort records of the fine cloud [B,n,4] (may be NULL: points in index order, correct but slower);
-// mask [B] bytes (may be NULL).  sum / sumsq [Hd] f64 are zeroed here.
+// mask [B] bytes (may be NULL).  part [2][B][Hd] f64 (zeroed here): per-CLOUD partial sums / sums of squares -- their
+// sums over B are the column statistics (704 workgroups adding into one row of 1024 doubles cost 27 of 97 us in L2
+// atomics on the same addresses; per cloud it is 32 workgroups per address).
 DH3D_API int dh3d_interp_bn_colstats(const float *G, int Hd, const int32_t *idx, const float *dist, const float *order,
-                                     int B, int n, int m, const unsigned char *mask, double *sum, double *sumsq,
-                                     void *stream) {
-  DH3D_REQUIRE(G && idx && dist && sum && sumsq && B > 0 && n > 0 && m > 0);
+                                     int B, int n, int m, const unsigned char *mask, double *part, void *stream) {
+  DH3D_REQUIRE(G && idx && dist && part && B > 0 && n > 0 && m > 0);
   DH3D_SUPPORTED(shape_ok(Hd, m));
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(sum, 0, sizeof(double) * Hd, s) != hipSuccess) return DH3D_ERR_LAUNCH;
-  if (hipMemsetAsync(sumsq, 0, sizeof(double) * Hd, s) != hipSuccess) return DH3D_ERR_LAUNCH;
+  if (hipMemsetAsync(part, 0, sizeof(double) * 2 * (size_t)B * Hd, s) != hipSuccess) return DH3D_ERR_LAUNCH;
   InterpBnArgs a{};
   a.G = G; a.NS = Hd / 256; a.Rc = (long long)B * m; a.idx = idx; a.dist = dist;
   a.order = reinterpret_cast<const float4 *>(order); a.B = B; a.n = n; a.m = m; a.nblk = dh3d_cdiv(n, kP); a.mask = mask;
-  a.s0 = sum; a.s1 = sumsq;
+  a.s0 = part; a.s1 = part + (size_t)B * Hd;
   return launch<0>(a, s);
 }
 
-// S1, S2, S3 [Hd] f64 (zeroed here): the sums of dh3d_bn_bwd_sums for the rank-one gradient dy = dlogit x w_fc on the
-// virtual rows h = interp(G);  dlogit [B*n] by original point index.
+// part [3][B][Hd] f64 (zeroed here): per-cloud partials of S1, S2, S3 -- the sums of dh3d_bn_bwd_sums for the rank-one
+// gradient dy = dlogit x w_fc on the virtual rows h = interp(G);  dlogit [B*n] by original point index.
 DH3D_API int dh3d_interp_bn_bwd_sums(const float *G, int Hd, const int32_t *idx, const float *dist, const float *order,
                                      int B, int n, int m, const unsigned char *mask, const float *dlogit,
                                      const float *w_fc, const float *mean, const float *rstd, const float *gamma,
-                                     const float *beta, double *S1, double *S2, double *S3, void *stream) {
-  DH3D_REQUIRE(G && idx && dist && dlogit && w_fc && mean && rstd && gamma && beta && S1 && S2 && S3);
+                                     const float *beta, double *part, void *stream) {
+  DH3D_REQUIRE(G && idx && dist && dlogit && w_fc && mean && rstd && gamma && beta && part);
   DH3D_REQUIRE(B > 0 && n > 0 && m > 0);
   DH3D_SUPPORTED(shape_ok(Hd, m));
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(S1, 0, sizeof(double) * Hd, s) != hipSuccess) return DH3D_ERR_LAUNCH;
-  if (hipMemsetAsync(S2, 0, sizeof(double) * Hd, s) != hipSuccess) return DH3D_ERR_LAUNCH;
-  if (hipMemsetAsync(S3, 0, sizeof(double) * Hd, s) != hipSuccess) return DH3D_ERR_LAUNCH;
+  if (hipMemsetAsync(part, 0, sizeof(double) * 3 * (size_t)B * Hd, s) != hipSuccess) return DH3D_ERR_LAUNCH;
   InterpBnArgs a{};
   a.G = G; a.NS = Hd / 256; a.Rc = (long long)B * m; a.idx = idx; a.dist = dist;
   a.order = reinterpret_cast<const float4 *>(order); a.B = B; a.n = n; a.m = m; a.nblk = dh3d_cdiv(n, kP); a.mask = mask;
   a.dlogit = dlogit; a.wfc = w_fc; a.v0 = mean; a.v1 = rstd; a.v2 = gamma; a.v3 = beta;
-  a.s0 = S1; a.s1 = S2; a.s2 = S3;
+  a.s0 = part; a.s1 = part + (size_t)B * Hd; a.s2 = part + 2 * (size_t)B * Hd;
   return launch<1>(a, s);
 }
 

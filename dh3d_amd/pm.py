@@ -691,16 +691,16 @@ def bn_bwd_apply(x, scale, shift, k2, k3, relu, dy=None, rowscale=None, colvec=N
 # ---- attention head, training mode, conv commuted through the up-sampling (csrc/interp_train.hip)
 def interp_bn_colstats(G, idx, dist, order, mask=None, out=None):
     """G [ns, B*m, 256] slices of coarse @ W + b; idx/dist [B,n,3]; order = spatial_sort records [B,n,4] or None ->
-    (sum, sumsq) [Hd] float64 of the virtual rows three_interpolate(G)."""
+    (sum, sumsq) [Hd] float64 of the virtual rows three_interpolate(G) (views of `out` [>= 2*Hd] if given)."""
     ns, Rc, _ = G.shape
     B, n = idx.shape[0], idx.shape[1]
     Hd = ns * 256
-    buf = out if out is not None else torch.empty((2 * Hd,), dtype=torch.float64, device=G.device)
-    s1, s2 = buf[:Hd], buf[Hd:2 * Hd]
+    part = torch.empty((2, B, Hd), dtype=torch.float64, device=G.device)
     L.check(L.lib().dh3d_interp_bn_colstats(L.ptr(G), Hd, L.ptr(idx), L.ptr(dist), L.ptr(order), B, n, Rc // B,
-                                            L.ptr(_mask_u8(mask)), L.ptr(s1), L.ptr(s2), L.stream_ptr()),
-            "interp_bn_colstats")
-    return s1, s2
+                                            L.ptr(_mask_u8(mask)), L.ptr(part), L.stream_ptr()), "interp_bn_colstats")
+    buf = out if out is not None else torch.empty((2 * Hd,), dtype=torch.float64, device=G.device)
+    torch.sum(part, dim=1, out=buf[:2 * Hd].view(2, Hd))
+    return buf[:Hd], buf[Hd:2 * Hd]
 
 
 def interp_head_rows(G, idx, dist, order, scale, shift, w_fc, b_fc_dev):
@@ -719,12 +719,11 @@ def interp_bn_bwd_sums(G, idx, dist, order, dlogit, w_fc, mean, rstd, gamma, bet
     ns, Rc, _ = G.shape
     B, n = idx.shape[0], idx.shape[1]
     Hd = ns * 256
-    S = torch.empty((3, Hd), dtype=torch.float64, device=G.device)
+    part = torch.empty((3, B, Hd), dtype=torch.float64, device=G.device)
     L.check(L.lib().dh3d_interp_bn_bwd_sums(L.ptr(G), Hd, L.ptr(idx), L.ptr(dist), L.ptr(order), B, n, Rc // B,
                                             L.ptr(_mask_u8(mask)), L.ptr(dlogit), L.ptr(w_fc), L.ptr(mean), L.ptr(rstd),
-                                            L.ptr(gamma), L.ptr(beta), L.ptr(S[0]), L.ptr(S[1]), L.ptr(S[2]),
-                                            L.stream_ptr()), "interp_bn_bwd_sums")
-    return S
+                                            L.ptr(gamma), L.ptr(beta), L.ptr(part), L.stream_ptr()), "interp_bn_bwd_sums")
+    return part.sum(1)
 
 
 def interp_bn_bwd_apply(G, idx, dist, order, dlogit, w_fc, scale, shift, k2, k3, mask=None):

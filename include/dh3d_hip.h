@@ -448,17 +448,19 @@ int dh3d_l2norm_rows_bwd(const float *x, const float *dxn, long long R, int C, f
  * pre-activation h = three_interpolate(G) of globalatt_block (core/backbones.py:89-100,156-173), G = the 256-column slices
  * [Hd/256][B*m][256] of coarse @ W + b, is never materialised.  idx / dist [B,n,3] = three_nn of the fine points, order =
  * dh3d_spatial_sort records [B,n,4] of the fine cloud (NULL: index order), mask [B] bytes (NULL: all clouds live).
- *   colstats : sum, sumsq [Hd] f64 of h over the live rows (zeroed by the call) -> dh3d_bn_finalize
+ *   colstats : per-cloud partials part [2][B][Hd] f64 (zeroed by the call) of sum / sumsq of h over the live rows; their
+ *              sums over B -> dh3d_bn_finalize
  *   forward  : dh3d_interp_head_sorted_fwd with the folded batch statistics as its epilogue
- *   bwd_sums : S1, S2, S3 [Hd] f64 of dh3d_bn_bwd_sums for dy = dlogit x w_fc (dlogit [B*n] by original point index)
+ *   bwd_sums : per-cloud partials part [3][B][Hd] of S1, S2, S3 of dh3d_bn_bwd_sums for dy = dlogit x w_fc (dlogit [B*n]
+ *              by original point index)
  *   bwd_apply: dG [Hd/256][B*m][256] = interp^T(scale dz - k2 - k3 h) (zeroed by the call, f32 atomics), from which
  *              dW = coarse^T dG and dcoarse = dG W^T are GEMMs on B*m rows.  Hd <= 1024, m <= 1024. */
 int dh3d_interp_bn_colstats(const float *G, int Hd, const int32_t *idx, const float *dist, const float *order, int B,
-                            int n, int m, const unsigned char *mask, double *sum, double *sumsq, void *stream);
+                            int n, int m, const unsigned char *mask, double *part /* [2][B][Hd] */, void *stream);
 int dh3d_interp_bn_bwd_sums(const float *G, int Hd, const int32_t *idx, const float *dist, const float *order, int B,
                             int n, int m, const unsigned char *mask, const float *dlogit, const float *w_fc,
-                            const float *mean, const float *rstd, const float *gamma, const float *beta, double *S1,
-                            double *S2, double *S3, void *stream);
+                            const float *mean, const float *rstd, const float *gamma, const float *beta,
+                            double *part /* [3][B][Hd] */, void *stream);
 int dh3d_interp_bn_bwd_apply(const float *G, int Hd, const int32_t *idx, const float *dist, const float *order, int B,
                              int n, int m, const unsigned char *mask, const float *dlogit, const float *w_fc,
                              const float *scale, const float *shift, const float *k2, const float *k3, float *dG,
