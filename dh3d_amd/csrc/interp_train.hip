@@ -277,7 +277,22 @@ __global__ __launch_bounds__(256) void interp_bn_kernel(const InterpBnArgs a) {
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.f;
+      // MODE 3: the gradient rows of the NEXT chunk's points are requested while this chunk is scattered (their L2
+      // round trip sat in front of every chunk before: 8 per block)
+      f32x16 nx = {};
+      auto request_dy = [&](int q) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < kCH / 4; ++j) {
+          const int o1 = __builtin_amdgcn_readfirstlane(s_slot[(q * kCH + wave * (kCH / 4) + j) * 4 + 3]);
+          // (padding points read row 0 of the cloud and are zeroed below: no load under a branch)
+          const float4 v = *reinterpret_cast<const float4 *>(a.dY + ((size_t)bi * n + (o1 ? o1 - 1 : 0)) * 256 + lane * 4);
+          nx[4 * j] = o1 ? v.x : 0.f; nx[4 * j + 1] = o1 ? v.y : 0.f; nx[4 * j + 2] = o1 ? v.z : 0.f; nx[4 * j + 3] = o1 ? v.w : 0.f;
+        }
+      };
+      if (MODE == 3) request_dy(0);
       for (int q = 0; q < kP / kCH; ++q) {
+        const f32x16 cur = nx;
+        if (MODE == 3 && q + 1 < kP / kCH) request_dy(q + 1);
         auto points = [&](auto ovf) __attribute__((always_inline)) {
           constexpr bool OVF = decltype(ovf)::value;
 #pragma unroll
@@ -289,9 +304,7 @@ __global__ __launch_bounds__(256) void interp_bn_kernel(const InterpBnArgs a) {
                       s2 = __builtin_amdgcn_readfirstlane(si.z);
             float4 dh;
             if (MODE == 3) {
-              const int o1 = __builtin_amdgcn_readfirstlane(si.w);
-              dh = o1 ? *reinterpret_cast<const float4 *>(a.dY + ((size_t)bi * n + (o1 - 1)) * 256 + lane * 4)
-                      : make_float4(0.f, 0.f, 0.f, 0.f);
+              dh = make_float4(cur[4 * j], cur[4 * j + 1], cur[4 * j + 2], cur[4 * j + 3]);
             } else {
             const float4 h = mix3(row4<OVF>(s_rows, Gs, s0, lane), row4<OVF>(s_rows, Gs, s1, lane),
                                   row4<OVF>(s_rows, Gs, s2, lane), sw.x, sw.y, sw.z);

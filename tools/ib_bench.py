@@ -26,3 +26,7 @@ def t(fn, reps=20):
 print("colstats  %.1f us" % t(lambda: pm.interp_bn_colstats(G, i3, d3, order)))
 print("bwd_sums  %.1f us" % t(lambda: pm.interp_bn_bwd_sums(G, i3, d3, order, dl, v[0], v[1], sc, sc, v[2])))
 print("bwd_apply %.1f us" % t(lambda: pm.interp_bn_bwd_apply(G, i3, d3, order, dl, v[0], sc, v[3], v[4], v[5])))
+from dh3d_amd import _lib as L
+dd = torch.clamp(d3, min=1e-10); w = ((1.0 / dd) / (1.0 / dd).sum(2, keepdim=True)).contiguous()
+go = torch.randn(Bt, N, 256, generator=g).to(dev); gp = torch.empty(Bt, M, 256, device=dev)
+print("interp_bwd_sorted %.1f us" % t(lambda: L.check(L.lib().dh3d_three_interpolate_bwd_sorted(Bt, N, 256, M, L.ptr(go), L.ptr(i3), L.ptr(w), L.ptr(order), L.ptr(gp), L.stream_ptr()), "x")))
