@@ -51,24 +51,33 @@ class DH3D(nn.Module):
             self.detection_block_reliable = bb.PointMLPHead(cfg.featdim or 128, [128, 256, 1024], fc_bias_init=1.0 / 8,
                                                             bn_eps=tp_eps)
         if cfg.extract_global:
-            if cfg.global_backbone not in (None, "global_before_assemble"):
-                raise NotImplementedError("global_backbone %r: only 'global_before_assemble' (core/backbones.py:178-186, "
-                                          "the shipped global_config) is built; 'global_before_assemble_conv1d' "
-                                          "(:189-197) is not" % cfg.global_backbone)
+            if cfg.global_backbone not in (None, "global_before_assemble", "global_before_assemble_conv1d"):
+                raise NotImplementedError("global_backbone %r (core/backbones.py:178-197 knows 'global_before_assemble' "
+                                          "and 'global_before_assemble_conv1d')" % cfg.global_backbone)
             if cfg.concat_xyz:
                 raise NotImplementedError("concat_xyz=True (core/backbones.py:180-181: 131 input channels to the "
                                           "global flex_conv) is not built; the shipped global_config sets False")
             if cfg.global_subsample and cfg.global_subsample > 0:
-                raise NotImplementedError("global_subsample > 0 (core/model.py:120-122) is not built; the shipped "
-                                          "global_config sets -1")
+                raise NotImplementedError("global_subsample > 0 (core/model.py:119-121) is not built -- nor upstream: that "
+                                          "branch calls backbones.subsample / self.global_subsample, neither of which "
+                                          "exists in the reference; the shipped global_config sets -1")
             if (cfg.featdim or 128) != 128:
                 raise NotImplementedError("extract_global with featdim < 128 is not built: the global flex_conv and "
                                           "attention kernels are instantiated for the 128-d descriptor of the "
                                           "shipped configs (core/configs.py:58)")
             gl_dims = list(cfg.gl_dims or [256])
-            self.global_before_assemble = bb.FlexConvDilate(128, gl_dims, dilate=cfg.gl_dilate or 8,
-                                                            knn=self.knn_num, concat=False, add_se="",
-                                                            upsample=True, bn_eps=tp_eps)
+            self.global_conv1d = cfg.global_backbone == "global_before_assemble_conv1d"
+            if self.global_conv1d:
+                # core/backbones.py:189-197 ("conv1d is found to be better than flexconv for global descriptor"): 1x1
+                # convs + BNReLU on the full-resolution descriptors; EVERY conv of the loop reads localdesc and only the
+                # last one's output is used (the others still exist as variables upstream, so they do here)
+                for i, d in enumerate(gl_dims):
+                    setattr(self, "global_before_assemble_conv1%d" % i, bb.Conv2D1x1(128, d, bn_eps=tp_eps))
+                self.global_before_assemble = None
+            else:
+                self.global_before_assemble = bb.FlexConvDilate(128, gl_dims, dilate=cfg.gl_dilate or 8,
+                                                                knn=self.knn_num, concat=False, add_se="",
+                                                                upsample=True, bn_eps=tp_eps)
             conv_dims = [256, 1024] if gl_dims[-1] > 256 else [1024]  # backbones.py:159-162
             self.globalatt = bb.PointMLPHead(gl_dims[-1], conv_dims, bn_eps=tp_eps)
             nv = bb.NetVLAD(gl_dims[-1], 64, 256, add_batch_norm=cfg.add_batch_norm is not False,
@@ -125,10 +134,18 @@ class DH3D(nn.Module):
 
     def _prepare_head(self):
         if self.config.extract_global:
-            self.global_before_assemble.prepare()
+            for top in self._global_front():
+                top.prepare()
             self.globalatt.prepare()
             self._netvlad.prepare()
         self._head_prepared = True
+
+    def _global_front(self):
+        """The modules in front of the attention head / NetVLAD: the sampled-level flex_conv block, or the 1x1 convs of
+        global_before_assemble_conv1d."""
+        if getattr(self, "global_conv1d", False):
+            return [getattr(self, "global_before_assemble_conv1%d" % i) for i in range(len(list(self.config.gl_dims or [256])))]
+        return [self.global_before_assemble]
 
     def invalidate(self, head_only=False):
         """Drop the folded / packed copies of the weights (rebuilt by the next forward): called whenever parameters
@@ -137,7 +154,7 @@ class DH3D(nn.Module):
         self._head_prepared = False
         mods = []
         if self.config.extract_global:
-            for top in (self.global_before_assemble, self.globalatt, self.__dict__.get("_netvlad")):
+            for top in self._global_front() + [self.globalatt, self.__dict__.get("_netvlad")]:
                 mods += [top] + (list(top.modules()) if top is not None else [])
         if not head_only:
             self._prepared = False
@@ -268,6 +285,12 @@ class DH3D(nn.Module):
     def compute_global(self, outs, l2_eps=0.0):
         self._check_mode()
         points, localdesc = outs["xyz"], outs["feat"]
+        if getattr(self, "global_conv1d", False):
+            # full-resolution rows: no sampled level, no interpolation -- the wide 1x1-conv GEMM, the head on the
+            # materialised rows, the row-streaming NetVLAD kernel
+            last = getattr(self, "global_before_assemble_conv1%d" % (len(list(self.config.gl_dims or [256])) - 1))
+            forglobal = last(localdesc, act=pm.ACT_RELU)
+            return self._netvlad(forglobal, self.globalatt(forglobal), l2_eps=l2_eps)
         geo = outs.get("_geo")
         if geo is None:
             geo = self._geometry(points, None)

@@ -183,7 +183,8 @@ def global_netvlad_block(features, att, w, slim_eps, cluster_size=64, add_batch_
 
 
 def forward(points, w, detection=False, extract_global=False, knn_num=8, tp_eps=1e-5, slim_eps=1e-3,
-            knn_inds=None, trace=None, featdim=128, add_batch_norm=True, add_se="max_pool"):
+            knn_inds=None, trace=None, featdim=128, add_batch_norm=True, add_se="max_pool",
+            global_backbone="global_before_assemble", gl_dims=(256,)):
     """core/model.py:135-210.  points [Bt,N,3] float32; returns dict of named outputs.
     trace (dict or None) collects the integer intermediates of the sampled levels (see flex_conv_dilate)."""
     points = np.ascontiguousarray(points, np.float32)
@@ -204,9 +205,14 @@ def forward(points, w, detection=False, extract_global=False, knn_num=8, tp_eps=
         outs["attention"] = att
         outs["xyz_feat_att"] = np.concatenate([newpoints, l2n, att], -1)
     if extract_global:
-        _, forglobal = flex_conv_dilate(points, localdesc, 8, knn_num, [256], "global_before_assemble", w, tp_eps,
-                                        knn_indices=None, concat=False, upsample=True, add_se="",
-                                        trace=trace)
+        if global_backbone == "global_before_assemble_conv1d":
+            # core/backbones.py:189-197: every conv of the loop reads localdesc, the last one is returned
+            for i, d in enumerate(gl_dims):
+                forglobal = _conv1x1(localdesc, w, "global_before_assemble_conv1%d" % i, bn_eps=tp_eps, act=_relu)
+        else:
+            _, forglobal = flex_conv_dilate(points, localdesc, 8, knn_num, [256], "global_before_assemble", w, tp_eps,
+                                            knn_indices=None, concat=False, upsample=True, add_se="",
+                                            trace=trace)
         gatt = globalatt_block(forglobal, w, tp_eps)
         g = global_netvlad_block(forglobal, gatt, w, slim_eps, add_batch_norm=add_batch_norm)
         outs["forglobal"] = forglobal

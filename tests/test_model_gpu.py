@@ -148,7 +148,7 @@ def test_fetch_only_normalised_descriptors_uses_fused_store(dev):
 def test_config_reachable_branches_vs_oracle(dev):
     """Branches no shipped preset selects but a reference config key / call can reach: featdim < 128 ('final_fc',
     core/backbones.py:125-126), NetVLAD without BatchNorm (cluster_biases / gating_biases, :224-229,310-314) and
-    without context gating (:276), SE on the neighbour average (flex_avg, :80-83)."""
+    without context gating (:276), SE on the neighbour average (flex_avg, :80-83), the conv1d global backbone (:189-197)."""
     from oracle import model_np
     from dh3d_amd import ConfigFactory, backbones as bb, pm
     from dh3d_amd.model import DH3D
@@ -176,6 +176,21 @@ def test_config_reachable_branches_vs_oracle(dev):
         g = m(torch.from_numpy(pts).to(dev))["globaldesc"].cpu().numpy()
     exp = model_np.forward(pts, _weights_np(m), extract_global=True, add_batch_norm=False)
     assert np.allclose(g, exp["globaldesc"], rtol=1e-4, atol=1e-4)
+    # global_backbone = 'global_before_assemble_conv1d' (core/backbones.py:189-197): 1x1 convs on the full-resolution
+    # descriptors instead of the sampled-level flex_conv; also at a size where the wide-GEMM / streaming kernels run
+    for npts, seed in ((1024, 8), (4096, 9)):
+        cfg = ConfigFactory("global_config").getconfig()
+        cfg.global_backbone = "global_before_assemble_conv1d"
+        m = DH3D(cfg).init_synthetic(seed)
+        _randomise_bn(m, seed + 1)
+        m = m.to(dev).eval()
+        assert "global_before_assemble_conv10.W" in m.state_dict() and not any(
+            k.startswith("global_before_assemble.") for k in m.state_dict())
+        p2 = rng.random((2, npts, 3), dtype=np.float32)
+        with torch.no_grad():
+            g = m(torch.from_numpy(p2).to(dev))["globaldesc"].cpu().numpy()
+        exp = model_np.forward(p2, _weights_np(m), extract_global=True, global_backbone="global_before_assemble_conv1d")
+        assert np.allclose(g, exp["globaldesc"], rtol=1e-4, atol=1e-4), float(np.abs(g - exp["globaldesc"]).max())
     # gating = False (a call-level argument upstream)
     nv = bb.NetVLAD(256, 64, 256, add_batch_norm=True, gating=False).to(dev)
     x = torch.randn(2, 300, 256, device=dev); att = torch.rand(2, 300, 1, device=dev)
@@ -196,7 +211,7 @@ def test_config_reachable_branches_vs_oracle(dev):
                                        concat=False, add_se="avg_pool")
     assert np.allclose(got, ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
     # and the branches that stay unbuilt say so, citing the reference
-    for key, val in (("global_backbone", "global_before_assemble_conv1d"), ("concat_xyz", True), ("global_subsample", 256)):
+    for key, val in (("global_backbone", "some_other_backbone"), ("concat_xyz", True), ("global_subsample", 256)):
         cfg = ConfigFactory("global_config").getconfig()
         cfg[key] = val
         with pytest.raises(NotImplementedError, match="core/"):
