@@ -185,11 +185,11 @@ def lib():
 
 
 def stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return torch.cuda.current_stream().cuda_stream  # (plain ints / None: argtypes convert them, no ctypes object per argument)
 
 
 def ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+    return t.data_ptr() if t is not None else None
 
 
 def check(status, what):
