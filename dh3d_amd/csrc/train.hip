@@ -264,8 +264,12 @@ DH3D_API int dh3d_bn_colstats(const float *x, long long R, int C, const unsigned
                               double *sum, double *sumsq, void *stream) {
   DH3D_REQUIRE(x && sum && sumsq && R > 0 && C > 0 && (!mask || rows_per_cloud > 0));
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(sum, 0, sizeof(double) * C, s) != hipSuccess) return DH3D_ERR_LAUNCH;
-  if (hipMemsetAsync(sumsq, 0, sizeof(double) * C, s) != hipSuccess) return DH3D_ERR_LAUNCH;
+  if (sumsq == sum + C) {  // one fill when the caller packs them (a fill is a 4 us launch of its own)
+    if (hipMemsetAsync(sum, 0, sizeof(double) * 2 * C, s) != hipSuccess) return DH3D_ERR_LAUNCH;
+  } else {
+    if (hipMemsetAsync(sum, 0, sizeof(double) * C, s) != hipSuccess) return DH3D_ERR_LAUNCH;
+    if (hipMemsetAsync(sumsq, 0, sizeof(double) * C, s) != hipSuccess) return DH3D_ERR_LAUNCH;
+  }
   int rows_per;
   const int chunks = row_chunks(R, &rows_per);
   hipLaunchKernelGGL(colstats_kernel, dim3(dh3d_cdiv(C, 64), chunks), dim3(256), 0, s, x, R, C, rows_per, mask,
@@ -299,9 +303,13 @@ DH3D_API int dh3d_bn_bwd_sums(const float *x, const float *dy, const float *rows
   DH3D_REQUIRE(dy || (rowscale && colvec && S3));
   DH3D_REQUIRE(!mask || rows_per_cloud > 0);
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(S1, 0, sizeof(double) * C, s) != hipSuccess) return DH3D_ERR_LAUNCH;
-  if (hipMemsetAsync(S2, 0, sizeof(double) * C, s) != hipSuccess) return DH3D_ERR_LAUNCH;
-  if (!dy && hipMemsetAsync(S3, 0, sizeof(double) * C, s) != hipSuccess) return DH3D_ERR_LAUNCH;
+  if (S2 == S1 + C && (dy || S3 == S2 + C)) {  // packed by the caller: one fill
+    if (hipMemsetAsync(S1, 0, sizeof(double) * (dy ? 2 : 3) * C, s) != hipSuccess) return DH3D_ERR_LAUNCH;
+  } else {
+    if (hipMemsetAsync(S1, 0, sizeof(double) * C, s) != hipSuccess) return DH3D_ERR_LAUNCH;
+    if (hipMemsetAsync(S2, 0, sizeof(double) * C, s) != hipSuccess) return DH3D_ERR_LAUNCH;
+    if (!dy && hipMemsetAsync(S3, 0, sizeof(double) * C, s) != hipSuccess) return DH3D_ERR_LAUNCH;
+  }
   int rows_per;
   const int chunks = row_chunks(R, &rows_per);
   hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(dh3d_cdiv(C, 64), chunks), dim3(256), 0, s, x, dy, rowscale, colvec, R, C,
