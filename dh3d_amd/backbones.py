@@ -334,12 +334,13 @@ class FlexConvDilate(nn.Module):
     """flex_conv_dilate (core/backbones.py:58-101)."""
 
     def __init__(self, cin, outdims, dilate, knn=8, concat=True, add_se="max_pool", upsample=True,
-                 bn_eps=1e-5):
+                 bn_eps=1e-5, xyz_prefix=False):
         super().__init__()
         if add_se not in ("max_pool", "avg_pool", ""):
             raise ValueError("add_se=%r (core/backbones.py:76-86 knows 'max_pool', 'avg_pool', anything else = none)"
                              % add_se)
         self.cin, self.outdims, self.dilate, self.knn = cin, list(outdims), dilate, knn
+        self.xyz_prefix = xyz_prefix  # the input is [xyz | features] (concat_xyz): cin = 3 + feature channels
         self.concat, self.add_se, self.upsample = concat, add_se, upsample
         c = cin
         for i, d in enumerate(outdims):
@@ -359,6 +360,22 @@ class FlexConvDilate(nn.Module):
             bn = getattr(self, "flexconv_%d_bn" % i)
             scale, shift = [t.detach() for t in bn.fold()]
             theta, bias = fc.position_theta.detach(), fc.position_bias.detach()
+            if i == 0 and self.xyz_prefix:
+                # concat_xyz (core/backbones.py:180-181): the input is [xyz | features], 3 + 128 channels.  flex_conv is
+                # linear in its input channels, so it splits into the fused kernel on the 128 feature channels plus the
+                # same kernel on the coordinates (padded to the feature width, zero weights in the padding); the
+                # feature_bias / BatchNorm / ReLU epilogue runs once on the sum
+                cf = theta.shape[1] - 3
+                fb = fc.feature_bias.detach().reshape(-1)
+                tx = torch.zeros((3, cf, d), dtype=theta.dtype, device=theta.device)
+                bx = torch.zeros((cf, d), dtype=theta.dtype, device=theta.device)
+                tx[:, :3], bx[:3] = theta[:, :3], bias[:3]
+                prep.append({
+                    "wp": pm.pack_flex_weight(theta[:, 3:].contiguous(), bias[3:].contiguous()), "wp3": None,
+                    "wp_xyz": pm.pack_flex_weight(tx, bx), "cf": cf,
+                    "fb": None, "scale": scale.contiguous(), "shift": (shift + fb * scale).contiguous(), "dout": d,
+                })
+                continue
             x6 = pm.flex_x6_supported(theta.shape[1], d, 8)  # full-resolution shapes: bf16x6 pipeline (K == 8)
             prep.append({
                 "wp": pm.pack_flex_weight(theta, bias),
@@ -409,7 +426,12 @@ class FlexConvDilate(nn.Module):
             xyz_s, nbr_s, x, remap = geo.xyz, (nbr if nbr is not None else geo.nbr), feat, None
         for p in prep:
             x6 = p["wp3"] is not None and nbr_s.shape[2] == 8 and remap is None
-            if x6:
+            if "wp_xyz" in p:  # [xyz | features] input: two launches of the fused kernel, one epilogue (see prepare)
+                xp = torch.zeros((x.shape[0], x.shape[1], p["cf"]), dtype=torch.float32, device=x.device)
+                xp[:, :, :3] = xyz_s
+                y = pm.flex_conv(x, xyz_s, nbr_s, p["wp"], p["dout"]) + pm.flex_conv(xp, xyz_s, nbr_s, p["wp_xyz"], p["dout"])
+                x = pm.scale_shift_act(y.reshape(-1, p["dout"]), p["scale"], p["shift"], True).reshape(y.shape)
+            elif x6:
                 x = pm.flex_conv_x6(x, xyz_s, nbr_s, p["wp3"], p["dout"], pre_bias=p["fb"], scale=p["scale"],
                                     shift=p["shift"], act=pm.ACT_RELU,
                                     reserve_cus_per_xcd=getattr(geo, "busy_cus_per_xcd", 0))

@@ -54,9 +54,9 @@ class DH3D(nn.Module):
             if cfg.global_backbone not in (None, "global_before_assemble", "global_before_assemble_conv1d"):
                 raise NotImplementedError("global_backbone %r (core/backbones.py:178-197 knows 'global_before_assemble' "
                                           "and 'global_before_assemble_conv1d')" % cfg.global_backbone)
-            if cfg.concat_xyz:
-                raise NotImplementedError("concat_xyz=True (core/backbones.py:180-181: 131 input channels to the "
-                                          "global flex_conv) is not built; the shipped global_config sets False")
+            if cfg.concat_xyz and cfg.global_backbone == "global_before_assemble_conv1d":
+                raise NotImplementedError("concat_xyz=True with global_before_assemble_conv1d (core/backbones.py:191-192: "
+                                          "a 131-channel 1x1 conv) is not built; the shipped global_config sets False")
             if cfg.global_subsample and cfg.global_subsample > 0:
                 raise NotImplementedError("global_subsample > 0 (core/model.py:119-121) is not built -- nor upstream: that "
                                           "branch calls backbones.subsample / self.global_subsample, neither of which "
@@ -75,9 +75,10 @@ class DH3D(nn.Module):
                     setattr(self, "global_before_assemble_conv1%d" % i, bb.Conv2D1x1(128, d, bn_eps=tp_eps))
                 self.global_before_assemble = None
             else:
-                self.global_before_assemble = bb.FlexConvDilate(128, gl_dims, dilate=cfg.gl_dilate or 8,
-                                                                knn=self.knn_num, concat=False, add_se="",
-                                                                upsample=True, bn_eps=tp_eps)
+                cx = bool(cfg.concat_xyz)  # core/backbones.py:180-181: [points | localdesc] into the flex_conv
+                self.global_before_assemble = bb.FlexConvDilate(128 + (3 if cx else 0), gl_dims,
+                                                                dilate=cfg.gl_dilate or 8, knn=self.knn_num, concat=False,
+                                                                add_se="", upsample=True, bn_eps=tp_eps, xyz_prefix=cx)
             conv_dims = [256, 1024] if gl_dims[-1] > 256 else [1024]  # backbones.py:159-162
             self.globalatt = bb.PointMLPHead(gl_dims[-1], conv_dims, bn_eps=tp_eps)
             nv = bb.NetVLAD(gl_dims[-1], 64, 256, add_batch_norm=cfg.add_batch_norm is not False,

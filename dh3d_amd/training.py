@@ -224,9 +224,10 @@ def global_head_hip(model, points, localdesc, lv, sync_bn=False, mask=None, comm
 
 def trainable_head_parameters(model):
     """Parameters that global_config trains (backbone frozen: configs.py:112-113)."""
-    if getattr(model, "global_conv1d", False):
-        raise NotImplementedError("training with global_backbone='global_before_assemble_conv1d' is not built (the "
-                                  "shipped global_config trains 'global_before_assemble')")
+    if getattr(model, "global_conv1d", False) or model.config.concat_xyz:
+        raise NotImplementedError("training with global_backbone='global_before_assemble_conv1d' or concat_xyz=True is "
+                                  "not built (the shipped global_config trains 'global_before_assemble' on the "
+                                  "descriptors alone)")
     mods = [model.global_before_assemble, model.globalatt, model._netvlad]
     seen, out = set(), []
     for mod in mods:

@@ -184,7 +184,7 @@ def global_netvlad_block(features, att, w, slim_eps, cluster_size=64, add_batch_
 
 def forward(points, w, detection=False, extract_global=False, knn_num=8, tp_eps=1e-5, slim_eps=1e-3,
             knn_inds=None, trace=None, featdim=128, add_batch_norm=True, add_se="max_pool",
-            global_backbone="global_before_assemble", gl_dims=(256,)):
+            global_backbone="global_before_assemble", gl_dims=(256,), concat_xyz=False):
     """core/model.py:135-210.  points [Bt,N,3] float32; returns dict of named outputs.
     trace (dict or None) collects the integer intermediates of the sampled levels (see flex_conv_dilate)."""
     points = np.ascontiguousarray(points, np.float32)
@@ -205,6 +205,8 @@ def forward(points, w, detection=False, extract_global=False, knn_num=8, tp_eps=
         outs["attention"] = att
         outs["xyz_feat_att"] = np.concatenate([newpoints, l2n, att], -1)
     if extract_global:
+        if concat_xyz:  # core/backbones.py:180-181
+            localdesc = np.concatenate([points, localdesc], -1)
         if global_backbone == "global_before_assemble_conv1d":
             # core/backbones.py:189-197: every conv of the loop reads localdesc, the last one is returned
             for i, d in enumerate(gl_dims):

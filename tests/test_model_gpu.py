@@ -191,6 +191,17 @@ def test_config_reachable_branches_vs_oracle(dev):
             g = m(torch.from_numpy(p2).to(dev))["globaldesc"].cpu().numpy()
         exp = model_np.forward(p2, _weights_np(m), extract_global=True, global_backbone="global_before_assemble_conv1d")
         assert np.allclose(g, exp["globaldesc"], rtol=1e-4, atol=1e-4), float(np.abs(g - exp["globaldesc"]).max())
+    # concat_xyz = True (core/backbones.py:180-181): [points | localdesc], 131 channels, into the global flex_conv
+    cfg = ConfigFactory("global_config").getconfig()
+    cfg.concat_xyz = True
+    m = DH3D(cfg).init_synthetic(12)
+    _randomise_bn(m, 13)
+    m = m.to(dev).eval()
+    assert tuple(m.state_dict()["global_before_assemble.flexconv_0.position_theta"].shape) == (3, 131, 256)
+    with torch.no_grad():
+        g = m(torch.from_numpy(pts).to(dev))["globaldesc"].cpu().numpy()
+    exp = model_np.forward(pts, _weights_np(m), extract_global=True, concat_xyz=True)
+    assert np.allclose(g, exp["globaldesc"], rtol=1e-4, atol=1e-4), float(np.abs(g - exp["globaldesc"]).max())
     # gating = False (a call-level argument upstream)
     nv = bb.NetVLAD(256, 64, 256, add_batch_norm=True, gating=False).to(dev)
     x = torch.randn(2, 300, 256, device=dev); att = torch.rand(2, 300, 1, device=dev)
@@ -211,8 +222,10 @@ def test_config_reachable_branches_vs_oracle(dev):
                                        concat=False, add_se="avg_pool")
     assert np.allclose(got, ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
     # and the branches that stay unbuilt say so, citing the reference
-    for key, val in (("global_backbone", "some_other_backbone"), ("concat_xyz", True), ("global_subsample", 256)):
+    for keys in ({"global_backbone": "some_other_backbone"}, {"global_subsample": 256},
+                 {"global_backbone": "global_before_assemble_conv1d", "concat_xyz": True}):
         cfg = ConfigFactory("global_config").getconfig()
-        cfg[key] = val
+        for key, val in keys.items():
+            cfg[key] = val
         with pytest.raises(NotImplementedError, match="core/"):
             DH3D(cfg)
