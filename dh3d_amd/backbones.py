@@ -216,6 +216,13 @@ class SEBlock(nn.Module):
             return pm.se_res_packed(x, pool, *packed)
         return pm.se_res(x, pool, W1, b1, W2, b2)
 
+    def forward_on_max_pool(self, x, nbr):
+        """forward(x, flex_pool(x, nbr)) (core/backbones.py:76-79); one launch where the matrix-pipe kernel applies."""
+        W1, b1, W2, b2, packed = self._prep or self.prepare()
+        if packed is not None and x.dim() == 3 and x.shape[2] in (64, 128):
+            return pm.se_res_pool_packed(x, nbr, *packed)
+        return self.forward(x, pm.flex_pool(x, nbr))
+
 
 # --------------------------------------------------------------------------- geometry (xyz-only work)
 class Geometry(object):
@@ -440,7 +447,7 @@ class FlexConvDilate(nn.Module):
                                  shift=p["shift"], act=pm.ACT_RELU, remap=remap)
             remap = None
         if self.add_se == "max_pool":
-            x = self.se(x, pm.flex_pool(x, nbr_s))
+            x = self.se.forward_on_max_pool(x, nbr_s)
         elif self.add_se == "avg_pool":  # flex_avg (theta 0, bias eye: the neighbour sum) * 1/knn, backbones.py:80-83
             x = self.se(x, pm.flex_avg(x, nbr_s, 1.0 / self.knn))
         if self.upsample and self.dilate > 1:

@@ -242,8 +242,12 @@ __global__ __launch_bounds__(256) void se_res_pm_kernel(const float *__restrict_
 //   squeeze  [64, C] x [C, 32]   waves 0/1 = the two row blocks
 //   excite   [64, 32] x [32, C]  all four waves, C/32 column blocks
 // then out = relu(x + x * sigmoid(.)) row-wise with 16-byte accesses.
-template <int C>
+// POOL: the pooled rows are not read but formed here, flex_pool's neighbour maximum (flex_pool_kernel_gpu.cu.cc:30-63)
+// fused into the staging -- the [R, C] pooled map is never written or read back and one launch (+ its dependency gap on
+// the critical tail of the local step) disappears.  Same values as flex_pool_pm_kernel: a maximum is order-independent.
+template <int C, bool POOL>
 __global__ __launch_bounds__(256) void se_res_mfma_kernel(const float *__restrict__ x, const float *__restrict__ pool,
+                                                         const int32_t *__restrict__ nbr, int N, int K,
                                                          const float *__restrict__ w1p, const float *__restrict__ b1p,
                                                          const float *__restrict__ w2p, const float *__restrict__ b2,
                                                          long long R, float *__restrict__ out) {
@@ -254,7 +258,27 @@ __global__ __launch_bounds__(256) void se_res_mfma_kernel(const float *__restric
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long long grow0 = (long long)blockIdx.x * kTM;
-  stage_rows(pool, C, pool, 0, grow0, R, s_p, LDP);
+  if (POOL) {
+    constexpr int CVP = C / 4;
+    for (int e = tid; e < kTM * CVP; e += 256) {
+      const int p = e / CVP, c4 = (e - p * CVP) * 4;
+      const long long g = grow0 + p;
+      float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (g < R) {
+        const long long cloud0 = (g / N) * N;
+        const int32_t *nb = nbr + g * K;
+        best = make_float4(-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f);  // -FLT_MAX
+#pragma unroll 4
+        for (int k = 0; k < K; ++k) {
+          const float4 v = *reinterpret_cast<const float4 *>(x + (cloud0 + nb[k]) * C + c4);
+          best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y); best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
+        }
+      }
+      *reinterpret_cast<float4 *>(s_p + (size_t)p * LDP + c4) = best;
+    }
+  } else {
+    stage_rows(pool, C, pool, 0, grow0, R, s_p, LDP);
+  }
   __syncthreads();
   if (wave < 2) {  // squeeze: relu(pool @ W1 + b1)
     f32x16 acc[1];
@@ -468,9 +492,31 @@ DH3D_API int dh3d_se_res_pm_packed_fwd(const float *x, const float *pool, const 
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(dh3d_cdiv(R, kTM)), block(256);
   if (C == 64)
-    hipLaunchKernelGGL(se_res_mfma_kernel<64>, grid, block, 0, s, x, pool, w1packed, b1pad, w2packed, b2, (long long)R, out);
+    hipLaunchKernelGGL((se_res_mfma_kernel<64, false>), grid, block, 0, s, x, pool, nullptr, 1, 0, w1packed, b1pad,
+                       w2packed, b2, (long long)R, out);
   else if (C == 128)
-    hipLaunchKernelGGL(se_res_mfma_kernel<128>, grid, block, 0, s, x, pool, w1packed, b1pad, w2packed, b2, (long long)R, out);
+    hipLaunchKernelGGL((se_res_mfma_kernel<128, false>), grid, block, 0, s, x, pool, nullptr, 1, 0, w1packed, b1pad,
+                       w2packed, b2, (long long)R, out);
+  else
+    return DH3D_ERR_UNSUPPORTED;
+  return dh3d_launch_status();
+}
+
+// se_res_bottleneck on the flex_pool of x (core/backbones.py:76-79: SE on max_pool) in one launch: pooled rows formed
+// while staging.  x [B*N, C], nbr [B, N, K].
+DH3D_API int dh3d_se_res_pool_pm_packed_fwd(const float *x, const int32_t *nbr, int B, int N, int K,
+                                            const float *w1packed, const float *b1pad, const float *w2packed,
+                                            const float *b2, int C, float *out, void *stream) {
+  DH3D_REQUIRE(x && nbr && w1packed && b1pad && w2packed && b2 && out && B > 0 && N > 0 && K > 0);
+  hipStream_t s = (hipStream_t)stream;
+  const long long R = (long long)B * N;
+  const dim3 grid(dh3d_cdiv(R, kTM)), block(256);
+  if (C == 64)
+    hipLaunchKernelGGL((se_res_mfma_kernel<64, true>), grid, block, 0, s, x, x, nbr, N, K, w1packed, b1pad, w2packed, b2,
+                       R, out);
+  else if (C == 128)
+    hipLaunchKernelGGL((se_res_mfma_kernel<128, true>), grid, block, 0, s, x, x, nbr, N, K, w1packed, b1pad, w2packed, b2,
+                       R, out);
   else
     return DH3D_ERR_UNSUPPORTED;
   return dh3d_launch_status();

@@ -252,6 +252,19 @@ def se_res_packed(x, pool, w1packed, b1pad, w2packed, b2):
     return out
 
 
+def se_res_pool_packed(x, nbr, w1packed, b1pad, w2packed, b2):
+    """se_res_packed(x, flex_pool(x, nbr)) in one launch (the pooled rows are formed while staging).  x [B,N,C], nbr
+    [B,N,K] int32, C = 64 or 128."""
+    a = L.require_cuda_f32(x, "x", 3)
+    nb = L.require_cuda_i32(nbr, "nbr", 3)
+    B, N, C = a.shape
+    out = torch.empty_like(a)
+    L.check(L.lib().dh3d_se_res_pool_pm_packed_fwd(L.ptr(a), L.ptr(nb), B, N, nb.shape[2], L.ptr(w1packed), L.ptr(b1pad),
+                                                   L.ptr(w2packed), L.ptr(b2), C, L.ptr(out), L.stream_ptr()),
+            "se_res_pool_pm_packed")
+    return out
+
+
 def three_interpolate_idw(points, idx, dist):
     p = L.require_cuda_f32(points, "points", 3)
     ix = L.require_cuda_i32(idx, "idx", 3)

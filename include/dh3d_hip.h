@@ -273,6 +273,11 @@ int dh3d_se_res_pm_fwd(const float *x, const float *pool, const float *W1, const
  * zero-padded to 32, w2packed = dh3d_pack_weight of W2 zero-padded to [32,C] rows. */
 int dh3d_se_res_pm_packed_fwd(const float *x, const float *pool, const float *w1packed, const float *b1pad,
                               const float *w2packed, const float *b2, int R, int C, float *out, void *stream);
+/* the same block on flex_pool(x, nbr) (core/backbones.py:76-79) in one launch: the pooled rows are formed while staging,
+ * the [B*N, C] pooled map is never written.  x [B*N, C], nbr [B, N, K] int32; C = 64 or 128. */
+int dh3d_se_res_pool_pm_packed_fwd(const float *x, const int32_t *nbr, int B, int N, int K, const float *w1packed,
+                                   const float *b1pad, const float *w2packed, const float *b2, int C, float *out,
+                                   void *stream);
 
 /* three_nn + inverse-distance weights + three_interpolate (core/backbones.py:90-96) fused:
  * weight = (1/max(d,1e-10)) / sum(1/max(d,1e-10)).  idx/dist from dh3d_three_nn.

@@ -227,6 +227,23 @@ def test_se_res_pm(dev, C):
     assert close(out2, np.maximum(x + x * g, 0), 1e-4, 1e-5)
 
 
+@pytest.mark.parametrize("C,B,N", [(64, 2, 1000), (128, 3, 333), (64, 8, 8192)])
+def test_se_res_on_max_pool_fused_equals_two_kernels(dev, C, B, N):
+    """SE-residual block on flex_pool(x) in one launch (pooled rows formed while staging) == flex_pool_pm then
+    se_res_packed, bit for bit (a maximum is order-independent, the rest is the same code)."""
+    from dh3d_amd import pm
+    g = torch.Generator().manual_seed(C + N)
+    x = torch.randn(B, N, C, generator=g).to(dev)
+    xyz = torch.rand(B, N, 3, generator=g).to(dev)
+    nbr, _ = pm.knn_xyz(xyz, 8)
+    W1 = (torch.randn(C, C // 4, generator=g) / 8).to(dev); b1 = torch.randn(C // 4, generator=g).to(dev)
+    W2 = (torch.randn(C // 4, C, generator=g) / 4).to(dev); b2 = torch.randn(C, generator=g).to(dev)
+    packed = pm.se_res_pack(W1, b1, W2)
+    two = pm.se_res_packed(x, pm.flex_pool(x, nbr), *packed, b2)
+    one = pm.se_res_pool_packed(x, nbr, *packed, b2)
+    assert torch.equal(one, two)
+
+
 def test_interpolate_idw_l2norm_and_head(dev, oracle):
     from dh3d_amd import ops, pm
     rng = np.random.default_rng(6)
