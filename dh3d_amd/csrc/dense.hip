@@ -259,19 +259,41 @@ __global__ __launch_bounds__(256) void se_res_mfma_kernel(const float *__restric
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long long grow0 = (long long)blockIdx.x * kTM;
   if (POOL) {
+    // the tile's neighbour ids once into LDS (as row offsets; every id is used by C/4 lanes), then all K row reads of a
+    // lane in flight together
+    int *s_nb = reinterpret_cast<int *>(s_h);  // [kTM][K <= 9] ints: the hidden tile is not live yet
+    const bool k8 = K == 8;
+    if (k8) {
+      for (int e = tid; e < kTM * 8; e += 256) {
+        const long long g = grow0 + (e >> 3);
+        s_nb[e] = g < R ? (int)((g / N) * N) + nbr[g * 8 + (e & 7)] : 0;
+      }
+      __syncthreads();
+    }
     constexpr int CVP = C / 4;
     for (int e = tid; e < kTM * CVP; e += 256) {
       const int p = e / CVP, c4 = (e - p * CVP) * 4;
       const long long g = grow0 + p;
       float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
       if (g < R) {
-        const long long cloud0 = (g / N) * N;
-        const int32_t *nb = nbr + g * K;
         best = make_float4(-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f);  // -FLT_MAX
+        if (k8) {
+          float4 v[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4 *>(x + (size_t)s_nb[p * 8 + k] * C + c4);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            best.x = fmaxf(best.x, v[k].x); best.y = fmaxf(best.y, v[k].y);
+            best.z = fmaxf(best.z, v[k].z); best.w = fmaxf(best.w, v[k].w);
+          }
+        } else {
+          const long long cloud0 = (g / N) * N;
+          const int32_t *nb = nbr + g * K;
 #pragma unroll 4
-        for (int k = 0; k < K; ++k) {
-          const float4 v = *reinterpret_cast<const float4 *>(x + (cloud0 + nb[k]) * C + c4);
-          best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y); best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
+          for (int k = 0; k < K; ++k) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + (cloud0 + nb[k]) * C + c4);
+            best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y); best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
+          }
         }
       }
       *reinterpret_cast<float4 *>(s_p + (size_t)p * LDP + c4) = best;
