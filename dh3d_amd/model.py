@@ -159,6 +159,7 @@ class DH3D(nn.Module):
                 mods += [top] + (list(top.modules()) if top is not None else [])
         if not head_only:
             self._prepared = False
+            self._backbone_version = getattr(self, "_backbone_version", 0) + 1  # captured graphs of it are stale now
             mods += list(self.modules()) + [self.__dict__.get("_local"), self.__dict__.get("_netvlad")]
         for m in mods:
             if m is not None and getattr(m, "_prep", None) is not None:

@@ -300,9 +300,10 @@ class QuadrupletTrainer(object):
                 _, localdesc = self.model.compute_local(block, _geo=geo)
                 lv = geo.level(8, self.model.knn_num)
             return localdesc, lv
-        key = (tuple(block.shape), block.device)
+        key = (tuple(block.shape), block.device, getattr(self.model, "_backbone_version", 0))
         ent = self._bb_graphs.get(key)
         if ent is None:
+            self._bb_graphs.clear()  # (a reloaded / moved model: the old graph points at freed weight copies)
             static_in = block.clone()
 
             def body():

@@ -411,3 +411,34 @@ def test_three_interpolate_sorted_backward_matches_the_drop_in_op(dev, B, N, scr
     assert torch.equal(outs[0][0], outs[1][0])
     err = float((outs[0][1] - outs[1][1]).abs().max())
     assert err <= 2e-5 * float(outs[1][1].abs().max()), err
+
+
+def test_trainer_backbone_graph_matches_eager_and_survives_a_reload(dev):
+    """QuadrupletTrainer replays the frozen backbone + geometry from a hipGraph: same losses and gradients as the eager
+    backbone, for two different batches (the graph's input buffer is refilled); after load_state_dict the graph is
+    re-captured (it would otherwise read the freed packed weights of the old model)."""
+    from dh3d_amd.training import QuadrupletTrainer
+    batches = [torch.rand(7, 1024, 3, generator=torch.Generator().manual_seed(s)).to(dev) for s in (1, 2)]
+    res = []
+    for graph in (True, False):
+        m = _build(dev, seed=21, B=1, P=2, Ng=3)
+        tr = QuadrupletTrainer(m, start_lr=1e-3, graph_backbone=graph)
+        tr.keep_grads = True
+        out = []
+        for b in batches:
+            loss = tr.step(b)
+            out.append((loss, [g.clone() for g in tr.last_grads]))
+        res.append((out, tr, m))
+    for (la, ga), (lb, gb) in zip(res[0][0], res[1][0]):
+        assert abs(la - lb) <= 1e-5 * max(1.0, abs(lb)), (la, lb)
+        for x, y in zip(ga, gb):
+            assert float((x - y).abs().max()) <= 5e-3 * float(y.abs().max()) + 1e-6
+    # reload other backbone weights into the graphed trainer's model: the next step must see them
+    tr, m = res[0][1], res[0][2]
+    assert len(tr._bb_graphs) == 1
+    other = _build(dev, seed=99, B=1, P=2, Ng=3)
+    m.load_state_dict(other.state_dict())
+    tr2 = QuadrupletTrainer(other, start_lr=1e-3, graph_backbone=False)
+    la, lb = tr.step(batches[0]), tr2.step(batches[0])
+    assert abs(la - lb) <= 1e-5 * max(1.0, abs(lb)), (la, lb)
+    assert len(tr._bb_graphs) == 1  # the stale graph was dropped, a new one captured
