@@ -223,6 +223,18 @@ class SEBlock(nn.Module):
             return pm.se_res_pool_packed(x, nbr, *packed)
         return self.forward(x, pm.flex_pool(x, nbr))
 
+    def forward_on_max_pool_then_conv(self, x, nbr, conv, act=pm.ACT_RELU):
+        """(y, conv(y)) with y = forward_on_max_pool(x, nbr): one launch when the block is 64 wide and `conv` a 64 -> 64
+        Conv2D1x1 (stage 1 -> before_stage2_conv1d, core/backbones.py:115-117); same values either way."""
+        W1, b1, W2, b2, packed = self._prep or self.prepare()
+        inner = getattr(conv, "tfconv0", conv)  # FeatureConv1d wraps its Conv2D1x1
+        cp = inner._prep or inner.prepare()
+        if (packed is not None and x.dim() == 3 and x.shape[2] == 64 and inner.cin == 64 and inner.cout == 64
+                and "wp" in cp and not cp.get("pad")):
+            return pm.se_res_pool_conv(x, nbr, *packed, cp["wp"], cp["b"], cp["scale"], cp["shift"], act=act)
+        y = self.forward_on_max_pool(x, nbr)
+        return y, conv(y, act=act)
+
 
 # --------------------------------------------------------------------------- geometry (xyz-only work)
 class Geometry(object):
@@ -415,11 +427,12 @@ class FlexConvDilate(nn.Module):
         return conv.lower_partial(feat)
 
     def forward(self, geo, feat, nbr=None, residual=None, l2cat=None, shortcut_src=None, lower_partial=None,
-                coarse_only=False):
+                coarse_only=False, post_conv=None):
         """geo: Geometry; feat [B,N,cin]; nbr [B,N,K] for dilate == 1 (else computed on the sampled set);
         residual [B,N,cout]: added to the concat conv's output in its store (the caller's shortcut branch);
         l2cat = (prefix [B,N,3], eps): return [prefix | l2_normalize(output)] instead of the output;
-        lower_partial: commuted_partial(feat), computed earlier by the caller."""
+        lower_partial: commuted_partial(feat), computed earlier by the caller; post_conv: a Conv2D1x1 the caller applies
+        to this block's output next -- where it can ride in the SE kernel the result is (output, post_conv(output))."""
         prep = self._prep or self.prepare()
         if self.dilate > 1:
             lv = geo.level(self.dilate, self.knn, finish=False)  # three_nn is joined only where it is consumed
@@ -446,8 +459,13 @@ class FlexConvDilate(nn.Module):
                 x = pm.flex_conv(x, xyz_s, nbr_s, p["wp"], p["dout"], pre_bias=p["fb"], scale=p["scale"],
                                  shift=p["shift"], act=pm.ACT_RELU, remap=remap)
             remap = None
+        post = None
         if self.add_se == "max_pool":
-            x = self.se.forward_on_max_pool(x, nbr_s)
+            if (post_conv is not None and not (self.upsample and self.dilate > 1) and not self.concat
+                    and residual is None and l2cat is None and shortcut_src is None):
+                x, post = self.se.forward_on_max_pool_then_conv(x, nbr_s, post_conv)  # x is this block's output
+            else:
+                x = self.se.forward_on_max_pool(x, nbr_s)
         elif self.add_se == "avg_pool":  # flex_avg (theta 0, bias eye: the neighbour sum) * 1/knn, backbones.py:80-83
             x = self.se(x, pm.flex_avg(x, nbr_s, 1.0 / self.knn))
         if self.upsample and self.dilate > 1:
@@ -474,6 +492,8 @@ class FlexConvDilate(nn.Module):
             x = self.concat_conv1d(x, x2=feat, act=pm.ACT_RELU, residual=residual)
         elif residual is not None:
             x = x + residual
+        if post is not None:
+            return x, post  # (block output, post_conv(block output))
         return x if l2cat is None else pm.l2norm_concat(x, l2cat[1], prefix=l2cat[0])
 
 

@@ -245,12 +245,17 @@ __global__ __launch_bounds__(256) void se_res_pm_kernel(const float *__restrict_
 // POOL: the pooled rows are not read but formed here, flex_pool's neighbour maximum (flex_pool_kernel_gpu.cu.cc:30-63)
 // fused into the staging -- the [R, C] pooled map is never written or read back and one launch (+ its dependency gap on
 // the critical tail of the local step) disappears.  Same values as flex_pool_pm_kernel: a maximum is order-independent.
-template <int C, bool POOL>
+// CONV: the block's output tile goes through one more 1x1 conv (C -> 64, its own bias / BatchNorm / activation)
+// before it leaves the chip: `before_stage2_conv1d` behind stage 1 (core/backbones.py:117) -- both results are stored,
+// the tile is not read back and a launch on the global path's critical chain disappears.
+template <int C, bool POOL, bool CONV>
 __global__ __launch_bounds__(256) void se_res_mfma_kernel(const float *__restrict__ x, const float *__restrict__ pool,
                                                          const int32_t *__restrict__ nbr, int N, int K,
                                                          const float *__restrict__ w1p, const float *__restrict__ b1p,
                                                          const float *__restrict__ w2p, const float *__restrict__ b2,
-                                                         long long R, float *__restrict__ out) {
+                                                         long long R, float *__restrict__ out,
+                                                         const float *__restrict__ wconv, EpilogueArgs cep,
+                                                         float *__restrict__ out2) {
   constexpr int LDP = C + 4;   // pooled rows, later the gate tile
   constexpr int LDH = 32 + 4;  // hidden rows
   __shared__ __attribute__((aligned(16))) float s_p[kTM * LDP];
@@ -341,7 +346,23 @@ __global__ __launch_bounds__(256) void se_res_mfma_kernel(const float *__restric
       r.x = r.x > 0.f ? r.x : 0.f; r.y = r.y > 0.f ? r.y : 0.f;
       r.z = r.z > 0.f ? r.z : 0.f; r.w = r.w > 0.f ? r.w : 0.f;
       *reinterpret_cast<float4 *>(out + g * C + c4) = r;
+      if (CONV) *reinterpret_cast<float4 *>(s_p + (size_t)p * LDP + c4) = r;  // over its own gate entry
+    } else if (CONV) {
+      *reinterpret_cast<float4 *>(s_p + (size_t)p * LDP + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+  }
+  if (CONV) {  // out2 = act(bn(tile @ Wconv + b)), 64 columns: one 32 x 32 accumulator per wave
+    __syncthreads();
+    const int row0 = (wave & 1) * 32, cb0 = wave >> 1;
+    f32x16 acc[1];
+    zero_acc<1>(acc);
+    EpilogueRegs er[1];
+    er[0] = epilogue_prefetch(cep, cb0 * 32 + (lane & 31));
+    wave_gemm_f32<1>(s_p, LDP, row0, wconv, C / 8, cb0, 2, acc);
+    __syncthreads();
+    wave_tiles_to_lds<1>(acc, er, cep.act, s_p, LDP, row0, cb0, 2);
+    __syncthreads();
+    block_store_rows(s_p, LDP, kTM, grow0, R, 64, nullptr, out2);
   }
 }
 
@@ -514,11 +535,11 @@ DH3D_API int dh3d_se_res_pm_packed_fwd(const float *x, const float *pool, const 
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(dh3d_cdiv(R, kTM)), block(256);
   if (C == 64)
-    hipLaunchKernelGGL((se_res_mfma_kernel<64, false>), grid, block, 0, s, x, pool, nullptr, 1, 0, w1packed, b1pad,
-                       w2packed, b2, (long long)R, out);
+    hipLaunchKernelGGL((se_res_mfma_kernel<64, false, false>), grid, block, 0, s, x, pool, nullptr, 1, 0, w1packed, b1pad,
+                       w2packed, b2, (long long)R, out, nullptr, EpilogueArgs{}, nullptr);
   else if (C == 128)
-    hipLaunchKernelGGL((se_res_mfma_kernel<128, false>), grid, block, 0, s, x, pool, nullptr, 1, 0, w1packed, b1pad,
-                       w2packed, b2, (long long)R, out);
+    hipLaunchKernelGGL((se_res_mfma_kernel<128, false, false>), grid, block, 0, s, x, pool, nullptr, 1, 0, w1packed, b1pad,
+                       w2packed, b2, (long long)R, out, nullptr, EpilogueArgs{}, nullptr);
   else
     return DH3D_ERR_UNSUPPORTED;
   return dh3d_launch_status();
@@ -534,13 +555,27 @@ DH3D_API int dh3d_se_res_pool_pm_packed_fwd(const float *x, const int32_t *nbr, 
   const long long R = (long long)B * N;
   const dim3 grid(dh3d_cdiv(R, kTM)), block(256);
   if (C == 64)
-    hipLaunchKernelGGL((se_res_mfma_kernel<64, true>), grid, block, 0, s, x, x, nbr, N, K, w1packed, b1pad, w2packed, b2,
-                       R, out);
+    hipLaunchKernelGGL((se_res_mfma_kernel<64, true, false>), grid, block, 0, s, x, x, nbr, N, K, w1packed, b1pad, w2packed, b2,
+                       R, out, nullptr, EpilogueArgs{}, nullptr);
   else if (C == 128)
-    hipLaunchKernelGGL((se_res_mfma_kernel<128, true>), grid, block, 0, s, x, x, nbr, N, K, w1packed, b1pad, w2packed, b2,
-                       R, out);
+    hipLaunchKernelGGL((se_res_mfma_kernel<128, true, false>), grid, block, 0, s, x, x, nbr, N, K, w1packed, b1pad, w2packed, b2,
+                       R, out, nullptr, EpilogueArgs{}, nullptr);
   else
     return DH3D_ERR_UNSUPPORTED;
+  return dh3d_launch_status();
+}
+
+// dh3d_se_res_pool_pm_packed_fwd followed by a 1x1 conv 64 -> 64 on the block's output (wconv = dh3d_pack_weight of
+// [64, 64], `ep` its bias / BatchNorm / activation) in the same launch: out [B*N, 64] and out2 [B*N, 64] both stored.
+DH3D_API int dh3d_se_res_pool_conv_pm_fwd(const float *x, const int32_t *nbr, int B, int N, int K, const float *w1packed,
+                                          const float *b1pad, const float *w2packed, const float *b2, int C, float *out,
+                                          const float *wconv_packed, const dh3d_epilogue *ep, int Dout, float *out2,
+                                          void *stream) {
+  DH3D_REQUIRE(x && nbr && w1packed && b1pad && w2packed && b2 && out && wconv_packed && out2 && B > 0 && N > 0 && K > 0);
+  DH3D_SUPPORTED(C == 64 && Dout == 64 && (!ep || ep->act != DH3D_ACT_SIGMOID));
+  const long long R = (long long)B * N;
+  hipLaunchKernelGGL((se_res_mfma_kernel<64, true, true>), dim3(dh3d_cdiv(R, kTM)), dim3(256), 0, (hipStream_t)stream, x,
+                     x, nbr, N, K, w1packed, b1pad, w2packed, b2, R, out, wconv_packed, dh3d_ep(ep), out2);
   return dh3d_launch_status();
 }
 

@@ -252,8 +252,8 @@ class DH3D(nn.Module):
             init = pm.conv_pointset_xyz(geo.xyz, nn_8, p["theta"], p["bias"], scale=p["scale"], shift=p["shift"],
                                         act=pm.ACT_RELU)
             init = pm.flex_pool(init, nn_8)
-            x1 = self.stage1(geo, init, nbr=nn_8)
-            x2 = self.before_stage2_conv1d(x1, act=pm.ACT_RELU)
+            r = self.stage1(geo, init, nbr=nn_8, post_conv=self.before_stage2_conv1d)
+            x1, x2 = r if isinstance(r, tuple) else (r, self.before_stage2_conv1d(r, act=pm.ACT_RELU))
             # BNReLU(conv(x1)) + stage2 (backbones.py:123).  Large clouds: the shortcut conv runs INSIDE stage 2's last
             # conv (its input x1 is just more K for that GEMM, with its own accumulators and epilogue), so its
             # [Bt,N,128] result is never written or read back.  Otherwise it runs here, beside the FPS chain, and its

@@ -278,6 +278,11 @@ int dh3d_se_res_pm_packed_fwd(const float *x, const float *pool, const float *w1
 int dh3d_se_res_pool_pm_packed_fwd(const float *x, const int32_t *nbr, int B, int N, int K, const float *w1packed,
                                    const float *b1pad, const float *w2packed, const float *b2, int C, float *out,
                                    void *stream);
+/* ... followed by a 1x1 conv 64 -> 64 (+ bias / BatchNorm / activation `ep`) on the block's output in the same launch
+ * (stage 1 -> before_stage2_conv1d, core/backbones.py:115-117): out and out2 [B*N, 64] are both stored. */
+int dh3d_se_res_pool_conv_pm_fwd(const float *x, const int32_t *nbr, int B, int N, int K, const float *w1packed,
+                                 const float *b1pad, const float *w2packed, const float *b2, int C, float *out,
+                                 const float *wconv_packed, const dh3d_epilogue *ep, int Dout, float *out2, void *stream);
 
 /* three_nn + inverse-distance weights + three_interpolate (core/backbones.py:90-96) fused:
  * weight = (1/max(d,1e-10)) / sum(1/max(d,1e-10)).  idx/dist from dh3d_three_nn.

@@ -244,6 +244,26 @@ def test_se_res_on_max_pool_fused_equals_two_kernels(dev, C, B, N):
     assert torch.equal(one, two)
 
 
+def test_se_res_pool_conv_fused_equals_separate_kernels(dev):
+    """... and with the following 64 -> 64 conv (+ BatchNorm + ReLU) in the same launch: the block's output bit for bit,
+    the conv's output equal to linear() of it (same MFMA code on the same tile)."""
+    from dh3d_amd import pm
+    g = torch.Generator().manual_seed(5)
+    B, N, C = 3, 2000, 64
+    x = torch.randn(B, N, C, generator=g).to(dev)
+    nbr, _ = pm.knn_xyz(torch.rand(B, N, 3, generator=g).to(dev), 8)
+    W1 = (torch.randn(C, C // 4, generator=g) / 8).to(dev); b1 = torch.randn(C // 4, generator=g).to(dev)
+    W2 = (torch.randn(C // 4, C, generator=g) / 4).to(dev); b2 = torch.randn(C, generator=g).to(dev)
+    Wc = (torch.randn(C, 64, generator=g) / 8).to(dev); bc = torch.randn(64, generator=g).to(dev)
+    sc = (0.5 + torch.rand(64, generator=g)).to(dev); sh = torch.randn(64, generator=g).to(dev)
+    packed = pm.se_res_pack(W1, b1, W2)
+    y_ref = pm.se_res_pool_packed(x, nbr, *packed, b2)
+    z_ref = pm.linear(y_ref, pm.pack_weight(Wc), 64, pre_bias=bc, scale=sc, shift=sh, act=pm.ACT_RELU)
+    y, z = pm.se_res_pool_conv(x, nbr, *packed, b2, pm.pack_weight(Wc), bc, sc, sh)
+    assert torch.equal(y, y_ref)
+    assert torch.equal(z, z_ref)
+
+
 def test_interpolate_idw_l2norm_and_head(dev, oracle):
     from dh3d_amd import ops, pm
     rng = np.random.default_rng(6)
