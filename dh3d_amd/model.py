@@ -176,13 +176,16 @@ class DH3D(nn.Module):
             self.invalidate()
         return out
 
-    def _check_mode(self):
+    def _check_mode(self, need_head=True):
         if self.training:
             raise NotImplementedError(
                 "training-mode BatchNorm is not implemented on the fused path; call model.eval()")
         if not self._prepared:
             self.prepare()
-        elif not self._head_prepared:
+        elif need_head and not self._head_prepared:
+            # (the trainer invalidates the head's packed copies after every optimiser step and only runs the frozen
+            #  backbone through this path: re-packing the head there would be wasted work -- and, inside a whole-step
+            #  hipGraph capture, host round trips)
             self._prepare_head()
 
     # ------------------------------------------------------------------ two streams
@@ -243,7 +246,7 @@ class DH3D(nn.Module):
         """(points, local descriptors [Bt,N,featdim]) (core/model.py:157-171).  _l2cat_eps (internal): the second item is
         [points | l2_normalize(descriptors)] instead, written by the last conv's store (forward(fetch=...) when nothing
         needs the raw descriptors)."""
-        self._check_mode()
+        self._check_mode(need_head=False)
         geo = _geo if _geo is not None else self._geometry(points, knn_inds)
         main = torch.cuda.current_stream()
         p = self._local._prep

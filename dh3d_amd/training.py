@@ -243,7 +243,7 @@ class QuadrupletTrainer(object):
     every rank, e.g. generated from a shared seed), runs this rank's block and returns the loss."""
 
     def __init__(self, model, start_lr=None, decay_step=None, decay_rate=None, weight_decay=None, sync_bn=True,
-                 impl="hip", graph_backbone=True):
+                 impl="hip", graph_backbone=True, graph_step=None):
         """Schedule / weight decay default to the model's config (core/configs.py:50-54,115-117).  sync_bn=True (the
         default) reproduces the reference's whole-batch BatchNorm statistics under sharding -- and keeps the running
         buffers identical on every rank; sync_bn=False normalises with per-rank statistics (a few clouds of one role
@@ -266,8 +266,23 @@ class QuadrupletTrainer(object):
         self.wd_params = [p for n, p in model.named_parameters() if n.endswith(".W")
                           and any(p is q for q in self.params)]
         self.weight_decay = weight_decay
-        self.opt = torch.optim.Adam(self.params, lr=start_lr)
-        self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, lambda s: decay_rate ** (s // decay_step))
+        # Whole-step hipGraph (forward, loss, backward, weight decay, Adam): a 22-cloud step is ~600 launches, about as
+        # much host time as GPU time.  Single process only (the collectives of a sharded step are not captured here);
+        # the first steps run eagerly (allocator / autograd warm-up), then the step is captured once per batch shape and
+        # replayed.  The learning rate is a device scalar the staircase schedule writes into.
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.graph_step = (impl == "hip" and world == 1) if graph_step is None else (bool(graph_step) and world == 1)
+        self._sched = (float(start_lr), int(decay_step), float(decay_rate))
+        self._steps_done = 0
+        self._step_graphs = {}
+        if self.graph_step:
+            dev = self.params[0].device
+            self._lr = torch.tensor(float(start_lr), dtype=torch.float32, device=dev)
+            self.opt = torch.optim.Adam(self.params, lr=self._lr, capturable=True)
+            self.sched = None
+        else:
+            self.opt = torch.optim.Adam(self.params, lr=start_lr)
+            self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, lambda s: decay_rate ** (s // decay_step))
 
     def forward_loss(self, points):
         cfg = self.cfg
@@ -278,7 +293,8 @@ class QuadrupletTrainer(object):
         self.model.eval()  # frozen backbone: fused inference path
         localdesc, lv = self._backbone(block)
         self._mark(1)
-        m = mask if not bool(mask.all()) else None
+        start, stop = D.local_slice(Bt, rank, world)
+        m = mask if (stop - start) < block.shape[0] else None  # (known on the host: no device round trip)
         if self.impl == "hip":
             desc = global_head_hip(self.model, block, localdesc.detach(), lv, sync_bn=self.sync_bn, mask=m)
         else:
@@ -294,11 +310,12 @@ class QuadrupletTrainer(object):
         """Frozen backbone + geometry of this rank's block: (localdesc [b,N,128], level dict of tensors).  Its weights
         never change during global_config training, so the two-stream forward is captured into a hipGraph once per
         block shape and replayed (eager, its ~45 launches cost 1.09 ms per step against ~0.75 ms replayed)."""
-        if not self.graph_backbone:
+        if not self.graph_backbone or torch.cuda.is_current_stream_capturing():  # (no replay inside a capture)
             with torch.no_grad():
                 geo = self.model._geometry(block, None)
                 _, localdesc = self.model.compute_local(block, _geo=geo)
                 lv = geo.level(8, self.model.knn_num)
+                self.model._join_side(geo)  # nothing of this step may stay open on the side stream (whole-step capture)
             return localdesc, lv
         key = (tuple(block.shape), block.device, getattr(self.model, "_backbone_version", 0))
         ent = self._bb_graphs.get(key)
@@ -354,7 +371,43 @@ class QuadrupletTrainer(object):
                 cnt[k0] += 1
         return {n: (t / c if c else None) for n, t, c in zip(names, tot, cnt)}
 
+    def _lr_now(self):
+        lr0, dstep, drate = self._sched
+        return lr0 * drate ** (self._steps_done // dstep)
+
+    def _step_graphed(self, points):
+        key = (tuple(points.shape), points.device, getattr(self.model, "_backbone_version", 0))
+        ent = self._step_graphs.get(key)
+        if ent is None:
+            self._step_graphs.clear()
+            static_in = points.clone()
+            self.opt.zero_grad(set_to_none=True)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                loss = self.forward_loss(static_in)
+                loss.backward()
+                if self.wd_params and self.weight_decay:
+                    gs = [p.grad for p in self.wd_params if p.grad is not None]
+                    ps = [p.detach() for p in self.wd_params if p.grad is not None]
+                    if gs:
+                        torch._foreach_add_(gs, ps, alpha=self.weight_decay)
+                self.opt.step()
+            ent = (graph, static_in, loss)
+            self._step_graphs[key] = ent
+        graph, static_in, loss = ent
+        static_in.copy_(points)
+        self._lr.fill_(self._lr_now())
+        graph.replay()
+        self._steps_done += 1
+        self.model.invalidate(head_only=True)
+        return float(loss.detach())
+
     def step(self, points):
+        # eager for the first steps, while phases are timed or gradients are kept for inspection
+        if self.graph_step and self._steps_done >= 3 and self._ev is None and not self.keep_grads:
+            return self._step_graphed(points)
+        if self.graph_step:
+            self._lr.fill_(self._lr_now())
         self.opt.zero_grad(set_to_none=True)
         self._mark(0)
         loss = self.forward_loss(points)
@@ -379,7 +432,9 @@ class QuadrupletTrainer(object):
         if self.keep_grads:  # tests: the reduced gradient of this step (Adam's m/sqrt(v) is sign-like in the first
             self.last_grads = [p.grad.detach().clone() for p in self.params]  # steps: parameters are ill-conditioned)
         self.opt.step()
-        self.sched.step()
+        if self.sched is not None:
+            self.sched.step()
+        self._steps_done += 1
         self._mark(4)
         self.model.invalidate(head_only=True)  # the packed / folded weight copies of the fused inference path are stale now
         return float(loss.detach())

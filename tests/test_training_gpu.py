@@ -430,7 +430,9 @@ def test_trainer_backbone_graph_matches_eager_and_survives_a_reload(dev):
             out.append((loss, [g.clone() for g in tr.last_grads]))
         res.append((out, tr, m))
     for (la, ga), (lb, gb) in zip(res[0][0], res[1][0]):
-        assert abs(la - lb) <= 1e-5 * max(1.0, abs(lb)), (la, lb)
+        # (the second step sees parameters moved by Adam's sign-like first update: the ~1e-6 run-to-run jitter of the
+        #  atomics-summed gradients shows up as ~1e-5 in its loss)
+        assert abs(la - lb) <= 1e-4 * max(1.0, abs(lb)), (la, lb)
         for x, y in zip(ga, gb):
             assert float((x - y).abs().max()) <= 5e-3 * float(y.abs().max()) + 1e-6
     # reload other backbone weights into the graphed trainer's model: the next step must see them
@@ -440,5 +442,29 @@ def test_trainer_backbone_graph_matches_eager_and_survives_a_reload(dev):
     m.load_state_dict(other.state_dict())
     tr2 = QuadrupletTrainer(other, start_lr=1e-3, graph_backbone=False)
     la, lb = tr.step(batches[0]), tr2.step(batches[0])
-    assert abs(la - lb) <= 1e-5 * max(1.0, abs(lb)), (la, lb)
+    assert abs(la - lb) <= 1e-4 * max(1.0, abs(lb)), (la, lb)
     assert len(tr._bb_graphs) == 1  # the stale graph was dropped, a new one captured
+
+
+def test_trainer_whole_step_graph_matches_eager_steps(dev):
+    """graph_step=True (forward + loss + backward + weight decay + Adam captured into one hipGraph after three eager
+    steps, replayed with the batch copied into its input buffer) follows the same trajectory as eager steps: losses
+    over eight steps on alternating batches, the learning-rate staircase included (decay_step = 4)."""
+    from dh3d_amd.training import QuadrupletTrainer
+    batches = [torch.rand(7, 1024, 3, generator=torch.Generator().manual_seed(s)).to(dev) for s in (11, 12)]
+    traj = []
+    for graph in (True, False):
+        m = _build(dev, seed=31, B=1, P=2, Ng=3)
+        tr = QuadrupletTrainer(m, start_lr=5e-4, decay_step=4, decay_rate=0.5, graph_step=graph, graph_backbone=graph)
+        assert tr.graph_step == graph
+        ls = [tr.step(batches[i % 2]) for i in range(8)]
+        traj.append((ls, [p.detach().clone() for p in tr.params], tr))
+    (la, pa, tra), (lb, pb, _) = traj
+    assert len(tra._step_graphs) == 1
+    assert all(np.isfinite(la)) and all(np.isfinite(lb))
+    # Adam's sign-like first steps amplify rounding differences of the (atomics-summed) gradients: the trajectories
+    # agree to a few 1e-3 in the loss, not bit for bit
+    for x, y in zip(la, lb):
+        assert abs(x - y) <= 2e-2 * max(1.0, abs(y)), (la, lb)
+    drift = max(float((x - y).abs().max()) for x, y in zip(pa, pb))
+    assert drift <= 5e-3, drift
