@@ -112,14 +112,14 @@ _SIGNATURES = {
                              c_fp, c_fp],
     "dh3d_interp_head_sorted_fwd": [c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, ctypes.POINTER(Epilogue), c_fp,
                                     c_float, c_fp, c_fp],
-    "dh3d_interp_head_sorted_fwd_dev": [c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, ctypes.POINTER(Epilogue), c_fp,
-                                        c_fp, c_fp, c_fp],
+    "dh3d_interp_head_sorted_fwd_dev": [c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, ctypes.POINTER(Epilogue),
+                                        c_fp, c_fp, c_fp, c_fp],
     "dh3d_three_interpolate_bwd_sorted": [c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp],
-    "dh3d_interp_bn_colstats": [c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp],
-    "dh3d_interp_bn_bwd_sums": [c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
-                                c_fp, c_fp, c_fp],
-    "dh3d_interp_bn_bwd_apply": [c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
-                                 c_fp, c_fp, c_fp],
+    "dh3d_interp_bn_colstats": [c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp],
+    "dh3d_interp_bn_bwd_sums": [c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp,
+                                c_fp, c_fp, c_fp, c_fp],
+    "dh3d_interp_bn_bwd_apply": [c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp,
+                                 c_fp, c_fp, c_fp, c_fp],
     "dh3d_linear_pm_x6_fwd": [c_fp, c_int, c_fp, c_int, c_fp, c_int, c_int, ctypes.POINTER(Epilogue), c_fp, c_fp, c_fp],
     "dh3d_se_res_pm_packed_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp],
     "dh3d_se_res_pool_pm_packed_fwd": [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp],

@@ -724,8 +724,8 @@ constexpr int kIHPW = kIHP / 4;  // points per wave
 // global memory.  The common case has no branch at all: a taken scalar branch costs ~35 cycles and there would be
 // three per point and slice.
 template <bool OVF>
-__device__ __forceinline__ float4 ih_row4(const float *s_rows, const float *gbase, int slot, int lane) {
-  if (OVF && slot < 0) return *reinterpret_cast<const float4 *>(gbase + (size_t)(-1 - slot) * 256 + lane * 4);
+__device__ __forceinline__ float4 ih_row4(const float *s_rows, const float *gbase, int slot, int lane, int rs = 256) {
+  if (OVF && slot < 0) return *reinterpret_cast<const float4 *>(gbase + (size_t)(-1 - slot) * rs + lane * 4);
   return *reinterpret_cast<const float4 *>(s_rows + (size_t)slot * 256 + lane * 4);
 }
 
@@ -737,6 +737,8 @@ struct VladTail {
   float *apart;           // [B, m, 64]  A' (zeroed by the launcher)
   float *asum;            // [B, 64]     sum_n a[n,:] (zeroed by the launcher)
   const float *b_dev;     // (either instantiation) the fc bias as a device scalar, added to b_fc; may be NULL
+  long long h_ss;         // (either) layout of H: slice stride and row stride in floats; 0 = the slice layout
+  int h_rs;               //          [NS][Rc][256] (h_ss = Rc * 256, h_rs = 256); row-major [Rc][Hd]: 256, Hd
 };
 
 template <bool VLAD>
@@ -814,6 +816,8 @@ __global__ __launch_bounds__(256) void interp_head_lds_kernel(const float *__res
   __syncthreads();
   const int nd = min(s_pre[32], kIHCap);
   const bool overflow = s_pre[32] > kIHCap;  // block-uniform: some rows are not staged
+  const long long SS = vt.h_ss ? vt.h_ss : Rc * 256;
+  const int RS = vt.h_rs ? vt.h_rs : 256;
   const float lo = ep.act == DH3D_ACT_RELU ? 0.f : -__builtin_inff();  // ReLU as a clamp, or no activation
   if (tid < kIHP) s_z[tid] = 0.f;
   // ---- staging: wave w takes slots w, w + 4, ...; the rows of slice sl + 1 are requested BEFORE the points of slice
@@ -827,12 +831,12 @@ __global__ __launch_bounds__(256) void interp_head_lds_kernel(const float *__res
 #pragma unroll
   for (int u = 0; u < kIHCap / 4; ++u) {
     const int r = wave + 4 * u;
-    rowoff[u] = (bi * m + s_row[r < nd ? r : 0]) * 256 + lane * 4;
+    rowoff[u] = (bi * m + s_row[r < nd ? r : 0]) * RS + lane * 4;
   }
   f32x64 rg;
 #define DH3D_IH_REQUEST(SL)                                                                     \
   {                                                                                             \
-    const float *Hn = H + (size_t)(SL) * Rc * 256;                                              \
+    const float *Hn = H + (size_t)(SL) * SS;                                                    \
     _Pragma("unroll") for (int u = 0; u < kIHCap / 4; ++u) {                                    \
       const float4 v = *reinterpret_cast<const float4 *>(Hn + rowoff[u]);                       \
       rg[4 * u] = v.x; rg[4 * u + 1] = v.y; rg[4 * u + 2] = v.z; rg[4 * u + 3] = v.w;           \
@@ -840,7 +844,7 @@ __global__ __launch_bounds__(256) void interp_head_lds_kernel(const float *__res
   }
   DH3D_IH_REQUEST(0)
   for (int sl = 0; sl < NS; ++sl) {
-    const float *Hs = H + ((size_t)sl * Rc + (size_t)bi * m) * 256;
+    const float *Hs = H + (size_t)sl * SS + (size_t)bi * m * RS;
 #pragma unroll
     for (int u = 0; u < kIHCap / 4; ++u) {  // all slots, used or not: no branch between the loads and these stores
       const int r = wave + 4 * u;
@@ -869,8 +873,8 @@ __global__ __launch_bounds__(256) void interp_head_lds_kernel(const float *__res
           const float4 sw = *reinterpret_cast<const float4 *>(s_w + pt * 4);
           const int s0 = __builtin_amdgcn_readfirstlane(si.x), s1 = __builtin_amdgcn_readfirstlane(si.y),
                     s2 = __builtin_amdgcn_readfirstlane(si.z);
-          const float4 v = idw_mix(ih_row4<OVF>(s_rows, Hs, s0, lane), ih_row4<OVF>(s_rows, Hs, s1, lane),
-                                   ih_row4<OVF>(s_rows, Hs, s2, lane), sw.x, sw.y, sw.z);  // padding: weight 0
+          const float4 v = idw_mix(ih_row4<OVF>(s_rows, Hs, s0, lane, RS), ih_row4<OVF>(s_rows, Hs, s1, lane, RS),
+                                   ih_row4<OVF>(s_rows, Hs, s2, lane, RS), sw.x, sw.y, sw.z);  // padding: weight 0
           float a = fmaxf((v.x + pb.x) * sc.x + sh.x, lo) * wf.x;
           a = fmaf(fmaxf((v.y + pb.y) * sc.y + sh.y, lo), wf.y, a);
           a = fmaf(fmaxf((v.z + pb.z) * sc.z + sh.z, lo), wf.z, a);
@@ -1055,9 +1059,10 @@ DH3D_API int dh3d_interp_head_sorted_fwd(const float *H, int Hd, const int32_t *
 }
 
 // Same with the fc bias read from device memory (a trainable parameter: no host round trip in the training step).
-DH3D_API int dh3d_interp_head_sorted_fwd_dev(const float *H, int Hd, const int32_t *idx, const float *dist,
-                                             const float *order, int B, int n, int m, const dh3d_epilogue *ep,
-                                             const float *w_fc, const float *b_fc_dev, float *att, void *stream) {
+DH3D_API int dh3d_interp_head_sorted_fwd_dev(const float *H, int Hd, int row_major, const int32_t *idx,
+                                             const float *dist, const float *order, int B, int n, int m,
+                                             const dh3d_epilogue *ep, const float *w_fc, const float *b_fc_dev,
+                                             float *att, void *stream) {
   DH3D_REQUIRE(H && idx && dist && w_fc && b_fc_dev && att && B > 0 && n > 0 && m > 0 && Hd > 0);
   DH3D_SUPPORTED(Hd % 256 == 0 && Hd <= 1024 && m <= 1024 && (!ep || ep->act != DH3D_ACT_SIGMOID));
   const int nblk = dh3d_cdiv(n, kIHP);
@@ -1065,6 +1070,7 @@ DH3D_API int dh3d_interp_head_sorted_fwd_dev(const float *H, int Hd, const int32
   DH3D_ALLOW_BIG_LDS(interp_head_lds_kernel<false>);
   VladTail vt{};
   vt.b_dev = b_fc_dev;
+  if (row_major) { vt.h_ss = 256; vt.h_rs = Hd; }  // H = [B*m][Hd] (one GEMM's output) instead of 256-column slices
   hipLaunchKernelGGL(interp_head_lds_kernel<false>, dim3(8 * per_xcd), dim3(256), interp_head_lds_bytes(),
                      (hipStream_t)stream, H, Hd / 256, (long long)B * m, idx, dist, reinterpret_cast<const float4 *>(order),
                      B, n, m, nblk, dh3d_ep(ep), w_fc, 0.f, att, vt);

@@ -55,8 +55,8 @@ __device__ __forceinline__ float4 mix3(const float4 a, const float4 b, const flo
 #pragma clang fp contract(fast)
 
 template <bool OVF>
-__device__ __forceinline__ float4 row4(const float *s_rows, const float *gbase, int slot, int lane) {
-  if (OVF && slot < 0) return *reinterpret_cast<const float4 *>(gbase + (size_t)(-1 - slot) * 256 + lane * 4);
+__device__ __forceinline__ float4 row4(const float *s_rows, const float *gbase, int slot, int lane, int rs) {
+  if (OVF && slot < 0) return *reinterpret_cast<const float4 *>(gbase + (size_t)(-1 - slot) * rs + lane * 4);
   return *reinterpret_cast<const float4 *>(s_rows + (size_t)slot * 256 + lane * 4);
 }
 
@@ -75,9 +75,11 @@ __device__ __forceinline__ f32x64 request_rows(const float *Gslice, const int (&
 }
 
 struct InterpBnArgs {
-  const float *G;            // [NS][Rc][256] slices of coarse @ W + b
-  int NS;
+  const float *G;            // coarse @ W + b: 256-column slices [NS][Rc][256] (SS = Rc*256, RS = 256) or row-major
+  int NS;                    //   [Rc][Hd] (SS = 256, RS = Hd); dG has the same layout
   long long Rc;              // B * m
+  long long SS;              // slice stride (floats)
+  int RS;                    // row stride (floats)
   const int32_t *idx;        // [B, n, 3]
   const float *dist;         // [B, n, 3]
   const float4 *order;       // [B, n] spatial_sort records of the fine cloud
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(256) void interp_bn_kernel(const InterpBnArgs a) {
 #pragma unroll
   for (int u = 0; u < CAP / 4; ++u) {
     const int r = wave + 4 * u;
-    rowoff[u] = (bi * m + s_row[r < nd ? r : 0]) * 256 + lane * 4;
+    rowoff[u] = (bi * m + s_row[r < nd ? r : 0]) * a.RS + lane * 4;
   }
   // (not in MODE 2: 64 more registers would leave one wave per SIMD there)
   constexpr bool PREFETCH = MODE != 2;
@@ -184,10 +186,10 @@ __global__ __launch_bounds__(256) void interp_bn_kernel(const InterpBnArgs a) {
   if (MODE != 3 && PREFETCH) rg = request_rows<CAP / 4>(a.G, rowoff);
 #endif
   for (int sl = 0; sl < a.NS; ++sl) {
-    const float *Gs = MODE == 3 ? nullptr : a.G + (size_t)sl * a.Rc * 256 + (size_t)bi * m * 256;
+    const float *Gs = MODE == 3 ? nullptr : a.G + (size_t)sl * a.SS + (size_t)bi * m * a.RS;
 #if !defined(DH3D_IB_EXP) || !(DH3D_IB_EXP & 16)
     if (MODE != 3) {
-      if (!PREFETCH) rg = request_rows<CAP / 4>(a.G + (size_t)sl * a.Rc * 256, rowoff);
+      if (!PREFETCH) rg = request_rows<CAP / 4>(a.G + (size_t)sl * a.SS, rowoff);
 #pragma unroll
       for (int u = 0; u < CAP / 4; ++u) {  // all CAP slots, used or not: no branch between the loads and these stores
         const int r = wave + 4 * u;
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(256) void interp_bn_kernel(const InterpBnArgs a) {
             make_float4(rg[4 * u], rg[4 * u + 1], rg[4 * u + 2], rg[4 * u + 3]);
       }
       // (unconditional -- the last slice once more: a load under a branch would be merged through memory)
-      if (PREFETCH) rg = request_rows<CAP / 4>(a.G + (size_t)(sl + 1 < a.NS ? sl + 1 : sl) * a.Rc * 256, rowoff);
+      if (PREFETCH) rg = request_rows<CAP / 4>(a.G + (size_t)(sl + 1 < a.NS ? sl + 1 : sl) * a.SS, rowoff);
     }
 #endif
     const int c = sl * 256 + lane * 4;
@@ -218,8 +220,8 @@ __global__ __launch_bounds__(256) void interp_bn_kernel(const InterpBnArgs a) {
           const float4 sw = *reinterpret_cast<const float4 *>(s_w + pt * 4);
           const int s0 = __builtin_amdgcn_readfirstlane(si.x), s1 = __builtin_amdgcn_readfirstlane(si.y),
                     s2 = __builtin_amdgcn_readfirstlane(si.z);
-          const float4 h = mix3(row4<OVF>(s_rows, Gs, s0, lane), row4<OVF>(s_rows, Gs, s1, lane),
-                                row4<OVF>(s_rows, Gs, s2, lane), sw.x, sw.y, sw.z);
+          const float4 h = mix3(row4<OVF>(s_rows, Gs, s0, lane, a.RS), row4<OVF>(s_rows, Gs, s1, lane, a.RS),
+                                row4<OVF>(s_rows, Gs, s2, lane, a.RS), sw.x, sw.y, sw.z);
           if (MODE == 0) {
             const float f = si.w ? 1.f : 0.f;  // padding points: h = 0 anyway (zero weights)
             A1.x += h.x; A1.y += h.y; A1.z += h.z; A1.w += h.w;
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(256) void interp_bn_kernel(const InterpBnArgs a) {
     } else {
       // ---- MODE 2: dh per point into LDS 32 points at a time, scattered onto the staged rows by an MFMA product
       float *s_dh = s_x;
-      float *dGs = a.dG + (size_t)sl * a.Rc * 256 + (size_t)bi * m * 256;  // (MODE 3: NS = 1)
+      float *dGs = a.dG + (size_t)sl * a.SS + (size_t)bi * m * a.RS;  // (MODE 3: NS = 1, RS = 256)
       const int nrt = nd > 32 ? 2 : 1;  // 32-slot row tiles in use (block-uniform)
       f32x16 acc[2][2];
 #pragma unroll
@@ -306,8 +308,8 @@ __global__ __launch_bounds__(256) void interp_bn_kernel(const InterpBnArgs a) {
             if (MODE == 3) {
               dh = make_float4(cur[4 * j], cur[4 * j + 1], cur[4 * j + 2], cur[4 * j + 3]);
             } else {
-            const float4 h = mix3(row4<OVF>(s_rows, Gs, s0, lane), row4<OVF>(s_rows, Gs, s1, lane),
-                                  row4<OVF>(s_rows, Gs, s2, lane), sw.x, sw.y, sw.z);
+            const float4 h = mix3(row4<OVF>(s_rows, Gs, s0, lane, a.RS), row4<OVF>(s_rows, Gs, s1, lane, a.RS),
+                                  row4<OVF>(s_rows, Gs, s2, lane, a.RS), sw.x, sw.y, sw.z);
             const float dl = sw.w, live = si.w ? 1.f : 0.f;
             // dh = k1 dz - k2 - k3 h,  dz = dlogit w_fc [h scale + shift > 0]   (0 on padding points)
 #define DH3D_IB_DH(X)                                                                           \
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(256) void interp_bn_kernel(const InterpBnArgs a) {
 #pragma unroll
               for (int t = 0; t < 3; ++t)
                 if (st[t] < 0) {
-                  float *dst = dGs + (size_t)(-1 - st[t]) * 256 + lane * 4;
+                  float *dst = dGs + (size_t)(-1 - st[t]) * a.RS + lane * 4;
                   unsafeAtomicAdd(dst, wt[t] * dh.x); unsafeAtomicAdd(dst + 1, wt[t] * dh.y);
                   unsafeAtomicAdd(dst + 2, wt[t] * dh.z); unsafeAtomicAdd(dst + 3, wt[t] * dh.w);
                 }
@@ -367,11 +369,11 @@ __global__ __launch_bounds__(256) void interp_bn_kernel(const InterpBnArgs a) {
             for (int r = 0; r < 16; ++r) {
               const int j = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);  // 32x32 accumulator layout
 #if defined(DH3D_IB_EXP) && (DH3D_IB_EXP & 2)   // timing experiment: plain stores instead of atomics (results wrong)
-              if (j < nd) dGs[(size_t)s_row[j] * 256 + wave * 64 + ct * 32 + (lane & 31)] = acc[rt][ct][r];
+              if (j < nd) dGs[(size_t)s_row[j] * a.RS + wave * 64 + ct * 32 + (lane & 31)] = acc[rt][ct][r];
 #elif defined(DH3D_IB_EXP) && (DH3D_IB_EXP & 4)   // timing experiment: no flush at all
               if (j < nd && acc[rt][ct][r] == 123.456f) dGs[0] = 1.f;
 #else
-              if (j < nd) unsafeAtomicAdd(dGs + (size_t)s_row[j] * 256 + wave * 64 + ct * 32 + (lane & 31), acc[rt][ct][r]);
+              if (j < nd) unsafeAtomicAdd(dGs + (size_t)s_row[j] * a.RS + wave * 64 + ct * 32 + (lane & 31), acc[rt][ct][r]);
 #endif
             }
         }
@@ -405,14 +407,16 @@ bool shape_ok(int Hd, int m) { return Hd % 256 == 0 && Hd >= 256 && Hd <= 1024 &
 // mask [B] bytes (may be NULL).  part [2][B][Hd] f64 (zeroed here): per-CLOUD partial sums / sums of squares -- their
 // sums over B are the column statistics (704 workgroups adding into one row of 1024 doubles cost 27 of 97 us in L2
 // atomics on the same addresses; per cloud it is 32 workgroups per address).
-DH3D_API int dh3d_interp_bn_colstats(const float *G, int Hd, const int32_t *idx, const float *dist, const float *order,
-                                     int B, int n, int m, const unsigned char *mask, double *part, void *stream) {
+DH3D_API int dh3d_interp_bn_colstats(const float *G, int Hd, int row_major, const int32_t *idx, const float *dist,
+                                     const float *order, int B, int n, int m, const unsigned char *mask, double *part,
+                                     void *stream) {
   DH3D_REQUIRE(G && idx && dist && part && B > 0 && n > 0 && m > 0);
   DH3D_SUPPORTED(shape_ok(Hd, m));
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(part, 0, sizeof(double) * 2 * (size_t)B * Hd, s) != hipSuccess) return DH3D_ERR_LAUNCH;
   InterpBnArgs a{};
   a.G = G; a.NS = Hd / 256; a.Rc = (long long)B * m; a.idx = idx; a.dist = dist;
+  a.SS = row_major ? 256 : a.Rc * 256; a.RS = row_major ? Hd : 256;
   a.order = reinterpret_cast<const float4 *>(order); a.B = B; a.n = n; a.m = m; a.nblk = dh3d_cdiv(n, kP); a.mask = mask;
   a.s0 = part; a.s1 = part + (size_t)B * Hd;
   return launch<0>(a, s);
@@ -420,8 +424,8 @@ DH3D_API int dh3d_interp_bn_colstats(const float *G, int Hd, const int32_t *idx,
 
 // part [3][B][Hd] f64 (zeroed here): per-cloud partials of S1, S2, S3 -- the sums of dh3d_bn_bwd_sums for the rank-one
 // gradient dy = dlogit x w_fc on the virtual rows h = interp(G);  dlogit [B*n] by original point index.
-DH3D_API int dh3d_interp_bn_bwd_sums(const float *G, int Hd, const int32_t *idx, const float *dist, const float *order,
-                                     int B, int n, int m, const unsigned char *mask, const float *dlogit,
+DH3D_API int dh3d_interp_bn_bwd_sums(const float *G, int Hd, int row_major, const int32_t *idx, const float *dist,
+                                     const float *order, int B, int n, int m, const unsigned char *mask, const float *dlogit,
                                      const float *w_fc, const float *mean, const float *rstd, const float *gamma,
                                      const float *beta, double *part, void *stream) {
   DH3D_REQUIRE(G && idx && dist && dlogit && w_fc && mean && rstd && gamma && beta && part);
@@ -431,6 +435,7 @@ DH3D_API int dh3d_interp_bn_bwd_sums(const float *G, int Hd, const int32_t *idx,
   if (hipMemsetAsync(part, 0, sizeof(double) * 3 * (size_t)B * Hd, s) != hipSuccess) return DH3D_ERR_LAUNCH;
   InterpBnArgs a{};
   a.G = G; a.NS = Hd / 256; a.Rc = (long long)B * m; a.idx = idx; a.dist = dist;
+  a.SS = row_major ? 256 : a.Rc * 256; a.RS = row_major ? Hd : 256;
   a.order = reinterpret_cast<const float4 *>(order); a.B = B; a.n = n; a.m = m; a.nblk = dh3d_cdiv(n, kP); a.mask = mask;
   a.dlogit = dlogit; a.wfc = w_fc; a.v0 = mean; a.v1 = rstd; a.v2 = gamma; a.v3 = beta;
   a.s0 = part; a.s1 = part + (size_t)B * Hd; a.s2 = part + 2 * (size_t)B * Hd;
@@ -439,8 +444,8 @@ DH3D_API int dh3d_interp_bn_bwd_sums(const float *G, int Hd, const int32_t *idx,
 
 // dG [Hd/256][B*m][256] (zeroed here) = interp^T(dh),  dh = scale dz - k2 - k3 h  (the coefficients of
 // dh3d_bn_bwd_finalize; dz = dlogit w_fc [h scale + shift > 0]); f32 atomics.
-DH3D_API int dh3d_interp_bn_bwd_apply(const float *G, int Hd, const int32_t *idx, const float *dist, const float *order,
-                                      int B, int n, int m, const unsigned char *mask, const float *dlogit,
+DH3D_API int dh3d_interp_bn_bwd_apply(const float *G, int Hd, int row_major, const int32_t *idx, const float *dist,
+                                      const float *order, int B, int n, int m, const unsigned char *mask, const float *dlogit,
                                       const float *w_fc, const float *scale, const float *shift, const float *k2,
                                       const float *k3, float *dG, void *stream) {
   DH3D_REQUIRE(G && idx && dist && dlogit && w_fc && scale && shift && k2 && k3 && dG && B > 0 && n > 0 && m > 0);
@@ -449,6 +454,7 @@ DH3D_API int dh3d_interp_bn_bwd_apply(const float *G, int Hd, const int32_t *idx
   if (hipMemsetAsync(dG, 0, sizeof(float) * (size_t)B * m * Hd, s) != hipSuccess) return DH3D_ERR_LAUNCH;
   InterpBnArgs a{};
   a.G = G; a.NS = Hd / 256; a.Rc = (long long)B * m; a.idx = idx; a.dist = dist;
+  a.SS = row_major ? 256 : a.Rc * 256; a.RS = row_major ? Hd : 256;
   a.order = reinterpret_cast<const float4 *>(order); a.B = B; a.n = n; a.m = m; a.nblk = dh3d_cdiv(n, kP); a.mask = mask;
   a.dlogit = dlogit; a.wfc = w_fc; a.v0 = scale; a.v1 = shift; a.v2 = k2; a.v3 = k3; a.dG = dG;
   return launch<2>(a, s);
@@ -465,7 +471,7 @@ DH3D_API int dh3d_three_interpolate_bwd_sorted(int b, int n, int c, int m, const
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * m * c, s) != hipSuccess) return DH3D_ERR_LAUNCH;
   InterpBnArgs a{};
-  a.NS = 1; a.Rc = (long long)b * m; a.idx = idx; a.weight = weight; a.dY = grad_out;
+  a.NS = 1; a.Rc = (long long)b * m; a.SS = 0; a.RS = 256; a.idx = idx; a.weight = weight; a.dY = grad_out;
   a.order = reinterpret_cast<const float4 *>(order); a.B = b; a.n = n; a.m = m; a.nblk = dh3d_cdiv(n, kP);
   a.dG = grad_points;
   return launch<3>(a, s);

@@ -716,14 +716,21 @@ def bn_bwd_apply(x, scale, shift, k2, k3, relu, dy=None, rowscale=None, colvec=N
 
 
 # ---- attention head, training mode, conv commuted through the up-sampling (csrc/interp_train.hip)
+def _g_layout(G, idx):
+    """G: [ns, B*m, 256] slices or [B*m, Hd] row-major -> (Hd, row_major flag, m)."""
+    B = idx.shape[0]
+    if G.dim() == 3:
+        return G.shape[0] * 256, 0, G.shape[1] // B
+    return G.shape[1], 1, G.shape[0] // B
+
+
 def interp_bn_colstats(G, idx, dist, order, mask=None, out=None):
-    """G [ns, B*m, 256] slices of coarse @ W + b; idx/dist [B,n,3]; order = spatial_sort records [B,n,4] or None ->
-    (sum, sumsq) [Hd] float64 of the virtual rows three_interpolate(G) (views of `out` [>= 2*Hd] if given)."""
-    ns, Rc, _ = G.shape
+    """G = coarse @ W + b as [ns, B*m, 256] slices or as [B*m, Hd]; idx/dist [B,n,3]; order = spatial_sort records
+    [B,n,4] or None -> (sum, sumsq) [Hd] float64 of the virtual rows three_interpolate(G) (views of `out` if given)."""
+    Hd, rm, m = _g_layout(G, idx)
     B, n = idx.shape[0], idx.shape[1]
-    Hd = ns * 256
     part = torch.empty((2, B, Hd), dtype=torch.float64, device=G.device)
-    L.check(L.lib().dh3d_interp_bn_colstats(L.ptr(G), Hd, L.ptr(idx), L.ptr(dist), L.ptr(order), B, n, Rc // B,
+    L.check(L.lib().dh3d_interp_bn_colstats(L.ptr(G), Hd, rm, L.ptr(idx), L.ptr(dist), L.ptr(order), B, n, m,
                                             L.ptr(_mask_u8(mask)), L.ptr(part), L.stream_ptr()), "interp_bn_colstats")
     buf = out if out is not None else torch.empty((2 * Hd,), dtype=torch.float64, device=G.device)
     torch.sum(part, dim=1, out=buf[:2 * Hd].view(2, Hd))
@@ -732,33 +739,32 @@ def interp_bn_colstats(G, idx, dist, order, mask=None, out=None):
 
 def interp_head_rows(G, idx, dist, order, scale, shift, w_fc, b_fc_dev):
     """att [B*n] = sigmoid(relu(three_interpolate(G) * scale + shift) . w_fc + b_fc), b_fc a device scalar."""
-    ns, Rc, _ = G.shape
+    Hd, rm, m = _g_layout(G, idx)
     B, n = idx.shape[0], idx.shape[1]
     out = torch.empty((B * n,), dtype=torch.float32, device=G.device)
     ep = _ep(None, scale, shift, ACT_RELU)
-    L.check(L.lib().dh3d_interp_head_sorted_fwd_dev(L.ptr(G), ns * 256, L.ptr(idx), L.ptr(dist), L.ptr(order), B, n,
-                                                    Rc // B, ep, L.ptr(w_fc), L.ptr(b_fc_dev), L.ptr(out),
-                                                    L.stream_ptr()), "interp_head_sorted_dev")
+    L.check(L.lib().dh3d_interp_head_sorted_fwd_dev(L.ptr(G), Hd, rm, L.ptr(idx), L.ptr(dist), L.ptr(order), B, n, m, ep,
+                                                    L.ptr(w_fc), L.ptr(b_fc_dev), L.ptr(out), L.stream_ptr()),
+            "interp_head_sorted_dev")
     return out
 
 
 def interp_bn_bwd_sums(G, idx, dist, order, dlogit, w_fc, mean, rstd, gamma, beta, mask=None):
-    ns, Rc, _ = G.shape
+    Hd, rm, m = _g_layout(G, idx)
     B, n = idx.shape[0], idx.shape[1]
-    Hd = ns * 256
     part = torch.empty((3, B, Hd), dtype=torch.float64, device=G.device)
-    L.check(L.lib().dh3d_interp_bn_bwd_sums(L.ptr(G), Hd, L.ptr(idx), L.ptr(dist), L.ptr(order), B, n, Rc // B,
+    L.check(L.lib().dh3d_interp_bn_bwd_sums(L.ptr(G), Hd, rm, L.ptr(idx), L.ptr(dist), L.ptr(order), B, n, m,
                                             L.ptr(_mask_u8(mask)), L.ptr(dlogit), L.ptr(w_fc), L.ptr(mean), L.ptr(rstd),
                                             L.ptr(gamma), L.ptr(beta), L.ptr(part), L.stream_ptr()), "interp_bn_bwd_sums")
     return part.sum(1)
 
 
 def interp_bn_bwd_apply(G, idx, dist, order, dlogit, w_fc, scale, shift, k2, k3, mask=None):
-    """-> dG [ns, B*m, 256] = interp^T(scale*dz - k2 - k3*h)."""
-    ns, Rc, _ = G.shape
+    """-> dG (the layout of G) = interp^T(scale*dz - k2 - k3*h)."""
+    Hd, rm, m = _g_layout(G, idx)
     B, n = idx.shape[0], idx.shape[1]
     dG = torch.empty_like(G)
-    L.check(L.lib().dh3d_interp_bn_bwd_apply(L.ptr(G), ns * 256, L.ptr(idx), L.ptr(dist), L.ptr(order), B, n, Rc // B,
+    L.check(L.lib().dh3d_interp_bn_bwd_apply(L.ptr(G), Hd, rm, L.ptr(idx), L.ptr(dist), L.ptr(order), B, n, m,
                                              L.ptr(_mask_u8(mask)), L.ptr(dlogit), L.ptr(w_fc), L.ptr(scale),
                                              L.ptr(shift), L.ptr(k2), L.ptr(k3), L.ptr(dG), L.stream_ptr()),
             "interp_bn_bwd_apply")

@@ -206,19 +206,16 @@ def three_interpolate_sorted(points, idx, weight, order):
 
 class _AttentionHeadCommuted(torch.autograd.Function):
     """The same head on the up-sampled rows three_interpolate(C) WITHOUT building them: conv(interp(C)) = interp(conv(C)),
-    so the three big GEMMs run on the sampled rows C [Bt*M, Cin] and the [Bt*N, H] pre-activation only exists inside
-    the kernels of csrc/interp_train.hip (statistics, forward, backward sums, backward apply + scatter)."""
+    so the three big GEMMs run on the sampled rows C [Bt*M, Cin] -- one launch each, G = C W + b in its natural
+    [Bt*M, H] layout -- and the [Bt*N, H] pre-activation only exists inside the kernels of csrc/interp_train.hip
+    (statistics, forward, backward sums, backward apply + scatter)."""
 
     @staticmethod
     def forward(ctx, C, W, b, gamma, beta, run_mean, run_var, eps, momentum, wfc, bfc, sync, mask, idx, dist, order):
         C = C.contiguous()
-        Wd, bd = W.detach(), b.detach()
+        Wd = W.detach().contiguous()
         H = Wd.shape[1]
-        ns = H // 256
-        G = torch.empty((ns, C.shape[0], 256), dtype=torch.float32, device=C.device)
-        Wt = Wd.reshape(Wd.shape[0], ns, 256).transpose(0, 1).contiguous()              # [ns, Cin, 256]
-        for j in range(ns):
-            pm.gemm_nn(C, Wt[j], bias=bd[j * 256:(j + 1) * 256].contiguous(), out=G[j])
+        G = pm.gemm_nn(C, Wd, bias=b.detach().contiguous())                             # [Bt*M, H]
         Bt, N = idx.shape[0], idx.shape[1]
         g, be = gamma.detach().contiguous(), beta.detach().contiguous()
         packed = torch.empty((2 * H + 1,), dtype=torch.float64, device=C.device)
@@ -233,13 +230,13 @@ class _AttentionHeadCommuted(torch.autograd.Function):
         st.cnt = cnt
         wv = wfc.detach().reshape(-1).contiguous()
         att = pm.interp_head_rows(G, idx, dist, order, st.stats[2], st.stats[3], wv, bfc.detach().reshape(-1).contiguous())
-        ctx.save_for_backward(C, Wt, G, g, be, wv, att)
+        ctx.save_for_backward(C, Wd, G, g, be, wv, att)
         ctx.cfg = (bool(sync), mask, idx, dist, order, st, W.shape, wfc.shape)
         return att
 
     @staticmethod
     def backward(ctx, datt):
-        C, Wt, G, g, be, wv, att = ctx.saved_tensors
+        C, Wd, G, g, be, wv, att = ctx.saved_tensors
         sync, mask, idx, dist, order, st, wshape, wfcshape = ctx.cfg
         N = idx.shape[1]
         dlogit = (datt * att * (1.0 - att)).contiguous()
@@ -250,15 +247,8 @@ class _AttentionHeadCommuted(torch.autograd.Function):
         dbfc = dlogit.sum().reshape(1)
         dgamma, dbeta, k = _backward_coeffs(S, st, g, sync)
         dG = pm.interp_bn_bwd_apply(G, idx, dist, order, dlogit, wv, st.stats[2], st.stats[3], k[0], k[1], mask)
-        ns = G.shape[0]
-        dW = torch.empty((ns, C.shape[1], 256), dtype=torch.float32, device=C.device)
-        dC = torch.empty_like(C) if ctx.needs_input_grad[0] else None
-        Wtt = pm.transpose_last2(Wt)                                                     # [ns, 256, Cin]
-        for j in range(ns):
-            pm.gemm_tn(C, dG[j], out=dW[j])
-            if dC is not None:
-                pm.gemm_nn(dG[j], Wtt[j], out=dC, accumulate=(j > 0))
-        dW = dW.transpose(0, 1).reshape(wshape)
+        dW = pm.gemm_tn(C, dG).reshape(wshape)                                           # [Cin, H]
+        dC = pm.gemm_nn(dG, pm.transpose_last2(Wd)) if ctx.needs_input_grad[0] else None
         db = torch.zeros_like(g)   # the BatchNorm removes any per-channel constant: exact gradient 0
         return dC, dW, db, dgamma, dbeta, None, None, None, None, dwfc, dbfc, None, None, None, None, None
 

@@ -350,9 +350,10 @@ int dh3d_interp_head_fwd(const float *H, int Hd, const int32_t *idx, const float
 int dh3d_interp_head_sorted_fwd(const float *H, int Hd, const int32_t *idx, const float *dist, const float *order, int B,
                                 int n, int m, const dh3d_epilogue *ep, const float *w_fc, float b_fc, float *att,
                                 void *stream);
-/* the same with the fc bias in device memory (a trainable parameter) */
-int dh3d_interp_head_sorted_fwd_dev(const float *H, int Hd, const int32_t *idx, const float *dist, const float *order,
-                                    int B, int n, int m, const dh3d_epilogue *ep, const float *w_fc,
+/* the same with the fc bias in device memory (a trainable parameter); row_major != 0: H is [B*m][Hd] (one GEMM's
+ * output) instead of the 256-column slices */
+int dh3d_interp_head_sorted_fwd_dev(const float *H, int Hd, int row_major, const int32_t *idx, const float *dist,
+                                    const float *order, int B, int n, int m, const dh3d_epilogue *ep, const float *w_fc,
                                     const float *b_fc_dev, float *att, void *stream);
 /* The tail of a concat conv commuted through the up-sampling (C = 128):
  *   out[n] = act(BN(interp3(coarse_w)[n] + partial[n] + pre_bias)) + residual[n]     (or [prefix | l2_normalize(.)])
@@ -455,8 +456,9 @@ int dh3d_netvlad_assign_rows_bwd(const float *s, long long R, int Cl, const floa
                                  const float *att, const float *da, float *dz, float *datt, void *stream);
 int dh3d_l2norm_rows_bwd(const float *x, const float *dxn, long long R, int C, float eps, float *dx, void *stream);
 /* Training-mode attention head with its convolution commuted through the up-sampling (csrc/interp_train.hip): the
- * pre-activation h = three_interpolate(G) of globalatt_block (core/backbones.py:89-100,156-173), G = the 256-column slices
- * [Hd/256][B*m][256] of coarse @ W + b, is never materialised.  idx / dist [B,n,3] = three_nn of the fine points, order =
+ * pre-activation h = three_interpolate(G) of globalatt_block (core/backbones.py:89-100,156-173), G = coarse @ W + b as
+ * 256-column slices [Hd/256][B*m][256] (row_major = 0) or as the GEMM's own [B*m][Hd] output (row_major = 1; dG likewise),
+ * is never materialised.  idx / dist [B,n,3] = three_nn of the fine points, order =
  * dh3d_spatial_sort records [B,n,4] of the fine cloud (NULL: index order), mask [B] bytes (NULL: all clouds live).
  *   colstats : per-cloud partials part [2][B][Hd] f64 (zeroed by the call) of sum / sumsq of h over the live rows; their
  *              sums over B -> dh3d_bn_finalize
@@ -465,14 +467,15 @@ int dh3d_l2norm_rows_bwd(const float *x, const float *dxn, long long R, int C, f
  *              by original point index)
  *   bwd_apply: dG [Hd/256][B*m][256] = interp^T(scale dz - k2 - k3 h) (zeroed by the call, f32 atomics), from which
  *              dW = coarse^T dG and dcoarse = dG W^T are GEMMs on B*m rows.  Hd <= 1024, m <= 1024. */
-int dh3d_interp_bn_colstats(const float *G, int Hd, const int32_t *idx, const float *dist, const float *order, int B,
-                            int n, int m, const unsigned char *mask, double *part /* [2][B][Hd] */, void *stream);
-int dh3d_interp_bn_bwd_sums(const float *G, int Hd, const int32_t *idx, const float *dist, const float *order, int B,
-                            int n, int m, const unsigned char *mask, const float *dlogit, const float *w_fc,
+int dh3d_interp_bn_colstats(const float *G, int Hd, int row_major, const int32_t *idx, const float *dist,
+                            const float *order, int B, int n, int m, const unsigned char *mask,
+                            double *part /* [2][B][Hd] */, void *stream);
+int dh3d_interp_bn_bwd_sums(const float *G, int Hd, int row_major, const int32_t *idx, const float *dist,
+                            const float *order, int B, int n, int m, const unsigned char *mask, const float *dlogit, const float *w_fc,
                             const float *mean, const float *rstd, const float *gamma, const float *beta,
                             double *part /* [3][B][Hd] */, void *stream);
-int dh3d_interp_bn_bwd_apply(const float *G, int Hd, const int32_t *idx, const float *dist, const float *order, int B,
-                             int n, int m, const unsigned char *mask, const float *dlogit, const float *w_fc,
+int dh3d_interp_bn_bwd_apply(const float *G, int Hd, int row_major, const int32_t *idx, const float *dist,
+                             const float *order, int B, int n, int m, const unsigned char *mask, const float *dlogit, const float *w_fc,
                              const float *scale, const float *shift, const float *k2, const float *k3, float *dG,
                              void *stream);
 /* three_interpolate's backward (threeinterpolate_grad_cpu, tf_interpolate.cpp:131-153) on the Morton order of the fine

@@ -10,7 +10,7 @@ samp = ops.farthest_point_sample(M, pts)
 cxyz = torch.gather(pts, 1, samp.long()[:, :, None].expand(-1, -1, 3)).contiguous()
 d3, i3 = ops.three_nn(pts, cxyz)
 order = pm.spatial_sort(pts)[0]
-G = torch.randn(4, Bt * M, 256, generator=g).to(dev)
+G = torch.randn(Bt * M, 1024, generator=g).to(dev)
 H = 1024
 v = [torch.randn(H, generator=g).to(dev) for _ in range(6)]
 sc = (0.5 + torch.rand(H, generator=g)).to(dev)
