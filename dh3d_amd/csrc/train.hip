@@ -231,6 +231,96 @@ __global__ __launch_bounds__(256) void netvlad_assign_rows_kernel(const float *_
   if (lane == 0) datt[row] = d1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// NetVLAD between the VLAD contraction and the hidden projection (core/backbones.py:241-262), one workgroup per cloud:
+//   u[d,c] = V[c,d] - asum[c] * W2[d,c];  y1 = u * rsqrt(max(sum_d u^2, eps))  (intra-normalisation per cluster);
+//   out[d*64 + c] = y1 * rsqrt(max(sum y1^2, eps))                              (L2 over the whole 16384-vector)
+// and its backward -- ~12 + ~25 tiny tensor ops of the training graph in two launches.  Thread (c = t & 63, q = t >> 6)
+// holds the 64 values d = 64 q .. 64 q + 63 of cluster c in registers.  D == 256, Cl == 64.
+template <bool BWD>
+__global__ __launch_bounds__(256) void vlad_normalize_kernel(const float *__restrict__ V, const float *__restrict__ asum,
+                                                            const float *__restrict__ W2, float eps,
+                                                            float *__restrict__ out, float *__restrict__ inv_c,
+                                                            float *__restrict__ inv_t, const float *__restrict__ g,
+                                                            float *__restrict__ dV, float *__restrict__ dasum,
+                                                            float *__restrict__ dW2) {
+  __shared__ float s_red[4][64];
+  __shared__ float s_tot[4];
+  const int b = blockIdx.x, t = threadIdx.x, c = t & 63, q = t >> 6, lane = t & 63;
+  const float *Vb = V + ((size_t)b * 64 + c) * 256 + q * 64;
+  const float as = asum[(size_t)b * 64 + c];
+  auto col_sum = [&](float v) {  // sum over the four d-quarters of cluster c (every thread of the column gets it)
+    __syncthreads();
+    s_red[q][c] = v;
+    __syncthreads();
+    return (s_red[0][c] + s_red[1][c]) + (s_red[2][c] + s_red[3][c]);
+  };
+  auto all_sum = [&](float v) {  // sum over the workgroup
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if (lane == 0) s_tot[q] = v;
+    __syncthreads();
+    return (s_tot[0] + s_tot[1]) + (s_tot[2] + s_tot[3]);
+  };
+  float u[64];
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < 64; j += 4) {
+    const float4 v = *reinterpret_cast<const float4 *>(Vb + j);
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      u[j + k] = vv[k] - as * W2[(size_t)(q * 64 + j + k) * 64 + c];
+      ss = fmaf(u[j + k], u[j + k], ss);
+    }
+  }
+  const float ssc = col_sum(ss);
+  const float ic = rsqrtf(fmaxf(ssc, eps));
+  const float tot = all_sum(q == 0 ? ssc * ic * ic : 0.f);  // sum of y1^2 = sum_c ssc * ic^2 (one thread per column)
+  const float it = rsqrtf(fmaxf(tot, eps));
+  if (!BWD) {
+#pragma unroll
+    for (int j = 0; j < 64; ++j) out[(size_t)b * 16384 + (size_t)(q * 64 + j) * 64 + c] = u[j] * ic * it;
+    if (q == 0) inv_c[(size_t)b * 64 + c] = ic;
+    if (t == 0) inv_t[b] = it;
+    return;
+  }
+  // backward.  y = y1 * it:  dy1 = it * (g - y * sum(g y))   [projection only where the norm is not clamped]
+  const float *gb = g + (size_t)b * 16384;
+  float gv[64];
+  float sgy = 0.f;
+#pragma unroll
+  for (int j = 0; j < 64; ++j) {
+    gv[j] = gb[(size_t)(q * 64 + j) * 64 + c];
+    sgy = fmaf(gv[j], u[j] * ic * it, sgy);
+  }
+  const float S = tot > eps ? all_sum(sgy) : 0.f;
+  // y1 = u * ic:  du = ic * (dy1 - y1 * sum_d(dy1 y1))
+  float sc = 0.f;
+#pragma unroll
+  for (int j = 0; j < 64; ++j) {
+    const float y1 = u[j] * ic;
+    gv[j] = it * (gv[j] - y1 * it * S);  // dy1
+    sc = fmaf(gv[j], y1, sc);
+  }
+  const float Sc = ssc > eps ? col_sum(sc) : 0.f;
+  float das = 0.f;
+#pragma unroll
+  for (int j = 0; j < 64; ++j) {
+    const float du = ic * (gv[j] - u[j] * ic * Sc);
+    u[j] = du;
+    const size_t wi = (size_t)(q * 64 + j) * 64 + c;
+    das = fmaf(du, W2[wi], das);
+    unsafeAtomicAdd(dW2 + wi, -du * as);
+  }
+  float *dVb = dV + ((size_t)b * 64 + c) * 256 + q * 64;
+#pragma unroll
+  for (int j = 0; j < 64; j += 4) *reinterpret_cast<float4 *>(dVb + j) = make_float4(u[j], u[j + 1], u[j + 2], u[j + 3]);
+  const float dsum = col_sum(das);
+  if (q == 0) dasum[(size_t)b * 64 + c] = -dsum;
+}
+
 // backward of xn = x * rsqrt(max(sum x^2, eps)) (tf.nn.l2_normalize), one wave per row
 __global__ __launch_bounds__(256) void l2norm_rows_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dxn,
                                                              long long R, int C, float eps, float *__restrict__ dx) {
@@ -374,5 +464,28 @@ DH3D_API int dh3d_l2norm_rows_bwd(const float *x, const float *dxn, long long R,
   DH3D_REQUIRE(x && dxn && dx && R > 0 && C > 0);
   hipLaunchKernelGGL(l2norm_rows_bwd_kernel, dim3(dh3d_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, x, dxn, R, C, eps,
                      dx);
+  return dh3d_launch_status();
+}
+
+// V [B, 64, 256] (sum_n a x^T per cloud), asum [B, 64], W2 [256, 64] (cluster_weights2) -> out [B, 16384] in (d, c) order;
+// inv_c [B, 64] and inv_t [B] are kept for inspection (the backward recomputes them).
+DH3D_API int dh3d_vlad_normalize_fwd(const float *V, const float *asum, const float *W2, int B, int D, int Cl, float eps,
+                                     float *out, float *inv_c, float *inv_t, void *stream) {
+  DH3D_REQUIRE(V && asum && W2 && out && inv_c && inv_t && B > 0);
+  DH3D_SUPPORTED(D == 256 && Cl == 64);
+  hipLaunchKernelGGL(vlad_normalize_kernel<false>, dim3(B), dim3(256), 0, (hipStream_t)stream, V, asum, W2, eps, out,
+                     inv_c, inv_t, nullptr, nullptr, nullptr, nullptr);
+  return dh3d_launch_status();
+}
+
+// gradients of the same: dV [B,64,256], dasum [B,64], dW2 [256,64] (zeroed here, f32 atomics over the clouds)
+DH3D_API int dh3d_vlad_normalize_bwd(const float *V, const float *asum, const float *W2, const float *grad_out, int B,
+                                     int D, int Cl, float eps, float *dV, float *dasum, float *dW2, void *stream) {
+  DH3D_REQUIRE(V && asum && W2 && grad_out && dV && dasum && dW2 && B > 0);
+  DH3D_SUPPORTED(D == 256 && Cl == 64);
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(dW2, 0, sizeof(float) * 256 * 64, s) != hipSuccess) return DH3D_ERR_LAUNCH;
+  hipLaunchKernelGGL(vlad_normalize_kernel<true>, dim3(B), dim3(256), 0, s, V, asum, W2, eps, nullptr, nullptr, nullptr,
+                     grad_out, dV, dasum, dW2);
   return dh3d_launch_status();
 }

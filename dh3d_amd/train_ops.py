@@ -170,6 +170,45 @@ def attention_head(X, conv, wfc, bfc, sync=False, mask=None, rows_per_cloud=0):
                                 bn.variance_EMA, bn.eps, 0.9, wfc, bfc, sync, mask, rows_per_cloud)
 
 
+class _VladNormalize(torch.autograd.Function):
+    """V [Bt, Cl, D], asum [Bt, Cl], W2 [1, D, Cl] -> [Bt, D*Cl]: subtract asum * cluster_weights2, intra-normalise per
+    cluster, flatten, L2-normalise (core/backbones.py:241-262) -- one launch per direction (csrc/train.hip) instead of
+    ~37 tiny tensor ops."""
+
+    @staticmethod
+    def forward(ctx, V, asum, W2):
+        from . import _lib as L
+        V, asum = V.contiguous(), asum.contiguous()
+        W2d = W2.detach().reshape(W2.shape[-2], W2.shape[-1]).contiguous()
+        Bt, Cl, Dm = V.shape
+        out = torch.empty((Bt, Dm * Cl), dtype=torch.float32, device=V.device)
+        aux = torch.empty((Bt * (Cl + 1),), dtype=torch.float32, device=V.device)
+        L.check(L.lib().dh3d_vlad_normalize_fwd(L.ptr(V), L.ptr(asum), L.ptr(W2d), Bt, Dm, Cl, 1e-12, L.ptr(out),
+                                                L.ptr(aux), L.ptr(aux[Bt * Cl:]), L.stream_ptr()), "vlad_normalize")
+        ctx.save_for_backward(V, asum, W2d)
+        ctx.w2shape = W2.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib as L
+        V, asum, W2d = ctx.saved_tensors
+        Bt, Cl, Dm = V.shape
+        g = g.contiguous()
+        dV, dasum, dW2 = torch.empty_like(V), torch.empty_like(asum), torch.empty_like(W2d)
+        L.check(L.lib().dh3d_vlad_normalize_bwd(L.ptr(V), L.ptr(asum), L.ptr(W2d), L.ptr(g), Bt, Dm, Cl, 1e-12, L.ptr(dV),
+                                                L.ptr(dasum), L.ptr(dW2), L.stream_ptr()), "vlad_normalize_bwd")
+        return dV, dasum, dW2.reshape(ctx.w2shape)
+
+
+def vlad_normalize(V, asum, W2):
+    return _VladNormalize.apply(V, asum, W2)
+
+
+def vlad_normalize_supported(V):
+    return V.dim() == 3 and V.shape[1] == 64 and V.shape[2] == 256
+
+
 class _ThreeInterpolateSorted(torch.autograd.Function):
     """ops.three_interpolate with the backward on the Morton order of the fine cloud (csrc/interp_train.hip MODE 3)."""
 

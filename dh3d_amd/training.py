@@ -213,10 +213,13 @@ def global_head_hip(model, points, localdesc, lv, sync_bn=False, mask=None, comm
     else:
         att = T.attention_head(forglobal.reshape(Bt * N, Dg), att_mod.detec_conv0, fcw.W, fcw.b, sync_bn, mask, N)
     V, asum = T.netvlad_assign(forglobal, att, nv.cluster_weights, nv.cluster_bn, sync_bn, mask)   # [Bt,C,D], [Bt,C]
-    vlad = V.transpose(1, 2) - asum.unsqueeze(1) * nv.cluster_weights2              # [Bt,D,C]  (backbones.py:241-256)
-    vlad = vlad * torch.rsqrt(torch.clamp((vlad * vlad).sum(1, keepdim=True), min=1e-12))
-    vlad = vlad.reshape(Bt, nv.C * Dg)
-    vlad = vlad * torch.rsqrt(torch.clamp((vlad * vlad).sum(1, keepdim=True), min=1e-12))
+    if T.vlad_normalize_supported(V):
+        vlad = T.vlad_normalize(V, asum, nv.cluster_weights2)                       # [Bt, D*C]  (backbones.py:241-262)
+    else:
+        vlad = V.transpose(1, 2) - asum.unsqueeze(1) * nv.cluster_weights2          # [Bt,D,C]
+        vlad = vlad * torch.rsqrt(torch.clamp((vlad * vlad).sum(1, keepdim=True), min=1e-12))
+        vlad = vlad.reshape(Bt, nv.C * Dg)
+        vlad = vlad * torch.rsqrt(torch.clamp((vlad * vlad).sum(1, keepdim=True), min=1e-12))
     v = T.batch_norm_train(T.linear(vlad, nv.hidden1_weights), nv.bn, False, sync_bn, mask, 1)
     gates = T.batch_norm_train(T.linear(v, nv.gating_weights), nv.gating_bn, False, sync_bn, mask, 1)
     return v * torch.sigmoid(gates)

@@ -485,6 +485,13 @@ int dh3d_interp_bn_bwd_apply(const float *G, int Hd, int row_major, const int32_
  * summation order. */
 int dh3d_three_interpolate_bwd_sorted(int b, int n, int c, int m, const float *grad_out, const int32_t *idx,
                                       const float *weight, const float *order, float *grad_points, void *stream);
+/* NetVLAD between the VLAD contraction and the hidden projection (core/backbones.py:241-262) for the training step:
+ * out[b, d*64 + c] = l2norm_all( intra_norm_d( V[b,c,d] - asum[b,c] * W2[d,c] ) ), one workgroup per cloud, and its
+ * gradients (dW2 zeroed by the call, f32 atomics over the clouds).  D == 256, Cl == 64. */
+int dh3d_vlad_normalize_fwd(const float *V, const float *asum, const float *W2, int B, int D, int Cl, float eps,
+                            float *out, float *inv_c, float *inv_t, void *stream);
+int dh3d_vlad_normalize_bwd(const float *V, const float *asum, const float *W2, const float *grad_out, int B, int D,
+                            int Cl, float eps, float *dV, float *dasum, float *dW2, void *stream);
 /* batched GEMMs: `batch` independent products on operands stored back to back; colbias [batch, N] (nn only). */
 int dh3d_gemm_tn_f32_batched(const float *A, const float *B, int batch, int K, int M, int N, float *C, void *stream);
 int dh3d_gemm_nn_f32_batched(const float *A, const float *B, const float *colbias, int batch, int M, int K, int N,

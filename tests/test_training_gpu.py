@@ -468,3 +468,26 @@ def test_trainer_whole_step_graph_matches_eager_steps(dev):
         assert abs(x - y) <= 2e-2 * max(1.0, abs(y)), (la, lb)
     drift = max(float((x - y).abs().max()) for x, y in zip(pa, pb))
     assert drift <= 5e-3, drift
+
+
+def test_vlad_normalize_kernels_match_the_tensor_expression(dev):
+    """train_ops.vlad_normalize (one launch per direction) == V^T - asum*W2 -> intra-normalise -> flatten -> L2-normalise
+    written with tensor ops (core/backbones.py:241-262), values and all three gradients, in float64 on the torch side."""
+    from dh3d_amd import train_ops as T
+    g = torch.Generator().manual_seed(3)
+    Bt, Cl, Dm = 5, 64, 256
+    V0 = torch.randn(Bt, Cl, Dm, generator=g).to(dev); a0 = torch.rand(Bt, Cl, generator=g).to(dev)
+    W0 = (torch.randn(1, Dm, Cl, generator=g) / 16).to(dev)
+    go = torch.randn(Bt, Dm * Cl, generator=g).to(dev)
+    V, a, W = [t.clone().requires_grad_(True) for t in (V0, a0, W0)]
+    y = T.vlad_normalize(V, a, W)
+    y.backward(go)
+    Vd, ad, Wd = [t.double().clone().requires_grad_(True) for t in (V0, a0, W0)]
+    r = Vd.transpose(1, 2) - ad.unsqueeze(1) * Wd
+    r = r * torch.rsqrt(torch.clamp((r * r).sum(1, keepdim=True), min=1e-12))
+    r = r.reshape(Bt, Dm * Cl)
+    r = r * torch.rsqrt(torch.clamp((r * r).sum(1, keepdim=True), min=1e-12))
+    r.backward(go.double())
+    assert float((y.double() - r).abs().max()) < 1e-6
+    for name, x, ref in (("dV", V.grad, Vd.grad), ("dasum", a.grad, ad.grad), ("dW2", W.grad, Wd.grad)):
+        assert float((x.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-9, name
