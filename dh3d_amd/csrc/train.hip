@@ -321,6 +321,80 @@ __global__ __launch_bounds__(256) void vlad_normalize_kernel(const float *__rest
   if (q == 0) dasum[(size_t)b * 64 + c] = -dsum;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Lazy quadruplet loss (core/losses.py:137-200) on the role-ordered descriptors [B | B*P | B*Ng | B] x 256 and its
+// gradient in ONE launch (the training graph spends ~60 tiny tensor ops on it):
+//   best_pos = min_p |pos_p - q|^2;  trip = max_j relu(m1 + best_pos - |neg_j - q|^2);
+//   second = max_j relu(m2 + best_pos - |neg_j - other|^2);  loss = mean_b trip + mean_b second.
+// One workgroup per tuple b, thread = descriptor channel (D == 256).  The gradient follows the winning indices (first
+// index on ties, like a max / min over a dimension) and vanishes where the hinge is inactive.
+__global__ __launch_bounds__(256) void quadruplet_loss_kernel(const float *__restrict__ desc, int B, int P, int Ng,
+                                                             float m1, float m2, float *__restrict__ loss,
+                                                             float *__restrict__ grad) {
+  __shared__ float s_w[4];
+  __shared__ float s_d[2 * 64 + 8];  // dneg[Ng], dother[Ng], dpos[P]   (Ng <= 64, P <= 8)
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int D = 256;
+  const float *q = desc + (size_t)b * D;
+  const float *pos = desc + ((size_t)B + (size_t)b * P) * D;
+  const float *neg = desc + ((size_t)B + (size_t)B * P + (size_t)b * Ng) * D;
+  const float *oth = desc + ((size_t)B + (size_t)B * P + (size_t)B * Ng + b) * D;
+  auto block_sum = [&](float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if (lane == 0) s_w[wave] = v;
+    __syncthreads();
+    return (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+  };
+  const float qv = q[t], ov = oth[t];
+  for (int p = 0; p < P; ++p) {
+    const float d = pos[(size_t)p * D + t] - qv;
+    const float sum = block_sum(d * d);
+    if (t == 0) s_d[128 + p] = sum;
+  }
+  for (int j = 0; j < Ng; ++j) {
+    const float nv = neg[(size_t)j * D + t];
+    const float d1 = nv - qv, d2 = nv - ov;
+    const float a = block_sum(d1 * d1), c = block_sum(d2 * d2);
+    if (t == 0) { s_d[j] = a; s_d[64 + j] = c; }
+  }
+  __syncthreads();
+  int ps = 0;
+  float best = s_d[128];
+  for (int p = 1; p < P; ++p)
+    if (s_d[128 + p] < best) { best = s_d[128 + p]; ps = p; }
+  int j1 = 0, j2 = 0;
+  float t1 = -1.f, t2 = -1.f;  // max over j of the clamped hinges (>= 0)
+  float r1 = 0.f, r2 = 0.f;    // the raw hinge at the winner
+  for (int j = 0; j < Ng; ++j) {
+    const float a = m1 + best - s_d[j], c = m2 + best - s_d[64 + j];
+    const float ac = fmaxf(a, 0.f), cc = fmaxf(c, 0.f);
+    if (ac > t1) { t1 = ac; j1 = j; r1 = a; }
+    if (cc > t2) { t2 = cc; j2 = j; r2 = c; }
+  }
+  const float invB = 1.f / (float)B;
+  if (t == 0) unsafeAtomicAdd(loss, (t1 + t2) * invB);
+  // gradient (rows of this tuple only: no atomics needed)
+  const float g1 = r1 >= 0.f ? invB : 0.f, g2 = r2 >= 0.f ? invB : 0.f;  // clamp(min=0) passes the gradient at x >= 0
+  const float pv = pos[(size_t)ps * D + t];
+  const float n1 = neg[(size_t)j1 * D + t], n2 = neg[(size_t)j2 * D + t];
+  float *gq = grad + (size_t)b * D, *gp = grad + ((size_t)B + (size_t)b * P) * D;
+  float *gn = grad + ((size_t)B + (size_t)B * P + (size_t)b * Ng) * D;
+  float *go = grad + ((size_t)B + (size_t)B * P + (size_t)B * Ng + b) * D;
+  // d best_pos: q gets -2 (pos - q), pos_ps gets +2 (pos - q), weight g1 + g2;  -d|n1 - q|^2: q gets +2 (n1 - q), n1 gets
+  // -2 (n1 - q), weight g1;  -d|n2 - o|^2: n2 gets -2 (n2 - o), o gets +2 (n2 - o), weight g2
+  gq[t] = -2.f * (g1 + g2) * (pv - qv) + 2.f * g1 * (n1 - qv);
+  for (int p = 0; p < P; ++p) gp[(size_t)p * D + t] = p == ps ? 2.f * (g1 + g2) * (pv - qv) : 0.f;
+  for (int j = 0; j < Ng; ++j) {
+    float v = 0.f;
+    if (j == j1) v -= 2.f * g1 * (n1 - qv);
+    if (j == j2) v -= 2.f * g2 * (n2 - ov);
+    gn[(size_t)j * D + t] = v;
+  }
+  go[t] = 2.f * g2 * (n2 - ov);
+}
+
 // backward of xn = x * rsqrt(max(sum x^2, eps)) (tf.nn.l2_normalize), one wave per row
 __global__ __launch_bounds__(256) void l2norm_rows_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dxn,
                                                              long long R, int C, float eps, float *__restrict__ dx) {
@@ -487,5 +561,17 @@ DH3D_API int dh3d_vlad_normalize_bwd(const float *V, const float *asum, const fl
   if (hipMemsetAsync(dW2, 0, sizeof(float) * 256 * 64, s) != hipSuccess) return DH3D_ERR_LAUNCH;
   hipLaunchKernelGGL(vlad_normalize_kernel<true>, dim3(B), dim3(256), 0, s, V, asum, W2, eps, nullptr, nullptr, nullptr,
                      grad_out, dV, dasum, dW2);
+  return dh3d_launch_status();
+}
+
+// desc [B*(2 + P + Ng), 256] role-ordered (queries, positives, negatives, other negatives) -> loss[0] (zeroed here) and
+// grad [same shape] = d loss / d desc.  P <= 8, Ng <= 64.
+DH3D_API int dh3d_quadruplet_loss(const float *desc, int B, int P, int Ng, int D, float margin, float margin2, float *loss,
+                                  float *grad, void *stream) {
+  DH3D_REQUIRE(desc && loss && grad && B > 0 && P > 0 && Ng > 0);
+  DH3D_SUPPORTED(D == 256 && P <= 8 && Ng <= 64);
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(loss, 0, sizeof(float), s) != hipSuccess) return DH3D_ERR_LAUNCH;
+  hipLaunchKernelGGL(quadruplet_loss_kernel, dim3(B), dim3(256), 0, s, desc, B, P, Ng, margin, margin2, loss, grad);
   return dh3d_launch_status();
 }

@@ -209,6 +209,57 @@ def vlad_normalize_supported(V):
     return V.dim() == 3 and V.shape[1] == 64 and V.shape[2] == 256
 
 
+class _QuadrupletLoss(torch.autograd.Function):
+    """losses.lazy_quadruplet_loss and its gradient in one launch (csrc/train.hip quadruplet_loss_kernel)."""
+
+    @staticmethod
+    def forward(ctx, desc, B, P, Ng, m1, m2):
+        from . import _lib as L
+        d = desc.contiguous()
+        loss = torch.empty((1,), dtype=torch.float32, device=d.device)
+        grad = torch.empty_like(d)
+        L.check(L.lib().dh3d_quadruplet_loss(L.ptr(d), B, P, Ng, d.shape[1], float(m1), float(m2), L.ptr(loss), L.ptr(grad),
+                                             L.stream_ptr()), "quadruplet_loss")
+        ctx.save_for_backward(grad)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None, None, None
+
+
+def quadruplet_loss(desc, batch_size, num_pos, num_neg, margin=0.5, margin2=0.2):
+    """desc [B*(2 + P + Ng), 256] role-ordered -> scalar loss (core/losses.py:173-200)."""
+    if desc.shape[0] != batch_size * (2 + num_pos + num_neg):
+        raise ValueError("descriptor rows %d do not match the role sizes" % desc.shape[0])
+    return _QuadrupletLoss.apply(desc, batch_size, num_pos, num_neg, margin, margin2)
+
+
+def quadruplet_loss_supported(desc, num_pos, num_neg):
+    return desc.is_cuda and desc.dim() == 2 and desc.shape[1] == 256 and num_pos <= 8 and num_neg <= 64
+
+
+class _L2NormalizeRows(torch.autograd.Function):
+    """x [R, C] -> x * rsqrt(max(sum x^2, eps)) (tf.nn.l2_normalize), one launch per direction."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.eps = eps
+        return pm.l2norm_concat(x, eps)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return pm.l2norm_rows_bwd(x, g.contiguous(), ctx.eps), None
+
+
+def l2_normalize_rows(x, eps):
+    return _L2NormalizeRows.apply(x, eps)
+
+
 class _ThreeInterpolateSorted(torch.autograd.Function):
     """ops.three_interpolate with the backward on the Morton order of the fine cloud (csrc/interp_train.hip MODE 3)."""
 

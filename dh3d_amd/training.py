@@ -303,11 +303,16 @@ class QuadrupletTrainer(object):
         else:
             desc = global_head_autograd(self.model, block, localdesc.detach(), lv, bn_training=True,
                                         sync_bn=self.sync_bn, mask=m)
-        desc = desc * torch.rsqrt(torch.clamp((desc * desc).sum(1, keepdim=True), min=1e-8))  # model.py:205
+        from . import train_ops as T
+        m1, m2 = cfg.global_triplet_margin or 0.5, cfg.global_quadruplet_margin or 0.2
+        if self.impl == "hip":
+            desc = T.l2_normalize_rows(desc, 1e-8)                                          # model.py:205
+        else:
+            desc = desc * torch.rsqrt(torch.clamp((desc * desc).sum(1, keepdim=True), min=1e-8))
         full = _AllGatherKeepOwn.apply(desc)[:Bt]
-        loss = losses.lazy_quadruplet_loss(full, cfg.batch_size, cfg.num_pos, cfg.num_neg,
-                                           cfg.global_triplet_margin or 0.5, cfg.global_quadruplet_margin or 0.2)
-        return loss
+        if self.impl == "hip" and T.quadruplet_loss_supported(full, cfg.num_pos, cfg.num_neg):
+            return T.quadruplet_loss(full.contiguous(), cfg.batch_size, cfg.num_pos, cfg.num_neg, m1, m2)
+        return losses.lazy_quadruplet_loss(full, cfg.batch_size, cfg.num_pos, cfg.num_neg, m1, m2)
 
     def _backbone(self, block):
         """Frozen backbone + geometry of this rank's block: (localdesc [b,N,128], level dict of tensors).  Its weights

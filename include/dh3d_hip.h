@@ -492,6 +492,10 @@ int dh3d_vlad_normalize_fwd(const float *V, const float *asum, const float *W2, 
                             float *out, float *inv_c, float *inv_t, void *stream);
 int dh3d_vlad_normalize_bwd(const float *V, const float *asum, const float *W2, const float *grad_out, int B, int D,
                             int Cl, float eps, float *dV, float *dasum, float *dW2, void *stream);
+/* lazy quadruplet loss (core/losses.py:137-200) and its gradient in one launch: desc [B*(2+P+Ng), 256] role-ordered
+ * (queries | positives | negatives | other negatives); loss[0] is zeroed by the call; grad has desc's shape. */
+int dh3d_quadruplet_loss(const float *desc, int B, int P, int Ng, int D, float margin, float margin2, float *loss,
+                         float *grad, void *stream);
 /* batched GEMMs: `batch` independent products on operands stored back to back; colbias [batch, N] (nn only). */
 int dh3d_gemm_tn_f32_batched(const float *A, const float *B, int batch, int K, int M, int N, float *C, void *stream);
 int dh3d_gemm_nn_f32_batched(const float *A, const float *B, const float *colbias, int batch, int M, int K, int N,

@@ -491,3 +491,20 @@ def test_vlad_normalize_kernels_match_the_tensor_expression(dev):
     assert float((y.double() - r).abs().max()) < 1e-6
     for name, x, ref in (("dV", V.grad, Vd.grad), ("dasum", a.grad, ad.grad), ("dW2", W.grad, Wd.grad)):
         assert float((x.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-9, name
+
+
+@pytest.mark.parametrize("B,P,Ng,scale", [(1, 2, 18, 1.0), (3, 2, 5, 1.0), (2, 3, 7, 0.05), (1, 2, 18, 3.0)])
+def test_quadruplet_loss_kernel_matches_the_tensor_expression(dev, B, P, Ng, scale):
+    """train_ops.quadruplet_loss (loss and gradient in one launch) == losses.lazy_quadruplet_loss under autograd
+    (core/losses.py:137-200): active and inactive hinges (`scale` moves the descriptors apart / together)."""
+    from dh3d_amd import losses, train_ops as T
+    g = torch.Generator().manual_seed(B * 100 + Ng)
+    d0 = torch.nn.functional.normalize(torch.randn(B * (2 + P + Ng), 256, generator=g), dim=1).to(dev) * scale
+    a = d0.clone().requires_grad_(True)
+    la = T.quadruplet_loss(a, B, P, Ng, 0.5, 0.2)
+    (la * 1.7).backward()
+    b = d0.clone().requires_grad_(True)
+    lb = losses.lazy_quadruplet_loss(b, B, P, Ng, 0.5, 0.2)
+    (lb * 1.7).backward()
+    assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(lb)))
+    assert float((a.grad - b.grad).abs().max()) <= 1e-6 * max(1.0, float(b.grad.abs().max()))
