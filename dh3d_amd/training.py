@@ -281,7 +281,8 @@ class QuadrupletTrainer(object):
         if self.graph_step:
             dev = self.params[0].device
             self._lr = torch.tensor(float(start_lr), dtype=torch.float32, device=dev)
-            self.opt = torch.optim.Adam(self.params, lr=self._lr, capturable=True)
+            # (fused: one multi-tensor kernel per step instead of ~8 foreach passes over the 20 parameter tensors)
+            self.opt = torch.optim.Adam(self.params, lr=self._lr, capturable=True, fused=True)
             self.sched = None
         else:
             self.opt = torch.optim.Adam(self.params, lr=start_lr)
