@@ -285,7 +285,7 @@ class QuadrupletTrainer(object):
             self.opt = torch.optim.Adam(self.params, lr=self._lr, capturable=True, fused=True)
             self.sched = None
         else:
-            self.opt = torch.optim.Adam(self.params, lr=start_lr)
+            self.opt = torch.optim.Adam(self.params, lr=start_lr, fused=bool(self.params[0].is_cuda))
             self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, lambda s: decay_rate ** (s // decay_step))
 
     def forward_loss(self, points):
