@@ -430,7 +430,8 @@ def main():
         trainer.time_phases(True)   # five more (untimed) steps with events around the phases
         for _ in range(5):
             trainer.step(pts)
-        extra = {"phases_ms": trainer.phase_times_ms(), "head_implementation": trainer.impl}
+        extra = {"phases_ms": trainer.phase_times_ms(), "head_implementation": trainer.impl,
+                 "step_graphed": bool(trainer._step_graphs)}
         trainer.time_phases(False)
         return wl["B"] * args.steps / dt, dt / args.steps * 1e3, extra
 
@@ -490,7 +491,10 @@ def main():
                    "steps_in_flight": args.inflight if args.workload != "train" else 1},
     }
     if args.workload == "train":
-        line["config"]["execution"] = "eager: fused HIP backbone (no grad) + trainable global head fwd/bwd"
+        line["config"]["execution"] = (
+            "whole step (backbone, head fwd/bwd, loss, fused Adam) replayed as one hipGraph; phases_ms from eager steps"
+            if info.get("step_graphed") else
+            "eager: backbone hipGraph (no grad) + trainable global head fwd/bwd + fused Adam")
         line["config"]["parallelism"] = ("one role-ordered batch sharded over %d GPU(s); all-gather of [clouds,256] "
                                          "descriptors + SUM all-reduce of head gradients over RCCL" % world)
         line.update(info)

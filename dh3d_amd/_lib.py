@@ -115,6 +115,8 @@ _SIGNATURES = {
     "dh3d_interp_head_sorted_fwd_dev": [c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, ctypes.POINTER(Epilogue),
                                         c_fp, c_fp, c_fp, c_fp],
     "dh3d_three_interpolate_bwd_sorted": [c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp],
+    "dh3d_bn_small_fwd": [c_fp, c_int, c_int, c_fp, c_fp, c_float, c_float, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp],
+    "dh3d_bn_small_bwd": [c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp],
     "dh3d_quadruplet_loss": [c_fp, c_int, c_int, c_int, c_int, c_float, c_float, c_fp, c_fp, c_fp],
     "dh3d_vlad_normalize_fwd": [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_float, c_fp, c_fp, c_fp, c_fp],
     "dh3d_vlad_normalize_bwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_float, c_fp, c_fp, c_fp, c_fp],

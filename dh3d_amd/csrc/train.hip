@@ -161,6 +161,85 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *x, const
   }
 }
 
+// Training-mode BatchNorm of a SHORT tensor (R <= 64 rows: the [clouds, 256] hidden / gating activations of NetVLAD) in
+// one launch per direction instead of fill + statistics + finalize + apply: a workgroup owns 64 channels, thread (c, q)
+// walks rows q, q + 4, ...  Same arithmetic as the long form: biased variance from f64 sums, folded scale / shift,
+// running buffers with decay `momentum`; dx = scale dz - k2 - k3 x.  mask [R] bytes (rows_per_cloud == 1) or NULL.
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_small_kernel(const float *__restrict__ x, const float *__restrict__ dy, int R,
+                                                      int C, const float *__restrict__ gamma,
+                                                      const float *__restrict__ beta, float eps, float momentum,
+                                                      int relu, const unsigned char *__restrict__ mask,
+                                                      float *run_mean, float *run_var, float *__restrict__ stats,
+                                                      float *__restrict__ out, float *__restrict__ dgamma,
+                                                      float *__restrict__ dbeta) {
+  __shared__ double s_a[4][64], s_b[4][64];
+  __shared__ int s_n;
+  const int t = threadIdx.x, lc = t & 63, q = t >> 6, c = blockIdx.x * 64 + lc;
+  if (t == 0) {
+    int n = 0;
+    for (int r = 0; r < R; ++r) n += (!mask || mask[r]) ? 1 : 0;
+    s_n = n;
+  }
+  const bool ok = c < C;
+  double a = 0.0, b = 0.0;
+  if (!BWD) {
+    if (ok)
+      for (int r = q; r < R; r += 4)
+        if (!mask || mask[r]) { const double v = x[(size_t)r * C + c]; a += v; b += v * v; }
+  }
+  float mu = 0.f, rs = 0.f, sc = 0.f, sh = 0.f;
+  if (BWD && ok) { mu = stats[c]; rs = stats[C + c]; sc = stats[2 * C + c]; sh = stats[3 * C + c]; }
+  if (BWD && ok) {
+    for (int r = q; r < R; r += 4) {
+      if (mask && !mask[r]) continue;
+      const float xv = x[(size_t)r * C + c];
+      float dz = dy[(size_t)r * C + c];
+      if (relu && !(fmaf(xv, sc, sh) > 0.f)) dz = 0.f;
+      a += dz; b += (double)dz * ((xv - mu) * rs);
+    }
+  }
+  s_a[q][lc] = a; s_b[q][lc] = b;
+  __syncthreads();
+  const double A = (s_a[0][lc] + s_a[1][lc]) + (s_a[2][lc] + s_a[3][lc]);
+  const double Bq = (s_b[0][lc] + s_b[1][lc]) + (s_b[2][lc] + s_b[3][lc]);
+  const double n = s_n > 1 ? (double)s_n : 1.0;
+  if (!ok) return;
+  if (!BWD) {
+    const double m = A / n;
+    double var = Bq / n - m * m;
+    var = var > 0.0 ? var : 0.0;
+    rs = (float)(1.0 / sqrt(var + (double)eps));
+    sc = gamma[c] * rs; mu = (float)m; sh = beta[c] - mu * sc;
+    if (q == 0) {
+      stats[c] = mu; stats[C + c] = rs; stats[2 * C + c] = sc; stats[3 * C + c] = sh;
+      if (s_n > 0) {
+        run_mean[c] = momentum * run_mean[c] + (1.f - momentum) * mu;
+        run_var[c] = momentum * run_var[c] + (1.f - momentum) * (float)var;
+      }
+    }
+    for (int r = q; r < R; r += 4) {
+      float v = fmaf(x[(size_t)r * C + c], sc, sh);
+      if (relu) v = fmaxf(v, 0.f);
+      out[(size_t)r * C + c] = v;
+    }
+  } else {
+    const float m1 = (float)(A / n), m2 = (float)(Bq / n);
+    const float k3 = gamma[c] * rs * rs * m2, k2 = gamma[c] * rs * m1 - k3 * mu;
+    if (q == 0) { dbeta[c] = (float)A; dgamma[c] = (float)Bq; }
+    for (int r = q; r < R; r += 4) {
+      float o = 0.f;
+      if (!mask || mask[r]) {
+        const float xv = x[(size_t)r * C + c];
+        float dz = dy[(size_t)r * C + c];
+        if (relu && !(fmaf(xv, sc, sh) > 0.f)) dz = 0.f;
+        o = fmaf(sc, dz, -k2) - k3 * xv;
+      }
+      out[(size_t)r * C + c] = o;
+    }
+  }
+}
+
 // One launch instead of ~15 tiny tensor ops per BatchNorm site and direction.
 // forward: (sum, sumsq, count) f64 -> mean, rstd, folded scale/shift; running buffers updated with decay `momentum`
 // (left alone when count == 0: a rank that holds only padding clouds).
@@ -573,5 +652,28 @@ DH3D_API int dh3d_quadruplet_loss(const float *desc, int B, int P, int Ng, int D
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(loss, 0, sizeof(float), s) != hipSuccess) return DH3D_ERR_LAUNCH;
   hipLaunchKernelGGL(quadruplet_loss_kernel, dim3(B), dim3(256), 0, s, desc, B, P, Ng, margin, margin2, loss, grad);
+  return dh3d_launch_status();
+}
+
+// Short tensors (R <= 64): training-mode BatchNorm (+ReLU) forward in ONE launch -- y [R,C], stats [4,C] = mean, rstd,
+// scale, shift (for the backward), running buffers updated; mask [R] bytes or NULL (every row its own cloud).
+DH3D_API int dh3d_bn_small_fwd(const float *x, int R, int C, const float *gamma, const float *beta, float eps,
+                               float momentum, int relu, const unsigned char *mask, float *run_mean, float *run_var,
+                               float *stats, float *y, void *stream) {
+  DH3D_REQUIRE(x && gamma && beta && run_mean && run_var && stats && y && R > 0 && C > 0);
+  DH3D_SUPPORTED(R <= 64);
+  hipLaunchKernelGGL(bn_small_kernel<false>, dim3(dh3d_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, x, nullptr, R, C,
+                     gamma, beta, eps, momentum, relu, mask, run_mean, run_var, stats, y, nullptr, nullptr);
+  return dh3d_launch_status();
+}
+
+// ... and its backward: dx [R,C], dgamma [C], dbeta [C] from x, dy and the forward's stats
+DH3D_API int dh3d_bn_small_bwd(const float *x, const float *dy, int R, int C, const float *gamma, const float *stats,
+                               int relu, const unsigned char *mask, float *dx, float *dgamma, float *dbeta,
+                               void *stream) {
+  DH3D_REQUIRE(x && dy && gamma && stats && dx && dgamma && dbeta && R > 0 && C > 0);
+  DH3D_SUPPORTED(R <= 64);
+  hipLaunchKernelGGL(bn_small_kernel<true>, dim3(dh3d_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, x, dy, R, C, gamma,
+                     nullptr, 0.f, 0.f, relu, mask, nullptr, nullptr, const_cast<float *>(stats), dx, dgamma, dbeta);
   return dh3d_launch_status();
 }

@@ -92,6 +92,39 @@ class _BatchNormTrain(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
+class _BatchNormTrainSmall(torch.autograd.Function):
+    """_BatchNormTrain for a short tensor (R <= 64 rows, one row per cloud): one launch per direction."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, run_mean, run_var, eps, momentum, relu, mask):
+        from . import _lib as L
+        x = x.contiguous()
+        R, C = x.shape
+        g, be = gamma.detach().contiguous(), beta.detach().contiguous()
+        stats = torch.empty((4, C), dtype=torch.float32, device=x.device)
+        y = torch.empty_like(x)
+        m8 = pm._mask_u8(mask)
+        L.check(L.lib().dh3d_bn_small_fwd(L.ptr(x), R, C, L.ptr(g), L.ptr(be), float(eps), float(momentum),
+                                          1 if relu else 0, L.ptr(m8), L.ptr(run_mean), L.ptr(run_var), L.ptr(stats),
+                                          L.ptr(y), L.stream_ptr()), "bn_small_fwd")
+        ctx.save_for_backward(x, g, stats)
+        ctx.cfg = (bool(relu), m8)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib as L
+        x, g, stats = ctx.saved_tensors
+        relu, m8 = ctx.cfg
+        R, C = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dgb = torch.empty((2, C), dtype=torch.float32, device=x.device)
+        L.check(L.lib().dh3d_bn_small_bwd(L.ptr(x), L.ptr(dy), R, C, L.ptr(g), L.ptr(stats), 1 if relu else 0, L.ptr(m8),
+                                          L.ptr(dx), L.ptr(dgb[0]), L.ptr(dgb[1]), L.stream_ptr()), "bn_small_bwd")
+        return dx, dgb[0], dgb[1], None, None, None, None, None, None
+
+
 def batch_norm_train(x, bnmod, relu, sync=False, mask=None, rows_per_cloud=0, momentum=None):
     """x [R, C] -> act(BN_train(x)); bnmod: backbones.TPBatchNorm / SlimBatchNorm (running buffers updated in place:
     decay 0.9 / 0.999 like tensorpack / slim).  mask [clouds] bool with rows_per_cloud rows each, or None."""
@@ -99,6 +132,9 @@ def batch_norm_train(x, bnmod, relu, sync=False, mask=None, rows_per_cloud=0, mo
     tp = isinstance(bnmod, bb.TPBatchNorm)
     rm, rv = (bnmod.mean_EMA, bnmod.variance_EMA) if tp else (bnmod.moving_mean, bnmod.moving_variance)
     mom = momentum if momentum is not None else (0.9 if tp else 0.999)
+    if x.shape[0] <= 64 and (mask is None or rows_per_cloud == 1) and not (sync and _world() > 1):
+        # the [clouds, C] activations behind NetVLAD: one launch per direction (single rank or per-rank statistics)
+        return _BatchNormTrainSmall.apply(x, bnmod.gamma, bnmod.beta, rm, rv, bnmod.eps, mom, relu, mask)
     return _BatchNormTrain.apply(x, bnmod.gamma, bnmod.beta, rm, rv, bnmod.eps, mom, relu, sync, mask, rows_per_cloud)
 
 

@@ -496,6 +496,13 @@ int dh3d_vlad_normalize_bwd(const float *V, const float *asum, const float *W2, 
  * (queries | positives | negatives | other negatives); loss[0] is zeroed by the call; grad has desc's shape. */
 int dh3d_quadruplet_loss(const float *desc, int B, int P, int Ng, int D, float margin, float margin2, float *loss,
                          float *grad, void *stream);
+/* training-mode BatchNorm (+ReLU) of a short tensor (R <= 64 rows, e.g. the [clouds, 256] activations behind NetVLAD) in
+ * one launch per direction; stats [4,C] = mean, rstd, scale, shift of the forward; mask [R] bytes or NULL. */
+int dh3d_bn_small_fwd(const float *x, int R, int C, const float *gamma, const float *beta, float eps, float momentum,
+                      int relu, const unsigned char *mask, float *run_mean, float *run_var, float *stats, float *y,
+                      void *stream);
+int dh3d_bn_small_bwd(const float *x, const float *dy, int R, int C, const float *gamma, const float *stats, int relu,
+                      const unsigned char *mask, float *dx, float *dgamma, float *dbeta, void *stream);
 /* batched GEMMs: `batch` independent products on operands stored back to back; colbias [batch, N] (nn only). */
 int dh3d_gemm_tn_f32_batched(const float *A, const float *B, int batch, int K, int M, int N, float *C, void *stream);
 int dh3d_gemm_nn_f32_batched(const float *A, const float *B, const float *colbias, int batch, int M, int K, int N,

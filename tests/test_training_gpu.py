@@ -254,7 +254,8 @@ def test_bn_train_kernels_match_torch(dev):
     from dh3d_amd import backbones as bb, train_ops as T
     g = torch.Generator().manual_seed(3)
     for (clouds, rpc, C, relu, use_mask) in [(3, 700, 256, True, False), (4, 512, 64, False, True), (5, 1, 256, False, True),
-                                             (2, 4096, 1024, True, False)]:
+                                             (2, 4096, 1024, True, False), (22, 1, 256, True, False),
+                                             (40, 1, 320, True, True), (64, 1, 64, False, False)]:   # short: one launch
         R = clouds * rpc
         x = (torch.randn(R, C, generator=g) * 2 + 0.5).to(dev)
         mask = None
