@@ -14,8 +14,10 @@
 // operand, each reused for WN (WM) MFMAs.  The next chunk's global loads are issued before the current chunk's MFMAs
 // (register prefetch, two LDS buffers, one barrier per chunk).
 #include "mfma_gemm.h"
+#include "bf16x3.h"
 
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+#include <type_traits>
 
 namespace {
 
@@ -150,6 +152,201 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
     }
 }
 
+// The same products on the bf16 matrix pipe with f32 accuracy (bf16x6, bf16x3.h) -- BOTH operands change every
+// training step, so both are split on the fly: a thread splits each element ONCE where it stages it (exact 8+8+8-bit
+// split, three bf16 planes in LDS, row = output index, 32 reduction steps + 8 pad contiguous), and a wave reads its
+// fragments with one 16-byte LDS read per plane.  Six v_mfma_f32_32x32x16_bf16 per 16 reduction steps replace eight
+// v_mfma_f32_32x32x2_f32 of twice the duration (2.7x less matrix-pipe time); products ordered small terms first and
+// interleaved over the wave's 2 x WN accumulator tiles, so no MFMA waits on its predecessor.  Operands stored with the
+// reduction index as the ROW ([K,M] of the tn form, every [K,N]) are loaded as dwords down a column (coalesced across
+// the lanes) and packed eight to a store.  One LDS buffer + register prefetch: 60 KB, two workgroups per CU.
+__device__ __forceinline__ void split3x8(const float *v, uint4 &c1, uint4 &c2, uint4 &c3) {
+  uint2 a1, a2, a3, b1, b2, b3;
+  split3x4(make_float4(v[0], v[1], v[2], v[3]), a1, a2, a3);
+  split3x4(make_float4(v[4], v[5], v[6], v[7]), b1, b2, b3);
+  c1 = make_uint4(a1.x, a1.y, b1.x, b1.y);
+  c2 = make_uint4(a2.x, a2.y, b2.x, b2.y);
+  c3 = make_uint4(a3.x, a3.y, b3.x, b3.y);
+}
+
+// KC reduction steps per stage: 16 -> 37 KB of LDS and <= 128 registers, four workgroups (16 waves) per CU hide the
+// load latency that one stage of MFMAs (0.3 us) cannot; 32 -> 60 KB, two workgroups.
+template <bool TA, int WN, int KC>
+__global__ __launch_bounds__(256, KC == 16 ? 4 : 2) void gemm_x6_kernel(
+    const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc, int M,
+    int N, int K, int kchunk, int atomic, float *__restrict__ C1, int rows0, const float *__restrict__ colbias,
+    int chunks, long long sA, long long sB, long long sC, long long sBias) {
+  constexpr int BM = 128, BN = 64 * WN, LD = KC + 8;
+  constexpr int NG = KC / 8;                                  // groups of 8 reduction steps per column
+  constexpr int TA_ = 256 / BM, TB_ = 256 / BN;               // threads along the reduction, column-wise operands
+  constexpr int GA = (NG + TA_ - 1) / TA_, GB = (NG + TB_ - 1) / TB_;  // groups per thread
+  constexpr int NF = BM * KC / 4 / 256;                       // float4 per thread of a row-wise A
+  __shared__ __attribute__((aligned(16))) unsigned short s_A[3][BM * LD];
+  __shared__ __attribute__((aligned(16))) unsigned short s_B[3][BN * LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+  const int bz = blockIdx.z / chunks;
+  const int kbeg = (blockIdx.z - bz * chunks) * kchunk, kend = min(K, kbeg + kchunk);
+  if (kbeg >= kend) return;
+  A += (size_t)bz * sA; B += (size_t)bz * sB; C += (size_t)bz * sC;
+  if (colbias) colbias += (size_t)bz * sBias;
+
+  // every load is unconditional on a clamped (valid) address and masked where it is staged (a load under a branch is
+  // merged through register copies that wait for it); threads without a group of their own (narrow tiles) re-read
+  // the last one and only skip the LDS store.  Interior stages take a mask-free copy of the staging code.
+  float4 ra[TA ? 1 : NF];
+  float ca[TA ? GA : 1][8], cb[GB][8];
+  const int acol = tid & (BM - 1), akg = tid / BM;  // TA: column of A, first group of reduction steps
+  const int bcol = tid & (BN - 1), bkg = tid / BN;
+  const int am = min(m0 + acol, M - 1), bn = min(n0 + bcol, N - 1);
+  const bool edge = (m0 + BM > M) | (n0 + BN > N);
+  auto load = [&](int k0) {
+    if (!TA) {
+#pragma unroll
+      for (int u = 0; u < NF; ++u) {
+        const int idx = tid + 256 * u, row = idx / (KC / 4), kq = idx % (KC / 4);
+        const int m = min(m0 + row, M - 1), k = min(k0 + 4 * kq, kend - 4);  // K % 4 == 0: whole float4 or nothing
+        ra[u] = *reinterpret_cast<const float4 *>(A + (size_t)m * lda + k);
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < GA; ++g) {
+        const int kg = k0 + 8 * min(akg + TA_ * g, NG - 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ca[g][j] = A[(size_t)min(kg + j, kend - 1) * lda + am];
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < GB; ++g) {
+      const int kg = k0 + 8 * min(bkg + TB_ * g, NG - 1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cb[g][j] = B[(size_t)min(kg + j, kend - 1) * ldb + bn];
+    }
+  };
+  auto keep = [](float x, bool ok) { return __uint_as_float(__float_as_uint(x) & (0u - (unsigned)ok)); };
+  auto stage = [&](int k0, auto ragged_c) {
+    constexpr bool RG = decltype(ragged_c)::value;
+    if (!TA) {
+#pragma unroll
+      for (int u = 0; u < NF; ++u) {
+        const int idx = tid + 256 * u, row = idx / (KC / 4), kq = idx % (KC / 4);
+        float4 v = ra[u];
+        if (RG) {
+          const bool ok = (m0 + row < M) & (k0 + 4 * kq < kend);
+          v = make_float4(keep(v.x, ok), keep(v.y, ok), keep(v.z, ok), keep(v.w, ok));
+        }
+        uint2 c1, c2, c3;
+        split3x4(v, c1, c2, c3);
+        *reinterpret_cast<uint2 *>(&s_A[0][row * LD + 4 * kq]) = c1;
+        *reinterpret_cast<uint2 *>(&s_A[1][row * LD + 4 * kq]) = c2;
+        *reinterpret_cast<uint2 *>(&s_A[2][row * LD + 4 * kq]) = c3;
+      }
+    } else {
+      const bool mok = m0 + acol < M;
+#pragma unroll
+      for (int g = 0; g < GA; ++g) {
+        const int kg = 8 * (akg + TA_ * g);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = RG ? keep(ca[g][j], mok & (k0 + kg + j < kend)) : ca[g][j];
+        uint4 c1, c2, c3;
+        split3x8(v, c1, c2, c3);
+        if (NG % TA_ == 0 || kg < KC) {
+          *reinterpret_cast<uint4 *>(&s_A[0][acol * LD + kg]) = c1;
+          *reinterpret_cast<uint4 *>(&s_A[1][acol * LD + kg]) = c2;
+          *reinterpret_cast<uint4 *>(&s_A[2][acol * LD + kg]) = c3;
+        }
+      }
+    }
+    const bool nok = n0 + bcol < N;
+#pragma unroll
+    for (int g = 0; g < GB; ++g) {
+      const int kg = 8 * (bkg + TB_ * g);
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = RG ? keep(cb[g][j], nok & (k0 + kg + j < kend)) : cb[g][j];
+      uint4 c1, c2, c3;
+      split3x8(v, c1, c2, c3);
+      if (NG % TB_ == 0 || kg < KC) {
+        *reinterpret_cast<uint4 *>(&s_B[0][bcol * LD + kg]) = c1;
+        *reinterpret_cast<uint4 *>(&s_B[1][bcol * LD + kg]) = c2;
+        *reinterpret_cast<uint4 *>(&s_B[2][bcol * LD + kg]) = c3;
+      }
+    }
+  };
+
+  f32x16 acc[2][WN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int arow = (wave & 1) * 64 + (lane & 31), brow = (wave >> 1) * 32 * WN + (lane & 31), kh8 = 8 * (lane >> 5);
+
+  load(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += KC) {
+    if (edge | (k0 + KC > kend)) stage(k0, std::true_type{});
+    else stage(k0, std::false_type{});
+    __syncthreads();
+    load(k0 + KC);  // clamped: past the end it re-reads the last rows and is never staged
+    __builtin_amdgcn_sched_barrier(0);  // ... and is in flight BEFORE the products, not wherever the scheduler sinks it
+#pragma unroll
+    for (int ks = 0; ks < KC; ks += 16) {
+      bf16x8 a[2][3], b[WN][3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          a[i][p] = *reinterpret_cast<const bf16x8 *>(&s_A[p][(arow + 32 * i) * LD + ks + kh8]);
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          b[j][p] = *reinterpret_cast<const bf16x8 *>(&s_B[p][(brow + 32 * j) * LD + ks + kh8]);
+      }
+#define DH3D_X6_PRODUCT(PA, PB)                                                                                 \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < WN; ++j)                  \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA], b[j][PB], acc[i][j], 0, 0, 0);
+      DH3D_X6_PRODUCT(2, 0) DH3D_X6_PRODUCT(0, 2) DH3D_X6_PRODUCT(1, 1)
+      DH3D_X6_PRODUCT(1, 0) DH3D_X6_PRODUCT(0, 1) DH3D_X6_PRODUCT(0, 0)
+#undef DH3D_X6_PRODUCT
+    }
+    __syncthreads();
+  }
+
+  if (!edge && !C1) {  // interior tile: no guards
+    float *c0 = C + (size_t)(m0 + (wave & 1) * 64 + 4 * (lane >> 5)) * ldc + n0 + (wave >> 1) * 32 * WN + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const float bias = colbias ? colbias[n0 + (wave >> 1) * 32 * WN + 32 * j + (lane & 31)] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float *dst = c0 + (size_t)(32 * i + (r & 3) + 8 * (r >> 2)) * ldc + 32 * j;
+          if (atomic) unsafeAtomicAdd(dst, acc[i][j][r]);
+          else *dst = acc[i][j][r] + bias;
+        }
+      }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int n = n0 + (wave >> 1) * 32 * WN + 32 * j + (lane & 31);
+      const float bias = (colbias && n < N) ? colbias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wave & 1) * 64 + 32 * i + mfma_row(r, lane);
+        if (m < M && n < N) {
+          float *dst = (C1 && m >= rows0) ? C1 + (size_t)(m - rows0) * ldc + n : C + (size_t)m * ldc + n;
+          if (atomic) unsafeAtomicAdd(dst, acc[i][j][r]);
+          else *dst = acc[i][j][r] + bias;
+        }
+      }
+    }
+}
+
 // [Bt][R][Cc] -> [Bt][Cc][R], 32-bit elements, 32x32 tiles through LDS.  The output may be a column block of a wider
 // matrix: row stride `ldo` (>= R) and batch stride `obs` elements (dense: ldo = R, obs = R*Cc).
 __global__ __launch_bounds__(256) void transpose32_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
@@ -198,8 +395,16 @@ int gemm_launch(bool ta, const float *A, int lda, const float *B, int ldb, float
   const int maxc = dh3d_cdiv(K, ta ? 64 : 256);  // [M,K] operands: only long reductions are worth the atomics
   chunks = chunks > maxc ? maxc : chunks;
   if (chunks < 1 || colbias) chunks = 1;
+  // products of >= 2^26 multiply-adds go to the bf16x6 kernel (f32-accurate, ~2x faster); small or odd-K ones stay on
+  // the exact-f32 pipe.  DH3D_GEMM_F32=1 keeps everything there (A/B timing, bit-level comparisons)
+  static const bool force_f32 = [] { const char *e = getenv("DH3D_GEMM_F32"); return e && e[0] == '1'; }();
+  const bool x6 = !force_f32 && K % 4 == 0 && K >= 32 && (double)M * N * K * bt.n >= 67108864.0;
+  // stage depth (measured, tools/gemm_bench.py): 16 for the 128-wide tiles (four workgroups per CU), 32 for N <= 64
+  // (the A stream dominates: whole 128-byte lines per row); DH3D_GEMM_KC=16|32 forces one (dev)
+  static const int x6kc = [] { const char *e = getenv("DH3D_GEMM_KC"); return e ? atoi(e) : 0; }();
+  const int kc = !x6 ? kKC : (x6kc == 16 || x6kc == 32) ? x6kc : narrow ? 32 : 16;
   int kchunk = dh3d_cdiv(K, chunks);
-  kchunk = (kchunk + kKC - 1) / kKC * kKC;  // multiple of 16: float4 loads of the [M,K] operand stay aligned
+  kchunk = (kchunk + kc - 1) / kc * kc;  // multiple of the stage depth: float4 loads of the [M,K] operand stay aligned
   chunks = dh3d_cdiv(K, kchunk);
   const int atomic = (chunks > 1 || accumulate) ? 1 : 0;
   if (colbias && atomic) return DH3D_ERR_UNSUPPORTED;
@@ -220,9 +425,18 @@ int gemm_launch(bool ta, const float *A, int lda, const float *B, int ldb, float
 #define DH3D_GEMM(TAV, WNV)                                                                                          \
   hipLaunchKernelGGL((gemm_f32_kernel<TAV, 2, WNV>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, kchunk, atomic, \
                      C1, rows0, colbias, chunks, bt.sA, bt.sB, bt.sC, bt.sBias)
-  if (ta) { if (narrow) DH3D_GEMM(true, 1); else DH3D_GEMM(true, 2); }
+#define DH3D_GEMM6(TAV, WNV, KCV)                                                                                    \
+  hipLaunchKernelGGL((gemm_x6_kernel<TAV, WNV, KCV>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, kchunk,       \
+                     atomic, C1, rows0, colbias, chunks, bt.sA, bt.sB, bt.sC, bt.sBias)
+#define DH3D_GEMM6K(TAV, WNV) do { if (kc == 16) DH3D_GEMM6(TAV, WNV, 16); else DH3D_GEMM6(TAV, WNV, 32); } while (0)
+  if (x6) {
+    if (ta) { if (narrow) DH3D_GEMM6K(true, 1); else DH3D_GEMM6K(true, 2); }
+    else { if (narrow) DH3D_GEMM6K(false, 1); else DH3D_GEMM6K(false, 2); }
+  } else if (ta) { if (narrow) DH3D_GEMM(true, 1); else DH3D_GEMM(true, 2); }
   else { if (narrow) DH3D_GEMM(false, 1); else DH3D_GEMM(false, 2); }
 #undef DH3D_GEMM
+#undef DH3D_GEMM6
+#undef DH3D_GEMM6K
   return dh3d_launch_status();
 }
 

@@ -12,7 +12,9 @@ def T(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
-@pytest.mark.parametrize("K,M,N", [(1000, 256, 64), (4097, 512, 256), (22, 16384, 256), (333, 128, 1024), (70, 36, 12)])
+# (products of >= 2^26 multiply-adds with K % 4 == 0 run on the bf16x6 kernel, the rest on the exact-f32 one)
+@pytest.mark.parametrize("K,M,N", [(1000, 256, 64), (4097, 512, 256), (22, 16384, 256), (333, 128, 1024), (70, 36, 12),
+                                   (11264, 256, 1024), (4100, 516, 260), (90112, 256, 64), (1028, 132, 1000)])
 def test_gemm_tn_vs_fp64(dev, K, M, N):
     from dh3d_amd import pm
     rng = np.random.default_rng(K + M + N)
@@ -28,7 +30,8 @@ def test_gemm_tn_vs_fp64(dev, K, M, N):
     assert np.all(np.abs(got2 - (exp + C0)) <= 2e-6 * (mag + np.abs(C0)) + 1e-6)
 
 
-@pytest.mark.parametrize("M,K,N", [(1000, 256, 512), (11264, 256, 512), (130, 1024, 256), (65, 64, 128), (300, 20, 36)])
+@pytest.mark.parametrize("M,K,N", [(1000, 256, 512), (11264, 256, 512), (130, 1024, 256), (65, 64, 128), (300, 20, 36),
+                                   (11264, 1024, 256), (90112, 64, 256), (4099, 260, 68), (70001, 36, 60)])
 def test_gemm_nn_vs_fp64(dev, M, K, N):
     from dh3d_amd import pm
     rng = np.random.default_rng(M + K + N)
@@ -38,6 +41,34 @@ def test_gemm_nn_vs_fp64(dev, M, K, N):
     mag = np.abs(A.astype(np.float64)) @ np.abs(B.astype(np.float64))
     got = pm.gemm_nn(T(A, dev), T(B, dev)).cpu().numpy()
     assert np.all(np.abs(got - exp) <= 2e-6 * mag + 1e-6), float(np.abs(got - exp).max())
+
+
+def test_gemm_batched_and_bias_vs_fp64(dev):
+    """batched forms (+ column bias, + wide-magnitude operands: the three-way bf16 split is exact for every f32) at
+    sizes that take the bf16x6 kernel and at sizes that stay on the f32 one."""
+    from dh3d_amd import pm
+    rng = np.random.default_rng(11)
+    for (b, M, K, N) in [(22, 4096, 256, 64), (22, 4096, 64, 256), (3, 130, 36, 20), (5, 1000, 128, 132)]:
+        A = (rng.standard_normal((b, M, K)) * np.exp(rng.uniform(-6, 6, (b, M, 1)))).astype(np.float32)
+        B = rng.standard_normal((b, K, N)).astype(np.float32)
+        bias = rng.standard_normal((b, N)).astype(np.float32)
+        A64, B64 = A.astype(np.float64), B.astype(np.float64)
+        exp = A64 @ B64 + bias[:, None, :]
+        mag = np.abs(A64) @ np.abs(B64) + np.abs(bias[:, None, :])
+        got = pm.gemm_nn_batched(T(A, dev), T(B, dev), bias=T(bias, dev)).cpu().numpy()
+        assert np.all(np.abs(got - exp) <= 2e-6 * mag + 1e-6), (b, M, K, N, float(np.abs(got - exp).max()))
+        # tn: C[b] = A[b]^T D[b],  A [b, M(reduction), K], D [b, M, N]
+        D = rng.standard_normal((b, M, N)).astype(np.float32)
+        exp = A64.transpose(0, 2, 1) @ D.astype(np.float64)
+        mag = np.abs(A64).transpose(0, 2, 1) @ np.abs(D.astype(np.float64))
+        got = pm.gemm_tn_batched(T(A, dev), T(D, dev)).cpu().numpy()
+        assert np.all(np.abs(got - exp) <= 2e-6 * mag + 1e-6), (b, M, K, N, float(np.abs(got - exp).max()))
+    A = rng.standard_normal((3000, 512)).astype(np.float32)
+    B = rng.standard_normal((512, 260)).astype(np.float32)
+    bias = rng.standard_normal(260).astype(np.float32)
+    got = pm.gemm_nn(T(A, dev), T(B, dev), bias=T(bias, dev)).cpu().numpy()
+    exp = A.astype(np.float64) @ B.astype(np.float64) + bias
+    assert np.all(np.abs(got - exp) <= 2e-6 * (np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64) + 1) + 1e-6)
 
 
 def test_transpose_and_colsum(dev):
