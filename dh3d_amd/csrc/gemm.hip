@@ -1,4 +1,7 @@
-// Exact-f32 MFMA GEMMs for the BACKWARD passes (gfx950), + the layout helpers the drop-in fast path needs.
+// f32 GEMMs for the BACKWARD passes (gfx950), + the layout helpers the drop-in fast path needs.  Two kernels behind the
+// same entries: products of >= 2^26 multiply-adds (K % 4 == 0) run on the bf16 matrix pipe with f32 accuracy
+// (gemm_x6_kernel below: both operands split three ways on the fly, six products), small or odd ones on the exact-f32
+// pipe (gemm_f32_kernel).
 //
 //   dh3d_gemm_tn_f32 : C[M,N] (+)= A[K,M]^T * B[K,N]   -- weight gradients dW = X^T dY: the reduction runs over the ROWS
 //                      (points) of two row-major activations, split over workgroups and combined with hardware f32
@@ -7,7 +10,7 @@
 //   dh3d_transpose32 : [B,R,C] -> [B,C,R] of 32-bit elements (channels-first <-> point-major)
 //   dh3d_colsum_f32  : column sums (bias gradients)
 //
-// One kernel template: a workgroup owns a (64*WM) x (64*WN) tile of C, its four waves a 2x2 arrangement of
+// gemm_f32_kernel: a workgroup owns a (64*WM) x (64*WN) tile of C, its four waves a 2x2 arrangement of
 // (32*WM) x (32*WN) sub-tiles on v_mfma_f32_32x32x2_f32 (a plain f32 fma chain per output -- exact f32, no reduced
 // precision).  Operand tiles are staged 16 reduction steps at a time through LDS in "k-major" form [16][tile+4]:
 // lane l of a wave then reads A[k = l>>5][i = l&31] and B[k][j] with conflict-free 4-byte LDS reads, one per MFMA
@@ -391,7 +394,11 @@ int gemm_launch(bool ta, const float *A, int lda, const float *B, int ldb, float
   const bool narrow = N <= 64;
   const int BM = 128, BN = narrow ? 64 : 128;
   const int gm = dh3d_cdiv(M, BM), gn = dh3d_cdiv(N, BN);
-  int chunks = dh3d_cdiv(768, gm * gn * bt.n);
+  // workgroups aimed at: the split partials meet in f32 atomics (~0.3 T/s chip-wide), so the long-reduction tn form
+  // wants fewer, longer chunks (tools/gemm_bench.py wgs: 384 beats 768 by 10-25 % there); DH3D_GEMM_WGS overrides (dev)
+  static const int wgs_env = [] { const char *e = getenv("DH3D_GEMM_WGS"); return e ? atoi(e) : 0; }();
+  const int wgs = wgs_env > 0 ? wgs_env : ta ? 384 : 768;
+  int chunks = dh3d_cdiv(wgs, gm * gn * bt.n);
   const int maxc = dh3d_cdiv(K, ta ? 64 : 256);  // [M,K] operands: only long reductions are worth the atomics
   chunks = chunks > maxc ? maxc : chunks;
   if (chunks < 1 || colbias) chunks = 1;

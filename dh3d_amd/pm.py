@@ -587,7 +587,8 @@ def flex_conv_bwd(features, xyz, nbr, theta, bias, grad_out, center_rank0=False,
 
 
 def gemm_tn(A, B, out=None, accumulate=False):
-    """C[M,N] (+)= A[K,M]^T @ B[K,N] on the exact-f32 MFMA pipe (weight gradients: the reduction runs over rows)."""
+    """C[M,N] (+)= A[K,M]^T @ B[K,N], f32-accurate (exact-f32 MFMA for small products, bf16x6 with both operands split on
+    the fly from 2^26 multiply-adds; csrc/gemm.hip) -- weight gradients: the reduction runs over rows."""
     A = L.require_cuda_f32(A, "A", 2)
     B = L.require_cuda_f32(B, "B", 2)
     K, M = A.shape
@@ -601,7 +602,7 @@ def gemm_tn(A, B, out=None, accumulate=False):
 
 
 def gemm_nn(A, B, out=None, accumulate=False, bias=None):
-    """C[M,N] (+)= A[M,K] @ B[K,N] (+ bias[N]) on the exact-f32 MFMA pipe."""
+    """C[M,N] (+)= A[M,K] @ B[K,N] (+ bias[N]), f32-accurate (see gemm_tn)."""
     A = L.require_cuda_f32(A, "A", 2)
     B = L.require_cuda_f32(B, "B", 2)
     M, K = A.shape

@@ -404,7 +404,9 @@ int dh3d_flex_conv_pm_bwd(const float *features, const float *xyz, const int32_t
                           int center_rank0, void *workspace, size_t workspace_bytes, float *grad_features,
                           float *grad_theta, float *grad_bias, void *stream);
 
-/* Exact-f32 MFMA GEMMs of the backward passes (csrc/gemm.hip), all row-major:
+/* f32 GEMMs of the backward passes (csrc/gemm.hip), all row-major; f32-accurate: the exact-f32 matrix pipe for small
+ * products, the bf16 pipe with a three-way split of BOTH operands (six products, ~2^-23 relative) from 2^26
+ * multiply-adds when K % 4 == 0 (environment DH3D_GEMM_F32=1 keeps everything on the exact-f32 kernel):
  *   tn: C[M,N] (+)= A[K,M]^T B[K,N]  (weight gradients: reduction over rows, split over workgroups + f32 atomics)
  *   nn: C[M,N] (+)= A[M,K]   B[K,N] (+ colbias[N], may be NULL; not with accumulate)  (linear layers of the
  *       training step, input gradients with W^T materialised)
