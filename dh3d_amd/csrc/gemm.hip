@@ -1,5 +1,5 @@
 // f32 GEMMs for the BACKWARD passes (gfx950), + the layout helpers the drop-in fast path needs.  Two kernels behind the
-// same entries: products of >= 2^26 multiply-adds (K % 4 == 0) run on the bf16 matrix pipe with f32 accuracy
+// same entries: products of >= 2^26 multiply-adds (K % 32 == 0) run on the bf16 matrix pipe with f32 accuracy
 // (gemm_x6_kernel below: both operands split three ways on the fly, six products), small or odd ones on the exact-f32
 // pipe (gemm_f32_kernel).
 //
@@ -173,7 +173,10 @@ __device__ __forceinline__ void split3x8(const float *v, uint4 &c1, uint4 &c2, u
 }
 
 // KC reduction steps per stage: 16 -> 37 KB of LDS and <= 128 registers, four workgroups (16 waves) per CU hide the
-// load latency that one stage of MFMAs (0.3 us) cannot; 32 -> 60 KB, two workgroups.
+// load latency that one stage of MFMAs (0.3 us) cannot; 32 -> 60 KB, two workgroups.  (A second register set with the
+// loads of TWO stages in flight, three workgroups per CU, measured the same to the microsecond: what the waves wait for
+// -- PMC: 47 % of their cycles in s_waitcnt / s_barrier, 34 % issue-stalled, MFMA and VALU each ~28 % busy -- is each
+// other at the two barriers of a stage, not memory.)
 template <bool TA, int WN, int KC>
 __global__ __launch_bounds__(256, KC == 16 ? 4 : 2) void gemm_x6_kernel(
     const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb, float *__restrict__ C, int ldc, int M,
@@ -194,40 +197,47 @@ __global__ __launch_bounds__(256, KC == 16 ? 4 : 2) void gemm_x6_kernel(
   A += (size_t)bz * sA; B += (size_t)bz * sB; C += (size_t)bz * sC;
   if (colbias) colbias += (size_t)bz * sBias;
 
-  // every load is unconditional on a clamped (valid) address and masked where it is staged (a load under a branch is
-  // merged through register copies that wait for it); threads without a group of their own (narrow tiles) re-read
-  // the last one and only skip the LDS store.  Interior stages take a mask-free copy of the staging code.
+  // K % 32 == 0 (dispatch): every stage is whole, no masks or clamps along the reduction.  Every load is unconditional
+  // (a load under a branch is merged through register copies that wait for it): rows / columns past the edge are
+  // clamped once and zeroed where they are staged; threads without a group of their own (narrow tiles) re-read the last
+  // one and only skip the LDS store.  Addresses are a wave-uniform base (scalar unit) + a per-lane 32-bit offset fixed
+  // for the kernel -- the vector unit is left to the split (PMC: VALU and MFMA busy were equal, 8 VALU per MFMA).
   float4 ra[TA ? 1 : NF];
   float ca[TA ? GA : 1][8], cb[GB][8];
-  const int acol = tid & (BM - 1), akg = tid / BM;  // TA: column of A, first group of reduction steps
-  const int bcol = tid & (BN - 1), bkg = tid / BN;
-  const int am = min(m0 + acol, M - 1), bn = min(n0 + bcol, N - 1);
+  const int acol = tid & (BM - 1), akg = __builtin_amdgcn_readfirstlane(tid / BM);  // TA: column of A, its first group
+  const int bcol = tid & (BN - 1), bkg = __builtin_amdgcn_readfirstlane(tid / BN);
+  const unsigned am = (unsigned)min(m0 + acol, M - 1), bn = (unsigned)min(n0 + bcol, N - 1);
   const bool edge = (m0 + BM > M) | (n0 + BN > N);
+  unsigned aoff[TA ? 1 : NF];
+  if (!TA) {
+#pragma unroll
+    for (int u = 0; u < NF; ++u) {
+      const int idx = tid + 256 * u, row = idx / (KC / 4), kq = idx % (KC / 4);
+      aoff[u] = (unsigned)min(m0 + row, M - 1) * (unsigned)lda + 4u * kq;  // M * lda < 2^30 (dispatch)
+    }
+  }
   auto load = [&](int k0) {
     if (!TA) {
+      const float *Ak = A + k0;
 #pragma unroll
-      for (int u = 0; u < NF; ++u) {
-        const int idx = tid + 256 * u, row = idx / (KC / 4), kq = idx % (KC / 4);
-        const int m = min(m0 + row, M - 1), k = min(k0 + 4 * kq, kend - 4);  // K % 4 == 0: whole float4 or nothing
-        ra[u] = *reinterpret_cast<const float4 *>(A + (size_t)m * lda + k);
-      }
+      for (int u = 0; u < NF; ++u) ra[u] = *reinterpret_cast<const float4 *>(Ak + aoff[u]);
     } else {
 #pragma unroll
       for (int g = 0; g < GA; ++g) {
-        const int kg = k0 + 8 * min(akg + TA_ * g, NG - 1);
+        const float *Ak = A + (size_t)(k0 + 8 * min(akg + TA_ * g, NG - 1)) * lda;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ca[g][j] = A[(size_t)min(kg + j, kend - 1) * lda + am];
+        for (int j = 0; j < 8; ++j) ca[g][j] = Ak[(size_t)j * lda + am];
       }
     }
 #pragma unroll
     for (int g = 0; g < GB; ++g) {
-      const int kg = k0 + 8 * min(bkg + TB_ * g, NG - 1);
+      const float *Bk = B + (size_t)(k0 + 8 * min(bkg + TB_ * g, NG - 1)) * ldb;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) cb[g][j] = B[(size_t)min(kg + j, kend - 1) * ldb + bn];
+      for (int j = 0; j < 8; ++j) cb[g][j] = Bk[(size_t)j * ldb + bn];
     }
   };
   auto keep = [](float x, bool ok) { return __uint_as_float(__float_as_uint(x) & (0u - (unsigned)ok)); };
-  auto stage = [&](int k0, auto ragged_c) {
+  auto stage = [&](auto ragged_c) {
     constexpr bool RG = decltype(ragged_c)::value;
     if (!TA) {
 #pragma unroll
@@ -235,7 +245,7 @@ __global__ __launch_bounds__(256, KC == 16 ? 4 : 2) void gemm_x6_kernel(
         const int idx = tid + 256 * u, row = idx / (KC / 4), kq = idx % (KC / 4);
         float4 v = ra[u];
         if (RG) {
-          const bool ok = (m0 + row < M) & (k0 + 4 * kq < kend);
+          const bool ok = m0 + row < M;
           v = make_float4(keep(v.x, ok), keep(v.y, ok), keep(v.z, ok), keep(v.w, ok));
         }
         uint2 c1, c2, c3;
@@ -251,7 +261,7 @@ __global__ __launch_bounds__(256, KC == 16 ? 4 : 2) void gemm_x6_kernel(
         const int kg = 8 * (akg + TA_ * g);
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = RG ? keep(ca[g][j], mok & (k0 + kg + j < kend)) : ca[g][j];
+        for (int j = 0; j < 8; ++j) v[j] = RG ? keep(ca[g][j], mok) : ca[g][j];
         uint4 c1, c2, c3;
         split3x8(v, c1, c2, c3);
         if (NG % TA_ == 0 || kg < KC) {
@@ -267,7 +277,7 @@ __global__ __launch_bounds__(256, KC == 16 ? 4 : 2) void gemm_x6_kernel(
       const int kg = 8 * (bkg + TB_ * g);
       float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = RG ? keep(cb[g][j], nok & (k0 + kg + j < kend)) : cb[g][j];
+      for (int j = 0; j < 8; ++j) v[j] = RG ? keep(cb[g][j], nok) : cb[g][j];
       uint4 c1, c2, c3;
       split3x8(v, c1, c2, c3);
       if (NG % TB_ == 0 || kg < KC) {
@@ -288,12 +298,12 @@ __global__ __launch_bounds__(256, KC == 16 ? 4 : 2) void gemm_x6_kernel(
   const int arow = (wave & 1) * 64 + (lane & 31), brow = (wave >> 1) * 32 * WN + (lane & 31), kh8 = 8 * (lane >> 5);
 
   load(kbeg);
-  for (int k0 = kbeg; k0 < kend; k0 += KC) {
-    if (edge | (k0 + KC > kend)) stage(k0, std::true_type{});
-    else stage(k0, std::false_type{});
+  for (int k0 = kbeg; k0 < kend; k0 += KC) {  // (kend - kbeg) % KC == 0 (dispatch)
+    if (edge) stage(std::true_type{});
+    else stage(std::false_type{});
     __syncthreads();
-    load(k0 + KC);  // clamped: past the end it re-reads the last rows and is never staged
-    __builtin_amdgcn_sched_barrier(0);  // ... and is in flight BEFORE the products, not wherever the scheduler sinks it
+    load(k0 + KC < kend ? k0 + KC : k0);  // (the last stage re-reads itself: unconditional, in bounds, never staged)
+    __builtin_amdgcn_sched_barrier(0);    // ... and in flight BEFORE the products, not wherever the scheduler sinks it
 #pragma unroll
     for (int ks = 0; ks < KC; ks += 16) {
       bf16x8 a[2][3], b[WN][3];
@@ -402,16 +412,18 @@ int gemm_launch(bool ta, const float *A, int lda, const float *B, int ldb, float
   const int maxc = dh3d_cdiv(K, ta ? 64 : 256);  // [M,K] operands: only long reductions are worth the atomics
   chunks = chunks > maxc ? maxc : chunks;
   if (chunks < 1 || colbias) chunks = 1;
-  // products of >= 2^26 multiply-adds go to the bf16x6 kernel (f32-accurate, ~2x faster); small or odd-K ones stay on
+  // products of >= 2^26 multiply-adds with K % 32 == 0 go to the bf16x6 kernel (f32-accurate); small or odd-K ones stay on
   // the exact-f32 pipe.  DH3D_GEMM_F32=1 keeps everything there (A/B timing, bit-level comparisons)
   static const bool force_f32 = [] { const char *e = getenv("DH3D_GEMM_F32"); return e && e[0] == '1'; }();
-  const bool x6 = !force_f32 && K % 4 == 0 && K >= 32 && (double)M * N * K * bt.n >= 67108864.0;
+  const bool x6 = !force_f32 && K % 32 == 0 && (double)M * N * K * bt.n >= 67108864.0 &&
+                  (ta || (lda % 4 == 0 && (double)M * lda < 1073741824.0));
   // stage depth (measured, tools/gemm_bench.py): 16 for the 128-wide tiles (four workgroups per CU), 32 for N <= 64
   // (the A stream dominates: whole 128-byte lines per row); DH3D_GEMM_KC=16|32 forces one (dev)
   static const int x6kc = [] { const char *e = getenv("DH3D_GEMM_KC"); return e ? atoi(e) : 0; }();
   const int kc = !x6 ? kKC : (x6kc == 16 || x6kc == 32) ? x6kc : narrow ? 32 : 16;
+  const int kgran = x6 ? 32 : kc;  // chunk granularity: whole stages of either depth
   int kchunk = dh3d_cdiv(K, chunks);
-  kchunk = (kchunk + kc - 1) / kc * kc;  // multiple of the stage depth: float4 loads of the [M,K] operand stay aligned
+  kchunk = (kchunk + kgran - 1) / kgran * kgran;  // multiple of the stage depth: float4 loads of the [M,K] operand stay aligned
   chunks = dh3d_cdiv(K, kchunk);
   const int atomic = (chunks > 1 || accumulate) ? 1 : 0;
   if (colbias && atomic) return DH3D_ERR_UNSUPPORTED;

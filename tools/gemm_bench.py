@@ -43,7 +43,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "run":
         main()
     else:
-        envs = ({"DH3D_GEMM_KC": "16"}, {"DH3D_GEMM_KC": "32"}, {"DH3D_GEMM_F32": "1"})
+        envs = ({}, {"DH3D_GEMM_KC": "16"}, {"DH3D_GEMM_KC": "32"}, {"DH3D_GEMM_F32": "1"})
         if len(sys.argv) > 1 and sys.argv[1] == "wgs":
             envs = tuple({"DH3D_GEMM_WGS": w} for w in ("256", "384", "512", "768", "1024", "1536"))
         for env in envs:
