@@ -69,7 +69,10 @@ _SIGNATURES = {
     "dh3d_bn_bwd_finalize": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_fp],
     "dh3d_bn_bwd_apply": [c_fp, c_fp, c_fp, c_fp, c_ll, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_int,
                           c_fp, c_fp],
-    "dh3d_netvlad_assign_rows": [c_fp, c_ll, c_int, c_fp, c_fp, c_fp, c_fp, c_fp],
+    "dh3d_netvlad_assign_rows": [c_fp, c_ll, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_ll, c_fp],
+    "dh3d_idw_weights": [c_fp, c_ll, c_fp, c_fp],
+    "dh3d_context_gate_fwd": [c_fp, c_fp, c_ll, c_fp, c_fp],
+    "dh3d_context_gate_bwd": [c_fp, c_fp, c_fp, c_ll, c_fp, c_fp, c_fp],
     "dh3d_netvlad_assign_rows_bwd": [c_fp, c_ll, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp],
     "dh3d_l2norm_rows_bwd": [c_fp, c_fp, c_ll, c_int, c_float, c_fp, c_fp],
     "dh3d_transpose32": [c_fp, c_int, c_int, c_int, c_fp, c_fp],

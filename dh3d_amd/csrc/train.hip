@@ -281,33 +281,80 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double *__re
 // NetVLAD soft assignment (core/backbones.py:214-238), one wave per row of s = xn @ Wc (64 clusters = 64 lanes):
 //   z = s*scale + shift (training: folded batch statistics);  p = softmax(z);  a = p * att[n]
 // backward given da = dL/da:  datt[n] = sum_c da*p;  dp = da*att;  dz = p * (dp - sum_c dp*p)
-template <bool BWD>
+// forward: a workgroup owns RPW consecutive rows (wave w the rows w, w + 4, ...); with asum != NULL the column sums of a
+// over the rows of a cloud (asum [clouds, 64], zeroed by the caller; rows_per_cloud % RPW == 0) ride along -- registers,
+// one LDS exchange, 64 atomics per workgroup -- instead of a second pass over a.
+template <bool BWD, int RPW>
 __global__ __launch_bounds__(256) void netvlad_assign_rows_kernel(const float *__restrict__ sm, long long R,
                                                                  const float *__restrict__ scale,
                                                                  const float *__restrict__ shift,
                                                                  const float *__restrict__ att,
                                                                  const float *__restrict__ da, float *__restrict__ out,
-                                                                 float *__restrict__ datt) {
-  const int lane = threadIdx.x & 63;
-  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= R) return;
-  const float z = fmaf(sm[row * 64 + lane], scale[lane], shift[lane]);
-  float m = z;
+                                                                 float *__restrict__ datt, float *__restrict__ asum,
+                                                                 long long rows_per_cloud) {
+  __shared__ float s_sum[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long row0 = (long long)blockIdx.x * RPW;
+  const float sc = scale[lane], sh = shift[lane];
+  float colsum = 0.f;
+  for (int i = wave; i < RPW; i += 4) {
+    const long long row = row0 + i;
+    if (row >= R) break;
+    const float z = fmaf(sm[row * 64 + lane], sc, sh);
+    float m = z;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-  const float e = expf(z - m);
-  float den = e;
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    const float e = expf(z - m);
+    float den = e;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) den += __shfl_xor(den, off, 64);
-  const float p = e / den, w = att[row];
-  if (!BWD) { out[row * 64 + lane] = p * w; return; }
-  const float g = da[row * 64 + lane];
-  float d1 = g * p;           // -> datt
-  float d2 = g * w * p;       // -> sum_c dp * p
+    for (int off = 32; off > 0; off >>= 1) den += __shfl_xor(den, off, 64);
+    const float p = e / den, w = att[row];
+    if (!BWD) {
+      const float a = p * w;
+      out[row * 64 + lane] = a;
+      colsum += a;
+      continue;
+    }
+    const float g = da[row * 64 + lane];
+    float d1 = g * p;           // -> datt
+    float d2 = g * w * p;       // -> sum_c dp * p
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { d1 += __shfl_xor(d1, off, 64); d2 += __shfl_xor(d2, off, 64); }
-  out[row * 64 + lane] = p * (g * w - d2);
-  if (lane == 0) datt[row] = d1;
+    for (int off = 32; off > 0; off >>= 1) { d1 += __shfl_xor(d1, off, 64); d2 += __shfl_xor(d2, off, 64); }
+    out[row * 64 + lane] = p * (g * w - d2);
+    if (lane == 0) datt[row] = d1;
+  }
+  if (!BWD && asum) {
+    s_sum[wave][lane] = colsum;
+    __syncthreads();
+    if (wave == 0 && row0 < R)
+      unsafeAtomicAdd(asum + (row0 / rows_per_cloud) * 64 + lane,
+                      (s_sum[0][lane] + s_sum[1][lane]) + (s_sum[2][lane] + s_sum[3][lane]));
+  }
+}
+
+// inverse-distance weights of three_interpolate (core/backbones.py:92-95): d = max(dist, 1e-10), w = (1/d) / sum_t (1/d)
+__global__ __launch_bounds__(256) void idw_weights_kernel(const float *__restrict__ dist, long long R,
+                                                         float *__restrict__ w) {
+  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= R) return;
+  const float r0 = 1.0f / fmaxf(dist[3 * r], 1e-10f), r1 = 1.0f / fmaxf(dist[3 * r + 1], 1e-10f),
+              r2 = 1.0f / fmaxf(dist[3 * r + 2], 1e-10f);
+  const float tot = (r0 + r1) + r2;
+  w[3 * r] = r0 / tot; w[3 * r + 1] = r1 / tot; w[3 * r + 2] = r2 / tot;
+}
+
+// context gating (core/backbones.py:271-277): y = v * sigmoid(g); backward dv = dy * sig, dg = dy * v * sig * (1 - sig)
+template <bool BWD>
+__global__ __launch_bounds__(256) void context_gate_kernel(const float *__restrict__ v, const float *__restrict__ g,
+                                                          const float *__restrict__ dy, long long n,
+                                                          float *__restrict__ o0, float *__restrict__ o1) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float sig = 1.0f / (1.0f + expf(-g[i]));
+  if (!BWD) { o0[i] = v[i] * sig; return; }
+  const float d = dy[i];
+  o0[i] = d * sig;
+  o1[i] = d * v[i] * sig * (1.0f - sig);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -594,12 +641,16 @@ DH3D_API int dh3d_bn_bwd_finalize(const double *S1, const double *S2, const doub
   return dh3d_launch_status();
 }
 
+// asum (may be NULL) [R / rows_per_cloud, 64]: column sums of a per cloud, zeroed and accumulated here
 DH3D_API int dh3d_netvlad_assign_rows(const float *s, long long R, int Cl, const float *scale, const float *shift,
-                                      const float *att, float *a, void *stream) {
+                                      const float *att, float *a, float *asum, long long rows_per_cloud, void *stream) {
   DH3D_REQUIRE(s && scale && shift && att && a && R > 0);
-  DH3D_SUPPORTED(Cl == 64);
-  hipLaunchKernelGGL(netvlad_assign_rows_kernel<false>, dim3(dh3d_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, s, R,
-                     scale, shift, att, nullptr, a, nullptr);
+  DH3D_SUPPORTED(Cl == 64 && (!asum || (rows_per_cloud > 0 && rows_per_cloud % 64 == 0 && R % rows_per_cloud == 0)));
+  hipStream_t st = (hipStream_t)stream;
+  if (asum && hipMemsetAsync(asum, 0, sizeof(float) * 64 * (size_t)(R / rows_per_cloud), st) != hipSuccess)
+    return DH3D_ERR_LAUNCH;
+  hipLaunchKernelGGL((netvlad_assign_rows_kernel<false, 64>), dim3(dh3d_cdiv(R, 64)), dim3(256), 0, st, s, R, scale,
+                     shift, att, nullptr, a, nullptr, asum, rows_per_cloud);
   return dh3d_launch_status();
 }
 
@@ -607,8 +658,30 @@ DH3D_API int dh3d_netvlad_assign_rows_bwd(const float *s, long long R, int Cl, c
                                           const float *att, const float *da, float *dz, float *datt, void *stream) {
   DH3D_REQUIRE(s && scale && shift && att && da && dz && datt && R > 0);
   DH3D_SUPPORTED(Cl == 64);
-  hipLaunchKernelGGL(netvlad_assign_rows_kernel<true>, dim3(dh3d_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, s, R,
-                     scale, shift, att, da, dz, datt);
+  hipLaunchKernelGGL((netvlad_assign_rows_kernel<true, 4>), dim3(dh3d_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, s, R,
+                     scale, shift, att, da, dz, datt, nullptr, 1);
+  return dh3d_launch_status();
+}
+
+// dist [R, 3] (three_nn) -> w [R, 3] inverse-distance weights
+DH3D_API int dh3d_idw_weights(const float *dist, long long R, float *w, void *stream) {
+  DH3D_REQUIRE(dist && w && R > 0);
+  hipLaunchKernelGGL(idw_weights_kernel, dim3(dh3d_cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, dist, R, w);
+  return dh3d_launch_status();
+}
+
+// y = v * sigmoid(g) over n elements, and its backward (dv, dg from dy)
+DH3D_API int dh3d_context_gate_fwd(const float *v, const float *g, long long n, float *y, void *stream) {
+  DH3D_REQUIRE(v && g && y && n > 0);
+  hipLaunchKernelGGL(context_gate_kernel<false>, dim3(dh3d_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, v, g, nullptr,
+                     n, y, nullptr);
+  return dh3d_launch_status();
+}
+DH3D_API int dh3d_context_gate_bwd(const float *v, const float *g, const float *dy, long long n, float *dv, float *dg,
+                                   void *stream) {
+  DH3D_REQUIRE(v && g && dy && dv && dg && n > 0);
+  hipLaunchKernelGGL(context_gate_kernel<true>, dim3(dh3d_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, v, g, dy, n, dv,
+                     dg);
   return dh3d_launch_status();
 }
 

@@ -772,12 +772,40 @@ def interp_bn_bwd_apply(G, idx, dist, order, dlogit, w_fc, scale, shift, k2, k3,
     return dG
 
 
-def netvlad_assign_rows(s, scale, shift, att):
+def netvlad_assign_rows(s, scale, shift, att, rows_per_cloud=0):
+    """a = softmax(s*scale + shift) * att; with rows_per_cloud (% 64 == 0) also (a, asum [clouds, 64]) -- the per-cloud
+    column sums of a from the same pass."""
     s = L.require_cuda_f32(s, "s", 2)
     a = torch.empty_like(s)
+    asum = None
+    if rows_per_cloud:
+        asum = torch.empty((s.shape[0] // rows_per_cloud, s.shape[1]), dtype=torch.float32, device=s.device)
     L.check(L.lib().dh3d_netvlad_assign_rows(L.ptr(s), s.shape[0], s.shape[1], L.ptr(scale), L.ptr(shift), L.ptr(att),
-                                             L.ptr(a), L.stream_ptr()), "netvlad_assign_rows")
-    return a
+                                             L.ptr(a), L.ptr(asum), int(rows_per_cloud), L.stream_ptr()),
+            "netvlad_assign_rows")
+    return (a, asum) if rows_per_cloud else a
+
+
+def idw_weights(dist):
+    """three_nn distances [..., 3] -> inverse-distance weights (core/backbones.py:92-95), one launch."""
+    dist = L.require_cuda_f32(dist, "dist", dist.dim())
+    w = torch.empty_like(dist)
+    L.check(L.lib().dh3d_idw_weights(L.ptr(dist), dist.numel() // 3, L.ptr(w), L.stream_ptr()), "idw_weights")
+    return w
+
+
+def context_gate(v, g):
+    v, g = L.require_cuda_f32(v, "v", v.dim()), L.require_cuda_f32(g, "g", g.dim())
+    y = torch.empty_like(v)
+    L.check(L.lib().dh3d_context_gate_fwd(L.ptr(v), L.ptr(g), v.numel(), L.ptr(y), L.stream_ptr()), "context_gate")
+    return y
+
+
+def context_gate_bwd(v, g, dy):
+    dv, dg = torch.empty_like(v), torch.empty_like(v)
+    L.check(L.lib().dh3d_context_gate_bwd(L.ptr(v), L.ptr(g), L.ptr(dy), v.numel(), L.ptr(dv), L.ptr(dg), L.stream_ptr()),
+            "context_gate_bwd")
+    return dv, dg
 
 
 def netvlad_assign_rows_bwd(s, scale, shift, att, da):

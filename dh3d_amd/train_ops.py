@@ -405,10 +405,13 @@ class _NetVLADAssign(torch.autograd.Function):
         st = _forward_stats(s, g, be, run_mean, run_var, eps, momentum, mask, N, sync)
         scale, shift = st.stats[2], st.stats[3]
         att = att.contiguous()
-        a = pm.netvlad_assign_rows(s, scale, shift, att)                   # softmax(bn(s)) * att
+        if N % 64 == 0:   # softmax(bn(s)) * att, and its per-cloud column sums from the same pass
+            a, asum = pm.netvlad_assign_rows(s, scale, shift, att, rows_per_cloud=N)
+        else:
+            a = pm.netvlad_assign_rows(s, scale, shift, att)
+            asum = a.reshape(Bt, N, a.shape[1]).sum(1)
         Cl = a.shape[1]
         V = pm.gemm_tn_batched(a.reshape(Bt, N, Cl), xn.reshape(Bt, N, Dm))   # [Bt, Cl, D]
-        asum = a.reshape(Bt, N, Cl).sum(1)
         ctx.save_for_backward(x2, xn, s, a, att, Wc, g, be)
         ctx.cfg = (Bt, N, bool(sync), mask, st)
         return V, asum
@@ -433,6 +436,25 @@ class _NetVLADAssign(torch.autograd.Function):
         if mask is not None:
             datt = datt * mask.repeat_interleave(N).to(datt.dtype)
         return dx, datt, dWc, dgamma, dbeta, None, None, None, None, None, None
+
+
+class _ContextGate(torch.autograd.Function):
+    """v * sigmoid(g) (core/backbones.py:271-277): one launch per direction."""
+
+    @staticmethod
+    def forward(ctx, v, g):
+        v, g = v.contiguous(), g.contiguous()
+        ctx.save_for_backward(v, g)
+        return pm.context_gate(v, g)
+
+    @staticmethod
+    def backward(ctx, dy):
+        v, g = ctx.saved_tensors
+        return pm.context_gate_bwd(v, g, dy.contiguous())
+
+
+def context_gate(v, g):
+    return _ContextGate.apply(v, g)
 
 
 def netvlad_assign(x, att, Wc, bnmod, sync=False, mask=None):

@@ -193,14 +193,13 @@ def global_head_hip(model, points, localdesc, lv, sync_bn=False, mask=None, comm
     x = x + fc.feature_bias.reshape(1, 1, -1)                                       # layers.py:330-331
     Dg = x.shape[2]
     new_feat = T.batch_norm_train(x.reshape(Bt * M, Dg), fbn, True, sync_bn, mask, M).reshape(Bt, M, Dg)
-    d = torch.clamp(lv["nn3_dist"], min=1e-10)                                      # backbones.py:92-95
-    w = (1.0 / d) / (1.0 / d).sum(2, keepdim=True)
+    from . import pm
+    w = pm.idw_weights(lv["nn3_dist"])                                              # backbones.py:92-95 (no gradient: geometry)
     fcw = att_mod.detec_conv_fc
     sorted_walks = commute_attention and T.attention_commute_supported(att_mod.detec_conv0, M) and Dg == 256
     if sorted_walks:
         # the fine clouds' Morton records: from the geometry level if it has them (compute_level stores them for
         # N >= 4096); three_interpolate's backward and the attention head walk the points in that order
-        from . import pm
         order = lv["_ordered"][0] if "_ordered" in lv else pm.spatial_sort(points)[0]
         forglobal = T.three_interpolate_sorted(new_feat, lv["nn3_idx"], w, order)   # [Bt,N,256]
     else:
@@ -222,7 +221,7 @@ def global_head_hip(model, points, localdesc, lv, sync_bn=False, mask=None, comm
         vlad = vlad * torch.rsqrt(torch.clamp((vlad * vlad).sum(1, keepdim=True), min=1e-12))
     v = T.batch_norm_train(T.linear(vlad, nv.hidden1_weights), nv.bn, False, sync_bn, mask, 1)
     gates = T.batch_norm_train(T.linear(v, nv.gating_weights), nv.gating_bn, False, sync_bn, mask, 1)
-    return v * torch.sigmoid(gates)
+    return T.context_gate(v, gates)
 
 
 def trainable_head_parameters(model):

@@ -451,12 +451,19 @@ int dh3d_bn_bwd_finalize(const double *S1, const double *S2, const double *count
 
 /* NetVLAD soft assignment rows (core/backbones.py:214-238; Cl = 64, one wave per row):
  *   a[r,:] = softmax(s[r,:]*scale + shift) * att[r];   backward: da -> dz (gradient at the BatchNorm output), datt.
- * l2norm_rows_bwd: backward of xn = x * rsqrt(max(sum x^2, eps)) (tf.nn.l2_normalize). */
+ * asum (may be NULL) [R / rows_per_cloud, 64]: the per-cloud column sums of a (backbones.py:241) from the same pass
+ * (rows_per_cloud % 64 == 0).  l2norm_rows_bwd: backward of xn = x * rsqrt(max(sum x^2, eps)) (tf.nn.l2_normalize).
+ * idw_weights: three_interpolate's inverse-distance weights from three_nn's distances (backbones.py:92-95).
+ * context_gate: y = v * sigmoid(g) (backbones.py:271-277) and its backward. */
 int dh3d_netvlad_assign_rows(const float *s, long long R, int Cl, const float *scale, const float *shift,
-                             const float *att, float *a, void *stream);
+                             const float *att, float *a, float *asum, long long rows_per_cloud, void *stream);
 int dh3d_netvlad_assign_rows_bwd(const float *s, long long R, int Cl, const float *scale, const float *shift,
                                  const float *att, const float *da, float *dz, float *datt, void *stream);
 int dh3d_l2norm_rows_bwd(const float *x, const float *dxn, long long R, int C, float eps, float *dx, void *stream);
+int dh3d_idw_weights(const float *dist, long long R, float *w, void *stream);
+int dh3d_context_gate_fwd(const float *v, const float *g, long long n, float *y, void *stream);
+int dh3d_context_gate_bwd(const float *v, const float *g, const float *dy, long long n, float *dv, float *dg,
+                          void *stream);
 /* Training-mode attention head with its convolution commuted through the up-sampling (csrc/interp_train.hip): the
  * pre-activation h = three_interpolate(G) of globalatt_block (core/backbones.py:89-100,156-173), G = coarse @ W + b as
  * 256-column slices [Hd/256][B*m][256] (row_major = 0) or as the GEMM's own [B*m][Hd] output (row_major = 1; dG likewise),

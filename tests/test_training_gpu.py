@@ -509,3 +509,37 @@ def test_quadruplet_loss_kernel_matches_the_tensor_expression(dev, B, P, Ng, sca
     (lb * 1.7).backward()
     assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(lb)))
     assert float((a.grad - b.grad).abs().max()) <= 1e-6 * max(1.0, float(b.grad.abs().max()))
+
+
+def test_small_fused_training_ops(dev):
+    """The one-launch forms of three groups of tiny tensor ops: inverse-distance weights, NetVLAD's per-cloud assignment
+    sums from the assignment pass, context gating (forward and backward) -- against the torch expressions they replace."""
+    from dh3d_amd import pm, train_ops as T
+    g = torch.Generator().manual_seed(9)
+    dist = torch.rand(3, 700, 3, generator=g).to(dev) * 0.1
+    dist[0, :5, 0] = 0.0                                           # coincident points: clamp at 1e-10
+    d = torch.clamp(dist, min=1e-10)
+    ref = (1.0 / d) / (1.0 / d).sum(2, keepdim=True)
+    assert torch.allclose(pm.idw_weights(dist), ref, rtol=2e-6, atol=1e-12)
+    # assignment rows + per-cloud sums
+    Bt, N = 3, 640
+    s = torch.randn(Bt * N, 64, generator=g).to(dev) * 3
+    scale, shift = (0.5 + torch.rand(64, generator=g)).to(dev), torch.randn(64, generator=g).to(dev)
+    att = torch.rand(Bt * N, generator=g).to(dev)
+    a_ref = torch.softmax(s.double() * scale.double() + shift.double(), dim=1) * att.double()[:, None]
+    a1 = pm.netvlad_assign_rows(s, scale, shift, att)
+    a2, asum = pm.netvlad_assign_rows(s, scale, shift, att, rows_per_cloud=N)
+    assert torch.equal(a1, a2)
+    assert float((a1.double() - a_ref).abs().max()) < 1e-6
+    assert float((asum.double() - a_ref.reshape(Bt, N, 64).sum(1)).abs().max()) < 1e-4
+    # context gate
+    v = torch.randn(22, 256, generator=g).to(dev).requires_grad_()
+    gt = (torch.randn(22, 256, generator=g) * 3).to(dev).requires_grad_()
+    dy = torch.randn(22, 256, generator=g).to(dev)
+    y = T.context_gate(v, gt)
+    y.backward(dy)
+    v2, g2 = v.detach().double().requires_grad_(), gt.detach().double().requires_grad_()
+    y2 = v2 * torch.sigmoid(g2)
+    y2.backward(dy.double())
+    assert float((y.double() - y2).abs().max()) < 1e-6
+    assert float((v.grad.double() - v2.grad).abs().max()) < 1e-6 and float((gt.grad.double() - g2.grad).abs().max()) < 1e-6
