@@ -388,6 +388,29 @@ def test_upsample_linear_shortcut_fused_matches_two_kernels(dev, B, n, l2):
     assert err < 1e-6, err
 
 
+@pytest.mark.parametrize("B,n,m", [(2, 4096, 512), (1, 1001, 125), (3, 514, 64)])
+def test_interp_combine_vs_fp64(dev, B, n, m):
+    """The tail of the commuted concat conv (gather of the coarse product, + partial, epilogue, + residual, optional
+    [xyz | l2_normalize] rows through LDS) against float64 -- also with an odd number of rows (the last wave holds one)."""
+    from dh3d_amd import pm, ops
+    g = torch.Generator().manual_seed(n + m)
+    fine = torch.rand(B, n, 3, generator=g).to(dev)
+    d3, i3 = ops.three_nn(fine, fine[:, :m].contiguous())
+    cw = torch.randn(B, m, 128, generator=g).to(dev)
+    part, res = torch.randn(B, n, 128, generator=g).to(dev), torch.randn(B, n, 128, generator=g).to(dev)
+    pb, sc, sh = torch.randn(128, generator=g).to(dev), (0.5 + torch.rand(128, generator=g)).to(dev), torch.randn(128, generator=g).to(dev)
+    w = 1.0 / d3.double().clamp_min(1e-10); w = w / w.sum(2, keepdim=True)
+    up = (torch.gather(cw.double(), 1, i3.long().reshape(B, -1, 1).expand(-1, -1, 128)).reshape(B, n, 3, 128) * w[..., None]).sum(2)
+    v = torch.relu((up + part.double() + pb.double()) * sc.double() + sh.double()) + res.double()
+    got = pm.interp_combine(cw, i3, d3, partial=part, pre_bias=pb, scale=sc, shift=sh, act=pm.ACT_RELU, residual=res)
+    assert got.shape == (B, n, 128) and float((got.double() - v).abs().max()) < 2e-5
+    got = pm.interp_combine(cw, i3, d3, partial=part, pre_bias=pb, scale=sc, shift=sh, act=pm.ACT_RELU, residual=res,
+                            l2cat=(fine, 1e-8))
+    ref = torch.cat([fine.double(), v * torch.rsqrt(torch.clamp((v * v).sum(2, keepdim=True), min=1e-8))], 2)
+    assert got.shape == (B, n, 131)
+    assert torch.equal(got[:, :, :3], fine) and float((got.double() - ref).abs().max()) < 2e-6
+
+
 @pytest.mark.parametrize("B,n", [(2, 4096), (1, 4100), (3, 5000)])
 def test_interp_head_equals_head_on_upsampled_rows(dev, B, n):
     """The attention head with its wide conv commuted through the 3-NN interpolation == the head run on the
