@@ -137,15 +137,30 @@ def global_head_autograd(model, points, localdesc, lv, bn_training=True, sync_bn
 
     points [Bt,N,3], localdesc [Bt,N,128] (detached backbone output), lv = geometry level dict
     (idx, xyz_s, nbr_s, nn3_dist, nn3_idx).  Returns the un-normalised global descriptor [Bt,256]."""
-    gba = model.global_before_assemble
-    fc, fbn = gba.flexconv_0, gba.flexconv_0_bn
-    feat_s = bb.gather_rows(localdesc, lv["idx"])                                   # [Bt,M,128]
-    x = flex_conv_factorised(feat_s, lv["xyz_s"], lv["nbr_s"], fc.position_theta, fc.position_bias)
-    x = x + fc.feature_bias.reshape(1, 1, -1)                                       # layers.py:330-331
-    new_feat = F.relu(_bn(x, 2, fbn, bn_training, sync_bn, mask)).contiguous()      # tf_utils.py:60-63; [Bt,M,256]
-    d = torch.clamp(lv["nn3_dist"], min=1e-10)                                      # backbones.py:92-95
-    w = (1.0 / d) / (1.0 / d).sum(2, keepdim=True)
-    forglobal = ops.three_interpolate(new_feat, lv["nn3_idx"], w.contiguous())      # [Bt,N,256]
+    if getattr(model, "global_conv1d", False):
+        # core/backbones.py:189-197: 1x1 conv + BNReLU on the full-resolution descriptors (only the last conv of the
+        # loop reaches the output)
+        conv = model._global_front()[-1]
+        h = localdesc @ conv.W.reshape(conv.cin, conv.cout) + conv.b
+        forglobal = F.relu(_bn(h, 2, conv.bn, bn_training, sync_bn, mask)).contiguous()
+    else:
+        gba = model.global_before_assemble
+        fc, fbn = gba.flexconv_0, gba.flexconv_0_bn
+        feat_s = bb.gather_rows(localdesc, lv["idx"])                                   # [Bt,M,128]
+        if model.config.concat_xyz:
+            # core/backbones.py:180-181: [xyz | descriptors] into the flex_conv -- here literally, through the drop-in
+            # operator in the reference's channels-first layout (any channel count)
+            xin = torch.cat([lv["xyz_s"], feat_s], 2).transpose(1, 2).contiguous()      # [Bt,131,M]
+            x = ops.flex_convolution(xin, lv["xyz_s"].transpose(1, 2).contiguous(),
+                                     lv["nbr_s"].transpose(1, 2).contiguous(), fc.position_theta,
+                                     fc.position_bias).transpose(1, 2)
+        else:
+            x = flex_conv_factorised(feat_s, lv["xyz_s"], lv["nbr_s"], fc.position_theta, fc.position_bias)
+        x = x + fc.feature_bias.reshape(1, 1, -1)                                       # layers.py:330-331
+        new_feat = F.relu(_bn(x, 2, fbn, bn_training, sync_bn, mask)).contiguous()      # tf_utils.py:60-63; [Bt,M,256]
+        d = torch.clamp(lv["nn3_dist"], min=1e-10)                                      # backbones.py:92-95
+        w = (1.0 / d) / (1.0 / d).sum(2, keepdim=True)
+        forglobal = ops.three_interpolate(new_feat, lv["nn3_idx"], w.contiguous())      # [Bt,N,256]
 
     att_mod = model.globalatt
     h = forglobal
@@ -183,13 +198,37 @@ def global_head_hip(model, points, localdesc, lv, sync_bn=False, mask=None, comm
     global_head_autograd(bn_training=True), which is kept as the plain-torch reference the tests compare with."""
     from . import train_ops as T
     gba, att_mod, nv = model.global_before_assemble, model.globalatt, model._netvlad
-    if len(att_mod.conv_dims) != 1 or len(gba.outdims) != 1 or not (nv.add_batch_norm and nv.gating):
+    conv1d = getattr(model, "global_conv1d", False)
+    if (len(att_mod.conv_dims) != 1 or (not conv1d and len(gba.outdims) != 1) or not (nv.add_batch_norm and nv.gating)):
         return global_head_autograd(model, points, localdesc, lv, True, sync_bn, mask)
-    fc, fbn = gba.flexconv_0, gba.flexconv_0_bn
     Bt, N = points.shape[0], points.shape[1]
+    if conv1d:
+        # global_before_assemble_conv1d (core/backbones.py:189-197): no sampled level, no interpolation -- a 1x1 conv +
+        # BNReLU on the full-resolution rows, the attention head on the materialised rows, NetVLAD as below
+        conv = model._global_front()[-1]
+        h = T.linear(localdesc.reshape(Bt * N, conv.cin), conv.W.reshape(conv.cin, conv.cout), conv.b)
+        forglobal = T.batch_norm_train(h, conv.bn, True, sync_bn, mask, N).reshape(Bt, N, conv.cout)
+        fcw = att_mod.detec_conv_fc
+        att = T.attention_head(forglobal.reshape(Bt * N, conv.cout), att_mod.detec_conv0, fcw.W, fcw.b, sync_bn, mask, N)
+        return _netvlad_tail_hip(T, nv, forglobal, att, sync_bn, mask)
+    fc, fbn = gba.flexconv_0, gba.flexconv_0_bn
     M = lv["xyz_s"].shape[1]
     feat_s = bb.gather_rows(localdesc, lv["idx"])                                   # [Bt,M,128]
-    x = flex_conv_factorised(feat_s, lv["xyz_s"], lv["nbr_s"], fc.position_theta, fc.position_bias)
+    if model.config.concat_xyz:
+        # [xyz | descriptors] input (core/backbones.py:180-181): flex_conv is linear in its input channels, so it is the
+        # factorised kernel on the 128 descriptor channels plus the same kernel on the coordinates padded to that
+        # width (zero weights in the padding -- the inference path's split, backbones.FlexConvDilate.prepare); the
+        # slices / concatenations are autograd's, so position_theta / position_bias receive their whole gradient
+        theta, bias = fc.position_theta, fc.position_bias
+        cf = theta.shape[1] - 3
+        xp = torch.zeros((Bt, M, cf), dtype=torch.float32, device=points.device)
+        xp[:, :, :3] = lv["xyz_s"]
+        tx = torch.cat([theta[:, :3], theta.new_zeros((3, cf - 3, theta.shape[2]))], 1)
+        bx = torch.cat([bias[:3], bias.new_zeros((cf - 3, bias.shape[1]))], 0)
+        x = (flex_conv_factorised(feat_s, lv["xyz_s"], lv["nbr_s"], theta[:, 3:].contiguous(), bias[3:].contiguous())
+             + flex_conv_factorised(xp, lv["xyz_s"], lv["nbr_s"], tx, bx))
+    else:
+        x = flex_conv_factorised(feat_s, lv["xyz_s"], lv["nbr_s"], fc.position_theta, fc.position_bias)
     x = x + fc.feature_bias.reshape(1, 1, -1)                                       # layers.py:330-331
     Dg = x.shape[2]
     new_feat = T.batch_norm_train(x.reshape(Bt * M, Dg), fbn, True, sync_bn, mask, M).reshape(Bt, M, Dg)
@@ -211,6 +250,13 @@ def global_head_hip(model, points, localdesc, lv, sync_bn=False, mask=None, comm
                                         lv["nn3_dist"], order, sync_bn, mask)
     else:
         att = T.attention_head(forglobal.reshape(Bt * N, Dg), att_mod.detec_conv0, fcw.W, fcw.b, sync_bn, mask, N)
+    return _netvlad_tail_hip(T, nv, forglobal, att, sync_bn, mask)
+
+
+def _netvlad_tail_hip(T, nv, forglobal, att, sync_bn, mask):
+    """NetVLAD + context gating of the training step on HIP nodes (core/backbones.py:202-279): forglobal [Bt,N,D] rows,
+    att [Bt*N] -> [Bt, 256]."""
+    Bt, Dg = forglobal.shape[0], forglobal.shape[2]
     V, asum = T.netvlad_assign(forglobal, att, nv.cluster_weights, nv.cluster_bn, sync_bn, mask)   # [Bt,C,D], [Bt,C]
     if T.vlad_normalize_supported(V):
         vlad = T.vlad_normalize(V, asum, nv.cluster_weights2)                       # [Bt, D*C]  (backbones.py:241-262)
@@ -225,12 +271,11 @@ def global_head_hip(model, points, localdesc, lv, sync_bn=False, mask=None, comm
 
 
 def trainable_head_parameters(model):
-    """Parameters that global_config trains (backbone frozen: configs.py:112-113)."""
-    if getattr(model, "global_conv1d", False) or model.config.concat_xyz:
-        raise NotImplementedError("training with global_backbone='global_before_assemble_conv1d' or concat_xyz=True is "
-                                  "not built (the shipped global_config trains 'global_before_assemble' on the "
-                                  "descriptors alone)")
-    mods = [model.global_before_assemble, model.globalatt, model._netvlad]
+    """Parameters that global_config trains (backbone frozen: configs.py:112-113).  With
+    global_before_assemble_conv1d only the LAST conv of the loop reaches the descriptor (core/backbones.py:189-197: every
+    conv reads localdesc), so only it has a gradient."""
+    front = model._global_front()[-1:] if getattr(model, "global_conv1d", False) else [model.global_before_assemble]
+    mods = front + [model.globalatt, model._netvlad]
     seen, out = set(), []
     for mod in mods:
         for p in mod.parameters():

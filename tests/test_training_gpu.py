@@ -543,3 +543,62 @@ def test_small_fused_training_ops(dev):
     y2.backward(dy.double())
     assert float((y.double() - y2).abs().max()) < 1e-6
     assert float((v.grad.double() - v2.grad).abs().max()) < 1e-6 and float((gt.grad.double() - g2.grad).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("variant", ["conv1d", "concat_xyz"])
+def test_hip_head_trains_the_other_global_front_ends(dev, variant):
+    """global_backbone='global_before_assemble_conv1d' (core/backbones.py:189-197) and concat_xyz=True (:180-181) under
+    the HIP training head: forward, gradients of every trainable parameter and running statistics against the torch
+    head (which runs concat_xyz literally -- 131 input channels through the drop-in flex_convolution)."""
+    from dh3d_amd import ConfigFactory
+    from dh3d_amd.model import DH3D
+    from dh3d_amd.training import global_head_hip, global_head_autograd, trainable_head_parameters, QuadrupletTrainer
+    res = []
+    for impl in (global_head_hip, global_head_autograd):
+        cfg = ConfigFactory("global_config").getconfig()
+        cfg.batch_size, cfg.num_pos, cfg.num_neg = 1, 2, 3
+        if variant == "conv1d":
+            cfg.global_backbone = "global_before_assemble_conv1d"
+        else:
+            cfg.concat_xyz = True
+        m = DH3D(cfg).init_synthetic(21).to(dev).eval().prepare()
+        pts = torch.rand(3, 1024, 3, generator=torch.Generator().manual_seed(6)).to(dev)
+        with torch.no_grad():
+            geo = m._geometry(pts, None)
+            _, local = m.compute_local(pts, _geo=geo)
+            lv = geo.level(8, 8)
+            m._join_side(geo)
+        if impl is global_head_hip:
+            desc = impl(m, pts, local.detach(), lv, sync_bn=False, mask=None)
+        else:
+            desc = impl(m, pts, local.detach(), lv, bn_training=True, sync_bn=False, mask=None)
+        wgt = torch.randn(desc.shape, generator=torch.Generator().manual_seed(9)).to(dev)
+        (desc * wgt).sum().backward()
+        params = trainable_head_parameters(m)
+        assert all(p.grad is not None for p in params)
+        byid = {id(p): n for n, p in m.named_parameters()}
+        res.append((desc.detach(), [p.grad.clone() for p in params], {k: v.clone() for k, v in m.named_buffers()},
+                    [byid[id(p)] for p in params]))
+    (d0, g0, b0, names), (d1, g1, b1, _) = res
+    assert float((d0 - d1).abs().max()) <= 1e-4 * float(d1.abs().max())
+    gmax = max(float(b.abs().max()) for b in g1)
+    for n, a, b in zip(names, g0, g1):
+        err, ref = float((a - b).abs().max()), float(b.abs().max())
+        if n.endswith(("feature_bias", ".b")) and not n.endswith("detec_conv_fc.b"):
+            # a bias in front of a BatchNorm: its gradient is exactly zero in theory, both sides hold rounding noise of
+            # their own summation order there (column sums of a batch-norm backward)
+            assert float(a.abs().max()) <= 1e-3 * gmax and ref <= 1e-3 * gmax, (n, float(a.abs().max()), ref, gmax)
+            continue
+        # (the two sides round the front end differently -- concat_xyz: one 131-channel convolution against the split
+        #  factorised pair -- and three chained batch norms over a few hundred rows amplify that: entries within 5 % of
+        #  the largest one, the tensor within 2 % in norm; a wrong slice or a missing term would be O(1))
+        nerr = float((a - b).norm()) / (float(b.norm()) + 1e-12)
+        assert err <= 5e-2 * ref + 1e-6 and nerr <= 2e-2, (n, err, ref, nerr)
+    for k in b0:
+        assert torch.allclose(b0[k], b1[k], rtol=1e-4, atol=1e-5), k
+    # and a whole trainer step runs on it
+    cfg.num_points = 1024
+    tr = QuadrupletTrainer(m, graph_step=False)
+    batch = torch.rand(1 + 2 + 3 + 1, 1024, 3, generator=torch.Generator().manual_seed(2)).to(dev)
+    l0 = tr.step(batch)
+    assert l0 == l0 and l0 >= 0.0
