@@ -127,3 +127,13 @@ def test_all_gather_world_size_2_gloo(tmp_path):
                        env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()  # (stdout of 2 ranks interleaves)
+
+
+def test_commuted_netvlad_training_algebra():
+    """The rewrite planned for NetVLAD's training rows: sampled-row GEMMs + 64-wide per-point values
+    reproduce autograd's V, asum and every gradient of the straightforward graph (float64, CPU)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "netvlad_commute_check.py")], capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
