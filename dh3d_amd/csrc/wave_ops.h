@@ -19,6 +19,15 @@
   "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"    \
   "s_nop 1\n\t"
 
+// The same chains on a NAMED asm operand (for hand-written loops): wave result in lane 63 of %[R].
+#define DH3D_DPP_WAVE_N(OP, R)                                                                   \
+  "s_nop 1\n\t" OP " %[" R "], %[" R "], %[" R "] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+  "s_nop 1\n\t" OP " %[" R "], %[" R "], %[" R "] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+  "s_nop 1\n\t" OP " %[" R "], %[" R "], %[" R "] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"     \
+  "s_nop 1\n\t" OP " %[" R "], %[" R "], %[" R "] row_mirror row_mask:0xf bank_mask:0xf\n\t"          \
+  "s_nop 1\n\t" OP " %[" R "], %[" R "], %[" R "] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"        \
+  "s_nop 1\n\t" OP " %[" R "], %[" R "], %[" R "] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+
 // max / min over each 16-lane row, result in every lane of the row
 __device__ __forceinline__ float row16_max_f32(float v) {
   asm volatile(DH3D_DPP_ROW16("v_max_f32_dpp") "s_nop 1\n\t" : "+v"(v));
