@@ -28,34 +28,14 @@ namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// LDS words that waves hand to one another WITHOUT a barrier (fps_stream_kernel): volatile accesses in the LDS address
-// space.  (A volatile access through a generic pointer is compiled to flat_load/flat_store sc0 sc1 + s_waitcnt vmcnt(0)
-// -- correct, and several times slower than the ds_read/ds_write it should be.)
-#define DH3D_LDS __attribute__((address_space(3)))
-__device__ __forceinline__ int lds_vload(const int *p) { return *(const volatile DH3D_LDS int *)p; }
-__device__ __forceinline__ float lds_vloadf(const float *p) { return *(const volatile DH3D_LDS float *)p; }
-__device__ __forceinline__ f32x2 lds_vload2(const f32x2 *p) { return *(const volatile DH3D_LDS f32x2 *)p; }
-__device__ __forceinline__ f32x4 lds_vload4(const f32x4 *p) { return *(const volatile DH3D_LDS f32x4 *)p; }
-__device__ __forceinline__ void lds_vstore(int *p, int v) { *(volatile DH3D_LDS int *)p = v; }
-__device__ __forceinline__ void lds_vstoref(float *p, float v) { *(volatile DH3D_LDS float *)p = v; }
-__device__ __forceinline__ void lds_vstore2(f32x2 *p, f32x2 v) { *(volatile DH3D_LDS f32x2 *)p = v; }
-__device__ __forceinline__ void lds_vstore4(f32x4 *p, f32x4 v) { *(volatile DH3D_LDS f32x4 *)p = v; }
-
-
-#ifdef DH3D_FPS_PROBE  // dev instrumentation: cycle stamps of one round of wave 0 (tools/fps_probe.py)
+#ifdef DH3D_FPS_PROBE  // dev instrumentation (tools/fps_list_phases.py): per-phase cycle sums of one wave of cloud 0
 __device__ long long g_probe[32];
-__device__ unsigned long long g_fps_cnt[2];  // ordered kernel: active (wave, round) pairs, updated groups
-#define PROBE(i) do { if (r == 300 && tid == 0 && blockIdx.x == 0) g_probe[i] = clock64(); } while (0)
-// batched kernel: per-phase cycle sums of one wave of cloud 0 (DH3D_FPS_PROBE_WAVE, default 0)
 #ifndef DH3D_FPS_PROBE_WAVE
 #define DH3D_FPS_PROBE_WAVE 0
 #endif
 #define STAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); pt[i] = clock64(); } while (0)
-#define ASTAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); at[i] = clock64(); } while (0)
 #else
-#define PROBE(i) do { } while (0)
 #define STAMP(i) do { } while (0)
-#define ASTAMP(i) do { } while (0)
 #endif
 
 __device__ __forceinline__ int fps_key(int k) { return ((k & 511) << 16) | (k >> 9); }
@@ -121,15 +101,10 @@ __global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float *__restrict
   int old = 0;
   int buf = 1;  // slot of round r is r % 3
   for (int r = 1; r < m; ++r) {
-    PROBE(0);
     float x1, y1, z1;
     if (LDS_COORDS) { x1 = s_x[old]; y1 = s_y[old]; z1 = s_z[old]; }
     else { x1 = pc[(size_t)old * 3]; y1 = pc[(size_t)old * 3 + 1]; z1 = pc[(size_t)old * 3 + 2]; }
     const f32x2 x2 = {x1, x1}, y2 = {y1, y1}, z2 = {z1, z1};
-#ifdef DH3D_FPS_PROBE
-    asm volatile("" :: "v"(x1), "v"(y1), "v"(z1));
-#endif
-    PROBE(1);
     // running min-distance update (two points per packed op) + the lane's best VALUE only
     float best = -1.f;
 #pragma unroll
@@ -140,9 +115,7 @@ __global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float *__restrict
       md[p][1] = vmin(d[1], md[p][1]);
       best = vmax3(best, md[p][0], md[p][1]);
     }
-    PROBE(2);
     const float wmax = wave_max_f32(best);
-    PROBE(3);
     // smallest key among the lane's points that hold wmax
     int lkey = INT_MAX;
 #pragma unroll
@@ -154,7 +127,6 @@ __global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float *__restrict
     int wkey;
     if (__popcll(hit) == 1) wkey = __builtin_amdgcn_readlane(lkey, __builtin_ctzll(hit));
     else wkey = wave_min_i32(lkey);  // several lanes tie: smallest key wins (non-hit lanes hold INT_MAX)
-    PROBE(4);
     if (lane == 0) {
       const unsigned long long packed =
           wmax >= 0.f ? (((unsigned long long)__float_as_uint(wmax) << 32) | (unsigned)~wkey) : 0ull;
@@ -162,10 +134,8 @@ __global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float *__restrict
       if (wave == 0) s_best[buf == 2 ? 0 : buf + 1] = 0ull;  // next round's slot (last read two rounds ago)
     }
     __syncthreads();
-    PROBE(5);
     const int bkey = ~(int)(unsigned)s_best[buf];
     old = fps_unkey(bkey);
-    PROBE(6);
     if (tid == 0) { if (LDS_COORDS) s_out[r] = old; else out[(size_t)b * m + r] = old; }
     buf = buf == 2 ? 0 : buf + 1;
   }
@@ -176,409 +146,32 @@ __global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// FPS on a spatially ordered cloud (spatial.hip).  Same results, far less work per round.
+// FPS on a spatially ordered cloud (spatial.hip): candidate LISTS + a sequential judge, ~10 picks per
+// synchronisation, same picks as the sequential rule.
 //
-// Wave w owns the Morton-consecutive groups [w*PPT, (w+1)*PPT) (64 points each: a compact region of the
-// cloud); lane l holds point l of each of them.  A point's running min-distance can only drop if the new sample
-// is closer to it than that distance, hence -- for a whole group -- only if the sample is closer to the group's
-// bounding box than the largest min-distance in the wave.  Per round every wave
-//   1. tests its PPT boxes in parallel (lane j <-> group j: ~12 VALU ops + one ballot) against its cached maximum;
-//   2. if nothing can change, re-offers its cached (max, key) -- no update, no reduction;
-//   3. otherwise updates just the hit groups (one point per lane each) and redoes ONE wave arg-max.
-// After the first few dozen samples a round touches one or two waves instead of all N points; the others spend
-// ~40 instructions.  (A first version cached a maximum per GROUP and reduced once per hit group: the
-// reductions serialised and it was no faster than the plain kernel.)
-// The skip test carries a 1e-5 relative margin: it may keep a group that cannot change, never the reverse.
-template <int PPT, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void fps_sorted_kernel(const float4 *__restrict__ sorted,
-                                                              const float *__restrict__ gbox, int N, int m,
-                                                              int32_t *__restrict__ out) {
-  static_assert(PPT <= 64, "one lane per group box");
-  extern __shared__ __attribute__((aligned(16))) float s_mem[];
-  // 3 rotating u64 block-best slots (as fps_kernel) | coordinates by ORIGINAL index | picks
-  // (Publishing each wave's candidate coordinates in a per-wave slot and selecting the winner's with v_readlane
-  //  -- to save the dependent table lookup -- measured SLOWER: 0.40 vs 0.36 ms of pure sync chain at 8 waves.)
-  unsigned long long *s_best = reinterpret_cast<unsigned long long *>(s_mem);
-  float *s_x = s_mem + 4 * WAVES;
-  float *s_y = s_x + N;
-  float *s_z = s_y + N;
-  int *s_out = reinterpret_cast<int *>(s_z + N);  // picks, written to global memory once at the end
-
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int NG = (N + 63) / 64;
-  const float4 *sc = sorted + (size_t)b * N;
-
-  float px[PPT], py[PPT], pz[PPT], md[PPT];
-  int pkey[PPT];
-#pragma unroll
-  for (int j = 0; j < PPT; ++j) {
-    const int i = (wave * PPT + j) * 64 + lane;
-    px[j] = py[j] = pz[j] = 0.f;
-    md[j] = -2.f;  // padding: below the reference's initial best = -1, never picked
-    pkey[j] = INT_MAX;
-    if (i < N) {
-      const float4 r = sc[i];
-      const int k = __float_as_int(r.w);
-      px[j] = r.x; py[j] = r.y; pz[j] = r.z;
-      md[j] = 1e38f;
-      pkey[j] = fps_key(k);
-      s_x[k] = r.x; s_y[k] = r.y; s_z[k] = r.z;
-    }
-  }
-  // lane j < PPT: bounding box of this wave's group j
-  float blx = INFINITY, bly = INFINITY, blz = INFINITY, bhx = -INFINITY, bhy = -INFINITY, bhz = -INFINITY;
-  bool has_box = false;
-  if (lane < PPT) {
-    const int g = wave * PPT + lane;
-    if (g < NG) {
-      const float *bx = gbox + ((size_t)b * NG + g) * 8;
-      blx = bx[0]; bly = bx[1]; blz = bx[2]; bhx = bx[4]; bhy = bx[5]; bhz = bx[6];
-      has_box = true;
-    }
-  }
-  if (tid == 0) s_out[0] = 0;
-  if (tid < 3) s_best[tid] = 0ull;
-  __syncthreads();
-
-  // cached wave maximum (uniform): 1e38 makes the first round update everything; a wave of pure padding
-  // offers nothing
-  float wmax = __ballot(has_box) != 0ull ? 1e38f : -2.f;
-  int wkey = INT_MAX;
-  int old = 0;
-  int buf = 1;  // slot of round r is r % 3
-  for (int r = 1; r < m; ++r) {
-    const float x1 = s_x[old], y1 = s_y[old], z1 = s_z[old];
-    // 1. which of my groups can change?  squared distance from the sample to each box (0 inside)
-    const float ex = fmaxf(fmaxf(blx - x1, x1 - bhx), 0.f);
-    const float ey = fmaxf(fmaxf(bly - y1, y1 - bhy), 0.f);
-    const float ez = fmaxf(fmaxf(blz - z1, z1 - bhz), 0.f);
-    const float bd = (ex * ex + ey * ey + ez * ez) * 0.99999f;
-    const unsigned long long need = __ballot(has_box && bd <= wmax);
-#if defined(DH3D_FPS_PROBE) && DH3D_FPS_PROBE == 1
-    if (lane == 0 && need != 0ull) { atomicAdd(&g_fps_cnt[0], 1ull); atomicAdd(&g_fps_cnt[1], (unsigned long long)__popcll(need)); }
-#endif
-#if defined(DH3D_FPS_PROBE) && DH3D_FPS_PROBE == 2  // timing experiment: sync chain only (results wrong)
-    if (need != 0ull && r < 4) {
-#else
-    if (need != 0ull) {  // wave-uniform
-#endif
-      // 2. update the hit groups, then one wave arg-max over everything the wave holds
-#pragma unroll
-      for (int j = 0; j < PPT; ++j) {
-        if ((need >> j) & 1ull) {
-          const float dx = px[j] - x1, dy = py[j] - y1, dz = pz[j] - z1;
-          const float d = __fmaf_rn(dz, dz, __fmaf_rn(dx, dx, __fmul_rn(dy, dy)));
-          md[j] = vmin(d, md[j]);
-        }
-      }
-      float best = -2.f;
-#pragma unroll
-      for (int j = 0; j + 1 < PPT; j += 2) best = vmax3(best, md[j], md[j + 1]);
-      if (PPT & 1) best = fmaxf(best, md[PPT - 1]);
-      wmax = wave_max_f32(best);
-      int lkey = INT_MAX;  // smallest key among the lane's points that hold wmax
-#pragma unroll
-      for (int j = 0; j < PPT; ++j) lkey = (md[j] == wmax) ? min(lkey, pkey[j]) : lkey;
-      const unsigned long long hit = __ballot(best == wmax);
-      if (__popcll(hit) == 1) wkey = __builtin_amdgcn_readlane(lkey, __builtin_ctzll(hit));
-      else wkey = wave_min_i32(lkey);  // several lanes tie: smallest key wins (non-hit lanes hold INT_MAX)
-    }
-    // 3. block arg-max: one 64-bit LDS atomic max per wave on (bits(value) << 32 | ~key)
-    if (lane == 0) {
-      const unsigned long long packed =
-          wmax >= 0.f ? (((unsigned long long)__float_as_uint(wmax) << 32) | (unsigned)~wkey) : 0ull;
-      atomicMax(&s_best[buf], packed);
-      if (wave == 0) s_best[buf == 2 ? 0 : buf + 1] = 0ull;  // next round's slot (last read two rounds ago)
-    }
-    __syncthreads();
-    const int bkey = ~(int)(unsigned)s_best[buf];
-    old = fps_unkey(bkey);
-    if (tid == 0) s_out[r] = old;
-    buf = buf == 2 ? 0 : buf + 1;
-  }
-  __syncthreads();
-  for (int r = tid; r < m; r += 64 * WAVES) out[(size_t)b * m + r] = s_out[r];
-}
-
-// ------------------------------------------------------------------------------------------------
-// Batched rounds on the ordered cloud: several picks per synchronisation, same picks as the sequential rule.
+// Wave w owns the Morton-consecutive groups [w*PPT, (w+1)*PPT) (64 points each: a compact region of the cloud); lane l
+// holds point l of each of them, coordinates and running min-distance in registers.  A point's distance can only drop
+// if the new sample is closer to it than that distance, hence -- for a whole group -- only if the sample is closer to
+// the group's bounding box than the largest distance in the wave: box tests (lane = pick * PPT + box, several picks
+// per pass) decide which waves update at all.  (Rounds 1-2: one pick per barrier, 0.68 ms for 8 x 8192 -> 1024; then
+// one published candidate per wave judged pairwise, 3.7 picks per sync, 0.39 ms.)
 //
-// What bounds fps_sorted_kernel is not its arithmetic but the barrier + LDS chain of a round.  FPS picks are far
-// apart by construction, so consecutive picks rarely interact: after a sync every wave holds the arg-max c_w of
-// its region (value v_w, tie key) and the second-largest value s_w in the region.  Order the candidates by
-// (value, key).  The j-th candidate IS the j-th next pick of the sequential algorithm if no higher-ranked
-// candidate c_p (a) lowers its distance (d(c_p, c_j) < v_j, computed with the update's own arithmetic) or
-// (b) leaves a better point behind in its region (s_p >= v_j); everything else can only have dropped.  Each wave
-// judges its OWN candidate against the 16 published ones (16 lanes, ~10 VALU), the first bad rank is an LDS
-// atomicMin, and all candidates ranked before it are taken at once: ~3.7 picks per sync on uniform clouds
-// (tools/fps_batch_sim.py).  Two barriers per sync instead of one per pick; the box tests of up to 64/PPT picks
-// against the wave's PPT boxes run in ONE pass (lane = pick * PPT + box).
-// TABLE: the by-original-index coordinate table lives in LDS (12 B per point: clouds of up to ~12 k points).  Larger
-// clouds (TABLE = false) read the winner's coordinates from the cloud itself (`xyz`, L2-resident) instead -- one global
-// round trip on the active wave's chain per sync, still far ahead of the one-pick-per-round kernel at 16384 points.
-template <int PPT, int WAVES, bool TABLE>
-__global__ __launch_bounds__(64 * WAVES) void fps_batched_kernel(const float4 *__restrict__ sorted,
-                                                               const float *__restrict__ gbox, int N, int m,
-                                                               int32_t *__restrict__ out,
-                                                               float *__restrict__ xyz_out,
-                                                               const float *__restrict__ xyz) {
-  static_assert(PPT <= 64 && WAVES <= 16, "one lane per group box, one lane per candidate");
-  constexpr int CAP0 = PPT <= 32 ? 64 / PPT : 1;
-  constexpr int CAP = CAP0 < WAVES ? CAP0 : WAVES;  // picks per sync
-  constexpr int NP = (PPT + 1) / 2;                 // groups are held and updated in pairs (packed f32)
-  constexpr int JW = WAVES < 4 ? WAVES : 4;         // judging waves (one per SIMD), CPJ candidates each
-  constexpr int CPJ = (WAVES + JW - 1) / JW;
-  constexpr int kBig = 1 << 20;
-  extern __shared__ __attribute__((aligned(16))) float s_mem[];
-  // candidates [WAVES][8]: key lo, key hi, second value, x | y, z, index, -   | picks [16] x,y,z,index | stop[4]
-  float4 *s_ent = reinterpret_cast<float4 *>(s_mem);
-  float4 *s_pick = s_ent + 2 * WAVES;
-  int *s_jthr = reinterpret_cast<int *>(s_pick + 16);  // per judging wave: first rank it holds back
-  float *s_x = reinterpret_cast<float *>(s_jthr + 4);
-  float *s_y = s_x + (TABLE ? N : 0);
-  float *s_z = s_y + (TABLE ? N : 0);
-  int *s_out = reinterpret_cast<int *>(s_z + (TABLE ? N : 0));
-  const float *pc = TABLE ? nullptr : xyz + (size_t)blockIdx.x * N * 3;
-
-  // the kernel is a dependent chain on 1 CU per cloud while the rest of the step shares the chip: its waves go first
-  __builtin_amdgcn_s_setprio(3);
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int NG = (N + 63) / 64;
-  const float4 *sc = sorted + (size_t)b * N;
-
-  f32x2 px[NP], py[NP], pz[NP], md[NP];
-  int pkey[2 * NP];
-#pragma unroll
-  for (int j = 0; j < 2 * NP; ++j) {
-    const int i = (wave * PPT + j) * 64 + lane;
-    float x = 0.f, y = 0.f, z = 0.f, d = -2.f;  // padding: below the reference's initial best = -1, never picked
-    pkey[j] = INT_MAX;
-    if (j < PPT && i < N) {
-      const float4 r = sc[i];
-      const int k = __float_as_int(r.w);
-      x = r.x; y = r.y; z = r.z;
-      d = 1e38f;
-      pkey[j] = fps_key(k);
-      if (TABLE) { s_x[k] = r.x; s_y[k] = r.y; s_z[k] = r.z; }
-    }
-    px[j >> 1][j & 1] = x; py[j >> 1][j & 1] = y; pz[j >> 1][j & 1] = z; md[j >> 1][j & 1] = d;
-  }
-  // lane = pick * PPT + box: every pick slot sees the wave's PPT boxes
-  const int bl = lane % PPT, pk = lane / PPT;
-  float blx = INFINITY, bly = INFINITY, blz = INFINITY, bhx = -INFINITY, bhy = -INFINITY, bhz = -INFINITY;
-  bool has_box = false;
-  if (pk < CAP) {
-    const int g = wave * PPT + bl;
-    if (g < NG) {
-      const float *bx = gbox + ((size_t)b * NG + g) * 8;
-      blx = bx[0]; bly = bx[1]; blz = bx[2]; bhx = bx[4]; bhy = bx[5]; bhz = bx[6];
-      has_box = true;
-    }
-  }
-  if (tid == 0) s_out[0] = 0;
-  if (tid < 4) s_jthr[tid] = kBig;
-  if (lane < 2) s_ent[2 * wave + lane] = make_float4(0.f, 0.f, -2.f, 0.f);  // key 0 = nothing to offer
-  __syncthreads();
-
-  // A wave executes ~1 instruction per 4.6 cycles whatever its kind (tools/fps_exp.py: the loop below is bound by the
-  // instruction count along the chain barrier -> judge -> barrier -> box test -> update -> arg-max, not by data), so
-  // every phase is written for few instructions: no per-group branches, no atomics, nothing recomputed.
-  float wmax = __ballot(has_box) != 0ull ? 1e38f : -2.f;  // cached wave maximum (uniform)
-  float qx, qy, qz;                                         // lane (pk, .): coordinates of pick pk of this sync
-  if (TABLE) { qx = s_x[0]; qy = s_y[0]; qz = s_z[0]; }
-  else { qx = pc[0]; qy = pc[1]; qz = pc[2]; }
-  int npick = 1, r = 1;
-#ifdef DH3D_FPS_PROBE
-  long long pt[12], at[8];
-#endif
-  constexpr unsigned long long kPickMask = PPT == 64 ? ~0ull : ((1ull << (PPT & 63)) - 1ull);
-  while (true) {
-    STAMP(0);
-    // 1. every (pick, box) pair at once: can the pick change anything in the group?
-    const float ex = fmaxf(fmaxf(blx - qx, qx - bhx), 0.f);
-    const float ey = fmaxf(fmaxf(bly - qy, qy - bhy), 0.f);
-    const float ez = fmaxf(fmaxf(blz - qz, qz - bhz), 0.f);
-    const float bd = (ex * ex + ey * ey + ez * ez) * 0.99999f;
-    const unsigned long long need = __ballot(has_box && pk < npick && bd <= wmax);
-    STAMP(1);
-#if defined(DH3D_FPS_EXP) && (DH3D_FPS_EXP & 1)  // timing experiment: sync chain only (results wrong)
-    if (need != 0ull && r < 8) {
-#else
-    if (need != 0ull) {  // wave-uniform
-#endif
-      unsigned long long nd = need;
-#if defined(DH3D_FPS_EXP) && (DH3D_FPS_EXP & 4)
-      if (r < 8)
-#endif
-      do {  // the picks that reach this wave
-        const int p = __builtin_ctzll(nd) / PPT;
-        const unsigned long long nb = (nd >> (p * PPT)) & kPickMask;
-        nd &= ~(kPickMask << (p * PPT));
-        const float x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), p * PPT));
-        const float y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy), p * PPT));
-        const float z1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz), p * PPT));
-        const f32x2 x2 = {x1, x1}, y2 = {y1, y1}, z2 = {z1, z1};
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-          // small waves: all groups, branch-free (an update that was not needed is harmless and a skipped pair
-          // would cost as many scalar instructions as it saves vector ones); large ones: the hit pairs only
-          if (PPT <= 8 || ((nb >> (2 * q)) & 3ull)) {
-            const f32x2 dx = px[q] - x2, dy = py[q] - y2, dz = pz[q] - z2;
-            const f32x2 d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
-            md[q][0] = __builtin_fminf(d[0], md[q][0]);
-            md[q][1] = __builtin_fminf(d[1], md[q][1]);
-          }
-        }
-      } while (nd != 0ull);
-      ASTAMP(0);
-#if defined(DH3D_FPS_EXP) && (DH3D_FPS_EXP & 8)
-      if (r < 8) {
-#else
-      {
-#endif
-      // one wave arg-max (+ runner-up value) over everything the wave holds
-      // (the key of each lane's first maximum rides along: a separate pass of compares after the wave maximum is
-      //  known costs ~270 cycles of chain, this ~40)
-      float b1 = -2.f, b2 = -2.f;
-      int lkey = INT_MAX;
-#pragma unroll
-      for (int j = 0; j < 2 * NP; ++j) {
-        const float x = md[j >> 1][j & 1];
-        lkey = x > b1 ? pkey[j] : lkey;
-        b2 = __builtin_amdgcn_fmed3f(b1, b2, x);
-        b1 = __builtin_fmaxf(b1, x);
-      }
-      asm volatile("" :: "v"(b1), "v"(b2));
-      ASTAMP(1);
-      wmax = wave_max_f32(b1);
-      ASTAMP(2);
-      const unsigned long long hit = __ballot(b1 == wmax);
-      int wl = __builtin_ctzll(hit);  // winner lane
-      float wsec = wave_max_f32(lane == wl ? b2 : b1);  // runner-up (redone below if wl changes)
-      ASTAMP(3);
-      int wkey;
-      if (__popcll(hit) == 1 && __ballot(b2 == wmax) == 0ull) {  // one point holds the maximum
-        wkey = __builtin_amdgcn_readlane(lkey, wl);
-      } else {  // ties: the smallest key wins
-        lkey = INT_MAX;
-#pragma unroll
-        for (int j = 0; j < 2 * NP; ++j) lkey = (md[j >> 1][j & 1] == wmax) ? min(lkey, pkey[j]) : lkey;
-        wkey = wave_min_i32(lkey);
-        wl = __builtin_ctzll(__ballot(lkey == wkey));
-        wsec = wave_max_f32(lane == wl ? b2 : b1);
-      }
-      ASTAMP(4);
-      const int widx = fps_unkey(wkey);
-      float wx, wy, wz;
-      if (TABLE) { wx = s_x[widx]; wy = s_y[widx]; wz = s_z[widx]; }
-      else { wx = pc[(size_t)widx * 3]; wy = pc[(size_t)widx * 3 + 1]; wz = pc[(size_t)widx * 3 + 2]; }
-      ASTAMP(5);
-      // publish the candidate (an untouched wave's entry stays valid)
-      if (lane == 0) {
-        s_ent[2 * wave] = make_float4(__int_as_float(~wkey), wmax, wsec, wx);
-        s_ent[2 * wave + 1] = make_float4(wy, wz, __int_as_float(widx), 0.f);
-      }
-      ASTAMP(6);
-#ifdef DH3D_FPS_PROBE
-      if (tid == 64 * DH3D_FPS_PROBE_WAVE && blockIdx.x == 0) {
-        g_probe[16] += at[0] - pt[1];
-        for (int i = 0; i < 6; ++i) g_probe[17 + i] += at[i + 1] - at[i];
-      }
-#endif
-      }
-    }
-    STAMP(2);
-    if (r >= m) break;
-    __syncthreads();
-    STAMP(3);
-    // 2. judge the candidates: lane (row, p) of a judging wave compares candidate c = wave*CPJ + row with candidate p
-#if defined(DH3D_FPS_EXP) && (DH3D_FPS_EXP & 2)  // timing experiment: no judging (results wrong)
-    if (wave < JW && r < 8) {
-#else
-    if (wave < JW) {
-#endif
-      const int row = lane >> 4, p = lane & 15;
-      const int c = wave * CPJ + row;
-      const bool valid = row < CPJ && c < WAVES;
-      const float4 c0 = s_ent[2 * (c < WAVES ? c : 0)], c1 = s_ent[2 * (c < WAVES ? c : 0) + 1];
-      const float4 p0 = s_ent[2 * (p < WAVES ? p : 0)], p1 = s_ent[2 * (p < WAVES ? p : 0) + 1];
-      STAMP(7);
-      const float vc = c0.y;
-      const unsigned long long key_c = ((unsigned long long)__float_as_uint(c0.y) << 32) | __float_as_uint(c0.x);
-      const unsigned long long key_p = ((unsigned long long)__float_as_uint(p0.y) << 32) | __float_as_uint(p0.x);
-      const bool gt = valid && p < WAVES && key_p > key_c;
-      const float dx = c0.w - p0.w, dy = c1.x - p1.x, dz = c1.y - p1.y;
-      const float d = __fmaf_rn(dz, dz, __fmaf_rn(dx, dx, __fmul_rn(dy, dy)));
-      const bool aff = d < vc || p0.z >= vc;
-      const unsigned rowg = (unsigned)(__ballot(gt) >> (16 * row)) & 0xffffu;
-      const unsigned rowa = (unsigned)(__ballot(gt && aff) >> (16 * row)) & 0xffffu;
-      const int rank = __popc(rowg);
-      // first rank that must wait for the next sync: my row's, if an outranking candidate interferes with it
-      const int stop = valid && rank > 0 && (rowa != 0u || !(vc > 0.f)) ? rank : kBig;
-      STAMP(8);
-      const int stop4 = min(min(__builtin_amdgcn_readlane(stop, 0), __builtin_amdgcn_readlane(stop, 16)),
-                            min(__builtin_amdgcn_readlane(stop, 32), __builtin_amdgcn_readlane(stop, 48)));
-      if (lane == 0) s_jthr[wave] = stop4;
-      if (p == 0 && valid && key_c != 0ull && rank < CAP) s_pick[rank] = make_float4(c0.w, c1.x, c1.y, c1.z);
-    }
-    STAMP(4);
-    __syncthreads();
-    STAMP(5);
-    // 3. the accepted picks
-    {
-      const int4 jt = *reinterpret_cast<const int4 *>(s_jthr);
-      const float4 pkv = s_pick[pk < CAP ? pk : 0];
-      const int thr = min(min(jt.x, jt.y), min(jt.z, jt.w));
-#if defined(DH3D_FPS_EXP)  // timing experiments: one pick per sync whatever the judges said
-      npick = min(min(thr, 1), m - r);
-#else
-      npick = min(min(thr, CAP), m - r);
-#endif
-      qx = pkv.x; qy = pkv.y; qz = pkv.z;
-      if (wave == 0 && bl == 0 && pk < npick) s_out[r + pk] = __float_as_int(pkv.w);
-      r += npick;
-    }
-#ifdef DH3D_FPS_PROBE
-    STAMP(6);
-    if (tid == 64 * DH3D_FPS_PROBE_WAVE && blockIdx.x == 0) {
-      for (int i = 0; i < 6; ++i) g_probe[i] += pt[i + 1] - pt[i];
-      if (wave < JW) { g_probe[6] += pt[7] - pt[3]; g_probe[7] += pt[8] - pt[7]; g_probe[8] += pt[4] - pt[8]; }
-      g_probe[14] += need != 0ull;
-      g_probe[15] += 1;
-    }
-#endif
-  }
-  __syncthreads();
-  for (int i = tid; i < m; i += 64 * WAVES) out[(size_t)b * m + i] = s_out[i];
-  if (xyz_out) {  // the sampled coordinates too (group_point of the xyz, core/tf_utils.py:92-95): they are in LDS
-    float *xo = xyz_out + (size_t)b * m * 3;
-    for (int e = tid; e < 3 * m; e += 64 * WAVES) {
-      const int i = e / 3, c = e - 3 * i, k = s_out[i];
-      xo[e] = TABLE ? (c == 0 ? s_x[k] : c == 1 ? s_y[k] : s_z[k]) : pc[(size_t)k * 3 + c];
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Candidate LISTS + a sequential judge: ~10-15 picks per synchronisation, same picks as the sequential rule.
-//
-// fps_batched_kernel offers ONE candidate per wave and stops a batch at the first rank that a higher-ranked candidate
-// might disturb: 3.7 picks per sync, 272 syncs for 8192 -> 1024.  What ends its batches is mostly rule (b) -- "the
-// region of a picked candidate may hold a better point than the next candidate" -- and that is a statement about
-// points nobody published.  Publish them.  Every wave lists its arg-max AND the other lanes whose best point lies
-// within a per-wave adaptive margin of it (at most L = 64 / WAVES entries: value + tie key), plus ONE bound: the
-// largest running distance among everything it did NOT list.  RB = the largest of the WAVES bounds.  The judge (wave
-// 0, one listed candidate per lane, coordinates from the LDS table) then simply RUNS the sequential algorithm on the
-// pool: arg-max by (value, smallest key) -> pick -> pool values = min(value, distance to the pick, the update's own
-// arithmetic) -> ... and every pick whose value is still STRICTLY above RB is the pick the full algorithm would make:
-// an unlisted point started at or below RB and running distances only drop.  The first pick of a sync needs no test
-// (the pool holds every wave's exact arg-max).  A judge round is ~35 instructions (one DPP wave maximum, four
-// v_readlane, seven VALU) instead of a barrier + box tests + a 512-point arg-max per 3.7 picks.
+// What ended the batches of the one-candidate version was mostly "the region of a picked candidate may hold a better
+// point than the next candidate" -- a statement about points nobody had published.  Publish them.  Every touched wave
+// lists its arg-max AND the other lanes whose best point lies within a per-wave adaptive margin of it (at most
+// L = 64 / WAVES entries: value + tie key), plus ONE bound: the largest running distance among everything it did NOT
+// list.  RB = the largest of the WAVES bounds.  The judge (wave 0, one listed candidate per lane, coordinates from the
+// LDS table) then simply RUNS the sequential algorithm on the pool: arg-max by (value, smallest key) -> pick -> pool
+// values = min(value, distance to the pick, the update's own arithmetic) -> ... and every pick whose value is still
+// STRICTLY above RB is the pick the full algorithm would make: an unlisted point started at or below RB and running
+// distances only drop.  The first pick of a sync needs no test (the pool holds every wave's exact arg-max).
 // Exact under ties: a lane whose two best points tie reports the second one in the bound, so a tied value is never
-// accepted past rank 0, and rank 0 is decided on the waves' exact (value, key) winners as before.
-// tools/fps_list_sim.py: 98 syncs (L = 4) / 67 (L = 8) for 8192 -> 1024 on uniform clouds.
+// accepted past rank 0, and rank 0 is decided on the waves' exact (value, key) winners.
+// 8 x 8192 -> 1024: 100 syncs of 10.2 picks, 6.8 k cycles each (update + list 3.2 k on the slowest wave, judge 3.5 k =
+// 294 cycles per pick); 0.355 ms against 0.388.  DEADENDS.md: the same lists with picks streamed to worker waves through
+// an LDS ring instead of barriers (slower: the workers' instruction issue, four waves per SIMD, is the bottleneck).
+// TABLE: the by-original-index coordinate table lives in LDS (12 B per point: clouds of up to ~12 k points).  Larger
+// clouds (TABLE = false) read candidate coordinates from the cloud itself (`xyz`, L2-resident).
 template <int PPT, int WAVES, bool TABLE>
 __global__ __launch_bounds__(64 * WAVES) void fps_list_kernel(const float4 *__restrict__ sorted,
                                                             const float *__restrict__ gbox, int N, int m,
@@ -879,425 +472,6 @@ int fps_list_launch(const float *sorted, const float *gbox, int B, int N, int m,
   return dh3d_launch_status();
 }
 
-// ------------------------------------------------------------------------------------------------
-// Candidate lists + a sequential judge + STREAMED picks: no workgroup barrier in the main loop.
-//
-// fps_batched_kernel offers ONE candidate per wave and ends a batch at the first rank that a higher-ranked candidate
-// might disturb (3.7 picks per sync, 272 syncs for 8192 -> 1024).  What ends its batches is mostly "the region of a
-// picked candidate may hold a better point than the next candidate" -- a statement about points nobody published.
-// Publish them:
-//   * a WORKER wave owns PPT consecutive 64-point groups of the ordered cloud, running distances in registers.  It
-//     lists its exact arg-max and the other lanes whose best point lies within a per-wave adaptive margin of it (at
-//     most L entries: value + tie key), plus ONE bound: the largest running distance among everything it did NOT list;
-//   * the JUDGE (wave 0, one listed candidate per lane, coordinates from the LDS table) RUNS the sequential algorithm
-//     on that pool: arg-max by (value, smallest key) -> pick -> pool values = min(value, distance to the pick) with the
-//     update's own arithmetic -> ...  A pick whose value is STRICTLY above RB = the largest of the bounds is the pick
-//     the full algorithm would make: an unlisted point started at or below RB and running distances only drop.  The
-//     first pick of a round needs no test (every list is current and holds its wave's exact arg-max).  ~10 picks per
-//     round on uniform clouds (tools/fps_list_sim.py);
-//   * every pick is pushed into an LDS ring the moment it is made; the workers scan the new entries (lane = pick,
-//     against the wave's bounding box), apply the ones that reach them and re-list WHILE the judge works on the next
-//     one.  When the pool runs dry the judge waits until every worker has applied all picks (s_ver), reloads the pool
-//     and goes on.  Hand-offs are plain LDS words (a wave's LDS operations execute in order: entry, then head / list,
-//     then version); nobody waits at an s_barrier.
-// WK = 12: waves 4, 8, 12 stay idle so that the judge has its SIMD to itself (waves go to SIMD wave % 4; a wave that
-// shares a SIMD with three busy ones issues at a third of its rate, and the judge's chain is the critical path).
-// Exact under ties: a lane whose two best points tie reports the second one in the bound, so a tied value is never
-// accepted past rank 0 of a round, and rank 0 is decided on the waves' exact (value, key) winners.
-template <int PPT, int WK, bool TABLE>
-__global__ __launch_bounds__(1024) void fps_stream_kernel(const float4 *__restrict__ sorted,
-                                                          const float *__restrict__ gbox, int N, int m,
-                                                          int32_t *__restrict__ out, float *__restrict__ xyz_out,
-                                                          const float *__restrict__ xyz) {
-  static_assert(PPT <= 32 && (WK == 12 || WK == 15), "one lane per box");
-  constexpr int L = 60 / WK;                          // list entries per worker: pool = 60 of the judge's lanes
-  constexpr int RING = 64, CAPR = 48;                 // picks per round < ring entries: a worker never lags a lap
-  constexpr int NP = (PPT + 1) / 2;                   // groups are held and updated in pairs (packed f32)
-  extern __shared__ __attribute__((aligned(16))) float s_mem[];
-  f32x4 *s_ring = reinterpret_cast<f32x4 *>(s_mem);                // x, y, z, index of pick r at r % RING
-  f32x4 *s_dum4 = s_ring + RING;                                   // [64] where the judge's losing lanes store
-  f32x2 *s_list = reinterpret_cast<f32x2 *>(s_dum4 + 64);          // [WK * L] value, key
-  float *s_rb = reinterpret_cast<float *>(s_list + 64);            // [16] bound of worker w
-  int *s_ver = reinterpret_cast<int *>(s_rb + 16);                 // [16] picks applied (and listed) by worker w
-  int *s_head = s_ver + 16;                                        // [4] picks published
-  int *s_dum1 = s_head + 4;                                        // [64]
-  float *s_x = reinterpret_cast<float *>(s_dum1 + 64);
-  float *s_y = s_x + (TABLE ? N : 0);
-  float *s_z = s_y + (TABLE ? N : 0);
-  int *s_out = reinterpret_cast<int *>(s_z + (TABLE ? N : 0));
-  const float *pc = TABLE ? nullptr : xyz + (size_t)blockIdx.x * N * 3;
-
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int NG = (N + 63) / 64;
-  const float4 *sc = sorted + (size_t)b * N;
-  // worker index: WK = 15 -> waves 1..15; WK = 12 -> the waves with wave % 4 != 0
-  const int wk = WK == 15 ? wave - 1 : ((wave & 3) ? wave - 1 - (wave >> 2) : -1);
-  const bool worker = wave > 0 && wk >= 0;
-
-  if (wave == 0) {
-    if (lane == 0) { s_out[0] = 0; s_head[0] = 1; }
-    if (lane < 16) { s_ver[lane] = 0; s_rb[lane] = -2.f; }
-    s_list[lane] = f32x2{-2.f, __int_as_float(INT_MAX)};
-  }
-  f32x2 px[NP], py[NP], pz[NP], md[NP];
-  int pkey[2 * NP];
-#pragma unroll
-  for (int j = 0; j < 2 * NP; ++j) {
-    const int i = (wk * PPT + j) * 64 + lane;
-    float x = 0.f, y = 0.f, z = 0.f, d = -2.f;  // padding: below the reference's initial best = -1, never picked
-    pkey[j] = INT_MAX;
-    if (worker && j < PPT && i < N) {
-      const float4 r = sc[i];
-      const int k = __float_as_int(r.w);
-      x = r.x; y = r.y; z = r.z;
-      d = 1e38f;
-      pkey[j] = fps_key(k);
-      if (TABLE) { s_x[k] = r.x; s_y[k] = r.y; s_z[k] = r.z; }
-      if (k == 0) s_ring[0] = f32x4{r.x, r.y, r.z, 0.f};  // pick 0 is point 0
-    }
-    px[j >> 1][j & 1] = x; py[j >> 1][j & 1] = y; pz[j >> 1][j & 1] = z; md[j >> 1][j & 1] = d;
-  }
-  __syncthreads();
-
-  if (wave == 0) {
-    // ---------------------------------------------------------------- the judge
-    __builtin_amdgcn_s_setprio(3);
-    int r = 1;
-    const unsigned ring0 = (unsigned)(unsigned long long)(DH3D_LDS f32x4 *)s_ring;  // LDS byte addresses
-    const unsigned rtop = ring0 + 16u * RING;
-    const unsigned dum4 = (unsigned)(unsigned long long)(DH3D_LDS f32x4 *)(s_dum4 + lane);
-    const unsigned dum1 = (unsigned)(unsigned long long)(DH3D_LDS int *)(s_dum1 + lane);
-    const unsigned hd = (unsigned)(unsigned long long)(DH3D_LDS int *)s_head;
-#ifdef DH3D_FPS_PROBE
-    long long pt[12];
-#endif
-    while (r < m) {
-      STAMP(0);
-      // every worker has applied (and listed after) all r picks
-      while (true) {
-        const int v = lds_vload(&s_ver[lane < WK ? lane : 0]);
-        if (__ballot(v == r) == ~0ull) break;
-        __builtin_amdgcn_s_sleep(1);
-      }
-      STAMP(1);
-      const int pl = lane < WK * L ? lane : 0;
-      const f32x2 ent = lds_vload2(&s_list[pl]);
-      float cv = lane < WK * L ? ent.x : -2.f;
-      const int ckey = __float_as_int(ent.y);
-      const int cidx = cv >= 0.f ? fps_unkey(ckey) : 0;
-      const float rbl = lds_vloadf(&s_rb[lane & 15]);
-      float cx, cy, cz;
-      if (TABLE) { cx = s_x[cidx]; cy = s_y[cidx]; cz = s_z[cidx]; }
-      else { cx = pc[(size_t)cidx * 3]; cy = pc[(size_t)cidx * 3 + 1]; cz = pc[(size_t)cidx * 3 + 2]; }
-      // non-negative floats order like their bit patterns: the judge compares on the scalar unit
-      const int RB = __builtin_amdgcn_readfirstlane(max(__float_as_int(wave_max_f32(lane < WK ? rbl : -2.f)), -1));
-      const int rend = __builtin_amdgcn_readfirstlane(r + min(CAPR, m - r));
-      int rbe = -1;  // the first pick of a round is unconditional
-      f32x4 rec = {cx, cy, cz, __int_as_float(cidx)};  // what the winner pushes into the ring
-      unsigned so = __builtin_amdgcn_readfirstlane(ring0 + 16u * (unsigned)(r & (RING - 1)));
-      // the pool must have landed BEFORE the loop: a wait inside it would also wait for the loop's own LDS stores
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(rec), "+v"(cx), "+v"(cy), "+v"(cz), "+v"(cv));
-      STAMP(2);
-#ifdef DH3D_FPS_PROBE
-      const int r0 = r;
-#endif
-      while (true) {
-        // One pick per trip, hand-scheduled (a compiled version of this loop: 52 instructions, 380 cycles per pick;
-        // the losing lanes store into slots of their own, so nothing touches EXEC and no branch is taken but the loop's).
-        // status: 0 = the pool ran dry (or the round is full), 1 = the maximum is tied (resolved below, on the keys)
-        int st, sv, sl, sx, sy, sz;
-        float t0, t1, t2;
-#ifdef DH3D_FPS_CJUDGE  // dev: the same trip compiled (tools/judge_probe.hip)
-        {
-          sv = __float_as_int(wave_max_f32(cv));
-          st = 0;
-          if (!(sv > rbe)) break;
-          rbe = RB;
-          const unsigned long long hit = __ballot(__float_as_int(cv) == sv);
-          st = 1;
-          if (__popcll(hit) == 1) {
-            const int l = __builtin_ctzll(hit);
-            const bool win = lane == l;
-            lds_vstore4(win ? &s_ring[r & (RING - 1)] : &s_dum4[lane], rec);
-            ++r;
-            so = so + 16u == rtop ? ring0 : so + 16u;
-            lds_vstore(win ? &s_head[0] : &s_dum1[lane], r);
-            const float x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cx), l));
-            const float y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cy), l));
-            const float z1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cz), l));
-            const float dx = cx - x1, dy = cy - y1, dz = cz - z1;
-            const float d = __fmaf_rn(dz, dz, __fmaf_rn(dx, dx, __fmul_rn(dy, dy)));
-            cv = __builtin_fminf(d, cv);
-            if (r == rend) break;
-            continue;
-          }
-          (void)sl; (void)sx; (void)sy; (void)sz; (void)t0; (void)t1; (void)t2;
-        }
-#else
-        asm volatile(
-            "1:\n\t"
-            "v_mov_b32 %[t0], %[cv]\n\t"
-            DH3D_DPP_WAVE_N("v_max_f32_dpp", "t0")
-            "s_nop 1\n\t"  // VALU write -> v_readlane of the same VGPR (the compiler pads this one itself; asm does not)
-            "v_readlane_b32 %[sv], %[t0], 63\n\t"
-            "s_mov_b32 %[st], 0\n\t"
-            "s_cmp_gt_i32 %[sv], %[rbe]\n\t"
-            "s_cbranch_scc0 9f\n\t"
-            "s_mov_b32 %[rbe], %[RB]\n\t"
-            "v_cmp_eq_u32 vcc, %[sv], %[cv]\n\t"
-            "s_bcnt1_i32_b64 %[sl], vcc\n\t"
-            "s_mov_b32 %[st], 1\n\t"
-            "s_cmp_eq_u32 %[sl], 1\n\t"
-            "s_cbranch_scc0 9f\n\t"
-            "s_ff1_i32_b64 %[sl], vcc\n\t"
-            "v_mov_b32 %[t1], %[so]\n\t"
-            "v_cndmask_b32 %[t1], %[dum4], %[t1], vcc\n\t"
-            "ds_write_b128 %[t1], %[rec]\n\t"
-            "s_add_u32 %[r], %[r], 1\n\t"
-            "s_add_u32 %[so], %[so], 16\n\t"
-            "v_mov_b32 %[t2], %[r]\n\t"
-            "v_cndmask_b32 %[t0], %[dum1], %[hd], vcc\n\t"
-            "ds_write_b32 %[t0], %[t2]\n\t"
-            "s_cmp_eq_u32 %[so], %[rtop]\n\t"
-            "s_cselect_b32 %[so], %[ring0], %[so]\n\t"
-            "v_readlane_b32 %[sx], %[cx], %[sl]\n\t"
-            "v_readlane_b32 %[sy], %[cy], %[sl]\n\t"
-            "v_readlane_b32 %[sz], %[cz], %[sl]\n\t"
-            "v_subrev_f32 %[t1], %[sx], %[cx]\n\t"
-            "v_subrev_f32 %[t0], %[sy], %[cy]\n\t"
-            "v_subrev_f32 %[t2], %[sz], %[cz]\n\t"
-            "v_mul_f32 %[t0], %[t0], %[t0]\n\t"
-            "v_fmac_f32 %[t0], %[t1], %[t1]\n\t"
-            "v_fmac_f32 %[t0], %[t2], %[t2]\n\t"
-            "v_min_f32 %[cv], %[t0], %[cv]\n\t"
-            "s_mov_b32 %[st], 0\n\t"
-            "s_cmp_lg_u32 %[r], %[rend]\n\t"
-            "s_cbranch_scc1 1b\n\t"
-            "9:\n\t"
-            : [cv] "+v"(cv), [r] "+s"(r), [so] "+s"(so), [rbe] "+s"(rbe), [st] "=&s"(st), [sv] "=&s"(sv), [sl] "=&s"(sl),
-              [sx] "=&s"(sx), [sy] "=&s"(sy), [sz] "=&s"(sz), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
-            : [cx] "v"(cx), [cy] "v"(cy), [cz] "v"(cz), [rec] "v"(rec), [dum4] "v"(dum4), [dum1] "v"(dum1), [hd] "v"(hd),
-              [RB] "s"(RB), [rend] "s"(rend), [ring0] "s"(ring0), [rtop] "s"(rtop)
-            : "vcc", "scc", "memory");
-#endif
-        if (st == 0) break;
-        // tied values in the pool: the smallest key wins (the test against the bound has passed)
-        const int kmin = wave_min_i32(__float_as_int(cv) == sv ? ckey : INT_MAX);
-        const int l = __builtin_ctzll(__ballot(__float_as_int(cv) == sv && ckey == kmin));
-        const bool win = lane == l;
-        lds_vstore4(win ? &s_ring[r & (RING - 1)] : &s_dum4[lane], rec);
-        ++r;
-        so = so + 16u == rtop ? ring0 : so + 16u;
-        lds_vstore(win ? &s_head[0] : &s_dum1[lane], r);
-        const float x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cx), l));
-        const float y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cy), l));
-        const float z1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cz), l));
-        const float dx = cx - x1, dy = cy - y1, dz = cz - z1;
-        const float d = __fmaf_rn(dz, dz, __fmaf_rn(dx, dx, __fmul_rn(dy, dy)));
-        cv = __builtin_fminf(d, cv);
-        if (r == rend) break;
-      }
-#ifdef DH3D_FPS_PROBE
-      STAMP(3);
-      if (lane == 0 && blockIdx.x == 0) {
-        for (int i = 0; i < 3; ++i) g_probe[i] += pt[i + 1] - pt[i];
-        g_probe[13] += r - r0;
-        g_probe[15] += 1;
-      }
-#endif
-    }
-  } else if (worker) {
-    // ---------------------------------------------------------------- a worker
-    __builtin_amdgcn_s_setprio(1);
-    // lane j < PPT: bounding box of group j; every lane: the bounding box of the wave's groups
-    float blx = INFINITY, bly = INFINITY, blz = INFINITY, bhx = -INFINITY, bhy = -INFINITY, bhz = -INFINITY;
-    bool has_box = false;
-    if (lane < PPT) {
-      const int g = wk * PPT + lane;
-      if (g < NG) {
-        const float *bx = gbox + ((size_t)b * NG + g) * 8;
-        blx = bx[0]; bly = bx[1]; blz = bx[2]; bhx = bx[4]; bhy = bx[5]; bhz = bx[6];
-        has_box = true;
-      }
-    }
-    const float wlx = wave_min_f32(blx), wly = wave_min_f32(bly), wlz = wave_min_f32(blz);
-    const float whx = wave_max_f32(bhx), why = wave_max_f32(bhy), whz = wave_max_f32(bhz);
-    const bool any_box = __ballot(has_box) != 0ull;
-    float wmax = any_box ? 1e38f : -2.f;  // cached wave maximum (uniform)
-    float delta = 0.05f;                    // listing margin, relative to the wave maximum
-    int ver = 0;
-    f32x2 *vl = s_list + wk * L;
-#ifdef DH3D_FPS_PROBE
-    long long pt[12];
-    const bool probed = tid == 64 * (DH3D_FPS_PROBE_WAVE ? DH3D_FPS_PROBE_WAVE : 5) && blockIdx.x == 0;
-#endif
-    while (ver < m) {
-      STAMP(4);
-      // the head and the ring entries behind it in ONE round trip (issued in this order: an entry is at least as new)
-      int head = lds_vload(&s_head[0]);
-      f32x4 q = lds_vload4(&s_ring[(ver + lane) & (RING - 1)]);
-      while (head == ver) {  // wait for the next pick
-        __builtin_amdgcn_s_sleep(1);
-        head = lds_vload(&s_head[0]);
-        q = lds_vload4(&s_ring[(ver + lane) & (RING - 1)]);
-      }
-      STAMP(5);
-      // the new ring entries, lane = pick: which of them can change anything in this wave's groups?
-      const int n = min(head - ver, RING);
-      if (wk == 0 && lane < n) s_out[ver + lane] = __float_as_int(q.w);  // worker 0 keeps the record
-      const float ex = fmaxf(fmaxf(wlx - q.x, q.x - whx), 0.f);
-      const float ey = fmaxf(fmaxf(wly - q.y, q.y - why), 0.f);
-      const float ez = fmaxf(fmaxf(wlz - q.z, q.z - whz), 0.f);
-      const float bd = (ex * ex + ey * ey + ez * ez) * 0.99999f;
-      unsigned long long nd = any_box ? __ballot(lane < n && bd <= wmax) : 0ull;
-      ver += n;
-      bool touched = false;
-      while (nd != 0ull) {  // in pick order
-        const int p = __builtin_ctzll(nd);
-        nd &= nd - 1ull;
-        const float x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.x), p));
-        const float y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.y), p));
-        const float z1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.z), p));
-        // the groups it reaches (lane = box)
-        const float gx = fmaxf(fmaxf(blx - x1, x1 - bhx), 0.f);
-        const float gy = fmaxf(fmaxf(bly - y1, y1 - bhy), 0.f);
-        const float gz = fmaxf(fmaxf(blz - z1, z1 - bhz), 0.f);
-        const float gd = (gx * gx + gy * gy + gz * gz) * 0.99999f;
-        const unsigned long long nb = __ballot(has_box && gd <= wmax);
-        if (nb == 0ull) continue;
-        touched = true;
-        const f32x2 x2 = {x1, x1}, y2 = {y1, y1}, z2 = {z1, z1};
-#pragma unroll
-        for (int qd = 0; qd < NP; ++qd) {
-          if (PPT <= 12 || ((nb >> (2 * qd)) & 3ull)) {
-            const f32x2 dx = px[qd] - x2, dy = py[qd] - y2, dz = pz[qd] - z2;
-            const f32x2 d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
-            md[qd][0] = __builtin_fminf(d[0], md[qd][0]);
-            md[qd][1] = __builtin_fminf(d[1], md[qd][1]);
-          }
-        }
-      }
-      STAMP(6);
-      if (touched) {  // new arg-max, list and bound right away (an untouched wave's published state stays valid): by
-                      // the time the judge's pool runs dry only the waves its last picks reached are still at it
-        float b1 = -2.f, b2 = -2.f;
-        int lkey = INT_MAX;
-#pragma unroll
-        for (int j = 0; j < 2 * NP; ++j) {
-          const float x = md[j >> 1][j & 1];
-          lkey = x > b1 ? pkey[j] : lkey;
-          b2 = __builtin_amdgcn_fmed3f(b1, b2, x);
-          b1 = __builtin_fmaxf(b1, x);
-        }
-        asm volatile("" :: "v"(b1), "v"(b2));
-        wmax = wave_max_f32(b1);
-        const float tau = wmax - delta * wmax;
-        const unsigned long long hit = __ballot(b1 == wmax);
-        const unsigned long long flag = __ballot(b1 > tau);
-        const unsigned long long two = __ballot(b2 > tau);  // two points of a lane inside the margin
-        const int cnt = __popcll(flag);
-        if (__popcll(hit) == 1 && two == 0ull && cnt >= 1 && cnt <= L) {
-          // the usual case: one point holds the maximum, every lane inside the margin has ONE point there and they
-          // all fit: list them in lane order; everything else is at or below tau
-          const int slot = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(flag >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)flag, 0u));
-          if (lane < L) lds_vstore2(&vl[lane], f32x2{-2.f, __int_as_float(INT_MAX)});
-          if ((flag >> lane) & 1ull) lds_vstore2(&vl[slot], f32x2{b1, __int_as_float(lkey)});
-          if (lane == 0) lds_vstoref(&s_rb[wk], tau);
-        } else {
-          int wl = __builtin_ctzll(hit);  // winner lane
-          int wkey;
-          if (__popcll(hit) == 1 && __ballot(b2 == wmax) == 0ull) {  // one point holds the maximum
-            wkey = __builtin_amdgcn_readlane(lkey, wl);
-          } else {  // ties: the smallest key wins
-            int tkey = INT_MAX;
-#pragma unroll
-            for (int j = 0; j < 2 * NP; ++j) tkey = (md[j >> 1][j & 1] == wmax) ? min(tkey, pkey[j]) : tkey;
-            wkey = wave_min_i32(tkey);
-            wl = __builtin_ctzll(__ballot(tkey == wkey));
-          }
-          // winner in slot 0, then the lanes within the margin in lane order; the rest goes into the bound
-          const unsigned long long others = flag & ~(1ull << wl);
-          const int slot = lane == wl ? 0 : 1 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(others >> 32),
-                                                       __builtin_amdgcn_mbcnt_lo((unsigned)others, 0u));
-          const bool listed = lane == wl || (((others >> lane) & 1ull) && slot < L);
-          const float rb = wave_max_f32(listed ? b2 : b1);
-          if (wmax >= 0.f) {
-            if (lane < L) lds_vstore2(&vl[lane], f32x2{-2.f, __int_as_float(INT_MAX)});
-            if (listed) lds_vstore2(&vl[slot], f32x2{b1, __int_as_float(lane == wl ? wkey : lkey)});
-            if (lane == 0) lds_vstoref(&s_rb[wk], rb);
-          }
-        }
-        delta = cnt > L - 1 ? delta * 0.7f : (cnt < (L + 1) / 2 ? fminf(delta * 1.3f, 0.5f) : delta);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-      if (lane == 0) lds_vstore(&s_ver[wk], ver);  // every pick below ver is applied AND listed
-#ifdef DH3D_FPS_PROBE
-      STAMP(7);
-      if (probed) {
-        g_probe[17] += pt[5] - pt[4]; g_probe[18] += pt[6] - pt[5]; g_probe[16] += touched ? pt[7] - pt[6] : 0;
-        g_probe[19] += 1; g_probe[20] += touched; g_probe[23] += n;
-      }
-#endif
-    }
-  }
-  __syncthreads();
-  for (int i = tid; i < m; i += 1024) out[(size_t)b * m + i] = s_out[i];
-  if (xyz_out) {  // the sampled coordinates too (group_point of the xyz, core/tf_utils.py:92-95): they are in LDS
-    float *xo = xyz_out + (size_t)b * m * 3;
-    for (int e = tid; e < 3 * m; e += 1024) {
-      const int i = e / 3, c = e - 3 * i, k = s_out[i];
-      xo[e] = TABLE ? (c == 0 ? s_x[k] : c == 1 ? s_y[k] : s_z[k]) : pc[(size_t)k * 3 + c];
-    }
-  }
-}
-
-template <int PPT, int WK>
-int fps_stream_launch(const float *sorted, const float *gbox, int B, int N, int m, int32_t *out, float *xyz_out,
-                      const float *xyz, hipStream_t s) {
-  const size_t small = sizeof(float) * (4 * 64 + 4 * 64 + 2 * 64 + 16 + 16 + 4 + 64 + (size_t)m);
-  const size_t lds = small + sizeof(float) * (size_t)3 * N;
-  if (lds <= 159 * 1024) {
-    DH3D_ALLOW_BIG_LDS((fps_stream_kernel<PPT, WK, true>));
-    hipLaunchKernelGGL((fps_stream_kernel<PPT, WK, true>), dim3(B), dim3(1024), lds, s,
-                       reinterpret_cast<const float4 *>(sorted), gbox, N, m, out, xyz_out, nullptr);
-  } else {
-    if (!xyz || small > 159 * 1024) return DH3D_ERR_UNSUPPORTED;  // no LDS table: the cloud itself is needed
-    DH3D_ALLOW_BIG_LDS((fps_stream_kernel<PPT, WK, false>));
-    hipLaunchKernelGGL((fps_stream_kernel<PPT, WK, false>), dim3(B), dim3(1024), small, s,
-                       reinterpret_cast<const float4 *>(sorted), gbox, N, m, out, xyz_out, xyz);
-  }
-  return dh3d_launch_status();
-}
-
-template <int PPT, int WAVES>
-int fps_batched_launch(const float *sorted, const float *gbox, int B, int N, int m, int32_t *out, float *xyz_out,
-                       const float *xyz, hipStream_t s) {
-  const size_t small = sizeof(float) * (8 * WAVES + 64 + 4 + (size_t)m);
-  const size_t lds = small + sizeof(float) * (size_t)3 * N;
-  if (lds <= 159 * 1024) {
-    DH3D_ALLOW_BIG_LDS((fps_batched_kernel<PPT, WAVES, true>));
-    hipLaunchKernelGGL((fps_batched_kernel<PPT, WAVES, true>), dim3(B), dim3(64 * WAVES), lds, s,
-                       reinterpret_cast<const float4 *>(sorted), gbox, N, m, out, xyz_out, nullptr);
-  } else {
-    if (!xyz || small > 159 * 1024) return DH3D_ERR_UNSUPPORTED;  // no LDS table: the cloud itself is needed
-    DH3D_ALLOW_BIG_LDS((fps_batched_kernel<PPT, WAVES, false>));
-    hipLaunchKernelGGL((fps_batched_kernel<PPT, WAVES, false>), dim3(B), dim3(64 * WAVES), small, s,
-                       reinterpret_cast<const float4 *>(sorted), gbox, N, m, out, xyz_out, xyz);
-  }
-  return dh3d_launch_status();
-}
-
-template <int PPT, int WAVES>
-int fps_sorted_launch(const float *sorted, const float *gbox, int B, int N, int m, int32_t *out, hipStream_t s) {
-  const size_t lds = sizeof(float) * (4 * WAVES + (size_t)3 * N + m);
-  if (lds > 159 * 1024) return DH3D_ERR_UNSUPPORTED;
-  DH3D_ALLOW_BIG_LDS((fps_sorted_kernel<PPT, WAVES>));
-  hipLaunchKernelGGL((fps_sorted_kernel<PPT, WAVES>), dim3(B), dim3(64 * WAVES), lds, s,
-                     reinterpret_cast<const float4 *>(sorted), gbox, N, m, out);
-  return dh3d_launch_status();
-}
-
 template <int PPT, int WAVES>
 int fps_launch(const float *xyz, int B, int N, int m, int32_t *out, hipStream_t s) {
   const size_t red = sizeof(float) * 4 * WAVES;
@@ -1363,10 +537,6 @@ __global__ __launch_bounds__(1024) void fps_anyn_kernel(const float *__restrict_
 
 }  // namespace
 
-// Dev knob (tools/geo_bench.py): waves per cloud; 0 = default.
-static int g_fps_waves = 0;
-DH3D_API void dh3d_dev_set_fps_waves(int w) { g_fps_waves = w; }
-
 DH3D_API int dh3d_farthest_point_sample_mode(int B, int N, int m, const float *inp, float *temp, int32_t *out,
                                              int contract, void *stream) {
   DH3D_REQUIRE(inp && out && temp && B > 0 && N > 0 && m > 0 && (contract == 0 || contract == 1));
@@ -1384,81 +554,27 @@ DH3D_API int dh3d_farthest_point_sample(int B, int N, int m, const float *inp, f
     return dh3d_farthest_point_sample_mode(B, N, m, inp, temp, out, 1, stream);
   }
   hipStream_t s = (hipStream_t)stream;
-  const int W = g_fps_waves ? g_fps_waves : (N <= 1024 ? 4 : 8);  // measured best on MI355X (tools/geo_bench.py)
-#define DH3D_FPS_CASE(WV)                                                              \
-  if (W == WV) {                                                                       \
-    const int per = 64 * WV;                                                           \
-    if (N <= per * 2) return fps_launch<2, WV>(inp, B, N, m, out, s);                  \
-    if (N <= per * 4) return fps_launch<4, WV>(inp, B, N, m, out, s);                  \
-    if (N <= per * 8) return fps_launch<8, WV>(inp, B, N, m, out, s);                  \
-    if (N <= per * 16) return fps_launch<16, WV>(inp, B, N, m, out, s);                \
-    if (N <= per * 32) return fps_launch<32, WV>(inp, B, N, m, out, s);                \
-    if (N <= per * 64) return fps_launch<64, WV>(inp, B, N, m, out, s);                \
-  }
-  DH3D_FPS_CASE(4)
-  DH3D_FPS_CASE(8)
-  DH3D_FPS_CASE(16)
-#undef DH3D_FPS_CASE
-  return DH3D_ERR_UNSUPPORTED;
+  // waves per cloud measured best on MI355X: 4 up to 1024 points, 8 above (<= 32 points per lane: no spills)
+  if (N <= 512) return fps_launch<2, 4>(inp, B, N, m, out, s);
+  if (N <= 1024) return fps_launch<4, 4>(inp, B, N, m, out, s);
+  if (N <= 2048) return fps_launch<4, 8>(inp, B, N, m, out, s);
+  if (N <= 4096) return fps_launch<8, 8>(inp, B, N, m, out, s);
+  if (N <= 8192) return fps_launch<16, 8>(inp, B, N, m, out, s);
+  return fps_launch<32, 8>(inp, B, N, m, out, s);
 }
-
-// Dev knob (tools/geo_bench.py): waves per cloud for the ordered kernel; 0 = default.
-static int g_fps_sorted_waves = 0;
-static int g_fps_sorted_mode = 0;  // 0 = lists + judge + streamed picks, 1 = one pick per round, 2 = one candidate per wave, 3 = lists + judge, barriers
-DH3D_API void dh3d_dev_set_fps_sorted_waves(int w) { g_fps_sorted_waves = w; }
-DH3D_API void dh3d_dev_set_fps_sorted_mode(int v) { g_fps_sorted_mode = v; }
 
 static int fps_sorted_dispatch(const float *sorted, const float *gbox, int B, int N, int m, int32_t *out,
                                float *xyz_out, const float *xyz, void *stream) {
   DH3D_REQUIRE(sorted && gbox && out && B > 0 && N > 0 && m > 0);
   // the by-original-index coordinate table must fit LDS (12 B / point) unless the cloud itself is given
-  DH3D_SUPPORTED(N <= 12288 || (xyz && N <= 16384 && g_fps_sorted_mode != 1));
+  DH3D_SUPPORTED(N <= 12288 || (xyz && N <= 16384));
   hipStream_t s = (hipStream_t)stream;
-  const int W = g_fps_sorted_waves ? g_fps_sorted_waves : 16;  // measured best on MI355X (tools/geo_bench.py)
-  const int NG = (N + 63) / 64;
-#define DH3D_FPS_CASE(WV)                                                                             \
-  if (W == WV) {                                                                                      \
-    const int gpw = (NG + WV - 1) / WV; /* groups per wave */                                         \
-    if (g_fps_sorted_mode == 3 && gpw <= 16) {                                                        \
-      if (gpw <= 1) return fps_list_launch<1, WV>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);            \
-      if (gpw <= 2) return fps_list_launch<2, WV>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);            \
-      if (gpw <= 4) return fps_list_launch<4, WV>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);            \
-      if (gpw <= 8) return fps_list_launch<8, WV>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);            \
-      return fps_list_launch<16, WV>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);                         \
-    }                                                                                                 \
-    if (g_fps_sorted_mode != 1) {                                                                     \
-      if (gpw <= 1) return fps_batched_launch<1, WV>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);         \
-      if (gpw <= 2) return fps_batched_launch<2, WV>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);         \
-      if (gpw <= 4) return fps_batched_launch<4, WV>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);         \
-      if (gpw <= 8) return fps_batched_launch<8, WV>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);         \
-      if (gpw <= 16) return fps_batched_launch<16, WV>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);       \
-      if (gpw <= 32) return fps_batched_launch<32, WV>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);       \
-      if (gpw <= 48) return fps_batched_launch<48, WV>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);       \
-    }                                                                                                 \
-    if (gpw <= 1) return fps_sorted_launch<1, WV>(sorted, gbox, B, N, m, out, s);                     \
-    if (gpw <= 2) return fps_sorted_launch<2, WV>(sorted, gbox, B, N, m, out, s);                     \
-    if (gpw <= 4) return fps_sorted_launch<4, WV>(sorted, gbox, B, N, m, out, s);                     \
-    if (gpw <= 8) return fps_sorted_launch<8, WV>(sorted, gbox, B, N, m, out, s);                     \
-    if (gpw <= 16) return fps_sorted_launch<16, WV>(sorted, gbox, B, N, m, out, s);                   \
-    if (gpw <= 32) return fps_sorted_launch<32, WV>(sorted, gbox, B, N, m, out, s);                   \
-    if (gpw <= 48) return fps_sorted_launch<48, WV>(sorted, gbox, B, N, m, out, s);                   \
-  }
-  if ((g_fps_sorted_mode == 0 || g_fps_sorted_mode == 4) && !g_fps_sorted_waves) {  // lists + judge + streamed picks
-    const bool w15 = g_fps_sorted_mode == 4 || NG > 16 * 12;  // 15 workers (the judge shares its SIMD) when 12 cannot hold the cloud
-    const int gpw = w15 ? (NG + 14) / 15 : (NG + 11) / 12;
-#define DH3D_FPS_STREAM(P)                                                                            \
-  if (gpw <= P) return w15 ? fps_stream_launch<P, 15>(sorted, gbox, B, N, m, out, xyz_out, xyz, s)    \
-                           : fps_stream_launch<P, 12>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);
-    DH3D_FPS_STREAM(1) DH3D_FPS_STREAM(2) DH3D_FPS_STREAM(3) DH3D_FPS_STREAM(4) DH3D_FPS_STREAM(6)
-    DH3D_FPS_STREAM(9) DH3D_FPS_STREAM(11) DH3D_FPS_STREAM(13) DH3D_FPS_STREAM(16) DH3D_FPS_STREAM(18)
-#undef DH3D_FPS_STREAM
-  }
-  if (xyz_out && g_fps_sorted_mode == 1) return DH3D_ERR_UNSUPPORTED;  // the one-pick-per-round kernel has no such output
-  DH3D_FPS_CASE(4)
-  DH3D_FPS_CASE(8)
-  DH3D_FPS_CASE(16)
-#undef DH3D_FPS_CASE
-  return DH3D_ERR_UNSUPPORTED;
+  const int gpw = ((N + 63) / 64 + 15) / 16;  // groups per wave, 16 waves per cloud
+  if (gpw <= 1) return fps_list_launch<1, 16>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);
+  if (gpw <= 2) return fps_list_launch<2, 16>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);
+  if (gpw <= 4) return fps_list_launch<4, 16>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);
+  if (gpw <= 8) return fps_list_launch<8, 16>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);
+  return fps_list_launch<16, 16>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);
 }
 
 DH3D_API int dh3d_fps_sorted(const float *sorted, const float *gbox, int B, int N, int m, int32_t *out,
@@ -1475,7 +591,7 @@ DH3D_API int dh3d_fps_sorted_xyz(const float *sorted, const float *gbox, int B, 
 }
 
 // + xyz [B, N, 3]: the cloud the records were sorted from.  Lifts the 12288-point limit of the LDS coordinate table
-// to the 16384 of the ordering itself (the winner's coordinates are then read from `xyz`); xyz_out may be NULL.
+// to the 16384 of the ordering itself (candidate coordinates are then read from `xyz`); xyz_out may be NULL.
 DH3D_API int dh3d_fps_sorted_cloud(const float *sorted, const float *gbox, const float *xyz, int B, int N, int m,
                                    int32_t *out, float *xyz_out, void *stream) {
   DH3D_REQUIRE(xyz);
@@ -1483,12 +599,7 @@ DH3D_API int dh3d_fps_sorted_cloud(const float *sorted, const float *gbox, const
 }
 
 #ifdef DH3D_FPS_PROBE
-DH3D_API int dh3d_fps_cnt_read(unsigned long long *host2, int reset) {
-  int rc = hipMemcpyFromSymbol(host2, HIP_SYMBOL(g_fps_cnt), 16) == hipSuccess ? 0 : 3;
-  if (reset) { unsigned long long z[2] = {0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fps_cnt), z, 16); }
-  return rc;
-}
-DH3D_API int dh3d_fps_probe_read(long long *host16) {
-  return hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_probe), sizeof(long long) * 32) == hipSuccess ? 0 : 3;
+DH3D_API int dh3d_fps_probe_read(long long *host32) {
+  return hipMemcpyFromSymbol(host32, HIP_SYMBOL(g_probe), sizeof(long long) * 32) == hipSuccess ? 0 : 3;
 }
 #endif

@@ -16,7 +16,6 @@ for B, N in ((8, 8192), (32, 4096)):
     out = torch.empty(B, m, dtype=torch.int32, device=dev)
     for name in sys.argv[1:] or ["tools/libfps_list_probe_w0.so", "tools/libfps_list_probe_w5.so"]:
         lib = ctypes.CDLL(os.path.abspath(name))
-        lib.dh3d_dev_set_fps_sorted_mode(3)
         h0 = (ctypes.c_longlong * 32)(); h1 = (ctypes.c_longlong * 32)()
         lib.dh3d_fps_sorted(p(srt), p(gbox), B, N, m, p(out), None); torch.cuda.synchronize()
         lib.dh3d_fps_probe_read(h0)
