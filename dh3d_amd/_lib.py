@@ -61,7 +61,7 @@ _SIGNATURES = {
     "dh3d_gemm_tn_f32_batched": [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp],
     "dh3d_gemm_nn_f32_batched": [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp],
     "dh3d_bn_colstats": [c_fp, c_ll, c_int, c_fp, c_int, c_fp, c_fp, c_fp],
-    "dh3d_bn_finalize": [c_fp, c_fp, c_fp, c_fp, c_fp, c_float, c_float, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp],
+    "dh3d_bn_finalize": [c_fp, c_fp, c_fp, c_fp, c_fp, c_float, c_float, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp],
     "dh3d_scale_shift_act": [c_fp, c_ll, c_int, c_fp, c_fp, c_int, c_fp, c_fp],
     "dh3d_row_logit_sigmoid": [c_fp, c_ll, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp],
     "dh3d_bn_bwd_sums": [c_fp, c_fp, c_fp, c_fp, c_ll, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_int,
@@ -118,7 +118,7 @@ _SIGNATURES = {
     "dh3d_interp_head_sorted_fwd_dev": [c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, ctypes.POINTER(Epilogue),
                                         c_fp, c_fp, c_fp, c_fp],
     "dh3d_three_interpolate_bwd_sorted": [c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp],
-    "dh3d_bn_small_fwd": [c_fp, c_int, c_int, c_fp, c_fp, c_float, c_float, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp],
+    "dh3d_bn_small_fwd": [c_fp, c_int, c_int, c_fp, c_fp, c_float, c_float, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp],
     "dh3d_bn_small_bwd": [c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp],
     "dh3d_quadruplet_loss": [c_fp, c_int, c_int, c_int, c_int, c_float, c_float, c_fp, c_fp, c_fp],
     "dh3d_vlad_normalize_fwd": [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_float, c_fp, c_fp, c_fp, c_fp],

@@ -30,6 +30,8 @@ from . import pm
 class TPBatchNorm(nn.Module):
     """tensorpack BatchNorm variables: gamma, beta, mean/EMA, variance/EMA (inference statistics)."""
 
+    ema_unbiased = True  # training: rank-4 inputs go through tf.nn.fused_batch_norm (Bessel-corrected moving variance)
+
     def __init__(self, channels, eps=1e-5):
         super().__init__()
         self.eps = eps
@@ -45,11 +47,14 @@ class TPBatchNorm(nn.Module):
 
 
 class SlimBatchNorm(nn.Module):
-    """slim / tf.contrib.layers batch_norm variables: gamma, beta, moving_mean, moving_variance."""
+    """slim / tf.contrib.layers batch_norm variables: gamma, beta, moving_mean, moving_variance.  fused: whether the
+    upstream layer runs the fused kernel in training (rank-2 input, fused=None: yes -- its moving variance then takes
+    the Bessel-corrected batch variance; cluster_bn is fused=False, core/backbones.py:218-223)."""
 
-    def __init__(self, channels, eps=1e-3):
+    def __init__(self, channels, eps=1e-3, fused=True):
         super().__init__()
         self.eps = eps
+        self.ema_unbiased = bool(fused)
         self.gamma = nn.Parameter(torch.ones(channels))
         self.beta = nn.Parameter(torch.zeros(channels))
         self.register_buffer("moving_mean", torch.zeros(channels))
@@ -619,7 +624,7 @@ class NetVLAD(nn.Module):
         self.add_batch_norm, self.gating = bool(add_batch_norm), bool(gating)
         self.cluster_weights = nn.Parameter(torch.randn(D, C) / math.sqrt(D))
         if add_batch_norm:
-            self.cluster_bn = SlimBatchNorm(C, slim_bn_eps)
+            self.cluster_bn = SlimBatchNorm(C, slim_bn_eps, fused=False)
         else:  # backbones.py:224-229
             self.cluster_biases = nn.Parameter(torch.randn(C) / math.sqrt(D))
         self.cluster_weights2 = nn.Parameter(torch.randn(1, D, C) / math.sqrt(D))

@@ -164,12 +164,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *x, const
 // Training-mode BatchNorm of a SHORT tensor (R <= 64 rows: the [clouds, 256] hidden / gating activations of NetVLAD) in
 // one launch per direction instead of fill + statistics + finalize + apply: a workgroup owns 64 channels, thread (c, q)
 // walks rows q, q + 4, ...  Same arithmetic as the long form: biased variance from f64 sums, folded scale / shift,
-// running buffers with decay `momentum`; dx = scale dz - k2 - k3 x.  mask [R] bytes (rows_per_cloud == 1) or NULL.
+// running buffers with decay `momentum` (variance Bessel-corrected if `unbiased`: what tf.nn.fused_batch_norm feeds the
+// moving average); dx = scale dz - k2 - k3 x.  mask [R] bytes (rows_per_cloud == 1) or NULL.
 template <bool BWD>
 __global__ __launch_bounds__(256) void bn_small_kernel(const float *__restrict__ x, const float *__restrict__ dy, int R,
                                                       int C, const float *__restrict__ gamma,
                                                       const float *__restrict__ beta, float eps, float momentum,
-                                                      int relu, const unsigned char *__restrict__ mask,
+                                                      int unbiased, int relu, const unsigned char *__restrict__ mask,
                                                       float *run_mean, float *run_var, float *__restrict__ stats,
                                                       float *__restrict__ out, float *__restrict__ dgamma,
                                                       float *__restrict__ dbeta) {
@@ -215,7 +216,8 @@ __global__ __launch_bounds__(256) void bn_small_kernel(const float *__restrict__
       stats[c] = mu; stats[C + c] = rs; stats[2 * C + c] = sc; stats[3 * C + c] = sh;
       if (s_n > 0) {
         run_mean[c] = momentum * run_mean[c] + (1.f - momentum) * mu;
-        run_var[c] = momentum * run_var[c] + (1.f - momentum) * (float)var;
+        const double uv = unbiased && s_n > 1 ? var * (n / (n - 1.0)) : var;
+        run_var[c] = momentum * run_var[c] + (1.f - momentum) * (float)uv;
       }
     }
     for (int r = q; r < R; r += 4) {
@@ -242,11 +244,13 @@ __global__ __launch_bounds__(256) void bn_small_kernel(const float *__restrict__
 
 // One launch instead of ~15 tiny tensor ops per BatchNorm site and direction.
 // forward: (sum, sumsq, count) f64 -> mean, rstd, folded scale/shift; running buffers updated with decay `momentum`
-// (left alone when count == 0: a rank that holds only padding clouds).
+// (left alone when count == 0: a rank that holds only padding clouds); `unbiased`: the moving variance takes the
+// Bessel-corrected batch variance (tf.nn.fused_batch_norm), else the biased one (slim batch_norm with fused=False).
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double *__restrict__ sum, const double *__restrict__ sumsq,
                                                          const double *__restrict__ cnt, const float *__restrict__ gamma,
                                                          const float *__restrict__ beta, float eps, float momentum,
-                                                         float *__restrict__ run_mean, float *__restrict__ run_var, int C,
+                                                         int unbiased, float *__restrict__ run_mean,
+                                                         float *__restrict__ run_var, int C,
                                                          float *__restrict__ mean, float *__restrict__ rstd,
                                                          float *__restrict__ scale, float *__restrict__ shift) {
   const int c = blockIdx.x * 256 + threadIdx.x;
@@ -260,7 +264,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double *__restri
   mean[c] = (float)mu; rstd[c] = rs; scale[c] = sc; shift[c] = beta[c] - (float)mu * sc;
   if (cnt[0] > 0.0) {
     run_mean[c] = momentum * run_mean[c] + (1.f - momentum) * (float)mu;
-    run_var[c] = momentum * run_var[c] + (1.f - momentum) * (float)var;
+    const double uv = unbiased && n > 1.0 ? var * (n / (n - 1.0)) : var;
+    run_var[c] = momentum * run_var[c] + (1.f - momentum) * (float)uv;
   }
 }
 // backward: (S1, S2, count) f64 (+ mean, rstd, gamma) -> k2, k3 of bn_bwd_apply
@@ -625,11 +630,12 @@ DH3D_API int dh3d_bn_bwd_apply(const float *x, const float *dy, const float *row
 }
 
 DH3D_API int dh3d_bn_finalize(const double *sum, const double *sumsq, const double *count, const float *gamma,
-                              const float *beta, float eps, float momentum, float *run_mean, float *run_var, int C,
-                              float *mean, float *rstd, float *scale, float *shift, void *stream) {
+                              const float *beta, float eps, float momentum, int unbiased, float *run_mean,
+                              float *run_var, int C, float *mean, float *rstd, float *scale, float *shift,
+                              void *stream) {
   DH3D_REQUIRE(sum && sumsq && count && gamma && beta && run_mean && run_var && mean && rstd && scale && shift && C > 0);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(dh3d_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sum, sumsq, count,
-                     gamma, beta, eps, momentum, run_mean, run_var, C, mean, rstd, scale, shift);
+                     gamma, beta, eps, momentum, unbiased, run_mean, run_var, C, mean, rstd, scale, shift);
   return dh3d_launch_status();
 }
 
@@ -731,12 +737,12 @@ DH3D_API int dh3d_quadruplet_loss(const float *desc, int B, int P, int Ng, int D
 // Short tensors (R <= 64): training-mode BatchNorm (+ReLU) forward in ONE launch -- y [R,C], stats [4,C] = mean, rstd,
 // scale, shift (for the backward), running buffers updated; mask [R] bytes or NULL (every row its own cloud).
 DH3D_API int dh3d_bn_small_fwd(const float *x, int R, int C, const float *gamma, const float *beta, float eps,
-                               float momentum, int relu, const unsigned char *mask, float *run_mean, float *run_var,
-                               float *stats, float *y, void *stream) {
+                               float momentum, int unbiased, int relu, const unsigned char *mask, float *run_mean,
+                               float *run_var, float *stats, float *y, void *stream) {
   DH3D_REQUIRE(x && gamma && beta && run_mean && run_var && stats && y && R > 0 && C > 0);
   DH3D_SUPPORTED(R <= 64);
   hipLaunchKernelGGL(bn_small_kernel<false>, dim3(dh3d_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, x, nullptr, R, C,
-                     gamma, beta, eps, momentum, relu, mask, run_mean, run_var, stats, y, nullptr, nullptr);
+                     gamma, beta, eps, momentum, unbiased, relu, mask, run_mean, run_var, stats, y, nullptr, nullptr);
   return dh3d_launch_status();
 }
 
@@ -747,6 +753,6 @@ DH3D_API int dh3d_bn_small_bwd(const float *x, const float *dy, int R, int C, co
   DH3D_REQUIRE(x && dy && gamma && stats && dx && dgamma && dbeta && R > 0 && C > 0);
   DH3D_SUPPORTED(R <= 64);
   hipLaunchKernelGGL(bn_small_kernel<true>, dim3(dh3d_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, x, dy, R, C, gamma,
-                     nullptr, 0.f, 0.f, relu, mask, nullptr, nullptr, const_cast<float *>(stats), dx, dgamma, dbeta);
+                     nullptr, 0.f, 0.f, 0, relu, mask, nullptr, nullptr, const_cast<float *>(stats), dx, dgamma, dbeta);
   return dh3d_launch_status();
 }

@@ -653,12 +653,13 @@ def bn_colstats(x, mask=None, rows_per_cloud=0, out=None):
     return s1, s2
 
 
-def bn_finalize(s1, s2, cnt, gamma, beta, eps, momentum, run_mean, run_var):
-    """(sum, sumsq, count) -> [mean, rstd, scale, shift] as rows of one [4, C] float32 tensor; running buffers updated."""
+def bn_finalize(s1, s2, cnt, gamma, beta, eps, momentum, run_mean, run_var, unbiased=True):
+    """(sum, sumsq, count) -> [mean, rstd, scale, shift] as rows of one [4, C] float32 tensor; running buffers updated
+    (unbiased: the moving variance takes the Bessel-corrected batch variance, as tf.nn.fused_batch_norm feeds it)."""
     C = gamma.numel()
     o = torch.empty((4, C), dtype=torch.float32, device=gamma.device)
     L.check(L.lib().dh3d_bn_finalize(L.ptr(s1), L.ptr(s2), L.ptr(cnt), L.ptr(gamma), L.ptr(beta), float(eps),
-                                     float(momentum), L.ptr(run_mean), L.ptr(run_var), C, L.ptr(o[0]), L.ptr(o[1]),
+                                     float(momentum), 1 if unbiased else 0, L.ptr(run_mean), L.ptr(run_var), C, L.ptr(o[0]), L.ptr(o[1]),
                                      L.ptr(o[2]), L.ptr(o[3]), L.stream_ptr()), "bn_finalize")
     return o
 

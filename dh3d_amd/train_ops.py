@@ -34,7 +34,11 @@ def _count(R, mask, rows_per_cloud, device):
     if mask is None:
         key = (str(device), int(R))
         if key not in _CNT:
-            _CNT[key] = torch.tensor([float(R)], dtype=torch.float64, device=device)
+            if torch.cuda.is_current_stream_capturing():
+                # first sight of this row count inside a graph capture: a fill on the device (no pageable host copy,
+                # which a capturing stream refuses) and NOT cached -- the tensor lives in the graph's private pool
+                return torch.full((1,), float(R), dtype=torch.float64, device=device)
+            _CNT[key] = torch.full((1,), float(R), dtype=torch.float64, device=device)
         return _CNT[key]
     return (mask.sum().to(torch.float64) * float(rows_per_cloud)).reshape(1)
 
@@ -44,7 +48,7 @@ class _BNState(object):
     __slots__ = ("stats", "cnt")
 
 
-def _forward_stats(x, gamma, beta, run_mean, run_var, eps, momentum, mask, rows_per_cloud, sync):
+def _forward_stats(x, gamma, beta, run_mean, run_var, eps, momentum, mask, rows_per_cloud, sync, unbiased=True):
     """Two launches (+ the all-reduce under sync-BN): column sums, then the finalize kernel."""
     C = x.shape[1]
     packed = torch.empty((2 * C + 1,), dtype=torch.float64, device=x.device)
@@ -55,7 +59,7 @@ def _forward_stats(x, gamma, beta, run_mean, run_var, eps, momentum, mask, rows_
         D.all_reduce_sum_(packed)
         cnt = packed[2 * C:]
     st = _BNState()
-    st.stats = pm.bn_finalize(s1, s2, cnt, gamma, beta, eps, momentum, run_mean, run_var)
+    st.stats = pm.bn_finalize(s1, s2, cnt, gamma, beta, eps, momentum, run_mean, run_var, unbiased)
     st.cnt = cnt
     return st
 
@@ -72,10 +76,10 @@ def _backward_coeffs(S, st, gamma, sync):
 
 class _BatchNormTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, run_mean, run_var, eps, momentum, relu, sync, mask, rows_per_cloud):
+    def forward(ctx, x, gamma, beta, run_mean, run_var, eps, momentum, relu, sync, mask, rows_per_cloud, unbiased):
         x = x.contiguous()
         g, be = gamma.detach().contiguous(), beta.detach().contiguous()
-        st = _forward_stats(x, g, be, run_mean, run_var, eps, momentum, mask, rows_per_cloud, sync)
+        st = _forward_stats(x, g, be, run_mean, run_var, eps, momentum, mask, rows_per_cloud, sync, unbiased)
         y = pm.scale_shift_act(x, st.stats[2], st.stats[3], relu)
         ctx.save_for_backward(x, g, be)
         ctx.cfg = (bool(relu), bool(sync), mask, int(rows_per_cloud), st)
@@ -89,14 +93,14 @@ class _BatchNormTrain(torch.autograd.Function):
         S = pm.bn_bwd_sums(x, st.stats[0], st.stats[1], g, be, relu, dy=dy, mask=mask, rows_per_cloud=rpc)
         dgamma, dbeta, k = _backward_coeffs(S, st, g, sync)
         dx = pm.bn_bwd_apply(x, st.stats[2], st.stats[3], k[0], k[1], relu, dy=dy, mask=mask, rows_per_cloud=rpc)
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
 class _BatchNormTrainSmall(torch.autograd.Function):
     """_BatchNormTrain for a short tensor (R <= 64 rows, one row per cloud): one launch per direction."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, run_mean, run_var, eps, momentum, relu, mask):
+    def forward(ctx, x, gamma, beta, run_mean, run_var, eps, momentum, relu, mask, unbiased):
         from . import _lib as L
         x = x.contiguous()
         R, C = x.shape
@@ -105,7 +109,7 @@ class _BatchNormTrainSmall(torch.autograd.Function):
         y = torch.empty_like(x)
         m8 = pm._mask_u8(mask)
         L.check(L.lib().dh3d_bn_small_fwd(L.ptr(x), R, C, L.ptr(g), L.ptr(be), float(eps), float(momentum),
-                                          1 if relu else 0, L.ptr(m8), L.ptr(run_mean), L.ptr(run_var), L.ptr(stats),
+                                          1 if unbiased else 0, 1 if relu else 0, L.ptr(m8), L.ptr(run_mean), L.ptr(run_var), L.ptr(stats),
                                           L.ptr(y), L.stream_ptr()), "bn_small_fwd")
         ctx.save_for_backward(x, g, stats)
         ctx.cfg = (bool(relu), m8)
@@ -122,20 +126,23 @@ class _BatchNormTrainSmall(torch.autograd.Function):
         dgb = torch.empty((2, C), dtype=torch.float32, device=x.device)
         L.check(L.lib().dh3d_bn_small_bwd(L.ptr(x), L.ptr(dy), R, C, L.ptr(g), L.ptr(stats), 1 if relu else 0, L.ptr(m8),
                                           L.ptr(dx), L.ptr(dgb[0]), L.ptr(dgb[1]), L.stream_ptr()), "bn_small_bwd")
-        return dx, dgb[0], dgb[1], None, None, None, None, None, None
+        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None
 
 
 def batch_norm_train(x, bnmod, relu, sync=False, mask=None, rows_per_cloud=0, momentum=None):
     """x [R, C] -> act(BN_train(x)); bnmod: backbones.TPBatchNorm / SlimBatchNorm (running buffers updated in place:
-    decay 0.9 / 0.999 like tensorpack / slim).  mask [clouds] bool with rows_per_cloud rows each, or None."""
+    decay 0.9 / 0.999 like tensorpack / slim; the moving variance takes the Bessel-corrected batch variance where the
+    upstream layer is a fused batch norm -- bnmod.ema_unbiased).  mask [clouds] bool with rows_per_cloud rows each, or
+    None."""
     from . import backbones as bb
     tp = isinstance(bnmod, bb.TPBatchNorm)
     rm, rv = (bnmod.mean_EMA, bnmod.variance_EMA) if tp else (bnmod.moving_mean, bnmod.moving_variance)
     mom = momentum if momentum is not None else (0.9 if tp else 0.999)
+    unb = bool(getattr(bnmod, "ema_unbiased", True))
     if x.shape[0] <= 64 and (mask is None or rows_per_cloud == 1) and not (sync and _world() > 1):
         # the [clouds, C] activations behind NetVLAD: one launch per direction (single rank or per-rank statistics)
-        return _BatchNormTrainSmall.apply(x, bnmod.gamma, bnmod.beta, rm, rv, bnmod.eps, mom, relu, mask)
-    return _BatchNormTrain.apply(x, bnmod.gamma, bnmod.beta, rm, rv, bnmod.eps, mom, relu, sync, mask, rows_per_cloud)
+        return _BatchNormTrainSmall.apply(x, bnmod.gamma, bnmod.beta, rm, rv, bnmod.eps, mom, relu, mask, unb)
+    return _BatchNormTrain.apply(x, bnmod.gamma, bnmod.beta, rm, rv, bnmod.eps, mom, relu, sync, mask, rows_per_cloud, unb)
 
 
 class _Linear(torch.autograd.Function):
@@ -402,7 +409,8 @@ class _NetVLADAssign(torch.autograd.Function):
         xn = pm.l2norm_concat(x2, 1e-12)                                   # tf.nn.l2_normalize(reshaped_input, 1)
         s = pm.gemm_nn(xn, Wc.detach().contiguous())                       # [R, Cl]
         g, be = gamma.detach().contiguous(), beta.detach().contiguous()
-        st = _forward_stats(s, g, be, run_mean, run_var, eps, momentum, mask, N, sync)
+        # cluster_bn is the one un-fused batch norm upstream (core/backbones.py:218-223): biased moving variance
+        st = _forward_stats(s, g, be, run_mean, run_var, eps, momentum, mask, N, sync, unbiased=False)
         scale, shift = st.stats[2], st.stats[3]
         att = att.contiguous()
         if N % 64 == 0:   # softmax(bn(s)) * att, and its per-cloud column sums from the same pass

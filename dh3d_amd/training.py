@@ -54,9 +54,11 @@ class _AllReduceSum(torch.autograd.Function):
         return D.all_reduce_sum_(grad.clone())
 
 
-def _batch_norm_train(x, channel_dim, gamma, beta, run_mean, run_var, eps, momentum, sync_bn, mask=None):
+def _batch_norm_train(x, channel_dim, gamma, beta, run_mean, run_var, eps, momentum, sync_bn, mask=None, unbiased=True):
     """Training-mode BatchNorm over all dims but `channel_dim`; updates the running buffers in place.
-    `momentum` is the EMA decay (tensorpack 0.9, slim 0.999).  `mask` ([leading] bool) drops padding clouds."""
+    `momentum` is the EMA decay (tensorpack 0.9, slim 0.999); `unbiased`: the moving variance takes the
+    Bessel-corrected batch variance (tf.nn.fused_batch_norm) -- every site but cluster_bn.  `mask` ([leading] bool)
+    drops padding clouds."""
     dims = [d for d in range(x.dim()) if d != channel_dim]
     shape = [1] * x.dim()
     shape[channel_dim] = -1
@@ -83,7 +85,8 @@ def _batch_norm_train(x, channel_dim, gamma, beta, run_mean, run_var, eps, momen
     with torch.no_grad():
         keep = empty.to(mean.dtype)  # 1 -> buffers unchanged
         run_mean.copy_(keep * run_mean + (1 - keep) * (momentum * run_mean + (1 - momentum) * mean.detach()))
-        run_var.copy_(keep * run_var + (1 - keep) * (momentum * run_var + (1 - momentum) * var.detach()))
+        uvar = var.detach() * (cnt / (cnt - 1).clamp_min(1.0)) if unbiased else var.detach()
+        run_var.copy_(keep * run_var + (1 - keep) * (momentum * run_var + (1 - momentum) * uvar))
     return (x - mean.reshape(shape)) * torch.rsqrt(var.reshape(shape) + eps) * gamma.reshape(shape) + beta.reshape(shape)
 
 
@@ -92,11 +95,62 @@ def _bn(x, channel_dim, bnmod, training, sync_bn, mask):
     rm, rv = (bnmod.mean_EMA, bnmod.variance_EMA) if tp else (bnmod.moving_mean, bnmod.moving_variance)
     if training:
         return _batch_norm_train(x, channel_dim, bnmod.gamma, bnmod.beta, rm, rv, bnmod.eps, 0.9 if tp else 0.999,
-                                 sync_bn, mask)
+                                 sync_bn, mask, bool(getattr(bnmod, "ema_unbiased", True)))
     shape = [1] * x.dim()
     shape[channel_dim] = -1
     return (x - rm.reshape(shape)) * torch.rsqrt(rv.reshape(shape) + bnmod.eps) * bnmod.gamma.reshape(shape) + \
         bnmod.beta.reshape(shape)
+
+
+@torch.no_grad()
+def backbone_local_batch_stats(model, points, geo, sync_bn=False, mask=None):
+    """The FROZEN local backbone as the reference runs it while global_config trains (core/backbones.py:104-127 under
+    core/tf_utils.py:145-153 freeze_variables(stop_gradient=False, skip_collection=True)): frozen means 'not in the
+    TRAINABLE collection' -- every BatchNorm still normalises with the statistics of the batch and updates its moving
+    averages.  Layer by layer on the fused kernels WITHOUT their folded BatchNorm epilogues (raw flex_conv /
+    conv_pointset / pooling outputs from HIP, the 1x1 convs, SE block and BatchNorm as tensor ops); the default
+    trainer uses the fused inference path with moving averages instead (a documented deviation),
+    this is `QuadrupletTrainer(backbone_bn="batch")`, compared with the oracle's training-mode graph in the tests.
+    Returns (localdesc [b,N,128], geometry level)."""
+    from . import pm
+
+    def bn_relu(x, bnmod, rows_dim):
+        return F.relu(_batch_norm_train(x, rows_dim, bnmod.gamma, bnmod.beta, bnmod.mean_EMA, bnmod.variance_EMA,
+                                        bnmod.eps, 0.9, sync_bn, mask, True))
+
+    def conv_bnrelu(x, fc1d):
+        conv = fc1d.tfconv0
+        return bn_relu(x @ conv.W.reshape(conv.cin, conv.cout) + conv.b, conv.bn, 2)
+
+    def flex_stack(mod, x, xyz, nbr):
+        for i in range(len(mod.outdims)):
+            fc, bn = getattr(mod, "flexconv_%d" % i), getattr(mod, "flexconv_%d_bn" % i)
+            y = pm.flex_conv(x.contiguous(), xyz, nbr, pm.pack_flex_weight(fc.position_theta.detach(),
+                                                                             fc.position_bias.detach()), fc.cout)
+            x = bn_relu(y + fc.feature_bias.reshape(1, 1, -1), bn, 2)
+        pool = pm.flex_pool(x.contiguous(), nbr)                                       # backbones.py:76-79
+        se = mod.se
+        sq = F.relu(pool @ se.f1.tfconv0.W.reshape(se.channels, -1) + se.f1.tfconv0.b)
+        sq = torch.sigmoid(sq @ se.f2.tfconv0.W.reshape(-1, se.channels) + se.f2.tfconv0.b)
+        return F.relu(x + x * sq)                                                       # backbones.py:45-55
+
+    if model._local.featdim < 128 or model.stage1.add_se != "max_pool":
+        raise NotImplementedError("backbone_bn='batch' covers the shipped backbone (featdim 128, max-pool SE)")
+    model._join_side(geo)  # the kNN of the full cloud runs on the geometry's side stream
+    nn_8 = geo.nbr if geo.nbr.shape[2] == 8 else geo.nbr[:, :, 0:8].contiguous()
+    ic = model.initconv
+    init = pm.conv_pointset_xyz(geo.xyz, nn_8, ic.position_theta.detach().contiguous(), ic.position_bias.detach().contiguous())
+    init = pm.flex_pool(bn_relu(init, model.initconv_bn, 2).contiguous(), nn_8)
+    x1 = flex_stack(model.stage1, init, geo.xyz, nn_8)
+    x2 = conv_bnrelu(x1, model.before_stage2_conv1d)
+    lv = geo.level(8, model.knn_num)
+    s2 = model.stage2
+    feat_s = bb.gather_rows(x2.contiguous(), lv["idx"])
+    y = flex_stack(s2, feat_s, lv["xyz_s"], lv["nbr_s"])
+    up = ops.three_interpolate(y.contiguous(), lv["nn3_idx"], pm.idw_weights(lv["nn3_dist"]).contiguous())
+    x2 = conv_bnrelu(torch.cat([up, x2], 2), s2.concat_conv1d)
+    feat = conv_bnrelu(x1, model.local_stage1_shortcut) + x2
+    return feat.contiguous(), lv
 
 
 class _FlexConvFactorised(torch.autograd.Function):
@@ -290,15 +344,21 @@ class QuadrupletTrainer(object):
     every rank, e.g. generated from a shared seed), runs this rank's block and returns the loss."""
 
     def __init__(self, model, start_lr=None, decay_step=None, decay_rate=None, weight_decay=None, sync_bn=True,
-                 impl="hip", graph_backbone=True, graph_step=None):
+                 impl="hip", graph_backbone=True, graph_step=None, backbone_bn="ema"):
         """Schedule / weight decay default to the model's config (core/configs.py:50-54,115-117).  sync_bn=True (the
         default) reproduces the reference's whole-batch BatchNorm statistics under sharding -- and keeps the running
         buffers identical on every rank; sync_bn=False normalises with per-rank statistics (a few clouds of one role
-        each under the contiguous role-ordered partition) and lets the buffers diverge."""
+        each under the contiguous role-ordered partition) and lets the buffers diverge.
+        backbone_bn: "ema" (default) -- the frozen backbone runs the fused inference path on its moving averages;
+        "batch" -- it normalises with batch statistics and updates its moving averages, which is what the reference
+        graph does while global_config trains (backbone_local_batch_stats; slower, un-fused)."""
+        if backbone_bn not in ("ema", "batch"):
+            raise ValueError("backbone_bn must be 'ema' or 'batch'")
         self.model = model
         self.cfg = model.config
         self.impl = impl          # "hip": train_ops kernels; "torch": the plain-torch restatement (test reference)
-        self.graph_backbone = graph_backbone and impl == "hip"
+        self.backbone_bn = backbone_bn
+        self.graph_backbone = graph_backbone and impl == "hip" and backbone_bn == "ema"
         self._bb_graphs = {}
         self.keep_grads, self.last_grads = False, None
         self._ev = None
@@ -322,6 +382,8 @@ class QuadrupletTrainer(object):
         self._sched = (float(start_lr), int(decay_step), float(decay_rate))
         self._steps_done = 0
         self._step_graphs = {}
+        self._eager_seen = {}   # batch shape -> eager steps run on it (every shape warms up before its capture)
+        self.keep_desc, self.last_desc = False, None
         if self.graph_step:
             dev = self.params[0].device
             self._lr = torch.tensor(float(start_lr), dtype=torch.float32, device=dev)
@@ -338,11 +400,16 @@ class QuadrupletTrainer(object):
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         Bt = points.shape[0]
         block, mask = D.shard_batch(points, rank, world)
-        self.model.eval()  # frozen backbone: fused inference path
-        localdesc, lv = self._backbone(block)
-        self._mark(1)
         start, stop = D.local_slice(Bt, rank, world)
         m = mask if (stop - start) < block.shape[0] else None  # (known on the host: no device round trip)
+        self.model.eval()
+        if self.backbone_bn == "batch":  # the reference's semantics: batch statistics + moving-average updates
+            geo = self.model._geometry(block, None)
+            localdesc, lv = backbone_local_batch_stats(self.model, block, geo, self.sync_bn, m)
+            self.model.invalidate()  # the folded copies of the backbone's moving averages are stale now
+        else:  # frozen backbone on the fused inference path (moving averages)
+            localdesc, lv = self._backbone(block)
+        self._mark(1)
         if self.impl == "hip":
             desc = global_head_hip(self.model, block, localdesc.detach(), lv, sync_bn=self.sync_bn, mask=m)
         else:
@@ -355,6 +422,8 @@ class QuadrupletTrainer(object):
         else:
             desc = desc * torch.rsqrt(torch.clamp((desc * desc).sum(1, keepdim=True), min=1e-8))
         full = _AllGatherKeepOwn.apply(desc)[:Bt]
+        if self.keep_desc:  # tests: the gathered, l2-normalised descriptors of this step
+            self.last_desc = full.detach().clone()
         if self.impl == "hip" and T.quadruplet_loss_supported(full, cfg.num_pos, cfg.num_neg):
             return T.quadruplet_loss(full.contiguous(), cfg.batch_size, cfg.num_pos, cfg.num_neg, m1, m2)
         return losses.lazy_quadruplet_loss(full, cfg.batch_size, cfg.num_pos, cfg.num_neg, m1, m2)
@@ -436,15 +505,22 @@ class QuadrupletTrainer(object):
             static_in = points.clone()
             self.opt.zero_grad(set_to_none=True)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                loss = self.forward_loss(static_in)
-                loss.backward()
-                if self.wd_params and self.weight_decay:
-                    gs = [p.grad for p in self.wd_params if p.grad is not None]
-                    ps = [p.detach() for p in self.wd_params if p.grad is not None]
-                    if gs:
-                        torch._foreach_add_(gs, ps, alpha=self.weight_decay)
-                self.opt.step()
+            try:
+                with torch.cuda.graph(graph):
+                    loss = self.forward_loss(static_in)
+                    loss.backward()
+                    if self.wd_params and self.weight_decay:
+                        gs = [p.grad for p in self.wd_params if p.grad is not None]
+                        ps = [p.detach() for p in self.wd_params if p.grad is not None]
+                        if gs:
+                            torch._foreach_add_(gs, ps, alpha=self.weight_decay)
+                    self.opt.step()
+            except RuntimeError:
+                # something in this shape's step cannot be captured: stay eager for good (the parameters are untouched --
+                # a capture records, it does not run)
+                self.graph_step = False
+                self.opt.zero_grad(set_to_none=True)
+                return None
             ent = (graph, static_in, loss)
             self._step_graphs[key] = ent
         graph, static_in, loss = ent
@@ -456,9 +532,15 @@ class QuadrupletTrainer(object):
         return float(loss.detach())
 
     def step(self, points):
-        # eager for the first steps, while phases are timed or gradients are kept for inspection
-        if self.graph_step and self._steps_done >= 3 and self._ev is None and not self.keep_grads:
-            return self._step_graphed(points)
+        # eager for the first steps ON EVERY BATCH SHAPE (allocator / autograd / lazily built constants warm up before
+        # the capture), while phases are timed or gradients / descriptors are kept for inspection
+        shape = (tuple(points.shape), points.device)
+        if (self.graph_step and self._eager_seen.get(shape, 0) >= 3 and self._ev is None and not self.keep_grads
+                and not self.keep_desc):
+            out = self._step_graphed(points)
+            if out is not None:
+                return out
+        self._eager_seen[shape] = self._eager_seen.get(shape, 0) + 1
         if self.graph_step:
             self._lr.fill_(self._lr_now())
         self.opt.zero_grad(set_to_none=True)

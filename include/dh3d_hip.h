@@ -444,8 +444,10 @@ int dh3d_bn_bwd_apply(const float *x, const float *dy, const float *rowscale, co
                       const float *scale, const float *shift, const float *k2, const float *k3, int relu,
                       const unsigned char *mask, int rows_per_cloud, float *dx, void *stream);
 int dh3d_bn_finalize(const double *sum, const double *sumsq, const double *count /* device scalar */,
-                     const float *gamma, const float *beta, float eps, float momentum, float *run_mean, float *run_var,
-                     int C, float *mean, float *rstd, float *scale, float *shift, void *stream);
+                     const float *gamma, const float *beta, float eps, float momentum,
+                     int unbiased /* moving variance <- Bessel-corrected batch variance (fused_batch_norm) */,
+                     float *run_mean, float *run_var, int C, float *mean, float *rstd, float *scale, float *shift,
+                     void *stream);
 int dh3d_bn_bwd_finalize(const double *S1, const double *S2, const double *count, const float *mean, const float *rstd,
                          const float *gamma, int C, float *k2, float *k3, void *stream);
 
@@ -508,8 +510,8 @@ int dh3d_quadruplet_loss(const float *desc, int B, int P, int Ng, int D, float m
 /* training-mode BatchNorm (+ReLU) of a short tensor (R <= 64 rows, e.g. the [clouds, 256] activations behind NetVLAD) in
  * one launch per direction; stats [4,C] = mean, rstd, scale, shift of the forward; mask [R] bytes or NULL. */
 int dh3d_bn_small_fwd(const float *x, int R, int C, const float *gamma, const float *beta, float eps, float momentum,
-                      int relu, const unsigned char *mask, float *run_mean, float *run_var, float *stats, float *y,
-                      void *stream);
+                      int unbiased, int relu, const unsigned char *mask, float *run_mean, float *run_var, float *stats,
+                      float *y, void *stream);
 int dh3d_bn_small_bwd(const float *x, const float *dy, int R, int C, const float *gamma, const float *stats, int relu,
                       const unsigned char *mask, float *dx, float *dgamma, float *dbeta, void *stream);
 /* batched GEMMs: `batch` independent products on operands stored back to back; colbias [batch, N] (nn only). */

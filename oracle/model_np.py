@@ -4,24 +4,69 @@ Follows the reference's Python graph code line by line, in the reference's own t
 its transposes), calling the C oracle for the custom ops:
     core/model.py:135-210 (build_graph), core/backbones.py:45-127,156-320, core/tf_utils.py:48-109.
 Weights come in as a dict keyed by TensorFlow variable name (models/*/*.index naming), so this file
-shares no code with dh3d_amd.  BatchNorm is inference mode; the third-party epsilons (tensorpack
-1e-5, slim 1e-3) are parameters -- PARITY UNPINNED at that boundary.
+shares no code with dh3d_amd.  The third-party BatchNorm constants (tensorpack: eps 1e-5, EMA decay 0.9;
+slim / contrib.layers: eps 1e-3, decay 0.999) are parameters -- PARITY UNPINNED at that boundary (see
+DESIGN.md): neither library is in the reference tree.
 Dense algebra runs in float32 numpy (matmul order differs from TF; tolerance 1e-4 covers it).
+
+Training mode (`train` = a TrainState; core/model.py:135-255 under global_config, BASELINE config 4):
+every BatchNorm normalises with the statistics of the WHOLE batch it is given (biased variance) and records
+the update of its moving buffers in train.updates.  tensorpack's BatchNorm on the rank-4 conv / flex_conv
+outputs (core/tf_utils.py:61,80,99-109) and contrib.layers.batch_norm on rank-2 input ('bn', 'gating_bn':
+fused=None -> fused; core/backbones.py:271-274,304-309) go through tf.nn.fused_batch_norm, whose moving-variance
+update takes the Bessel-corrected batch variance (n / (n - 1)); 'cluster_bn' is fused=False upstream
+(core/backbones.py:218-223) and updates with the biased one.  The FROZEN local backbone of global_config
+(core/configs.py:112-113) is frozen by freeze_variables(stop_gradient=False, skip_collection=True)
+(core/tf_utils.py:145-153): its variables leave the TRAINABLE collection, but its BatchNorm layers still see
+training=True -- batch statistics and moving-average updates; `train.backbone_batch_stats=False` selects the
+moving averages there instead (what dh3d_amd's default trainer does, a documented deviation).
 """
 import numpy as np
 
 from . import cpu as O
 
 
-def _bn(x, w, scope, axis, eps, names=("gamma", "beta", "mean/EMA", "variance/EMA")):
+class TrainState(object):
+    """Training-mode switch of the graph: batch statistics in every BatchNorm it reaches, moving-buffer updates
+    collected in `updates` (TF variable name -> new value).  mask [Bt] bool (optional): clouds that count (padding
+    clouds of a sharded block are left out of the statistics)."""
+
+    def __init__(self, tp_decay=0.9, slim_decay=0.999, backbone_batch_stats=True, mask=None):
+        self.tp_decay, self.slim_decay = tp_decay, slim_decay
+        self.backbone_batch_stats = backbone_batch_stats
+        self.mask = mask
+        self.updates = {}
+
+
+def _bn(x, w, scope, axis, eps, names=("gamma", "beta", "mean/EMA", "variance/EMA"), train=None, decay=0.9,
+        bessel=True, rows_per_cloud=None):
+    """Inference: moving averages.  Training (train = TrainState): statistics over every axis but `axis` in float64
+    (biased variance), moving buffers <- decay * old + (1 - decay) * batch value (variance Bessel-corrected when the
+    upstream layer is a fused batch norm)."""
     shape = [1] * x.ndim
     shape[axis] = -1
     g, b, m, v = [w["%s/%s" % (scope, n)].reshape(shape) for n in names]
+    if train is not None:
+        axes = tuple(a for a in range(x.ndim) if a != axis)
+        xs = x.astype(np.float64)
+        if train.mask is not None:  # leading axis = clouds (or clouds * rows_per_cloud flattened rows)
+            mk = np.asarray(train.mask, bool)
+            if rows_per_cloud is not None:
+                mk = np.repeat(mk, rows_per_cloud)
+            xs = xs[mk]
+        n = xs.size // xs.shape[axis]
+        mu = xs.mean(axis=axes)
+        var = xs.var(axis=axes)
+        train.updates["%s/%s" % (scope, names[2])] = (decay * m.reshape(-1) + (1 - decay) * mu).astype(np.float32)
+        uvar = var * (n / max(n - 1, 1)) if bessel else var
+        train.updates["%s/%s" % (scope, names[3])] = (decay * v.reshape(-1) + (1 - decay) * uvar).astype(np.float32)
+        m, v = mu.astype(np.float32).reshape(shape), var.astype(np.float32).reshape(shape)
     return (x - m) / np.sqrt(v + np.float32(eps)) * g + b
 
 
-def _slim_bn(x, w, scope, eps):
-    return _bn(x, w, scope, x.ndim - 1, eps, names=("gamma", "beta", "moving_mean", "moving_variance"))
+def _slim_bn(x, w, scope, eps, train=None, bessel=True, rows_per_cloud=None):
+    return _bn(x, w, scope, x.ndim - 1, eps, names=("gamma", "beta", "moving_mean", "moving_variance"), train=train,
+               decay=train.slim_decay if train is not None else 0.999, bessel=bessel, rows_per_cloud=rows_per_cloud)
 
 
 def _relu(x):
@@ -32,12 +77,12 @@ def _sigmoid(x):
     return (1.0 / (1.0 + np.exp(-x.astype(np.float64)))).astype(np.float32)
 
 
-def _conv1x1(x, w, scope, bn_eps=None, act=None):
+def _conv1x1(x, w, scope, bn_eps=None, act=None, train=None):
     """tensorpack Conv2D(kernel 1) on channels-last x [..., Cin]; scope holds W [1,1,Cin,Cout], b, bn/*."""
     W = w[scope + "/W"].reshape(w[scope + "/W"].shape[2], -1)
     y = x @ W + w[scope + "/b"]
     if bn_eps is not None:
-        y = _bn(y, w, scope + "/bn", y.ndim - 1, bn_eps)
+        y = _bn(y, w, scope + "/bn", y.ndim - 1, bn_eps, train=train, decay=train.tp_decay if train is not None else 0.9)
     if act is not None:
         y = act(y)
     return y.astype(np.float32)
@@ -54,12 +99,13 @@ def knn_bruteforce_layer(points_T, k):
     return np.ascontiguousarray(nn.transpose(0, 2, 1)), np.ascontiguousarray(dist.transpose(0, 2, 1))
 
 
-def flexconv_bn(feats_T, points_T, nn, w, scope, eps):
+def flexconv_bn(feats_T, points_T, nn, w, scope, eps, train=None):
     """flexconv_withBatchnorm, core/tf_utils.py:48-64 (+ feature_bias, core/layers.py:330-331)."""
     x = O.flex_convolution(feats_T, points_T, nn, w[scope + "/position_theta"], w[scope + "/position_bias"],
                            center_self=True)
     x = x + w[scope + "/feature_bias"].reshape(1, -1, 1)
-    return _relu(_bn(x, w, scope + "_bn", 1, eps)).astype(np.float32)
+    return _relu(_bn(x, w, scope + "_bn", 1, eps, train=train,
+                     decay=train.tp_decay if train is not None else 0.9)).astype(np.float32)
 
 
 def se_res_bottleneck(l, pool_l, w, scope):
@@ -79,7 +125,7 @@ def subsample(points, feat, targetnum):
 
 
 def flex_conv_dilate(xyz, feat, dilate, knn, outdims, scope, w, eps, knn_indices=None, concat=True,
-                     add_se="max_pool", upsample=True, trace=None):
+                     add_se="max_pool", upsample=True, trace=None, train=None):
     """core/backbones.py:58-101.  trace (dict or None): receives the block's integer intermediates
     ('<scope>/fps_idx' [B,m], '<scope>/knn' [B,K,m], '<scope>/nn3_idx' [B,N,3], '<scope>/nn3_dist')."""
     N = xyz.shape[1]
@@ -97,7 +143,7 @@ def flex_conv_dilate(xyz, feat, dilate, knn, outdims, scope, w, eps, knn_indices
             trace[scope + "/knn"] = knn_indices
     x = feats_T
     for i, d in enumerate(outdims):
-        x = flexconv_bn(x, points_T, knn_indices, w, "%s/flexconv_%d" % (scope, i), eps)
+        x = flexconv_bn(x, points_T, knn_indices, w, "%s/flexconv_%d" % (scope, i), eps, train=train)
     if add_se == "max_pool":
         x_pool, _ = O.flex_pooling(x, knn_indices)
         x = se_res_bottleneck(x, x_pool, w, scope + "/se")
@@ -118,49 +164,52 @@ def flex_conv_dilate(xyz, feat, dilate, knn, outdims, scope, w, eps, knn_indices
         new_feat = O.three_interpolate(new_feat, idx, weight.astype(np.float32))
     if concat:
         new_feat = np.concatenate([new_feat, feat], axis=2)
-        new_feat = _conv1x1(new_feat, w, scope + "/concat_conv1d/tfconv0", bn_eps=eps, act=_relu)
+        new_feat = _conv1x1(new_feat, w, scope + "/concat_conv1d/tfconv0", bn_eps=eps, act=_relu, train=train)
     return xyz, new_feat
 
 
-def backbone_local_dilate(points, knn_ind, w, eps, trace=None, featdim=128, add_se="max_pool"):
+def backbone_local_dilate(points, knn_ind, w, eps, trace=None, featdim=128, add_se="max_pool", train=None):
     """core/backbones.py:104-127 (add_se is 'max_pool' upstream; a parameter here to exercise :80-83)."""
     nn_8 = np.ascontiguousarray(knn_ind[:, 0:8, :])
     pts_T = np.ascontiguousarray(points.transpose(0, 2, 1))
     init = O.convolution_pointset(pts_T, nn_8, w["initconv/position_theta"], w["initconv/position_bias"])
-    init = _relu(_bn(init, w, "initconv_bn", 1, eps)).astype(np.float32)
+    init = _relu(_bn(init, w, "initconv_bn", 1, eps, train=train,
+                     decay=train.tp_decay if train is not None else 0.9)).astype(np.float32)
     init, _ = O.flex_pooling(init, nn_8)
     init = np.ascontiguousarray(init.transpose(0, 2, 1))
     _, x1 = flex_conv_dilate(points, init, 1, 8, [64, 64], "stage1", w, eps, knn_indices=nn_8, concat=False,
-                             add_se=add_se)
-    x2 = _conv1x1(x1, w, "before_stage2_conv1d/tfconv0", bn_eps=eps, act=_relu)
+                             add_se=add_se, train=train)
+    x2 = _conv1x1(x1, w, "before_stage2_conv1d/tfconv0", bn_eps=eps, act=_relu, train=train)
     _, x2 = flex_conv_dilate(points, x2, 8, 8, [128, 128], "stage2", w, eps, knn_indices=None, concat=True,
-                             trace=trace, add_se=add_se)
-    feat = _conv1x1(x1, w, "local_stage1_shortcut/tfconv0", bn_eps=eps, act=_relu) + x2
+                             trace=trace, add_se=add_se, train=train)
+    feat = _conv1x1(x1, w, "local_stage1_shortcut/tfconv0", bn_eps=eps, act=_relu, train=train) + x2
     if featdim < 128:  # :125-126
-        feat = _conv1x1(feat, w, "final_fc/tfconv0", bn_eps=eps, act=_relu)
+        feat = _conv1x1(feat, w, "final_fc/tfconv0", bn_eps=eps, act=_relu, train=train)
     return points, feat.astype(np.float32)
 
 
-def detection_block(features, w, eps, scope="detection_block_reliable"):
+def detection_block(features, w, eps, scope="detection_block_reliable", train=None):
     """core/backbones.py:132-151."""
     x = features
     for i in range(3):
-        x = _conv1x1(x, w, "%s/detec_conv%d" % (scope, i), bn_eps=eps, act=_relu)
+        x = _conv1x1(x, w, "%s/detec_conv%d" % (scope, i), bn_eps=eps, act=_relu, train=train)
     return _sigmoid(_conv1x1(x, w, scope + "/detec_conv_fc"))
 
 
-def globalatt_block(features, w, eps, scope="globalatt"):
+def globalatt_block(features, w, eps, scope="globalatt", train=None):
     """core/backbones.py:156-173 (featdim <= 256 -> conv_dims [1024])."""
-    x = _conv1x1(features, w, scope + "/detec_conv0", bn_eps=eps, act=_relu)
+    x = _conv1x1(features, w, scope + "/detec_conv0", bn_eps=eps, act=_relu, train=train)
     return _sigmoid(_conv1x1(x, w, scope + "/detec_conv_fc"))
 
 
-def global_netvlad_block(features, att, w, slim_eps, cluster_size=64, add_batch_norm=True, gating=True):
+def global_netvlad_block(features, att, w, slim_eps, cluster_size=64, add_batch_norm=True, gating=True, train=None):
     """core/backbones.py:202-279 + context_gating :282-320."""
     B, N, D = features.shape
     x = _l2_normalize(features.reshape(-1, D), 1, 1e-12)
     act = x @ w["cluster_weights"]
-    act = _slim_bn(act, w, "cluster_bn", slim_eps) if add_batch_norm else act + w["cluster_biases"]
+    # cluster_bn: fused=False upstream (:218-223) -> biased variance in the moving-variance update
+    act = (_slim_bn(act, w, "cluster_bn", slim_eps, train=train, bessel=False, rows_per_cloud=N) if add_batch_norm
+           else act + w["cluster_biases"])
     act = act - act.max(axis=1, keepdims=True)
     act = np.exp(act)
     act = (act / act.sum(axis=1, keepdims=True)).astype(np.float32)
@@ -174,19 +223,20 @@ def global_netvlad_block(features, att, w, slim_eps, cluster_size=64, add_batch_
     vlad = vlad.reshape(B, cluster_size * D)
     vlad = _l2_normalize(vlad, 1, 1e-12)
     vlad = vlad @ w["hidden1_weights"]
-    vlad = _slim_bn(vlad, w, "bn", slim_eps)
+    vlad = _slim_bn(vlad, w, "bn", slim_eps, train=train).astype(np.float32)
     if not gating:
         return vlad.astype(np.float32)
     gates = vlad @ w["gating_weights"]
-    gates = _slim_bn(gates, w, "gating_bn", slim_eps) if add_batch_norm else gates + w["gating_biases"]
+    gates = _slim_bn(gates, w, "gating_bn", slim_eps, train=train) if add_batch_norm else gates + w["gating_biases"]
     return (vlad * _sigmoid(gates)).astype(np.float32)
 
 
 def forward(points, w, detection=False, extract_global=False, knn_num=8, tp_eps=1e-5, slim_eps=1e-3,
             knn_inds=None, trace=None, featdim=128, add_batch_norm=True, add_se="max_pool",
-            global_backbone="global_before_assemble", gl_dims=(256,), concat_xyz=False):
+            global_backbone="global_before_assemble", gl_dims=(256,), concat_xyz=False, train=None):
     """core/model.py:135-210.  points [Bt,N,3] float32; returns dict of named outputs.
-    trace (dict or None) collects the integer intermediates of the sampled levels (see flex_conv_dilate)."""
+    trace (dict or None) collects the integer intermediates of the sampled levels (see flex_conv_dilate).
+    train (TrainState or None): training-mode BatchNorm (module docstring)."""
     points = np.ascontiguousarray(points, np.float32)
     outs = {"pointclouds": points}
     if knn_inds is not None:
@@ -194,14 +244,15 @@ def forward(points, w, detection=False, extract_global=False, knn_num=8, tp_eps=
     else:
         knn_indices, _ = knn_bruteforce_layer(np.ascontiguousarray(points.transpose(0, 2, 1)), knn_num)
     outs["knn_indices"] = knn_indices
+    bb_train = train if (train is not None and train.backbone_batch_stats) else None
     newpoints, localdesc = backbone_local_dilate(points, knn_indices, w, tp_eps, trace=trace, featdim=featdim,
-                                                  add_se=add_se)
+                                                  add_se=add_se, train=bb_train)
     l2n = _l2_normalize(localdesc, 2, 1e-8)
     outs["feat"] = localdesc
     outs["feat_l2normed"] = l2n
     outs["xyz_feat"] = np.concatenate([newpoints, l2n], -1)
     if detection:
-        att = detection_block(localdesc, w, tp_eps)
+        att = detection_block(localdesc, w, tp_eps, train=bb_train)
         outs["attention"] = att
         outs["xyz_feat_att"] = np.concatenate([newpoints, l2n, att], -1)
     if extract_global:
@@ -210,14 +261,33 @@ def forward(points, w, detection=False, extract_global=False, knn_num=8, tp_eps=
         if global_backbone == "global_before_assemble_conv1d":
             # core/backbones.py:189-197: every conv of the loop reads localdesc, the last one is returned
             for i, d in enumerate(gl_dims):
-                forglobal = _conv1x1(localdesc, w, "global_before_assemble_conv1%d" % i, bn_eps=tp_eps, act=_relu)
+                forglobal = _conv1x1(localdesc, w, "global_before_assemble_conv1%d" % i, bn_eps=tp_eps, act=_relu,
+                                     train=train)
         else:
             _, forglobal = flex_conv_dilate(points, localdesc, 8, knn_num, [256], "global_before_assemble", w, tp_eps,
                                             knn_indices=None, concat=False, upsample=True, add_se="",
-                                            trace=trace)
-        gatt = globalatt_block(forglobal, w, tp_eps)
-        g = global_netvlad_block(forglobal, gatt, w, slim_eps, add_batch_norm=add_batch_norm)
+                                            trace=trace, train=train)
+        gatt = globalatt_block(forglobal, w, tp_eps, train=train)
+        g = global_netvlad_block(forglobal, gatt, w, slim_eps, add_batch_norm=add_batch_norm, train=train)
         outs["forglobal"] = forglobal
         outs["global_att"] = gatt
         outs["globaldesc"] = _l2_normalize(g, -1, 1e-8)
     return outs
+
+
+def training_step_forward(points, w, batch_size=1, num_pos=2, num_neg=18, other_neg=True, margin1=0.5, margin2=0.2,
+                          backbone_batch_stats=True, mask=None, **fw):
+    """Forward half of the Siamese step under global_config (core/model.py:135-236, core/configs.py:104-144): the
+    role-ordered batch [B*(1+P+Ng+1), N, 3] through the graph in TRAINING mode, then the lazy quadruplet loss on the
+    l2-normalised descriptors (core/losses.py:173-200, global_loss_weight 1).  Returns (loss, outs, updates): updates
+    maps every moving-average variable the step touches to its value after the step.  (The weight-decay term
+    regularize_cost('.*/W') of model.py:238-243 is added by the caller: it does not depend on the data.)"""
+    from . import losses_np
+    st = TrainState(backbone_batch_stats=backbone_batch_stats, mask=mask)
+    outs = forward(points, w, extract_global=True, train=st, **fw)
+    desc = outs["globaldesc"] if mask is None else outs["globaldesc"][np.asarray(mask, bool)]
+    if other_neg:
+        loss = losses_np.lazy_quadruplet_loss(desc, batch_size, num_pos, num_neg, margin1, margin2)
+    else:
+        loss = losses_np.lazy_triplet_loss(desc, batch_size, num_pos, num_neg, margin1)
+    return float(loss), outs, st.updates

@@ -222,3 +222,40 @@ def test_fps_properties_and_golden(oracle):
     z = np.zeros((1, 1500, 3), np.float32)
     z[0, 700] = 1.0; z[0, 188] = 1.0  # two equidistant farthest points: 188 = (188,0) beats 700 = (188,1)
     assert oracle.farthest_point_sample(2, z)[0, 1] == 188
+
+
+def test_training_mode_batchnorm_of_the_numpy_graph():
+    """oracle/model_np._bn in training mode against torch's batch_norm on the CPU: batch statistics with the biased
+    variance in the normalisation, moving buffers updated with decay 0.9 / 0.999 and the Bessel-corrected variance
+    (the fused kernel's rule; torch's is the same), the biased one for cluster_bn; a cloud mask drops padding clouds."""
+    import torch
+    from oracle import model_np
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((6, 50, 16)).astype(np.float32) * 2 + 1
+    w = {"s/gamma": rng.random(16).astype(np.float32) + 0.5, "s/beta": rng.standard_normal(16).astype(np.float32),
+         "s/mean/EMA": rng.standard_normal(16).astype(np.float32), "s/variance/EMA": rng.random(16).astype(np.float32) + 0.5}
+    st = model_np.TrainState()
+    y = model_np._bn(x, w, "s", 2, 1e-5, train=st, decay=0.9)
+    rm, rv = torch.from_numpy(w["s/mean/EMA"].copy()), torch.from_numpy(w["s/variance/EMA"].copy())
+    yt = torch.nn.functional.batch_norm(torch.from_numpy(x).reshape(-1, 16), rm, rv, torch.from_numpy(w["s/gamma"]),
+                                        torch.from_numpy(w["s/beta"]), training=True, momentum=0.1, eps=1e-5)
+    assert np.allclose(y.reshape(-1, 16), yt.numpy(), rtol=1e-5, atol=1e-5)
+    assert np.allclose(st.updates["s/mean/EMA"], rm.numpy(), rtol=1e-5, atol=1e-6)
+    assert np.allclose(st.updates["s/variance/EMA"], rv.numpy(), rtol=1e-5, atol=1e-6)
+    # inference mode is untouched by the switch
+    y0 = model_np._bn(x, w, "s", 2, 1e-5)
+    assert np.allclose(y0, (x - w["s/mean/EMA"]) / np.sqrt(w["s/variance/EMA"] + np.float32(1e-5)) * w["s/gamma"] + w["s/beta"])
+    # biased moving variance (cluster_bn, fused=False upstream): n/(n-1) apart
+    st2 = model_np.TrainState()
+    model_np._bn(x, w, "s", 2, 1e-5, train=st2, decay=0.9, bessel=False)
+    n = 300.0
+    dv_b = st2.updates["s/variance/EMA"] - 0.9 * w["s/variance/EMA"]
+    dv_u = st.updates["s/variance/EMA"] - 0.9 * w["s/variance/EMA"]
+    assert np.allclose(dv_u, dv_b * n / (n - 1), rtol=1e-4)
+    # mask: padding clouds do not count
+    mask = np.array([1, 1, 1, 1, 0, 0], bool)
+    st3 = model_np.TrainState(mask=mask)
+    ym = model_np._bn(x, w, "s", 2, 1e-5, train=st3, decay=0.9)
+    st4 = model_np.TrainState()
+    y4 = model_np._bn(x[:4], w, "s", 2, 1e-5, train=st4, decay=0.9)
+    assert np.allclose(ym[:4], y4, rtol=1e-5, atol=1e-6) and np.allclose(st3.updates["s/mean/EMA"], st4.updates["s/mean/EMA"])
