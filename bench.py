@@ -426,14 +426,62 @@ def main():
         model = DH3D(cfg).init_synthetic(0).to(dev).eval().prepare()
         trainer = QuadrupletTrainer(model)
         pts = synthetic_clouds(wl["B"], wl["N"], wl["seed"], dev, 0)  # same role-ordered batch on every rank
-        dt = time_steps(lambda p: trainer.step(p), pts, args.steps, args.warmup, dev)
+        # (the loss stays on the device: nothing in the timed loop waits for the GPU but the closing synchronize)
+        dt = time_steps(lambda p: trainer.step(p, sync=False), pts, args.steps, args.warmup, dev)
         trainer.time_phases(True)   # five more (untimed) steps with events around the phases
+        D.COLLECTIVE_CALLS[0] = 0
         for _ in range(5):
             trainer.step(pts)
         extra = {"phases_ms": trainer.phase_times_ms(), "head_implementation": trainer.impl,
-                 "step_graphed": bool(trainer._step_graphs)}
+                 "step_graphed": bool(trainer._step_graphs), "collectives_per_step": D.COLLECTIVE_CALLS[0] / 5.0,
+                 "frozen_backbone_batchnorm": "moving averages (fused inference path); the reference graph uses batch "
+                                              "statistics there -- QuadrupletTrainer(backbone_bn='batch'), DESIGN.md 6"}
         trainer.time_phases(False)
+        if world == 1:
+            extra["sharded_path"] = sharded_path_at_one_rank(model, pts, dt / args.steps * 1e3)
         return wl["B"] * args.steps / dt, dt / args.steps * 1e3, extra
+
+    def sharded_path_at_one_rank(model, pts, plain_ms):
+        """The step as the sharded run issues it -- sync-BN statistics all-reduced, descriptors all-gathered, the flat
+        gradient arena all-reduced, all inside the replayed hipGraph -- on a 1-rank RCCL group, next to the plain
+        single-process step: what the collectives' code path costs before any second GPU is involved."""
+        import socket
+        import torch.distributed as tdist
+        from dh3d_amd.training import QuadrupletTrainer
+        out = {"plain_ms": plain_ms}
+        own_group = not tdist.is_initialized()
+        try:
+            if own_group:
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    port = sk.getsockname()[1]
+                tdist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+            D.FORCE_COLLECTIVES = True
+            tr = QuadrupletTrainer(model, sync_bn=True)
+            dt = time_steps(lambda p: tr.step(p, sync=False), pts, args.steps, max(args.warmup, 5), dev)
+            out["sharded_path_ms"] = dt / args.steps * 1e3
+            out["ratio"] = out["sharded_path_ms"] / plain_ms
+            out["step_graphed"] = bool(tr._step_graphs)
+            tr.graph_step = False  # one eager step: count what a step issues
+            D.COLLECTIVE_CALLS[0] = 0
+            launches = None
+            try:
+                from torch.profiler import profile, ProfilerActivity
+                with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                    tr.step(pts)
+                    torch.cuda.synchronize()
+                launches = sum(1 for e in prof.events() if str(getattr(e, "device_type", "")).endswith("CUDA"))
+            except Exception:  # no profiler on this box: the collective count alone
+                tr.step(pts)
+            out["collectives_per_step"] = D.COLLECTIVE_CALLS[0]
+            out["device_launches_per_step"] = launches
+        except Exception as e:  # noqa: BLE001 -- informational key: the bench line must not die with it
+            out["error"] = repr(e)[:200]
+        finally:
+            D.FORCE_COLLECTIVES = False
+            if own_group and tdist.is_initialized():
+                tdist.destroy_process_group()
+        return out
 
     def measure(workload, batch=None):
         if workload == "train":

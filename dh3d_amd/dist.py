@@ -56,6 +56,18 @@ def shard_batch(points, rank, world):
     return out, mask
 
 
+# The sharded code path with a single rank (bench.py "sharded_path_ms", tests): every collective of the step is issued
+# on the (1-rank) process group instead of being skipped.
+FORCE_COLLECTIVES = False
+# calls of all_reduce_sum_ / all_gather_rows since the last reset (bench.py reports collectives per step)
+COLLECTIVE_CALLS = [0]
+
+
+def collectives_active():
+    """Whether the step issues its collectives: a process group with more than one rank, or the forced 1-rank path."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
+
+
 def _staged(t):
     """gloo moves CUDA tensors only for broadcast / all_reduce; everything else is staged through the host there
     (the CPU-test / single-GPU multi-process path -- RCCL takes device tensors directly)."""
@@ -65,6 +77,7 @@ def _staged(t):
 def all_gather_rows(local):
     """local [n, ...] (same n on every rank) -> [world*n, ...] in rank order."""
     world = dist.get_world_size()
+    COLLECTIVE_CALLS[0] += 1
     if _staged(local):
         host = local.detach().cpu().contiguous()
         out = torch.empty((world * host.shape[0],) + tuple(host.shape[1:]), dtype=host.dtype)
@@ -77,6 +90,7 @@ def all_gather_rows(local):
 
 def all_reduce_sum_(t):
     """In-place SUM all-reduce (device tensors over RCCL; host-staged under gloo)."""
+    COLLECTIVE_CALLS[0] += 1
     if _staged(t):
         host = t.detach().cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM)

@@ -54,7 +54,7 @@ def _forward_stats(x, gamma, beta, run_mean, run_var, eps, momentum, mask, rows_
     packed = torch.empty((2 * C + 1,), dtype=torch.float64, device=x.device)
     s1, s2 = pm.bn_colstats(x, mask, rows_per_cloud, out=packed)
     cnt = _count(x.shape[0], mask, rows_per_cloud, x.device)
-    if sync and _world() > 1:
+    if sync and D.collectives_active():
         packed[2 * C:] = cnt
         D.all_reduce_sum_(packed)
         cnt = packed[2 * C:]
@@ -67,7 +67,7 @@ def _forward_stats(x, gamma, beta, run_mean, run_var, eps, momentum, mask, rows_
 def _backward_coeffs(S, st, gamma, sync):
     """S [3, C] f64 local sums -> (local dgamma, dbeta as float32, [k2, k3]) with the all-reduce under sync-BN."""
     local = S[:2].float()                       # this rank's partials: dbeta = S1, dgamma = S2
-    if sync and _world() > 1:
+    if sync and D.collectives_active():
         S = S.clone()
         D.all_reduce_sum_(S[:2])
     k = pm.bn_bwd_finalize(S[0], S[1], st.cnt, st.stats[0], st.stats[1], gamma)
@@ -139,7 +139,7 @@ def batch_norm_train(x, bnmod, relu, sync=False, mask=None, rows_per_cloud=0, mo
     rm, rv = (bnmod.mean_EMA, bnmod.variance_EMA) if tp else (bnmod.moving_mean, bnmod.moving_variance)
     mom = momentum if momentum is not None else (0.9 if tp else 0.999)
     unb = bool(getattr(bnmod, "ema_unbiased", True))
-    if x.shape[0] <= 64 and (mask is None or rows_per_cloud == 1) and not (sync and _world() > 1):
+    if x.shape[0] <= 64 and (mask is None or rows_per_cloud == 1) and not (sync and D.collectives_active()):
         # the [clouds, C] activations behind NetVLAD: one launch per direction (single rank or per-rank statistics)
         return _BatchNormTrainSmall.apply(x, bnmod.gamma, bnmod.beta, rm, rv, bnmod.eps, mom, relu, mask, unb)
     return _BatchNormTrain.apply(x, bnmod.gamma, bnmod.beta, rm, rv, bnmod.eps, mom, relu, sync, mask, rows_per_cloud, unb)
@@ -354,7 +354,7 @@ class _AttentionHeadCommuted(torch.autograd.Function):
         packed = torch.empty((2 * H + 1,), dtype=torch.float64, device=C.device)
         s1, s2 = pm.interp_bn_colstats(G, idx, dist, order, mask, out=packed)
         cnt = _count(Bt * N, mask, N, C.device)
-        if sync and _world() > 1:
+        if sync and D.collectives_active():
             packed[2 * H:] = cnt
             D.all_reduce_sum_(packed)
             cnt = packed[2 * H:]

@@ -30,7 +30,7 @@ class _AllGatherKeepOwn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, local):
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not D.collectives_active():
             ctx.rank, ctx.n = 0, local.shape[0]
             return local.clone()
         ctx.rank, ctx.n = dist.get_rank(), local.shape[0]
@@ -71,7 +71,7 @@ def _batch_norm_train(x, channel_dim, gamma, beta, run_mean, run_var, eps, momen
         cnt = torch.tensor(float(x.numel() / x.shape[channel_dim]), device=x.device)
         s1 = x.sum(dims)
         s2 = (x * x).sum(dims)
-    if sync_bn and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if sync_bn and D.collectives_active():
         packed = _AllReduceSum.apply(torch.cat([s1, s2, cnt.reshape(1)]))
         C = s1.numel()
         s1, s2, cnt = packed[:C], packed[C:2 * C], packed[2 * C]
@@ -373,12 +373,17 @@ class QuadrupletTrainer(object):
         self.wd_params = [p for n, p in model.named_parameters() if n.endswith(".W")
                           and any(p is q for q in self.params)]
         self.weight_decay = weight_decay
-        # Whole-step hipGraph (forward, loss, backward, weight decay, Adam): a 22-cloud step is ~600 launches, about as
-        # much host time as GPU time.  Single process only (the collectives of a sharded step are not captured here);
-        # the first steps run eagerly (allocator / autograd warm-up), then the step is captured once per batch shape and
-        # replayed.  The learning rate is a device scalar the staircase schedule writes into.
+        # Whole-step hipGraph (forward, loss, backward, weight decay, gradient all-reduce, Adam): a 22-cloud step is ~600
+        # launches, about as much host time as GPU time.  The first steps on a batch shape run eagerly (allocator /
+        # autograd warm-up), then the step is captured once per shape and replayed.  The learning rate is a device
+        # scalar the staircase schedule writes into.  Sharded (RCCL): the collectives -- sync-BN statistics, the
+        # descriptor all-gather, ONE all-reduce of the flat gradient arena -- are captured with the kernels between
+        # them (torch's NCCL process group enqueues on the capturing stream); gloo's host-staged collectives cannot be
+        # captured, so the CPU-test path stays eager.
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        self.graph_step = (impl == "hip" and world == 1) if graph_step is None else (bool(graph_step) and world == 1)
+        capturable = world == 1 and not D.collectives_active() or (D.collectives_active() and dist.get_backend() == "nccl")
+        self.graph_step = (impl == "hip" and capturable) if graph_step is None else (bool(graph_step) and capturable)
+        self._garena = None     # flat gradient arena of the sharded step (all-reduced in place, .grad are views of it)
         self._sched = (float(start_lr), int(decay_step), float(decay_rate))
         self._steps_done = 0
         self._step_graphs = {}
@@ -497,6 +502,30 @@ class QuadrupletTrainer(object):
         lr0, dstep, drate = self._sched
         return lr0 * drate ** (self._steps_done // dstep)
 
+    def _reduce_gradients(self):
+        """Sharded step: SUM all-reduce of the head gradients.  One persistent flat arena (18.7 MB for global_config):
+        the gradients are gathered into it by ONE multi-tensor copy, all-reduced in place, and every .grad becomes a
+        view of it -- no per-step concatenation, no per-parameter clones."""
+        self._ensure_arena()
+        have = [(v, p.grad) for v, p in zip(self._gviews, self.params) if p.grad is not None and p.grad is not v]
+        none = [v for v, p in zip(self._gviews, self.params) if p.grad is None]
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        if none:
+            torch._foreach_zero_(none)
+        D.all_reduce_sum_(self._garena)  # every rank holds a partial of the SAME loss
+        for v, p in zip(self._gviews, self.params):
+            p.grad = v
+
+    def _ensure_arena(self):
+        if self._garena is None:  # (never first built inside a capture: it must outlive any one graph's pool)
+            n = sum(p.numel() for p in self.params)
+            self._garena = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
+            self._gviews, off = [], 0
+            for p in self.params:
+                self._gviews.append(self._garena[off:off + p.numel()].view(p.shape))
+                off += p.numel()
+
     def _step_graphed(self, points):
         key = (tuple(points.shape), points.device, getattr(self.model, "_backbone_version", 0))
         ent = self._step_graphs.get(key)
@@ -504,16 +533,20 @@ class QuadrupletTrainer(object):
             self._step_graphs.clear()
             static_in = points.clone()
             self.opt.zero_grad(set_to_none=True)
+            if D.collectives_active():
+                self._ensure_arena()
             graph = torch.cuda.CUDAGraph()
             try:
                 with torch.cuda.graph(graph):
                     loss = self.forward_loss(static_in)
                     loss.backward()
-                    if self.wd_params and self.weight_decay:
+                    if self.wd_params and self.weight_decay and (not D.collectives_active() or dist.get_rank() == 0):
                         gs = [p.grad for p in self.wd_params if p.grad is not None]
                         ps = [p.detach() for p in self.wd_params if p.grad is not None]
                         if gs:
                             torch._foreach_add_(gs, ps, alpha=self.weight_decay)
+                    if D.collectives_active():
+                        self._reduce_gradients()
                     self.opt.step()
             except RuntimeError:
                 # something in this shape's step cannot be captured: stay eager for good (the parameters are untouched --
@@ -529,9 +562,15 @@ class QuadrupletTrainer(object):
         graph.replay()
         self._steps_done += 1
         self.model.invalidate(head_only=True)
-        return float(loss.detach())
+        return loss.detach()
 
-    def step(self, points):
+    def step(self, points, sync=True):
+        """One optimisation step; returns the loss -- as a float (sync=True: one host round trip per step) or as the
+        device scalar the step wrote (sync=False: nothing waits for the GPU; a replayed step overwrites it)."""
+        loss = self._step(points)
+        return float(loss) if sync else loss
+
+    def _step(self, points):
         # eager for the first steps ON EVERY BATCH SHAPE (allocator / autograd / lazily built constants warm up before
         # the capture), while phases are timed or gradients / descriptors are kept for inspection
         shape = (tuple(points.shape), points.device)
@@ -556,14 +595,8 @@ class QuadrupletTrainer(object):
             if gs:
                 torch._foreach_add_(gs, ps, alpha=self.weight_decay)
         self._mark(3)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params])
-            D.all_reduce_sum_(flat)  # every rank holds a partial of the SAME loss
-            off = 0
-            for p in self.params:
-                n = p.numel()
-                p.grad = flat[off:off + n].reshape(p.shape).clone()
-                off += n
+        if D.collectives_active():
+            self._reduce_gradients()
         if self.keep_grads:  # tests: the reduced gradient of this step (Adam's m/sqrt(v) is sign-like in the first
             self.last_grads = [p.grad.detach().clone() for p in self.params]  # steps: parameters are ill-conditioned)
         self.opt.step()
@@ -572,4 +605,4 @@ class QuadrupletTrainer(object):
         self._steps_done += 1
         self._mark(4)
         self.model.invalidate(head_only=True)  # the packed / folded weight copies of the fused inference path are stale now
-        return float(loss.detach())
+        return loss.detach()

@@ -213,6 +213,70 @@ open(os.path.join(%(out)r, "rank%%d_%%d.ok" %% (rank, int(sync_bn))), "w").write
 """
 
 
+_ONE_RANK = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch
+import torch.distributed as tdist
+from dh3d_amd import ConfigFactory, dist as D
+from dh3d_amd.model import DH3D
+from dh3d_amd.training import QuadrupletTrainer
+
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+
+def build():
+    cfg = ConfigFactory("global_config").getconfig()
+    cfg.batch_size, cfg.num_pos, cfg.num_neg = 1, 2, 3
+    return DH3D(cfg).init_synthetic(5).to(dev).eval()
+
+pts = torch.from_numpy(np.random.default_rng(78).random((7, 1024, 3), dtype=np.float32)).to(dev)
+ref = build()
+tr = QuadrupletTrainer(ref, sync_bn=False)              # plain single-process step (graphed after three eager ones)
+ref_losses = [tr.step(pts) for _ in range(6)]
+assert tr._step_graphs, "the plain step was not captured"
+
+tdist.init_process_group("nccl", init_method="tcp://127.0.0.1:%(port)s", rank=0, world_size=1)
+D.FORCE_COLLECTIVES = True
+m = build()
+t1 = QuadrupletTrainer(m, sync_bn=True)                 # the sharded code path: every collective issued, on RCCL
+assert t1.graph_step, "the sharded step must be capturable on RCCL"
+D.COLLECTIVE_CALLS[0] = 0
+losses = [t1.step(pts)]
+per_step = D.COLLECTIVE_CALLS[0]
+losses += [float(t1.step(pts, sync=False)) for _ in range(5)]
+assert t1._step_graphs, "the sharded step fell back to eager launches"
+assert per_step == 12, per_step   # 5 forward + 5 backward BatchNorm statistics, descriptor all-gather, gradient arena
+assert np.allclose(losses, ref_losses, rtol=2e-3, atol=2e-4), (losses, ref_losses)
+for p, q in zip(t1.params, tr.params):                  # six Adam steps later the parameters still agree
+    assert torch.allclose(p, q, rtol=0, atol=2e-3 * float(q.abs().max()) + 1e-6), float((p - q).abs().max())
+for p in t1.params:                                     # .grad are views of the one arena that was all-reduced
+    assert p.grad.untyped_storage().data_ptr() == t1._garena.untyped_storage().data_ptr()
+tdist.destroy_process_group()
+open(os.path.join(%(out)r, "one_rank.ok"), "w").write("ok")
+"""
+
+
+def test_trainer_sharded_path_on_a_one_rank_rccl_group(dev, tmp_path):
+    """The step as a sharded run issues it (sync-BN all-reduces, descriptor all-gather, ONE all-reduce of the flat
+    gradient arena), replayed from a hipGraph WITH its RCCL collectives, on a 1-rank nccl group: same losses and
+    parameters as the plain single-process step; 12 collectives per step."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    script = tmp_path / "one_rank.py"
+    script.write_text(_ONE_RANK % {"root": root, "out": str(tmp_path), "port": port})
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert (tmp_path / "one_rank.ok").exists()
+
+
 @pytest.mark.parametrize("sync_bn", [1, 0])
 def test_trainer_step_world_size_2_matches_single_process(dev, tmp_path, sync_bn):
     """QuadrupletTrainer.step with two ranks (gloo, collectives staged through the host, both ranks on this GPU):
