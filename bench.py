@@ -106,6 +106,24 @@ def time_steps(run, pts, steps, warmup, dev):
     return D.max_over_ranks(dt, dev)
 
 
+def repeat_blocks(run, pts, steps, dev, repeats):
+    """`repeats` more blocks of `steps` timed steps (same barrier + synchronize bracketing): the spread of the
+    contract number.  K steps of this path are ~10 ms of timed region, run-to-run +-1.5 %; effects below that are only
+    visible in the median / minimum over several blocks.  Informational -- `value` is the first block alone."""
+    from dh3d_amd import dist as D
+    out = []
+    for _ in range(repeats):
+        torch.cuda.synchronize(dev)
+        D.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run(pts)
+        torch.cuda.synchronize(dev)
+        D.barrier()
+        out.append(D.max_over_ranks(time.perf_counter() - t0, dev) / steps * 1e3)
+    return out
+
+
 def event_time_ms(fn, iters=50, warm=5):
     """Average duration of fn() (kernels on torch's current stream) from HIP events on that stream."""
     for _ in range(warm):
@@ -236,6 +254,80 @@ def flex_conv_roofline(dev, in_step_ms=None, pmc=True, B=8, N=8192, K=8, Din=64,
     return out
 
 
+def global_tail_roofline(dev, B=32, N=4096):
+    """MFMA figures of the global path's head (core/backbones.py:156-173,202-279) at config 3's
+    shape, timed with HIP events on isolated launches:
+      * `netvlad_block`: the NetVLAD + gating block on a MATERIALISED [B,N,256] map (csrc/netvlad.hip: assignment GEMM,
+        BN + softmax x attention, VLAD contraction, hidden split-K projection, gate) -- the block as BASELINE.md counts
+        it: 4*B*N*256*64 + 2*B*16384*256 + 2*B*256^2 flop against the 157.3 TF f32-MFMA peak;
+      * `fused_tail`: what the model runs at this shape (pm.global_tail): the attention conv 256->1024 and NetVLAD's
+        assignment both commuted through the three_interpolate up-sampling -- GEMMs on the N/8 coarse rows (bf16x6:
+        f32-accurate on the bf16 pipe), one walk over the fine points, `A'^T c`, the same hidden / gate tail.  Its
+        reference-formulation flops include the attention conv on the fine rows (2*B*N*256*1024) that the commuted
+        form never executes; `flops_executed` counts what the kernels do (bf16x6 products counted once, as f32 flops).
+    PMC counters of the same kernels (MFMA busy cycles, L2 requests / hits of the walk): profiles/r03_c_pmc_global_tail.txt."""
+    from dh3d_amd import pm
+    model = build_model("global_config", dev, seed=0, num_points=N)
+    pts = synthetic_clouds(B, N, 3003, dev, 0)
+    out = {}
+    with torch.no_grad():
+        model(pts, fetch=("globaldesc",))
+        geo = model._geometry(pts, None)
+        model._join_side(geo)
+        _, local = model.compute_local(pts, _geo=geo)
+        lv = geo.level(8, model.knn_num)
+        gba, ga, nv = model.global_before_assemble, model.globalatt, model._netvlad
+        coarse = gba(geo, local, coarse_only=True)
+        last = ga.detec_conv0
+        lp, gp, p = last._prep, ga._prep or ga.prepare(), nv._prep or nv.prepare()
+        torch.cuda.synchronize(dev)
+        m = coarse.shape[1]
+        f_att_ref = 2.0 * B * N * 256 * 1024
+        f_vlad = 4.0 * B * N * 256 * 64 + 2.0 * B * 16384 * 256 + 2.0 * B * 256 * 256
+        if "wslices" in gp and "_ordered" in lv:
+            ms = event_time_ms(lambda: pm.global_tail(
+                coarse, lv["nn3_idx"], lv["nn3_dist"], lv["_ordered"][0], gp["wslices"], last.cout, gp["w_fc"], gp["b_fc"],
+                (lp["b"], lp["scale"], lp["shift"], pm.ACT_RELU), p["wc"], p["cs"], p["ch"], p["W2"], p["Wh"], p["s1"],
+                p["h1"], p["Wg"], p["s2"], p["h2"], l2_eps=1e-8), iters=20, warm=3)
+            # executed: GEMMs on the coarse rows (attention 256->1024, cluster logits 256->64), interpolation of the 1024
+            # + 64 wide rows at the fine points (3 fma each), slot-matrix scatter product per 128-point block,
+            # A'^T c, hidden projection, gate
+            f_exec = (2.0 * B * m * 256 * (1024 + 64) + 2.0 * B * N * 3 * (1024 + 64) + 2.0 * B * N * 64 * 64
+                      + 2.0 * B * 64 * m * 256 + 2.0 * B * 16384 * 256 + 2.0 * B * 256 * 256)
+            t = ms * 1e-3
+            out["fused_tail"] = {
+                "kernels": "linear_x6 slices (attention GEMM on coarse rows) + interp_head_lds_kernel<true> (walk) + "
+                           "gemm_x6 (A'^T c) + netvlad_finalize / hidden_splitk / gate",
+                "launch_ms": ms, "flops_reference": f_att_ref + f_vlad, "flops_executed": f_exec,
+                "reference_flops_rate": {"achieved": (f_att_ref + f_vlad) / t / 1e12, "peak": F32_MFMA_PEAK_TF,
+                                         "unit": "TFLOP/s", "frac": (f_att_ref + f_vlad) / t / 1e12 / F32_MFMA_PEAK_TF},
+                "executed_flops_rate": {"achieved": f_exec / t / 1e12, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                                        "frac": f_exec / t / 1e12 / F32_MFMA_PEAK_TF},
+                "binding_roof": "L2 gather of the walk (12 KB of coarse rows per fine point) + VALU; the GEMMs are 1/8 of "
+                                "the reference's flops"}
+        # the literal block on materialised rows
+        d = torch.clamp(lv["nn3_dist"], min=1e-10)
+        w = (1.0 / d) / (1.0 / d).sum(2, keepdim=True)
+        from dh3d_amd import ops
+        forglobal = ops.three_interpolate(coarse, lv["nn3_idx"], w.contiguous())
+        att = torch.rand(B, N, 1, device=dev)
+        ms2 = event_time_ms(lambda: nv(forglobal, att, l2_eps=1e-8), iters=20, warm=3)
+        t2 = ms2 * 1e-3
+        out["netvlad_block"] = {
+            "kernels": "netvlad_assign_accumulate + finalize + l2scale + hidden_splitk + gate (csrc/netvlad.hip) on the "
+                       "materialised [B,N,256] map",
+            "launch_ms": ms2, "flops": f_vlad, "bound": "mfma",
+            "achieved": f_vlad / t2 / 1e12, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+            "frac": f_vlad / t2 / 1e12 / F32_MFMA_PEAK_TF,
+            "hbm": {"bytes": 4.0 * B * N * 257 + 4.0 * 16384 * 256, "achieved": (4.0 * B * N * 257 + 4.0 * 16384 * 256) / t2 / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": (4.0 * B * N * 257 + 4.0 * 16384 * 256) / t2 / 1e9 / HBM_PEAK_GBS},
+            "note": "8.9 GF over 151 MB of compulsory bytes = 58 flop/B, three times ABOVE the f32-MFMA ridge (157.3 TF / 8 TB/s = "
+                    "19.7 flop/B): the block is MFMA-bound; the HBM fraction is given beside it"}
+    out["workload"] = "global_config, B=%d, N=%d, 64-cluster NetVLAD" % (B, N)
+    return out
+
+
 def flex_in_step_ms(dev, reps=10):
     """Duration of the stage-1 flex_conv 64->64 launch INSIDE the local forward (events on the stream it runs on)."""
     from dh3d_amd import pm
@@ -333,9 +425,35 @@ def cpu_model_string():
     return "unknown"
 
 
+def usable_cpus():
+    """Cores this process may actually run on: the affinity mask, capped by the cgroup's CPU quota (os.cpu_count() is
+    the machine's -- round 2 started 256 workers on a pod that may use far fewer and reported it as 256 cores)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().split()[0])
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    if quota is not None:
+        n = max(1, min(n, int(quota)))
+    return n, quota
+
+
 def cpu_baseline(workload):
     """The CPU oracle (numpy graph + C ops, oracle/) on the workload's clouds: single thread, and one single-threaded
-    process per host core.  A reported baseline ("port"), never the thing measured as `value`."""
+    process per USABLE host core.  A reported baseline ("port"), never the thing measured as `value`."""
     from dh3d_amd import ConfigFactory
     from dh3d_amd.model import DH3D, tf_variable_name
     wl = WORKLOADS[workload]
@@ -355,20 +473,38 @@ def cpu_baseline(workload):
     n1 = 4  # bounded sample: ~10-20 s of single-core work
     p = worker(n1, wl["seed"])
     t1 = float(p.communicate()[0].strip() or "nan")
-    cores = os.cpu_count() or 1
+    usable, quota = usable_cpus()
+    workers = min(usable, 64)  # bounded: 64 single-threaded workers, two clouds each
+    per_worker = 2
     t0 = time.perf_counter()
-    procs = [worker(1, wl["seed"] + 1 + i) for i in range(cores)]
+    procs = [worker(per_worker, wl["seed"] + 1 + i) for i in range(workers)]
     inner = [float(q.communicate()[0].strip() or "nan") for q in procs]
     wall = time.perf_counter() - t0
+    # BASELINE config 1 on this host: knn_bruteforce + one flex_conv 32->32, N=1024, K=8, one thread (C oracle ops)
+    q1 = subprocess.run([sys.executable, "-m", "oracle.cpu_worker", "cfg1", "5"], cwd=ROOT, env=env, capture_output=True,
+                        text=True)
+    try:
+        cfg1_ms = float(q1.stdout.strip())
+    except ValueError:
+        cfg1_ms = None
     import shutil
     shutil.rmtree(tmp, ignore_errors=True)
-    return {"value": n1 / t1, "unit": "point-clouds/sec", "cores": 1, "kind": "port",
+    single = n1 / t1
+    allc = workers * per_worker / wall
+    return {"value": single, "unit": "point-clouds/sec", "cores": 1, "kind": "port",
             "sample": "%d clouds of N=%d through oracle/model_np.forward (C oracle ops + numpy dense, one thread), %.1f s"
                       % (n1, wl["N"], t1),
-            "all_cores": {"value": cores / wall, "unit": "point-clouds/sec", "cores": cores,
-                          "sample": "one single-threaded oracle process per host core, one cloud each, wall %.1f s "
-                                    "(process start included; slowest worker's compute %.1f s)" % (wall, np.nanmax(inner))},
-            "cpu_model": cpu_model_string(), "host_cpus": cores}
+            "cfg1_ms": cfg1_ms,
+            "cfg1_sample": "BASELINE config 1: knn_bruteforce + one flex_conv 32->32 on one cloud of N=1024, K=8, C oracle "
+                           "ops, one thread, best of 5",
+            "all_cores": {"value": allc, "unit": "point-clouds/sec", "cores": workers,
+                          "workers": workers, "clouds_per_worker": per_worker,
+                          "median_worker_s": float(np.nanmedian(inner)), "slowest_worker_s": float(np.nanmax(inner)),
+                          "scaling_vs_one_thread": allc / single if single > 0 else None,
+                          "sample": "one single-threaded oracle process per usable core (capped at 64), %d clouds each, "
+                                    "wall %.1f s (process start included)" % (per_worker, wall)},
+            "cpu_model": cpu_model_string(), "host_cpus": os.cpu_count(), "usable_cpus": usable,
+            "cgroup_cpu_quota": quota}
 
 
 # --------------------------------------------------------------------------------------------- main
@@ -383,6 +519,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / breakdown / other workloads")
     ap.add_argument("--no-pmc", action="store_true", help="do not collect live PMC traffic for the roofline kernel")
+    ap.add_argument("--repeats", type=int, default=7,
+                    help="further blocks of K timed steps after the contract block (median / min / max as extra keys)")
     ap.add_argument("--inflight", type=int, default=1,
                     help="independent steps in flight (graph instances on separate streams, each with its own batch "
                          "buffers): a serving loop's overlap of consecutive batches.  Default 1 = one step at a time")
@@ -495,7 +633,16 @@ def main():
             # the batch is resident in the graph's input buffer (where a loader's H2D copy would put it)
             run.static_input.copy_(pts)
             dt = time_steps(run, run.static_input, args.steps, args.warmup, dev)
-        return total * args.steps / dt, dt / args.steps * 1e3, {"clouds_per_gpu": per}
+            info = {"clouds_per_gpu": per}
+            if workload == args.workload and args.repeats > 0:
+                blocks = repeat_blocks(run, run.static_input, args.steps, dev, args.repeats)
+                info["repeats"] = {"blocks": args.repeats, "steps_per_block": args.steps,
+                                   "ms_per_step": [round(b, 5) for b in blocks],
+                                   "median_ms": float(np.median(blocks)), "min_ms": float(np.min(blocks)),
+                                   "max_ms": float(np.max(blocks)),
+                                   "median_value": total / (float(np.median(blocks)) * 1e-3),
+                                   "note": "further timed blocks after the contract one; `value` is the first block"}
+        return total * args.steps / dt, dt / args.steps * 1e3, info
 
     def measure_in_flight(workload, depth=2):
         """Throughput with `depth` independent steps in flight (graph instances on separate streams, every step still
@@ -538,6 +685,8 @@ def main():
                    "weights": "random-init (no checkpoint blobs exist upstream)", "execution": "hipGraph replay",
                    "steps_in_flight": args.inflight if args.workload != "train" else 1},
     }
+    if "repeats" in info:
+        line["repeats"] = info["repeats"]
     if args.workload == "train":
         line["config"]["execution"] = (
             "whole step (backbone, head fwd/bwd, loss, fused Adam) replayed as one hipGraph; phases_ms from eager steps"
@@ -551,6 +700,11 @@ def main():
         with torch.no_grad():
             in_step = flex_in_step_ms(dev)
             line["roofline"] = flex_conv_roofline(dev, in_step_ms=in_step, pmc=(not args.no_pmc and world == 1))
+            if world == 1:
+                try:
+                    line["roofline_global"] = global_tail_roofline(dev)
+                except Exception as e:  # noqa: BLE001 -- informational key
+                    line["roofline_global"] = {"error": repr(e)[:200]}
             line["kernels_ms"] = kernel_breakdown(dev, wl["B"], wl["N"])
             if world == 1:
                 line["dropin_ops_ms"] = dropin_ops_line(dev)

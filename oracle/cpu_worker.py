@@ -4,6 +4,8 @@ host core ("one process per cloud across all host cores") -- it impor
 torch and never dh3d_amd.
 
     python -m oracle.cpu_worker <weights.npz> <N> <count> <seed> <global:0|1>
+    python -m oracle.cpu_worker cfg1 <repeats>      BASELINE config 1: knn_bruteforce + one flex_conv 32->32 on a single
+                                                    cloud of N=1024, K=8 (C oracle ops, one thread): prints the best ms
 """
 import os
 import sys
@@ -15,7 +17,26 @@ for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
 import numpy as np  # noqa: E402
 
 
+def cfg1(repeats):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import cpu as O
+    rng = np.random.default_rng(1001)
+    pts_T = np.ascontiguousarray(rng.random((1, 1024, 3), dtype=np.float32).transpose(0, 2, 1))
+    feat = rng.standard_normal((1, 32, 1024)).astype(np.float32)
+    theta = rng.standard_normal((3, 32, 32)).astype(np.float32)
+    bias = rng.standard_normal((32, 32)).astype(np.float32)
+    best = float("inf")
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        nn, _ = O.knn_bruteforce(pts_T, 8)                                           # [1, N, K]
+        O.flex_convolution(feat, pts_T, np.ascontiguousarray(nn.transpose(0, 2, 1)), theta, bias, center_self=True)
+        best = min(best, time.perf_counter() - t0)
+    print("%.6f" % (best * 1e3), flush=True)
+
+
 def main(argv):
+    if argv[0] == "cfg1":
+        return cfg1(int(argv[1]))
     path, N, count, seed, glob = argv[0], int(argv[1]), int(argv[2]), int(argv[3]), bool(int(argv[4]))
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from oracle import model_np
