@@ -561,9 +561,12 @@ DH3D_API int dh3d_pack_weight_x3(const float *W, int Kd, int Dout, void *packed,
   return dh3d_launch_status();
 }
 
-// Dev knob (tools/dense_bench.py): column waves of the head GEMM (4 = eight waves, 2 = four waves).
+#ifdef DH3D_DEV  // dev builds only (tools/dense_bench.py): column waves of the head GEMM (4 = eight waves, 2 = four)
 static int g_head_wc = 4;
 DH3D_API void dh3d_dev_set_head_wc(int wc) { g_head_wc = wc == 2 ? 2 : 4; }
+#else
+static constexpr int g_head_wc = 4;
+#endif
 
 DH3D_API int dh3d_mlp_head_pm_x6_fwd(const float *h, int R, int C, const void *wpacked_x3, int H,
                                      const dh3d_epilogue *ep, const float *w_fc, float b_fc, float *att,

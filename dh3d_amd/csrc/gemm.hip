@@ -405,8 +405,13 @@ int gemm_launch(bool ta, const float *A, int lda, const float *B, int ldb, float
   const int BM = 128, BN = narrow ? 64 : 128;
   const int gm = dh3d_cdiv(M, BM), gn = dh3d_cdiv(N, BN);
   // workgroups aimed at: the split partials meet in f32 atomics (~0.3 T/s chip-wide), so the long-reduction tn form
-  // wants fewer, longer chunks (tools/gemm_bench.py wgs: 384 beats 768 by 10-25 % there); DH3D_GEMM_WGS overrides (dev)
+  // wants fewer, longer chunks (tools/gemm_bench.py wgs: 384 beats 768 by 10-25 % there); a -DDH3D_DEV build reads
+  // DH3D_GEMM_WGS / DH3D_GEMM_F32 / DH3D_GEMM_KC from the environment (A/B timing); the shipped library has no such state
+#ifdef DH3D_DEV
   static const int wgs_env = [] { const char *e = getenv("DH3D_GEMM_WGS"); return e ? atoi(e) : 0; }();
+#else
+  constexpr int wgs_env = 0;
+#endif
   const int wgs = wgs_env > 0 ? wgs_env : ta ? 384 : 768;
   int chunks = dh3d_cdiv(wgs, gm * gn * bt.n);
   const int maxc = dh3d_cdiv(K, ta ? 64 : 256);  // [M,K] operands: only long reductions are worth the atomics
@@ -414,12 +419,20 @@ int gemm_launch(bool ta, const float *A, int lda, const float *B, int ldb, float
   if (chunks < 1 || colbias) chunks = 1;
   // products of >= 2^26 multiply-adds with K % 32 == 0 go to the bf16x6 kernel (f32-accurate); small or odd-K ones stay on
   // the exact-f32 pipe.  DH3D_GEMM_F32=1 keeps everything there (A/B timing, bit-level comparisons)
+#ifdef DH3D_DEV
   static const bool force_f32 = [] { const char *e = getenv("DH3D_GEMM_F32"); return e && e[0] == '1'; }();
+#else
+  constexpr bool force_f32 = false;
+#endif
   const bool x6 = !force_f32 && K % 32 == 0 && (double)M * N * K * bt.n >= 67108864.0 &&
                   (ta || (lda % 4 == 0 && (double)M * lda < 1073741824.0));
   // stage depth (measured, tools/gemm_bench.py): 16 for the 128-wide tiles (four workgroups per CU), 32 for N <= 64
   // (the A stream dominates: whole 128-byte lines per row); DH3D_GEMM_KC=16|32 forces one (dev)
+#ifdef DH3D_DEV
   static const int x6kc = [] { const char *e = getenv("DH3D_GEMM_KC"); return e ? atoi(e) : 0; }();
+#else
+  constexpr int x6kc = 0;
+#endif
   const int kc = !x6 ? kKC : (x6kc == 16 || x6kc == 32) ? x6kc : narrow ? 32 : 16;
   const int kgran = x6 ? 32 : kc;  // chunk granularity: whole stages of either depth
   int kchunk = dh3d_cdiv(K, chunks);

@@ -757,13 +757,71 @@ int knn_launch(const float *pos, int B, int N, int K, int32_t *nn, float *dist, 
   return dh3d_launch_status();
 }
 
+// Any position dimension (the reference loops over Dp, knn_bruteforce_kernel_gpu.cu.cc:98-107; DH3D itself only ever
+// passes xyz).  The coverage path: lane = query, candidates staged 256 at a time through LDS ([Dp][256], Dp <= 16), the
+// same roundings -- sum = fma(val, val, sum) in dimension order from 0, IEEE sqrt -- and the same (distance, CUB rank)
+// order, kept as a sorted list of 64-bit keys per lane (insertion; in scratch for large K).  Unfilled slots (N < K):
+// id -1, distance FLT_MAX (:110-111).
+template <int KMAX>
+__global__ __launch_bounds__(256) void knn_anydp_kernel(const float *__restrict__ pos, int Dp, int N, int K, KnnLadder lad,
+                                                        int32_t *__restrict__ nn, float *__restrict__ dist) {
+  __shared__ float s_c[16][256];
+  const int b = blockIdx.y, y = blockIdx.x * 256 + threadIdx.x;
+  const float *pc = pos + (size_t)b * Dp * N;
+  float q[16];
+#pragma unroll
+  for (int dp = 0; dp < 16; ++dp) q[dp] = (dp < Dp && y < N) ? pc[(size_t)dp * N + y] : 0.f;
+  u64 keys[KMAX];
+#pragma unroll
+  for (int i = 0; i < KMAX; ++i) keys[i] = ~0ull;
+  for (int x0 = 0; x0 < N; x0 += 256) {
+    __syncthreads();
+    for (int dp = 0; dp < Dp; ++dp) s_c[dp][threadIdx.x] = x0 + (int)threadIdx.x < N ? pc[(size_t)dp * N + x0 + threadIdx.x] : 0.f;
+    __syncthreads();
+    const int cnt = min(256, N - x0);
+    for (int j = 0; j < cnt; ++j) {
+      float sum = 0.f;
+      for (int dp = 0; dp < Dp; ++dp) {
+        const float val = s_c[dp][j] - q[dp];
+        sum = __builtin_fmaf(val, val, sum);
+      }
+      const float d = sqrtf(sum);
+      const int x = x0 + j;
+      const unsigned tb = (unsigned)((x & lad.ctmask) * lad.cv + (x >> lad.log2ct));
+      const u64 key = ((u64)__float_as_uint(d) << 32) | tb;
+      if (key < keys[K - 1]) {
+        int i = K - 1;
+        while (i > 0 && keys[i - 1] > key) { keys[i] = keys[i - 1]; --i; }
+        keys[i] = key;
+      }
+    }
+  }
+  if (y >= N) return;
+  int32_t *o_nn = nn + ((size_t)b * N + y) * K;
+  float *o_d = dist + ((size_t)b * N + y) * K;
+  for (int i = 0; i < K; ++i) {
+    if (keys[i] == ~0ull) { o_nn[i] = -1; o_d[i] = 3.402823466e+38f; continue; }
+    const unsigned tb = (unsigned)keys[i];
+    o_nn[i] = (int)(((tb % (unsigned)lad.cv) << lad.log2ct) + tb / (unsigned)lad.cv);
+    o_d[i] = __uint_as_float((unsigned)(keys[i] >> 32));
+  }
+}
+
 }  // namespace
 
 DH3D_API int dh3d_knn_bruteforce(const float *positions, int B, int Dp, int N, int K, int32_t *nn,
                                  float *dist, void *stream) {
   DH3D_REQUIRE(positions && nn && dist && B > 0 && N > 0 && K > 0 && Dp > 0);
-  DH3D_SUPPORTED(Dp == 3 && K <= 64 && B <= 65535);
-  return knn_launch<false>(positions, B, N, K, nn, dist, (hipStream_t)stream);
+  DH3D_SUPPORTED(K <= 64 && B <= 65535);
+  if (Dp == 3) return knn_launch<false>(positions, B, N, K, nn, dist, (hipStream_t)stream);
+  DH3D_SUPPORTED(Dp <= 16);  // (any Dp upstream; the staging tile here holds 16 coordinates)
+  const KnnLadder lad = knn_ladder(N);
+  dim3 grid(dh3d_cdiv(N, 256), B), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (K <= 8) hipLaunchKernelGGL(knn_anydp_kernel<8>, grid, block, 0, s, positions, Dp, N, K, lad, nn, dist);
+  else if (K <= 16) hipLaunchKernelGGL(knn_anydp_kernel<16>, grid, block, 0, s, positions, Dp, N, K, lad, nn, dist);
+  else hipLaunchKernelGGL(knn_anydp_kernel<64>, grid, block, 0, s, positions, Dp, N, K, lad, nn, dist);
+  return dh3d_launch_status();
 }
 
 DH3D_API int dh3d_knn_bruteforce_xyz(const float *xyz, int B, int N, int K, int32_t *nn, float *dist,
@@ -773,9 +831,12 @@ DH3D_API int dh3d_knn_bruteforce_xyz(const float *xyz, int B, int N, int K, int3
   return knn_launch<true>(xyz, B, N, K, nn, dist, (hipStream_t)stream);
 }
 
-// Dev knob (tools/geo_bench.py): waves per query group of the ordered search; -1 = default, 0 = one-wave kernel.
+#ifdef DH3D_DEV  // dev builds only (tools/geo_bench.py): waves per query group of the ordered search; -1 = default
 static int g_knn_split = -1;
 DH3D_API void dh3d_dev_set_knn_split(int s) { g_knn_split = s; }
+#else
+static constexpr int g_knn_split = -1;
+#endif
 
 DH3D_API int dh3d_knn_sorted(const float *sorted, const float *gbox, int B, int N, int K, int32_t *nn,
                              float *dist, void *stream) {

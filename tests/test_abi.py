@@ -36,7 +36,7 @@ def test_invalid_arguments_are_status_codes_not_crashes():
     z = ctypes.c_void_p(0)
     assert lib.dh3d_knn_bruteforce(z, 1, 3, 8, 4, z, z, z) == 1          # null pointers
     one = ctypes.c_void_p(16)
-    assert lib.dh3d_knn_bruteforce(one, 1, 2, 8, 4, one, one, z) == 2      # Dp != 3 unsupported
+    assert lib.dh3d_knn_bruteforce(one, 1, 17, 8, 4, one, one, z) == 2     # Dp > 16: beyond the staging tile
     assert lib.dh3d_knn_bruteforce(one, 1, 3, 8, 0, one, one, z) == 1      # K <= 0
     assert lib.dh3d_farthest_point_sample(1, 20000, 8, one, z, one, z) == 2  # N > 16384
     assert lib.dh3d_farthest_point_sample(1, 64, 0, one, z, one, z) == 1     # npoint <= 0 (tf_sampling.cpp:100)

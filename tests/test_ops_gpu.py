@@ -87,6 +87,20 @@ def test_knn_beyond_reference_cap(dev, oracle):
 
 
 # ------------------------------------------------------------------------------ FPS
+@pytest.mark.parametrize("B,Dp,N,K", [(2, 2, 700, 8), (1, 5, 300, 16), (2, 8, 1030, 4), (1, 16, 260, 33), (1, 4, 6, 8)])
+def test_knn_any_position_dimension_bitexact_vs_oracle(dev, oracle, B, Dp, N, K):
+    """knn_bruteforce on positions of any dimension (the reference loops over Dp, knn_bruteforce_kernel_gpu.cu.cc:
+    98-107): ids and distances bit-equal to the oracle, exact ties (a lattice) ordered by the CUB rank, N < K padded
+    with -1 / FLT_MAX."""
+    from dh3d_amd import ops
+    rng = np.random.default_rng(Dp * 1000 + N)
+    pos = rng.random((B, Dp, N), dtype=np.float32)
+    pos[0] = np.round(pos[0] * 4) / 4          # a coarse lattice: many exact distance ties
+    nn, d = ops.knn_bruteforce(T(pos, dev), K)
+    enn, ed = oracle.knn_bruteforce(pos, K)
+    assert np.array_equal(nn.cpu().numpy(), enn) and np.array_equal(d.cpu().numpy(), ed)
+
+
 @pytest.mark.parametrize("B,N,m", [(2, 1024, 128), (1, 600, 64), (2, 4096, 512), (1, 8192, 1024), (1, 100, 100),
                                    (1, 10000, 300)])
 def test_fps_bitexact_vs_oracle(dev, oracle, B, N, m):

@@ -106,10 +106,11 @@ def test_flex_conv_x6_full_size_matches_f32_kernel(dev, Din):
     assert err < 2e-6, err
 
 
-def test_flex_conv_cfg5_shape_matches_reference_formulation(dev):
+def test_flex_conv_cfg5_shape_matches_reference_formulation(dev, oracle):
     """BASELINE config 5: one flex_conv 128 -> 128 at B=1, N=16384, K=12 (localdesc_extract.py:146,166).  The fused
-    factorised kernel (run-time K) against the drop-in kernel that keeps the reference's formulation and
-    summation order (itself checked against the oracle at small sizes)."""
+    factorised kernel (run-time K) against (a) the drop-in kernel that keeps the reference's formulation and summation
+    order -- with ops.FAST_PATH off, so that it is NOT the fused kernel behind two transposes -- and (b) the ORACLE on a
+    strided sample of the 16384 rows (the C loop is 9*K*Din*Dout flop per point: the full launch would take a minute)."""
     from dh3d_amd import ops, pm
     g = torch.Generator().manual_seed(5)
     B, N, K, Din, Dout = 1, 16384, 12, 128, 128
@@ -119,11 +120,29 @@ def test_flex_conv_cfg5_shape_matches_reference_formulation(dev):
     theta = (torch.randn(3, Din, Dout, generator=g) / Din ** 0.5).to(dev)
     bias = (torch.randn(Din, Dout, generator=g) / (K * Din) ** 0.5).to(dev)
     fused = pm.flex_conv(f, xyz, nbr, pm.pack_flex_weight(theta, bias), Dout)
-    ref = ops.flex_convolution(f.transpose(1, 2).contiguous(), xyz.transpose(1, 2).contiguous(),
-                               nbr.transpose(1, 2).contiguous(), theta, bias).transpose(1, 2)
+    fast = ops.FAST_PATH
+    try:
+        ops.FAST_PATH = False  # the reference-formulation kernel (csrc/flex_generic.hip), not the fused one re-wrapped
+        ref = ops.flex_convolution(f.transpose(1, 2).contiguous(), xyz.transpose(1, 2).contiguous(),
+                                   nbr.transpose(1, 2).contiguous(), theta, bias).transpose(1, 2)
+    finally:
+        ops.FAST_PATH = fast
     err = (fused - ref).abs().max().item() / ref.abs().max().item()
     assert err < 5e-6, err
     assert nbr.shape == (B, N, K) and bool((nbr[:, :, 0] == torch.arange(N, device=dev)).all())
+    # (b) the oracle on every 97th row: gather those rows' neighbourhoods into a compact cloud of 169 * 12 points
+    rows = np.arange(0, N, 97)
+    nb = nbr[0].cpu().numpy()[rows]                                     # [R, K] ids into the full cloud
+    ids = nb.reshape(-1)
+    sub_f = f[0].cpu().numpy()[ids].T[None]                             # [1, Din, R*K]
+    sub_p = xyz[0].cpu().numpy()[ids].T[None]
+    R = len(rows)
+    sub_nb = np.zeros((1, K, R * K), np.int32)                          # row r*K is query r (its rank-0 neighbour = itself)
+    sub_nb[0, :, ::K] = (np.arange(R)[None, :] * K + np.arange(K)[:, None])
+    exp = oracle.flex_convolution(np.ascontiguousarray(sub_f), np.ascontiguousarray(sub_p), sub_nb,
+                                  theta.cpu().numpy(), bias.cpu().numpy(), center_self=True)[0][:, ::K].T   # [R, Dout]
+    got = fused[0].cpu().numpy()[rows]
+    assert np.abs(got - exp).max() <= 1e-5 * np.abs(exp).max() + 1e-4 * np.abs(exp).mean(), np.abs(got - exp).max()
 
 
 def test_flex_pool_pm_exact(dev, oracle):
