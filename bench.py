@@ -406,6 +406,12 @@ def dropin_ops_line(dev):
         out["ops.flex_convolution 64->64 fwd"] = event_time_ms(
             lambda: ops.flex_convolution(f_cf, p_cf, nbr_cf, theta, bias), iters=10, warm=2)
         out["ops.flex_pooling D=64 fwd"] = event_time_ms(lambda: ops.flex_pooling(f_cf, nbr_cf), iters=10, warm=2)
+        # a shape no DH3D layer has (48 -> 96): the factorisation in two launches on the GEMM kernels
+        g = torch.Generator(device="cpu").manual_seed(2)
+        f48 = torch.randn(B, 48, N, generator=g).to(dev)
+        th48, b48 = torch.randn(3, 48, 96, generator=g).to(dev) / 7, torch.randn(48, 96, generator=g).to(dev) / 20
+        out["ops.flex_convolution 48->96 fwd (generic channel counts)"] = event_time_ms(
+            lambda: ops.flex_convolution(f48, p_cf, nbr_cf, th48, b48), iters=10, warm=2)
         th0, b0 = torch.randn(3, 32, device=dev), torch.randn(32, device=dev)
         out["ops.convolution_pointset 3->32 fwd"] = event_time_ms(
             lambda: ops.convolution_pointset(p_cf, nbr_cf, th0, b0), iters=10, warm=2)

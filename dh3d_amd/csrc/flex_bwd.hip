@@ -130,21 +130,32 @@ DH3D_API int dh3d_flex_conv_pm_bwd(const float *features, const float *xyz, cons
 // [B,3,N] positions).  A neighbour row in that layout is C scattered 4-byte reads (N*4 bytes apart), so the gather
 // kernels want point-major rows: the inputs are transposed through LDS tiles into the caller's workspace (HBM-bound,
 // ~2*size/5 TB/s each), the fused point-major kernel runs, and the result is transposed back.
-static bool fast_fwd_shape(int K, int Dp, int Din, int Dout, bool *x6) {
-  if (Dp != 3) return false;
+// 1 = fused kernel (x6: the persistent bf16x6 one), 2 = any other channel counts that are multiples of four: the
+// factorisation in two launches -- S = [S0|Sx|Sy|Sz] materialised by flex_S_kernel, then out = S @ [bias; theta] on the
+// GEMM kernels (gemm.hip) -- instead of the reference formulation's 9*K*Din*Dout flop per point on the vector unit
+// (flex_generic.hip: 3.4 ms at 64 -> 64, 8 x 8192, where this form takes ~0.1 ms)
+static int fast_fwd_shape(int K, int Dp, int Din, int Dout, bool *x6) {
+  *x6 = false;
+  if (Dp != 3) return 0;
   *x6 = K == 8 && Dout == 64 && (Din == 32 || Din == 64);
-  if (*x6) return true;
+  if (*x6) return 1;
   static const int ok[][2] = {{32, 64}, {32, 128}, {64, 64}, {64, 128}, {64, 256}, {128, 128}, {128, 256}};
   for (auto &p : ok)
-    if (p[0] == Din && p[1] == Dout) return true;
-  return false;
+    if (p[0] == Din && p[1] == Dout) return 1;
+  return (Din % 4 == 0 && Dout % 4 == 0) ? 2 : 0;
 }
 
 DH3D_API size_t dh3d_flex_conv_fwd_workspace_bytes(int B, int N, int K, int Dp, int Din, int Dout) {
   bool x6;
-  if (B <= 0 || N <= 1 || K <= 0 || !fast_fwd_shape(K, Dp, Din, Dout, &x6)) return 0;
+  const int kind = (B <= 0 || N <= 1 || K <= 0) ? 0 : fast_fwd_shape(K, Dp, Din, Dout, &x6);
+  if (kind == 0) return 0;
   const size_t R = (size_t)B * N;
   if (x6 && R * Din * 4 >= (1ull << 32)) return 0;
+  if (kind == 2) {  // + S [R, 4*Din] and the concatenated weight
+    if (R * 4 * Din >= (1ull << 31)) return 0;
+    return al256(4 * R * Din) + al256(4 * R * K) + al256(4 * R * 3) + al256((size_t)4 * 4 * Din * Dout) +
+           al256(4 * R * Dout) + al256(4 * R * 4 * Din);
+  }
   return al256(4 * R * Din) + al256(4 * R * K) + al256(4 * R * 3) + al256((size_t)6 * 4 * Din * Dout) + al256(4 * R * Dout);
 }
 
@@ -157,20 +168,32 @@ DH3D_API int dh3d_flex_conv_fwd_ws(const float *features, const float *theta, co
   DH3D_SUPPORTED(need != 0);
   DH3D_REQUIRE(workspace_bytes >= need);
   bool x6;
-  fast_fwd_shape(K, Dp, Din, Dout, &x6);
+  const int kind = fast_fwd_shape(K, Dp, Din, Dout, &x6);
   hipStream_t s = (hipStream_t)stream;
   const size_t R = (size_t)B * N;
   char *w = static_cast<char *>(workspace);
   float *f_pm = reinterpret_cast<float *>(w); w += al256(4 * R * Din);
   int32_t *nbr_pm = reinterpret_cast<int32_t *>(w); w += al256(4 * R * K);
   float *xyz_pm = reinterpret_cast<float *>(w); w += al256(4 * R * 3);
-  void *wp = w; w += al256((size_t)6 * 4 * Din * Dout);
+  void *wp = w; w += al256((size_t)(kind == 2 ? 4 : 6) * 4 * Din * Dout);
   float *out_pm = reinterpret_cast<float *>(w);
   int st;
   if ((st = dh3d_internal_transpose32(features, f_pm, B, Din, N, 0, 0, s)) != DH3D_OK) return st;
   if ((st = dh3d_internal_transpose32(neighborhood, nbr_pm, B, K, N, 0, 0, s)) != DH3D_OK) return st;
   if ((st = dh3d_internal_transpose32(positions, xyz_pm, B, 3, N, 0, 0, s)) != DH3D_OK) return st;
-  if (x6) {
+  if (kind == 2) {
+    w += al256(4 * R * Dout);
+    float *S = reinterpret_cast<float *>(w);
+    float *Wcat = static_cast<float *>(wp);  // [bias; theta_x; theta_y; theta_z]: [4*Din, Dout]
+    if (hipMemcpyAsync(Wcat, bias, sizeof(float) * Din * Dout, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(Wcat + (size_t)Din * Dout, theta, sizeof(float) * 3 * Din * Dout, hipMemcpyDeviceToDevice, s) != hipSuccess)
+      return DH3D_ERR_LAUNCH;
+    // centre = the point itself (the GPU forward's rule, flex_conv_kernel_gpu.cu.cc:77-79)
+    hipLaunchKernelGGL(flex_S_kernel, dim3(flat_grid256((long long)R * (Din / 4))), dim3(256), 0, s, f_pm, xyz_pm, nbr_pm,
+                       (long long)R, N, K, Din, 0, S);
+    if ((st = dh3d_launch_status()) != DH3D_OK) return st;
+    st = dh3d_internal_gemm(false, S, 4 * Din, Wcat, Dout, out_pm, Dout, (int)R, Dout, 4 * Din, nullptr, 0, false, s);
+  } else if (x6) {
     if ((st = dh3d_pack_flex_weight_x3(theta, bias, Din, Dout, wp, stream)) != DH3D_OK) return st;
     st = dh3d_flex_conv_pm_x6_fwd(f_pm, xyz_pm, nbr_pm, wp, B, N, K, Din, Dout, nullptr, out_pm, stream);
   } else {

@@ -435,7 +435,8 @@ __global__ __launch_bounds__(256) void vlad_normalize_kernel(const float *__rest
     gv[j] = it * (gv[j] - y1 * it * S);  // dy1
     sc = fmaf(gv[j], y1, sc);
   }
-  const float Sc = ssc > eps ? col_sum(sc) : 0.f;
+  const float Sc_all = col_sum(sc);  // (barriers inside: every thread calls it, the empty-cluster select comes after)
+  const float Sc = ssc > eps ? Sc_all : 0.f;
   float das = 0.f;
 #pragma unroll
   for (int j = 0; j < 64; ++j) {

@@ -43,6 +43,15 @@ def _count(R, mask, rows_per_cloud, device):
     return (mask.sum().to(torch.float64) * float(rows_per_cloud)).reshape(1)
 
 
+def _once(ctx, what):
+    """Several backward nodes overwrite a saved tensor with its gradient through raw pointers (autograd's version
+    counters cannot see that): a second backward over the same graph would silently read garbage -- refuse it."""
+    if getattr(ctx, "_dh3d_used", False):
+        raise RuntimeError("dh3d_amd.train_ops.%s: this node's backward reuses its saved activations in place and can "
+                           "run only once per forward (retain_graph / double backward are not supported)" % what)
+    ctx._dh3d_used = True
+
+
 class _BNState(object):
     """Forward statistics of one BatchNorm site: [mean, rstd, scale, shift] rows + the row count."""
     __slots__ = ("stats", "cnt")
@@ -186,6 +195,7 @@ class _AttentionHead(torch.autograd.Function):
     def backward(ctx, datt):
         X, W, h, g, be, wfc, att = ctx.saved_tensors
         sync, mask, rpc, st = ctx.cfg
+        _once(ctx, "attention_head")  # h is overwritten by its gradient below
         dlogit = (datt * att * (1.0 - att)).contiguous()                                # sigmoid
         if mask is not None:
             dlogit = dlogit * mask.repeat_interleave(rpc).to(dlogit.dtype)

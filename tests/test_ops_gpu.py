@@ -133,8 +133,12 @@ def _case(rng, B, N, K, Din, Dout, oracle):
                 topdiff=rng.standard_normal((B, Dout, N)).astype(np.float32))
 
 
-@pytest.mark.parametrize("shape", [(2, 32, 4, 2, 6), (2, 200, 8, 16, 24), (1, 513, 8, 32, 40)])
+@pytest.mark.parametrize("shape", [(2, 32, 4, 2, 6), (2, 200, 8, 16, 24), (1, 513, 8, 32, 40), (1, 700, 12, 100, 36),
+                                   (2, 1024, 8, 48, 96)])
 def test_flex_conv_fwd_bwd(dev, oracle, shape):
+    """The drop-in op at shapes no DH3D layer has: channel counts that are multiples of four run the factorisation in
+    two launches (S, then S @ [bias; theta] on the GEMM kernels; csrc/flex_bwd.hip), anything else the reference
+    formulation (csrc/flex_generic.hip) -- both against the oracle, forward and the three gradients."""
     from dh3d_amd import ops
     c = load("fake_pointcloud.npz") if shape == (2, 32, 4, 2, 6) else _case(np.random.default_rng(7), *shape, oracle)
     f = T(c["features"], dev).requires_grad_()
