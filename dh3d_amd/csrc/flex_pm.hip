@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256) void flex_conv_pm_kernel(
     // neighbour ids, (2) every neighbour row + coordinate of two rounds at a time, all in flight together.
     // (The round-by-round form spent ~16k cycles per tile waiting on vmcnt(0): profiles/r01_e.)
     constexpr int KK = KT > 0 ? KT : 1;
+    constexpr int HF = KK <= 8 ? 2 : 1;  // rounds whose neighbour rows are in flight together (registers: 4 * KK per round)
     int nid[C::ROUNDS][KK];
     float pxyz[C::ROUNDS][3];
     long long cloud0[C::ROUNDS];
@@ -82,19 +83,19 @@ __global__ __launch_bounds__(256) void flex_conv_pm_kernel(
       pxyz[rd][0] = xyz[nn * 3]; pxyz[rd][1] = xyz[nn * 3 + 1]; pxyz[rd][2] = xyz[nn * 3 + 2];
     }
 #pragma unroll
-    for (int rp = 0; rp < C::ROUNDS; rp += 2) {
-      float4 fv[2][KK];
-      float qv[2][KK][3];
-      long long gf[2][KK];
+    for (int rp = 0; rp < C::ROUNDS; rp += HF) {
+      float4 fv[HF][KK];
+      float qv[HF][KK][3];
+      long long gf[HF][KK];
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < HF; ++h)
 #pragma unroll
         for (int k = 0; k < KK; ++k) {
           const long long g = cloud0[rp + h] + nid[rp + h][k];
           gf[h][k] = remap ? (cloud0[rp + h] / N) * Nsrc + remap[g] : g;
         }
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < HF; ++h)
 #pragma unroll
         for (int k = 0; k < KK; ++k) {
           const long long g = cloud0[rp + h] + nid[rp + h][k];
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void flex_conv_pm_kernel(
           qv[h][k][0] = xyz[g * 3]; qv[h][k][1] = xyz[g * 3 + 1]; qv[h][k][2] = xyz[g * 3 + 2];
         }
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < HF; ++h) {
         const int rd = rp + h;
         float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), sx = s0, sy = s0, sz = s0;
 #pragma unroll
@@ -200,6 +201,12 @@ int flex_conv_pm_launch(const float *feat, const float *xyz, const int32_t *nbr,
   const dim3 grid(dh3d_cdiv(R, C::TM)), block(256);
   if (K == 8) {
     auto kern = flex_conv_pm_kernel<DIN, DOUT, 8>;
+    DH3D_ALLOW_BIG_LDS(kern);
+    hipLaunchKernelGGL(kern, grid, block, lds, s, feat, xyz, nbr, wpacked, R, N, K, ep, out, remap, Nsrc);
+  } else if (K == 12 && DIN == 128 && DOUT == 128) {
+    // BASELINE config 5's stress kernel (localdesc_extract.py:146,166: K = 12 on 128-d features): the two-round-trip
+    // gather with a compile-time K instead of the run-time-K loop (a dependent id -> row load chain per neighbour)
+    auto kern = flex_conv_pm_kernel<DIN, DOUT, 12>;
     DH3D_ALLOW_BIG_LDS(kern);
     hipLaunchKernelGGL(kern, grid, block, lds, s, feat, xyz, nbr, wpacked, R, N, K, ep, out, remap, Nsrc);
   } else {
