@@ -535,6 +535,12 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         relaunch_under_torchrun(args.gpus)  # does not return
 
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version / host block on stdout
+    # when a communicator is created): everything but the final line is routed to stderr at the file-descriptor level.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     from dh3d_amd import dist as D
     rank, world = D.init_from_env()
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -748,7 +754,8 @@ def main():
         line["cpu_baseline"] = cpu_baseline(args.workload)
     D.barrier()
     if rank == 0:
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if world > 1:
         torch.distributed.destroy_process_group()
 
