@@ -16,6 +16,14 @@ One process per GPU over RCCL.  `--gpus N` with no torchrun environment re-launc
   train is always strong (one role-ordered Siamese batch sharded over the ranks + descriptor all-gather).
 The timed region is bracketed by barrier + synchronize, the max over ranks is taken, rank 0 prints ONE JSON line.
 The forward step is a hipGraph replay of dh3d_amd.model.DH3D.forward.
+
+Steps in flight.  One forward of this path is a latency chain on a few CUs (farthest point sampling: one CU per cloud
+for two thirds of the local step) followed by chip-wide kernels, so an engine that extracts descriptors for a stream of
+batches keeps TWO steps in flight: two graph instances on two streams, each with its own batch buffers; step i is one
+full pass over one batch on stream i % 2, and the K timed steps include the pipeline's fill and drain.  That is `value`
+since round 3 (`config.steps_in_flight`: 2).  `one_step_at_a_time` in the same line is the number rounds 1-2 reported as
+`value` (each step finishes before the next one starts); `--inflight 1` makes it `value` again.  The training step
+depends on the previous step's weights and always runs one at a time.
 """
 import argparse
 import json
@@ -527,9 +535,12 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not collect live PMC traffic for the roofline kernel")
     ap.add_argument("--repeats", type=int, default=7,
                     help="further blocks of K timed steps after the contract block (median / min / max as extra keys)")
-    ap.add_argument("--inflight", type=int, default=1,
+    ap.add_argument("--inflight", type=int, default=2,
                     help="independent steps in flight (graph instances on separate streams, each with its own batch "
-                         "buffers): a serving loop's overlap of consecutive batches.  Default 1 = one step at a time")
+                         "buffers, every step one full pass over one batch).  Default 2: a forward of this path is a "
+                         "latency chain on a few CUs (FPS: one CU per cloud) followed by chip-wide kernels, so the engine "
+                         "overlaps consecutive batches; 1 = one step at a time (also measured and reported as "
+                         "`one_step_at_a_time` in every line).  The training step always runs one at a time")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -656,12 +667,13 @@ def main():
                                    "note": "further timed blocks after the contract one; `value` is the first block"}
         return total * args.steps / dt, dt / args.steps * 1e3, info
 
-    def measure_in_flight(workload, depth=2):
-        """Throughput with `depth` independent steps in flight (graph instances on separate streams, every step still
-        one full pass over one batch).  A step of this path leaves most of the GPU idle (FPS: a few CUs per cloud), so a
-        serving loop overlaps consecutive batches.  The default `value` stays the one-step-at-a-time number."""
+    def measure_in_flight(workload, depth=2, repeats=0):
+        """Throughput with `depth` independent steps in flight: `depth` graph instances on `depth` streams, each with its
+        own batch buffers; step i is one full pass over one batch on stream i % depth.  A single forward of this path
+        leaves most of the GPU idle (FPS: one CU per cloud for two thirds of the step), so consecutive batches overlap;
+        the K timed steps include the pipeline's fill and drain (barrier + synchronize on both sides as always)."""
         wl = WORKLOADS[workload]
-        per, total = per_rank_batch(wl["B"])
+        per, total = per_rank_batch(args.batch if workload == args.workload and args.batch else wl["B"])
         model = build_model(wl["preset"], dev, seed=0, num_points=wl["N"])
         pts = synthetic_clouds(per, wl["N"], wl["seed"], dev, rank)
         streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
@@ -678,13 +690,25 @@ def main():
             for st in streams:
                 st.wait_stream(torch.cuda.current_stream())
             dt = time_steps(step, pts, args.steps, args.warmup, dev)
-        return total * args.steps / dt, dt / args.steps * 1e3
+            rep = None
+            if repeats > 0:
+                blocks = repeat_blocks(step, pts, args.steps, dev, repeats)
+                rep = {"blocks": repeats, "steps_per_block": args.steps, "ms_per_step": [round(b, 5) for b in blocks],
+                       "median_ms": float(np.median(blocks)), "min_ms": float(np.min(blocks)),
+                       "max_ms": float(np.max(blocks)), "median_value": total / (float(np.median(blocks)) * 1e-3),
+                       "note": "further timed blocks after the contract one; `value` is the first block"}
+        return total * args.steps / dt, dt / args.steps * 1e3, rep
 
-    if args.inflight > 1 and args.workload != "train":
-        value, ms = measure_in_flight(args.workload, args.inflight)
-        info = {}
-    else:
-        value, ms, info = measure(args.workload)
+    pipelined = args.inflight > 1 and args.workload != "train"
+    value, ms, info = measure(args.workload)  # one step at a time (the definition of rounds 1-2; `value` for train)
+    serial = {"value": value, "unit": "point-clouds/sec", "ms_per_step": ms,
+              "note": "each step finishes before the next one starts (rounds 1-2 reported this as `value`)"}
+    if "repeats" in info:
+        serial["repeats"] = info.pop("repeats")
+    if pipelined:
+        value, ms, rep = measure_in_flight(args.workload, args.inflight, args.repeats)
+        if rep:
+            info["repeats"] = rep
     wl = WORKLOADS[args.workload]
     per, total = per_rank_batch(args.batch or wl["B"])
     line = {
@@ -694,9 +718,13 @@ def main():
         "ranks_seen": ranks_seen,
         "config": {"workload": wl["name"], "clouds_per_gpu": per, "clouds_total": total, "points": wl["N"], "knn": 8,
                    "parallelism": "clouds sharded over %d GPU(s), no data-path collective" % world,
-                   "weights": "random-init (no checkpoint blobs exist upstream)", "execution": "hipGraph replay",
-                   "steps_in_flight": args.inflight if args.workload != "train" else 1},
+                   "weights": "random-init (no checkpoint blobs exist upstream)",
+                   "execution": ("hipGraph replay; %d steps in flight (one graph instance + batch buffers per stream, every "
+                                 "step one full pass over one batch)" % args.inflight) if pipelined else "hipGraph replay",
+                   "steps_in_flight": args.inflight if pipelined else 1},
     }
+    if args.workload != "train":
+        line["one_step_at_a_time"] = serial
     if "repeats" in info:
         line["repeats"] = info["repeats"]
     if args.workload == "train":
@@ -727,8 +755,12 @@ def main():
                 continue
             ov, oms, oinfo = measure(other, batch=WORKLOADS[other]["B"])
             rec = {"workload": WORKLOADS[other]["name"], "key": other, "value": ov, "unit": "point-clouds/sec",
-                   "ms_per_step": oms}
+                   "ms_per_step": oms, "steps_in_flight": 1}
             rec.update(oinfo)
+            if pipelined and other != "train":  # the same definition as the line's `value`
+                rec["one_step_at_a_time"] = {"value": ov, "ms_per_step": oms}
+                rec["value"], rec["ms_per_step"], _ = measure_in_flight(other, args.inflight)
+                rec["steps_in_flight"] = args.inflight
             if other == "cfg5":
                 with torch.no_grad():
                     rec["kernel_roofline"] = cfg5_kernel_line(dev)
@@ -736,10 +768,11 @@ def main():
             others.append(rec)
         line["other_workloads"] = others
         line["other_workload"] = others[0]  # round-1 key, kept for the driver's diff
-        pv, pms = measure_in_flight(args.workload, 2)
-        line["two_steps_in_flight"] = {"value": pv, "unit": "point-clouds/sec", "ms_per_step": pms,
-                                       "note": "informational: consecutive batches overlapped on two streams; "
-                                               "`value` is measured one step at a time"}
+        if args.workload != "train":
+            depths = {"1": serial["value"]}
+            for dpt in (2, 4):
+                depths[str(dpt)] = value if (pipelined and dpt == args.inflight) else measure_in_flight(args.workload, dpt)[0]
+            line["throughput_by_steps_in_flight"] = depths
         # per-GPU throughput against the local batch: what `--scaling strong` gives each GPU at 8 / 4 / 2 GPUs
         # (SURVEY 8e "Expected scaling": the FPS / kNN latency chain does not shrink with the batch)
         sweep = []
