@@ -249,8 +249,10 @@ losses += [float(t1.step(pts, sync=False)) for _ in range(5)]
 assert t1._step_graphs, "the sharded step fell back to eager launches"
 assert per_step == 12, per_step   # 5 forward + 5 backward BatchNorm statistics, descriptor all-gather, gradient arena
 assert np.allclose(losses, ref_losses, rtol=2e-3, atol=2e-4), (losses, ref_losses)
-for p, q in zip(t1.params, tr.params):                  # six Adam steps later the parameters still agree
-    assert torch.allclose(p, q, rtol=0, atol=2e-3 * float(q.abs().max()) + 1e-6), float((p - q).abs().max())
+for p, q in zip(t1.params, tr.params):                  # six Adam steps later the parameters still agree: Adam moves an
+    d = (p.detach() - q.detach()).abs()                   # entry by ~lr * sign(g) per step, so an entry whose gradient is
+    assert float(d.max()) <= 6 * 2 * 5e-4 + 1e-6, float(d.max())   # rounding noise may differ by 2 * lr per step -- few do
+    assert float(d.mean()) <= 1e-4, float(d.mean())
 for p in t1.params:                                     # .grad are views of the one arena that was all-reduced
     assert p.grad.untyped_storage().data_ptr() == t1._garena.untyped_storage().data_ptr()
 tdist.destroy_process_group()
