@@ -382,6 +382,8 @@ class QuadrupletTrainer(object):
         # captured, so the CPU-test path stays eager.
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         capturable = world == 1 and not D.collectives_active() or (D.collectives_active() and dist.get_backend() == "nccl")
+        if backbone_bn == "batch":
+            capturable = False  # the backbone's moving averages change every step: its folded copies are rebuilt eagerly
         self.graph_step = (impl == "hip" and capturable) if graph_step is None else (bool(graph_step) and capturable)
         self._garena = None     # flat gradient arena of the sharded step (all-reduced in place, .grad are views of it)
         self._sched = (float(start_lr), int(decay_step), float(decay_rate))
