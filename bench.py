@@ -675,6 +675,7 @@ def main():
         wl = WORKLOADS[workload]
         per, total = per_rank_batch(args.batch if workload == args.workload and args.batch else wl["B"])
         model = build_model(wl["preset"], dev, seed=0, num_points=wl["N"])
+        model.steps_in_flight = depth  # placement hint of the persistent kernels: that many FPS kernels hold CUs
         pts = synthetic_clouds(per, wl["N"], wl["seed"], dev, rank)
         streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
         with torch.no_grad():

@@ -216,10 +216,13 @@ class DH3D(nn.Module):
         # are the other way round and it runs on the side stream after stage 1 (compute_local).
         if self._side_is_critical(points):
             bb.finish_level(points, geo._lv, same_stream=True)
+            if getattr(self, "steps_in_flight", 1) > 1:  # the OTHER steps' FPS kernels hold CUs while stage 1 runs
+                geo.busy_cus_per_xcd = min(8, (self.steps_in_flight - 1) * ((points.shape[0] + 7) // 8))
         else:
             # the FPS chain outlasts stage 1: one CU per cloud (block b -> XCD b % 8) is held with ~100 KB of LDS while
             # the persistent flex_conv kernels of stage 1 run -- they leave those CUs out (placement hint, speed only)
-            geo.busy_cus_per_xcd = min(4, (points.shape[0] + 7) // 8)
+            # (steps_in_flight: a serving loop that overlaps consecutive batches has that many FPS kernels on the chip)
+            geo.busy_cus_per_xcd = min(8, getattr(self, "steps_in_flight", 1) * ((points.shape[0] + 7) // 8))
         side.wait_event(fork)
         with torch.cuda.stream(side):
             if knn_inds is not None:
