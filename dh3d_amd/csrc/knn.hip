@@ -70,6 +70,20 @@ __device__ __forceinline__ int cand_slot(int c, int comp) {
   return g * 12 + off;
 }
 
+__device__ __forceinline__ float knn_bcast(float v, int lane) {  // lane is wave-uniform
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// the set bit of m (!= 0) nearest to position gl (0..63), wave-uniform: candidate groups are visited outwards from the
+// queries' own group -- Morton neighbours are mostly spatial neighbours, and a K-list fed nearest-first takes ~K
+// insertions where one fed in index order takes ~K ln(n/K)
+__device__ __forceinline__ int knn_pick_near(unsigned long long m, int gl) {
+  const unsigned long long up = m >> gl, dn = m & ((1ull << gl) - 1);
+  const int da = up ? __builtin_ctzll(up) : 128;
+  const int db = dn ? gl - (63 - __builtin_clzll(dn)) : 128;
+  return da <= db ? gl + da : gl - db;
+}
+
 template <int KMAX>
 struct KnnState {
   u64 keys[KMAX];
@@ -84,13 +98,29 @@ __device__ __forceinline__ void knn_offer(KnnState<KMAX> &st, float s, int x, co
     const unsigned tb = (unsigned)((x & lad.ctmask) * lad.cv + (x >> lad.log2ct));
     const u64 key = ((u64)__float_as_uint(d) << 32) | tb;
     if (key < st.keys[KMAX - 1]) {
-      st.keys[KMAX - 1] = key;
+      if constexpr (KMAX <= 16) {
+        // the list is sorted and keys are unique: entry i becomes its left neighbour where the key goes in further
+        // left, the key where it goes in exactly here.  KMAX - 1 independent compares and two selects per entry --
+        // no dependent chain (a bubble pass is one compare + four selects per step, each waiting for the last)
+        bool lt[KMAX];
 #pragma unroll
-      for (int i = KMAX - 1; i > 0; --i) {
-        const u64 a = st.keys[i - 1], b = st.keys[i];
-        const bool lt = b < a;
-        st.keys[i - 1] = lt ? b : a;
-        st.keys[i] = lt ? a : b;
+        for (int i = 0; i < KMAX - 1; ++i) lt[i] = key < st.keys[i];
+        lt[KMAX - 1] = true;
+#pragma unroll
+        for (int i = KMAX - 1; i > 0; --i) {
+          const u64 in = lt[i - 1] ? st.keys[i - 1] : key;
+          st.keys[i] = lt[i] ? in : st.keys[i];
+        }
+        st.keys[0] = lt[0] ? key : st.keys[0];
+      } else {
+        st.keys[KMAX - 1] = key;
+#pragma unroll
+        for (int i = KMAX - 1; i > 0; --i) {
+          const u64 a = st.keys[i - 1], b = st.keys[i];
+          const bool lt = b < a;
+          st.keys[i - 1] = lt ? b : a;
+          st.keys[i] = lt ? a : b;
+        }
       }
       const unsigned hb = (unsigned)(st.keys[KMAX - 1] >> 32);
       if (hb <= 0x7f800000u) {
@@ -254,7 +284,7 @@ __global__ __launch_bounds__(kQueriesPerBlock) void knn_kernel(const float *__re
 // bit-identical to it (tests).  Waves are independent: no block-level barrier.
 constexpr int kSortedWaves = 4;
 #ifdef DH3D_KNN_PROBE  // dev instrumentation (tools/knn_probe.py): per-wave cycle / event counters
-__device__ long long g_kprobe[8 * 512];
+__device__ long long g_kprobe[8 * 4096];
 #endif
 
 template <int KMAX>
@@ -300,21 +330,19 @@ __global__ __launch_bounds__(64 * kSortedWaves) void knn_sorted_kernel(const flo
     const long long d0 = clock64();
     ++pr_ndrain;
 #endif
-    // all queued entries are requested from LDS before the first (long) insertion: one exposed latency per drain
-    // instead of one per slot
+    // ONE copy of the (long) insertion per drain site, the next slot requested from LDS while this one is inserted.
+    // Unrolled over the 16 slots the kernel was > 100 KB of code (the drain is inlined at every site of the scan): more
+    // than the instruction cache two CUs share, and the waves of a CU are all at different places of it.
     const int deepest = -wave_min_i32(-cnt);
-    uint2 ent[kQueue];
-#pragma unroll
-    for (int i = 0; i < kQueue; ++i)
-      if (i < deepest) ent[i] = my_q[i * 64 + lane];
-#pragma unroll
-    for (int i = 0; i < kQueue; ++i) {
-      if (i < deepest) {  // wave-uniform
+    uint2 nxt = my_q[lane];
+#pragma unroll 1
+    for (int i = 0; i < deepest; ++i) {  // wave-uniform trip count
+      const uint2 e = nxt;
+      if (i + 1 < deepest) nxt = my_q[(i + 1) * 64 + lane];
 #ifdef DH3D_KNN_PROBE
-        ++pr_nslots;
+      ++pr_nslots;
 #endif
-        if (i < cnt) knn_offer<KMAX>(st, __uint_as_float(ent[i].x), (int)ent[i].y, lad);
-      }
+      if (i < cnt) knn_offer<KMAX>(st, __uint_as_float(e.x), (int)e.y, lad);
     }
     cnt = 0;
     wave_bound = wave_max_f32(valid ? st.bound : 0.f);
@@ -371,13 +399,19 @@ __global__ __launch_bounds__(64 * kSortedWaves) void knn_sorted_kernel(const flo
 
   // other groups: lane <-> candidate group box test (64 groups per round), overlapping boxes (distance 0)
   // first, then whatever still lies within the (tightened) bound; next group's records are prefetched.
+  const int cg = g >> 6, NC = (NG + 63) >> 6;
   for (int tier = 0; tier < 2; ++tier) {
-    for (int c0 = 0; c0 < NG; c0 += 64) {
+    for (int k = 0; k < 2 * NC; ++k) {  // chunks of 64 groups outwards from the own one: cg, cg+1, cg-1, cg+2, ...
+      const int ci = cg + ((k & 1) ? (k + 1) / 2 : -(k / 2));
+      if (ci < 0 || ci >= NC) continue;
+      const int c0 = ci * 64, gl = min(max(g - c0, 0), 63);
       const int gi = c0 + lane;
       const bool other = gi < NG && gi != g;
       float bd = INFINITY;
+      float4 clo = make_float4(INFINITY, INFINITY, INFINITY, 0.f), chi = clo;
       if (other) {
-        const float4 clo = gb[gi * 2], chi = gb[gi * 2 + 1];
+        clo = gb[gi * 2];
+        chi = gb[gi * 2 + 1];
         const float ex = fmaxf(fmaxf(clo.x - qhi.x, qlo.x - chi.x), 0.f);
         const float ey = fmaxf(fmaxf(clo.y - qhi.y, qlo.y - chi.y), 0.f);
         const float ez = fmaxf(fmaxf(clo.z - qhi.z, qlo.z - chi.z), 0.f);
@@ -386,20 +420,32 @@ __global__ __launch_bounds__(64 * kSortedWaves) void knn_sorted_kernel(const flo
       unsigned long long mask =
           tier == 0 ? __ballot(other && bd == 0.f) : __ballot(other && bd > 0.f && bd <= wave_bound);
       if (!mask) continue;
-      int l = __builtin_ctzll(mask);
-      mask &= mask - 1;
+      int l = knn_pick_near(mask, gl);
+      mask &= ~(1ull << l);
       float4 nxt = load_group(c0 + l);
       while (true) {
         const int lcur = l;
         const float4 cr = nxt;
         const bool more = mask != 0;
         if (more) {
-          l = __builtin_ctzll(mask);
-          mask &= mask - 1;
+          l = knn_pick_near(mask, gl);
+          mask &= ~(1ull << l);
           nxt = load_group(c0 + l);
         }
         const float bdl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bd), lcur));
-        if (bdl <= wave_bound) scan_group(c0 + lcur, cr);  // the bound may have tightened since the ballot
+        if (bdl <= wave_bound) {  // the bound may have tightened since the ballot
+          // box against box says "some query of the wave MIGHT reach the group" with the union of the 64 queries and
+          // the loosest of their bounds; the same test per query (point to box, own bound) is ~20 instructions
+          // against the ~450 of scanning the group, and decides most of the overlapping (tier 0) groups of a query
+          // group whose own box is large (Morton order jumps across the cloud inside it)
+          const float lx = knn_bcast(clo.x, lcur), ly = knn_bcast(clo.y, lcur), lz = knn_bcast(clo.z, lcur);
+          const float hx = knn_bcast(chi.x, lcur), hy = knn_bcast(chi.y, lcur), hz = knn_bcast(chi.z, lcur);
+          const float px = fmaxf(fmaxf(lx - qr.x, qr.x - hx), 0.f);
+          const float py = fmaxf(fmaxf(ly - qr.y, qr.y - hy), 0.f);
+          const float pz = fmaxf(fmaxf(lz - qr.z, qr.z - hz), 0.f);
+          const float pd = (px * px + py * py + pz * pz) * 0.99999f;
+          if (__any(valid && pd <= st.bound)) scan_group(c0 + lcur, cr);
+        }
         if (!more) break;
       }
     }
@@ -481,6 +527,10 @@ __global__ __launch_bounds__(64 * S) void knn_split_kernel(const float4 *__restr
   s_share[wave][lane] = INFINITY;
   s_kth[wave][lane] = INFINITY;
   __syncthreads();
+#ifdef DH3D_KNN_PROBE
+  long long pr_t0 = clock64(), pr_drain = 0, pr_scan = 0;
+  int pr_ndrain = 0, pr_nslots = 0, pr_ngroups = 0, pr_hits = 0;
+#endif
 
   // everyone's progress -> my screen: the true K-th distance is at most any wave's own K-th, and at most the largest
   // of the S R-th distances
@@ -496,16 +546,20 @@ __global__ __launch_bounds__(64 * S) void knn_split_kernel(const float4 *__restr
   };
 
   auto drain = [&]() {
+#ifdef DH3D_KNN_PROBE
+    const long long d0 = clock64();
+    ++pr_ndrain;
+#endif
     const int deepest = -wave_min_i32(-cnt);
-    uint2 ent[kQueue];
-#pragma unroll
-    for (int i = 0; i < kQueue; ++i)
-      if (i < deepest) ent[i] = my_q[i * 64 + lane];
-#pragma unroll
-    for (int i = 0; i < kQueue; ++i) {
-      if (i < deepest) {  // wave-uniform
-        if (i < cnt) knn_offer<KMAX, true>(st, __uint_as_float(ent[i].x), (int)ent[i].y, lad);
-      }
+    uint2 nxt = my_q[lane];
+#pragma unroll 1
+    for (int i = 0; i < deepest; ++i) {  // one copy of the insertion per site (code size, see knn_sorted_kernel)
+      const uint2 e = nxt;
+      if (i + 1 < deepest) nxt = my_q[(i + 1) * 64 + lane];
+#ifdef DH3D_KNN_PROBE
+      ++pr_nslots;
+#endif
+      if (i < cnt) knn_offer<KMAX, true>(st, __uint_as_float(e.x), (int)e.y, lad);
     }
     cnt = 0;
     // publish my R-th distance, take the largest of everyone's
@@ -522,9 +576,16 @@ __global__ __launch_bounds__(64 * S) void knn_split_kernel(const float4 *__restr
       s_kth[wave][lane] = __fmul_rn(__fmul_rn(dk, dk), 1.000001f);
     }
     adopt(mx);
+#ifdef DH3D_KNN_PROBE
+    pr_drain += clock64() - d0;
+#endif
   };
 
   auto scan_group = [&](int gcc, const float4 cr) {
+#ifdef DH3D_KNN_PROBE
+    ++pr_ngroups;
+    const long long s0 = clock64(), dr0 = pr_drain;
+#endif
     my_c[cand_slot(lane, 0)] = cr.x;
     my_c[cand_slot(lane, 1)] = cr.y;
     my_c[cand_slot(lane, 2)] = cr.z;
@@ -541,6 +602,9 @@ __global__ __launch_bounds__(64 * S) void knn_split_kernel(const float4 *__restr
       }
       const float m = fminf(fminf(mn[0], mn[1]), fminf(mn[2], mn[3]));
       if (__any(valid && m <= st.bound)) {
+#ifdef DH3D_KNN_PROBE
+        ++pr_hits;
+#endif
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           if (valid && mn[u] <= st.bound) {
@@ -558,48 +622,118 @@ __global__ __launch_bounds__(64 * S) void knn_split_kernel(const float4 *__restr
       }
     }
     __builtin_amdgcn_wave_barrier();
+#ifdef DH3D_KNN_PROBE
+    pr_scan += (clock64() - s0) - (pr_drain - dr0);
+#endif
   };
   auto load_group = [&](int gcc) { const int ci = gcc * 64 + lane; return ci < N ? sc[ci] : pad; };
 
-  if (g % S == wave) {  // the queries' own group goes first where it is owned
-    scan_group(g, qr);
-    if (__any(cnt > 0)) drain();
+  // lane <-> a candidate group this wave OWNS: the j-th is group j * S + wave.  Box against box in the lanes, 64 owned
+  // groups per round; their boxes are requested before the own group is scanned and stay in registers for both tiers.
+  const int NO = (NG - wave + S - 1) / S, NCH = (NO + 63) >> 6;  // owned groups, chunks of 64 of them
+  const int jg = g / S, cj = min(jg >> 6, max(NCH - 1, 0));      // where the own group sits among them
+  bool other = false;
+  float bd = INFINITY;
+  float4 clo = make_float4(INFINITY, INFINITY, INFINITY, 0.f), chi = clo;
+  auto fetch_boxes = [&](int ci) {
+    const int j = ci * 64 + lane, gi = j * S + wave;
+    other = j < NO && gi != g;
+    if (other) {
+      clo = gb[gi * 2];
+      chi = gb[gi * 2 + 1];
+    }
+  };
+  auto test_boxes = [&]() {
+    bd = INFINITY;
+    if (other) {
+      const float ex = fmaxf(fmaxf(clo.x - qhi.x, qlo.x - chi.x), 0.f);
+      const float ey = fmaxf(fmaxf(clo.y - qhi.y, qlo.y - chi.y), 0.f);
+      const float ez = fmaxf(fmaxf(clo.z - qhi.z, qlo.z - chi.z), 0.f);
+      bd = (ex * ex + ey * ey + ez * ez) * 0.99999f;
+    }
+  };
+  if (NCH == 1) fetch_boxes(0);
+
+  {
+    // The queries' own group goes first, its blocks of 8 candidates dealt round-robin to the S waves: every wave enters
+    // the other groups with a list of its own and -- after the one barrier -- a bound all 64 candidates contributed
+    // to.  (With the group scanned by its owner alone the other waves met their first group with no bound at all and
+    // queued every candidate of it.)
+    my_c[cand_slot(lane, 0)] = qr.x;
+    my_c[cand_slot(lane, 1)] = qr.y;
+    my_c[cand_slot(lane, 2)] = qr.z;
+    my_id[lane] = __float_as_int(qr.w);
+    __builtin_amdgcn_wave_barrier();
+    const int clen = min(64, N - g * 64);
+    for (int blk = wave; blk * 8 < clen; blk += S) {
+      f32x2 sq[4];
+      knn_dist8(my_c + 2 * blk * 12, qx2, qy2, qz2, sq);
+      if (valid) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const float sv = sq[t >> 1][t & 1];
+          if (sv <= st.bound && blk * 8 + t < clen) {
+            my_q[cnt * 64 + lane] = make_uint2(__float_as_uint(sv), (unsigned)my_id[blk * 8 + t]);
+            ++cnt;
+          }
+        }
+      }
+      if (__any(cnt > 0)) drain();
+    }
+    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    adopt(s_share[wave][lane]);
   }
   for (int tier = 0; tier < 2; ++tier) {
-    for (int c0 = 0; c0 < NG; c0 += 64) {
-      const int gi = c0 + lane;
-      const bool other = gi < NG && gi != g && gi % S == wave;
-      float bd = INFINITY;
-      if (other) {
-        const float4 clo = gb[gi * 2], chi = gb[gi * 2 + 1];
-        const float ex = fmaxf(fmaxf(clo.x - qhi.x, qlo.x - chi.x), 0.f);
-        const float ey = fmaxf(fmaxf(clo.y - qhi.y, qlo.y - chi.y), 0.f);
-        const float ez = fmaxf(fmaxf(clo.z - qhi.z, qlo.z - chi.z), 0.f);
-        bd = (ex * ex + ey * ey + ez * ez) * 0.99999f;
-      }
+    for (int k = 0; k < 2 * NCH; ++k) {  // chunks of 64 owned groups outwards from the own one: cj, cj+1, cj-1, ...
+      const int ci = cj + ((k & 1) ? (k + 1) / 2 : -(k / 2));
+      if (ci < 0 || ci >= NCH) continue;
+      if (NCH > 1) fetch_boxes(ci);  // one chunk (N <= 64*64*S points): fetched once, before the own group
+      if (NCH > 1 || tier == 0) test_boxes();
+      const int gl = min(max(jg - ci * 64, 0), 63);
       if (tier == 1) adopt(s_share[wave][lane]);  // the others have worked since the last look
       unsigned long long mask =
           tier == 0 ? __ballot(other && bd == 0.f) : __ballot(other && bd > 0.f && bd <= wave_bound);
       if (!mask) continue;
-      int l = __builtin_ctzll(mask);
-      mask &= mask - 1;
-      float4 nxt = load_group(c0 + l);
+      int l = knn_pick_near(mask, gl);
+      mask &= ~(1ull << l);
+      float4 nxt = load_group((ci * 64 + l) * S + wave);
       while (true) {
         const int lcur = l;
         const float4 cr = nxt;
         const bool more = mask != 0;
         if (more) {
-          l = __builtin_ctzll(mask);
-          mask &= mask - 1;
-          nxt = load_group(c0 + l);
+          l = knn_pick_near(mask, gl);
+          mask &= ~(1ull << l);
+          nxt = load_group((ci * 64 + l) * S + wave);
         }
-        const float bdl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bd), lcur));
-        if (bdl <= wave_bound) scan_group(c0 + lcur, cr);  // the bound may have tightened since the ballot
+        const float bdl = knn_bcast(bd, lcur);
+        if (bdl <= wave_bound) {  // the bound may have tightened since the ballot
+          // box against box says "some query of the wave MIGHT reach the group" with the union of the 64 queries and
+          // the loosest of their bounds; the same test per query (point to box, own bound) is ~20 instructions
+          // against the ~450 of scanning the group, and decides most of the overlapping (tier 0) groups of a query
+          // group whose own box is large (Morton order jumps across the cloud inside it)
+          const float lx = knn_bcast(clo.x, lcur), ly = knn_bcast(clo.y, lcur), lz = knn_bcast(clo.z, lcur);
+          const float hx = knn_bcast(chi.x, lcur), hy = knn_bcast(chi.y, lcur), hz = knn_bcast(chi.z, lcur);
+          const float px = fmaxf(fmaxf(lx - qr.x, qr.x - hx), 0.f);
+          const float py = fmaxf(fmaxf(ly - qr.y, qr.y - hy), 0.f);
+          const float pz = fmaxf(fmaxf(lz - qr.z, qr.z - hz), 0.f);
+          const float pd = (px * px + py * py + pz * pz) * 0.99999f;
+          if (__any(valid && pd <= st.bound)) scan_group((ci * 64 + lcur) * S + wave, cr);
+        }
         if (!more) break;
       }
     }
   }
   if (__any(cnt > 0)) drain();
+#ifdef DH3D_KNN_PROBE
+  if (lane == 0 && ((b * NG + g) * S + wave) < 4096) {
+    long long *o = g_kprobe + (size_t)((b * NG + g) * S + wave) * 8;
+    o[7] = pr_t0;
+    o[0] = clock64() - pr_t0; o[1] = pr_drain; o[2] = pr_ndrain; o[3] = pr_nslots; o[4] = pr_ngroups;
+    o[5] = pr_scan; o[6] = pr_hits;
+  }
+#endif
 
   // merge the S lists (tree: w <- w + step), keys are unique so plain insertion
   for (int step = S / 2; step >= 1; step >>= 1) {

@@ -1,18 +1,39 @@
-import ctypes, torch, numpy as np
+"""Per-wave counters of knn_split_kernel (built with -DDH3D_KNN_PROBE, tools/gpu_knn_probe.sh) on the bench's clouds."""
+import ctypes, sys, torch, numpy as np
+sys.path.insert(0, ".")
+from bench import synthetic_clouds
 lib = ctypes.CDLL("tools/libknn_probe.so")
 dev = torch.device("cuda")
-for N in (4096, 8192):
-    xyz = torch.rand(8, N, 3, device=dev)
+for B, N in ((8, 8192), (32, 4096)):
+    xyz = synthetic_clouds(B, N, 1234, dev)[..., :3].contiguous()
     NG = (N + 63) // 64
-    srt = torch.empty(8, N, 4, device=dev); gbox = torch.empty(8, NG, 8, device=dev)
-    nn = torch.empty(8, N, 8, dtype=torch.int32, device=dev); d = torch.empty(8, N, 8, device=dev)
+    S = 4 if NG * B <= 1280 else 2
+    srt = torch.empty(B, N, 4, device=dev); gbox = torch.empty(B, NG, 8, device=dev)
+    nn = torch.empty(B, N, 8, dtype=torch.int32, device=dev); d = torch.empty(B, N, 8, device=dev)
     p = lambda t: ctypes.c_void_p(t.data_ptr())
-    for _ in range(2):
-        lib.dh3d_spatial_sort(p(xyz), 8, N, p(srt), p(gbox), None)
-        lib.dh3d_knn_sorted(p(srt), p(gbox), 8, N, 8, p(nn), p(d), None)
+    for _ in range(3):
+        lib.dh3d_spatial_sort(p(xyz), B, N, p(srt), p(gbox), None)
+        lib.dh3d_knn_sorted(p(srt), p(gbox), B, N, 8, p(nn), p(d), None)
     torch.cuda.synchronize()
-    h = (ctypes.c_longlong * (8 * NG))()
-    lib.dh3d_knn_probe_read(h, 8 * NG)
-    a = np.array(list(h)).reshape(NG, 8)
-    print("N=%d groups=%d: per wave mean cycles %.0f (max %.0f), in drains %.0f, #drains %.1f, #slot-iterations %.1f, #groups scanned %.1f" % (
-        N, NG, a[:, 0].mean(), a[:, 0].max(), a[:, 1].mean(), a[:, 2].mean(), a[:, 3].mean(), a[:, 4].mean()))
+    n = min(4096, B * NG * S)
+    h = (ctypes.c_longlong * (8 * n))()
+    lib.dh3d_knn_probe_read(h, 8 * n)
+    a = np.array(list(h)).reshape(n, 8)
+    print("B=%d N=%d S=%d, %d waves: cycles mean %.0f max %.0f | scanning %.0f | in drains %.0f | #drains %.1f "
+          "#slot-iterations %.1f | #groups scanned %.1f of %d owned | 32-candidate steps with a survivor %.1f of %.1f"
+          % (B, N, S, n, a[:, 0].mean(), a[:, 0].max(), a[:, 5].mean(), a[:, 1].mean(), a[:, 2].mean(), a[:, 3].mean(),
+             a[:, 4].mean(), NG // S, a[:, 6].mean(), 2 * a[:, 4].mean()))
+    g = a.reshape(-1, S, 8)
+    life = g[:, :, 0].max(1)
+    print("   per query group: slowest wave mean %.0f; percentiles 50/90/99/100: %s; groups scanned mean %.1f max %d"
+          % (life.mean(), np.percentile(life, [50, 90, 99, 100]).astype(int), g[:, :, 4].sum(1).mean(), g[:, :, 4].sum(1).max()))
+    t0 = a[:, 7].min()
+    end = (a[:, 7] + a[:, 0] - t0)
+    print("   wave start (cycles after the first) percentiles 50/90/100: %s; wave end 50/90/99/100: %s"
+          % (np.percentile(a[:, 7] - t0, [50, 90, 100]).astype(int), np.percentile(end, [50, 90, 99, 100]).astype(int)))
+    worst = np.argsort(-a[:, 0])[:5]
+    for w in worst:
+        print("   slow wave %d: cycles %d scan %d drain %d drains %d slots %d groups %d hits %d"
+              % (w, a[w, 0], a[w, 5], a[w, 1], a[w, 2], a[w, 3], a[w, 4], a[w, 6]))
+    c = np.corrcoef(a[:, 0], a[:, 4])[0, 1], np.corrcoef(a[:, 0], a[:, 3])[0, 1]
+    print("   correlation of a wave's cycles with groups scanned %.2f, with slot-iterations %.2f" % c)
