@@ -123,6 +123,14 @@ _SIGNATURES = {
     "dh3d_quadruplet_loss": [c_fp, c_int, c_int, c_int, c_int, c_float, c_float, c_fp, c_fp, c_fp],
     "dh3d_vlad_normalize_fwd": [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_float, c_fp, c_fp, c_fp, c_fp],
     "dh3d_vlad_normalize_bwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_float, c_fp, c_fp, c_fp, c_fp],
+    "dh3d_netvlad_commuted_fwd_stats": [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp],
+    "dh3d_netvlad_commuted_fwd_assign": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp,
+                                         c_fp, c_fp, c_fp],
+    "dh3d_netvlad_commuted_bwd_sums": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int,
+                                       c_fp, c_fp, c_fp, c_fp, c_fp, c_fp],
+    "dh3d_netvlad_commuted_bwd_apply": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp,
+                                        c_fp, c_fp, c_fp],
+    "dh3d_interp_scatter_scaled": [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp],
     "dh3d_interp_bn_colstats": [c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp],
     "dh3d_interp_bn_bwd_sums": [c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp,
                                 c_fp, c_fp, c_fp, c_fp],

@@ -14,6 +14,8 @@
 //   MODE 2  dh = k1 dz - k2 - k3 h  scattered back through the interpolation:  dG[i_t(n), c] += w_t(n) dh[n, c]
 //   MODE 3  the same scatter for MATERIALISED gradient rows dY [B*n, 256] and explicit weights: the backward of
 //           three_interpolate (tf_interpolate.cpp:131-153) without one global atomic per (point, neighbour, channel)
+//   MODE 4  dh = -q[n] h[n] with a per-POINT factor q, ADDED to dG: the l2-normalisation term of NetVLAD's commuted
+//           backward (netvlad_train.hip: dc -= interp^T(q x), x = interp(c) rebuilt from the staged rows)
 // with dz[n,c] = dlogit[n] * w_fc[c] * [y > 0] (the rank-one gradient of train.hip's attention head).  The scatter of
 // MODE 2 is a product on the matrix cores: per 32 points, dG_tile[slot, c] += sum_n S[n, slot] dh[n, c] with S built in
 // registers from the slot table (S[n, slot_t(n)] = w_t(n)) -- LDS float atomics retire about one lane per 2.4 cycles
@@ -97,7 +99,7 @@ struct InterpBnArgs {
 template <int MODE>
 __global__ __launch_bounds__(256) void interp_bn_kernel(const InterpBnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float s_mem[];
-  constexpr int CAP = MODE >= 2 ? kCap2 : kCap;
+  constexpr int CAP = MODE >= 2 ? kCap2 : kCap;  // (MODE 4 = MODE 2 with another dh)
   constexpr int ROWS = MODE == 3 ? 0 : CAP;                        // MODE 3 stages nothing
   float *s_rows = s_mem;                                           // [ROWS][256]
   int *s_slot = reinterpret_cast<int *>(s_rows + ROWS * 256);      // [kP][4] slots (or -1 - coarse row), .w = 1 + original index (0: none)
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256) void interp_bn_kernel(const InterpBnArgs a) {
     rowoff[u] = (bi * m + s_row[r < nd ? r : 0]) * a.RS + lane * 4;
   }
   // (not in MODE 2: 64 more registers would leave one wave per SIMD there)
-  constexpr bool PREFETCH = MODE != 2;
+  constexpr bool PREFETCH = MODE != 2 && MODE != 4;
 #if !defined(DH3D_IB_EXP) || !(DH3D_IB_EXP & 16)   // exp 16: no staging (results wrong)
   if (MODE != 3 && PREFETCH) rg = request_rows<CAP / 4>(a.G, rowoff);
 #endif
@@ -311,6 +313,9 @@ __global__ __launch_bounds__(256) void interp_bn_kernel(const InterpBnArgs a) {
             const float4 h = mix3(row4<OVF>(s_rows, Gs, s0, lane, a.RS), row4<OVF>(s_rows, Gs, s1, lane, a.RS),
                                   row4<OVF>(s_rows, Gs, s2, lane, a.RS), sw.x, sw.y, sw.z);
             const float dl = sw.w, live = si.w ? 1.f : 0.f;
+            if (MODE == 4) {  // dl = q[n] (0 on padding points)
+              dh = make_float4(-dl * h.x, -dl * h.y, -dl * h.z, -dl * h.w);
+            } else {
             // dh = k1 dz - k2 - k3 h,  dz = dlogit w_fc [h scale + shift > 0]   (0 on padding points)
 #define DH3D_IB_DH(X)                                                                           \
   {                                                                                             \
@@ -319,6 +324,7 @@ __global__ __launch_bounds__(256) void interp_bn_kernel(const InterpBnArgs a) {
   }
             DH3D_IB_DH(x) DH3D_IB_DH(y) DH3D_IB_DH(z) DH3D_IB_DH(w)
 #undef DH3D_IB_DH
+            }
             }
             *reinterpret_cast<float4 *>(s_dh + pl * kLDH + lane * 4) = dh;
             if (OVF) {  // rows that did not fit the staging area: straight to memory
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(256) void interp_bn_kernel(const InterpBnArgs a) {
 }
 
 size_t interp_bn_lds(int mode) {
-  const size_t rows = mode == 3 ? 0 : (mode == 2 ? kCap2 : kCap);
+  const size_t rows = mode == 3 ? 0 : (mode == 2 || mode == 4 ? kCap2 : kCap);
   const size_t base = sizeof(float) * (rows * 256 + kP * 4 * 2 + 32 + 33 + kCap + 3);
   return base + sizeof(float) * (mode >= 2 ? (size_t)kCH * kLDH : 0);  // 70 / 79.6 KB: two workgroups per CU; 22 KB
 }
@@ -475,4 +481,18 @@ DH3D_API int dh3d_three_interpolate_bwd_sorted(int b, int n, int c, int m, const
   a.order = reinterpret_cast<const float4 *>(order); a.B = b; a.n = n; a.m = m; a.nblk = dh3d_cdiv(n, kP);
   a.dG = grad_points;
   return launch<3>(a, s);
+}
+
+// dc [B*m, 256] += interp^T(-q x),  x = three_interpolate(c) rebuilt in the walk, q [B*n] by original point index: the
+// l2-normalisation term of NetVLAD's commuted backward (netvlad_train.hip).  dc is NOT zeroed: it holds the GEMM terms.
+DH3D_API int dh3d_interp_scatter_scaled(const float *c, const float *q, const int32_t *idx, const float *dist,
+                                        const float *order, int B, int n, int m, const unsigned char *mask, float *dc,
+                                        void *stream) {
+  DH3D_REQUIRE(c && q && idx && dist && dc && B > 0 && n > 0 && m > 0);
+  DH3D_SUPPORTED(m <= 1024);
+  InterpBnArgs a{};
+  a.G = c; a.NS = 1; a.Rc = (long long)B * m; a.SS = a.Rc * 256; a.RS = 256; a.idx = idx; a.dist = dist;
+  a.order = reinterpret_cast<const float4 *>(order); a.B = B; a.n = n; a.m = m; a.nblk = dh3d_cdiv(n, kP); a.mask = mask;
+  a.dlogit = q; a.dG = dc;
+  return launch<4>(a, (hipStream_t)stream);
 }

@@ -773,6 +773,72 @@ def interp_bn_bwd_apply(G, idx, dist, order, dlogit, w_fc, scale, shift, k2, k3,
     return dG
 
 
+# ---- NetVLAD's assignment, training mode, rows commuted through the up-sampling (csrc/netvlad_train.hip)
+def nv_commuted_fwd_stats(c, cw, idx, dist, order, mask=None, out=None):
+    """c [B*m,256], cw = c @ Wc [B*m,64] -> s [B*n,64], rinv [B*n] (by original point index) and (sum, sumsq) [64]
+    float64 of the columns of s (views of `out` if given)."""
+    B, n = idx.shape[0], idx.shape[1]
+    m = c.shape[0] // B
+    s = torch.empty((B * n, 64), dtype=torch.float32, device=c.device)
+    rinv = torch.empty((B * n,), dtype=torch.float32, device=c.device)
+    part = torch.empty((2, B, 64), dtype=torch.float64, device=c.device)
+    L.check(L.lib().dh3d_netvlad_commuted_fwd_stats(L.ptr(c), L.ptr(cw), L.ptr(idx), L.ptr(dist), L.ptr(order), B, n, m,
+                                                    L.ptr(_mask_u8(mask)), L.ptr(s), L.ptr(rinv), L.ptr(part),
+                                                    L.stream_ptr()), "netvlad_commuted_fwd_stats")
+    buf = out if out is not None else torch.empty((128,), dtype=torch.float64, device=c.device)
+    torch.sum(part, dim=1, out=buf[:128].view(2, 64))
+    return s, rinv, buf[:64], buf[64:128]
+
+
+def nv_commuted_fwd_assign(s, rinv, att, scale, shift, idx, dist, order, m, mask=None):
+    """-> p [B*n,64] = softmax(s*scale + shift), asum [B,64] = sum_n p*att, Ap [B*m,64] = interp^T(p*att*rinv)."""
+    B, n = idx.shape[0], idx.shape[1]
+    p = torch.empty_like(s)
+    asum = torch.empty((B, 64), dtype=torch.float32, device=s.device)
+    Ap = torch.empty((B * m, 64), dtype=torch.float32, device=s.device)
+    L.check(L.lib().dh3d_netvlad_commuted_fwd_assign(L.ptr(s), L.ptr(rinv), L.ptr(att), L.ptr(scale), L.ptr(shift),
+                                                     L.ptr(idx), L.ptr(dist), L.ptr(order), B, n, m, L.ptr(_mask_u8(mask)),
+                                                     L.ptr(p), L.ptr(asum), L.ptr(Ap), L.stream_ptr()),
+            "netvlad_commuted_fwd_assign")
+    return p, asum, Ap
+
+
+def nv_commuted_bwd_sums(E, p, s, att, rinv, dasum, mean, rstd, idx, dist, order, mask=None):
+    """-> dz [B*n,64], datt [B*n], t2 [B*n], S [2,64] float64 (sum dz, sum dz*shat)."""
+    B, n = idx.shape[0], idx.shape[1]
+    m = E.shape[0] // B
+    dz = torch.empty_like(s)
+    datt = torch.empty((B * n,), dtype=torch.float32, device=s.device)
+    t2 = torch.empty((B * n,), dtype=torch.float32, device=s.device)
+    part = torch.empty((2, B, 64), dtype=torch.float64, device=s.device)
+    L.check(L.lib().dh3d_netvlad_commuted_bwd_sums(L.ptr(E), L.ptr(p), L.ptr(s), L.ptr(att), L.ptr(rinv), L.ptr(dasum),
+                                                   L.ptr(mean), L.ptr(rstd), L.ptr(idx), L.ptr(dist), L.ptr(order), B, n, m,
+                                                   L.ptr(_mask_u8(mask)), L.ptr(dz), L.ptr(datt), L.ptr(t2), L.ptr(part),
+                                                   L.stream_ptr()), "netvlad_commuted_bwd_sums")
+    return dz, datt, t2, part.sum(1)
+
+
+def nv_commuted_bwd_apply(dz, s, rinv, t2, k1, k2, k3, idx, dist, order, m, mask=None):
+    """-> q [B*n], dcw [B*m,64] = interp^T(rinv * (k1*dz - k2 - k3*s))."""
+    B, n = idx.shape[0], idx.shape[1]
+    q = torch.empty((B * n,), dtype=torch.float32, device=s.device)
+    dcw = torch.empty((B * m, 64), dtype=torch.float32, device=s.device)
+    L.check(L.lib().dh3d_netvlad_commuted_bwd_apply(L.ptr(dz), L.ptr(s), L.ptr(rinv), L.ptr(t2), L.ptr(k1), L.ptr(k2),
+                                                    L.ptr(k3), L.ptr(idx), L.ptr(dist), L.ptr(order), B, n, m,
+                                                    L.ptr(_mask_u8(mask)), L.ptr(q), L.ptr(dcw), L.stream_ptr()),
+            "netvlad_commuted_bwd_apply")
+    return q, dcw
+
+
+def interp_scatter_scaled(c, q, idx, dist, order, dc, mask=None):
+    """dc [B*m,256] += interp^T(-q * interp(c)) in place."""
+    B, n = idx.shape[0], idx.shape[1]
+    m = c.shape[0] // B
+    L.check(L.lib().dh3d_interp_scatter_scaled(L.ptr(c), L.ptr(q), L.ptr(idx), L.ptr(dist), L.ptr(order), B, n, m,
+                                               L.ptr(_mask_u8(mask)), L.ptr(dc), L.stream_ptr()), "interp_scatter_scaled")
+    return dc
+
+
 def netvlad_assign_rows(s, scale, shift, att, rows_per_cloud=0):
     """a = softmax(s*scale + shift) * att; with rows_per_cloud (% 64 == 0) also (a, asum [clouds, 64]) -- the per-cloud
     column sums of a from the same pass."""

@@ -456,6 +456,65 @@ class _NetVLADAssign(torch.autograd.Function):
         return dx, datt, dWc, dgamma, dbeta, None, None, None, None, None, None
 
 
+class _NetVLADAssignCommuted(torch.autograd.Function):
+    """_NetVLADAssign on the rows three_interpolate(c) WITHOUT building them (csrc/netvlad_train.hip): c [Bt, M, 256]
+    sampled rows, att [Bt*N]; idx / dist [Bt,N,3] three_nn of the fine points, order = spatial_sort records of the fine
+    clouds -> (V [Bt, 64, 256], asum [Bt, 64]).  GEMMs on the Bt*M sampled rows, 64-wide walks over the fine points."""
+
+    @staticmethod
+    def forward(ctx, c, att, Wc, gamma, beta, run_mean, run_var, eps, momentum, sync, mask, idx, dist, order):
+        Bt, M, Dm = c.shape
+        N = idx.shape[1]
+        c2 = c.reshape(Bt * M, Dm).contiguous()
+        Wd = Wc.detach().contiguous()
+        cw = pm.gemm_nn(c2, Wd)                                            # [Bt*M, 64]
+        g, be = gamma.detach().contiguous(), beta.detach().contiguous()
+        packed = torch.empty((2 * 64 + 1,), dtype=torch.float64, device=c.device)
+        s, rinv, s1, s2 = pm.nv_commuted_fwd_stats(c2, cw, idx, dist, order, mask, out=packed)
+        cnt = _count(Bt * N, mask, N, c.device)
+        if sync and D.collectives_active():
+            packed[128:] = cnt
+            D.all_reduce_sum_(packed)
+            cnt = packed[128:]
+        st = _BNState()
+        # cluster_bn is the one un-fused batch norm upstream (core/backbones.py:218-223): biased moving variance
+        st.stats = pm.bn_finalize(s1, s2, cnt, g, be, eps, momentum, run_mean, run_var, unbiased=False)
+        st.cnt = cnt
+        att = att.contiguous()
+        p, asum, Ap = pm.nv_commuted_fwd_assign(s, rinv, att, st.stats[2], st.stats[3], idx, dist, order, M, mask)
+        V = pm.gemm_tn_batched(Ap.reshape(Bt, M, 64), c2.reshape(Bt, M, Dm))   # [Bt, 64, 256]
+        ctx.save_for_backward(c2, s, rinv, p, att, Wd, g, Ap)
+        ctx.cfg = (Bt, M, bool(sync), mask, st, idx, dist, order)
+        return V, asum
+
+    @staticmethod
+    def backward(ctx, dV, dasum):
+        c2, s, rinv, p, att, Wd, g, Ap = ctx.saved_tensors
+        Bt, M, sync, mask, st, idx, dist, order = ctx.cfg
+        Dm = c2.shape[1]
+        dV = dV.contiguous()
+        E = pm.gemm_nn_batched(c2.reshape(Bt, M, Dm), pm.transpose_last2(dV)).reshape(Bt * M, 64)
+        dz, datt, t2, S = pm.nv_commuted_bwd_sums(E, p, s, att, rinv, dasum.contiguous(), st.stats[0], st.stats[1],
+                                                  idx, dist, order, mask)
+        dgamma, dbeta, k = _backward_coeffs(S, st, g, sync)
+        q, dcw = pm.nv_commuted_bwd_apply(dz, s, rinv, t2, st.stats[2], k[0], k[1], idx, dist, order, M, mask)
+        dWc = pm.gemm_tn(c2, dcw)
+        dc = pm.gemm_nn_batched(Ap.reshape(Bt, M, 64), dV).reshape(Bt * M, Dm)
+        pm.gemm_nn(dcw, pm.transpose_last2(Wd), out=dc, accumulate=True)
+        pm.interp_scatter_scaled(c2, q, idx, dist, order, dc, mask)
+        return dc.reshape(Bt, M, Dm), datt, dWc, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+
+
+def netvlad_assign_commuted(c, att, Wc, bnmod, idx, dist, order, sync=False, mask=None):
+    return _NetVLADAssignCommuted.apply(c, att, Wc, bnmod.gamma, bnmod.beta, bnmod.moving_mean, bnmod.moving_variance,
+                                        bnmod.eps, 0.999, sync, mask, idx.contiguous(), dist.contiguous(),
+                                        order.contiguous())
+
+
+def netvlad_commute_supported(c, Wc):
+    return c.shape[2] == 256 and Wc.shape[1] == 64 and c.shape[1] <= 1024
+
+
 class _ContextGate(torch.autograd.Function):
     """v * sigmoid(g) (core/backbones.py:271-277): one launch per direction."""
 

@@ -244,7 +244,8 @@ def global_head_autograd(model, points, localdesc, lv, bn_training=True, sync_bn
     return v * torch.sigmoid(gates)
 
 
-def global_head_hip(model, points, localdesc, lv, sync_bn=False, mask=None, commute_attention=True):
+def global_head_hip(model, points, localdesc, lv, sync_bn=False, mask=None, commute_attention=True,
+                    commute_netvlad=True):
     """compute_global (core/model.py:112-133) in training mode with every row-level operator -- flex_conv, the three
     training-mode BatchNorms on rows, three_interpolate, the attention MLP, NetVLAD's assignment / aggregation -- as a
     hand-written HIP kernel in BOTH directions (dh3d_amd.train_ops, csrc/train.hip / gemm.hip / flex_bwd.hip); what is
@@ -290,11 +291,15 @@ def global_head_hip(model, points, localdesc, lv, sync_bn=False, mask=None, comm
     w = pm.idw_weights(lv["nn3_dist"])                                              # backbones.py:92-95 (no gradient: geometry)
     fcw = att_mod.detec_conv_fc
     sorted_walks = commute_attention and T.attention_commute_supported(att_mod.detec_conv0, M) and Dg == 256
+    commuted_vlad = (sorted_walks and commute_netvlad and T.netvlad_commute_supported(new_feat, nv.cluster_weights)
+                     and nv.add_batch_norm)
+    forglobal = None
     if sorted_walks:
         # the fine clouds' Morton records: from the geometry level if it has them (compute_level stores them for
         # N >= 4096); three_interpolate's backward and the attention head walk the points in that order
         order = lv["_ordered"][0] if "_ordered" in lv else pm.spatial_sort(points)[0]
-        forglobal = T.three_interpolate_sorted(new_feat, lv["nn3_idx"], w, order)   # [Bt,N,256]
+        if not commuted_vlad:
+            forglobal = T.three_interpolate_sorted(new_feat, lv["nn3_idx"], w, order)   # [Bt,N,256]
     else:
         forglobal = ops.three_interpolate(new_feat, lv["nn3_idx"], w.contiguous())
     if sorted_walks:
@@ -304,14 +309,26 @@ def global_head_hip(model, points, localdesc, lv, sync_bn=False, mask=None, comm
                                         lv["nn3_dist"], order, sync_bn, mask)
     else:
         att = T.attention_head(forglobal.reshape(Bt * N, Dg), att_mod.detec_conv0, fcw.W, fcw.b, sync_bn, mask, N)
+    if commuted_vlad:
+        # NetVLAD's assignment commuted through the up-sampling as well: the [Bt,N,256] rows are never built in the
+        # training step (csrc/netvlad_train.hip)
+        return _netvlad_tail_hip(T, nv, None, att, sync_bn, mask,
+                                 commuted=(new_feat, lv["nn3_idx"], lv["nn3_dist"], order))
     return _netvlad_tail_hip(T, nv, forglobal, att, sync_bn, mask)
 
 
-def _netvlad_tail_hip(T, nv, forglobal, att, sync_bn, mask):
-    """NetVLAD + context gating of the training step on HIP nodes (core/backbones.py:202-279): forglobal [Bt,N,D] rows,
-    att [Bt*N] -> [Bt, 256]."""
-    Bt, Dg = forglobal.shape[0], forglobal.shape[2]
-    V, asum = T.netvlad_assign(forglobal, att, nv.cluster_weights, nv.cluster_bn, sync_bn, mask)   # [Bt,C,D], [Bt,C]
+def _netvlad_tail_hip(T, nv, forglobal, att, sync_bn, mask, commuted=None):
+    """NetVLAD + context gating of the training step on HIP nodes (core/backbones.py:202-279): forglobal [Bt,N,D] rows
+    (or commuted = (sampled rows [Bt,M,D], three_nn idx, dist, Morton records of the fine clouds)), att [Bt*N] ->
+    [Bt, 256]."""
+    if commuted is not None:
+        coarse, idx3, dist3, order = commuted
+        Bt, Dg = coarse.shape[0], coarse.shape[2]
+        V, asum = T.netvlad_assign_commuted(coarse, att, nv.cluster_weights, nv.cluster_bn, idx3, dist3, order, sync_bn,
+                                            mask)
+    else:
+        Bt, Dg = forglobal.shape[0], forglobal.shape[2]
+        V, asum = T.netvlad_assign(forglobal, att, nv.cluster_weights, nv.cluster_bn, sync_bn, mask)   # [Bt,C,D], [Bt,C]
     if T.vlad_normalize_supported(V):
         vlad = T.vlad_normalize(V, asum, nv.cluster_weights2)                       # [Bt, D*C]  (backbones.py:241-262)
     else:

@@ -498,6 +498,37 @@ int dh3d_interp_bn_bwd_apply(const float *G, int Hd, int row_major, const int32_
  * summation order. */
 int dh3d_three_interpolate_bwd_sorted(int b, int n, int c, int m, const float *grad_out, const int32_t *idx,
                                       const float *weight, const float *order, float *grad_points, void *stream);
+/* NetVLAD's assignment (core/backbones.py:202-256) in the training step with its rows commuted through
+ * three_interpolate (core/backbones.py:89-100), csrc/netvlad_train.hip: c [B*m,256] are the sampled rows, cw = c Wc and
+ * E = c dV^T GEMMs on them; s / p / dz [B*n,64], rinv / att / datt / t2 / q [B*n] live on the fine points (by original
+ * point index); idx / dist = dh3d_three_nn of the fine points [B,n,3], order = dh3d_spatial_sort records of the fine
+ * clouds [B,n,4] (NULL: index order), mask [B] bytes (NULL: every cloud).  m <= 1024.
+ *   fwd_stats : s = rinv * interp(cw), rinv = rsqrt(max(|interp(c)|^2, 1e-12)), part [2][B][64] f64 = per-cloud column
+ *               sums / sums of squares of s (zeroed by the call)
+ *   fwd_assign: p = softmax(s*scale + shift), asum [B,64] = sum_n p*att, Ap [B*m,64] = interp^T(p*att*rinv) (zeroed by
+ *               the call; V[b] = Ap[b]^T c[b])
+ *   bwd_sums  : da = rinv*interp(E) + dasum; datt = sum_k da p (0 for masked clouds); dz = softmax backward of da*att;
+ *               t2 = sum_k p att interp(E); part [2][B][64] = per-cloud sums of dz and dz*(s - mean)*rstd
+ *   bwd_apply : ds = k1*dz - k2 - k3*s (dh3d_bn_bwd_finalize); q = rinv^2 sum_k ds s + rinv^3 t2; dcw [B*m,64] =
+ *               interp^T(rinv*ds) (zeroed by the call)
+ * dh3d_interp_scatter_scaled: dc [B*m,256] += interp^T(-q * interp(c)) (dc NOT zeroed: it holds Ap dV + dcw Wc^T). */
+int dh3d_netvlad_commuted_fwd_stats(const float *c, const float *cw, const int32_t *idx, const float *dist,
+                                    const float *order, int B, int n, int m, const unsigned char *mask, float *s,
+                                    float *rinv, double *part, void *stream);
+int dh3d_netvlad_commuted_fwd_assign(const float *s, const float *rinv, const float *att, const float *scale,
+                                     const float *shift, const int32_t *idx, const float *dist, const float *order, int B,
+                                     int n, int m, const unsigned char *mask, float *p, float *asum, float *Ap,
+                                     void *stream);
+int dh3d_netvlad_commuted_bwd_sums(const float *E, const float *p, const float *s, const float *att, const float *rinv,
+                                   const float *dasum, const float *mean, const float *rstd, const int32_t *idx,
+                                   const float *dist, const float *order, int B, int n, int m, const unsigned char *mask,
+                                   float *dz, float *datt, float *t2, double *part, void *stream);
+int dh3d_netvlad_commuted_bwd_apply(const float *dz, const float *s, const float *rinv, const float *t2, const float *k1,
+                                    const float *k2, const float *k3, const int32_t *idx, const float *dist,
+                                    const float *order, int B, int n, int m, const unsigned char *mask, float *q,
+                                    float *dcw, void *stream);
+int dh3d_interp_scatter_scaled(const float *c, const float *q, const int32_t *idx, const float *dist, const float *order,
+                               int B, int n, int m, const unsigned char *mask, float *dc, void *stream);
 /* NetVLAD between the VLAD contraction and the hidden projection (core/backbones.py:241-262) for the training step:
  * out[b, d*64 + c] = l2norm_all( intra_norm_d( V[b,c,d] - asum[b,c] * W2[d,c] ) ), one workgroup per cloud, and its
  * gradients (dW2 zeroed by the call, f32 atomics over the clouds).  D == 256, Cl == 64. */

@@ -456,6 +456,65 @@ def test_commuted_attention_head_matches_the_materialised_one(dev, N, use_mask):
     assert torch.allclose(b0[0], b1[0], rtol=1e-5, atol=1e-6) and torch.allclose(b0[1], b1[1], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("N,use_mask,scrambled", [(4096, False, False), (4096, True, False), (5000, False, False),
+                                                  (4096, False, True)])
+def test_commuted_netvlad_assignment_matches_the_materialised_one(dev, N, use_mask, scrambled):
+    """train_ops.netvlad_assign_commuted (NetVLAD's rows commuted through three_interpolate, nothing 256 wide written
+    for the fine points, csrc/netvlad_train.hip + interp_train.hip MODE 4) == train_ops.netvlad_assign on the
+    materialised up-sampled rows (core/backbones.py:202-256): V, asum, the gradients of the sampled rows, the
+    attention, the cluster weights and the cluster BatchNorm, its running buffers.  Same math reassociated;
+    statistics and scatters use f64 / f32 atomics.  `scrambled`: neighbours without spatial coherence -- every block
+    exceeds the slot table and takes the overflow paths."""
+    from dh3d_amd import ops, pm, train_ops as T
+    g = torch.Generator().manual_seed(N + use_mask + 2 * scrambled)
+    Bt, M, Dm = 3, N // 8, 256
+    pts = torch.rand(Bt, N, 3, generator=g).to(dev)
+    samp = ops.farthest_point_sample(M, pts)
+    cxyz = torch.gather(pts, 1, samp.long()[:, :, None].expand(-1, -1, 3)).contiguous()
+    d3, i3 = ops.three_nn(pts, cxyz)
+    if scrambled:
+        i3 = torch.randint(0, M, (Bt, N, 3), generator=g, dtype=torch.int32).to(dev)
+    order = pm.spatial_sort(pts)[0]
+    mask = torch.tensor([True, False, True], device=dev) if use_mask else None
+    dV = torch.randn(Bt, 64, Dm, generator=torch.Generator().manual_seed(11)).to(dev)
+    dA = torch.randn(Bt, 64, generator=torch.Generator().manual_seed(12)).to(dev)
+    if mask is not None:   # the loss never sees a padding cloud's descriptor
+        dV, dA = dV * mask[:, None, None].float(), dA * mask[:, None].float()
+    res = []
+    for commuted in (True, False):
+        m = _build(dev, seed=3)
+        nv = m._netvlad
+        with torch.no_grad():
+            nv.cluster_bn.gamma.copy_(0.5 + torch.rand(64, generator=torch.Generator().manual_seed(1)).to(dev))
+            nv.cluster_bn.beta.copy_(0.3 * torch.randn(64, generator=torch.Generator().manual_seed(2)).to(dev))
+        coarse = torch.randn(Bt, M, Dm, generator=torch.Generator().manual_seed(7)).to(dev).requires_grad_(True)
+        att = torch.rand(Bt * N, generator=torch.Generator().manual_seed(8)).to(dev).requires_grad_(True)
+        if commuted:
+            V, asum = T.netvlad_assign_commuted(coarse, att, nv.cluster_weights, nv.cluster_bn, i3, d3, order, False, mask)
+        else:
+            dd = torch.clamp(d3, min=1e-10)
+            w = (1.0 / dd) / (1.0 / dd).sum(2, keepdim=True)
+            up = ops.three_interpolate(coarse, i3, w.contiguous())
+            V, asum = T.netvlad_assign(up, att, nv.cluster_weights, nv.cluster_bn, False, mask)
+        ((V * dV).sum() + (asum * dA).sum()).backward()
+        ps = [nv.cluster_weights, nv.cluster_bn.gamma, nv.cluster_bn.beta]
+        res.append((V.detach(), asum.detach(), coarse.grad.clone(), att.grad.clone(), [p.grad.clone() for p in ps],
+                    (nv.cluster_bn.moving_mean.clone(), nv.cluster_bn.moving_variance.clone())))
+    (V0, A0, c0, t0, g0, b0), (V1, A1, c1, t1, g1, b1) = res
+    live = slice(None) if mask is None else mask
+    def agree(x, y, name, tol=2e-4):
+        rel = float((x - y).norm() / (y.norm() + 1e-30))
+        assert rel <= tol, (name, rel)
+        assert float((x - y).abs().max()) <= 10 * tol * float(y.abs().max()) + 1e-7, (name, float((x - y).abs().max()))
+    agree(V0[live], V1[live], "V", 2e-5)
+    agree(A0[live], A1[live], "asum", 2e-5)
+    agree(c0, c1, "dcoarse")
+    agree(t0, t1, "datt")
+    for name, x, y in zip(("Wc", "gamma", "beta"), g0, g1):
+        agree(x, y, name)
+    assert torch.allclose(b0[0], b1[0], rtol=1e-5, atol=1e-6) and torch.allclose(b0[1], b1[1], rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("B,N,scrambled", [(3, 4096, False), (2, 5000, False), (2, 4096, True)])
 def test_three_interpolate_sorted_backward_matches_the_drop_in_op(dev, B, N, scrambled):
     """train_ops.three_interpolate_sorted: same forward kernel, backward on the Morton order (MFMA scatter in LDS, one
