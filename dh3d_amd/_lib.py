@@ -131,6 +131,8 @@ _SIGNATURES = {
     "dh3d_netvlad_commuted_bwd_apply": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp,
                                         c_fp, c_fp, c_fp],
     "dh3d_interp_scatter_scaled": [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp],
+    "dh3d_bn_bwd_finalize_parts": [c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp],
+    "dh3d_sigmoid_bwd": [c_fp, c_fp, c_fp, c_int, c_ll, c_fp, c_fp, c_fp],
     "dh3d_interp_bn_colstats": [c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp],
     "dh3d_interp_bn_bwd_sums": [c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp,
                                 c_fp, c_fp, c_fp, c_fp],

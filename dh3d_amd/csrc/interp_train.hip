@@ -410,7 +410,7 @@ bool shape_ok(int Hd, int m) { return Hd % 256 == 0 && Hd >= 256 && Hd <= 1024 &
 
 // G: the 256-column slices [Hd/256][B*m][256] of coarse @ W + b; idx / dist: three_nn of the fine points [B,n,3];
 // order: dh3d_spatial_sort records of the fine cloud [B,n,4] (may be NULL: points in index order, correct but slower);
-// mask [B] bytes (may be NULL).  part [2][B][Hd] f64 (zeroed here): per-CLOUD partial sums / sums of squares -- their
+// mask [B] bytes (may be NULL).  part [2][B][Hd] f64 (zeroed by the CALLER): per-CLOUD partial sums / sums of squares -- their
 // sums over B are the column statistics (704 workgroups adding into one row of 1024 doubles cost 27 of 97 us in L2
 // atomics on the same addresses; per cloud it is 32 workgroups per address).
 DH3D_API int dh3d_interp_bn_colstats(const float *G, int Hd, int row_major, const int32_t *idx, const float *dist,
@@ -419,7 +419,6 @@ DH3D_API int dh3d_interp_bn_colstats(const float *G, int Hd, int row_major, cons
   DH3D_REQUIRE(G && idx && dist && part && B > 0 && n > 0 && m > 0);
   DH3D_SUPPORTED(shape_ok(Hd, m));
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(part, 0, sizeof(double) * 2 * (size_t)B * Hd, s) != hipSuccess) return DH3D_ERR_LAUNCH;
   InterpBnArgs a{};
   a.G = G; a.NS = Hd / 256; a.Rc = (long long)B * m; a.idx = idx; a.dist = dist;
   a.SS = row_major ? 256 : a.Rc * 256; a.RS = row_major ? Hd : 256;
@@ -428,7 +427,7 @@ DH3D_API int dh3d_interp_bn_colstats(const float *G, int Hd, int row_major, cons
   return launch<0>(a, s);
 }
 
-// part [3][B][Hd] f64 (zeroed here): per-cloud partials of S1, S2, S3 -- the sums of dh3d_bn_bwd_sums for the rank-one
+// part [3][B][Hd] f64 (zeroed by the CALLER): per-cloud partials of S1, S2, S3 -- the sums of dh3d_bn_bwd_sums for the rank-one
 // gradient dy = dlogit x w_fc on the virtual rows h = interp(G);  dlogit [B*n] by original point index.
 DH3D_API int dh3d_interp_bn_bwd_sums(const float *G, int Hd, int row_major, const int32_t *idx, const float *dist,
                                      const float *order, int B, int n, int m, const unsigned char *mask, const float *dlogit,
@@ -438,7 +437,6 @@ DH3D_API int dh3d_interp_bn_bwd_sums(const float *G, int Hd, int row_major, cons
   DH3D_REQUIRE(B > 0 && n > 0 && m > 0);
   DH3D_SUPPORTED(shape_ok(Hd, m));
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(part, 0, sizeof(double) * 3 * (size_t)B * Hd, s) != hipSuccess) return DH3D_ERR_LAUNCH;
   InterpBnArgs a{};
   a.G = G; a.NS = Hd / 256; a.Rc = (long long)B * m; a.idx = idx; a.dist = dist;
   a.SS = row_major ? 256 : a.Rc * 256; a.RS = row_major ? Hd : 256;
@@ -448,7 +446,7 @@ DH3D_API int dh3d_interp_bn_bwd_sums(const float *G, int Hd, int row_major, cons
   return launch<1>(a, s);
 }
 
-// dG [Hd/256][B*m][256] (zeroed here) = interp^T(dh),  dh = scale dz - k2 - k3 h  (the coefficients of
+// dG [Hd/256][B*m][256] (zeroed by the CALLER) = interp^T(dh),  dh = scale dz - k2 - k3 h  (the coefficients of
 // dh3d_bn_bwd_finalize; dz = dlogit w_fc [h scale + shift > 0]); f32 atomics.
 DH3D_API int dh3d_interp_bn_bwd_apply(const float *G, int Hd, int row_major, const int32_t *idx, const float *dist,
                                       const float *order, int B, int n, int m, const unsigned char *mask, const float *dlogit,
@@ -457,7 +455,6 @@ DH3D_API int dh3d_interp_bn_bwd_apply(const float *G, int Hd, int row_major, con
   DH3D_REQUIRE(G && idx && dist && dlogit && w_fc && scale && shift && k2 && k3 && dG && B > 0 && n > 0 && m > 0);
   DH3D_SUPPORTED(shape_ok(Hd, m));
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(dG, 0, sizeof(float) * (size_t)B * m * Hd, s) != hipSuccess) return DH3D_ERR_LAUNCH;
   InterpBnArgs a{};
   a.G = G; a.NS = Hd / 256; a.Rc = (long long)B * m; a.idx = idx; a.dist = dist;
   a.SS = row_major ? 256 : a.Rc * 256; a.RS = row_major ? Hd : 256;

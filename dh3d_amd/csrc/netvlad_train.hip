@@ -454,20 +454,19 @@ NvArgs base_args(const int32_t *idx, const float *dist, const float *order, int 
 
 // c [B*m, 256] sampled rows, cw [B*m, 64] = c Wc; idx / dist: three_nn of the fine points [B,n,3]; order: spatial_sort
 // records of the fine clouds [B,n,4] (may be NULL); mask [B] bytes (may be NULL).  Writes s [B*n, 64] and rinv [B*n] by
-// original point index and the per-cloud partial column sums / sums of squares of s: part [2][B][64] f64 (zeroed here).
+// original point index and the per-cloud partial column sums / sums of squares of s: part [2][B][64] f64 (zeroed by the CALLER).
 DH3D_API int dh3d_netvlad_commuted_fwd_stats(const float *c, const float *cw, const int32_t *idx, const float *dist,
                                              const float *order, int B, int n, int m, const unsigned char *mask, float *s,
                                              float *rinv, double *part, void *stream) {
   DH3D_REQUIRE(c && cw && idx && dist && s && rinv && part && B > 0 && n > 0 && m > 0);
   DH3D_SUPPORTED(m <= 1024);
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(part, 0, sizeof(double) * 2 * (size_t)B * 64, st) != hipSuccess) return DH3D_ERR_LAUNCH;
   NvArgs a = base_args(idx, dist, order, B, n, m, mask);
   a.c = c; a.rows64 = cw; a.s = s; a.rinv = rinv; a.s0 = part; a.s1 = part + (size_t)B * 64;
   return launch<0>(a, st);
 }
 
-// p [B*n, 64] = softmax(s scale + shift);  asum [B, 64] = sum_n p att;  Ap [B*m, 64] = A' (both zeroed here, f32 atomics).
+// p [B*n, 64] = softmax(s scale + shift);  asum [B, 64] = sum_n p att;  Ap [B*m, 64] = A' (both zeroed by the CALLER, f32 atomics).
 DH3D_API int dh3d_netvlad_commuted_fwd_assign(const float *s, const float *rinv, const float *att, const float *scale,
                                               const float *shift, const int32_t *idx, const float *dist, const float *order,
                                               int B, int n, int m, const unsigned char *mask, float *p, float *asum,
@@ -475,8 +474,6 @@ DH3D_API int dh3d_netvlad_commuted_fwd_assign(const float *s, const float *rinv,
   DH3D_REQUIRE(s && rinv && att && scale && shift && idx && dist && p && asum && Ap && B > 0 && n > 0 && m > 0);
   DH3D_SUPPORTED(m <= 1024);
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(asum, 0, sizeof(float) * (size_t)B * 64, st) != hipSuccess) return DH3D_ERR_LAUNCH;
-  if (hipMemsetAsync(Ap, 0, sizeof(float) * (size_t)B * m * 64, st) != hipSuccess) return DH3D_ERR_LAUNCH;
   NvArgs a = base_args(idx, dist, order, B, n, m, mask);
   a.s = const_cast<float *>(s); a.rinv = const_cast<float *>(rinv); a.att = att; a.v0 = scale; a.v1 = shift;
   a.p = p; a.asum = asum; a.scat = Ap;
@@ -485,7 +482,7 @@ DH3D_API int dh3d_netvlad_commuted_fwd_assign(const float *s, const float *rinv,
 
 // E [B*m, 64] = c dV^T;  dasum [B, 64];  mean / rstd [64] of the forward BatchNorm.  Writes dz [B*n, 64], datt [B*n]
 // (0 for padding clouds), t2 [B*n] and the per-cloud partials of S1 = sum dz, S2 = sum dz shat: part [2][B][64] f64
-// (zeroed here).
+// (zeroed by the CALLER).
 DH3D_API int dh3d_netvlad_commuted_bwd_sums(const float *E, const float *p, const float *s, const float *att,
                                             const float *rinv, const float *dasum, const float *mean, const float *rstd,
                                             const int32_t *idx, const float *dist, const float *order, int B, int n, int m,
@@ -495,7 +492,6 @@ DH3D_API int dh3d_netvlad_commuted_bwd_sums(const float *E, const float *p, cons
   DH3D_REQUIRE(B > 0 && n > 0 && m > 0);
   DH3D_SUPPORTED(m <= 1024);
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(part, 0, sizeof(double) * 2 * (size_t)B * 64, st) != hipSuccess) return DH3D_ERR_LAUNCH;
   NvArgs a = base_args(idx, dist, order, B, n, m, mask);
   a.rows64 = E; a.p = const_cast<float *>(p); a.s = const_cast<float *>(s); a.att = att; a.rinv = const_cast<float *>(rinv);
   a.dasum = dasum; a.v0 = mean; a.v1 = rstd; a.dz = dz; a.datt = datt; a.t2 = t2;
@@ -504,7 +500,7 @@ DH3D_API int dh3d_netvlad_commuted_bwd_sums(const float *E, const float *p, cons
 }
 
 // ds = k1 dz - k2 - k3 s (the coefficients of dh3d_bn_bwd_finalize, k1 = scale);  q [B*n] = r^2 sum_k ds s + r^3 t2;
-// dcw [B*m, 64] = interp^T(r ds) (zeroed here, f32 atomics).
+// dcw [B*m, 64] = interp^T(r ds) (zeroed by the CALLER, f32 atomics).
 DH3D_API int dh3d_netvlad_commuted_bwd_apply(const float *dz, const float *s, const float *rinv, const float *t2,
                                              const float *k1, const float *k2, const float *k3, const int32_t *idx,
                                              const float *dist, const float *order, int B, int n, int m,
@@ -512,7 +508,6 @@ DH3D_API int dh3d_netvlad_commuted_bwd_apply(const float *dz, const float *s, co
   DH3D_REQUIRE(dz && s && rinv && t2 && k1 && k2 && k3 && idx && dist && q && dcw && B > 0 && n > 0 && m > 0);
   DH3D_SUPPORTED(m <= 1024);
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(dcw, 0, sizeof(float) * (size_t)B * m * 64, st) != hipSuccess) return DH3D_ERR_LAUNCH;
   NvArgs a = base_args(idx, dist, order, B, n, m, mask);
   a.dz = const_cast<float *>(dz); a.s = const_cast<float *>(s); a.rinv = const_cast<float *>(rinv); a.t2 = const_cast<float *>(t2);
   a.v0 = k1; a.v1 = k2; a.v2 = k3; a.q = q; a.scat = dcw;

@@ -282,6 +282,53 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double *__re
   k2[c] = gamma[c] * rstd[c] * m1 - q3 * mean[c];
 }
 
+// The same from per-cloud PARTIAL sums part [nk][P][C] (nk = 2: S1, S2; 3: + S3 -- what the walks of interp_train.hip /
+// netvlad_train.hip leave): their sums over P, k2 / k3, and the sums themselves as float32 rows grads [nk][C] (dbeta,
+// dgamma, d w_fc) -- one launch instead of a reduction, a conversion and the finalize.
+__global__ __launch_bounds__(256) void bn_bwd_finalize_parts_kernel(const double *__restrict__ part, int nk, int P,
+                                                                   const double *__restrict__ cnt,
+                                                                   const float *__restrict__ mean,
+                                                                   const float *__restrict__ rstd,
+                                                                   const float *__restrict__ gamma, int C,
+                                                                   float *__restrict__ k2, float *__restrict__ k3,
+                                                                   float *__restrict__ grads) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double S[3] = {0.0, 0.0, 0.0};
+  for (int k = 0; k < nk; ++k) {
+    double a = 0.0;
+    for (int p = 0; p < P; ++p) a += part[((size_t)k * P + p) * C + c];
+    S[k] = a;
+    grads[(size_t)k * C + c] = (float)a;
+  }
+  const double n = cnt[0] > 1.0 ? cnt[0] : 1.0;
+  const float m1 = (float)(S[0] / n), m2 = (float)(S[1] / n);
+  const float q3 = gamma[c] * rstd[c] * rstd[c] * m2;
+  k3[c] = q3;
+  k2[c] = gamma[c] * rstd[c] * m1 - q3 * mean[c];
+}
+
+// dlogit = datt * att * (1 - att) (sigmoid backward of the attention head; 0 on rows of padding clouds) and its sum
+// (the gradient of the fc bias; `sum` zeroed by the caller): one launch instead of three element-wise passes and a
+// reduction.
+__global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float *__restrict__ datt, const float *__restrict__ att,
+                                                         const unsigned char *__restrict__ mask, int rows_per_cloud,
+                                                         long long n, float *__restrict__ dlogit, float *__restrict__ sum) {
+  __shared__ float s_p[4];
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float a = att[i];
+    const float d = row_live(mask, i, rows_per_cloud) ? datt[i] * a * (1.0f - a) : 0.f;
+    dlogit[i] = d;
+    acc += d;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) s_p[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(sum, (s_p[0] + s_p[1]) + (s_p[2] + s_p[3]));
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // NetVLAD soft assignment (core/backbones.py:214-238), one wave per row of s = xn @ Wc (64 clusters = 64 lanes):
 //   z = s*scale + shift (training: folded batch statistics);  p = softmax(z);  a = p * att[n]
@@ -560,12 +607,6 @@ DH3D_API int dh3d_bn_colstats(const float *x, long long R, int C, const unsigned
                               double *sum, double *sumsq, void *stream) {
   DH3D_REQUIRE(x && sum && sumsq && R > 0 && C > 0 && (!mask || rows_per_cloud > 0));
   hipStream_t s = (hipStream_t)stream;
-  if (sumsq == sum + C) {  // one fill when the caller packs them (a fill is a 4 us launch of its own)
-    if (hipMemsetAsync(sum, 0, sizeof(double) * 2 * C, s) != hipSuccess) return DH3D_ERR_LAUNCH;
-  } else {
-    if (hipMemsetAsync(sum, 0, sizeof(double) * C, s) != hipSuccess) return DH3D_ERR_LAUNCH;
-    if (hipMemsetAsync(sumsq, 0, sizeof(double) * C, s) != hipSuccess) return DH3D_ERR_LAUNCH;
-  }
   int rows_per;
   const int chunks = row_chunks(R, &rows_per);
   hipLaunchKernelGGL(colstats_kernel, dim3(dh3d_cdiv(C, 64), chunks), dim3(256), 0, s, x, R, C, rows_per, mask,
@@ -599,13 +640,6 @@ DH3D_API int dh3d_bn_bwd_sums(const float *x, const float *dy, const float *rows
   DH3D_REQUIRE(dy || (rowscale && colvec && S3));
   DH3D_REQUIRE(!mask || rows_per_cloud > 0);
   hipStream_t s = (hipStream_t)stream;
-  if (S2 == S1 + C && (dy || S3 == S2 + C)) {  // packed by the caller: one fill
-    if (hipMemsetAsync(S1, 0, sizeof(double) * (dy ? 2 : 3) * C, s) != hipSuccess) return DH3D_ERR_LAUNCH;
-  } else {
-    if (hipMemsetAsync(S1, 0, sizeof(double) * C, s) != hipSuccess) return DH3D_ERR_LAUNCH;
-    if (hipMemsetAsync(S2, 0, sizeof(double) * C, s) != hipSuccess) return DH3D_ERR_LAUNCH;
-    if (!dy && hipMemsetAsync(S3, 0, sizeof(double) * C, s) != hipSuccess) return DH3D_ERR_LAUNCH;
-  }
   int rows_per;
   const int chunks = row_chunks(R, &rows_per);
   hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(dh3d_cdiv(C, 64), chunks), dim3(256), 0, s, x, dy, rowscale, colvec, R, C,
@@ -645,6 +679,24 @@ DH3D_API int dh3d_bn_bwd_finalize(const double *S1, const double *S2, const doub
   DH3D_REQUIRE(S1 && S2 && count && mean && rstd && gamma && k2 && k3 && C > 0);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dh3d_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, S1, S2, count,
                      mean, rstd, gamma, C, k2, k3);
+  return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_bn_bwd_finalize_parts(const double *part, int nk, int P, const double *count, const float *mean,
+                                        const float *rstd, const float *gamma, int C, float *k2, float *k3, float *grads,
+                                        void *stream) {
+  DH3D_REQUIRE(part && count && mean && rstd && gamma && k2 && k3 && grads && C > 0 && P > 0 && (nk == 2 || nk == 3));
+  hipLaunchKernelGGL(bn_bwd_finalize_parts_kernel, dim3(dh3d_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, part, nk, P,
+                     count, mean, rstd, gamma, C, k2, k3, grads);
+  return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_sigmoid_bwd(const float *datt, const float *att, const unsigned char *mask, int rows_per_cloud,
+                              long long n, float *dlogit, float *sum, void *stream) {
+  DH3D_REQUIRE(datt && att && dlogit && sum && n > 0 && (!mask || rows_per_cloud > 0));
+  const int g = (int)(n / 1024 > 1024 ? 1024 : (n + 1023) / 1024);
+  hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, datt, att, mask,
+                     rows_per_cloud > 0 ? rows_per_cloud : 1, n, dlogit, sum);
   return dh3d_launch_status();
 }
 

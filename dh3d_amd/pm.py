@@ -640,12 +640,73 @@ def _mask_u8(mask):
     return None if mask is None else mask.to(torch.uint8).contiguous()
 
 
+class ZeroArena(object):
+    """One zeroed device buffer per training step for the accumulators its kernels add into (statistics partials, scatter
+    targets: include/dh3d_hip.h "zeroed by the CALLER").  `begin()` clears it with ONE fill and rewinds; `zeros()` below
+    hands out views while the arena is active (`with pm.zero_arena(a): ...`) and falls back to torch.zeros otherwise or
+    when the arena is too small -- the demand of a step is recorded, the next `begin()` outside a graph capture grows
+    the buffer to it.  Views are only valid until the next `begin()`: nothing that outlives a step (the loss, the
+    parameter gradients) is taken from here."""
+
+    def __init__(self):
+        self.buf, self.off, self.demand, self.peak = None, 0, 0, 0
+
+    def begin(self, device):
+        self.peak = max(self.peak, self.demand)
+        capturing = torch.cuda.is_current_stream_capturing() if torch.cuda.is_available() else False
+        if self.peak and not capturing and (self.buf is None or self.buf.numel() < self.peak or self.buf.device != device):
+            self.buf = torch.empty((self.peak,), dtype=torch.uint8, device=device)
+        if self.buf is not None:
+            self.buf.zero_()
+        self.off, self.demand = 0, 0
+
+    def take(self, shape, dtype, device):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        span = (nbytes + 255) // 256 * 256
+        self.demand += span
+        if self.buf is None or self.buf.device != device or self.off + span > self.buf.numel():
+            return torch.zeros(shape, dtype=dtype, device=device)
+        # a tensor of its own on the arena's storage (NOT a view of `buf`: autograd would tie every accumulator that
+        # leaves a custom Function to the arena's version counter, which the next begin() bumps)
+        esz = nbytes // max(n, 1) if n else 1
+        v = torch.empty((0,), dtype=dtype, device=device).set_(self.buf.untyped_storage(), self.off // esz, tuple(shape))
+        self.off += span
+        return v
+
+
+_ZERO_ARENA = [None]
+
+
+class zero_arena(object):
+    """Context: accumulators come out of `arena` (a ZeroArena, already begun) instead of one torch.zeros each."""
+
+    def __init__(self, arena):
+        self.arena, self.prev = arena, None
+
+    def __enter__(self):
+        self.prev, _ZERO_ARENA[0] = _ZERO_ARENA[0], self.arena
+        return self.arena
+
+    def __exit__(self, *exc):
+        _ZERO_ARENA[0] = self.prev
+        return False
+
+
+def zeros(shape, dtype, device):
+    """A zeroed accumulator: a view of the active ZeroArena, or torch.zeros."""
+    a = _ZERO_ARENA[0]
+    return a.take(tuple(shape), dtype, device) if a is not None else torch.zeros(tuple(shape), dtype=dtype, device=device)
+
+
 def bn_colstats(x, mask=None, rows_per_cloud=0, out=None):
     """x [R,C] -> (sum [C], sumsq [C]) float64 (views of `out` [>= 2C] if given); mask [clouds] bool excludes padding
     clouds of rows_per_cloud rows."""
     x = L.require_cuda_f32(x, "x", 2)
     R, C = x.shape
-    buf = out if out is not None else torch.empty((2 * C,), dtype=torch.float64, device=x.device)
+    buf = out if out is not None else zeros((2 * C,), torch.float64, x.device)   # `out` must be zeroed by the caller
     s1, s2 = buf[:C], buf[C:2 * C]
     m = _mask_u8(mask)
     L.check(L.lib().dh3d_bn_colstats(L.ptr(x), R, C, L.ptr(m), int(rows_per_cloud), L.ptr(s1), L.ptr(s2),
@@ -673,6 +734,28 @@ def bn_bwd_finalize(S1, S2, cnt, mean, rstd, gamma):
     return o
 
 
+def bn_bwd_finalize_parts(part, cnt, mean, rstd, gamma):
+    """part [nk, P, C] float64 per-cloud partial sums (nk = 2 or 3) -> ([k2, k3] rows of a [2, C] tensor, grads [nk, C]
+    float32 = their sums over P: dbeta, dgamma(, d w_fc)) in one launch."""
+    nk, P, C = part.shape
+    o = torch.empty((2, C), dtype=torch.float32, device=part.device)
+    grads = torch.empty((nk, C), dtype=torch.float32, device=part.device)
+    L.check(L.lib().dh3d_bn_bwd_finalize_parts(L.ptr(part), nk, P, L.ptr(cnt), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), C,
+                                               L.ptr(o[0]), L.ptr(o[1]), L.ptr(grads), L.stream_ptr()),
+            "bn_bwd_finalize_parts")
+    return o, grads
+
+
+def sigmoid_bwd(datt, att, mask=None, rows_per_cloud=0):
+    """-> (dlogit = datt*att*(1-att), 0 on the rows of masked clouds; its sum as a [1] tensor)."""
+    datt, att = datt.contiguous(), att.contiguous()
+    dlogit = torch.empty_like(att)
+    tot = torch.zeros((1,), dtype=torch.float32, device=att.device)   # (a parameter gradient: not from the step arena)
+    L.check(L.lib().dh3d_sigmoid_bwd(L.ptr(datt), L.ptr(att), L.ptr(_mask_u8(mask)), int(rows_per_cloud), att.numel(),
+                                     L.ptr(dlogit), L.ptr(tot), L.stream_ptr()), "sigmoid_bwd")
+    return dlogit, tot
+
+
 def scale_shift_act(x, scale, shift, relu, out=None):
     x = L.require_cuda_f32(x, "x", 2)
     R, C = x.shape
@@ -696,7 +779,7 @@ def bn_bwd_sums(x, mean, rstd, gamma, beta, relu, dy=None, rowscale=None, colvec
     """-> S [3, C] float64: S[0] = sum dz, S[1] = sum dz*xhat, S[2] = sum rowscale*y (rank-one form only; else unused)."""
     x = L.require_cuda_f32(x, "x", 2)
     R, C = x.shape
-    S = torch.empty((3, C), dtype=torch.float64, device=x.device)
+    S = zeros((3, C), torch.float64, x.device)
     m = _mask_u8(mask)
     L.check(L.lib().dh3d_bn_bwd_sums(L.ptr(x), L.ptr(dy), L.ptr(rowscale), L.ptr(colvec), R, C, L.ptr(mean), L.ptr(rstd),
                                      L.ptr(gamma), L.ptr(beta), 1 if relu else 0, L.ptr(m), int(rows_per_cloud),
@@ -731,7 +814,7 @@ def interp_bn_colstats(G, idx, dist, order, mask=None, out=None):
     [B,n,4] or None -> (sum, sumsq) [Hd] float64 of the virtual rows three_interpolate(G) (views of `out` if given)."""
     Hd, rm, m = _g_layout(G, idx)
     B, n = idx.shape[0], idx.shape[1]
-    part = torch.empty((2, B, Hd), dtype=torch.float64, device=G.device)
+    part = zeros((2, B, Hd), torch.float64, G.device)
     L.check(L.lib().dh3d_interp_bn_colstats(L.ptr(G), Hd, rm, L.ptr(idx), L.ptr(dist), L.ptr(order), B, n, m,
                                             L.ptr(_mask_u8(mask)), L.ptr(part), L.stream_ptr()), "interp_bn_colstats")
     buf = out if out is not None else torch.empty((2 * Hd,), dtype=torch.float64, device=G.device)
@@ -751,21 +834,22 @@ def interp_head_rows(G, idx, dist, order, scale, shift, w_fc, b_fc_dev):
     return out
 
 
-def interp_bn_bwd_sums(G, idx, dist, order, dlogit, w_fc, mean, rstd, gamma, beta, mask=None):
+def interp_bn_bwd_sums(G, idx, dist, order, dlogit, w_fc, mean, rstd, gamma, beta, mask=None, parts=False):
+    """-> S [3, Hd] float64 (parts: the per-cloud partials [3, B, Hd] for bn_bwd_finalize_parts)."""
     Hd, rm, m = _g_layout(G, idx)
     B, n = idx.shape[0], idx.shape[1]
-    part = torch.empty((3, B, Hd), dtype=torch.float64, device=G.device)
+    part = zeros((3, B, Hd), torch.float64, G.device)
     L.check(L.lib().dh3d_interp_bn_bwd_sums(L.ptr(G), Hd, rm, L.ptr(idx), L.ptr(dist), L.ptr(order), B, n, m,
                                             L.ptr(_mask_u8(mask)), L.ptr(dlogit), L.ptr(w_fc), L.ptr(mean), L.ptr(rstd),
                                             L.ptr(gamma), L.ptr(beta), L.ptr(part), L.stream_ptr()), "interp_bn_bwd_sums")
-    return part.sum(1)
+    return part if parts else part.sum(1)
 
 
 def interp_bn_bwd_apply(G, idx, dist, order, dlogit, w_fc, scale, shift, k2, k3, mask=None):
     """-> dG (the layout of G) = interp^T(scale*dz - k2 - k3*h)."""
     Hd, rm, m = _g_layout(G, idx)
     B, n = idx.shape[0], idx.shape[1]
-    dG = torch.empty_like(G)
+    dG = zeros(G.shape, torch.float32, G.device)
     L.check(L.lib().dh3d_interp_bn_bwd_apply(L.ptr(G), Hd, rm, L.ptr(idx), L.ptr(dist), L.ptr(order), B, n, m,
                                              L.ptr(_mask_u8(mask)), L.ptr(dlogit), L.ptr(w_fc), L.ptr(scale),
                                              L.ptr(shift), L.ptr(k2), L.ptr(k3), L.ptr(dG), L.stream_ptr()),
@@ -781,7 +865,7 @@ def nv_commuted_fwd_stats(c, cw, idx, dist, order, mask=None, out=None):
     m = c.shape[0] // B
     s = torch.empty((B * n, 64), dtype=torch.float32, device=c.device)
     rinv = torch.empty((B * n,), dtype=torch.float32, device=c.device)
-    part = torch.empty((2, B, 64), dtype=torch.float64, device=c.device)
+    part = zeros((2, B, 64), torch.float64, c.device)
     L.check(L.lib().dh3d_netvlad_commuted_fwd_stats(L.ptr(c), L.ptr(cw), L.ptr(idx), L.ptr(dist), L.ptr(order), B, n, m,
                                                     L.ptr(_mask_u8(mask)), L.ptr(s), L.ptr(rinv), L.ptr(part),
                                                     L.stream_ptr()), "netvlad_commuted_fwd_stats")
@@ -794,8 +878,8 @@ def nv_commuted_fwd_assign(s, rinv, att, scale, shift, idx, dist, order, m, mask
     """-> p [B*n,64] = softmax(s*scale + shift), asum [B,64] = sum_n p*att, Ap [B*m,64] = interp^T(p*att*rinv)."""
     B, n = idx.shape[0], idx.shape[1]
     p = torch.empty_like(s)
-    asum = torch.empty((B, 64), dtype=torch.float32, device=s.device)
-    Ap = torch.empty((B * m, 64), dtype=torch.float32, device=s.device)
+    asum = zeros((B, 64), torch.float32, s.device)
+    Ap = zeros((B * m, 64), torch.float32, s.device)
     L.check(L.lib().dh3d_netvlad_commuted_fwd_assign(L.ptr(s), L.ptr(rinv), L.ptr(att), L.ptr(scale), L.ptr(shift),
                                                      L.ptr(idx), L.ptr(dist), L.ptr(order), B, n, m, L.ptr(_mask_u8(mask)),
                                                      L.ptr(p), L.ptr(asum), L.ptr(Ap), L.stream_ptr()),
@@ -803,26 +887,26 @@ def nv_commuted_fwd_assign(s, rinv, att, scale, shift, idx, dist, order, m, mask
     return p, asum, Ap
 
 
-def nv_commuted_bwd_sums(E, p, s, att, rinv, dasum, mean, rstd, idx, dist, order, mask=None):
+def nv_commuted_bwd_sums(E, p, s, att, rinv, dasum, mean, rstd, idx, dist, order, mask=None, parts=False):
     """-> dz [B*n,64], datt [B*n], t2 [B*n], S [2,64] float64 (sum dz, sum dz*shat)."""
     B, n = idx.shape[0], idx.shape[1]
     m = E.shape[0] // B
     dz = torch.empty_like(s)
     datt = torch.empty((B * n,), dtype=torch.float32, device=s.device)
     t2 = torch.empty((B * n,), dtype=torch.float32, device=s.device)
-    part = torch.empty((2, B, 64), dtype=torch.float64, device=s.device)
+    part = zeros((2, B, 64), torch.float64, s.device)
     L.check(L.lib().dh3d_netvlad_commuted_bwd_sums(L.ptr(E), L.ptr(p), L.ptr(s), L.ptr(att), L.ptr(rinv), L.ptr(dasum),
                                                    L.ptr(mean), L.ptr(rstd), L.ptr(idx), L.ptr(dist), L.ptr(order), B, n, m,
                                                    L.ptr(_mask_u8(mask)), L.ptr(dz), L.ptr(datt), L.ptr(t2), L.ptr(part),
                                                    L.stream_ptr()), "netvlad_commuted_bwd_sums")
-    return dz, datt, t2, part.sum(1)
+    return dz, datt, t2, (part if parts else part.sum(1))
 
 
 def nv_commuted_bwd_apply(dz, s, rinv, t2, k1, k2, k3, idx, dist, order, m, mask=None):
     """-> q [B*n], dcw [B*m,64] = interp^T(rinv * (k1*dz - k2 - k3*s))."""
     B, n = idx.shape[0], idx.shape[1]
     q = torch.empty((B * n,), dtype=torch.float32, device=s.device)
-    dcw = torch.empty((B * m, 64), dtype=torch.float32, device=s.device)
+    dcw = zeros((B * m, 64), torch.float32, s.device)
     L.check(L.lib().dh3d_netvlad_commuted_bwd_apply(L.ptr(dz), L.ptr(s), L.ptr(rinv), L.ptr(t2), L.ptr(k1), L.ptr(k2),
                                                     L.ptr(k3), L.ptr(idx), L.ptr(dist), L.ptr(order), B, n, m,
                                                     L.ptr(_mask_u8(mask)), L.ptr(q), L.ptr(dcw), L.stream_ptr()),

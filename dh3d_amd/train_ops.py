@@ -60,7 +60,7 @@ class _BNState(object):
 def _forward_stats(x, gamma, beta, run_mean, run_var, eps, momentum, mask, rows_per_cloud, sync, unbiased=True):
     """Two launches (+ the all-reduce under sync-BN): column sums, then the finalize kernel."""
     C = x.shape[1]
-    packed = torch.empty((2 * C + 1,), dtype=torch.float64, device=x.device)
+    packed = pm.zeros((2 * C + 1,), torch.float64, x.device)
     s1, s2 = pm.bn_colstats(x, mask, rows_per_cloud, out=packed)
     cnt = _count(x.shape[0], mask, rows_per_cloud, x.device)
     if sync and D.collectives_active():
@@ -71,6 +71,18 @@ def _forward_stats(x, gamma, beta, run_mean, run_var, eps, momentum, mask, rows_
     st.stats = pm.bn_finalize(s1, s2, cnt, gamma, beta, eps, momentum, run_mean, run_var, unbiased)
     st.cnt = cnt
     return st
+
+
+def _backward_coeffs_parts(part, st, gamma, sync):
+    """part [nk, P, C] f64 per-cloud partials -> (grads [nk, C] float32 local sums: dbeta, dgamma(, d w_fc), [k2, k3]).
+    One launch; under sync-BN the sums are all-reduced first (the long way)."""
+    if sync and D.collectives_active():
+        S = part.sum(1)
+        dgamma, dbeta, k = _backward_coeffs(S, st, gamma, sync)
+        grads = [dbeta, dgamma] + ([S[2].float()] if part.shape[0] > 2 else [])
+        return grads, k
+    k, grads = pm.bn_bwd_finalize_parts(part, st.cnt, st.stats[0], st.stats[1], gamma)
+    return grads, k
 
 
 def _backward_coeffs(S, st, gamma, sync):
@@ -382,13 +394,10 @@ class _AttentionHeadCommuted(torch.autograd.Function):
         C, Wd, G, g, be, wv, att = ctx.saved_tensors
         sync, mask, idx, dist, order, st, wshape, wfcshape = ctx.cfg
         N = idx.shape[1]
-        dlogit = (datt * att * (1.0 - att)).contiguous()
-        if mask is not None:
-            dlogit = dlogit * mask.repeat_interleave(N).to(dlogit.dtype)
-        S = pm.interp_bn_bwd_sums(G, idx, dist, order, dlogit, wv, st.stats[0], st.stats[1], g, be, mask)
-        dwfc = S[2].float().reshape(wfcshape)
-        dbfc = dlogit.sum().reshape(1)
-        dgamma, dbeta, k = _backward_coeffs(S, st, g, sync)
+        dlogit, dbfc = pm.sigmoid_bwd(datt, att, mask, N)
+        part = pm.interp_bn_bwd_sums(G, idx, dist, order, dlogit, wv, st.stats[0], st.stats[1], g, be, mask, parts=True)
+        grads, k = _backward_coeffs_parts(part, st, g, sync)
+        dbeta, dgamma, dwfc = grads[0], grads[1], grads[2].reshape(wfcshape)
         dG = pm.interp_bn_bwd_apply(G, idx, dist, order, dlogit, wv, st.stats[2], st.stats[3], k[0], k[1], mask)
         dW = pm.gemm_tn(C, dG).reshape(wshape)                                           # [Cin, H]
         dC = pm.gemm_nn(dG, pm.transpose_last2(Wd)) if ctx.needs_input_grad[0] else None
@@ -494,9 +503,9 @@ class _NetVLADAssignCommuted(torch.autograd.Function):
         Dm = c2.shape[1]
         dV = dV.contiguous()
         E = pm.gemm_nn_batched(c2.reshape(Bt, M, Dm), pm.transpose_last2(dV)).reshape(Bt * M, 64)
-        dz, datt, t2, S = pm.nv_commuted_bwd_sums(E, p, s, att, rinv, dasum.contiguous(), st.stats[0], st.stats[1],
-                                                  idx, dist, order, mask)
-        dgamma, dbeta, k = _backward_coeffs(S, st, g, sync)
+        dz, datt, t2, part = pm.nv_commuted_bwd_sums(E, p, s, att, rinv, dasum.contiguous(), st.stats[0], st.stats[1],
+                                                     idx, dist, order, mask, parts=True)
+        (dbeta, dgamma), k = _backward_coeffs_parts(part, st, g, sync)
         q, dcw = pm.nv_commuted_bwd_apply(dz, s, rinv, t2, st.stats[2], k[0], k[1], idx, dist, order, M, mask)
         dWc = pm.gemm_tn(c2, dcw)
         dc = pm.gemm_nn_batched(Ap.reshape(Bt, M, 64), dV).reshape(Bt * M, Dm)

@@ -22,7 +22,7 @@ import torch.nn.functional as F
 
 from . import backbones as bb
 from . import dist as D
-from . import losses, ops
+from . import losses, ops, pm
 
 
 class _AllGatherKeepOwn(torch.autograd.Function):
@@ -402,6 +402,7 @@ class QuadrupletTrainer(object):
         if backbone_bn == "batch":
             capturable = False  # the backbone's moving averages change every step: its folded copies are rebuilt eagerly
         self.graph_step = (impl == "hip" and capturable) if graph_step is None else (bool(graph_step) and capturable)
+        self._zarena = pm.ZeroArena()   # the step's accumulators: one fill per step (pm.ZeroArena)
         self._garena = None     # flat gradient arena of the sharded step (all-reduced in place, .grad are views of it)
         self._sched = (float(start_lr), int(decay_step), float(decay_rate))
         self._steps_done = 0
@@ -411,6 +412,7 @@ class QuadrupletTrainer(object):
         if self.graph_step:
             dev = self.params[0].device
             self._lr = torch.tensor(float(start_lr), dtype=torch.float32, device=dev)
+            self._lr_value = float(start_lr)
             # (fused: one multi-tensor kernel per step instead of ~8 foreach passes over the 20 parameter tensors)
             self.opt = torch.optim.Adam(self.params, lr=self._lr, capturable=True, fused=True)
             self.sched = None
@@ -521,6 +523,21 @@ class QuadrupletTrainer(object):
         lr0, dstep, drate = self._sched
         return lr0 * drate ** (self._steps_done // dstep)
 
+    def _set_lr(self):
+        lr = self._lr_now()
+        if lr != self._lr_value:  # (staircase schedule: changes every decay_step steps)
+            self._lr.fill_(lr)
+            self._lr_value = lr
+
+    def input_buffer(self, shape, device=None):
+        """The replayed step's own input tensor for batches of `shape` (None until that shape has been captured): a
+        loader that writes the next batch straight into it and passes it to `step` saves the copy into the graph's
+        input (the graph reads this buffer; any other tensor is copied into it first)."""
+        for (shp, dev, _), ent in self._step_graphs.items():
+            if tuple(shp) == tuple(shape) and (device is None or dev == device):
+                return ent[1]
+        return None
+
     def _reduce_gradients(self):
         """Sharded step: SUM all-reduce of the head gradients.  One persistent flat arena (18.7 MB for global_config):
         the gradients are gathered into it by ONE multi-tensor copy, all-reduced in place, and every .grad becomes a
@@ -556,7 +573,8 @@ class QuadrupletTrainer(object):
                 self._ensure_arena()
             graph = torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph), pm.zero_arena(self._zarena):
+                    self._zarena.begin(static_in.device)   # ONE fill for every accumulator of the step
                     loss = self.forward_loss(static_in)
                     loss.backward()
                     if self.wd_params and self.weight_decay and (not D.collectives_active() or dist.get_rank() == 0):
@@ -576,8 +594,11 @@ class QuadrupletTrainer(object):
             ent = (graph, static_in, loss)
             self._step_graphs[key] = ent
         graph, static_in, loss = ent
-        static_in.copy_(points)
-        self._lr.fill_(self._lr_now())
+        # (each of these two is a launch of its own in front of the replay -- ~10 us of queue latency apiece: skipped
+        # when the batch already sits in the step's input buffer (`input_buffer`) / the rate has not changed)
+        if points.data_ptr() != static_in.data_ptr():
+            static_in.copy_(points)
+        self._set_lr()
         graph.replay()
         self._steps_done += 1
         self.model.invalidate(head_only=True)
@@ -600,12 +621,14 @@ class QuadrupletTrainer(object):
                 return out
         self._eager_seen[shape] = self._eager_seen.get(shape, 0) + 1
         if self.graph_step:
-            self._lr.fill_(self._lr_now())
+            self._set_lr()
         self.opt.zero_grad(set_to_none=True)
         self._mark(0)
-        loss = self.forward_loss(points)
-        self._mark(2)
-        loss.backward()
+        with pm.zero_arena(self._zarena):
+            self._zarena.begin(points.device)
+            loss = self.forward_loss(points)
+            self._mark(2)
+            loss.backward()
         # L2 weight decay on '.*/W' (regularize_cost, core/model.py:239-243): d/dp [wd/2 * sum p^2] = wd * p, added to the
         # gradients directly (one multi-tensor launch) by rank 0 only -- the SUM all-reduce below then counts it once
         if self.wd_params and self.weight_decay and (not dist.is_initialized() or dist.get_rank() == 0):

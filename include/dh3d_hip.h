@@ -6,8 +6,11 @@
  *   - plain device pointers + sizes, no framework types; `stream` is a hipStream_t passed as void*;
  *   - returns an int status (DH3D_OK = 0); never throws, never allocates or frees device memory,
  *     never synchronises the device; all work is enqueued on `stream` (graph-capturable);
- *   - the caller owns every buffer including scratch; gradient outputs are zeroed by the library
- *     (hipMemsetAsync on `stream`), as the reference kernels do with cudaMemset;
+ *   - the caller owns every buffer including scratch; gradient outputs of the reference's operators are zeroed by
+ *     the library (hipMemsetAsync on `stream`), as the reference kernels do with cudaMemset.  The ACCUMULATORS of the
+ *     training step's internal kernels (statistics partials and scatter targets of dh3d_bn_colstats / dh3d_bn_bwd_sums /
+ *     dh3d_interp_bn_* / dh3d_netvlad_commuted_*, marked "zeroed by the CALLER" below) are not: a step takes all of them
+ *     from one arena that it clears with ONE fill (each hipMemsetAsync is a ~4 us launch of its own; there were ~30);
  *   - float32 + int32 only; re-entrant, no global mutable state.
  *
  * Section A are drop-ins for the reference's TF custom ops, in the reference's tensor layouts
@@ -427,12 +430,21 @@ int dh3d_colsum_f32(const float *x, long long R, int C, int accumulate, float *o
  *   colstats       : sum[c] = sum_r x, sumsq[c] = sum_r x^2                         (zeroes its outputs)
  *   scale_shift_act: y = act(x*scale[c] + shift[c])   (relu = 0/1; y may alias x)
  *   row_logit_sigmoid: att[r] = sigmoid(sum_c relu(h*scale+shift)[r,c] w[c] + b)    (attention head, backbones.py:170-173)
- *   bn_bwd_sums    : S1 = sum dz, S2 = sum dz*xhat with xhat = (x-mean)*rstd, dz = dy masked by relu(xhat*gamma+beta) > 0;
+ *   bn_colstats    : sum / sumsq [C] f64 += column sums of x over the live rows (zeroed by the CALLER)
+ *   bn_bwd_sums    : (S1, S2, S3 zeroed by the CALLER) S1 = sum dz, S2 = sum dz*xhat with xhat = (x-mean)*rstd, dz = dy masked by relu(xhat*gamma+beta) > 0;
  *                    dy == NULL: dy[r,c] = rowscale[r]*colvec[c] (rank one) and S3[c] = sum_r rowscale[r]*y[r,c]
  *   bn_finalize    : (sum, sumsq, count) -> mean, rstd, scale = gamma*rstd, shift = beta - mean*scale; running buffers
  *                    <- momentum*old + (1-momentum)*batch statistic (untouched when count == 0)
  *   bn_bwd_finalize: (S1, S2, count) -> k2, k3 of bn_bwd_apply
  *   bn_bwd_apply   : dx = scale*dz - k2[c] - k3[c]*x  == gamma*rstd*(dz - S1/n - xhat*S2/n)   (dx may alias x) */
+/* bn_bwd_finalize from per-cloud partial sums part [nk][P][C] f64 (nk = 2: S1, S2; 3: + S3): their sums over P give k2 / k3
+ * and, as float32, grads [nk][C] (dbeta, dgamma, d w_fc).  dh3d_sigmoid_bwd: dlogit = datt*att*(1-att) (0 on rows of
+ * masked clouds) and sum[0] += sum dlogit (sum zeroed by the CALLER). */
+int dh3d_bn_bwd_finalize_parts(const double *part, int nk, int P, const double *count, const float *mean,
+                               const float *rstd, const float *gamma, int C, float *k2, float *k3, float *grads,
+                               void *stream);
+int dh3d_sigmoid_bwd(const float *datt, const float *att, const unsigned char *mask, int rows_per_cloud, long long n,
+                     float *dlogit, float *sum, void *stream);
 int dh3d_bn_colstats(const float *x, long long R, int C, const unsigned char *mask, int rows_per_cloud, double *sum,
                      double *sumsq, void *stream);
 int dh3d_scale_shift_act(const float *x, long long R, int C, const float *scale, const float *shift, int relu,
@@ -473,12 +485,12 @@ int dh3d_context_gate_bwd(const float *v, const float *g, const float *dy, long 
  * 256-column slices [Hd/256][B*m][256] (row_major = 0) or as the GEMM's own [B*m][Hd] output (row_major = 1; dG likewise),
  * is never materialised.  idx / dist [B,n,3] = three_nn of the fine points, order =
  * dh3d_spatial_sort records [B,n,4] of the fine cloud (NULL: index order), mask [B] bytes (NULL: all clouds live).
- *   colstats : per-cloud partials part [2][B][Hd] f64 (zeroed by the call) of sum / sumsq of h over the live rows; their
+ *   colstats : per-cloud partials part [2][B][Hd] f64 (zeroed by the CALLER) of sum / sumsq of h over the live rows; their
  *              sums over B -> dh3d_bn_finalize
  *   forward  : dh3d_interp_head_sorted_fwd with the folded batch statistics as its epilogue
- *   bwd_sums : per-cloud partials part [3][B][Hd] of S1, S2, S3 of dh3d_bn_bwd_sums for dy = dlogit x w_fc (dlogit [B*n]
+ *   bwd_sums : per-cloud partials part [3][B][Hd] f64 (zeroed by the CALLER) of S1, S2, S3 of dh3d_bn_bwd_sums for dy = dlogit x w_fc (dlogit [B*n]
  *              by original point index)
- *   bwd_apply: dG [Hd/256][B*m][256] = interp^T(scale dz - k2 - k3 h) (zeroed by the call, f32 atomics), from which
+ *   bwd_apply: dG [Hd/256][B*m][256] = interp^T(scale dz - k2 - k3 h) (zeroed by the CALLER, f32 atomics), from which
  *              dW = coarse^T dG and dcoarse = dG W^T are GEMMs on B*m rows.  Hd <= 1024, m <= 1024. */
 int dh3d_interp_bn_colstats(const float *G, int Hd, int row_major, const int32_t *idx, const float *dist,
                             const float *order, int B, int n, int m, const unsigned char *mask,
@@ -504,13 +516,13 @@ int dh3d_three_interpolate_bwd_sorted(int b, int n, int c, int m, const float *g
  * point index); idx / dist = dh3d_three_nn of the fine points [B,n,3], order = dh3d_spatial_sort records of the fine
  * clouds [B,n,4] (NULL: index order), mask [B] bytes (NULL: every cloud).  m <= 1024.
  *   fwd_stats : s = rinv * interp(cw), rinv = rsqrt(max(|interp(c)|^2, 1e-12)), part [2][B][64] f64 = per-cloud column
- *               sums / sums of squares of s (zeroed by the call)
- *   fwd_assign: p = softmax(s*scale + shift), asum [B,64] = sum_n p*att, Ap [B*m,64] = interp^T(p*att*rinv) (zeroed by
- *               the call; V[b] = Ap[b]^T c[b])
+ *               sums / sums of squares of s (zeroed by the CALLER)
+ *   fwd_assign: p = softmax(s*scale + shift), asum [B,64] = sum_n p*att, Ap [B*m,64] = interp^T(p*att*rinv) (both zeroed
+ *               by the CALLER; V[b] = Ap[b]^T c[b])
  *   bwd_sums  : da = rinv*interp(E) + dasum; datt = sum_k da p (0 for masked clouds); dz = softmax backward of da*att;
- *               t2 = sum_k p att interp(E); part [2][B][64] = per-cloud sums of dz and dz*(s - mean)*rstd
+ *               t2 = sum_k p att interp(E); part [2][B][64] f64 (zeroed by the CALLER) = per-cloud sums of dz and dz*(s - mean)*rstd
  *   bwd_apply : ds = k1*dz - k2 - k3*s (dh3d_bn_bwd_finalize); q = rinv^2 sum_k ds s + rinv^3 t2; dcw [B*m,64] =
- *               interp^T(rinv*ds) (zeroed by the call)
+ *               interp^T(rinv*ds) (zeroed by the CALLER)
  * dh3d_interp_scatter_scaled: dc [B*m,256] += interp^T(-q * interp(c)) (dc NOT zeroed: it holds Ap dV + dcw Wc^T). */
 int dh3d_netvlad_commuted_fwd_stats(const float *c, const float *cw, const int32_t *idx, const float *dist,
                                     const float *order, int B, int n, int m, const unsigned char *mask, float *s,

@@ -14,7 +14,8 @@ def T(a, dev):
 
 # (products of >= 2^26 multiply-adds with K % 4 == 0 run on the bf16x6 kernel, the rest on the exact-f32 one)
 @pytest.mark.parametrize("K,M,N", [(1000, 256, 64), (4097, 512, 256), (22, 16384, 256), (333, 128, 1024), (70, 36, 12),
-                                   (11264, 256, 1024), (4100, 516, 260), (90112, 256, 64), (1028, 132, 1000)])
+                                   (11264, 256, 1024), (4100, 516, 260), (90112, 256, 64), (1028, 132, 1000),
+                                   (22, 256, 256), (7, 100, 36), (32, 16384, 64)])   # short reductions: gemm_shortk_kernel
 def test_gemm_tn_vs_fp64(dev, K, M, N):
     from dh3d_amd import pm
     rng = np.random.default_rng(K + M + N)
@@ -31,7 +32,8 @@ def test_gemm_tn_vs_fp64(dev, K, M, N):
 
 
 @pytest.mark.parametrize("M,K,N", [(1000, 256, 512), (11264, 256, 512), (130, 1024, 256), (65, 64, 128), (300, 20, 36),
-                                   (11264, 1024, 256), (90112, 64, 256), (4099, 260, 68), (70001, 36, 60)])
+                                   (11264, 1024, 256), (90112, 64, 256), (4099, 260, 68), (70001, 36, 60),
+                                   (22, 256, 256), (22, 256, 16384), (5, 36, 100), (32, 512, 68)])   # few rows: gemm_rows_kernel
 def test_gemm_nn_vs_fp64(dev, M, K, N):
     from dh3d_amd import pm
     rng = np.random.default_rng(M + K + N)
@@ -41,6 +43,12 @@ def test_gemm_nn_vs_fp64(dev, M, K, N):
     mag = np.abs(A.astype(np.float64)) @ np.abs(B.astype(np.float64))
     got = pm.gemm_nn(T(A, dev), T(B, dev)).cpu().numpy()
     assert np.all(np.abs(got - exp) <= 2e-6 * mag + 1e-6), float(np.abs(got - exp).max())
+    bias = rng.standard_normal((N,)).astype(np.float32)
+    got = pm.gemm_nn(T(A, dev), T(B, dev), bias=T(bias, dev)).cpu().numpy()
+    assert np.all(np.abs(got - (exp + bias)) <= 2e-6 * (mag + np.abs(bias)) + 1e-6)
+    C0 = rng.standard_normal((M, N)).astype(np.float32)
+    got = pm.gemm_nn(T(A, dev), T(B, dev), out=T(C0, dev), accumulate=True).cpu().numpy()
+    assert np.all(np.abs(got - (exp + C0)) <= 2e-6 * (mag + np.abs(C0)) + 1e-6)
 
 
 def test_gemm_batched_and_bias_vs_fp64(dev):
