@@ -56,6 +56,7 @@ _SIGNATURES = {
     "dh3d_flex_conv_pm_bwd_workspace_bytes": [c_int, c_int, c_int, c_int],
     "dh3d_flex_conv_pm_bwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp,
                               c_size_t, c_fp, c_fp, c_fp, c_fp],
+    "dh3d_gemm_is_split": [c_int, c_int, c_int, c_int, c_int],
     "dh3d_gemm_tn_f32": [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp],
     "dh3d_gemm_nn_f32": [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp],
     "dh3d_gemm_tn_f32_batched": [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp],
@@ -131,6 +132,8 @@ _SIGNATURES = {
     "dh3d_netvlad_commuted_bwd_apply": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp,
                                         c_fp, c_fp, c_fp],
     "dh3d_interp_scatter_scaled": [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp],
+    "dh3d_bn_finalize_parts": [c_fp, c_int, c_fp, c_fp, c_fp, c_float, c_float, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp,
+                               c_fp],
     "dh3d_bn_bwd_finalize_parts": [c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp],
     "dh3d_sigmoid_bwd": [c_fp, c_fp, c_fp, c_int, c_ll, c_fp, c_fp, c_fp],
     "dh3d_interp_bn_colstats": [c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp],

@@ -492,6 +492,17 @@ __global__ __launch_bounds__(256) void gemm_shortk_kernel(const float *__restric
 
 struct GemmBatch { int n; long long sA, sB, sC, sBias; };
 
+// reduction chunks of a product (> 1: the split partials meet in f32 atomics on a zeroed C)
+int gemm_chunks(bool ta, int M, int N, int K, int batch, int wgs) {
+  if (batch == 1 && ((!ta && M <= kSkM && K <= kSkK && K % 4 == 0) || (ta && K <= kSkM))) return 1;  // plain-FMA kernels
+  const int BN = N <= 64 ? 64 : 128;
+  const int gm = dh3d_cdiv(M, 128), gn = dh3d_cdiv(N, BN);
+  int chunks = dh3d_cdiv(wgs, gm * gn * batch);
+  const int maxc = dh3d_cdiv(K, ta ? 64 : 256);  // [M,K] operands: only long reductions are worth the atomics
+  chunks = chunks > maxc ? maxc : chunks;
+  return chunks < 1 ? 1 : chunks;
+}
+
 int gemm_launch(bool ta, const float *A, int lda, const float *B, int ldb, float *C, int ldc, int M, int N, int K,
                 float *C1, int rows0, bool accumulate, hipStream_t s, const float *colbias = nullptr,
                 GemmBatch bt = GemmBatch{1, 0, 0, 0, 0}) {
@@ -521,10 +532,8 @@ int gemm_launch(bool ta, const float *A, int lda, const float *B, int ldb, float
   constexpr int wgs_env = 0;
 #endif
   const int wgs = wgs_env > 0 ? wgs_env : ta ? 384 : 768;
-  int chunks = dh3d_cdiv(wgs, gm * gn * bt.n);
-  const int maxc = dh3d_cdiv(K, ta ? 64 : 256);  // [M,K] operands: only long reductions are worth the atomics
-  chunks = chunks > maxc ? maxc : chunks;
-  if (chunks < 1 || colbias) chunks = 1;
+  int chunks = gemm_chunks(ta, M, N, K, bt.n, wgs);
+  if (colbias) chunks = 1;
   // products of >= 2^26 multiply-adds with K % 32 == 0 go to the bf16x6 kernel (f32-accurate); small or odd-K ones stay on
   // the exact-f32 pipe.  DH3D_GEMM_F32=1 keeps everything there (A/B timing, bit-level comparisons)
 #ifdef DH3D_DEV
@@ -593,6 +602,13 @@ int dh3d_internal_transpose32(const void *in, void *out, int Bt, int R, int Cc, 
                      static_cast<const uint32_t *>(in), static_cast<uint32_t *>(out), R, Cc, ldo ? ldo : R,
                      ldo ? obs : (long long)R * Cc);
   return dh3d_launch_status();
+}
+
+// 1 when the product's reduction is split (the library then zeroes C and adds the partials with atomics -- or, with
+// accumulate = 1, adds them onto what the caller put there: a caller that owns a zeroed arena passes accumulate = 1 and
+// saves the fill).  ta: 1 = the tn form.  Pure function of the shape.
+DH3D_API int dh3d_gemm_is_split(int ta, int M, int N, int K, int batch) {
+  return gemm_chunks(ta != 0, M, N, K, batch > 0 ? batch : 1, ta ? 384 : 768) > 1 ? 1 : 0;
 }
 
 DH3D_API int dh3d_gemm_tn_f32(const float *A, const float *B, int K, int M, int N, int accumulate, float *C,

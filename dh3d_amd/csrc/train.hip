@@ -252,12 +252,14 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double *__restri
                                                          int unbiased, float *__restrict__ run_mean,
                                                          float *__restrict__ run_var, int C,
                                                          float *__restrict__ mean, float *__restrict__ rstd,
-                                                         float *__restrict__ scale, float *__restrict__ shift) {
+                                                         float *__restrict__ scale, float *__restrict__ shift, int P) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   const double n = cnt[0] > 1.0 ? cnt[0] : 1.0;
-  const double mu = sum[c] / n;
-  double var = sumsq[c] / n - mu * mu;
+  double s1 = 0.0, s2 = 0.0;  // P > 1: per-cloud partial rows (dh3d_bn_finalize_parts)
+  for (int p = 0; p < P; ++p) { s1 += sum[(size_t)p * C + c]; s2 += sumsq[(size_t)p * C + c]; }
+  const double mu = s1 / n;
+  double var = s2 / n - mu * mu;
   var = var > 0.0 ? var : 0.0;
   const float rs = (float)(1.0 / sqrt(var + (double)eps));
   const float sc = gamma[c] * rs;
@@ -670,7 +672,19 @@ DH3D_API int dh3d_bn_finalize(const double *sum, const double *sumsq, const doub
                               void *stream) {
   DH3D_REQUIRE(sum && sumsq && count && gamma && beta && run_mean && run_var && mean && rstd && scale && shift && C > 0);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(dh3d_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sum, sumsq, count,
-                     gamma, beta, eps, momentum, unbiased, run_mean, run_var, C, mean, rstd, scale, shift);
+                     gamma, beta, eps, momentum, unbiased, run_mean, run_var, C, mean, rstd, scale, shift, 1);
+  return dh3d_launch_status();
+}
+
+// The same from per-cloud partial rows part [2][P][C] (sum | sumsq) as the walks of interp_train.hip / netvlad_train.hip
+// leave them: the reduction over P happens here instead of in a launch of its own.
+DH3D_API int dh3d_bn_finalize_parts(const double *part, int P, const double *count, const float *gamma, const float *beta,
+                                    float eps, float momentum, int unbiased, float *run_mean, float *run_var, int C,
+                                    float *mean, float *rstd, float *scale, float *shift, void *stream) {
+  DH3D_REQUIRE(part && count && gamma && beta && run_mean && run_var && mean && rstd && scale && shift && C > 0 && P > 0);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(dh3d_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, part,
+                     part + (size_t)P * C, count, gamma, beta, eps, momentum, unbiased, run_mean, run_var, C, mean, rstd,
+                     scale, shift, P);
   return dh3d_launch_status();
 }
 

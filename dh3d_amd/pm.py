@@ -595,6 +595,8 @@ def gemm_tn(A, B, out=None, accumulate=False):
     if B.shape[0] != K:
         raise ValueError("gemm_tn: row counts differ")
     N = B.shape[1]
+    if out is None and _ZERO_ARENA[0] is not None and L.lib().dh3d_gemm_is_split(1, M, N, K, 1):
+        out, accumulate = zeros((M, N), torch.float32, A.device), True   # split reduction: the arena's zeros, no fill
     C = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=A.device)
     L.check(L.lib().dh3d_gemm_tn_f32(L.ptr(A), L.ptr(B), K, M, N, 1 if accumulate else 0, L.ptr(C), L.stream_ptr()),
             "gemm_tn")
@@ -609,6 +611,8 @@ def gemm_nn(A, B, out=None, accumulate=False, bias=None):
     if B.shape[0] != K:
         raise ValueError("gemm_nn: inner dimensions differ")
     N = B.shape[1]
+    if out is None and bias is None and _ZERO_ARENA[0] is not None and L.lib().dh3d_gemm_is_split(0, M, N, K, 1):
+        out, accumulate = zeros((M, N), torch.float32, A.device), True
     C = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=A.device)
     L.check(L.lib().dh3d_gemm_nn_f32(L.ptr(A), L.ptr(B), L.ptr(bias), M, K, N, 1 if accumulate else 0, L.ptr(C),
                                      L.stream_ptr()), "gemm_nn")
@@ -734,6 +738,17 @@ def bn_bwd_finalize(S1, S2, cnt, mean, rstd, gamma):
     return o
 
 
+def bn_finalize_parts(part, cnt, gamma, beta, eps, momentum, run_mean, run_var, unbiased=True):
+    """bn_finalize from per-cloud partial rows part [2, P, C] float64 (sum | sumsq), the reduction over P included."""
+    _, P, C = part.shape
+    o = torch.empty((4, C), dtype=torch.float32, device=gamma.device)
+    L.check(L.lib().dh3d_bn_finalize_parts(L.ptr(part), P, L.ptr(cnt), L.ptr(gamma), L.ptr(beta), float(eps),
+                                           float(momentum), 1 if unbiased else 0, L.ptr(run_mean), L.ptr(run_var), C,
+                                           L.ptr(o[0]), L.ptr(o[1]), L.ptr(o[2]), L.ptr(o[3]), L.stream_ptr()),
+            "bn_finalize_parts")
+    return o
+
+
 def bn_bwd_finalize_parts(part, cnt, mean, rstd, gamma):
     """part [nk, P, C] float64 per-cloud partial sums (nk = 2 or 3) -> ([k2, k3] rows of a [2, C] tensor, grads [nk, C]
     float32 = their sums over P: dbeta, dgamma(, d w_fc)) in one launch."""
@@ -809,7 +824,7 @@ def _g_layout(G, idx):
     return G.shape[1], 1, G.shape[0] // B
 
 
-def interp_bn_colstats(G, idx, dist, order, mask=None, out=None):
+def interp_bn_colstats(G, idx, dist, order, mask=None, out=None, parts=False):
     """G = coarse @ W + b as [ns, B*m, 256] slices or as [B*m, Hd]; idx/dist [B,n,3]; order = spatial_sort records
     [B,n,4] or None -> (sum, sumsq) [Hd] float64 of the virtual rows three_interpolate(G) (views of `out` if given)."""
     Hd, rm, m = _g_layout(G, idx)
@@ -817,6 +832,8 @@ def interp_bn_colstats(G, idx, dist, order, mask=None, out=None):
     part = zeros((2, B, Hd), torch.float64, G.device)
     L.check(L.lib().dh3d_interp_bn_colstats(L.ptr(G), Hd, rm, L.ptr(idx), L.ptr(dist), L.ptr(order), B, n, m,
                                             L.ptr(_mask_u8(mask)), L.ptr(part), L.stream_ptr()), "interp_bn_colstats")
+    if parts:
+        return part
     buf = out if out is not None else torch.empty((2 * Hd,), dtype=torch.float64, device=G.device)
     torch.sum(part, dim=1, out=buf[:2 * Hd].view(2, Hd))
     return buf[:Hd], buf[Hd:2 * Hd]
@@ -858,7 +875,7 @@ def interp_bn_bwd_apply(G, idx, dist, order, dlogit, w_fc, scale, shift, k2, k3,
 
 
 # ---- NetVLAD's assignment, training mode, rows commuted through the up-sampling (csrc/netvlad_train.hip)
-def nv_commuted_fwd_stats(c, cw, idx, dist, order, mask=None, out=None):
+def nv_commuted_fwd_stats(c, cw, idx, dist, order, mask=None, out=None, parts=False):
     """c [B*m,256], cw = c @ Wc [B*m,64] -> s [B*n,64], rinv [B*n] (by original point index) and (sum, sumsq) [64]
     float64 of the columns of s (views of `out` if given)."""
     B, n = idx.shape[0], idx.shape[1]
@@ -869,6 +886,8 @@ def nv_commuted_fwd_stats(c, cw, idx, dist, order, mask=None, out=None):
     L.check(L.lib().dh3d_netvlad_commuted_fwd_stats(L.ptr(c), L.ptr(cw), L.ptr(idx), L.ptr(dist), L.ptr(order), B, n, m,
                                                     L.ptr(_mask_u8(mask)), L.ptr(s), L.ptr(rinv), L.ptr(part),
                                                     L.stream_ptr()), "netvlad_commuted_fwd_stats")
+    if parts:
+        return s, rinv, part
     buf = out if out is not None else torch.empty((128,), dtype=torch.float64, device=c.device)
     torch.sum(part, dim=1, out=buf[:128].view(2, 64))
     return s, rinv, buf[:64], buf[64:128]

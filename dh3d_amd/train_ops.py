@@ -87,6 +87,9 @@ def _backward_coeffs_parts(part, st, gamma, sync):
 
 def _backward_coeffs(S, st, gamma, sync):
     """S [3, C] f64 local sums -> (local dgamma, dbeta as float32, [k2, k3]) with the all-reduce under sync-BN."""
+    if not (sync and D.collectives_active()):   # one launch: k2 / k3 and the float32 gradients
+        k, grads = pm.bn_bwd_finalize_parts(S[:2].reshape(2, 1, S.shape[1]), st.cnt, st.stats[0], st.stats[1], gamma)
+        return grads[1], grads[0], k
     local = S[:2].float()                       # this rank's partials: dbeta = S1, dgamma = S2
     if sync and D.collectives_active():
         S = S.clone()
@@ -373,15 +376,18 @@ class _AttentionHeadCommuted(torch.autograd.Function):
         G = pm.gemm_nn(C, Wd, bias=b.detach().contiguous())                             # [Bt*M, H]
         Bt, N = idx.shape[0], idx.shape[1]
         g, be = gamma.detach().contiguous(), beta.detach().contiguous()
-        packed = torch.empty((2 * H + 1,), dtype=torch.float64, device=C.device)
-        s1, s2 = pm.interp_bn_colstats(G, idx, dist, order, mask, out=packed)
         cnt = _count(Bt * N, mask, N, C.device)
+        st = _BNState()
         if sync and D.collectives_active():
+            packed = torch.empty((2 * H + 1,), dtype=torch.float64, device=C.device)
+            s1, s2 = pm.interp_bn_colstats(G, idx, dist, order, mask, out=packed)
             packed[2 * H:] = cnt
             D.all_reduce_sum_(packed)
             cnt = packed[2 * H:]
-        st = _BNState()
-        st.stats = pm.bn_finalize(s1, s2, cnt, g, be, eps, momentum, run_mean, run_var)
+            st.stats = pm.bn_finalize(s1, s2, cnt, g, be, eps, momentum, run_mean, run_var)
+        else:  # the per-cloud partial rows straight into the finalize kernel
+            part = pm.interp_bn_colstats(G, idx, dist, order, mask, parts=True)
+            st.stats = pm.bn_finalize_parts(part, cnt, g, be, eps, momentum, run_mean, run_var)
         st.cnt = cnt
         wv = wfc.detach().reshape(-1).contiguous()
         att = pm.interp_head_rows(G, idx, dist, order, st.stats[2], st.stats[3], wv, bfc.detach().reshape(-1).contiguous())
@@ -478,16 +484,19 @@ class _NetVLADAssignCommuted(torch.autograd.Function):
         Wd = Wc.detach().contiguous()
         cw = pm.gemm_nn(c2, Wd)                                            # [Bt*M, 64]
         g, be = gamma.detach().contiguous(), beta.detach().contiguous()
-        packed = torch.empty((2 * 64 + 1,), dtype=torch.float64, device=c.device)
-        s, rinv, s1, s2 = pm.nv_commuted_fwd_stats(c2, cw, idx, dist, order, mask, out=packed)
         cnt = _count(Bt * N, mask, N, c.device)
+        st = _BNState()
+        # cluster_bn is the one un-fused batch norm upstream (core/backbones.py:218-223): biased moving variance
         if sync and D.collectives_active():
+            packed = torch.empty((2 * 64 + 1,), dtype=torch.float64, device=c.device)
+            s, rinv, s1, s2 = pm.nv_commuted_fwd_stats(c2, cw, idx, dist, order, mask, out=packed)
             packed[128:] = cnt
             D.all_reduce_sum_(packed)
             cnt = packed[128:]
-        st = _BNState()
-        # cluster_bn is the one un-fused batch norm upstream (core/backbones.py:218-223): biased moving variance
-        st.stats = pm.bn_finalize(s1, s2, cnt, g, be, eps, momentum, run_mean, run_var, unbiased=False)
+            st.stats = pm.bn_finalize(s1, s2, cnt, g, be, eps, momentum, run_mean, run_var, unbiased=False)
+        else:
+            s, rinv, part = pm.nv_commuted_fwd_stats(c2, cw, idx, dist, order, mask, parts=True)
+            st.stats = pm.bn_finalize_parts(part, cnt, g, be, eps, momentum, run_mean, run_var, unbiased=False)
         st.cnt = cnt
         att = att.contiguous()
         p, asum, Ap = pm.nv_commuted_fwd_assign(s, rinv, att, st.stats[2], st.stats[3], idx, dist, order, M, mask)

@@ -416,6 +416,9 @@ int dh3d_flex_conv_pm_bwd(const float *features, const float *xyz, const int32_t
  *   nn: C[M,N] (+)= A[M,K]   B[K,N] (+ colbias[N], may be NULL; not with accumulate)  (linear layers of the
  *       training step, input gradients with W^T materialised)
  * accumulate = 0 overwrites C.  M, N (tn) / K, N (nn) multiples of 4. */
+/* 1 when the product's reduction is split over workgroups (C is then zeroed by the call and the partials added with f32
+ * atomics; with accumulate = 1 they are added onto the caller's C -- a caller holding zeroed memory saves the fill). */
+int dh3d_gemm_is_split(int ta /* 1: tn form */, int M, int N, int K, int batch);
 int dh3d_gemm_tn_f32(const float *A, const float *B, int K, int M, int N, int accumulate, float *C, void *stream);
 int dh3d_gemm_nn_f32(const float *A, const float *B, const float *colbias, int M, int K, int N, int accumulate,
                      float *C, void *stream);
@@ -440,6 +443,9 @@ int dh3d_colsum_f32(const float *x, long long R, int C, int accumulate, float *o
 /* bn_bwd_finalize from per-cloud partial sums part [nk][P][C] f64 (nk = 2: S1, S2; 3: + S3): their sums over P give k2 / k3
  * and, as float32, grads [nk][C] (dbeta, dgamma, d w_fc).  dh3d_sigmoid_bwd: dlogit = datt*att*(1-att) (0 on rows of
  * masked clouds) and sum[0] += sum dlogit (sum zeroed by the CALLER). */
+int dh3d_bn_finalize_parts(const double *part /* [2][P][C]: sum | sumsq per cloud */, int P, const double *count,
+                           const float *gamma, const float *beta, float eps, float momentum, int unbiased, float *run_mean,
+                           float *run_var, int C, float *mean, float *rstd, float *scale, float *shift, void *stream);
 int dh3d_bn_bwd_finalize_parts(const double *part, int nk, int P, const double *count, const float *mean,
                                const float *rstd, const float *gamma, int C, float *k2, float *k3, float *grads,
                                void *stream);
