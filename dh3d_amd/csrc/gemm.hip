@@ -401,6 +401,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x
 //   rows form:  C[M <= 32, N] (+)= A[M, K <= 512] B[K, N] (+ bias): a workgroup owns 64 columns, lane = column, the
 //               four waves split the rows; B is read once, coalesced
 constexpr int kSkM = 32, kSkK = 512;
+template <int RB>  // rows in use, in blocks of eight
 __global__ __launch_bounds__(256) void gemm_rows_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B,
                                                        int ldb, float *__restrict__ C, int ldc, int M, int N, int K,
                                                        int accumulate, const float *__restrict__ colbias) {
@@ -424,34 +425,46 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const float *__restrict_
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col = blockIdx.x * 64 + lane, cc = col < N ? col : N - 1;
-  float acc[kSkM / 4];
+  // The four waves split K (a quarter each, all 32 rows): at K = 256 a wave's whole share of B is 64 loads in flight at
+  // once -- ONE round trip to L2 / HBM where rows split over the waves made four (the kernel is nothing but latency:
+  // 22 of 26 us); rows of A as broadcast 16-byte LDS reads, no test in the loop (the padding is zero).  Partial sums
+  // meet in LDS.
+  constexpr int NR = 8 * RB;
+  float acc[NR];
 #pragma unroll
-  for (int i = 0; i < kSkM / 4; ++i) acc[i] = 0.f;
-  // 64 loads of B in flight per thread (one after the other the steps of K are that many L2 round trips: 80 us at
-  // K = 256); rows of A as broadcast 16-byte LDS reads, no test in the loop (the padding is zero)
-  for (int k0 = 0; k0 < K; k0 += 64) {
+  for (int i = 0; i < NR; ++i) acc[i] = 0.f;
+  const int kq = KP / 4;  // multiple of 16
+  for (int k0 = wave * kq; k0 < (wave + 1) * kq; k0 += 64) {
+    const int span = min(64, (wave + 1) * kq - k0);  // 16, 32, 48 or 64
     float b[64];
 #pragma unroll
     for (int u = 0; u < 64; ++u) b[u] = B[(size_t)(k0 + u < K ? k0 + u : K - 1) * ldb + cc];
 #pragma unroll
-    for (int i = 0; i < kSkM / 4; ++i) {
-      const float4 *ar = reinterpret_cast<const float4 *>(s_a + (wave + 4 * i) * KP + k0);
+    for (int u4 = 0; u4 < 16; ++u4) {
+      if (4 * u4 < span) {  // wave-uniform
 #pragma unroll
-      for (int u4 = 0; u4 < 16; ++u4) {
-        const float4 av = ar[u4];
-        acc[i] = fmaf(av.x, b[4 * u4], acc[i]); acc[i] = fmaf(av.y, b[4 * u4 + 1], acc[i]);
-        acc[i] = fmaf(av.z, b[4 * u4 + 2], acc[i]); acc[i] = fmaf(av.w, b[4 * u4 + 3], acc[i]);
+        for (int i = 0; i < NR; ++i) {
+          const float4 av = *reinterpret_cast<const float4 *>(s_a + i * KP + k0 + 4 * u4);
+          acc[i] = fmaf(av.x, b[4 * u4], acc[i]); acc[i] = fmaf(av.y, b[4 * u4 + 1], acc[i]);
+          acc[i] = fmaf(av.z, b[4 * u4 + 2], acc[i]); acc[i] = fmaf(av.w, b[4 * u4 + 3], acc[i]);
+        }
       }
     }
   }
+  float *s_red = s_a + kSkM * KP;  // [4][32][64]
+#pragma unroll
+  for (int i = 0; i < NR; ++i) s_red[(wave * kSkM + i) * 64 + lane] = acc[i];
+  __syncthreads();
   if (col < N) {
     const float bias = colbias ? colbias[col] : 0.f;
 #pragma unroll
     for (int i = 0; i < kSkM / 4; ++i) {
       const int r = wave + 4 * i;
       if (r < M) {
+        const float v = (s_red[(0 * kSkM + r) * 64 + lane] + s_red[(1 * kSkM + r) * 64 + lane]) +
+                        (s_red[(2 * kSkM + r) * 64 + lane] + s_red[(3 * kSkM + r) * 64 + lane]);
         float *o = C + (size_t)r * ldc + col;
-        *o = (accumulate ? *o : bias) + acc[i];
+        *o = (accumulate ? *o : bias) + v;
       }
     }
   }
@@ -508,9 +521,15 @@ int gemm_launch(bool ta, const float *A, int lda, const float *B, int ldb, float
                 GemmBatch bt = GemmBatch{1, 0, 0, 0, 0}) {
   if (bt.n == 1 && !C1) {  // one tiny dimension: the plain-FMA kernels above
     if (!ta && M <= kSkM && K <= kSkK && K % 4 == 0 && lda % 4 == 0) {
-      DH3D_ALLOW_BIG_LDS(gemm_rows_kernel);
-      hipLaunchKernelGGL(gemm_rows_kernel, dim3(dh3d_cdiv(N, 64)), dim3(256), sizeof(float) * kSkM * ((K + 63) / 64 * 64), s, A, lda, B, ldb, C,
-                         ldc, M, N, K, accumulate ? 1 : 0, colbias);
+      const size_t lds = sizeof(float) * (kSkM * ((K + 63) / 64 * 64) + 4 * kSkM * 64);
+#define DH3D_ROWS(RBV)                                                                                                 \
+  do {                                                                                                                 \
+    DH3D_ALLOW_BIG_LDS(gemm_rows_kernel<RBV>);                                                                         \
+    hipLaunchKernelGGL(gemm_rows_kernel<RBV>, dim3(dh3d_cdiv(N, 64)), dim3(256), lds, s, A, lda, B, ldb, C, ldc, M, N, \
+                       K, accumulate ? 1 : 0, colbias);                                                                \
+  } while (0)
+      if (M <= 8) DH3D_ROWS(1); else if (M <= 16) DH3D_ROWS(2); else if (M <= 24) DH3D_ROWS(3); else DH3D_ROWS(4);
+#undef DH3D_ROWS
       return dh3d_launch_status();
     }
     if (ta && K <= kSkM && !colbias) {
