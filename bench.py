@@ -681,7 +681,7 @@ def main():
                                    "note": "further timed blocks after the contract one; `value` is the first block"}
         return total * args.steps / dt, dt / args.steps * 1e3, info
 
-    def measure_in_flight(workload, depth=2, repeats=0):
+    def measure_in_flight(workload, depth=2, repeats=0, steps=None):
         """Throughput with `depth` independent steps in flight: `depth` graph instances on `depth` streams, each with its
         own batch buffers; step i is one full pass over one batch on stream i % depth.  A single forward of this path
         leaves most of the GPU idle (FPS: one CU per cloud for two thirds of the step), so consecutive batches overlap;
@@ -704,7 +704,8 @@ def main():
 
             for st in streams:
                 st.wait_stream(torch.cuda.current_stream())
-            dt = time_steps(step, pts, args.steps, args.warmup, dev)
+            nsteps = steps or args.steps
+            dt = time_steps(step, pts, nsteps, args.warmup, dev)
             rep = None
             if repeats > 0:
                 blocks = repeat_blocks(step, pts, args.steps, dev, repeats)
@@ -712,7 +713,7 @@ def main():
                        "median_ms": float(np.median(blocks)), "min_ms": float(np.min(blocks)),
                        "max_ms": float(np.max(blocks)), "median_value": total / (float(np.median(blocks)) * 1e-3),
                        "note": "further timed blocks after the contract one; `value` is the first block"}
-        return total * args.steps / dt, dt / args.steps * 1e3, rep
+        return total * nsteps / dt, dt / nsteps * 1e3, rep
 
     pipelined = args.inflight > 1 and args.workload != "train"
     value, ms, info = measure(args.workload)  # one step at a time (the definition of rounds 1-2; `value` for train)
@@ -786,7 +787,8 @@ def main():
         if args.workload != "train":
             depths = {"1": serial["value"]}
             for dpt in (2, 4):
-                depths[str(dpt)] = value if (pipelined and dpt == args.inflight) else measure_in_flight(args.workload, dpt)[0]
+                # (the sweep times 25 steps per step in flight: a deep pipeline's fill and drain weigh on K = 20)
+                depths[str(dpt)] = value if (pipelined and dpt == args.inflight) else measure_in_flight(args.workload, dpt, steps=max(args.steps, 25 * dpt))[0]
             line["throughput_by_steps_in_flight"] = depths
         # per-GPU throughput against the local batch: what `--scaling strong` gives each GPU at 8 / 4 / 2 GPUs
         # (SURVEY 8e "Expected scaling": the FPS / kNN latency chain does not shrink with the batch)

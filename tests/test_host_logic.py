@@ -137,3 +137,38 @@ def test_commuted_netvlad_training_algebra():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "netvlad_commute_check.py")], capture_output=True,
                        text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_zero_arena_hands_out_zeroed_independent_tensors():
+    """pm.ZeroArena (the training step's accumulators): zeros without an arena, the recorded demand sizes the buffer at
+    the next begin(), tensors are independent of the arena's version counter (not views), 256-byte spaced, cleared by
+    begin(), and an exhausted arena falls back to torch.zeros."""
+    import torch
+    from dh3d_amd import pm
+    cpu = torch.device("cpu")
+    z = pm.zeros((3, 4), torch.float64, cpu)
+    assert z.shape == (3, 4) and z.dtype == torch.float64 and float(z.abs().sum()) == 0.0
+    a = pm.ZeroArena()
+    with pm.zero_arena(a):
+        a.begin(cpu)                                  # nothing known yet: every request falls back
+        x = pm.zeros((3, 5), torch.float64, cpu)
+        y = pm.zeros((7,), torch.float32, cpu)
+        assert a.buf is None and float(x.sum()) == 0.0 and a.demand == 256 + 256
+        a.begin(cpu)                                  # sized by the step before
+        assert a.buf is not None and a.buf.numel() == 512
+        x = pm.zeros((3, 5), torch.float64, cpu)
+        y = pm.zeros((7,), torch.float32, cpu)
+        assert not x._is_view() and not y._is_view()
+        assert y.data_ptr() - x.data_ptr() == 256 and x.data_ptr() == a.buf.data_ptr()
+        x += 1.0
+        y += 2.0
+        extra = pm.zeros((100,), torch.float32, cpu)  # beyond the buffer: a plain zeros tensor, demand recorded
+        assert float(extra.sum()) == 0.0 and a.demand == 512 + 512
+        v = x._version
+        a.begin(cpu)                                  # grows to 1024 bytes; the old tensors keep the old storage
+        assert a.buf.numel() == 1024 and x._version == v
+        w = pm.zeros((3, 5), torch.float64, cpu)
+        w += 3.0
+        a.begin(cpu)
+        assert float(w.sum()) == 0.0                  # same buffer this time: cleared by ONE fill
+    assert pm.zeros((2,), torch.float32, cpu).data_ptr() != a.buf.data_ptr()   # outside the context: no arena
