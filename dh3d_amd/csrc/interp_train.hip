@@ -22,6 +22,7 @@
 // and three_interp_bwd's global atomics take 218 us for a quarter of the channels; the staged tile is added to memory
 // once per block and slice (f32 atomics on <= 64 rows).  Rows of padding clouds (mask) take no part.
 #include "common.h"
+#include "interp_walk.h"
 #include "wave_ops.h"
 
 #include <type_traits>
@@ -30,7 +31,9 @@
 
 namespace {
 
-constexpr int kP = 128;    // fine points per workgroup
+using dh3d_walk::idw3;
+using dh3d_walk::kP;
+using dh3d_walk::mix3;
 constexpr int kCap = 64;   // staged coarse rows per slice (a 128-point block touches 46 on average, 62 at most)
 constexpr int kPW = kP / 4;
 // MODE 2 keeps a chunk of dh rows next to the staged rows; 56 slots + 16 points x 272 floats leave room for two
@@ -38,23 +41,6 @@ constexpr int kPW = kP / 4;
 constexpr int kCap2 = 56;  // staged rows in MODE 2 (blocks touching more take the overflow path for the excess)
 constexpr int kCH = 16;    // points per dh chunk
 constexpr int kLDH = 272;  // row stride of the dh chunk (floats)
-
-// must round like three_interp_fwd_kernel<IDW> / interp_head_lds_kernel (no contraction)
-#pragma clang fp contract(off)
-__device__ __forceinline__ void idw3(float d1, float d2, float d3, float &w1, float &w2, float &w3) {
-  const float r1 = 1.0f / fmaxf(d1, 1e-10f), r2 = 1.0f / fmaxf(d2, 1e-10f), r3 = 1.0f / fmaxf(d3, 1e-10f);
-  const float norm = (r1 + r2) + r3;
-  w1 = r1 / norm; w2 = r2 / norm; w3 = r3 / norm;
-}
-__device__ __forceinline__ float4 mix3(const float4 a, const float4 b, const float4 c, float w1, float w2, float w3) {
-  float4 r;
-  r.x = (a.x * w1 + b.x * w2) + c.x * w3;
-  r.y = (a.y * w1 + b.y * w2) + c.y * w3;
-  r.z = (a.z * w1 + b.z * w2) + c.z * w3;
-  r.w = (a.w * w1 + b.w * w2) + c.w * w3;
-  return r;
-}
-#pragma clang fp contract(fast)
 
 template <bool OVF>
 __device__ __forceinline__ float4 row4(const float *s_rows, const float *gbase, int slot, int lane, int rs) {
@@ -114,62 +100,13 @@ __global__ __launch_bounds__(256) void interp_bn_kernel(const InterpBnArgs a) {
   if (bi >= a.B) return;
   if (a.mask && !a.mask[bi]) return;  // a padding cloud: no statistics, zero gradients
   const int n = a.n, m = a.m;
-  if (tid < 32) s_bits[tid] = 0u;
-  __syncthreads();
-  int my_i[3] = {0, 0, 0}, my_orig = 0;
-  bool have = false;
-  if (tid < kP) {
-    const int q = blk * kP + tid;
-    if (q < n) {
-      const int orig = a.order ? __float_as_int(a.order[(size_t)bi * n + q].w) : q;
-      const long long r = (long long)bi * n + orig;
-      float w1, w2, w3;
-      if (MODE == 3) { w1 = a.weight[r * 3]; w2 = a.weight[r * 3 + 1]; w3 = a.weight[r * 3 + 2]; }
-      else idw3(a.dist[r * 3], a.dist[r * 3 + 1], a.dist[r * 3 + 2], w1, w2, w3);
-      *reinterpret_cast<float4 *>(s_w + tid * 4) = make_float4(w1, w2, w3, (MODE == 0 || MODE == 3) ? 0.f : a.dlogit[r]);
-      my_orig = orig;
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        my_i[t] = a.idx[r * 3 + t];
-        atomicOr(&s_bits[my_i[t] >> 5], 1u << (my_i[t] & 31));
-      }
-      have = true;
-    } else {  // padding point of the last block: slot 0 with zero weights, flagged invalid
-      *reinterpret_cast<float4 *>(s_w + tid * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<int4 *>(s_slot + tid * 4) = make_int4(0, 0, 0, 0);
-    }
-  }
-  __syncthreads();
-  if (tid < 64) {
-    int c = tid < 32 ? __popc(s_bits[tid]) : 0, v = c;
-#pragma unroll
-    for (int off = 1; off < 32; off <<= 1) {
-      const int o = __shfl_up(v, off, 64);
-      if ((tid & 63) >= off) v += o;
-    }
-    if (tid < 32) s_pre[tid] = v - c;
-    if (tid == 31) s_pre[32] = v;
-  }
-  __syncthreads();
-  if (have) {
-    int sl3[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const int j = my_i[t];
-      const int slot = s_pre[j >> 5] + __popc(s_bits[j >> 5] & ((1u << (j & 31)) - 1u));
-      sl3[t] = slot < CAP ? slot : -1 - j;
-    }
-    *reinterpret_cast<int4 *>(s_slot + tid * 4) = make_int4(sl3[0], sl3[1], sl3[2], 1 + my_orig);
-  }
-  for (int j = tid; j < m; j += 256) {
-    if ((s_bits[j >> 5] >> (j & 31)) & 1u) {
-      const int slot = s_pre[j >> 5] + __popc(s_bits[j >> 5] & ((1u << (j & 31)) - 1u));
-      if (slot < CAP) s_row[slot] = j;
-    }
-  }
-  __syncthreads();
-  const int nd = min(s_pre[32], CAP);
-  const bool overflow = s_pre[32] > CAP;
+  const dh3d_walk::SlotTable tab{s_slot, s_w, s_bits, s_pre, s_row};
+  // the per-point scalar: dlogit (MODE 1, 2) / q (MODE 4); MODE 3 brings its own interpolation weights
+  const int distinct = dh3d_walk::build_slot_table<CAP>(
+      tab, a.idx, a.dist, MODE == 3 ? a.weight : nullptr, a.order, bi, blk, n, m,
+      [&](long long r, int) { return (MODE == 0 || MODE == 3) ? 0.f : a.dlogit[r]; });
+  const int nd = min(distinct, CAP);
+  const bool overflow = distinct > CAP;
 
   // The rows of slice sl + 1 are requested BEFORE the points of slice sl are worked on and parked in registers (CAP / 4
   // float4 per lane) until the buffer is free: staging and per-point work each took ~32 us of the 97 us statistics

@@ -22,6 +22,7 @@
 // interp_head_lds_kernel<true> (dense_x6.hip).  The last term of dc is MODE 4 of interp_bn_kernel (interp_train.hip).
 // Rows of padding clouds (mask) take no part.
 #include "common.h"
+#include "interp_walk.h"
 #include "wave_ops.h"
 
 #include <type_traits>
@@ -30,27 +31,11 @@
 
 namespace {
 
-constexpr int kP = 128;   // fine points per workgroup
+using dh3d_walk::kP;
+using dh3d_walk::mix3;
 constexpr int kPW = kP / 4;
 constexpr int kCap0 = 56;  // staged rows in MODE 0 (c and cw rows: 71.7 KB; blocks touching more read the excess from L2)
 constexpr int kCap = 64;   // slots in the other modes
-
-// must round like three_interp_fwd_kernel<IDW> / interp_head_lds_kernel (no contraction)
-#pragma clang fp contract(off)
-__device__ __forceinline__ void idw3(float d1, float d2, float d3, float &w1, float &w2, float &w3) {
-  const float r1 = 1.0f / fmaxf(d1, 1e-10f), r2 = 1.0f / fmaxf(d2, 1e-10f), r3 = 1.0f / fmaxf(d3, 1e-10f);
-  const float norm = (r1 + r2) + r3;
-  w1 = r1 / norm; w2 = r2 / norm; w3 = r3 / norm;
-}
-__device__ __forceinline__ float4 mix3(const float4 a, const float4 b, const float4 c, float w1, float w2, float w3) {
-  float4 r;
-  r.x = (a.x * w1 + b.x * w2) + c.x * w3;
-  r.y = (a.y * w1 + b.y * w2) + c.y * w3;
-  r.z = (a.z * w1 + b.z * w2) + c.z * w3;
-  r.w = (a.w * w1 + b.w * w2) + c.w * w3;
-  return r;
-}
-#pragma clang fp contract(fast)
 
 struct NvArgs {
   const float *c;        // [B*m, 256] sampled rows (MODE 0)
@@ -101,66 +86,18 @@ __global__ __launch_bounds__(256) void nv_walk_kernel(const NvArgs a) {
     if (MODE == 2 && tid < kP && blk * kP + tid < n) a.datt[(size_t)bi * n + blk * kP + tid] = 0.f;
     return;
   }
-  if (tid < 32) s_bits[tid] = 0u;
-  __syncthreads();
-  int my_i[3] = {0, 0, 0}, my_orig = 0;
-  bool have = false;
-  if (tid < kP) {
-    const int q = blk * kP + tid;
-    float f0 = 0.f, f1 = 0.f, f2 = 0.f;
-    if (q < n) {
-      const int orig = a.order ? __float_as_int(a.order[(size_t)bi * n + q].w) : q;
-      const long long r = (long long)bi * n + orig;
-      float w1, w2, w3;
-      idw3(a.dist[r * 3], a.dist[r * 3 + 1], a.dist[r * 3 + 2], w1, w2, w3);
-      *reinterpret_cast<float4 *>(s_w + tid * 4) = make_float4(w1, w2, w3, 0.f);
-      my_orig = orig;
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        my_i[t] = a.idx[r * 3 + t];
-        atomicOr(&s_bits[my_i[t] >> 5], 1u << (my_i[t] & 31));
-      }
-      have = true;
-      if (MODE == 1 || MODE == 2) f0 = a.att[r];
-      if (MODE != 0) f1 = a.rinv[r];
-      if (MODE == 3) f2 = a.t2[r];
-    } else {  // padding point of the last block: slot 0 with zero weights, flagged invalid
-      *reinterpret_cast<float4 *>(s_w + tid * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<int4 *>(s_slot + tid * 4) = make_int4(0, 0, 0, 0);
-    }
-    s_f0[tid] = f0; s_f1[tid] = f1; s_f2[tid] = f2;
-  }
-  __syncthreads();
-  if (tid < 64) {
-    int c = tid < 32 ? __popc(s_bits[tid]) : 0, v = c;
-#pragma unroll
-    for (int off = 1; off < 32; off <<= 1) {
-      const int o = __shfl_up(v, off, 64);
-      if ((tid & 63) >= off) v += o;
-    }
-    if (tid < 32) s_pre[tid] = v - c;
-    if (tid == 31) s_pre[32] = v;
-  }
-  __syncthreads();
-  if (have) {
-    int sl3[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const int j = my_i[t];
-      const int slot = s_pre[j >> 5] + __popc(s_bits[j >> 5] & ((1u << (j & 31)) - 1u));
-      sl3[t] = slot < CAP ? slot : -1 - j;
-    }
-    *reinterpret_cast<int4 *>(s_slot + tid * 4) = make_int4(sl3[0], sl3[1], sl3[2], 1 + my_orig);
-  }
-  for (int j = tid; j < m; j += 256) {
-    if ((s_bits[j >> 5] >> (j & 31)) & 1u) {
-      const int slot = s_pre[j >> 5] + __popc(s_bits[j >> 5] & ((1u << (j & 31)) - 1u));
-      if (slot < CAP) s_row[slot] = j;
-    }
-  }
-  __syncthreads();
-  const int nd = min(s_pre[32], CAP);
-  const bool overflow = s_pre[32] > CAP;
+  if (tid < kP) { s_f0[tid] = 0.f; s_f1[tid] = 0.f; s_f2[tid] = 0.f; }  // (padding points keep these)
+  const dh3d_walk::SlotTable tab{s_slot, s_w, s_bits, s_pre, s_row};
+  const int distinct = dh3d_walk::build_slot_table<CAP>(tab, a.idx, a.dist, nullptr, a.order, bi, blk, n, m,
+                                                        [&](long long r, int t) {
+                                                          // per-point scalars of the live points: att, rinv, t2
+                                                          if (MODE == 1 || MODE == 2) s_f0[t] = a.att[r];
+                                                          if (MODE != 0) s_f1[t] = a.rinv[r];
+                                                          if (MODE == 3) s_f2[t] = a.t2[r];
+                                                          return 0.f;
+                                                        });
+  const int nd = min(distinct, CAP);
+  const bool overflow = distinct > CAP;
 
   // this wave's points: original row of point p (or -1), every lane the same value
   auto orig_of = [&](int p) { return __builtin_amdgcn_readfirstlane(s_slot[(wave * kPW + p) * 4 + 3]) - 1; };
