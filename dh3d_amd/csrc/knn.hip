@@ -529,7 +529,7 @@ __global__ __launch_bounds__(64 * S) void knn_split_kernel(const float4 *__restr
   __syncthreads();
 #ifdef DH3D_KNN_PROBE
   long long pr_t0 = clock64(), pr_drain = 0, pr_scan = 0;
-  int pr_ndrain = 0, pr_nslots = 0, pr_ngroups = 0, pr_hits = 0;
+  int pr_ndrain = 0, pr_nslots = 0, pr_ngroups = 0, pr_hits = 0, pr_sparse = 0, pr_sparse_slots = 0, pr_entries = 0;
 #endif
 
   // everyone's progress -> my screen: the true K-th distance is at most any wave's own K-th, and at most the largest
@@ -551,6 +551,15 @@ __global__ __launch_bounds__(64 * S) void knn_split_kernel(const float4 *__restr
     ++pr_ndrain;
 #endif
     const int deepest = -wave_min_i32(-cnt);
+#ifdef DH3D_KNN_PROBE
+    {
+      const int deep = __popcll(__ballot(cnt > 4));
+      int tot = cnt;
+      for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
+      pr_entries += tot;
+      if (deep <= 3) { ++pr_sparse; pr_sparse_slots += deepest; }
+    }
+#endif
     uint2 nxt = my_q[lane];
 #pragma unroll 1
     for (int i = 0; i < deepest; ++i) {  // one copy of the insertion per site (code size, see knn_sorted_kernel)
@@ -731,7 +740,7 @@ __global__ __launch_bounds__(64 * S) void knn_split_kernel(const float4 *__restr
     long long *o = g_kprobe + (size_t)((b * NG + g) * S + wave) * 8;
     o[7] = pr_t0;
     o[0] = clock64() - pr_t0; o[1] = pr_drain; o[2] = pr_ndrain; o[3] = pr_nslots; o[4] = pr_ngroups;
-    o[5] = pr_scan; o[6] = pr_hits;
+    o[5] = pr_scan; o[6] = pr_hits + 1000 * pr_sparse + 1000000ll * pr_sparse_slots + 1000000000ll * pr_entries;
   }
 #endif
 

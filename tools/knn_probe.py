@@ -19,10 +19,17 @@ for B, N in ((8, 8192), (32, 4096)):
     h = (ctypes.c_longlong * (8 * n))()
     lib.dh3d_knn_probe_read(h, 8 * n)
     a = np.array(list(h)).reshape(n, 8)
+    packed = a[:, 6].copy()   # hits + 1e3 * sparse drains + 1e6 * their slot-iterations + 1e9 * queued entries
+    a[:, 6] = packed % 1000
+    sparse, sparse_slots, entries = (packed // 1000) % 1000, (packed // 1000000) % 1000, packed // 1000000000
     print("B=%d N=%d S=%d, %d waves: cycles mean %.0f max %.0f | scanning %.0f | in drains %.0f | #drains %.1f "
           "#slot-iterations %.1f | #groups scanned %.1f of %d owned | 32-candidate steps with a survivor %.1f of %.1f"
           % (B, N, S, n, a[:, 0].mean(), a[:, 0].max(), a[:, 5].mean(), a[:, 1].mean(), a[:, 2].mean(), a[:, 3].mean(),
              a[:, 4].mean(), NG // S, a[:, 6].mean(), 2 * a[:, 4].mean()))
+    print("   drains with <= 3 lanes holding more than 4 entries: %.1f of %.1f per wave, %.1f of the %.1f slot-iterations; "
+          "queued entries per wave %.0f (= %.1f per lane), i.e. %.1f %% of the lane-slots of its drains"
+          % (sparse.mean(), a[:, 2].mean(), sparse_slots.mean(), a[:, 3].mean(), entries.mean(), entries.mean() / 64,
+             100.0 * entries.sum() / (64.0 * a[:, 3].sum())))
     g = a.reshape(-1, S, 8)
     life = g[:, :, 0].max(1)
     print("   per query group: slowest wave mean %.0f; percentiles 50/90/99/100: %s; groups scanned mean %.1f max %d"
