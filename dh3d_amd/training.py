@@ -284,7 +284,7 @@ def global_head_hip(model, points, localdesc, lv, sync_bn=False, mask=None, comm
              + flex_conv_factorised(xp, lv["xyz_s"], lv["nbr_s"], tx, bx))
     else:
         x = flex_conv_factorised(feat_s, lv["xyz_s"], lv["nbr_s"], fc.position_theta, fc.position_bias)
-    x = x + fc.feature_bias.reshape(1, 1, -1)                                       # layers.py:330-331
+    x = T.add_channel_bias(x, fc.feature_bias.reshape(-1))                          # layers.py:330-331
     Dg = x.shape[2]
     new_feat = T.batch_norm_train(x.reshape(Bt * M, Dg), fbn, True, sync_bn, mask, M).reshape(Bt, M, Dg)
     from . import pm
