@@ -802,8 +802,9 @@ __global__ __launch_bounds__(64 * S) void knn_split_kernel(const float4 *__restr
 // threshold replaces any bookkeeping of what was taken.  Same keys, same order, same outputs as knn_kernel.
 template <int CPL, bool XYZ>
 __global__ __launch_bounds__(256) void knn_small_kernel(const float *__restrict__ pos, int N, int K, KnnLadder lad,
-                                                       int32_t *__restrict__ nn, float *__restrict__ dist) {
-  constexpr int Q = 4;  // queries per wave
+                                                       int32_t *__restrict__ nn, float *__restrict__ dist, int Q) {
+  // Q: queries per wave (the candidates are loaded once per wave): 4, or 2 when that still leaves few waves per SIMD --
+  // a query is K dependent rounds of two DPP reductions, the kernel is as long as one wave's queries
   const int b = blockIdx.y, lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q0 = (blockIdx.x * 4 + wave) * Q;
@@ -819,6 +820,7 @@ __global__ __launch_bounds__(256) void knn_small_kernel(const float *__restrict_
     cz[c] = XYZ ? base[(size_t)jj * 3 + 2] : base[(size_t)2 * N + jj];
     tbk[c] = j < N ? (unsigned)((j & lad.ctmask) * lad.cv + (j >> lad.log2ct)) : 0xFFFFFFFFu;
   }
+#pragma unroll 1
   for (int qi = 0; qi < Q; ++qi) {
     const int q = q0 + qi;
     if (q >= N) break;
@@ -885,10 +887,11 @@ template <bool XYZ>
 int knn_launch(const float *pos, int B, int N, int K, int32_t *nn, float *dist, hipStream_t s) {
   const KnnLadder lad = knn_ladder(N);
   if (N <= 2048) {  // wave-per-query kernel
-    dim3 sgrid(dh3d_cdiv(N, 16), B), sblock(256);
-    if (N <= 512) hipLaunchKernelGGL((knn_small_kernel<8, XYZ>), sgrid, sblock, 0, s, pos, N, K, lad, nn, dist);
-    else if (N <= 1024) hipLaunchKernelGGL((knn_small_kernel<16, XYZ>), sgrid, sblock, 0, s, pos, N, K, lad, nn, dist);
-    else hipLaunchKernelGGL((knn_small_kernel<32, XYZ>), sgrid, sblock, 0, s, pos, N, K, lad, nn, dist);
+    const int Q = (long long)B * N <= 16384 ? 2 : 4;  // <= 4 waves per SIMD with two queries per wave
+    dim3 sgrid(dh3d_cdiv(N, 4 * Q), B), sblock(256);
+    if (N <= 512) hipLaunchKernelGGL((knn_small_kernel<8, XYZ>), sgrid, sblock, 0, s, pos, N, K, lad, nn, dist, Q);
+    else if (N <= 1024) hipLaunchKernelGGL((knn_small_kernel<16, XYZ>), sgrid, sblock, 0, s, pos, N, K, lad, nn, dist, Q);
+    else hipLaunchKernelGGL((knn_small_kernel<32, XYZ>), sgrid, sblock, 0, s, pos, N, K, lad, nn, dist, Q);
     return dh3d_launch_status();
   }
   dim3 grid(dh3d_cdiv(N, kQueriesPerBlock), B), block(kQueriesPerBlock);
