@@ -19,9 +19,9 @@ The forward step is a hipGraph replay of dh3d_amd.model.DH3D.forward.
 
 Steps in flight.  One forward of this path is a latency chain on a few CUs (farthest point sampling: one CU per cloud
 for two thirds of the local step) followed by chip-wide kernels, so an engine that extracts descriptors for a stream of
-batches keeps TWO steps in flight: two graph instances on two streams, each with its own batch buffers; step i is one
-full pass over one batch on stream i % 2, and the K timed steps include the pipeline's fill and drain.  That is `value`
-since round 3 (`config.steps_in_flight`: 2).  `one_step_at_a_time` in the same line is the number rounds 1-2 reported as
+batches keeps SEVERAL steps in flight (local and cfg5: four, global: two): one graph instance per step in flight, each on
+its own stream with its own batch buffers; step i is one full pass over one batch on stream i % depth, and the K timed
+steps include the pipeline's fill and drain.  That is `value` since round 3 (`config.steps_in_flight`).  `one_step_at_a_time` in the same line is the number rounds 1-2 reported as
 `value` (each step finishes before the next one starts); `--inflight 1` makes it `value` again.  The training step
 depends on the previous step's weights and always runs one at a time.
 """
@@ -45,13 +45,13 @@ F32_MFMA_PEAK_TF = 157.3  # dense f32 MFMA = f32 vector peak
 BF16_MFMA_PEAK_TF = 2500.0
 
 WORKLOADS = {
-    "local": dict(preset="basic_config", B=8, N=8192, seed=2002, out="xyz_feat",
+    "local": dict(preset="basic_config", B=8, N=8192, seed=2002, out="xyz_feat", inflight=4,
                   name="local-descriptor forward (basic_config), N=8192 K=8, batch=8"),
-    "global": dict(preset="global_config", B=32, N=4096, seed=3003, out="globaldesc",
+    "global": dict(preset="global_config", B=32, N=4096, seed=3003, out="globaldesc", inflight=2,
                    name="global-descriptor forward (global_config), N=4096, 64-cluster NetVLAD, batch=32"),
-    "cfg5": dict(preset="detection_config", B=4, N=16384, seed=5005, out="xyz_feat_att",
+    "cfg5": dict(preset="detection_config", B=4, N=16384, seed=5005, out="xyz_feat_att", inflight=4,
                  name="dense local feature map (save_all path, detection_config), N=16384 K=8, batch=4, device kNN"),
-    "train": dict(preset="global_config", B=22, N=4096, seed=4004, out=None,
+    "train": dict(preset="global_config", B=22, N=4096, seed=4004, out=None, inflight=1,
                   name="Siamese quadruplet training step, Oxford-shaped batch (1 anchor + 2 pos + 18 neg + 1 other-neg), "
                        "N=4096, frozen backbone, batch sharded over ranks + RCCL all-gather of descriptors"),
 }
@@ -535,13 +535,17 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not collect live PMC traffic for the roofline kernel")
     ap.add_argument("--repeats", type=int, default=7,
                     help="further blocks of K timed steps after the contract block (median / min / max as extra keys)")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=0,
                     help="independent steps in flight (graph instances on separate streams, each with its own batch "
-                         "buffers, every step one full pass over one batch).  Default 2: a forward of this path is a "
-                         "latency chain on a few CUs (FPS: one CU per cloud) followed by chip-wide kernels, so the engine "
-                         "overlaps consecutive batches; 1 = one step at a time (also measured and reported as "
-                         "`one_step_at_a_time` in every line).  The training step always runs one at a time")
+                         "buffers, every step one full pass over one batch).  Default 0 = the workload's own (local 4, "
+                         "global 2, cfg5 4): a forward of this path is a latency chain on a few CUs (FPS: one CU per "
+                         "cloud) followed by chip-wide kernels, so the engine overlaps consecutive batches; 1 = one step "
+                         "at a time (also measured and reported as `one_step_at_a_time` in every line).  The training "
+                         "step always runs one at a time")
     args = ap.parse_args()
+    explicit_inflight = args.inflight > 0
+    if not explicit_inflight:
+        args.inflight = WORKLOADS[args.workload]["inflight"]
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         relaunch_under_torchrun(args.gpus)  # does not return
@@ -681,6 +685,8 @@ def main():
                                    "note": "further timed blocks after the contract one; `value` is the first block"}
         return total * args.steps / dt, dt / args.steps * 1e3, info
 
+    _STREAM_POOL = []
+
     def measure_in_flight(workload, depth=2, repeats=0, steps=None):
         """Throughput with `depth` independent steps in flight: `depth` graph instances on `depth` streams, each with its
         own batch buffers; step i is one full pass over one batch on stream i % depth.  A single forward of this path
@@ -691,7 +697,11 @@ def main():
         model = build_model(wl["preset"], dev, seed=0, num_points=wl["N"])
         model.steps_in_flight = depth  # placement hint of the persistent kernels: that many FPS kernels hold CUs
         pts = synthetic_clouds(per, wl["N"], wl["seed"], dev, rank)
-        streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+        # (the same streams for every measurement of the process: a stream's hardware queue follows from its creation
+        # order, and with fresh ones per call a later measurement found its steps sharing queues -- 20 k instead of 26 k)
+        while len(_STREAM_POOL) < depth:
+            _STREAM_POOL.append(torch.cuda.Stream(device=dev))
+        streams = _STREAM_POOL[:depth]
         with torch.no_grad():
             runs = [model.graphed(pts, outputs=(wl["out"],)) for _ in range(depth)]
             state = {"i": 0}
@@ -751,6 +761,23 @@ def main():
         line["config"]["parallelism"] = ("one role-ordered batch sharded over %d GPU(s); all-gather of [clouds,256] "
                                          "descriptors + SUM all-reduce of head gradients over RCCL" % world)
         line.update(info)
+    def fresh_process_in_flight(workload, depth, steps):
+        """(value, ms_per_step) of `bench.py --workload w --inflight depth` in a process of its own.  How well steps in
+        flight overlap depends on which hardware queue each stream and each graph instance's internal branch lands on,
+        and that follows from the creation order of every stream of the process: measured after other workloads in THIS
+        process the same configuration gave 16.9 k where a fresh process gives 24 k.  The line's `value` is measured
+        first, in the state a process that only runs this workload has; the informational numbers get that state too."""
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", workload, "--inflight", str(depth),
+               "--steps", str(steps), "--warmup", str(args.warmup), "--no-extras", "--no-cpu-baseline", "--repeats", "0"]
+        try:
+            out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300).stdout.decode()
+            rec = json.loads([ln for ln in out.splitlines() if ln.startswith('{"metric"')][-1])
+            return rec["value"], rec["ms_per_step"]
+        except Exception:  # noqa: BLE001 -- informational numbers: fall back to this process
+            v, ms, _ = measure_in_flight(workload, depth, steps=steps)
+            return v, ms
+
     extras = rank == 0 and not args.no_extras and args.workload in ("local", "global")
     if extras:
         with torch.no_grad():
@@ -775,8 +802,9 @@ def main():
             rec.update(oinfo)
             if pipelined and other != "train":  # the same definition as the line's `value`
                 rec["one_step_at_a_time"] = {"value": ov, "ms_per_step": oms}
-                rec["value"], rec["ms_per_step"], _ = measure_in_flight(other, args.inflight)
-                rec["steps_in_flight"] = args.inflight
+                odepth = args.inflight if explicit_inflight else WORKLOADS[other]["inflight"]
+                rec["value"], rec["ms_per_step"] = fresh_process_in_flight(other, odepth, args.steps)
+                rec["steps_in_flight"] = odepth
             if other == "cfg5":
                 with torch.no_grad():
                     rec["kernel_roofline"] = cfg5_kernel_line(dev)
@@ -788,7 +816,7 @@ def main():
             depths = {"1": serial["value"]}
             for dpt in (2, 4):
                 # (the sweep times 25 steps per step in flight: a deep pipeline's fill and drain weigh on K = 20)
-                depths[str(dpt)] = value if (pipelined and dpt == args.inflight) else measure_in_flight(args.workload, dpt, steps=max(args.steps, 25 * dpt))[0]
+                depths[str(dpt)] = value if (pipelined and dpt == args.inflight) else fresh_process_in_flight(args.workload, dpt, max(args.steps, 25 * dpt))[0]
             line["throughput_by_steps_in_flight"] = depths
         # per-GPU throughput against the local batch: what `--scaling strong` gives each GPU at 8 / 4 / 2 GPUs
         # (SURVEY 8e "Expected scaling": the FPS / kNN latency chain does not shrink with the batch)
