@@ -438,7 +438,10 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const float *__restrict_
     const int span = min(64, (wave + 1) * kq - k0);  // 16, 32, 48 or 64
     float b[64];
 #pragma unroll
-    for (int u = 0; u < 64; ++u) b[u] = B[(size_t)(k0 + u < K ? k0 + u : K - 1) * ldb + cc];
+    for (int u = 0; u < 64; ++u) {  // (clamped address, then a select: no load under a branch; 0 beyond K, not 0 * B)
+      const float v = B[(size_t)(k0 + u < K ? k0 + u : K - 1) * ldb + cc];
+      b[u] = k0 + u < K ? v : 0.f;
+    }
 #pragma unroll
     for (int u4 = 0; u4 < 16; ++u4) {
       if (4 * u4 < span) {  // wave-uniform
