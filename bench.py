@@ -697,8 +697,7 @@ def main():
         model = build_model(wl["preset"], dev, seed=0, num_points=wl["N"])
         model.steps_in_flight = depth  # placement hint of the persistent kernels: that many FPS kernels hold CUs
         pts = synthetic_clouds(per, wl["N"], wl["seed"], dev, rank)
-        # (the same streams for every measurement of the process: a stream's hardware queue follows from its creation
-        # order, and with fresh ones per call a later measurement found its steps sharing queues -- 20 k instead of 26 k)
+        # (the same streams for every measurement of the process)
         while len(_STREAM_POOL) < depth:
             _STREAM_POOL.append(torch.cuda.Stream(device=dev))
         streams = _STREAM_POOL[:depth]
@@ -763,10 +762,10 @@ def main():
         line.update(info)
     def fresh_process_in_flight(workload, depth, steps):
         """(value, ms_per_step) of `bench.py --workload w --inflight depth` in a process of its own.  How well steps in
-        flight overlap depends on which hardware queue each stream and each graph instance's internal branch lands on,
-        and that follows from the creation order of every stream of the process: measured after other workloads in THIS
-        process the same configuration gave 16.9 k where a fresh process gives 24 k.  The line's `value` is measured
-        first, in the state a process that only runs this workload has; the informational numbers get that state too."""
+        flight overlap depends on the live streams and graph instances of the process (they share four hardware
+        queues): measured after other workloads in THIS process the same configuration gave 16.9 k where a fresh process
+        gives 24 k.  The line's `value` is measured first, in the state a process that only runs this workload has; the
+        informational numbers get that state too."""
         import subprocess
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", workload, "--inflight", str(depth),
                "--steps", str(steps), "--warmup", str(args.warmup), "--no-extras", "--no-cpu-baseline", "--repeats", "0"]
