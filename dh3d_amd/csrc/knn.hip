@@ -529,7 +529,7 @@ __global__ __launch_bounds__(64 * S) void knn_split_kernel(const float4 *__restr
   __syncthreads();
 #ifdef DH3D_KNN_PROBE
   long long pr_t0 = clock64(), pr_drain = 0, pr_scan = 0;
-  int pr_ndrain = 0, pr_nslots = 0, pr_ngroups = 0, pr_hits = 0, pr_sparse = 0, pr_sparse_slots = 0, pr_entries = 0;
+  int pr_ndrain = 0, pr_nslots = 0, pr_ngroups = 0, pr_hits = 0, pr_sparse = 0, pr_sparse_slots = 0, pr_entries = 0, pr_halfskip = 0, pr_steps = 0;
 #endif
 
   // everyone's progress -> my screen: the true K-th distance is at most any wave's own K-th, and at most the largest
@@ -602,6 +602,24 @@ __global__ __launch_bounds__(64 * S) void knn_split_kernel(const float4 *__restr
     __builtin_amdgcn_wave_barrier();
     const int clen = min(64, N - gcc * 64);
     for (int j = 0; j < clen; j += 32) {
+#ifdef DH3D_KNN_PROBE  // would a per-query test against the box of these 32 candidates have skipped the step?
+      {
+        const bool mine = (lane >> 5) == (j >> 5);   // the half-group's candidates sit in lanes 32*(j/32)..
+        float lo[3] = {mine ? cr.x : INFINITY, mine ? cr.y : INFINITY, mine ? cr.z : INFINITY};
+        float hi[3] = {mine ? cr.x : -INFINITY, mine ? cr.y : -INFINITY, mine ? cr.z : -INFINITY};
+        if (cr.x == INFINITY) { hi[0] = hi[1] = hi[2] = -INFINITY; }  // padding records
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3)
+          for (int off = 32; off > 0; off >>= 1) {
+            lo[c3] = fminf(lo[c3], __shfl_xor(lo[c3], off, 64));
+            hi[c3] = fmaxf(hi[c3], __shfl_xor(hi[c3], off, 64));
+          }
+        const float px = fmaxf(fmaxf(lo[0] - qr.x, qr.x - hi[0]), 0.f), py = fmaxf(fmaxf(lo[1] - qr.y, qr.y - hi[1]), 0.f),
+                    pz = fmaxf(fmaxf(lo[2] - qr.z, qr.z - hi[2]), 0.f);
+        if (!__any(valid && (px * px + py * py + pz * pz) * 0.99999f <= st.bound)) ++pr_halfskip;
+        ++pr_steps;
+      }
+#endif
       f32x2 sq[4][4];
       float mn[4];
 #pragma unroll
@@ -738,7 +756,7 @@ __global__ __launch_bounds__(64 * S) void knn_split_kernel(const float4 *__restr
 #ifdef DH3D_KNN_PROBE
   if (lane == 0 && ((b * NG + g) * S + wave) < 4096) {
     long long *o = g_kprobe + (size_t)((b * NG + g) * S + wave) * 8;
-    o[7] = pr_t0;
+    o[7] = pr_halfskip * 1000 + pr_steps;
     o[0] = clock64() - pr_t0; o[1] = pr_drain; o[2] = pr_ndrain; o[3] = pr_nslots; o[4] = pr_ngroups;
     o[5] = pr_scan; o[6] = pr_hits + 1000 * pr_sparse + 1000000ll * pr_sparse_slots + 1000000000ll * pr_entries;
   }

@@ -34,10 +34,9 @@ for B, N in ((8, 8192), (32, 4096)):
     life = g[:, :, 0].max(1)
     print("   per query group: slowest wave mean %.0f; percentiles 50/90/99/100: %s; groups scanned mean %.1f max %d"
           % (life.mean(), np.percentile(life, [50, 90, 99, 100]).astype(int), g[:, :, 4].sum(1).mean(), g[:, :, 4].sum(1).max()))
-    t0 = a[:, 7].min()
-    end = (a[:, 7] + a[:, 0] - t0)
-    print("   wave start (cycles after the first) percentiles 50/90/100: %s; wave end 50/90/99/100: %s"
-          % (np.percentile(a[:, 7] - t0, [50, 90, 100]).astype(int), np.percentile(end, [50, 90, 99, 100]).astype(int)))
+    hs, st = a[:, 7] // 1000, a[:, 7] % 1000
+    print("   32-candidate steps a per-query test against the HALF-group's box would skip: %.1f of %.1f per wave (%.0f %%)"
+          % (hs.mean(), st.mean(), 100.0 * hs.sum() / max(st.sum(), 1)))
     worst = np.argsort(-a[:, 0])[:5]
     for w in worst:
         print("   slow wave %d: cycles %d scan %d drain %d drains %d slots %d groups %d hits %d"
