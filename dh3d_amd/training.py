@@ -447,7 +447,10 @@ class QuadrupletTrainer(object):
             desc = T.l2_normalize_rows(desc, 1e-8)                                          # model.py:205
         else:
             desc = desc * torch.rsqrt(torch.clamp((desc * desc).sum(1, keepdim=True), min=1e-8))
-        full = _AllGatherKeepOwn.apply(desc)[:Bt]
+        if not D.collectives_active() and desc.shape[0] == Bt:
+            full = desc   # one rank, no padding: nothing to gather or slice (a clone, a fill and two copies per step)
+        else:
+            full = _AllGatherKeepOwn.apply(desc)[:Bt]
         if self.keep_desc:  # tests: the gathered, l2-normalised descriptors of this step
             self.last_desc = full.detach().clone()
         if self.impl == "hip" and T.quadruplet_loss_supported(full, cfg.num_pos, cfg.num_neg):
