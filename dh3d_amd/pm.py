@@ -644,6 +644,9 @@ def _mask_u8(mask):
     return None if mask is None else mask.to(torch.uint8).contiguous()
 
 
+_ITEMSIZE = {torch.float32: 4, torch.float64: 8, torch.int32: 4, torch.int64: 8, torch.uint8: 1}
+
+
 class ZeroArena(object):
     """One zeroed device buffer per training step for the accumulators its kernels add into (statistics partials, scatter
     targets: include/dh3d_hip.h "zeroed by the CALLER").  `begin()` clears it with ONE fill and rewinds; `zeros()` below
@@ -668,7 +671,7 @@ class ZeroArena(object):
         n = 1
         for d in shape:
             n *= int(d)
-        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        nbytes = n * _ITEMSIZE[dtype]
         span = (nbytes + 255) // 256 * 256
         self.demand += span
         if self.buf is None or self.buf.device != device or self.off + span > self.buf.numel():
