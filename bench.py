@@ -730,10 +730,17 @@ def main():
               "note": "each step finishes before the next one starts (rounds 1-2 reported this as `value`)"}
     if "repeats" in info:
         serial["repeats"] = info.pop("repeats")
+    in_flight_error = None
     if pipelined:
-        value, ms, rep = measure_in_flight(args.workload, args.inflight, args.repeats)
-        if rep:
-            info["repeats"] = rep
+        try:
+            value, ms, rep = measure_in_flight(args.workload, args.inflight, args.repeats)
+            if rep:
+                info["repeats"] = rep
+        except Exception as e:  # noqa: BLE001 -- the line must not be lost: fall back to the one-at-a-time measurement
+            if world > 1:  # (the ranks could not agree on the fallback without another collective)
+                raise
+            in_flight_error = repr(e)[:300]
+            pipelined = False
     wl = WORKLOADS[args.workload]
     per, total = per_rank_batch(args.batch or wl["B"])
     line = {
@@ -748,6 +755,8 @@ def main():
                                  "step one full pass over one batch)" % args.inflight) if pipelined else "hipGraph replay",
                    "steps_in_flight": args.inflight if pipelined else 1},
     }
+    if in_flight_error:
+        line["in_flight_error"] = in_flight_error
     if args.workload != "train":
         line["one_step_at_a_time"] = serial
     if "repeats" in info:
