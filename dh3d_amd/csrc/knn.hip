@@ -331,8 +331,9 @@ __global__ __launch_bounds__(64 * kSortedWaves) void knn_sorted_kernel(const flo
     ++pr_ndrain;
 #endif
     // ONE copy of the (long) insertion per drain site, the next slot requested from LDS while this one is inserted.
-    // Unrolled over the 16 slots the kernel was > 100 KB of code (the drain is inlined at every site of the scan): more
-    // than the instruction cache two CUs share, and the waves of a CU are all at different places of it.
+    // Unrolled over the 16 slots the kernel was > 100 KB of code (the drain is inlined at every site of the scan); the
+    // instruction cache coped with that in the shipped build (0.2 % misses, profiles/r03_d_pmc_knn.txt) but not in the
+    // probe build, and nothing is gained by the unrolling.
     const int deepest = -wave_min_i32(-cnt);
     uint2 nxt = my_q[lane];
 #pragma unroll 1
