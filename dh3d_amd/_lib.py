@@ -45,6 +45,14 @@ _SIGNATURES = {
     "dh3d_conv_pointset_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp],
     "dh3d_conv_pointset_bwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp,
                                c_fp],
+    "dh3d_flex_conv_fwd_f64": [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp],
+    "dh3d_flex_conv_bwd_f64": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp,
+                               c_fp, c_fp, c_fp],
+    "dh3d_flex_pool_fwd_f64": [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp],
+    "dh3d_flex_pool_bwd_f64": [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp],
+    "dh3d_conv_pointset_fwd_f64": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp],
+    "dh3d_conv_pointset_bwd_f64": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp,
+                                   c_fp],
     "dh3d_flex_conv_fwd_workspace_bytes": [c_int, c_int, c_int, c_int, c_int, c_int],
     "dh3d_flex_conv_fwd_ws": [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp,
                               c_size_t, c_fp],
@@ -238,6 +246,22 @@ def require_cuda_f32(t, name, ndim=None):
         raise ValueError("%s must be a torch.Tensor" % name)
     if t.dtype != torch.float32:
         raise ValueError("%s must be float32, got %s" % (name, t.dtype))
+    if not t.is_cuda:
+        raise ValueError("%s must live on the GPU (the HIP path has no CPU fallback)" % name)
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError("%s must have rank %d, got shape %s" % (name, ndim, tuple(t.shape)))
+    return t.contiguous()
+
+
+def require_cuda_float(t, name, ndim=None, like=None):
+    """float32 or float64 (the six reference-layout flex operators accept both, as the reference's registrations do);
+    `like`: a tensor whose dtype this one has to share."""
+    if not isinstance(t, torch.Tensor):
+        raise ValueError("%s must be a torch.Tensor" % name)
+    if t.dtype not in (torch.float32, torch.float64):
+        raise ValueError("%s must be float32 or float64, got %s" % (name, t.dtype))
+    if like is not None and t.dtype != like.dtype:
+        raise ValueError("%s must have the dtype of the features (%s), got %s" % (name, like.dtype, t.dtype))
     if not t.is_cuda:
         raise ValueError("%s must live on the GPU (the HIP path has no CPU fallback)" % name)
     if ndim is not None and t.dim() != ndim:

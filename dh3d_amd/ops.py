@@ -49,11 +49,12 @@ def knn_bruteforce(positions, k, name=None):
 class _FlexConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, features, theta, bias, neighborhood, position):
-        f = L.require_cuda_f32(features, "features", 3)
-        t = L.require_cuda_f32(theta, "theta", 3)
-        bi = L.require_cuda_f32(bias, "bias", 2)
+        f = L.require_cuda_float(features, "features", 3)
+        t = L.require_cuda_float(theta, "theta", 3, like=f)
+        bi = L.require_cuda_float(bias, "bias", 2, like=f)
         nb = L.require_cuda_i32(neighborhood, "neighborhood", 3)
-        p = L.require_cuda_f32(position, "position", 3)
+        p = L.require_cuda_float(position, "position", 3, like=f)
+        f64 = f.dtype == torch.float64   # (flex_conv_op.cc:97-106 registers double too: the reference formulation)
         B, Din, N = f.shape
         Dp, Din_t, Dout = t.shape
         K = nb.shape[1]
@@ -62,10 +63,13 @@ class _FlexConv(torch.autograd.Function):
         _same(tuple(bi.shape), (Din, Dout), "bias shape")
         _same((nb.shape[0], nb.shape[2]), (B, N), "neighborhood [B,_,N]")
         _same(tuple(p.shape), (B, Dp, N), "position shape")
-        out = torch.empty((B, Dout, N), dtype=torch.float32, device=f.device)
+        out = torch.empty((B, Dout, N), dtype=f.dtype, device=f.device)
         with torch.cuda.device(f.device):
-            ws_bytes = L.lib().dh3d_flex_conv_fwd_workspace_bytes(B, N, K, Dp, Din, Dout) if FAST_PATH else 0
-            if ws_bytes:  # the DH3D shapes: fused MFMA kernels behind the reference signature (section A' of the ABI)
+            ws_bytes = L.lib().dh3d_flex_conv_fwd_workspace_bytes(B, N, K, Dp, Din, Dout) if FAST_PATH and not f64 else 0
+            if f64:
+                L.check(L.lib().dh3d_flex_conv_fwd_f64(L.ptr(f), L.ptr(t), L.ptr(bi), L.ptr(nb), L.ptr(p), B, N, K, Dp,
+                                                       Din, Dout, L.ptr(out), L.stream_ptr()), "flex_convolution")
+            elif ws_bytes:  # the DH3D shapes: fused MFMA kernels behind the reference signature (section A' of the ABI)
                 ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=f.device)
                 L.check(L.lib().dh3d_flex_conv_fwd_ws(L.ptr(f), L.ptr(t), L.ptr(bi), L.ptr(nb), L.ptr(p), B, N, K, Dp,
                                                       Din, Dout, L.ptr(out), L.ptr(ws), ws_bytes, L.stream_ptr()),
@@ -85,8 +89,13 @@ class _FlexConv(torch.autograd.Function):
         K = nb.shape[1]
         gf, gt, gb = torch.empty_like(f), torch.empty_like(t), torch.empty_like(bi)
         with torch.cuda.device(f.device):
-            ws_bytes = L.lib().dh3d_flex_conv_bwd_workspace_bytes(B, N, K, Dp, Din, Dout) if FAST_PATH else 0
-            if ws_bytes:  # factorised backward on the MFMA pipe + atomics scatter (csrc/flex_bwd.hip)
+            f64 = f.dtype == torch.float64
+            ws_bytes = L.lib().dh3d_flex_conv_bwd_workspace_bytes(B, N, K, Dp, Din, Dout) if FAST_PATH and not f64 else 0
+            if f64:
+                L.check(L.lib().dh3d_flex_conv_bwd_f64(L.ptr(f), L.ptr(t), L.ptr(bi), L.ptr(nb), L.ptr(p), L.ptr(td), B,
+                                                       N, K, Dp, Din, Dout, L.ptr(gf), L.ptr(gt), L.ptr(gb),
+                                                       L.stream_ptr()), "flex_convolution_grad")
+            elif ws_bytes:  # factorised backward on the MFMA pipe + atomics scatter (csrc/flex_bwd.hip)
                 ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=f.device)
                 L.check(L.lib().dh3d_flex_conv_bwd_ws(L.ptr(f), L.ptr(t), L.ptr(bi), L.ptr(nb), L.ptr(p), L.ptr(td), B,
                                                       N, K, Dp, Din, Dout, L.ptr(gf), L.ptr(gt), L.ptr(gb), L.ptr(ws),
@@ -108,16 +117,20 @@ def flex_convolution(features, position, neighborhood, theta, bias, name=None):
 class _FlexPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, features, neighborhood):
-        f = L.require_cuda_f32(features, "features", 3)
+        f = L.require_cuda_float(features, "features", 3)
         nb = L.require_cuda_i32(neighborhood, "neighborhood", 3)
+        f64 = f.dtype == torch.float64
         B, D, N = f.shape
         K = nb.shape[1]
         _same((nb.shape[0], nb.shape[2]), (B, N), "neighborhood [B,_,N]")  # ops/flex_pool.cc:35-56
         out = torch.empty_like(f)
         argmax = torch.empty((B, D, N), dtype=torch.int32, device=f.device)
         with torch.cuda.device(f.device):
-            ws_bytes = L.lib().dh3d_flex_pool_fwd_workspace_bytes(B, N, K, D) if FAST_PATH else 0
-            if ws_bytes:
+            ws_bytes = L.lib().dh3d_flex_pool_fwd_workspace_bytes(B, N, K, D) if FAST_PATH and not f64 else 0
+            if f64:
+                L.check(L.lib().dh3d_flex_pool_fwd_f64(L.ptr(f), L.ptr(nb), B, N, K, D, L.ptr(out), L.ptr(argmax),
+                                                       L.stream_ptr()), "flex_pooling")
+            elif ws_bytes:
                 ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=f.device)
                 L.check(L.lib().dh3d_flex_pool_fwd_ws(L.ptr(f), L.ptr(nb), B, N, K, D, L.ptr(out), L.ptr(argmax),
                                                       L.ptr(ws), ws_bytes, L.stream_ptr()), "flex_pooling")
@@ -135,8 +148,8 @@ class _FlexPool(torch.autograd.Function):
         B, D, N = td.shape
         gf = torch.empty_like(td)
         with torch.cuda.device(td.device):
-            L.check(L.lib().dh3d_flex_pool_bwd(L.ptr(td), L.ptr(argmax), B, N, D, L.ptr(gf), L.stream_ptr()),
-                    "flex_pooling_grad")
+            fn = L.lib().dh3d_flex_pool_bwd_f64 if td.dtype == torch.float64 else L.lib().dh3d_flex_pool_bwd
+            L.check(fn(L.ptr(td), L.ptr(argmax), B, N, D, L.ptr(gf), L.stream_ptr()), "flex_pooling_grad")
         return gf, None
 
 
@@ -150,9 +163,9 @@ def flex_pooling(features, neighborhood, name=None):
 class _ConvPointset(torch.autograd.Function):
     @staticmethod
     def forward(ctx, features, theta, bias, neighborhood):
-        f = L.require_cuda_f32(features, "features", 3)
-        t = L.require_cuda_f32(theta, "theta", 2)
-        bi = L.require_cuda_f32(bias, "bias", 1)
+        f = L.require_cuda_float(features, "features", 3)
+        t = L.require_cuda_float(theta, "theta", 2, like=f)
+        bi = L.require_cuda_float(bias, "bias", 1, like=f)
         nb = L.require_cuda_i32(neighborhood, "neighborhood", 3)
         B, Din, N = f.shape
         Din_t, Dout = t.shape
@@ -160,10 +173,11 @@ class _ConvPointset(torch.autograd.Function):
         _same(Din_t, Din, "Din(theta/features)")  # ops/conv_pointset.cc:38-73
         _same(bi.shape[0], Dout, "bias length")
         _same((nb.shape[0], nb.shape[2]), (B, N), "neighborhood [B,_,N]")
-        out = torch.empty((B, Dout, N), dtype=torch.float32, device=f.device)
+        out = torch.empty((B, Dout, N), dtype=f.dtype, device=f.device)
         with torch.cuda.device(f.device):
-            L.check(L.lib().dh3d_conv_pointset_fwd(L.ptr(f), L.ptr(t), L.ptr(bi), L.ptr(nb), B, N, K, Din, Dout,
-                                                   L.ptr(out), L.stream_ptr()), "convolution_pointset")
+            fn = L.lib().dh3d_conv_pointset_fwd_f64 if f.dtype == torch.float64 else L.lib().dh3d_conv_pointset_fwd
+            L.check(fn(L.ptr(f), L.ptr(t), L.ptr(bi), L.ptr(nb), B, N, K, Din, Dout, L.ptr(out), L.stream_ptr()),
+                    "convolution_pointset")
         ctx.save_for_backward(f, t, nb)
         return out
 
@@ -175,11 +189,11 @@ class _ConvPointset(torch.autograd.Function):
         Dout = t.shape[1]
         K = nb.shape[1]
         gf, gt = torch.empty_like(f), torch.empty_like(t)
-        gb = torch.empty((Dout,), dtype=torch.float32, device=f.device)
+        gb = torch.empty((Dout,), dtype=f.dtype, device=f.device)
         with torch.cuda.device(f.device):
-            L.check(L.lib().dh3d_conv_pointset_bwd(L.ptr(f), L.ptr(t), L.ptr(nb), L.ptr(td), B, N, K, Din, Dout,
-                                                   L.ptr(gf), L.ptr(gt), L.ptr(gb), L.stream_ptr()),
-                    "convolution_pointset_grad")
+            fn = L.lib().dh3d_conv_pointset_bwd_f64 if f.dtype == torch.float64 else L.lib().dh3d_conv_pointset_bwd
+            L.check(fn(L.ptr(f), L.ptr(t), L.ptr(nb), L.ptr(td), B, N, K, Din, Dout, L.ptr(gf), L.ptr(gt), L.ptr(gb),
+                       L.stream_ptr()), "convolution_pointset_grad")
         return gf, gt, gb, None
 
 

@@ -11,7 +11,8 @@
  *     training step's internal kernels (statistics partials and scatter targets of dh3d_bn_colstats / dh3d_bn_bwd_sums /
  *     dh3d_interp_bn_* / dh3d_netvlad_commuted_*, marked "zeroed by the CALLER" below) are not: a step takes all of them
  *     from one arena that it clears with ONE fill (each hipMemsetAsync is a ~4 us launch of its own; there were ~30);
- *   - float32 + int32 only; re-entrant, no global mutable state.
+ *   - float32 + int32 (the six flex operators of section A also for double: *_f64); re-entrant, no global mutable
+ *     state.
  *
  * Section A are drop-ins for the reference's TF custom ops, in the reference's tensor layouts
  * (user_ops: channels-first [B,C,N]; tf_ops: channels-last [B,N,C]).  Section B are the fused
@@ -98,6 +99,26 @@ int dh3d_conv_pointset_bwd(const float *features, const float *theta,
                            const int32_t *neighborhood, const float *topdiff, int B, int N, int K,
                            int Din, int Dout, float *grad_features, float *grad_theta,
                            float *grad_bias, void *stream);
+
+/* The same six operators for double (the reference registers float AND double kernels, flex_conv_op.cc:97-106 /
+ * flex_pool_op.cc / conv_pointset_op.cc, and its gradient tests run in double, test_flex_convolution.py:93-115): the
+ * reference formulation of csrc/flex_generic.hip instantiated for double, any shape. */
+int dh3d_flex_conv_fwd_f64(const double *features, const double *theta, const double *bias, const int32_t *neighborhood,
+                           const double *positions, int B, int N, int K, int Dp, int Din, int Dout, double *output,
+                           void *stream);
+int dh3d_flex_conv_bwd_f64(const double *features, const double *theta, const double *bias, const int32_t *neighborhood,
+                           const double *positions, const double *topdiff, int B, int N, int K, int Dp, int Din, int Dout,
+                           double *grad_features, double *grad_theta, double *grad_bias, void *stream);
+int dh3d_flex_pool_fwd_f64(const double *features, const int32_t *neighborhood, int B, int N, int K, int D, double *output,
+                           int32_t *argmax, void *stream);
+int dh3d_flex_pool_bwd_f64(const double *topdiff, const int32_t *argmax, int B, int N, int D, double *grad_features,
+                           void *stream);
+int dh3d_conv_pointset_fwd_f64(const double *features, const double *theta, const double *bias,
+                               const int32_t *neighborhood, int B, int N, int K, int Din, int Dout, double *output,
+                               void *stream);
+int dh3d_conv_pointset_bwd_f64(const double *features, const double *theta, const int32_t *neighborhood,
+                               const double *topdiff, int B, int N, int K, int Din, int Dout, double *grad_features,
+                               double *grad_theta, double *grad_bias, void *stream);
 
 /* FarthestPointSample -- replaces farthestpointsamplingLauncher (tf_ops/sampling/tf_sampling.cpp:94,
  * tf_sampling_g.cu:105-170,203-205).  inp [B,N,3] -> out [B,m] int32, first pick 0, bit-exact tie

@@ -408,3 +408,65 @@ def test_three_nn_vs_reference_twin_lattice_golden(dev):
     s1, g1 = pm.spatial_sort(t1); s2, g2 = pm.spatial_sort(t2)
     d2, i2 = pm.three_nn_sorted(s1, g1, s2, g2)
     assert np.array_equal(d2.cpu().numpy(), c["dist"]) and np.array_equal(i2.cpu().numpy(), c["idx"])
+
+
+def _f64_case(dev, B=2, N=32, K=4, Din=2, Dout=6, Dp=3, seed=42):
+    """The reference's FakePointCloud (user_ops/misc.py:32-69; B=2, N=32, K=4, Din=2, Dout=6, Dp=3 in every op test) in
+    float64, neighbours from the exact distance matrix."""
+    rng = np.random.default_rng(seed)
+    pos = rng.standard_normal((B, Dp, N))
+    d = ((pos[:, :, :, None] - pos[:, :, None, :]) ** 2).sum(1)
+    nbr = np.argsort(d, axis=2, kind="stable")[:, :, :K].transpose(0, 2, 1).astype(np.int32)   # [B,K,N], rank 0 = self
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return dict(pos=t(pos), nbr=t(nbr), feat=t(rng.standard_normal((B, Din, N))), theta=t(rng.standard_normal((Dp, Din, Dout))),
+                bias=t(rng.standard_normal((Din, Dout))), theta_rel=t(rng.standard_normal((Din, Dout))),
+                bias_rel=t(rng.standard_normal((Dout,))))
+
+
+def test_flex_ops_float64_forward_and_numeric_gradients(dev):
+    """The reference registers double kernels for the flex operators (flex_conv_op.cc:97-106) and checks its gradients in
+    float64 against numeric differentiation (test_flex_convolution.py:93-115, test_conv_pointset.py, test_flex_pooling.py;
+    tf.test.compute_gradient).  Same recipe on the *_f64 entry points: forward against a float64 numpy restatement of
+    the operator, analytic against numeric Jacobians with torch.autograd.gradcheck at the reference's case size."""
+    from dh3d_amd import ops
+    c = _f64_case(dev)
+    f, p, nb, th, bi = c["feat"], c["pos"], c["nbr"], c["theta"], c["bias"]
+    # forward, flex_conv: out[b,o,n] = sum_k sum_i (bias[i,o] + sum_d theta[d,i,o] (p[nk] - p[n])_d) f[b,i,nk]
+    fn, pn, nbn, thn, bin_ = (x.cpu().numpy() for x in (f, p, nb, th, bi))
+    B, Din, N = fn.shape
+    exp = np.zeros((B, thn.shape[2], N))
+    for b in range(B):
+        for n in range(N):
+            for k in range(nbn.shape[1]):
+                nk = nbn[b, k, n]
+                w = bin_ + np.einsum("d,dio->io", pn[b, :, nk] - pn[b, :, n], thn)
+                exp[b, :, n] += fn[b, :, nk] @ w
+    out = ops.flex_convolution(f, p, nb, th, bi)
+    assert out.dtype == torch.float64 and np.abs(out.cpu().numpy() - exp).max() < 1e-12
+    # conv_pointset: out[b,o,n] = bias[o] + sum_k sum_i theta[i,o] (f[nk] - f[n0]),  n0 = rank-0 neighbour
+    thr, br = c["theta_rel"], c["bias_rel"]
+    exp = np.zeros((B, thr.shape[1], N))
+    for b in range(B):
+        for n in range(N):
+            n0 = nbn[b, 0, n]
+            for k in range(nbn.shape[1]):
+                exp[b, :, n] += (fn[b, :, nbn[b, k, n]] - fn[b, :, n0]) @ thr.cpu().numpy()
+            exp[b, :, n] += br.cpu().numpy()
+    out = ops.convolution_pointset(f, nb, thr, br)
+    assert out.dtype == torch.float64 and np.abs(out.cpu().numpy() - exp).max() < 1e-12
+    # flex_pool: max over the neighbourhood, argmax = point id
+    out, arg = ops.flex_pooling(f, nb)
+    g = fn[np.arange(B)[:, None, None, None], np.arange(Din)[None, :, None, None], nbn[:, None, :, :]]   # [B,Din,K,N]
+    assert out.dtype == torch.float64 and np.array_equal(out.cpu().numpy(), g.max(2))
+    assert np.array_equal(arg.cpu().numpy(), np.take_along_axis(np.broadcast_to(nbn[:, None], g.shape), g.argmax(2)[:, :, None], 2)[:, :, 0])
+    # numeric against analytic Jacobians, every differentiable input
+    req = lambda x: x.clone().requires_grad_(True)
+    assert torch.autograd.gradcheck(lambda a, t_, b_: ops.flex_convolution(a, p, nb, t_, b_), (req(f), req(th), req(bi)),
+                                    eps=1e-6, atol=1e-7, rtol=1e-6, nondet_tol=1e-12)
+    assert torch.autograd.gradcheck(lambda a, t_, b_: ops.convolution_pointset(a, nb, t_, b_), (req(f), req(thr), req(br)),
+                                    eps=1e-6, atol=1e-7, rtol=1e-6, nondet_tol=1e-12)
+    assert torch.autograd.gradcheck(lambda a: ops.flex_pooling(a, nb)[0], (req(f),), eps=1e-6, atol=1e-7, rtol=1e-6,
+                                    nondet_tol=1e-12)
+    # mixed dtypes are refused like the op registration would
+    with pytest.raises(ValueError):
+        ops.flex_convolution(f, p.float(), nb, th, bi)
