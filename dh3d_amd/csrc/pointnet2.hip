@@ -296,6 +296,165 @@ __global__ __launch_bounds__(kBlock) void three_nn_sorted_kernel(int n, int m, c
   }
 }
 
+// The same search with the candidates pruned by their group boxes (m <= kNNChunk: the whole sampled set in LDS -- every
+// DH3D level).  three_nn_sorted_kernel evaluates every candidate for every query: 2.5 k VALU instructions per wave, the
+// kernel is VALU-issue bound (profiles/r03_d_pmc_three_nn.txt: 37 us for 8 x 8192 against 8 x 1024).  Here
+//   A. every wave scans ONE 32-candidate step around the rank-proportional start (128 candidates per query group):
+//      every lane gets a 3-deep list; the waves share, per query, the smallest of their third distances -- each is an
+//      upper bound of the query's true third distance;
+//   B. lane = candidate group (64 Morton-consecutive samples, box from dh3d_spatial_sort): the groups whose box lies
+//      within the loosest bound of the query group's box are dealt round-robin to the waves; before a group is scanned
+//      the same test per QUERY (point to box, own bound); steps of phase A are not scanned again.
+// Skipping is exact: the box distance carries a (1 - 1e-5) factor against roundings of a few 1e-7, and '<=' keeps a
+// candidate at exactly the third distance (a smaller index must still be seen).  Same lists, same merge as above.
+__global__ __launch_bounds__(kBlock) void three_nn_pruned_kernel(int n, int m, const float4 *__restrict__ qs,
+                                                                const float *__restrict__ qbox,
+                                                                const float4 *__restrict__ cs,
+                                                                const float *__restrict__ cbox,
+                                                                float *__restrict__ dist, int32_t *__restrict__ idx) {
+  __shared__ __attribute__((aligned(16))) float s_c[kNNChunk * 3];
+  __shared__ int s_k[kNNChunk];
+  __shared__ float s_b[4][64];
+  __shared__ unsigned long long s_mk[3][3][64];  // partial lists of waves 1..3
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = blockIdx.x * 64 + lane;
+  const bool valid = j < n;
+  const float4 q = qs[(size_t)b * n + (valid ? j : blockIdx.x * 64)];
+  const float4 *cand = cs + (size_t)b * m;
+  const f32x2 qx = {q.x, q.x}, qy = {q.y, q.y}, qz = {q.z, q.z};
+  const int len32 = (m + 31) & ~31, nsteps = len32 >> 5;
+  for (int e = threadIdx.x; e < len32; e += kBlock) {
+    float4 r = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(INT_MAX));  // padding: d = inf, never taken
+    if (e < m) r = cand[e];
+    s_c[nn_slot(e, 0)] = r.x; s_c[nn_slot(e, 1)] = r.y; s_c[nn_slot(e, 2)] = r.z;
+    s_k[e] = __float_as_int(r.w);
+  }
+  // boxes: the query group's, and (lane = candidate group) the candidates'
+  const int NGq = (n + 63) / 64, MG = (m + 63) / 64;
+  const float *qb = qbox + ((size_t)b * NGq + blockIdx.x) * 8;
+  const float qlx = qb[0], qly = qb[1], qlz = qb[2], qhx = qb[4], qhy = qb[5], qhz = qb[6];
+  float clx = INFINITY, cly = INFINITY, clz = INFINITY, chx = -INFINITY, chy = -INFINITY, chz = -INFINITY, bd = INFINITY;
+  if (lane < MG) {
+    const float *cb = cbox + ((size_t)b * MG + lane) * 8;
+    clx = cb[0]; cly = cb[1]; clz = cb[2]; chx = cb[4]; chy = cb[5]; chz = cb[6];
+    const float ex = fmaxf(fmaxf(clx - qhx, qlx - chx), 0.f), ey = fmaxf(fmaxf(cly - qhy, qly - chy), 0.f),
+                ez = fmaxf(fmaxf(clz - qhz, qlz - chz), 0.f);
+    bd = (ex * ex + ey * ey + ez * ez) * 0.99999f;
+  }
+  const unsigned long long kInf = (unsigned long long)__float_as_uint(INFINITY) << 32;
+  unsigned long long k1 = kInf, k2 = kInf, k3 = kInf;
+  float kb = INFINITY;  // the screen: min(own third distance, the shared bound)
+  __syncthreads();
+
+  auto scan_step = [&](int step) __attribute__((always_inline)) {
+    const int k = step << 5;
+    f32x2 d[4][4];
+    float mn[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float *g0 = s_c + ((k >> 2) + 2 * u) * 12;
+      const f32x4 a0 = *reinterpret_cast<const f32x4 *>(g0), a1 = *reinterpret_cast<const f32x4 *>(g0 + 4),
+                  a2 = *reinterpret_cast<const f32x4 *>(g0 + 8), b0 = *reinterpret_cast<const f32x4 *>(g0 + 12),
+                  b1 = *reinterpret_cast<const f32x4 *>(g0 + 16), b2 = *reinterpret_cast<const f32x4 *>(g0 + 20);
+      {
+        const f32x2 dx = f32x2{a0[0], a0[1]} - qx, dy = f32x2{a0[2], a0[3]} - qy, dz = f32x2{a1[0], a1[1]} - qz;
+        d[u][0] = (dx * dx + dy * dy) + dz * dz;
+      }
+      {
+        const f32x2 dx = f32x2{a1[2], a1[3]} - qx, dy = f32x2{a2[0], a2[1]} - qy, dz = f32x2{a2[2], a2[3]} - qz;
+        d[u][1] = (dx * dx + dy * dy) + dz * dz;
+      }
+      {
+        const f32x2 dx = f32x2{b0[0], b0[1]} - qx, dy = f32x2{b0[2], b0[3]} - qy, dz = f32x2{b1[0], b1[1]} - qz;
+        d[u][2] = (dx * dx + dy * dy) + dz * dz;
+      }
+      {
+        const f32x2 dx = f32x2{b1[2], b1[3]} - qx, dy = f32x2{b2[0], b2[1]} - qy, dz = f32x2{b2[2], b2[3]} - qz;
+        d[u][3] = (dx * dx + dy * dy) + dz * dz;
+      }
+      mn[u] = fminf(fminf(fminf(d[u][0][0], d[u][0][1]), fminf(d[u][1][0], d[u][1][1])),
+                    fminf(fminf(d[u][2][0], d[u][2][1]), fminf(d[u][3][0], d[u][3][1])));
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      // '<=': an equal distance with a smaller index must still be seen
+      if (__any(valid && mn[u] <= kb)) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const unsigned long long x = ((unsigned long long)__float_as_uint(d[u][t >> 1][t & 1]) << 32) |
+                                       (unsigned)s_k[k + 8 * u + t];
+          const bool l1 = x < k1, l2 = x < k2, l3 = x < k3;
+          k3 = l2 ? k2 : (l3 ? x : k3);
+          k2 = l1 ? k1 : (l2 ? x : k2);
+          k1 = l1 ? x : k1;
+        }
+        kb = fminf(kb, __uint_as_float((unsigned)(k3 >> 32)));
+      }
+    }
+  };
+
+  // A. one step per wave around the rank-proportional start
+  long long c0 = ((long long)blockIdx.x * 64 + 32) * m / n - 64;
+  c0 = c0 < 0 ? 0 : c0;
+  const int s0 = (int)(c0 >> 5);
+  unsigned long long done = 0ull;  // steps of phase A (all four waves')
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int st = (s0 + w) % nsteps;
+    if (!((done >> st) & 1ull)) {
+      done |= 1ull << st;
+      if (w == wave) scan_step(st);
+    }
+  }
+  s_b[wave][lane] = __uint_as_float((unsigned)(k3 >> 32));
+  __syncthreads();
+  kb = fminf(fminf(s_b[0][lane], s_b[1][lane]), fminf(s_b[2][lane], s_b[3][lane]));
+  const float wb = wave_max_f32(valid ? kb : 0.f);
+
+  // B. the candidate groups that can still matter, dealt to the waves
+  unsigned long long mask = __ballot(lane < MG && bd <= wb);
+  int mine = 0;
+  while (mask != 0ull) {
+    const int g = __builtin_ctzll(mask);
+    mask &= mask - 1;
+    if ((mine++ & 3) != wave) continue;
+    const float lx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(clx), g)),
+                ly = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cly), g)),
+                lz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(clz), g)),
+                hx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(chx), g)),
+                hy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(chy), g)),
+                hz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(chz), g));
+    const float px = fmaxf(fmaxf(lx - q.x, q.x - hx), 0.f), py = fmaxf(fmaxf(ly - q.y, q.y - hy), 0.f),
+                pz = fmaxf(fmaxf(lz - q.z, q.z - hz), 0.f);
+    if (!__any(valid && (px * px + py * py + pz * pz) * 0.99999f <= kb)) continue;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int st = 2 * g + h;
+      if (st < nsteps && !((done >> st) & 1ull)) scan_step(st);
+    }
+  }
+
+  if (wave > 0) { s_mk[wave - 1][0][lane] = k1; s_mk[wave - 1][1][lane] = k2; s_mk[wave - 1][2][lane] = k3; }
+  __syncthreads();
+  if (wave == 0 && valid) {
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const unsigned long long x = s_mk[w][t][lane];
+        const bool l1 = x < k1, l2 = x < k2, l3 = x < k3;
+        k3 = l2 ? k2 : (l3 ? x : k3);
+        k2 = l1 ? k1 : (l2 ? x : k2);
+        k1 = l1 ? x : k1;
+      }
+    const size_t o = ((size_t)b * n + __float_as_int(q.w)) * 3;
+    dist[o] = __uint_as_float((unsigned)(k1 >> 32)); dist[o + 1] = __uint_as_float((unsigned)(k2 >> 32));
+    dist[o + 2] = __uint_as_float((unsigned)(k3 >> 32));
+    idx[o] = (int)(unsigned)k1; idx[o + 1] = (int)(unsigned)k2; idx[o + 2] = (int)(unsigned)k3;
+  }
+}
+
 // ------------------------------------------------------------------ three_interpolate
 // IDW: weights derived from squared distances (core/backbones.py:92-95); else read from `weight`.
 template <bool IDW, int VEC>
@@ -399,9 +558,14 @@ DH3D_API int dh3d_three_nn(int b, int n, int m, const float *xyz1, const float *
 DH3D_API int dh3d_three_nn_sorted(int b, int n, int m, const float *sorted1, const float *gbox1,
                                   const float *sorted2, const float *gbox2, float *dist, int32_t *idx,
                                   void *stream) {
-  (void)gbox1; (void)gbox2;  // accepted for symmetry with the other ordered kernels; the scan needs the order only
   DH3D_REQUIRE(sorted1 && sorted2 && dist && idx && b > 0 && n > 0 && m > 0);
   DH3D_SUPPORTED(b <= 65535);
+  if (m <= kNNChunk && m >= 128 && gbox1 && gbox2) {  // the sampled set fits LDS: candidate groups pruned by their boxes
+    hipLaunchKernelGGL(three_nn_pruned_kernel, dim3(dh3d_cdiv(n, 64), b), dim3(kBlock), 0, (hipStream_t)stream, n, m,
+                       reinterpret_cast<const float4 *>(sorted1), gbox1, reinterpret_cast<const float4 *>(sorted2), gbox2,
+                       dist, idx);
+    return dh3d_launch_status();
+  }
   hipLaunchKernelGGL(three_nn_sorted_kernel, dim3(dh3d_cdiv(n, 64), b), dim3(kBlock), 0, (hipStream_t)stream, n, m,
                      reinterpret_cast<const float4 *>(sorted1), reinterpret_cast<const float4 *>(sorted2), dist, idx);
   return dh3d_launch_status();

@@ -30,7 +30,9 @@ for B, N in ((1, 8192), (8, 8192), (32, 4096), (8, 1024), (32, 512)):
             res3.append("s%d %.3f" % (sp, ev(lambda: pm.knn_sorted(srt, gbox, 8))))
         raw.dh3d_dev_set_knn_split(-1)
         print("   knn_sorted by split:", " ".join(res3))
-    print(B, N, "sort %.3f knn_bf %.3f knn_sorted %.3f fps_bf %.3f fps_sorted %.3f three_nn %.3f" % (
+    samp = torch.gather(xyz, 1, pm.fps_sorted(srt, gbox, m).long()[:, :, None].expand(-1, -1, 3)).contiguous()
+    srt2, gbox2 = pm.spatial_sort(samp)
+    print(B, N, "sort %.3f knn_bf %.3f knn_sorted %.3f fps_bf %.3f fps_sorted %.3f three_nn %.3f three_nn_sorted %.3f" % (
         ev(lambda: pm.spatial_sort(xyz)), ev(lambda: pm.knn_xyz(xyz, 8)), ev(lambda: pm.knn_sorted(srt, gbox, 8)),
         ev(lambda: ops.farthest_point_sample(m, xyz)), ev(lambda: pm.fps_sorted(srt, gbox, m)),
-        ev(lambda: ops.three_nn(xyz, xyz[:, :m].contiguous()))))
+        ev(lambda: ops.three_nn(xyz, samp)), ev(lambda: pm.three_nn_sorted(srt, gbox, srt2, gbox2))))
