@@ -135,12 +135,16 @@ class Conv2D1x1(nn.Module):
             p["c_top"] = c_top
             p["wp_top"] = pm.pack_weight(p["W2"][:c_top].contiguous())
             p["wp_bot"] = pm.pack_weight(p["W2"][c_top:].contiguous())
+            if (self.cin - c_top) % 32 == 0:  # full-resolution rows: the tiled bf16x6 GEMM (26.6 -> 19.1 us at 8 x 8192)
+                p["wp3_bot"] = pm.pack_weight_x3(p["W2"][c_top:].contiguous())
         return p.get("c_top") == c_top
 
     def lower_partial(self, x2):
         """x2 @ W[c_top:] (no bias / BN / activation): the part of a commuted concat conv that needs the full-resolution
         input only -- the caller runs it off the critical chain."""
         p = self._prep
+        if "wp3_bot" in p and x2.shape[-2] >= 4096:  # (points per cloud, never the batch: see forward)
+            return pm.linear_x6(x2, p["wp3_bot"], self.cout)
         return pm.linear(x2, p["wp_bot"], self.cout)
 
     def forward_commuted(self, coarse, idx, dist, partial, act=pm.ACT_RELU, residual=None, l2cat=None):
