@@ -569,6 +569,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     ranks_seen = 1
+    if world == 1 and os.environ.get("DH3D_BENCH_RCCL_AT_ONE_RANK") == "1":
+        # dev: the process state of a multi-GPU rank on one GPU -- a 1-rank RCCL communicator (its streams and kernels)
+        # exists and the barriers of the timed region go through it, before anything is measured
+        torch.distributed.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1)
+        one = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(one)
     if world > 1:
         one = torch.ones(1, device=dev)
         torch.distributed.all_reduce(one)  # over RCCL: every rank is alive on its own GPU
