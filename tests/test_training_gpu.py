@@ -602,6 +602,54 @@ def test_trainer_whole_step_graph_matches_eager_steps(dev):
     assert drift <= 5e-3, drift
 
 
+def test_trainer_zero_arena_and_input_buffer(dev, monkeypatch):
+    """(a) The step's accumulators come from ONE zeroed arena (pm.ZeroArena): same gradients as with every accumulator a
+    torch.zeros of its own, and the arena is in use (non-empty, its demand stable from step to step).  (b) A batch
+    written straight into the replayed step's input buffer (QuadrupletTrainer.input_buffer) gives the step it gives
+    when passed as a tensor of its own (which is copied into that buffer)."""
+    from dh3d_amd import pm
+    from dh3d_amd.training import QuadrupletTrainer
+    batches = [torch.rand(7, 4096, 3, generator=torch.Generator().manual_seed(s)).to(dev) for s in (41, 42)]
+    grads = []
+    for arena in (True, False):
+        if not arena:   # every request falls back to torch.zeros
+            monkeypatch.setattr(pm.ZeroArena, "take", lambda self, shape, dtype, device: torch.zeros(shape, dtype=dtype, device=device))
+        m = _build(dev, seed=51, B=1, P=2, Ng=3)
+        tr = QuadrupletTrainer(m, start_lr=1e-3, graph_step=False)
+        tr.keep_grads = True
+        out = []
+        for b in batches:
+            loss = tr.step(b)
+            out.append((loss, [g.clone() for g in tr.last_grads]))
+        if arena:
+            assert tr._zarena.buf is not None and tr._zarena.buf.numel() > 1 << 20 and tr._zarena.off > 0
+            assert tr._zarena.demand == tr._zarena.peak   # the same requests every step
+        grads.append(out)
+    monkeypatch.undo()
+    for (la, ga), (lb, gb) in zip(*grads):
+        assert abs(la - lb) <= 1e-4 * max(1.0, abs(lb)), (la, lb)
+        for x, y in zip(ga, gb):
+            assert float((x - y).abs().max()) <= 5e-3 * float(y.abs().max()) + 1e-6
+    # (b) two graph-replaying trainers on the same trajectory; one is fed through its input buffer
+    losses = []
+    for zero_copy in (True, False):
+        m = _build(dev, seed=61, B=1, P=2, Ng=3)
+        tr = QuadrupletTrainer(m, start_lr=5e-4)
+        ls = [tr.step(batches[0]) for _ in range(4)]          # three eager steps, then the capture
+        assert tr.input_buffer(batches[0].shape) is not None and tr.input_buffer((3, 5, 3)) is None
+        for i in range(4):
+            nxt = batches[(i + 1) % 2]
+            if zero_copy:
+                buf = tr.input_buffer(nxt.shape)
+                buf.copy_(nxt)                                   # the loader's write
+                ls.append(tr.step(buf))
+            else:
+                ls.append(tr.step(nxt))
+        losses.append(ls)
+    for x, y in zip(*losses):
+        assert abs(x - y) <= 2e-2 * max(1.0, abs(y)), losses
+
+
 def test_vlad_normalize_kernels_match_the_tensor_expression(dev):
     """train_ops.vlad_normalize (one launch per direction) == V^T - asum*W2 -> intra-normalise -> flatten -> L2-normalise
     written with tensor ops (core/backbones.py:241-262), values and all three gradients, in float64 on the torch side."""
