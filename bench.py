@@ -701,24 +701,21 @@ def main():
         wl = WORKLOADS[workload]
         per, total = per_rank_batch(args.batch if workload == args.workload and args.batch else wl["B"])
         model = build_model(wl["preset"], dev, seed=0, num_points=wl["N"])
-        model.steps_in_flight = depth  # placement hint of the persistent kernels: that many FPS kernels hold CUs
         pts = synthetic_clouds(per, wl["N"], wl["seed"], dev, rank)
         # (the same streams for every measurement of the process)
         while len(_STREAM_POOL) < depth:
             _STREAM_POOL.append(torch.cuda.Stream(device=dev))
-        streams = _STREAM_POOL[:depth]
         with torch.no_grad():
-            runs = [model.graphed(pts, outputs=(wl["out"],)) for _ in range(depth)]
-            state = {"i": 0}
+            # the package's engine (dh3d_amd/engine.py: model.pipeline): one hipGraph instance + batch buffers + stream
+            # per slot, the persistent kernels' placement hint set for `depth` steps in flight
+            pipe = model.pipeline(pts, depth=depth, outputs=(wl["out"],), streams=_STREAM_POOL[:depth])
+            for k in range(depth):  # a DIFFERENT batch resident in every slot (where a loader's H2D copy would put it)
+                pipe.input_buffer(k).copy_(synthetic_clouds(per, wl["N"], wl["seed"] + 7919 * k, dev, rank))
+            torch.cuda.synchronize()
 
             def step(p):
-                k = state["i"] % depth
-                state["i"] += 1
-                with torch.cuda.stream(streams[k]):
-                    runs[k]()  # each instance's batch is resident in its own input buffer
+                pipe.submit()  # zero-copy: the slot's batch is already in its input buffer
 
-            for st in streams:
-                st.wait_stream(torch.cuda.current_stream())
             nsteps = steps or args.steps
             dt = time_steps(step, pts, nsteps, args.warmup, dev)
             rep = None
@@ -757,8 +754,9 @@ def main():
         "config": {"workload": wl["name"], "clouds_per_gpu": per, "clouds_total": total, "points": wl["N"], "knn": 8,
                    "parallelism": "clouds sharded over %d GPU(s), no data-path collective" % world,
                    "weights": "random-init (no checkpoint blobs exist upstream)",
-                   "execution": ("hipGraph replay; %d steps in flight (one graph instance + batch buffers per stream, every "
-                                 "step one full pass over one batch)" % args.inflight) if pipelined else "hipGraph replay",
+                   "execution": ("dh3d_amd.engine.Pipeline (DH3D.pipeline): hipGraph replay, %d steps in flight -- one graph "
+                                 "instance + its own batch + stream per slot, every step one full pass over one batch"
+                                 % args.inflight) if pipelined else "hipGraph replay",
                    "steps_in_flight": args.inflight if pipelined else 1},
     }
     if in_flight_error:

@@ -33,6 +33,7 @@ class Epilogue(ctypes.Structure):
 # name -> argtypes (restype is int unless listed in _RESTYPES)
 _SIGNATURES = {
     "dh3d_version": [],
+    "dh3d_abi_version": [],
     "dh3d_arch": [],
     "dh3d_status_string": [c_int],
     "dh3d_knn_bruteforce": [c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp],
@@ -197,6 +198,7 @@ _RESTYPES = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+ABI_VERSION = 2  # include/dh3d_hip.h DH3D_ABI_VERSION: the semantics (not just the signatures) this file was written against
 
 
 def lib():
@@ -212,6 +214,10 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the header and the library disagree
             fn.argtypes = argtypes
             fn.restype = _RESTYPES.get(name, c_int)
+        if handle.dh3d_abi_version() != ABI_VERSION:
+            raise RuntimeError("dh3d_amd: %s implements ABI version %d, this binding was written against %d "
+                               "(include/dh3d_hip.h DH3D_ABI_VERSION): rebuild with `make -C dh3d_amd/csrc`"
+                               % (LIB_PATH, handle.dh3d_abi_version(), ABI_VERSION))
         _lib = handle
     return _lib
 

@@ -1,0 +1,137 @@
+"""Steps in flight: `depth` hipGraph instances of the forward on `depth` streams.
+
+One forward of this path leaves most of the chip idle -- farthest point sampling holds ONE CU per cloud for two thirds
+of the step -- so a server that has the next batch ready overlaps consecutive batches: batch i runs on
+slot i % depth while the previous depth-1 batches are still in their latency-bound phases.  The reference has no
+counterpart (a TF session runs one `sess.run` at a time, core/model.py:135-210 builds one graph); every slot computes
+exactly that graph, so a slot's outputs are bit-equal to the serial forward of the same batch
+(tests/test_engine_gpu.py).
+
+    pipe = model.pipeline(example_points, depth=4, outputs=("xyz_feat",))
+    t = pipe.submit(batch)            # copies `batch` into the slot's input buffer and replays the slot's graph
+    ...                               # up to depth-1 further submits before the slot is reused
+    outs = pipe.result(t)             # the CURRENT stream waits for that step; dict of the slot's static buffers
+
+Zero-copy hand-over: write the batch into `pipe.input_buffer(slot)` (e.g. as the destination of the host-to-device
+copy, enqueued on `pipe.stream(slot)` or ordered before the submit) and call `pipe.submit()` without an argument.
+"""
+import torch
+
+
+class Ticket:
+    """One submitted step: the slot it ran on and the event that marks its end."""
+    __slots__ = ("slot", "event", "seq")
+
+    def __init__(self, slot, event, seq):
+        self.slot, self.event, self.seq = slot, event, seq
+
+
+class Pipeline:
+    """`depth` captured forwards of ONE model, each with its own batch buffers and stream.
+
+    The persistent flex_conv kernels are told how many other steps' FPS kernels hold CUs while they run
+    (`steps_in_flight` -> `Geometry.busy_cus_per_xcd` -> `reserve_cus_per_xcd`, a placement hint: speed only, the
+    results do not depend on it -- tests/test_engine_gpu.py::test_flex_conv_x6_reserve_hint_vs_oracle)."""
+
+    def __init__(self, model, example_points, depth=2, outputs=None, example_knn=None, streams=None, warmup=2):
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
+        if streams is not None and len(streams) < depth:
+            raise ValueError("need %d streams, got %d" % (depth, len(streams)))
+        self.model, self.depth, self.outputs = model, int(depth), outputs
+        dev = example_points.device
+        self._streams = list(streams[:depth]) if streams is not None else [torch.cuda.Stream(device=dev) for _ in range(depth)]
+        hint = getattr(model, "steps_in_flight", 1)
+        model.steps_in_flight = self.depth  # read by DH3D._geometry while the slots are captured
+        try:
+            with torch.no_grad():
+                self._runs = [model.graphed(example_points, example_knn, outputs=outputs, warmup=warmup if k == 0 else 1)
+                              for k in range(self.depth)]
+        finally:
+            model.steps_in_flight = hint
+        self._version = getattr(model, "_backbone_version", 0)
+        self._events = [torch.cuda.Event() for _ in range(self.depth)]
+        self._consumed = [None] * self.depth  # event after which slot k's buffers may be overwritten
+        self._seq = 0
+        cur = torch.cuda.current_stream(dev)
+        for st in self._streams:
+            st.wait_stream(cur)
+
+    # ------------------------------------------------------------------ slots
+    def stream(self, slot):
+        return self._streams[slot]
+
+    def input_buffer(self, slot):
+        """The slot's resident batch [Bt, N, 3]: write the next batch here (ordered before submit) for a zero-copy step."""
+        return self._runs[slot].static_input
+
+    def knn_buffer(self, slot):
+        return self._runs[slot].static_knn
+
+    @property
+    def next_slot(self):
+        return self._seq % self.depth
+
+    # ------------------------------------------------------------------ steps
+    def submit(self, points=None, knn_inds=None):
+        """Enqueue one full forward on the next slot.  `points` (optional) is copied into the slot's input buffer on the
+        slot's stream, after the caller's stream has reached this point (so a batch produced on the current stream is
+        complete) and after the previous consumer of this slot's outputs (result()) is done with them."""
+        if getattr(self.model, "_backbone_version", 0) != self._version:
+            raise RuntimeError("the model's weights changed (invalidate / load_state_dict) after this pipeline was "
+                               "captured: build a new one")
+        k = self._seq % self.depth
+        run, st = self._runs[k], self._streams[k]
+        if points is not None or knn_inds is not None:
+            st.wait_stream(torch.cuda.current_stream(run.static_input.device))
+        if self._consumed[k] is not None:
+            st.wait_event(self._consumed[k])
+            self._consumed[k] = None
+        with torch.cuda.stream(st):
+            run(points, knn_inds)
+            self._events[k].record(st)
+        t = Ticket(k, self._events[k], self._seq)
+        self._seq += 1
+        return t
+
+    def result(self, ticket, wait="stream"):
+        """The outputs of a submitted step (the slot's static buffers: valid until `depth` further submits).
+        wait="stream": the current stream waits for the step (no host block); "host": the host does; None: neither."""
+        if self._seq - ticket.seq > self.depth:
+            raise RuntimeError("slot %d has been reused since this step was submitted" % ticket.slot)
+        if wait == "stream":
+            torch.cuda.current_stream().wait_event(ticket.event)
+        elif wait == "host":
+            ticket.event.synchronize()
+        return self._runs[ticket.slot].outputs
+
+    def release(self, ticket):
+        """Mark the current stream's position as the end of the consumer's reads of this step's outputs (call after
+        the kernels that read them were enqueued): the slot's next step waits for it."""
+        ev = torch.cuda.Event()
+        ev.record()
+        self._consumed[ticket.slot] = ev
+
+    def drain(self):
+        """The current stream waits for every slot (the host does not)."""
+        cur = torch.cuda.current_stream()
+        for st in self._streams:
+            cur.wait_stream(st)
+
+    def map(self, batches, clone=True):
+        """Run an iterable of batches `depth` deep and yield their output dicts in order (cloned by default: a slot's
+        buffers are overwritten `depth` steps later)."""
+        tickets = []
+        for b in batches:
+            if len(tickets) == self.depth:
+                yield self._take(tickets.pop(0), clone)
+            tickets.append(self.submit(b))
+        while tickets:
+            yield self._take(tickets.pop(0), clone)
+
+    def _take(self, ticket, clone):
+        outs = self.result(ticket, wait="stream")
+        if clone:
+            outs = {k: v.clone() for k, v in outs.items()}
+        self.release(ticket)
+        return outs

@@ -367,9 +367,11 @@ class DH3D(nn.Module):
             _, xyz_feat = self.compute_local(points, _geo=geo, _l2cat_eps=1e-8)
             outs["xyz_feat"] = xyz_feat
             outs["feat_l2normed"] = xyz_feat[:, :, 3:]
+            self._level_ids(geo, outs, fetch)
             return outs
         newpoints, localdesc = self.compute_local(points, _geo=geo)
         outs["feat"] = localdesc
+        self._level_ids(geo, outs, fetch)
         xyz_feat = None
         if want("xyz_feat", "feat_l2normed", "xyz_feat_att"):
             xyz_feat = pm.l2norm_concat(localdesc, 1e-8, prefix=newpoints)  # l2_normalize(dim=2, eps=1e-8) + concat
@@ -386,7 +388,24 @@ class DH3D(nn.Module):
             del outs["_geo"]
         return outs
 
+    @staticmethod
+    def _level_ids(geo, outs, fetch):
+        """The integer results of the shared N/8 level (FPS picks, sampled-set kNN ids, three_nn ids) as named outputs
+        -- only on request: the parity tests of graph replays / steps in flight compare them bit for bit."""
+        lv = getattr(geo, "_lv", None)
+        if lv is None or fetch is None:
+            return
+        for name, key in (("fps_inds", "idx"), ("sampled_knn_inds", "nbr_s"), ("nn3_inds", "nn3_idx")):
+            if key in lv and name in fetch:
+                outs[name] = lv[key]
+
     # ------------------------------------------------------------------ hipGraph replay
+    def pipeline(self, example_points, depth=2, outputs=None, example_knn=None, streams=None):
+        """`depth` forwards in flight: one hipGraph instance + batch buffers + stream per slot (dh3d_amd/engine.py).
+        Returns an engine.Pipeline: submit(batch) -> ticket, result(ticket) -> outputs, map(batches)."""
+        from .engine import Pipeline
+        return Pipeline(self, example_points, depth=depth, outputs=outputs, example_knn=example_knn, streams=streams)
+
     def graphed(self, example_points, example_knn=None, outputs=None, warmup=2):
         """Capture forward() for inputs shaped like `example_points` into a hipGraph.
 
@@ -420,6 +439,7 @@ class DH3D(nn.Module):
             return outs
 
         run.graph = graph
+        run.outputs = outs
         run.static_input = static_in
         run.static_knn = static_knn
         return run

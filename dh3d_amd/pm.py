@@ -652,16 +652,28 @@ class ZeroArena(object):
     targets: include/dh3d_hip.h "zeroed by the CALLER").  `begin()` clears it with ONE fill and rewinds; `zeros()` below
     hands out views while the arena is active (`with pm.zero_arena(a): ...`) and falls back to torch.zeros otherwise or
     when the arena is too small -- the demand of a step is recorded, the next `begin()` outside a graph capture grows
-    the buffer to it.  Views are only valid until the next `begin()`: nothing that outlives a step (the loss, the
-    parameter gradients) is taken from here."""
+    the buffer to it.  Views are only valid until the next `begin()`.  Two kinds of tensors that leave a step DO come
+    from here and inherit that lifetime: the loss never does, but the parameter gradients of split-reduction GEMMs
+    (`gemm_tn` / `gemm_nn` below: dW of the attention head and of NetVLAD's assignment) are arena views -- `p.grad` is
+    valid until the next step begins, which is what an optimiser step needs; code that keeps gradients across steps
+    (gradient accumulation, inspection) must clone them (QuadrupletTrainer.keep_grads does).
 
-    def __init__(self):
+    A buffer is never freed or replaced while a captured hipGraph may still replay into it: an arena built with
+    `fixed_bytes` (one per captured step graph, owned by that graph's entry) never reallocates -- `take()` falls back
+    to torch.zeros (inside a capture: the graph's own pool) when it is too small; only the growing arena of the eager
+    steps reallocates, and no graph records its address."""
+
+    def __init__(self, fixed_bytes=None, device=None):
         self.buf, self.off, self.demand, self.peak = None, 0, 0, 0
+        self.fixed = fixed_bytes is not None
+        if self.fixed and fixed_bytes > 0:
+            self.buf = torch.empty((int(fixed_bytes),), dtype=torch.uint8, device=device)
 
     def begin(self, device):
         self.peak = max(self.peak, self.demand)
         capturing = torch.cuda.is_current_stream_capturing() if torch.cuda.is_available() else False
-        if self.peak and not capturing and (self.buf is None or self.buf.numel() < self.peak or self.buf.device != device):
+        if (not self.fixed and self.peak and not capturing
+                and (self.buf is None or self.buf.numel() < self.peak or self.buf.device != device)):
             self.buf = torch.empty((self.peak,), dtype=torch.uint8, device=device)
         if self.buf is not None:
             self.buf.zero_()

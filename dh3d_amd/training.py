@@ -407,6 +407,7 @@ class QuadrupletTrainer(object):
         self._sched = (float(start_lr), int(decay_step), float(decay_rate))
         self._steps_done = 0
         self._step_graphs = {}
+        self._shape_demand = {}  # batch shape -> accumulator bytes one step of it takes from the ZeroArena
         self._eager_seen = {}   # batch shape -> eager steps run on it (every shape warms up before its capture)
         self.keep_desc, self.last_desc = False, None
         if self.graph_step:
@@ -569,15 +570,20 @@ class QuadrupletTrainer(object):
         key = (tuple(points.shape), points.device, getattr(self.model, "_backbone_version", 0))
         ent = self._step_graphs.get(key)
         if ent is None:
-            self._step_graphs.clear()
+            for k in [k for k in self._step_graphs if k[2] != key[2]]:  # graphs of an older backbone are stale
+                del self._step_graphs[k]
             static_in = points.clone()
+            # the graph's OWN accumulator arena, sized by this shape's eager steps and never reallocated: the eager
+            # arena grows (and frees its old buffer) whenever a larger shape comes along, and a graph replaying into a
+            # freed buffer would corrupt whatever owns that memory by then
+            arena = pm.ZeroArena(fixed_bytes=self._shape_demand.get(key[:2], self._zarena.peak), device=points.device)
             self.opt.zero_grad(set_to_none=True)
             if D.collectives_active():
                 self._ensure_arena()
             graph = torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(graph), pm.zero_arena(self._zarena):
-                    self._zarena.begin(static_in.device)   # ONE fill for every accumulator of the step
+                with torch.cuda.graph(graph), pm.zero_arena(arena):
+                    arena.begin(static_in.device)   # ONE fill for every accumulator of the step
                     loss = self.forward_loss(static_in)
                     loss.backward()
                     if self.wd_params and self.weight_decay and (not D.collectives_active() or dist.get_rank() == 0):
@@ -588,15 +594,23 @@ class QuadrupletTrainer(object):
                     if D.collectives_active():
                         self._reduce_gradients()
                     self.opt.step()
-            except RuntimeError:
+            except RuntimeError as e:
                 # something in this shape's step cannot be captured: stay eager for good (the parameters are untouched --
-                # a capture records, it does not run)
+                # a capture records, it does not run) -- and say so.  In a sharded run the ranks must not diverge (one
+                # replaying captured collectives, one issuing them eagerly), and a capture that died inside a
+                # collective leaves the communicator undefined: that is an error, not a fallback.
+                if D.collectives_active():
+                    raise
+                import warnings
+                warnings.warn("dh3d_amd: the training step for batches of shape %s could not be captured into a "
+                              "hipGraph (%s: %s); continuing with eager steps" % (tuple(points.shape), type(e).__name__, e),
+                              RuntimeWarning)
                 self.graph_step = False
                 self.opt.zero_grad(set_to_none=True)
                 return None
-            ent = (graph, static_in, loss)
+            ent = (graph, static_in, loss, arena)
             self._step_graphs[key] = ent
-        graph, static_in, loss = ent
+        graph, static_in, loss = ent[:3]
         # (each of these two is a launch of its own in front of the replay -- ~10 us of queue latency apiece: skipped
         # when the batch already sits in the step's input buffer (`input_buffer`) / the rate has not changed)
         if points.data_ptr() != static_in.data_ptr():
@@ -632,6 +646,7 @@ class QuadrupletTrainer(object):
             loss = self.forward_loss(points)
             self._mark(2)
             loss.backward()
+        self._shape_demand[shape] = max(self._shape_demand.get(shape, 0), self._zarena.demand)
         # L2 weight decay on '.*/W' (regularize_cost, core/model.py:239-243): d/dp [wd/2 * sum p^2] = wd * p, added to the
         # gradients directly (one multi-tensor launch) by rank 0 only -- the SUM all-reduce below then counts it once
         if self.wd_params and self.weight_decay and (not dist.is_initialized() or dist.get_rank() == 0):

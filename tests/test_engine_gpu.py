@@ -1,0 +1,160 @@
+"""GPU: the steps-in-flight engine (dh3d_amd/engine.py) -- the mode bench.py's `value` is measured in.
+
+  * every slot of a depth-4 pipeline at the BASELINE shape (B=8, N=8192), each with its OWN batch, against the serial
+    forward of the same batch: kNN / FPS / sampled-set kNN / three_nn ids and the descriptors bit-equal; one cloud per
+    slot against the CPU oracle (oracle/model_np.py) within 1e-4;
+  * the persistent flex_conv's placement hint (`reserve_cus_per_xcd`, the only thing a step in flight changes inside
+    a kernel) at every value the engine can produce, against the oracle on a row sample and bit-equal to hint 0;
+  * the global path two deep.
+"""
+import numpy as np
+import pytest
+import torch
+
+from test_parity_fullsize_gpu import _build, _weights_np
+
+pytestmark = pytest.mark.gpu
+
+IDS = ("knn_inds", "fps_inds", "sampled_knn_inds", "nn3_inds")
+
+
+def _batches(n, B, N, seed, dev):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        p = rng.random((B, N, 3), dtype=np.float32)
+        if i % 3 == 2:
+            p = p * 40 - 20  # Oxford-like extent
+        out.append(torch.from_numpy(p).to(dev))
+    return out
+
+
+def test_local_pipeline_depth4_B8_N8192_slots_equal_serial_and_oracle(dev):
+    from oracle import model_np
+    m = _build("basic_config", dev, seed=41)
+    B, N, depth = 8, 8192, 4
+    fetch = ("xyz_feat",) + IDS
+    batches = _batches(2 * depth + 1, B, N, 4100, dev)  # every slot used twice (+1: the ring wraps unevenly)
+    with torch.no_grad():
+        serial = []
+        for b in batches:
+            o = m(b, fetch=fetch)
+            serial.append({k: o[k].clone() for k in fetch})
+        pipe = m.pipeline(batches[0], depth=depth, outputs=fetch)
+        assert pipe.depth == depth and len({pipe.input_buffer(k).data_ptr() for k in range(depth)}) == depth
+        got = list(pipe.map(batches))
+    torch.cuda.synchronize()
+    assert len(got) == len(batches)
+    for i, (g, s) in enumerate(zip(got, serial)):
+        for k in IDS:
+            assert torch.equal(g[k], s[k]), (i, k)
+        assert torch.equal(g["xyz_feat"], s["xyz_feat"]), (i, "xyz_feat", (g["xyz_feat"] - s["xyz_feat"]).abs().max().item())
+    # one cloud per slot against the oracle (a single 8192-point cloud takes the C restatement ~2 s)
+    w = _weights_np(m)
+    for slot in range(depth):
+        i, c = slot, (3 * slot + 1) % B
+        pts = batches[i][c:c + 1].cpu().numpy()
+        trace = {}
+        exp = model_np.forward(pts, w, detection=False, extract_global=False, trace=trace)
+        g = got[i]
+        assert np.array_equal(g["knn_inds"][c:c + 1].cpu().numpy(), exp["knn_indices"].transpose(0, 2, 1))
+        assert np.array_equal(g["fps_inds"][c:c + 1].cpu().numpy(), trace["stage2/fps_idx"])
+        assert np.array_equal(g["sampled_knn_inds"][c:c + 1].cpu().numpy(), trace["stage2/knn"].transpose(0, 2, 1))
+        assert np.array_equal(g["nn3_inds"][c:c + 1].cpu().numpy(), trace["stage2/nn3_idx"])
+        err = float(np.abs(g["xyz_feat"][c:c + 1].cpu().numpy() - exp["xyz_feat"]).max())
+        assert err < 1e-4, (slot, err)
+
+
+def test_pipeline_submit_result_zero_copy_and_slot_reuse_guard(dev):
+    m = _build("basic_config", dev, seed=42)
+    B, N, depth = 2, 4096, 2
+    batches = _batches(4, B, N, 4200, dev)
+    with torch.no_grad():
+        serial = [m(b, fetch=("xyz_feat",))["xyz_feat"].clone() for b in batches]
+        pipe = m.pipeline(batches[0], depth=depth, outputs=("xyz_feat",))
+        # zero-copy: the batch is written into the slot's buffer on the slot's stream, submit() takes no argument
+        tickets, outs = [], []
+        for i, b in enumerate(batches):
+            k = pipe.next_slot
+            if i >= depth:  # the slot's previous result must be consumed before its buffers are overwritten
+                o = pipe.result(tickets[i - depth])
+                outs.append(o["xyz_feat"].clone())
+                pipe.release(tickets[i - depth])
+            with torch.cuda.stream(pipe.stream(k)):
+                pipe.input_buffer(k).copy_(b, non_blocking=True)
+            tickets.append(pipe.submit())
+        with pytest.raises(RuntimeError):
+            pipe.result(tickets[0])  # reused since
+        for t in tickets[-depth:]:
+            outs.append(pipe.result(t, wait="host")["xyz_feat"].clone())
+    torch.cuda.synchronize()
+    for i in range(len(batches)):
+        assert torch.equal(outs[i], serial[i]), i
+    m.invalidate()
+    m.prepare()
+    with pytest.raises(RuntimeError):
+        pipe.submit()
+
+
+@pytest.mark.parametrize("Din", [32, 64])
+def test_flex_conv_x6_reserve_hint_vs_oracle(dev, oracle, Din):
+    """B=8 x N=8192, K=8, reserve_cus_per_xcd in {0, 1, 3, 4, 8}: a different tile -> workgroup assignment each, the same
+    bits out; rows sampled against the oracle's reference formulation (the full launch is 19 GF of scalar C)."""
+    from dh3d_amd import pm
+    g = torch.Generator().manual_seed(100 + Din)
+    B, N, K, Dout = 8, 8192, 8, 64
+    xyz = torch.rand(B, N, 3, generator=g).to(dev)
+    nbr, _ = pm.knn_xyz(xyz, K)
+    f = torch.randn(B, N, Din, generator=g).to(dev)
+    theta = (torch.randn(3, Din, Dout, generator=g) / Din ** 0.5).to(dev)
+    bias = (torch.randn(Din, Dout, generator=g) / (8 * Din) ** 0.5).to(dev)
+    wp3 = pm.pack_flex_weight_x3(theta, bias)
+    base = pm.flex_conv_x6(f, xyz, nbr, wp3, Dout, reserve_cus_per_xcd=0)
+    outs = {0: base}
+    for r in (1, 3, 4, 8, 31):
+        outs[r] = pm.flex_conv_x6(f, xyz, nbr, wp3, Dout, reserve_cus_per_xcd=r)
+        assert torch.equal(outs[r], base), r
+    torch.cuda.synchronize()
+    # the oracle on every 61st row of every cloud (first and last rows included): the sampled rows' neighbourhoods
+    # gathered into a compact cloud of R*K points, row r*K = query r with itself as rank-0 neighbour
+    rows = np.unique(np.concatenate([np.arange(0, N, 61), [N - 1]]))
+    R = len(rows)
+    th, bi = theta.cpu().numpy(), bias.cpu().numpy()
+    for b in range(B):
+        nb = nbr[b].cpu().numpy()[rows]
+        assert np.array_equal(nb[:, 0], rows)
+        ids = nb.reshape(-1)
+        sub_f = np.ascontiguousarray(f[b].cpu().numpy()[ids].T[None])
+        sub_p = np.ascontiguousarray(xyz[b].cpu().numpy()[ids].T[None])
+        sub_nb = np.zeros((1, K, R * K), np.int32)
+        sub_nb[0, :, ::K] = (np.arange(R)[None, :] * K + np.arange(K)[:, None])
+        exp = oracle.flex_convolution(sub_f, sub_p, sub_nb, th, bi, center_self=True)[0][:, ::K].T  # [R, Dout]
+        for r in (0, 4, 8):
+            got = outs[r][b].cpu().numpy()[rows]
+            assert np.abs(got - exp).max() <= 2e-6 * np.abs(exp).max() + 1e-4 * np.abs(exp).mean(), (b, r)
+
+
+def test_global_pipeline_depth2_B32_N4096_slots_equal_serial_and_oracle(dev):
+    from oracle import model_np
+    m = _build("global_config", dev, seed=43)
+    B, N, depth = 32, 4096, 2
+    fetch = ("globaldesc",) + IDS
+    batches = _batches(2 * depth + 1, B, N, 4300, dev)
+    with torch.no_grad():
+        serial = []
+        for b in batches:
+            o = m(b, fetch=fetch)
+            serial.append({k: o[k].clone() for k in fetch})
+        pipe = m.pipeline(batches[0], depth=depth, outputs=fetch)
+        got = list(pipe.map(batches))
+    torch.cuda.synchronize()
+    for i, (g, s) in enumerate(zip(got, serial)):
+        for k in IDS + ("globaldesc",):
+            assert torch.equal(g[k], s[k]), (i, k)
+    w = _weights_np(m)
+    for slot in range(depth):
+        i, c = slot + depth, (7 * slot + 3) % B
+        pts = batches[i][c:c + 1].cpu().numpy()
+        exp = model_np.forward(pts, w, detection=False, extract_global=True)
+        err = float(np.abs(got[i]["globaldesc"][c:c + 1].cpu().numpy() - exp["globaldesc"]).max())
+        assert err < 1e-4, (slot, err)

@@ -650,6 +650,38 @@ def test_trainer_zero_arena_and_input_buffer(dev, monkeypatch):
         assert abs(x - y) <= 2e-2 * max(1.0, abs(y)), losses
 
 
+def test_trainer_graphs_of_two_shapes_keep_their_own_arenas(dev):
+    """A small batch shape is captured, then a LARGER one runs its eager warm-up (the eager accumulator arena grows
+    and frees its old buffer) and is captured too; steps on the two shapes then alternate.  Every captured graph owns
+    a fixed arena (pm.ZeroArena(fixed_bytes=...)), so the small shape's replays never touch freed memory, both
+    graphs stay alive (no re-capture per switch), and the trajectory follows an eager trainer's."""
+    from dh3d_amd.training import QuadrupletTrainer
+    small = [torch.rand(7, 1024, 3, generator=torch.Generator().manual_seed(s)).to(dev) for s in (71, 72)]
+    large = [torch.rand(7, 4096, 3, generator=torch.Generator().manual_seed(s)).to(dev) for s in (73, 74)]
+    order = [small[0]] * 4 + [large[0]] * 4 + [small[1], large[1], small[0], large[0], small[1], large[1]]
+    traj = []
+    for graph in (True, False):
+        m = _build(dev, seed=81, B=1, P=2, Ng=3)
+        tr = QuadrupletTrainer(m, start_lr=5e-4, graph_step=graph, graph_backbone=graph)
+        ls = []
+        for i, b in enumerate(order):
+            ls.append(tr.step(b))
+            if graph and i >= 8:
+                # scribble over whatever the caching allocator hands out now: a replay into a freed arena would
+                # accumulate onto this instead of onto zeros
+                junk = torch.full((1 << 22,), 1e30, device=dev)
+                del junk
+        traj.append((ls, tr))
+    (la, tra), (lb, _) = traj
+    assert len(tra._step_graphs) == 2, list(tra._step_graphs)
+    arenas = [ent[3] for ent in tra._step_graphs.values()]
+    assert all(a.fixed and a.buf is not None for a in arenas)
+    assert arenas[0].buf.data_ptr() != arenas[1].buf.data_ptr()
+    assert all(np.isfinite(la)) and all(np.isfinite(lb))
+    for x, y in zip(la, lb):
+        assert abs(x - y) <= 2e-2 * max(1.0, abs(y)), (la, lb)
+
+
 def test_vlad_normalize_kernels_match_the_tensor_expression(dev):
     """train_ops.vlad_normalize (one launch per direction) == V^T - asum*W2 -> intra-normalise -> flatten -> L2-normalise
     written with tensor ops (core/backbones.py:241-262), values and all three gradients, in float64 on the torch side."""
