@@ -149,8 +149,11 @@ def test_global_pipeline_depth2_B32_N4096_slots_equal_serial_and_oracle(dev):
         got = list(pipe.map(batches))
     torch.cuda.synchronize()
     for i, (g, s) in enumerate(zip(got, serial)):
-        for k in IDS + ("globaldesc",):
+        for k in IDS:
             assert torch.equal(g[k], s[k]), (i, k)
+        # (the global tail sums A'^T c and the split-K projection with f32 atomics: run-to-run rounding, not bit-equal)
+        d = float((g["globaldesc"] - s["globaldesc"]).abs().max())
+        assert d <= 2e-6, (i, d)
     w = _weights_np(m)
     for slot in range(depth):
         i, c = slot + depth, (7 * slot + 3) % B
