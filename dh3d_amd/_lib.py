@@ -159,6 +159,8 @@ _SIGNATURES = {
     "dh3d_flex_avg_pm_fwd": [c_fp, c_fp, c_int, c_int, c_int, c_int, c_float, c_fp, c_fp],
     "dh3d_conv_pointset_pm_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, ctypes.POINTER(Epilogue),
                                   c_fp, c_fp],
+    "dh3d_conv_pointset_pool_pm_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, ctypes.POINTER(Epilogue),
+                                       c_fp, c_fp, c_fp],
     "dh3d_linear_pm_fwd": [c_fp, c_int, c_fp, c_int, c_fp, c_int, c_int, ctypes.POINTER(Epilogue), c_fp, c_fp,
                            c_fp],
     "dh3d_se_res_pm_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp],

@@ -369,6 +369,71 @@ __global__ __launch_bounds__(256) void conv_pointset_pm_anyk_kernel(
   }
 }
 
+// ------------------------------------------------------------------ conv_pointset on coordinates + flex_pool, fused
+// The first two operators of the backbone (core/backbones.py:107-110: conv_pointset 3 -> 32, BNReLU, flex_pool) without
+// the [B, N, Dout] map in between.  conv_pointset on coordinates is linear in ONE 3-vector per point,
+//   S[j] = sum_k (p[nbr[j,k]] - p[nbr[j,0]]),      conv[j, o] = theta[:, o] . S[j] + bias[o]
+// (conv_pointset_kernel.cc:46-64 with Din = 3), so the pooled value  max_k act(bn(conv[nbr[n,k], o]))  needs the eight
+// neighbours' S vectors (16 bytes each), not their Dout-wide rows:
+//   pass 1 (pointset_sum_kernel):  S[j] for every point, one lane per point, [R, 4] floats (1 MB at 8 x 8192);
+//   pass 2 (pointset_pool_kernel): Dout/4 lanes per point: the K ids once, K float4 gathers of S, 3 fma + epilogue per
+//           (neighbour, channel), running max, one 16-byte store per lane (a row = one 128-byte line at Dout = 32).
+// Against the two separate kernels: the 8.4 MB map is neither written nor gathered (8 x 128 bytes per point through
+// the L2), and the conv is evaluated with Dout/4 lanes per point (the separate kernel: one lane per point, one wave
+// per SIMD on the whole chip).  Values: theta . (sum of differences) instead of the per-neighbour fma chain of
+// conv_pointset_pm_kernel -- the same sum associated differently (~1e-7 relative), both within the reference's 1e-4.
+__global__ __launch_bounds__(256) void pointset_sum_kernel(const float *__restrict__ xyz,
+                                                          const int32_t *__restrict__ nbr, long long R, int N,
+                                                          float4 *__restrict__ S) {
+  const long long n = (long long)dh3d_xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+  if (n >= R) return;
+  const long long cloud0 = (n / N) * N;
+  const int4 a = *reinterpret_cast<const int4 *>(nbr + n * 8), b = *reinterpret_cast<const int4 *>(nbr + n * 8 + 4);
+  const int id[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  float px[8], py[8], pz[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float *q = xyz + (cloud0 + id[k]) * 3;
+    px[k] = q[0]; py[k] = q[1]; pz[k] = q[2];
+  }
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { sx += px[k] - px[0]; sy += py[k] - py[0]; sz += pz[k] - pz[0]; }
+  S[n] = make_float4(sx, sy, sz, 0.f);
+}
+
+__global__ __launch_bounds__(256) void pointset_pool_kernel(const float4 *__restrict__ S, const int32_t *__restrict__ nbr,
+                                                           const float *__restrict__ theta, const float *__restrict__ bias,
+                                                           long long R, int N, int Dout, EpilogueArgs ep,
+                                                           float *__restrict__ out) {
+  const int cv = Dout / 4;
+  const long long e = (long long)dh3d_xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+  if (e >= R * cv) return;
+  const long long n = e / cv;
+  const int c4 = (int)(e - n * cv) * 4;
+  const long long cloud0 = (n / N) * N;
+  const int4 a = *reinterpret_cast<const int4 *>(nbr + n * 8), b = *reinterpret_cast<const int4 *>(nbr + n * 8 + 4);
+  const int id[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  float4 s[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s[k] = S[cloud0 + id[k]];
+  const float4 tx = *reinterpret_cast<const float4 *>(theta + c4);
+  const float4 ty = *reinterpret_cast<const float4 *>(theta + Dout + c4);
+  const float4 tz = *reinterpret_cast<const float4 *>(theta + 2 * Dout + c4);
+  const float4 bq = *reinterpret_cast<const float4 *>(bias + c4);
+  float4 best = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float4 v;
+    v.x = dh3d_epilogue_apply(fmaf(tz.x, s[k].z, fmaf(ty.x, s[k].y, tx.x * s[k].x)) + bq.x, c4, ep);
+    v.y = dh3d_epilogue_apply(fmaf(tz.y, s[k].z, fmaf(ty.y, s[k].y, tx.y * s[k].x)) + bq.y, c4 + 1, ep);
+    v.z = dh3d_epilogue_apply(fmaf(tz.z, s[k].z, fmaf(ty.z, s[k].y, tx.z * s[k].x)) + bq.z, c4 + 2, ep);
+    v.w = dh3d_epilogue_apply(fmaf(tz.w, s[k].z, fmaf(ty.w, s[k].y, tx.w * s[k].x)) + bq.w, c4 + 3, ep);
+    best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y); best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
+  }
+  *reinterpret_cast<float4 *>(out + n * Dout + c4) = best;
+}
+
 inline int flat_grid(long long total) {
   long long g = (total + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
@@ -438,6 +503,20 @@ DH3D_API int dh3d_conv_pointset_pm_fwd(const float *xyz, const int32_t *nbr, con
     hipLaunchKernelGGL(conv_pointset_pm_anyk_kernel, dim3(flat_grid(R * (Dout / 4))), dim3(256), 0,
                        (hipStream_t)stream, xyz, nbr, theta, bias, R, N, K, Dout, dh3d_ep(ep), out);
   }
+  return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_conv_pointset_pool_pm_fwd(const float *xyz, const int32_t *nbr, const float *theta, const float *bias,
+                                            int B, int N, int K, int Dout, const dh3d_epilogue *ep, float *scratch,
+                                            float *out, void *stream) {
+  DH3D_REQUIRE(xyz && nbr && theta && bias && scratch && out && B > 0 && N > 0 && Dout > 0);
+  DH3D_SUPPORTED(K == 8 && Dout % 4 == 0);
+  const long long R = (long long)B * N;
+  hipStream_t s = (hipStream_t)stream;
+  float4 *S = reinterpret_cast<float4 *>(scratch);
+  hipLaunchKernelGGL(pointset_sum_kernel, dim3(dh3d_cdiv(R, 256)), dim3(256), 0, s, xyz, nbr, R, N, S);
+  hipLaunchKernelGGL(pointset_pool_kernel, dim3(dh3d_cdiv(R * (Dout / 4), 256)), dim3(256), 0, s, S, nbr, theta, bias, R, N,
+                     Dout, dh3d_ep(ep), out);
   return dh3d_launch_status();
 }
 

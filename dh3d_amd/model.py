@@ -255,9 +255,9 @@ class DH3D(nn.Module):
         p = self._local._prep
         with torch.cuda.stream(geo._side):  # behind kNN(N), beside the FPS chain
             nn_8 = geo.nbr if geo.nbr.shape[2] == 8 else geo.nbr[:, :, 0:8].contiguous()
-            init = pm.conv_pointset_xyz(geo.xyz, nn_8, p["theta"], p["bias"], scale=p["scale"], shift=p["shift"],
-                                        act=pm.ACT_RELU)
-            init = pm.flex_pool(init, nn_8)
+            # conv_pointset 3 -> 32, BNReLU, flex_pool (backbones.py:107-110) fused: the map between them is not built
+            init = pm.conv_pointset_pool_xyz(geo.xyz, nn_8, p["theta"], p["bias"], scale=p["scale"], shift=p["shift"],
+                                             act=pm.ACT_RELU)
             r = self.stage1(geo, init, nbr=nn_8, post_conv=self.before_stage2_conv1d)
             x1, x2 = r if isinstance(r, tuple) else (r, self.before_stage2_conv1d(r, act=pm.ACT_RELU))
             # BNReLU(conv(x1)) + stage2 (backbones.py:123).  Large clouds: the shortcut conv runs INSIDE stage 2's last

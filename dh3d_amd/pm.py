@@ -194,6 +194,21 @@ def conv_pointset_xyz(xyz, nbr, theta, bias, pre_bias=None, scale=None, shift=No
     return out
 
 
+def conv_pointset_pool_xyz(xyz, nbr, theta, bias, pre_bias=None, scale=None, shift=None, act=ACT_NONE):
+    """flex_pool(epilogue(conv_pointset(xyz))) over the same neighbourhoods [B,N,8] in two small launches; the
+    [B,N,Dout] map between the two operators is not materialised (core/backbones.py:107-110)."""
+    x = L.require_cuda_f32(xyz, "xyz", 3)
+    nb = L.require_cuda_i32(nbr, "nbr", 3)
+    B, N, _ = x.shape
+    Dout = theta.shape[1]
+    out = torch.empty((B, N, Dout), dtype=torch.float32, device=x.device)
+    scratch = torch.empty((B, N, 4), dtype=torch.float32, device=x.device)
+    ep = _ep(pre_bias, scale, shift, act)
+    L.check(L.lib().dh3d_conv_pointset_pool_pm_fwd(L.ptr(x), L.ptr(nb), L.ptr(theta), L.ptr(bias), B, N, nb.shape[2], Dout,
+                                                   ep, L.ptr(scratch), L.ptr(out), L.stream_ptr()), "conv_pointset_pool_pm")
+    return out
+
+
 def linear(x1, wpacked, Dout, x2=None, pre_bias=None, scale=None, shift=None, act=ACT_NONE, residual=None):
     """out = epilogue([x1 | x2] @ W) (+ residual); x* are [..., C] with identical leading dims."""
     a = L.require_cuda_f32(x1, "x1")

@@ -167,6 +167,33 @@ def test_conv_pointset_pm_vs_oracle(dev, oracle):
     assert close(out, exp, 1e-4, 1e-5)
 
 
+@pytest.mark.parametrize("B,N,scale", [(2, 1234, 1.0), (3, 8192, 40.0), (1, 64, 1.0)])
+def test_conv_pointset_pool_fused_vs_oracle(dev, oracle, B, N, scale):
+    """conv_pointset 3 -> 32 + BatchNorm (negative scales included: max and BN do not commute) + ReLU + flex_pool in the
+    fused two-launch form against the oracle's two operators (conv_pointset_kernel.cc:46-64, flex_pool_kernel.cc:41-57),
+    and against the two separate HIP kernels; duplicated points (rank-0 neighbour not the point itself) included."""
+    from dh3d_amd import pm
+    rng = np.random.default_rng(B * 1000 + N)
+    xyz = (rng.random((B, N, 3), dtype=np.float32) * scale - scale / 2).astype(np.float32)
+    xyz[:, N // 2] = xyz[:, N // 3]  # an exact duplicate in every cloud
+    nn, _ = oracle.knn_bruteforce(np.ascontiguousarray(xyz.transpose(0, 2, 1)), 8)
+    theta = (rng.standard_normal((3, 32)) * 4 / scale).astype(np.float32)
+    bias = rng.standard_normal(32).astype(np.float32)
+    sc = rng.standard_normal(32).astype(np.float32)  # both signs
+    sh = (0.5 * rng.standard_normal(32)).astype(np.float32)
+    conv = oracle.convolution_pointset(xyz.transpose(0, 2, 1), nn.transpose(0, 2, 1), theta, bias)       # [B,32,N]
+    act = np.maximum(conv * sc[None, :, None] + sh[None, :, None], 0).astype(np.float32)
+    exp, _ = oracle.flex_pooling(act, np.ascontiguousarray(nn.transpose(0, 2, 1)))
+    exp = exp.transpose(0, 2, 1)
+    args = (T(xyz, dev), T(nn, dev), T(theta, dev), T(bias, dev))
+    kw = dict(scale=T(sc, dev), shift=T(sh, dev), act=pm.ACT_RELU)
+    got = pm.conv_pointset_pool_xyz(*args, **kw).cpu().numpy()
+    tol = 1e-5 * np.abs(conv).max()
+    assert np.abs(got - exp).max() <= tol + 1e-4 * np.abs(exp).max(), np.abs(got - exp).max()
+    two = pm.flex_pool(pm.conv_pointset_xyz(*args, **kw), T(nn, dev)).cpu().numpy()
+    assert np.abs(got - two).max() <= tol, np.abs(got - two).max()
+
+
 @pytest.mark.parametrize("C1,C2,Dout", [(64, 0, 64), (64, 0, 128), (128, 64, 128), (128, 0, 256), (256, 0, 192)])
 def test_linear_pm_vs_fp64(dev, C1, C2, Dout):
     from dh3d_amd import pm
