@@ -336,6 +336,131 @@ def global_tail_roofline(dev, B=32, N=4096):
     return out
 
 
+def step_kernel_rows(workload):
+    """The kernels of one step of `workload` with their ALGORITHMIC work (SURVEY 8d's per-op figures at the bench shape):
+    (regex on the kernel name, launches per step, what it is, bytes, flops, bound).  Bytes are the compulsory HBM bytes
+    of the operator as executed (inputs once + outputs once; for the commuted global tail the intermediates that do
+    travel through memory are counted once written + once read), flops the factorised / executed count in f32 flops
+    (bf16x6 products counted once)."""
+    wl = WORKLOADS[workload]
+    B, N, K = wl["B"], wl["N"], 8
+    M = N // 8
+    R, Rs = float(B * N), float(B * M)
+    ff = flex_figures
+    rows = [
+        ("spatial_sort_kernel<%d>" % (N // 1024), 1, "Morton sort of the clouds", 4 * R * 7 + 32 * R / 64, 0.0, "latency (one workgroup per cloud)"),
+        ("fps_list_kernel", 1, "farthest point sampling N -> N/8", 16 * R + 16 * Rs, 8.0 * B * N * M, "latency (N/8 dependent picks, one CU per cloud)"),
+        ("knn_split_kernel", 1, "kNN K=8 on the full clouds", 16 * R + 8 * R * K, 8.0 * B * N * N, "f32 VALU (brute-force pair count; the kernel prunes)"),
+        ("pointset_sum_kernel", 1, "conv_pointset: neighbour-offset sums", 4 * R * (3 + K + 4), 6.0 * R * K, "hbm"),
+        ("pointset_pool_kernel", 1, "conv_pointset 3->32 + BNReLU + flex_pool", 4 * R * (4 + K + 32), 2.0 * R * K * 32 * 3, "hbm"),
+        ("conv_pointset_pm_kernel", 1, "conv_pointset 3->32 + BNReLU", 4 * R * (3 + K + 32), 2.0 * R * K * 32 * 3, "hbm"),
+        ("flex_pool_pm_kernel", 1, "flex_pool D=32", 4 * R * (2 * 32 + K), 0.0, "hbm"),
+        ("flex_conv_x6_kernel<32, 64", 1, "flex_conv 32->64 @N", ff(B, N, K, 32, 64)[0], ff(B, N, K, 32, 64)[2], "hbm (contract) / matrix pipe"),
+        ("flex_conv_x6_kernel<64, 64", 1, "flex_conv 64->64 @N", ff(B, N, K, 64, 64)[0], ff(B, N, K, 64, 64)[2], "hbm (contract) / matrix pipe"),
+        ("se_res_mfma_kernel<64, true, true>", 1, "flex_pool + SE + residual + 1x1 conv 64->64 @N", 4 * R * (64 + K + 64 + 64), 2.0 * R * (2 * 64 * 16 + 64 * 64), "hbm"),
+        ("knn_small_kernel", 1, "kNN K=8 on the sampled sets", 12 * Rs + 8 * Rs * K, 8.0 * B * M * M, "latency / VALU issue"),
+        ("spatial_sort_kernel<1>", 1, "Morton sort of the sampled sets", 4 * Rs * 7 + 32 * Rs / 64, 0.0, "latency"),
+        ("three_nn_pruned_kernel", 1, "three_nn N vs N/8", 16 * R + 16 * Rs + 24 * R, 8.0 * B * N * M, "f32 VALU (brute-force pair count; the kernel prunes)"),
+        ("flex_conv_pm_kernel<64, 128", 1, "flex_conv 64->128 @N/8", ff(B, M, K, 64, 128)[0], ff(B, M, K, 64, 128)[2], "f32 MFMA"),
+        ("flex_conv_pm_kernel<128, 128", 1, "flex_conv 128->128 @N/8", ff(B, M, K, 128, 128)[0], ff(B, M, K, 128, 128)[2], "f32 MFMA"),
+        ("se_res_mfma_kernel<128, true, false>", 1, "flex_pool + SE + residual @N/8", 4 * Rs * (128 + K + 128), 2.0 * Rs * 2 * 128 * 32, "hbm"),
+    ]
+    if workload == "global":
+        rows += [
+            ("group_point_fwd4_kernel", 2, "group_point of the sampled rows (C=64, C=128)", 4 * Rs * (2 + 2 * 64 + 2 * 128), 0.0, "hbm"),
+            ("linear_x6_kernel<1, true>", 1, "concat conv [interp(c)|x2] + shortcut conv -> 128 @N (fused up-sampling)",
+             4 * R * (64 + 64 + 6 + 128) + 4 * Rs * 128, 2.0 * R * 256 * 128, "hbm / matrix pipe"),
+            ("flex_conv_pm_kernel<128, 256", 1, "flex_conv 128->256 @N/8 (global)", ff(B, M, K, 128, 256)[0], ff(B, M, K, 128, 256)[2], "f32 MFMA"),
+            ("linear_x6_kernel<2, false>", 1, "attention conv 256->1024 on the coarse rows (commuted)", 4 * Rs * (256 + 1024), 2.0 * Rs * 256 * 1024, "matrix pipe"),
+            ("linear_pm_kernel<1>", 1, "cluster logits 256->64 on the coarse rows", 4 * Rs * (256 + 64), 2.0 * Rs * 256 * 64, "hbm"),
+            ("fillBufferAligned", 1, "zero fill of the walk's accumulators", 4.0 * B * M * 64, 0.0, "hbm"),
+            ("interp_head_lds_kernel", 1, "walk: interpolated attention logit + NetVLAD assignment -> A'",
+             4 * Rs * (1024 + 64) + 4 * R * (6 + 4) + 4.0 * B * M * 64, 2.0 * R * 3 * (1024 + 64) + 2.0 * R * 1024 + 2.0 * R * 64 * 64, "L2 gather + VALU"),
+            ("gemm_x6_kernel", 1, "VLAD = A'^T c", 4.0 * B * (M * 64 + M * 256 + 64 * 256), 2.0 * B * 64 * M * 256, "matrix pipe"),
+            ("netvlad_finalize", 1, "VLAD residual + intra-normalise", 4.0 * B * 64 * 256 * 2, 0.0, "hbm"),
+            ("netvlad_hidden_splitk", 1, "hidden projection 16384->256", 4.0 * 16384 * 256 + 4.0 * B * 16384, 2.0 * B * 16384 * 256, "hbm (16.8 MB of weights)"),
+            ("netvlad_gate", 1, "BN + context gating", 4.0 * 256 * 256 + 4.0 * B * 512, 2.0 * B * 256 * 256, "latency"),
+        ]
+    else:
+        rows += [
+            ("group_point_fwd4_kernel", 1, "group_point of the sampled rows (C=64)", 4 * Rs * (1 + 2 * 64), 0.0, "hbm"),
+            ("linear_x6_kernel<1, false>", 2, "shortcut conv 64->128 and concat conv's lower block 64->128 @N", 2 * 4 * R * (64 + 128), 2 * 2.0 * R * 64 * 128, "hbm"),
+            ("linear_x6_kernel<2, false>", 1, "shortcut + lower block in one launch @N", 4 * R * (64 + 64 + 256), 2 * 2.0 * R * 64 * 128, "hbm"),
+            ("linear_pm_kernel<2>", 1, "concat conv's upper block 128->128 on the coarse rows", 4 * Rs * 256, 2.0 * Rs * 128 * 128, "hbm"),
+            ("interp_combine_kernel", 1, "up-sampling + bias/BN/ReLU + shortcut + l2-normalise/concat store @N",
+             4 * R * (128 + 128 + 6 + 131) + 4 * Rs * 128, 2.0 * R * 3 * 128, "hbm"),
+        ]
+    return rows
+
+
+def step_roofline(workload, serial_ms=None, in_flight_ms=None, depth=None, timeout=240):
+    """Step-level roofline: every kernel of one step -- algorithmic bytes / flops (step_kernel_rows), its floor at 8 TB/s
+    and 157.3 TF (f32 MFMA = f32 VALU peak), its stand-alone duration measured NOW by `rocprofv3 --kernel-trace` over
+    tools/step_forward.py (the eager forward on ONE stream: no kernel overlaps another) -- and how far the whole step is
+    from the sum of the floors, one step at a time and in flight."""
+    import re
+    import shutil
+    import sqlite3
+    out = {"workload": WORKLOADS[workload]["name"], "peaks": {"hbm_GBps": HBM_PEAK_GBS, "f32_TFps": F32_MFMA_PEAK_TF}}
+    if not shutil.which("rocprofv3"):
+        out["error"] = "rocprofv3 not on PATH"
+        return out
+    d = tempfile.mkdtemp(prefix="dh3d_step_", dir="/tmp")
+    try:
+        env = dict(os.environ, PYTHONPATH=ROOT, TMPDIR="/tmp")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        subprocess.run(["rocprofv3", "--kernel-trace", "-d", d, "-o", "p", "--", sys.executable,
+                        os.path.join(ROOT, "tools", "step_forward.py"), workload, "6"],
+                       cwd="/tmp", env=env, timeout=timeout, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        db = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
+        if not db:
+            out["error"] = "rocprofv3 produced no database"
+            return out
+        c = sqlite3.connect(db[0])
+        cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
+        namecol = "name" if "name" in cols else "kernel_name"
+        disp = c.execute("select %s, start, end from kernels order by start" % namecol).fetchall()
+    except Exception as e:  # noqa: BLE001 -- measurement aid: never fail the bench line
+        out["error"] = "kernel trace failed: %r" % (e,)
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    # the LAST forward of the trace (everything after the last dispatch of the step's first kernel)
+    first = "spatial_sort_kernel"
+    starts = [i for i, (n, _, _) in enumerate(disp) if first in n and "<1>" not in n]
+    last = disp[starts[-1]:] if starts else disp
+    rows, tot_floor, tot_meas, listed = [], 0.0, 0.0, 0
+    for pat, calls, what, nbytes, flops, bound in step_kernel_rows(workload):
+        durs = [(e - s) / 1e3 for n, s, e in last if pat in n]
+        if not durs:
+            continue
+        listed += len(durs)
+        meas = sum(durs)
+        f_hbm, f_fl = nbytes / (HBM_PEAK_GBS * 1e9) * 1e6, flops / (F32_MFMA_PEAK_TF * 1e12) * 1e6
+        floor = max(f_hbm, f_fl)
+        tot_floor += floor
+        tot_meas += meas
+        rows.append({"kernel": pat, "launches": len(durs), "what": what, "bytes": nbytes, "flops": flops, "bound": bound,
+                     "floor_us": round(floor, 2), "floor_hbm_us": round(f_hbm, 2), "floor_f32_us": round(f_fl, 2),
+                     "measured_us": round(meas, 2), "frac": round(floor / meas, 4) if meas > 0 else None})
+    other = [(n, (e - s) / 1e3) for n, s, e in last if not any(r["kernel"] in n for r in rows)]
+    out["kernels"] = rows
+    out["unlisted_kernels_us"] = round(sum(t for _, t in other), 2)
+    out["unlisted_kernel_names"] = sorted({re.sub(r"\(.*", "", n)[:60] for n, _ in other})[:8]
+    out["sum_of_floors_ms"] = tot_floor / 1e3
+    out["sum_of_measured_kernel_ms"] = tot_meas / 1e3
+    out["frac_of_kernel_time"] = tot_floor / tot_meas if tot_meas else None
+    if serial_ms:
+        out["one_step_at_a_time"] = {"ms_per_step": serial_ms, "frac_step": tot_floor / 1e3 / serial_ms}
+    if in_flight_ms:
+        out["in_flight"] = {"steps_in_flight": depth, "ms_per_step": in_flight_ms, "frac_step": tot_floor / 1e3 / in_flight_ms}
+    out["note"] = ("floor_us = max(bytes / 8 TB/s, flops / 157.3 TF) per kernel; FPS and the sorts are latency chains on "
+                   "one CU per cloud -- their floors assume the whole chip and are never reached by one step, which is "
+                   "why steps run in flight; PMC utilisation of the same forward: profiles/r04_*_pmc_step_*.txt")
+    return out
+
+
 def flex_in_step_ms(dev, reps=10):
     """Duration of the stage-1 flex_conv 64->64 launch INSIDE the local forward (events on the stream it runs on)."""
     from dh3d_amd import pm
@@ -803,6 +928,9 @@ def main():
             line["kernels_ms"] = kernel_breakdown(dev, wl["B"], wl["N"])
             if world == 1:
                 line["dropin_ops_ms"] = dropin_ops_line(dev)
+                line["roofline_step"] = step_roofline(args.workload, serial_ms=serial["ms_per_step"],
+                                                      in_flight_ms=ms if pipelined else None,
+                                                      depth=args.inflight if pipelined else None)
     if extras and world == 1:
         others = []
         for other in ("local", "global", "cfg5", "train"):
@@ -817,6 +945,10 @@ def main():
                 odepth = args.inflight if explicit_inflight else WORKLOADS[other]["inflight"]
                 rec["value"], rec["ms_per_step"] = fresh_process_in_flight(other, odepth, args.steps)
                 rec["steps_in_flight"] = odepth
+            if other in ("local", "global"):
+                rec["roofline_step"] = step_roofline(other, serial_ms=oms,
+                                                     in_flight_ms=rec["ms_per_step"] if rec["steps_in_flight"] > 1 else None,
+                                                     depth=rec["steps_in_flight"] if rec["steps_in_flight"] > 1 else None)
             if other == "cfg5":
                 with torch.no_grad():
                     rec["kernel_roofline"] = cfg5_kernel_line(dev)

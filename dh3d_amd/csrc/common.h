@@ -77,5 +77,15 @@ __device__ __forceinline__ float dh3d_epilogue_apply(float v, int c, const Epilo
   return dh3d_act(v, e.act);
 }
 
+// epilogue coefficients of four consecutive channels in registers (defaults: + 0, x 1, + 0 -- the value is unchanged)
+struct Ep4 { float4 pb, sc, sh; };
+__device__ __forceinline__ Ep4 ep4_prefetch(const EpilogueArgs &ep, int c4) {
+  Ep4 e{make_float4(0.f, 0.f, 0.f, 0.f), make_float4(1.f, 1.f, 1.f, 1.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+  if (ep.pre_bias) e.pb = *reinterpret_cast<const float4 *>(ep.pre_bias + c4);
+  if (ep.scale) e.sc = *reinterpret_cast<const float4 *>(ep.scale + c4);
+  if (ep.shift) e.sh = *reinterpret_cast<const float4 *>(ep.shift + c4);
+  return e;
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -262,7 +262,9 @@ __global__ __launch_bounds__(256) void se_res_mfma_kernel(const float *__restric
   __shared__ __attribute__((aligned(16))) float s_h[kTM * LDH];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const long long grow0 = (long long)blockIdx.x * kTM;
+  // POOL gathers neighbour rows of the tile's own cloud: every XCD gets a CONTIGUOUS range of tiles, so a cloud's map is
+  // fetched into one L2 instead of all eight (PMC, 8 x 8192 x 64: FETCH_SIZE 57.9 MB raw with the round-robin order)
+  const long long grow0 = (long long)(POOL ? dh3d_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x) * kTM;
   if (POOL) {
     // the tile's neighbour ids once into LDS (as row offsets; every id is used by C/4 lanes), then all K row reads of a
     // lane in flight together

@@ -307,6 +307,7 @@ __global__ __launch_bounds__(256) void conv_pointset_pm_kernel(
     const float4 tx = *reinterpret_cast<const float4 *>(theta + o4);
     const float4 ty = *reinterpret_cast<const float4 *>(theta + Dout + o4);
     const float4 tz = *reinterpret_cast<const float4 *>(theta + 2 * Dout + o4);
+    const Ep4 q = ep4_prefetch(ep, o4);  // requested with theta, not one dependent load per channel behind the sum
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < KK; ++k) {
@@ -317,10 +318,10 @@ __global__ __launch_bounds__(256) void conv_pointset_pm_kernel(
     }
     const float4 bq = *reinterpret_cast<const float4 *>(bias + o4);
     float4 r;
-    r.x = dh3d_epilogue_apply(acc.x + bq.x, o4, ep);
-    r.y = dh3d_epilogue_apply(acc.y + bq.y, o4 + 1, ep);
-    r.z = dh3d_epilogue_apply(acc.z + bq.z, o4 + 2, ep);
-    r.w = dh3d_epilogue_apply(acc.w + bq.w, o4 + 3, ep);
+    r.x = dh3d_act(((acc.x + bq.x) + q.pb.x) * q.sc.x + q.sh.x, ep.act);
+    r.y = dh3d_act(((acc.y + bq.y) + q.pb.y) * q.sc.y + q.sh.y, ep.act);
+    r.z = dh3d_act(((acc.z + bq.z) + q.pb.z) * q.sc.z + q.sh.z, ep.act);
+    r.w = dh3d_act(((acc.w + bq.w) + q.pb.w) * q.sc.w + q.sh.w, ep.act);
     *reinterpret_cast<float4 *>(s_o + (size_t)tid * LDO + o4) = r;
   }
   __syncthreads();
@@ -350,6 +351,7 @@ __global__ __launch_bounds__(256) void conv_pointset_pm_anyk_kernel(
     const float4 tx = *reinterpret_cast<const float4 *>(theta + o4);
     const float4 ty = *reinterpret_cast<const float4 *>(theta + Dout + o4);
     const float4 tz = *reinterpret_cast<const float4 *>(theta + 2 * Dout + o4);
+    const Ep4 q = ep4_prefetch(ep, o4);  // requested with theta, not one dependent load per channel behind the sum
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int k = 0; k < K; ++k) {
       const long long g = cloud0 + nb[k];
@@ -361,10 +363,10 @@ __global__ __launch_bounds__(256) void conv_pointset_pm_anyk_kernel(
     }
     const float4 bq = *reinterpret_cast<const float4 *>(bias + o4);
     float4 r;
-    r.x = dh3d_epilogue_apply(acc.x + bq.x, o4, ep);
-    r.y = dh3d_epilogue_apply(acc.y + bq.y, o4 + 1, ep);
-    r.z = dh3d_epilogue_apply(acc.z + bq.z, o4 + 2, ep);
-    r.w = dh3d_epilogue_apply(acc.w + bq.w, o4 + 3, ep);
+    r.x = dh3d_act(((acc.x + bq.x) + q.pb.x) * q.sc.x + q.sh.x, ep.act);
+    r.y = dh3d_act(((acc.y + bq.y) + q.pb.y) * q.sc.y + q.sh.y, ep.act);
+    r.z = dh3d_act(((acc.z + bq.z) + q.pb.z) * q.sc.z + q.sh.z, ep.act);
+    r.w = dh3d_act(((acc.w + bq.w) + q.pb.w) * q.sc.w + q.sh.w, ep.act);
     *reinterpret_cast<float4 *>(out + n * Dout + o4) = r;
   }
 }
@@ -402,36 +404,40 @@ __global__ __launch_bounds__(256) void pointset_sum_kernel(const float *__restri
   S[n] = make_float4(sx, sy, sz, 0.f);
 }
 
+// CV = Dout / 4 lanes per point (compile time: the point / channel split is a shift); 32-bit indexing (R * CV < 2^31)
+template <int CV>
 __global__ __launch_bounds__(256) void pointset_pool_kernel(const float4 *__restrict__ S, const int32_t *__restrict__ nbr,
                                                            const float *__restrict__ theta, const float *__restrict__ bias,
-                                                           long long R, int N, int Dout, EpilogueArgs ep,
-                                                           float *__restrict__ out) {
-  const int cv = Dout / 4;
-  const long long e = (long long)dh3d_xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
-  if (e >= R * cv) return;
-  const long long n = e / cv;
-  const int c4 = (int)(e - n * cv) * 4;
-  const long long cloud0 = (n / N) * N;
-  const int4 a = *reinterpret_cast<const int4 *>(nbr + n * 8), b = *reinterpret_cast<const int4 *>(nbr + n * 8 + 4);
-  const int id[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-  float4 s[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) s[k] = S[cloud0 + id[k]];
+                                                           int R, int N, EpilogueArgs ep, float *__restrict__ out) {
+  constexpr int Dout = CV * 4;
+  const unsigned e = (unsigned)dh3d_xcd_remap(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
+  const unsigned n = e / CV;
+  if (n >= (unsigned)R) return;
+  const int c4 = (int)(e % CV) * 4;
+  const unsigned cloud0 = (n / (unsigned)N) * (unsigned)N;
+  const int4 a = *reinterpret_cast<const int4 *>(nbr + (size_t)n * 8), b = *reinterpret_cast<const int4 *>(nbr + (size_t)n * 8 + 4);
+  // (everything below that does not depend on the ids is requested before the ids are waited for)
   const float4 tx = *reinterpret_cast<const float4 *>(theta + c4);
   const float4 ty = *reinterpret_cast<const float4 *>(theta + Dout + c4);
   const float4 tz = *reinterpret_cast<const float4 *>(theta + 2 * Dout + c4);
   const float4 bq = *reinterpret_cast<const float4 *>(bias + c4);
+  const Ep4 q = ep4_prefetch(ep, c4);
+  const int act = ep.act;
+  const int id[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  float4 s[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s[k] = S[cloud0 + (unsigned)id[k]];
   float4 best = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     float4 v;
-    v.x = dh3d_epilogue_apply(fmaf(tz.x, s[k].z, fmaf(ty.x, s[k].y, tx.x * s[k].x)) + bq.x, c4, ep);
-    v.y = dh3d_epilogue_apply(fmaf(tz.y, s[k].z, fmaf(ty.y, s[k].y, tx.y * s[k].x)) + bq.y, c4 + 1, ep);
-    v.z = dh3d_epilogue_apply(fmaf(tz.z, s[k].z, fmaf(ty.z, s[k].y, tx.z * s[k].x)) + bq.z, c4 + 2, ep);
-    v.w = dh3d_epilogue_apply(fmaf(tz.w, s[k].z, fmaf(ty.w, s[k].y, tx.w * s[k].x)) + bq.w, c4 + 3, ep);
+    v.x = dh3d_act(((fmaf(tz.x, s[k].z, fmaf(ty.x, s[k].y, tx.x * s[k].x)) + bq.x) + q.pb.x) * q.sc.x + q.sh.x, act);
+    v.y = dh3d_act(((fmaf(tz.y, s[k].z, fmaf(ty.y, s[k].y, tx.y * s[k].x)) + bq.y) + q.pb.y) * q.sc.y + q.sh.y, act);
+    v.z = dh3d_act(((fmaf(tz.z, s[k].z, fmaf(ty.z, s[k].y, tx.z * s[k].x)) + bq.z) + q.pb.z) * q.sc.z + q.sh.z, act);
+    v.w = dh3d_act(((fmaf(tz.w, s[k].z, fmaf(ty.w, s[k].y, tx.w * s[k].x)) + bq.w) + q.pb.w) * q.sc.w + q.sh.w, act);
     best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y); best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
   }
-  *reinterpret_cast<float4 *>(out + n * Dout + c4) = best;
+  *reinterpret_cast<float4 *>(out + (size_t)n * Dout + c4) = best;
 }
 
 inline int flat_grid(long long total) {
@@ -510,13 +516,19 @@ DH3D_API int dh3d_conv_pointset_pool_pm_fwd(const float *xyz, const int32_t *nbr
                                             int B, int N, int K, int Dout, const dh3d_epilogue *ep, float *scratch,
                                             float *out, void *stream) {
   DH3D_REQUIRE(xyz && nbr && theta && bias && scratch && out && B > 0 && N > 0 && Dout > 0);
-  DH3D_SUPPORTED(K == 8 && Dout % 4 == 0);
+  DH3D_SUPPORTED(K == 8 && (Dout == 32 || Dout == 64 || Dout == 128) && (long long)B * N * (Dout / 4) < (1ll << 31));
   const long long R = (long long)B * N;
   hipStream_t s = (hipStream_t)stream;
   float4 *S = reinterpret_cast<float4 *>(scratch);
   hipLaunchKernelGGL(pointset_sum_kernel, dim3(dh3d_cdiv(R, 256)), dim3(256), 0, s, xyz, nbr, R, N, S);
-  hipLaunchKernelGGL(pointset_pool_kernel, dim3(dh3d_cdiv(R * (Dout / 4), 256)), dim3(256), 0, s, S, nbr, theta, bias, R, N,
-                     Dout, dh3d_ep(ep), out);
+  const dim3 grid(dh3d_cdiv(R * (Dout / 4), 256)), block(256);
+  const EpilogueArgs e = dh3d_ep(ep);
+  if (Dout == 32)
+    hipLaunchKernelGGL(pointset_pool_kernel<8>, grid, block, 0, s, S, nbr, theta, bias, (int)R, N, e, out);
+  else if (Dout == 64)
+    hipLaunchKernelGGL(pointset_pool_kernel<16>, grid, block, 0, s, S, nbr, theta, bias, (int)R, N, e, out);
+  else
+    hipLaunchKernelGGL(pointset_pool_kernel<32>, grid, block, 0, s, S, nbr, theta, bias, (int)R, N, e, out);
   return dh3d_launch_status();
 }
 

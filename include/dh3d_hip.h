@@ -292,7 +292,7 @@ int dh3d_conv_pointset_pm_fwd(const float *xyz, const int32_t *nbr, const float 
 /* conv_pointset on the coordinates (Din = 3) -> epilogue (bias once, BatchNorm, activation) -> flex_pool over the same
  * neighbourhoods, fused (core/backbones.py:107-110; conv_pointset_kernel.cc:46-64 + flex_pool_kernel.cc:41-57): the
  * [B,N,Dout] map between the two is never materialised.  out [B,N,Dout] = max_k act(bn(conv[nbr[n,k]])).  K == 8,
- * Dout % 4 == 0; scratch: B*N*4 floats (one 3-vector per point, the sum of its neighbour offsets). */
+ * Dout in {32, 64, 128}; scratch: B*N*4 floats (one 3-vector per point, the sum of its neighbour offsets). */
 int dh3d_conv_pointset_pool_pm_fwd(const float *xyz, const int32_t *nbr, const float *theta, const float *bias, int B,
                                    int N, int K, int Dout, const dh3d_epilogue *ep, float *scratch, float *out,
                                    void *stream);
