@@ -19,6 +19,14 @@ namespace {
 constexpr int kThreads = 1024;
 constexpr int kWaves = 16;
 
+#ifdef DH3D_SORT_PROBE  // dev instrumentation (tools/sort_probe.py): s_memtime stamps of wave 0 / wave 15 of a few clouds
+__device__ long long g_sprobe[8 * 2 * 16];
+#define SPROBE(i) do { if ((threadIdx.x == 0 || threadIdx.x == 960) && blockIdx.x < 8) \
+  g_sprobe[(blockIdx.x * 2 + (threadIdx.x != 0)) * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SPROBE(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ unsigned spread6(unsigned v) {  // 6 bits -> every third bit
   v &= 63u;
   v = (v | (v << 8)) & 0x300Fu;
@@ -43,18 +51,23 @@ __global__ __launch_bounds__(kThreads) void spatial_sort_kernel(const float *__r
   // steps of 64: the arrangement the stable radix passes below need.
   const int SEG = npad / kWaves;  // = 64 * PPT
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  SPROBE(0);
   float px[PPT], py[PPT], pz[PPT];
+  // every load of the thread is requested before the first one is used: no load sits under a branch (a padding lane
+  // re-reads the last point) -- with `if (k < N) load` the compiler waited for each of the PPT loads in turn
+  // (s_waitcnt vmcnt(0) after every one: PPT dependent round trips to HBM at the head of the step's critical chain)
 #pragma unroll
   for (int j = 0; j < PPT; ++j) {
-    const int k = wave * SEG + j * 64 + lane;
-    px[j] = py[j] = pz[j] = 0.f;
-    if (k < N) {
-      px[j] = pc[(size_t)k * 3]; py[j] = pc[(size_t)k * 3 + 1]; pz[j] = pc[(size_t)k * 3 + 2];
-      lo[0] = fminf(lo[0], px[j]); hi[0] = fmaxf(hi[0], px[j]);
-      lo[1] = fminf(lo[1], py[j]); hi[1] = fmaxf(hi[1], py[j]);
-      lo[2] = fminf(lo[2], pz[j]); hi[2] = fmaxf(hi[2], pz[j]);
-    }
+    const int k = min(wave * SEG + j * 64 + lane, N - 1);
+    px[j] = pc[(size_t)k * 3]; py[j] = pc[(size_t)k * 3 + 1]; pz[j] = pc[(size_t)k * 3 + 2];
   }
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {  // (a re-read point changes no minimum / maximum)
+    lo[0] = fminf(lo[0], px[j]); hi[0] = fmaxf(hi[0], px[j]);
+    lo[1] = fminf(lo[1], py[j]); hi[1] = fmaxf(hi[1], py[j]);
+    lo[2] = fminf(lo[2], pz[j]); hi[2] = fmaxf(hi[2], pz[j]);
+  }
+  SPROBE(1);
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     const float wl = wave_min_f32(lo[a]), wh = wave_max_f32(hi[a]);
@@ -86,6 +99,7 @@ __global__ __launch_bounds__(kThreads) void spatial_sort_kernel(const float *__r
   // ---- three stable counting passes over 6-bit digits of the cell.  Per pass: every wave ranks its keys digit by
   // digit (same-digit lanes found with 6 ballots; the running per-(wave, digit) count lives in LDS), one block scan
   // of the 64 x 16 counts in (digit, wave) order gives the bases, and the keys move to their places.
+  SPROBE(2);
   unsigned *src = s_raw, *dst = s_raw + npad;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   for (int pass = 0; pass < 3; ++pass) {
@@ -109,7 +123,9 @@ __global__ __launch_bounds__(kThreads) void spatial_sort_kernel(const float *__r
       local[j] = before + rank;
       if (rank == 0) whist[d] = before + (unsigned)__popcll(same);  // one lane per digit; reads above precede it
     }
+    if (pass == 0) SPROBE(3);
     __syncthreads();
+    if (pass == 0) SPROBE(4);
     // exclusive scan over (digit, wave): thread t <-> digit t / 16, wave t % 16
     {
       const int d = tid >> 4, w = tid & 15;
@@ -128,29 +144,44 @@ __global__ __launch_bounds__(kThreads) void spatial_sort_kernel(const float *__r
       s_hist[w * 64 + d] = base + inc - v;
     }
     __syncthreads();
+    if (pass == 0) SPROBE(5);
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
       const unsigned d = (key[j] >> shift) & 63u;
       dst[whist[d] + local[j]] = key[j];
     }
     __syncthreads();
+    if (pass == 0) SPROBE(6);
     // reload in the wave-contiguous arrangement for the next pass
 #pragma unroll
     for (int j = 0; j < PPT; ++j) key[j] = dst[wave * SEG + j * 64 + lane];
     unsigned *t = src; src = dst; dst = t;
+    if (pass == 0) SPROBE(7);
   }
+  SPROBE(8);
   const unsigned *s_keys = src;  // sorted
-  // ---- sorted records + one box per 64: lane l of wave w owns positions (w + 16 j) * 64 + l
+  // ---- sorted records + one box per 64: lane l of wave w owns positions (w + 16 j) * 64 + l.  Gather first (all PPT
+  // rows requested together, padding lanes re-read the cloud's last sorted point), then store and reduce.
+  float gx[PPT], gy[PPT], gz[PPT];
+  int gk[PPT];
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    const int i = min((wave + kWaves * j) * 64 + lane, N - 1);
+    gk[j] = (int)(s_keys[i] & 0x3FFFu);
+  }
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    gx[j] = pc[(size_t)gk[j] * 3]; gy[j] = pc[(size_t)gk[j] * 3 + 1]; gz[j] = pc[(size_t)gk[j] * 3 + 2];
+  }
+  SPROBE(9);
 #pragma unroll
   for (int j = 0; j < PPT; ++j) {
     const int g = wave + kWaves * j;
     const int i = g * 64 + lane;
-    float x = 0.f, y = 0.f, z = 0.f;
+    const float x = gx[j], y = gy[j], z = gz[j];
     float lx = INFINITY, ly = INFINITY, lz = INFINITY, hx = -INFINITY, hy = -INFINITY, hz = -INFINITY;
     if (i < N) {
-      const int k = (int)(s_keys[i] & 0x3FFFu);
-      x = pc[(size_t)k * 3]; y = pc[(size_t)k * 3 + 1]; z = pc[(size_t)k * 3 + 2];
-      sorted[(size_t)b * N + i] = make_float4(x, y, z, __int_as_float(k));
+      sorted[(size_t)b * N + i] = make_float4(x, y, z, __int_as_float(gk[j]));
       lx = hx = x; ly = hy = y; lz = hz = z;
     }
     if (g < NG) {  // wave-uniform
@@ -162,6 +193,7 @@ __global__ __launch_bounds__(kThreads) void spatial_sort_kernel(const float *__r
       }
     }
   }
+  SPROBE(10);
 }
 
 template <int PPT>
@@ -176,6 +208,12 @@ int sort_launch(const float *xyz, int B, int N, float4 *sorted, float *gbox, hip
 }
 
 }  // namespace
+
+#ifdef DH3D_SORT_PROBE
+DH3D_API int dh3d_sort_probe_read(long long *host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sprobe), sizeof(long long) * n) == hipSuccess ? 0 : 3;
+}
+#endif
 
 DH3D_API int dh3d_spatial_sort(const float *xyz, int B, int N, float *sorted, float *gbox, void *stream) {
   DH3D_REQUIRE(xyz && sorted && gbox && B > 0 && N > 0);
