@@ -318,8 +318,8 @@ def compute_level(xyz, dilate, knn, ordered=None, fps_contract=None):
         xyz_s = gather_rows(xyz, idx)
     ready = torch.cuda.Event()
     ready.record()  # xyz_s exists: three_nn may start on another stream while the sampled-set kNN runs here
-    if npoint <= 2048:  # small sets: the brute-force kernel beats sort + pruned search (launch/latency bound)
-        nbr_s, _ = pm.knn_xyz(xyz_s, knn)
+    if npoint <= 2048 or npoint > 16384:  # small sets: the brute-force kernel beats sort + pruned search (launch /
+        nbr_s, _ = pm.knn_xyz(xyz_s, knn)  # latency bound); sets beyond the Morton sort's 14-bit ids: it is what serves any N
     else:
         srt_s, gbox_s = pm.spatial_sort(xyz_s)
         nbr_s, _ = pm.knn_sorted(srt_s, gbox_s, knn)
@@ -328,7 +328,7 @@ def compute_level(xyz, dilate, knn, ordered=None, fps_contract=None):
     lv = {"idx": idx, "xyz_s": xyz_s, "nbr_s": nbr_s, "_xyz_ready": ready, "_level_ready": level_ready}
     if ordered is not None:
         lv["_ordered"] = ordered            # Morton records + boxes of the full cloud: the pruned three_nn uses them
-        if npoint > 2048:
+        if 2048 < npoint <= 16384:
             lv["_ordered_s"] = (srt_s, gbox_s)
     return lv
 

@@ -1,7 +1,7 @@
 """Layer wrappers in the reference's channels-first convention (mirrors core/layers.py).
 
 KnnBruteforce (core/layers.py:49-107), FlexPooling (:110-175), FlexConvolution (:178-339, :439-461),
-ConvolutionPointset (:564-707): same constructor arguments that matter, same weight names
+Flex_Avg (:342-436, :464-480), ConvolutionPointset (:564-707): same constructor arguments that matter, same weight names
 (position_theta / position_bias / feature_bias), same tensor layouts ([B, C, N] features,
 [B, K, N] neighbourhoods).  They call the drop-in operators of dh3d_amd.ops and are differentiable
 through the registered gradients.  The fused point-major model path lives in dh3d_amd.backbones.
@@ -14,7 +14,7 @@ from torch import nn
 from . import ops
 
 __all__ = ["KnnBruteforce", "knn_bruteforce", "FlexPooling", "flex_pooling", "FlexConvolution",
-           "ConvolutionPointset"]
+           "ConvolutionPointset", "Flex_Avg", "flex_avg"]
 
 
 class KnnBruteforce(nn.Module):
@@ -115,3 +115,50 @@ class ConvolutionPointset(nn.Module):
         if self.data_format == "expanded":
             y = y.unsqueeze(2)
         return y
+
+
+class Flex_Avg(nn.Module):
+    """core/layers.py:342-436: FlexConvolution with a NON-trainable `position_theta` [Dp, Din, Dout] (zeros by default,
+    :347,379-384) and `position_bias` = eye(Dout) (:386, which makes Din == Dout): with theta = 0 every positional term
+    of the flex_conv sum is an exact 0 * f and what is left is the neighbour sum out[b, c, n] = sum_k f[b, c, nbr[b, k, n]]
+    (backbones.py:80-83 scales it by 1/knn for `add_se='avg_pool'`).  That case runs on the neighbour-sum kernel
+    (dh3d_flex_avg_pm_fwd, point-major, through two LDS-tile transposes); a theta that was loaded with non-zero values,
+    or inputs that need gradients, take the flex_conv operator with the same theta / eye -- the layer as the reference
+    wrote it."""
+
+    def __init__(self, in_channels, filters, dp=3, activation=None, data_format="simple"):
+        super().__init__()
+        assert data_format in ["simple", "expanded"]
+        if int(in_channels) != int(filters):
+            raise ValueError("Flex_Avg: position_bias = eye(filters) needs in_channels == filters (core/layers.py:386)")
+        self.filters = int(filters)
+        self.activation = activation
+        self.data_format = data_format
+        self.position_theta = nn.Parameter(torch.zeros(dp, in_channels, filters), requires_grad=False)
+        self.register_buffer("position_bias", torch.eye(filters), persistent=False)  # not a variable upstream
+
+    def forward(self, features, positions, neighborhoods):
+        from . import pm
+        if self.data_format == "expanded":
+            features, positions, neighborhoods = features.squeeze(2), positions.squeeze(2), neighborhoods.squeeze(2)
+        plain_sum = (not features.requires_grad and features.dtype == torch.float32 and features.shape[1] % 4 == 0
+                     and not bool(self.position_theta.any()))
+        if plain_sum:
+            f_pm = pm.transpose_last2(features)                                   # [B, N, C]
+            nb_pm = pm.transpose_last2(neighborhoods.to(torch.int32))             # [B, N, K]
+            y = pm.transpose_last2(pm.flex_avg(f_pm, nb_pm, 1.0))                 # [B, C, N]
+        else:
+            y = ops.flex_convolution(features, positions, neighborhoods, self.position_theta,
+                                     self.position_bias.to(features.dtype))
+        if self.activation is not None:
+            y = self.activation(y)
+        if self.data_format == "expanded":
+            y = y.unsqueeze(2)
+        return y
+
+
+def flex_avg(features, positions, neighborhoods, filters, activation=None, data_format="simple"):
+    """core/layers.py:464-480."""
+    cin = features.shape[1]
+    layer = Flex_Avg(cin, filters, dp=positions.shape[1], activation=activation, data_format=data_format).to(features.device)
+    return layer(features, positions, neighborhoods)

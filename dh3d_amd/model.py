@@ -198,7 +198,7 @@ class DH3D(nn.Module):
     def _geometry(self, points, knn_inds=None):
         geo = bb.Geometry(points, self.knn_num, fps_contract=self.config.fps_contract)
         main = torch.cuda.current_stream()
-        if knn_inds is None or (4096 <= points.shape[1] <= 16384 and self.config.fps_contract is None):
+        if points.shape[1] <= 16384 and (knn_inds is None or (4096 <= points.shape[1] and self.config.fps_contract is None)):
             geo.ordered()  # Morton order + group boxes: shared by the kNN (side) and the pruned FPS (here)
         if self._geo_stream is None:
             self._geo_stream = torch.cuda.Stream(device=points.device)
@@ -227,6 +227,11 @@ class DH3D(nn.Module):
         with torch.cuda.stream(side):
             if knn_inds is not None:
                 geo.nbr = knn_inds.contiguous()
+            elif points.shape[1] > 16384:
+                # beyond the Morton-ordered kernels' range (14-bit point ids in the sort keys): the brute-force kernel,
+                # any N, same ids bit for bit (the reference needs host sklearn indices here: core/model.py:148-155,
+                # core/utils.py:53-57)
+                geo.nbr, _ = pm.knn_xyz(points, self.knn_num)
             else:
                 srt, gbox = geo.ordered()  # exact kNN with box pruning
                 geo.nbr, _ = pm.knn_sorted(srt, gbox, self.knn_num)  # core/model.py:157
@@ -332,7 +337,8 @@ class DH3D(nn.Module):
     def forward(self, points, knn_inds=None, fetch=None):
         """points [Bt, N, 3] float32 on the GPU (anchor/pos/neg already concatenated, core/model.py:139-146).
         knn_inds [Bt, N, K] int32: optional precomputed neighbours (the reference requires them for
-        num_points > 8192, core/model.py:148-155; here the device kNN serves N <= 16384).
+        num_points > 8192, core/model.py:148-155; here the device kNN serves every N: the Morton-pruned kernels up to
+        16384 points, the brute-force kernel beyond).
         fetch: names of the outputs wanted (None = all).  Like a TF session fetch, tensors nobody asked for are not
         computed: the global-descriptor extraction (globaldesc_extract.py fetches 'globaldesc' only) skips the
         normalised per-point descriptors and the detector."""
@@ -341,10 +347,6 @@ class DH3D(nn.Module):
         cfg = self.config
         if points.dim() != 3 or points.shape[2] != 3:
             raise ValueError("points must be [Bt, N, 3]")
-        if knn_inds is None and points.shape[1] > 16384:
-            raise ValueError("more than 16384 points: pass knn_inds [Bt, N, K] (the device kNN stops there)")
-        if points.shape[1] > 131072:
-            raise ValueError("more than 131072 points per cloud are not supported (sampled-set kNN: N/8 <= 16384)")
         if knn_inds is not None:
             # the kernels never bounds-check neighbour ids (nor does the reference): do it here
             if (knn_inds.dim() != 3 or knn_inds.shape[0] != points.shape[0] or knn_inds.shape[1] != points.shape[1]
@@ -357,7 +359,7 @@ class DH3D(nn.Module):
                     raise ValueError("knn_inds out of range [0, %d): min %d max %d (kNN pads with -1 when N < K)"
                                      % (points.shape[1], lo, hi))
         # num_points > 8192: the reference feeds host (sklearn) kNN indices because its op stops at 8192
-        # (core/model.py:38,148-155); they are still accepted, but the device search covers N <= 16384 itself.
+        # (core/model.py:38,148-155); they are still accepted, but the device search covers every N itself.
         outs = {"pointclouds": points, "xyz": points}
         geo = self._geometry(points, knn_inds)
         outs["knn_inds"] = geo.nbr

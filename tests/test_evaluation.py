@@ -41,3 +41,51 @@ def test_no_valid_query_is_nan():
     r = np.zeros((5, 4), np.float32)
     rec, one = ev.evaluate_pair(r, np.zeros((5, 2)), r, np.full((5, 2), 1e6), max_num_nn=3)
     assert rec.shape == (3,) and bool(torch.isnan(rec).all()) and one != one
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_retrieval_metrics_on_device_descriptors_vs_kdtree_recipe(dev):
+    """The evaluation as globaldesc_extract.py + evaluation_retrieval.py run it, end to end on the device: global
+    descriptors of two synthetic 'traversals' (the same places, re-sampled and jittered) out of the HIP forward, metrics
+    computed on those DEVICE tensors, against the reference's recipe (scipy cKDTree on host copies,
+    evaluation_retrieval.py:37-53,129-169)."""
+    from dh3d_amd import ConfigFactory, evaluation as ev
+    from dh3d_amd.model import DH3D
+    m = DH3D(ConfigFactory("global_config").getconfig()).init_synthetic(7).to(dev).eval().prepare()
+    rng = np.random.default_rng(11)
+    places, N = 48, 2048
+    base = rng.random((places, N, 3), dtype=np.float32) * np.array([40, 40, 6], np.float32)
+    for p in range(places):  # every place its own structure: a few dense blobs
+        c = rng.integers(0, N, 5)
+        base[p, : N // 2] = base[p, c[rng.integers(0, 5, N // 2)]] + rng.normal(0, 1.0 + 0.1 * p, (N // 2, 3)).astype(np.float32)
+    ref_pos = rng.random((places, 2)) * 3000
+    qsel = rng.permutation(places)[:40]
+    qry = base[qsel][:, rng.permutation(N)] + rng.normal(0, 0.05, (40, N, 3)).astype(np.float32)
+    qry_pos = ref_pos[qsel] + rng.normal(0, 8, (40, 2))
+    qry_pos[:3] += 1e5  # three queries without a true match
+    with torch.no_grad():
+        ref_d = m(torch.from_numpy(base).to(dev), fetch=("globaldesc",))["globaldesc"]
+        qry_d = m(torch.from_numpy(qry).to(dev), fetch=("globaldesc",))["globaldesc"]
+    assert ref_d.is_cuda and ref_d.shape == (places, 256)
+    k = 25
+    gt_dev = ev.is_gt_match_2d(torch.from_numpy(qry_pos).to(dev), torch.from_numpy(ref_pos).to(dev), 25.0)
+    idx = ev.retrieval(ref_d, qry_d, k)
+    assert idx.is_cuda and gt_dev.is_cuda
+    rec, one = ev.evaluate_pair(ref_d, torch.from_numpy(ref_pos).to(dev), qry_d, torch.from_numpy(qry_pos).to(dev), max_num_nn=k)
+    # the reference's recipe on host copies of the SAME descriptors
+    rd, qd = ref_d.cpu().numpy(), qry_d.cpu().numpy()
+    gt = np.linalg.norm(qry_pos[:, None] - ref_pos[None], axis=2) < 25
+    assert np.array_equal(gt_dev.cpu().numpy(), gt)
+    dist, ind = cKDTree(rd).query(qd, k=k)
+    got = idx.cpu().numpy()
+    same = got == ind
+    if not same.all():  # only exact ties of the float32 descriptors' distances may order differently
+        q, j = np.nonzero(~same)
+        dg = np.linalg.norm(qd[q].astype(np.float64) - rd[got[q, j]].astype(np.float64), axis=1)
+        assert np.allclose(dg, dist[q, j], rtol=0, atol=1e-12)
+    rec0, one0 = _ref_metrics(rd, qd, gt, k)
+    assert np.allclose(rec.cpu().numpy(), rec0) and abs(one - one0) < 1e-12
+    assert rec0[0] > 0.5  # the same place is retrieved for most queries: the descriptors carry the place

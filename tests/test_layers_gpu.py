@@ -1,6 +1,7 @@
 """GPU: the Layer API (dh3d_amd/layers.py, mirrors core/layers.py:49-707) -- initconv + stage 1 of the local backbone
 assembled from the Layer classes in the reference's channels-first convention (as core/backbones.py:104-116 with
 core/tf_utils.py:48-83 does) must reproduce the fused point-major path, and be differentiable."""
+import numpy as np
 import pytest
 import torch
 
@@ -68,3 +69,41 @@ def test_stage1_from_layer_classes_matches_fused_path(dev):
     y.sum().backward()
     for t in (feats.grad, fc0.position_theta.grad, fc1.position_bias.grad, conv0.position_theta.grad):
         assert t is not None and torch.isfinite(t).all() and float(t.abs().sum()) > 0
+
+
+def test_flex_avg_layer_vs_oracle_flex_conv_with_zero_theta(dev, oracle):
+    """Flex_Avg (core/layers.py:342-436) = the reference's FlexConv functor with theta = 0 and bias = eye(Dout): the
+    layer's neighbour-sum kernel against exactly that call of the oracle (flex_conv_kernel.cc:48-63); a non-zero theta
+    (a loaded variable) takes the flex_conv operator and matches the oracle too; gradients flow to the features."""
+    import torch
+    from dh3d_amd.layers import Flex_Avg, flex_avg
+    rng = np.random.default_rng(8)
+    B, N, C, K = 2, 777, 32, 8
+    xyz = rng.random((B, N, 3), dtype=np.float32)
+    nn, _ = oracle.knn_bruteforce(np.ascontiguousarray(xyz.transpose(0, 2, 1)), K)
+    f = rng.standard_normal((B, C, N)).astype(np.float32)
+    p_cf = np.ascontiguousarray(xyz.transpose(0, 2, 1))
+    nb_cf = np.ascontiguousarray(nn.transpose(0, 2, 1))
+    exp = oracle.flex_convolution(f, p_cf, nb_cf, np.zeros((3, C, C), np.float32), np.eye(C, dtype=np.float32), True)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    layer = Flex_Avg(C, C).to(dev)
+    assert [n for n, p in layer.named_parameters() if p.requires_grad] == []  # position_theta is not trainable (:384)
+    got = layer(T(f), T(p_cf), T(nb_cf))
+    assert got.shape == (B, C, N) and np.array_equal(got.cpu().numpy(), exp)  # a sum in neighbour order: exact
+    assert np.array_equal(flex_avg(T(f), T(p_cf), T(nb_cf), C).cpu().numpy(), exp)
+    exp4 = layer.__class__(C, C, data_format="expanded").to(dev)(T(f).unsqueeze(2), T(p_cf).unsqueeze(2), T(nb_cf).unsqueeze(2))
+    assert exp4.shape == (B, C, 1, N) and torch.equal(exp4.squeeze(2), got)
+    # gradients: d(sum out)/d f[c, j] = number of neighbourhoods j appears in
+    fr = T(f).requires_grad_(True)
+    layer(fr, T(p_cf), T(nb_cf)).sum().backward()
+    cnt = np.stack([np.bincount(nn[b].reshape(-1), minlength=N) for b in range(B)]).astype(np.float32)
+    assert np.allclose(fr.grad.cpu().numpy(), np.broadcast_to(cnt[:, None, :], (B, C, N)), atol=1e-4)
+    # a loaded, non-zero theta
+    theta = (0.1 * rng.standard_normal((3, C, C))).astype(np.float32)
+    with torch.no_grad():
+        layer.position_theta.copy_(T(theta))
+    exp2 = oracle.flex_convolution(f, p_cf, nb_cf, theta, np.eye(C, dtype=np.float32), True)
+    got2 = layer(T(f), T(p_cf), T(nb_cf)).cpu().numpy()
+    assert np.abs(got2 - exp2).max() <= 1e-4 * np.abs(exp2).max()
+    with pytest.raises(ValueError):
+        Flex_Avg(32, 64)

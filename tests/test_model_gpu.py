@@ -107,8 +107,11 @@ def test_input_knn_path_above_8192(dev):
         own = m(pts)
     assert out["xyz_feat"].shape == (1, 16384, 131) and torch.isfinite(out["xyz_feat"]).all()
     assert torch.equal(own["knn_inds"], nbr) and torch.equal(own["xyz_feat"], out["xyz_feat"])
-    with pytest.raises(ValueError):
-        m(torch.rand(1, 16400, 3, device=dev))
+    big = torch.rand(1, 16400, 3, device=dev)  # beyond the Morton-ordered kernels: the brute-force device kNN, any N
+    with torch.no_grad():
+        o = m(big)
+    nb2, _ = pm.knn_xyz(big, 8)
+    assert torch.equal(o["knn_inds"], nb2) and torch.isfinite(o["xyz_feat"]).all()
 
 
 def test_shard_then_gather_equals_unsharded(dev):

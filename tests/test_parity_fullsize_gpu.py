@@ -197,13 +197,37 @@ def test_forward_above_16384_points_with_host_knn_vs_oracle(dev):
     nn, _ = O.knn_bruteforce(np.ascontiguousarray(pts.transpose(0, 2, 1)), 8)
     nbr = torch.from_numpy(nn).to(dev)
     _run_and_compare(m, pts, dev, knn_inds=nbr)
-    with pytest.raises(ValueError):
-        m(torch.from_numpy(pts).to(dev))                      # no device kNN above 16384
     bad = nbr.clone(); bad[0, 5, 3] = 18000
     with pytest.raises(ValueError):
         m(torch.from_numpy(pts).to(dev), knn_inds=bad)       # out-of-range ids are refused, not dereferenced
     with pytest.raises(ValueError):
         m(torch.from_numpy(pts).to(dev), knn_inds=nbr[:, :100])
+
+
+@pytest.mark.parametrize("N", [20000, 40000])
+def test_device_knn_above_16384_points_vs_oracle(dev, N):
+    """no host round trip for the neighbours of ANY cloud size (the reference: host sklearn indices above
+    8192 points, core/utils.py:53-57).  N = 20000: the whole forward with the device kNN against the oracle; N = 40000:
+    the kNN ids + distances against the oracle's brute force (1.6 G pairs of scalar C), ties included (a duplicated
+    block of points), and the forward on them finite with exact pass-through coordinates."""
+    from oracle import cpu as O
+    from dh3d_amd import pm
+    rng = np.random.default_rng(N)
+    pts = rng.random((1, N, 3), dtype=np.float32)
+    pts[0, N - 50:] = pts[0, 100:150]  # exact duplicates: the CUB tie rule with the continued ladder (1024, ceil(N/1024))
+    m = _build("basic_config", dev, seed=44, num_points=N)
+    if N <= 20000:
+        _run_and_compare(m, pts, dev)  # knn_inds=None: the device search
+        return
+    tp = torch.from_numpy(pts).to(dev)
+    nbr, dist = pm.knn_xyz(tp, 8)
+    nn, dd = O.knn_bruteforce(np.ascontiguousarray(pts.transpose(0, 2, 1)), 8)
+    assert np.array_equal(nbr.cpu().numpy(), nn)
+    assert np.array_equal(dist.cpu().numpy().view(np.uint32), dd.view(np.uint32))
+    with torch.no_grad():
+        o = m(tp, fetch=("xyz_feat", "knn_inds"))
+    assert torch.equal(o["knn_inds"], nbr) and torch.isfinite(o["xyz_feat"]).all()
+    assert torch.equal(o["xyz_feat"][:, :, :3], tp)
 
 
 def test_fps_contract_switch_reaches_the_model(dev):
