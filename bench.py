@@ -749,6 +749,19 @@ def main():
         trainer.time_phases(False)
         if world == 1:
             extra["sharded_path"] = sharded_path_at_one_rank(model, pts, dt / args.steps * 1e3)
+            # the reference's own graph: the frozen backbone's BatchNorms on BATCH statistics, moving averages updated
+            # (core/tf_utils.py:145-153), on HIP kernels inside the same whole-step hipGraph
+            try:
+                model2 = DH3D(cfg).init_synthetic(0).to(dev).eval().prepare()
+                tr2 = QuadrupletTrainer(model2, backbone_bn="batch")
+                dt2 = time_steps(resident_step(tr2), pts, args.steps, max(args.warmup, 5), dev)
+                extra["reference_semantics"] = {
+                    "ms_per_step": dt2 / args.steps * 1e3, "value": wl["B"] * args.steps / dt2,
+                    "step_graphed": bool(tr2._step_graphs), "ratio_to_moving_average_step": dt2 / dt,
+                    "note": "QuadrupletTrainer(backbone_bn='batch'): batch-statistics BatchNorm + EMA updates in the frozen "
+                            "backbone (8 sites: colstats / finalize / apply on HIP kernels), what upstream trains with"}
+            except Exception as e:  # noqa: BLE001 -- informational key
+                extra["reference_semantics"] = {"error": repr(e)[:200]}
         return wl["B"] * args.steps / dt, dt / args.steps * 1e3, extra
 
     def sharded_path_at_one_rank(model, pts, plain_ms):

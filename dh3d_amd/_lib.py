@@ -73,6 +73,7 @@ _SIGNATURES = {
     "dh3d_bn_colstats": [c_fp, c_ll, c_int, c_fp, c_int, c_fp, c_fp, c_fp],
     "dh3d_bn_finalize": [c_fp, c_fp, c_fp, c_fp, c_fp, c_float, c_float, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp],
     "dh3d_scale_shift_act": [c_fp, c_ll, c_int, c_fp, c_fp, c_int, c_fp, c_fp],
+    "dh3d_scale_shift_act_res": [c_fp, c_ll, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_fp],
     "dh3d_row_logit_sigmoid": [c_fp, c_ll, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp],
     "dh3d_bn_bwd_sums": [c_fp, c_fp, c_fp, c_fp, c_ll, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_int,
                          c_fp, c_fp, c_fp, c_fp],

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float *__restrict__
 __global__ __launch_bounds__(256) void scale_shift_act_kernel(const float *__restrict__ x, long long R, int C,
                                                              const float *__restrict__ scale,
                                                              const float *__restrict__ shift, int relu,
-                                                             float *__restrict__ y) {
+                                                             const float *__restrict__ residual, float *__restrict__ y) {
   const int cv = C / 4;
   const long long total = R * cv;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
@@ -57,6 +57,10 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const float *__res
     float4 o;
     o.x = fmaf(v.x, sc.x, sh.x); o.y = fmaf(v.y, sc.y, sh.y); o.z = fmaf(v.z, sc.z, sh.z); o.w = fmaf(v.w, sc.w, sh.w);
     if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    if (residual) {  // added after the activation (the shortcut sum of core/backbones.py:123)
+      const float4 r = reinterpret_cast<const float4 *>(residual)[e];
+      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
     reinterpret_cast<float4 *>(y)[e] = o;
   }
 }
@@ -621,7 +625,16 @@ DH3D_API int dh3d_scale_shift_act(const float *x, long long R, int C, const floa
   DH3D_REQUIRE(x && scale && shift && y && R > 0 && C > 0);
   DH3D_SUPPORTED(C % 4 == 0);
   hipLaunchKernelGGL(scale_shift_act_kernel, dim3(flat_grid(R * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, R, C,
-                     scale, shift, relu, y);
+                     scale, shift, relu, nullptr, y);
+  return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_scale_shift_act_res(const float *x, long long R, int C, const float *scale, const float *shift, int relu,
+                                      const float *residual, float *y, void *stream) {
+  DH3D_REQUIRE(x && scale && shift && y && R > 0 && C > 0);
+  DH3D_SUPPORTED(C % 4 == 0);
+  hipLaunchKernelGGL(scale_shift_act_kernel, dim3(flat_grid(R * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, R, C,
+                     scale, shift, relu, residual, y);
   return dh3d_launch_status();
 }
 

@@ -177,6 +177,11 @@ class DH3D(nn.Module):
         return out
 
     def _check_mode(self, need_head=True):
+        if self.__dict__.get("_bn_stale"):
+            # a trainer updated the backbone's moving averages on the device (training.backbone_local_batch_stats_hip):
+            # the folded BatchNorm copies of the inference path are rebuilt now, by the first forward that needs them
+            self._bn_stale = False
+            self.invalidate()
         if self.training:
             raise NotImplementedError(
                 "training-mode BatchNorm is not implemented on the fused path; call model.eval()")

@@ -801,10 +801,18 @@ def sigmoid_bwd(datt, att, mask=None, rows_per_cloud=0):
     return dlogit, tot
 
 
-def scale_shift_act(x, scale, shift, relu, out=None):
+def scale_shift_act(x, scale, shift, relu, out=None, residual=None):
+    """y = act(x * scale[c] + shift[c]) (+ residual, added after the activation)."""
     x = L.require_cuda_f32(x, "x", 2)
     R, C = x.shape
     y = out if out is not None else torch.empty_like(x)
+    if residual is not None:
+        r = L.require_cuda_f32(residual, "residual", 2)
+        if r.shape != x.shape:
+            raise ValueError("scale_shift_act: residual shape differs")
+        L.check(L.lib().dh3d_scale_shift_act_res(L.ptr(x), R, C, L.ptr(scale), L.ptr(shift), 1 if relu else 0, L.ptr(r),
+                                                 L.ptr(y), L.stream_ptr()), "scale_shift_act_res")
+        return y
     L.check(L.lib().dh3d_scale_shift_act(L.ptr(x), R, C, L.ptr(scale), L.ptr(shift), 1 if relu else 0, L.ptr(y),
                                          L.stream_ptr()), "scale_shift_act")
     return y

@@ -153,6 +153,73 @@ def backbone_local_batch_stats(model, points, geo, sync_bn=False, mask=None):
     return feat.contiguous(), lv
 
 
+@torch.no_grad()
+def backbone_local_batch_stats_hip(model, points, geo, sync_bn=False, mask=None):
+    """backbone_local_batch_stats -- the frozen backbone normalising with BATCH statistics and updating its moving
+    averages, as the reference's global_config graph does (core/tf_utils.py:60-63,145-153; core/backbones.py:104-127)
+    -- built from the HIP kernels only, so that the whole training step stays one replayable hipGraph:
+
+      every BatchNorm site = the producing kernel with its epilogue reduced to the conv bias (raw pre-BN rows)
+                             -> dh3d_bn_colstats (f64 column sums) [-> SUM all-reduce under sync-BN]
+                             -> dh3d_bn_finalize (mean / rstd / scale / shift on the device + the EMA update of the
+                                moving averages, decay 0.9, Bessel-corrected variance)
+                             -> dh3d_scale_shift_act (BN + ReLU in one fma pass; the last one adds the shortcut)
+
+    The producers are the inference path's kernels with the SAME packed weights (the backbone is frozen: packed once):
+    conv_pointset / flex_conv_x6 / flex_conv (exact-f32 MFMA) / linear (x6) / the fused flex_pool + SE + residual
+    kernel / group_point / three_interpolate.  No tensor-op matmul, no host round trip.  The moving averages change every
+    step; the FOLDED copies the inference path keeps are marked stale (model._bn_stale) and rebuilt by the next
+    inference forward, not here.  Returns (localdesc [b, N, 128], geometry level)."""
+    from . import train_ops as T
+    if model._local.featdim < 128 or model.stage1.add_se != "max_pool":
+        raise NotImplementedError("backbone_bn='batch' covers the shipped backbone (featdim 128, max-pool SE)")
+
+    def bn_relu(x3, bnmod, residual=None):
+        b, n, c = x3.shape
+        x2 = x3.reshape(b * n, c)
+        if residual is None:
+            return T.batch_norm_train(x2, bnmod, True, sync=sync_bn, mask=mask, rows_per_cloud=n).reshape(b, n, c)
+        st = T._forward_stats(x2, bnmod.gamma.detach().contiguous(), bnmod.beta.detach().contiguous(), bnmod.mean_EMA,
+                              bnmod.variance_EMA, bnmod.eps, 0.9, mask, n, sync_bn, bool(getattr(bnmod, "ema_unbiased", True)))
+        return pm.scale_shift_act(x2, st.stats[2], st.stats[3], True, residual=residual.reshape(b * n, c)).reshape(b, n, c)
+
+    def conv_raw(x3, fc1d, x2=None):
+        conv = fc1d.tfconv0
+        p = conv._prep or conv.prepare()
+        per_cloud = x3.shape[-2]
+        if "wp3" in p and per_cloud >= 4096 and x3.shape[-1] % 32 == 0 and (x2 is None or x2.shape[-1] % 32 == 0):
+            return pm.linear_x6(x3, p["wp3"], conv.cout, x2=x2, pre_bias=p["b"])
+        return pm.linear(x3, p["wp"], conv.cout, x2=x2, pre_bias=p["b"])
+
+    def flex_stack(mod, x, xyz, nbr):
+        prep = mod._prep or mod.prepare()
+        for i, p in enumerate(prep):
+            bn = getattr(mod, "flexconv_%d_bn" % i)
+            if p["wp3"] is not None and nbr.shape[2] == 8:
+                y = pm.flex_conv_x6(x, xyz, nbr, p["wp3"], p["dout"], pre_bias=p["fb"],
+                                    reserve_cus_per_xcd=getattr(geo, "busy_cus_per_xcd", 0))
+            else:
+                y = pm.flex_conv(x, xyz, nbr, p["wp"], p["dout"], pre_bias=p["fb"])
+            x = bn_relu(y, bn)
+        return mod.se.forward_on_max_pool(x, nbr)   # flex_pool + SE + residual + ReLU: no BatchNorm inside (:45-55,76-79)
+
+    model._join_side(geo)  # the kNN of the full cloud runs on the geometry's side stream
+    nn_8 = geo.nbr if geo.nbr.shape[2] == 8 else geo.nbr[:, :, 0:8].contiguous()
+    lp = model._local._prep or model._local.prepare()
+    init = pm.conv_pointset_xyz(geo.xyz, nn_8, lp["theta"], lp["bias"])
+    init = pm.flex_pool(bn_relu(init, model.initconv_bn), nn_8)
+    x1 = flex_stack(model.stage1, init, geo.xyz, nn_8)
+    x2 = bn_relu(conv_raw(x1, model.before_stage2_conv1d), model.before_stage2_conv1d.tfconv0.bn)
+    lv = geo.level(8, model.knn_num)
+    s2 = model.stage2
+    y = flex_stack(s2, bb.gather_rows(x2, lv["idx"]), lv["xyz_s"], lv["nbr_s"])
+    up = pm.three_interpolate_idw(y, lv["nn3_idx"], lv["nn3_dist"])
+    shortcut = bn_relu(conv_raw(x1, model.local_stage1_shortcut), model.local_stage1_shortcut.tfconv0.bn)
+    feat = bn_relu(conv_raw(up, s2.concat_conv1d, x2=x2), s2.concat_conv1d.tfconv0.bn, residual=shortcut)
+    model._bn_stale = True
+    return feat, lv
+
+
 class _FlexConvFactorised(torch.autograd.Function):
     """flex_conv for the training step, point-major, in its factorised form
         out = [S0 | Sx | Sy | Sz] @ [bias; theta_x; theta_y; theta_z],  S0 = sum_k f[n_k],  Sd = sum_k dp_d(k) f[n_k]
@@ -399,8 +466,8 @@ class QuadrupletTrainer(object):
         # captured, so the CPU-test path stays eager.
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         capturable = world == 1 and not D.collectives_active() or (D.collectives_active() and dist.get_backend() == "nccl")
-        if backbone_bn == "batch":
-            capturable = False  # the backbone's moving averages change every step: its folded copies are rebuilt eagerly
+        if backbone_bn == "batch" and impl != "hip":
+            capturable = False  # the tensor-op restatement rebuilds the backbone's folded copies on the host every step
         self.graph_step = (impl == "hip" and capturable) if graph_step is None else (bool(graph_step) and capturable)
         self._zarena = pm.ZeroArena()   # the step's accumulators: one fill per step (pm.ZeroArena)
         self._garena = None     # flat gradient arena of the sharded step (all-reduced in place, .grad are views of it)
@@ -432,8 +499,12 @@ class QuadrupletTrainer(object):
         self.model.eval()
         if self.backbone_bn == "batch":  # the reference's semantics: batch statistics + moving-average updates
             geo = self.model._geometry(block, None)
-            localdesc, lv = backbone_local_batch_stats(self.model, block, geo, self.sync_bn, m)
-            self.model.invalidate()  # the folded copies of the backbone's moving averages are stale now
+            if self.impl == "hip":   # HIP kernels only, capturable (the moving averages are updated on the device)
+                localdesc, lv = backbone_local_batch_stats_hip(self.model, block, geo, self.sync_bn, m)
+                lv = {k: v for k, v in lv.items() if torch.is_tensor(v) or k == "_ordered"}
+            else:                    # the tensor-op restatement (test reference)
+                localdesc, lv = backbone_local_batch_stats(self.model, block, geo, self.sync_bn, m)
+                self.model.invalidate()  # the folded copies of the backbone's moving averages are stale now
         else:  # frozen backbone on the fused inference path (moving averages)
             localdesc, lv = self._backbone(block)
         self._mark(1)

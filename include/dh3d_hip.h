@@ -491,6 +491,10 @@ int dh3d_bn_colstats(const float *x, long long R, int C, const unsigned char *ma
                      double *sumsq, void *stream);
 int dh3d_scale_shift_act(const float *x, long long R, int C, const float *scale, const float *shift, int relu,
                          float *y, void *stream);
+/* The same pass with `residual` [R,C] (or NULL) added AFTER the activation: y = act(x*scale+shift) + residual -- the
+ * shortcut sum behind the last BatchNorm of the local backbone in training mode (core/backbones.py:123). */
+int dh3d_scale_shift_act_res(const float *x, long long R, int C, const float *scale, const float *shift, int relu,
+                             const float *residual, float *y, void *stream);
 int dh3d_row_logit_sigmoid(const float *h, long long R, int C, const float *scale, const float *shift, const float *w,
                            const float *b /* device scalar */, float *att, void *stream);
 int dh3d_bn_bwd_sums(const float *x, const float *dy, const float *rowscale, const float *colvec, long long R, int C,

@@ -124,3 +124,66 @@ def test_cfg4_gradients_hip_vs_torch_restatement(dev):
         report.append((err, n))
         assert err <= TOL_GRAD, (n, err, scale)
     print("cfg4 gradient errors (relative to the tensor's largest entry):", sorted(report, reverse=True)[:6])
+
+
+def test_cfg4_reference_semantics_backbone_runs_on_hip_kernels_only(dev, monkeypatch):
+    """The batch-statistics backbone of backbone_bn='batch' is built from HIP kernels: no tensor-op matmul / linear / relu /
+    batch_norm is reached while it runs, and it agrees with the tensor-op restatement (the round-3 form, kept as the
+    test reference) on the descriptors and on every moving average it updates."""
+    import torch.nn.functional as F
+    from dh3d_amd import training as TR
+    pts = _points().to(dev)
+    outs = {}
+    for which in ("hip", "torch"):
+        m = _build(dev)
+        geo = m._geometry(pts, None)
+        if which == "hip":
+            def banned(*a, **k):
+                raise AssertionError("a tensor-op GEMM / BatchNorm was reached inside the HIP backbone")
+            with monkeypatch.context() as mp:
+                for name in ("matmul", "mm", "bmm", "addmm", "einsum"):
+                    mp.setattr(torch, name, banned)
+                mp.setattr(torch.Tensor, "__matmul__", banned)
+                for name in ("linear", "relu", "batch_norm"):
+                    mp.setattr(F, name, banned)
+                feat, lv = TR.backbone_local_batch_stats_hip(m, pts, geo)
+        else:
+            feat, lv = TR.backbone_local_batch_stats(m, pts, geo)
+        torch.cuda.synchronize()
+        outs[which] = (feat.clone(), {k: v.clone() for k, v in m.state_dict().items() if "EMA" in k})
+    a, b = outs["hip"][0], outs["torch"][0]
+    assert a.shape == b.shape == (BT, N, 128)
+    err = float((a - b).abs().max()) / float(b.abs().max())
+    assert err <= 2e-5, err
+    assert len(outs["hip"][1]) == 16
+    for k, v in outs["hip"][1].items():
+        w = outs["torch"][1][k]
+        assert torch.allclose(v, w, rtol=1e-4, atol=1e-6), (k, float((v - w).abs().max()))
+
+
+def test_cfg4_reference_semantics_whole_step_is_replayed(dev):
+    """backbone_bn='batch' no longer forces eager steps: forward (batch-statistics backbone included), loss, backward
+    and Adam are captured into ONE hipGraph after the eager warm-up and replayed; the trajectory (losses, and the
+    backbone's moving averages, which only this mode updates) follows eager steps of the same trainer class."""
+    from dh3d_amd.training import QuadrupletTrainer
+    batches = [torch.rand(BT, 2048, 3, generator=torch.Generator().manual_seed(s)).to(dev) for s in (5, 6)]
+    res = []
+    for graph in (True, False):
+        m = _build(dev)
+        before = m.stage1.flexconv_0_bn.mean_EMA.clone()
+        tr = QuadrupletTrainer(m, start_lr=1e-5, backbone_bn="batch", graph_step=graph)
+        assert tr.graph_step == graph
+        ls = [tr.step(batches[i % 2]) for i in range(7)]
+        assert bool(tr._step_graphs) == graph
+        assert float((m.stage1.flexconv_0_bn.mean_EMA - before).abs().max()) > 1e-4  # the frozen backbone's averages move
+        res.append((ls, {k: v.clone() for k, v in m.state_dict().items() if "EMA" in k or "moving" in k}))
+    for x, y in zip(res[0][0], res[1][0]):
+        assert abs(x - y) <= 2e-3 * max(1.0, abs(y)), (res[0][0], res[1][0])
+    for k, v in res[0][1].items():
+        w = res[1][1][k]
+        assert torch.allclose(v, w, rtol=2e-3, atol=2e-5), (k, float((v - w).abs().max()))
+    # an inference forward after training sees the updated moving averages (the folded copies are rebuilt lazily)
+    m.eval()
+    with torch.no_grad():
+        o = m(batches[0][:2], fetch=("globaldesc",))
+    assert torch.isfinite(o["globaldesc"]).all() and not m.__dict__.get("_bn_stale")
