@@ -51,6 +51,9 @@ WORKLOADS = {
                    name="global-descriptor forward (global_config), N=4096, 64-cluster NetVLAD, batch=32"),
     "cfg5": dict(preset="detection_config", B=4, N=16384, seed=5005, out="xyz_feat_att", inflight=4,
                  name="dense local feature map (save_all path, detection_config), N=16384 K=8, batch=4, device kNN"),
+    "train_local": dict(preset="basic_config", B=20, N=8192, seed=6006, out=None, inflight=1,
+                        name="stage-1 training step (basic_config: 10 anchors + 10 positives, N=8192, 512 keypoints per cloud, "
+                             "desc_local_loss), whole local backbone forward + backward + Adam"),
     "train": dict(preset="global_config", B=22, N=4096, seed=4004, out=None, inflight=1,
                   name="Siamese quadruplet training step, Oxford-shaped batch (1 anchor + 2 pos + 18 neg + 1 other-neg), "
                        "N=4096, frozen backbone, batch sharded over ranks + RCCL all-gather of descriptors"),
@@ -806,9 +809,39 @@ def main():
                 tdist.destroy_process_group()
         return out
 
+    def measure_train_local():
+        """Stage-1 training (core/configs.py:35-82 basic_config: batch_size 10, num_pos 1, 8192 points, 512 keypoints):
+        the whole local backbone in training mode, forward + backward + Adam, one hipGraph per step."""
+        from dh3d_amd import ConfigFactory
+        from dh3d_amd.model import DH3D
+        from dh3d_amd.training import LocalTrainer
+        wl = WORKLOADS["train_local"]
+        cfg = ConfigFactory(wl["preset"]).getconfig()
+        model = DH3D(cfg).init_synthetic(0).to(dev).eval().prepare()
+        tr = LocalTrainer(model)
+        pairs, M = wl["B"] // 2, cfg.sampled_kpnum
+        rng = np.random.default_rng(wl["seed"])
+        anc = (rng.random((pairs, wl["N"], 3), dtype=np.float32) * 30.0).astype(np.float32)
+        Rm = np.tile(np.eye(3, dtype=np.float32), (pairs, 1, 1))
+        pos = (anc + rng.normal(0, 0.02, anc.shape)).astype(np.float32)
+        ia = np.stack([rng.permutation(wl["N"])[:M] for _ in range(pairs)]).astype(np.int32)
+        pts = torch.from_numpy(np.concatenate([anc, pos])).to(dev)
+        Rt, idx = torch.from_numpy(Rm).to(dev), torch.from_numpy(np.concatenate([ia, ia])).to(dev)
+        for _ in range(4):  # three eager steps, then the capture
+            tr.step(pts, Rt, idx)
+        key = next(iter(tr._graphs)) if tr._graphs else None
+        if key is not None:  # the batch resident in the graph's own input buffers
+            pts, Rt, idx = tr._graphs[key][1]
+        dt = time_steps(lambda p: tr.step(pts, Rt, idx, sync=False), pts, args.steps, args.warmup, dev)
+        extra = {"step_graphed": bool(tr._graphs), "trainable_tensors": len(tr.params),
+                 "losses": "desc_local_loss x local_loss_weight (core/losses.py:29-63) via losses.compute_loss"}
+        return wl["B"] * args.steps / dt, dt / args.steps * 1e3, extra
+
     def measure(workload, batch=None):
         if workload == "train":
             return measure_train()
+        if workload == "train_local":
+            return measure_train_local()
         wl = WORKLOADS[workload]
         per, total = per_rank_batch(batch or (args.batch if workload == args.workload and args.batch else wl["B"]))
         model = build_model(wl["preset"], dev, seed=0, num_points=wl["N"])
@@ -865,7 +898,7 @@ def main():
                        "note": "further timed blocks after the contract one; `value` is the first block"}
         return total * nsteps / dt, dt / nsteps * 1e3, rep
 
-    pipelined = args.inflight > 1 and args.workload != "train"
+    pipelined = args.inflight > 1 and args.workload not in ("train", "train_local")
     value, ms, info = measure(args.workload)  # one step at a time (the definition of rounds 1-2; `value` for train)
     serial = {"value": value, "unit": "point-clouds/sec", "ms_per_step": ms,
               "note": "each step finishes before the next one starts (rounds 1-2 reported this as `value`)"}
@@ -899,8 +932,14 @@ def main():
     }
     if in_flight_error:
         line["in_flight_error"] = in_flight_error
-    if args.workload != "train":
+    if args.workload not in ("train", "train_local"):
         line["one_step_at_a_time"] = serial
+    if args.workload == "train_local":
+        line["config"]["execution"] = ("whole step (local backbone fwd/bwd in training mode, loss, weight decay, fused Adam) "
+                                       "replayed as one hipGraph" if info.get("step_graphed") else "eager")
+        line["config"]["parallelism"] = "single GPU (LocalTrainer has no sharded path yet: DESIGN.md 6)"
+        line["config"].pop("knn", None)
+        line.update(info)
     if "repeats" in info:
         line["repeats"] = info["repeats"]
     if args.workload == "train":

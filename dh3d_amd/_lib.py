@@ -73,6 +73,12 @@ _SIGNATURES = {
     "dh3d_bn_colstats": [c_fp, c_ll, c_int, c_fp, c_int, c_fp, c_fp, c_fp],
     "dh3d_bn_finalize": [c_fp, c_fp, c_fp, c_fp, c_fp, c_float, c_float, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp],
     "dh3d_scale_shift_act": [c_fp, c_ll, c_int, c_fp, c_fp, c_int, c_fp, c_fp],
+    "dh3d_flex_pool_pm_bwd": [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp],
+    "dh3d_se_gate_fwd": [c_fp, c_fp, c_ll, c_fp, c_fp],
+    "dh3d_se_gate_bwd": [c_fp, c_fp, c_fp, c_ll, c_fp, c_fp, c_fp],
+    "dh3d_relu_fwd": [c_fp, c_ll, c_fp, c_fp],
+    "dh3d_relu_bwd": [c_fp, c_fp, c_ll, c_fp, c_fp],
+    "dh3d_pointset_sum_pm": [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp],
     "dh3d_scale_shift_act_res": [c_fp, c_ll, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_fp],
     "dh3d_row_logit_sigmoid": [c_fp, c_ll, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp],
     "dh3d_bn_bwd_sums": [c_fp, c_fp, c_fp, c_fp, c_ll, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_int,

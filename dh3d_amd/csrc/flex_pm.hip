@@ -512,6 +512,15 @@ DH3D_API int dh3d_conv_pointset_pm_fwd(const float *xyz, const int32_t *nbr, con
   return dh3d_launch_status();
 }
 
+DH3D_API int dh3d_pointset_sum_pm(const float *xyz, const int32_t *nbr, int B, int N, int K, float *S, void *stream) {
+  DH3D_REQUIRE(xyz && nbr && S && B > 0 && N > 0);
+  DH3D_SUPPORTED(K == 8);
+  const long long R = (long long)B * N;
+  hipLaunchKernelGGL(pointset_sum_kernel, dim3(dh3d_cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, xyz, nbr, R, N,
+                     reinterpret_cast<float4 *>(S));
+  return dh3d_launch_status();
+}
+
 DH3D_API int dh3d_conv_pointset_pool_pm_fwd(const float *xyz, const int32_t *nbr, const float *theta, const float *bias,
                                             int B, int N, int K, int Dout, const dh3d_epilogue *ep, float *scratch,
                                             float *out, void *stream) {

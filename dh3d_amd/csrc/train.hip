@@ -596,6 +596,70 @@ __global__ __launch_bounds__(256) void l2norm_rows_bwd_kernel(const float *__res
   for (int c = lane; c < C; c += 64) dx[row * C + c] = fmaf(-x[row * C + c], k, inv * dxn[row * C + c]);
 }
 
+// ------------------------------------------------------------------ local-backbone training: element-wise passes
+// (stage-1/2 training step, dh3d_amd/training.py LocalTrainer; core/model.py:212-246 with basic_config / detection_config)
+// FlexPoolGrad on point-major rows (flex_pool_kernel_gpu.cu.cc:65-93: the gradient of an output goes to the neighbour
+// that won the maximum -- argmax holds its point id within the cloud): din[cloud0 + argmax[n,c], c] += dout[n,c].
+__global__ __launch_bounds__(256) void flex_pool_pm_bwd_kernel(const float *__restrict__ dout,
+                                                              const int32_t *__restrict__ argmax, long long R, int N,
+                                                              int C, float *__restrict__ din) {
+  const long long total = R * C;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long n = e / C;
+    const int c = (int)(e - n * C);
+    const long long cloud0 = (n / N) * N;
+    atomicAdd(din + (cloud0 + argmax[e]) * C + c, dout[e]);
+  }
+}
+
+// y = relu(x + x * sigmoid(z))   (se_res_bottleneck's tail, core/backbones.py:52-55), float4 per lane
+__global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float4 *__restrict__ x, const float4 *__restrict__ z,
+                                                         long long n4, float4 *__restrict__ y) {
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long long)gridDim.x * 256) {
+    const float4 a = x[e], b = z[e];
+    float4 o;
+    o.x = fmaxf(a.x + a.x * (1.f / (1.f + __expf(-b.x))), 0.f);
+    o.y = fmaxf(a.y + a.y * (1.f / (1.f + __expf(-b.y))), 0.f);
+    o.z = fmaxf(a.z + a.z * (1.f / (1.f + __expf(-b.z))), 0.f);
+    o.w = fmaxf(a.w + a.w * (1.f / (1.f + __expf(-b.w))), 0.f);
+    y[e] = o;
+  }
+}
+
+__device__ __forceinline__ void se_gate_bwd1(float x, float z, float dy, float &dx, float &dz) {
+  const float g = 1.f / (1.f + __expf(-z));
+  const float dt = (x + x * g) > 0.f ? dy : 0.f;
+  dx = dt * (1.f + g);
+  dz = dt * x * g * (1.f - g);
+}
+__global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float4 *__restrict__ x, const float4 *__restrict__ z,
+                                                         const float4 *__restrict__ dy, long long n4,
+                                                         float4 *__restrict__ dx, float4 *__restrict__ dz) {
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long long)gridDim.x * 256) {
+    const float4 a = x[e], b = z[e], g = dy[e];
+    float4 ox, oz;
+    se_gate_bwd1(a.x, b.x, g.x, ox.x, oz.x); se_gate_bwd1(a.y, b.y, g.y, ox.y, oz.y);
+    se_gate_bwd1(a.z, b.z, g.z, ox.z, oz.z); se_gate_bwd1(a.w, b.w, g.w, ox.w, oz.w);
+    dx[e] = ox; dz[e] = oz;
+  }
+}
+
+// mode 0: y = relu(x);  mode 1: dx = y > 0 ? dy : 0   (a = x | y, b = unused | dy)
+__global__ __launch_bounds__(256) void relu_kernel(const float4 *__restrict__ a, const float4 *__restrict__ b, long long n4,
+                                                  int mode, float4 *__restrict__ o) {
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long long)gridDim.x * 256) {
+    const float4 v = a[e];
+    float4 r;
+    if (mode == 0) {
+      r = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+    } else {
+      const float4 g = b[e];
+      r = make_float4(v.x > 0.f ? g.x : 0.f, v.y > 0.f ? g.y : 0.f, v.z > 0.f ? g.z : 0.f, v.w > 0.f ? g.w : 0.f);
+    }
+    o[e] = r;
+  }
+}
+
 inline int flat_grid(long long work) {
   long long g = (work + 255) / 256;
   return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
@@ -617,6 +681,51 @@ DH3D_API int dh3d_bn_colstats(const float *x, long long R, int C, const unsigned
   const int chunks = row_chunks(R, &rows_per);
   hipLaunchKernelGGL(colstats_kernel, dim3(dh3d_cdiv(C, 64), chunks), dim3(256), 0, s, x, R, C, rows_per, mask,
                      rows_per_cloud > 0 ? rows_per_cloud : 1, sum, sumsq);
+  return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_flex_pool_pm_bwd(const float *dout, const int32_t *argmax, int B, int N, int C, float *din, void *stream) {
+  DH3D_REQUIRE(dout && argmax && din && B > 0 && N > 0 && C > 0);
+  const long long R = (long long)B * N;
+  hipLaunchKernelGGL(flex_pool_pm_bwd_kernel, dim3(flat_grid(R * C)), dim3(256), 0, (hipStream_t)stream, dout, argmax, R, N, C,
+                     din);
+  return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_se_gate_fwd(const float *x, const float *z, long long n, float *y, void *stream) {
+  DH3D_REQUIRE(x && z && y && n > 0);
+  DH3D_SUPPORTED(n % 4 == 0);
+  hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(z), n / 4,
+                     reinterpret_cast<float4 *>(y));
+  return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_se_gate_bwd(const float *x, const float *z, const float *dy, long long n, float *dx, float *dz,
+                              void *stream) {
+  DH3D_REQUIRE(x && z && dy && dx && dz && n > 0);
+  DH3D_SUPPORTED(n % 4 == 0);
+  hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(z),
+                     reinterpret_cast<const float4 *>(dy), n / 4, reinterpret_cast<float4 *>(dx),
+                     reinterpret_cast<float4 *>(dz));
+  return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_relu_fwd(const float *x, long long n, float *y, void *stream) {
+  DH3D_REQUIRE(x && y && n > 0);
+  DH3D_SUPPORTED(n % 4 == 0);
+  hipLaunchKernelGGL(relu_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4 *>(x), (const float4 *)nullptr, n / 4, 0, reinterpret_cast<float4 *>(y));
+  return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_relu_bwd(const float *y, const float *dy, long long n, float *dx, void *stream) {
+  DH3D_REQUIRE(y && dy && dx && n > 0);
+  DH3D_SUPPORTED(n % 4 == 0);
+  hipLaunchKernelGGL(relu_kernel, dim3(flat_grid(n / 4)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4 *>(y), reinterpret_cast<const float4 *>(dy), n / 4, 1,
+                     reinterpret_cast<float4 *>(dx));
   return dh3d_launch_status();
 }
 

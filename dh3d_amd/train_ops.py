@@ -573,3 +573,108 @@ def context_gate(v, g):
 def netvlad_assign(x, att, Wc, bnmod, sync=False, mask=None):
     return _NetVLADAssign.apply(x, att, Wc, bnmod.gamma, bnmod.beta, bnmod.moving_mean, bnmod.moving_variance, bnmod.eps,
                                 0.999, sync, mask)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Local backbone in training mode (stage 1-2 training: basic_config / detection_config, core/model.py:212-246): the nodes
+# the frozen-backbone step never needed -- conv_pointset, flex_pool, the SE gate, a plain ReLU -- point-major, forward and
+# backward on HIP kernels (include/dh3d_hip.h: dh3d_pointset_sum_pm, dh3d_flex_pool_pm_bwd, dh3d_se_gate_*, dh3d_relu_*).
+from . import _lib as _L
+
+
+class _ConvPointsetXYZ(torch.autograd.Function):
+    """conv_pointset on the coordinates (Din = 3): out = theta^T S + bias with S[n] = sum_k (p[n_k] - p[n_0])
+    (conv_pointset_kernel.cc:46-64).  Backward = ConvPointsetGrad (conv_pointset_kernel_gpu.cu.cc:157-347) in its
+    factorised form: grad_theta = S^T grad_out (one split-reduction GEMM over the rows), grad_bias = column sums; the
+    coordinates are data."""
+
+    @staticmethod
+    def forward(ctx, xyz, nbr, theta, bias):
+        out = pm.conv_pointset_xyz(xyz, nbr, theta.detach().contiguous(), bias.detach().contiguous())
+        ctx.save_for_backward(xyz, nbr)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xyz, nbr = ctx.saved_tensors
+        B, N, _ = xyz.shape
+        d2 = dout.reshape(B * N, -1).contiguous()
+        S = torch.empty((B * N, 4), dtype=torch.float32, device=xyz.device)
+        _L.check(_L.lib().dh3d_pointset_sum_pm(_L.ptr(xyz), _L.ptr(nbr), B, N, nbr.shape[2], _L.ptr(S), _L.stream_ptr()),
+                 "pointset_sum")
+        dtheta = pm.gemm_tn(S, d2)[:3]          # [4, Dout]: the fourth row of S is zero padding
+        return None, None, dtheta, pm.colsum(d2)
+
+
+def conv_pointset_xyz(xyz, nbr, theta, bias):
+    return _ConvPointsetXYZ.apply(xyz.contiguous(), nbr.contiguous(), theta, bias)
+
+
+class _FlexPoolPM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, nbr):
+        out, arg = pm.flex_pool(x.contiguous(), nbr, want_argmax=True)
+        ctx.save_for_backward(arg)
+        ctx.n = x.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (arg,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        B, N, C = dout.shape
+        din = pm.zeros((B, N, C), torch.float32, dout.device)
+        _L.check(_L.lib().dh3d_flex_pool_pm_bwd(_L.ptr(dout), _L.ptr(arg), B, N, C, _L.ptr(din), _L.stream_ptr()),
+                 "flex_pool_pm_bwd")
+        return din, None
+
+
+def flex_pool(x, nbr):
+    """x [B,N,C], nbr [B,N,K] -> max over the neighbourhood, differentiable (FlexPool / FlexPoolGrad)."""
+    return _FlexPoolPM.apply(x, nbr)
+
+
+class _SEGate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, z):
+        x, z = x.contiguous(), z.contiguous()
+        y = torch.empty_like(x)
+        _L.check(_L.lib().dh3d_se_gate_fwd(_L.ptr(x), _L.ptr(z), x.numel(), _L.ptr(y), _L.stream_ptr()), "se_gate_fwd")
+        ctx.save_for_backward(x, z)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, z = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx, dz = torch.empty_like(x), torch.empty_like(z)
+        _L.check(_L.lib().dh3d_se_gate_bwd(_L.ptr(x), _L.ptr(z), _L.ptr(dy), x.numel(), _L.ptr(dx), _L.ptr(dz),
+                                           _L.stream_ptr()), "se_gate_bwd")
+        return dx, dz
+
+
+def se_gate(x, z):
+    """relu(x + x * sigmoid(z))  (core/backbones.py:52-55)."""
+    return _SEGate.apply(x, z)
+
+
+class _ReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        _L.check(_L.lib().dh3d_relu_fwd(_L.ptr(x), x.numel(), _L.ptr(y), _L.stream_ptr()), "relu_fwd")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        _L.check(_L.lib().dh3d_relu_bwd(_L.ptr(y), _L.ptr(dy), y.numel(), _L.ptr(dx), _L.stream_ptr()), "relu_bwd")
+        return dx
+
+
+def relu(x):
+    return _ReLU.apply(x)

@@ -737,3 +737,214 @@ class QuadrupletTrainer(object):
         self._mark(4)
         self.model.invalidate(head_only=True)  # the packed / folded weight copies of the fused inference path are stale now
         return loss.detach()
+
+
+# ======================================================================================================================
+# Stage 1-2 training: the LOCAL backbone (+ the detector) trained with desc_local_loss / local_detection_loss_nn
+# (core/model.py:135-246 with core/configs.py:35-102 basic_config / detection_config, core/losses.py:29-133).
+def local_backbone_train(model, points, geo, sync_bn=False, mask=None):
+    """backbone_local_dilate (core/backbones.py:104-127) in TRAINING mode with autograd: every BatchNorm on batch
+    statistics (moving averages updated), every operator a HIP kernel in both directions --
+      conv_pointset / ConvPointsetGrad (factorised: grad_theta = S^T grad_out), flex_pool / FlexPoolGrad (argmax scatter),
+      flex_conv / FlexConvGrad in the factorised form at FULL resolution (S^T dOut, dOut W^T on the MFMA pipe, the
+      feature gradient scattered over the neighbour lists), the 1x1 convs as f32-accurate GEMMs (x W, dy W^T, x^T dy),
+      BatchNorm-train (two passes per direction), the SE gate, group_point / three_interpolate with their gradients.
+    What torch contributes is autograd's bookkeeping, one concatenation and the residual add.
+    points [Bt,N,3]; geo: model._geometry(points) (kNN, FPS level -- integer work, no gradient).  Returns the
+    un-normalised descriptors [Bt,N,128]."""
+    from . import train_ops as T
+    if model._local.featdim < 128 or model.stage1.add_se != "max_pool" or model.stage2.add_se != "max_pool":
+        raise NotImplementedError("LocalTrainer covers the shipped backbone (featdim 128, max-pool SE)")
+    Bt, N, _ = points.shape
+
+    def bn_relu(x3, bnmod):
+        b, n, c = x3.shape
+        return T.batch_norm_train(x3.reshape(b * n, c), bnmod, True, sync=sync_bn, mask=mask, rows_per_cloud=n).reshape(b, n, c)
+
+    def conv_bnrelu(x3, fc1d):
+        conv = fc1d.tfconv0
+        b, n, c = x3.shape
+        h = T.linear(x3.reshape(b * n, c), conv.W.reshape(conv.cin, conv.cout), conv.b)
+        return T.batch_norm_train(h, conv.bn, True, sync=sync_bn, mask=mask, rows_per_cloud=n).reshape(b, n, conv.cout)
+
+    def flex_stack(mod, x, xyz, nbr):
+        for i in range(len(mod.outdims)):
+            fc, bn = getattr(mod, "flexconv_%d" % i), getattr(mod, "flexconv_%d_bn" % i)
+            y = flex_conv_factorised(x, xyz, nbr, fc.position_theta, fc.position_bias)
+            x = bn_relu(T.add_channel_bias(y, fc.feature_bias.reshape(-1)), bn)
+        b, n, c = x.shape
+        se = mod.se
+        pool = T.flex_pool(x, nbr)                                                           # backbones.py:76-79
+        f1, f2 = se.f1.tfconv0, se.f2.tfconv0
+        sq = T.relu(T.linear(pool.reshape(b * n, c), f1.W.reshape(f1.cin, f1.cout), f1.b))
+        z = T.linear(sq, f2.W.reshape(f2.cin, f2.cout), f2.b)
+        return T.se_gate(x, z.reshape(b, n, c))                                              # relu(x + x * sigmoid(z))
+
+    model._join_side(geo)  # the kNN of the full cloud runs on the geometry's side stream
+    nn_8 = geo.nbr if geo.nbr.shape[2] == 8 else geo.nbr[:, :, 0:8].contiguous()
+    ic = model.initconv
+    init = T.conv_pointset_xyz(geo.xyz, nn_8, ic.position_theta, ic.position_bias)
+    init = T.flex_pool(bn_relu(init, model.initconv_bn), nn_8)
+    x1 = flex_stack(model.stage1, init, geo.xyz, nn_8)
+    x2 = conv_bnrelu(x1, model.before_stage2_conv1d)
+    lv = geo.level(8, model.knn_num)
+    s2 = model.stage2
+    feat_s = ops.group_point(x2, lv["idx"].unsqueeze(2)).squeeze(2)                          # [Bt,M,64], differentiable
+    y = flex_stack(s2, feat_s, lv["xyz_s"], lv["nbr_s"])
+    up = ops.three_interpolate(y, lv["nn3_idx"], pm.idw_weights(lv["nn3_dist"]))             # backbones.py:89-95
+    x2 = conv_bnrelu(torch.cat([up, x2], 2), s2.concat_conv1d)                               # :98-100
+    return conv_bnrelu(x1, model.local_stage1_shortcut) + x2                                 # :123
+
+
+def detection_block_train(model, feat, sync_bn=False, mask=None):
+    """detection_block (core/backbones.py:132-151) in training mode on rows feat [Bt,N,128]: Conv2D + BNReLU chain as
+    GEMM + BatchNorm-train nodes, the last wide layer + the 1-channel logit + sigmoid as the fused attention-head node
+    (its [R, 1024] pre-activation is the only tensor of that width).  Returns att [Bt,N,1]."""
+    from . import train_ops as T
+    det = model.detection_block_reliable
+    Bt, N, C = feat.shape
+    x = feat.reshape(Bt * N, C)
+    nconv = len(det.conv_dims)
+    for i in range(nconv - 1):
+        conv = getattr(det, "detec_conv%d" % i)
+        x = T.batch_norm_train(T.linear(x, conv.W.reshape(conv.cin, conv.cout), conv.b), conv.bn, True, sync=sync_bn,
+                               mask=mask, rows_per_cloud=N)
+    last, fcw = getattr(det, "detec_conv%d" % (nconv - 1)), det.detec_conv_fc
+    att = T.attention_head(x, last, fcw.W, fcw.b, sync_bn, mask, N)
+    return att.reshape(Bt, N, 1)
+
+
+def local_training_outputs(model, points, R, sample_idx, sync_bn=False, mask=None):
+    """The named outputs the local losses read (core/model.py:166-199): 'xyz', 'feat', 'local_desc', 'R',
+    'sample_nodes_concat', 'xyz_sampled', 'feat_sampled' (+ 'attention', 'att_sampled' with config.detection).
+    points [2B,N,3] = [anchors | positives]; R [B,3,3]; sample_idx [2B,M] int32: the keypoint indices the data loader
+    supplies as sample_ind_anchor / sample_ind_pos (model.py:159-163).  `backbones.subsample(points, feat, kpnum,
+    kp_idx=...)` that model.py:187 calls does not exist upstream; with the indices given it can only be the gather of
+    those rows (group_point), which is what runs here."""
+    from . import train_ops as T
+    cfg = model.config
+    Bt, N, _ = points.shape
+    geo = model._geometry(points, None)
+    feat = local_backbone_train(model, points, geo, sync_bn, mask)
+    desc = T.l2_normalize_rows(feat.reshape(Bt * N, -1), 1e-8).reshape(Bt, N, -1)            # model.py:177
+    kp = sample_idx.to(torch.int32).reshape(Bt, -1, 1).contiguous()
+    outs = {"xyz": points, "feat": feat, "local_desc": desc, "R": R, "sample_nodes_concat": kp,
+            "xyz_sampled": ops.group_point(points, kp).squeeze(2), "feat_sampled": ops.group_point(desc, kp).squeeze(2)}
+    if cfg.detection:
+        freeze_det = bool(cfg.get("freezedetection"))
+        att = detection_block_train(model, feat.detach() if freeze_det else feat, sync_bn, mask)
+        outs["attention"] = att
+        outs["att_sampled"] = ops.group_point(att, kp).squeeze(2)                            # model.py:196
+    return outs
+
+
+def local_trainable_parameters(model):
+    """Everything basic_config / detection_config train (freezebackbone / freezedetection False, configs.py:41-43): the
+    local backbone and, with config.detection, the detector."""
+    mods = [model._local] + ([model.detection_block_reliable] if model.config.detection else [])
+    seen, out = set(), []
+    for mod in mods:
+        for p in mod.parameters():
+            if id(p) not in seen:
+                seen.add(id(p))
+                out.append(p)
+    return out
+
+
+class LocalTrainer(object):
+    """Stage 1-2 training step on ONE GPU: forward of the whole local backbone in training mode (local_backbone_train),
+    desc_local_loss (+ local_detection_loss_nn x det_loss_weight with detection_config) through losses.compute_loss as
+    core/model.py:212-237 assembles them, backward, L2 weight decay on '.*/W', Adam with the staircase learning rate
+    (model.py:238-255).  After three eager steps on a batch shape the whole step -- ~500 launches -- is captured into one
+    hipGraph and replayed from its own input buffers."""
+
+    def __init__(self, model, start_lr=None, decay_step=None, decay_rate=None, weight_decay=None, graph_step=True):
+        self.model, self.cfg = model, model.config
+        c = self.cfg
+        if c.extract_global:
+            raise ValueError("LocalTrainer trains basic_config / detection_config (extract_global False); the global "
+                             "stage is QuadrupletTrainer")
+        start_lr = start_lr if start_lr is not None else (c.start_lr or 5e-4)
+        decay_step = decay_step if decay_step is not None else (c.decay_step or 10000)
+        decay_rate = decay_rate if decay_rate is not None else (c.decay_rate or 0.5)
+        if weight_decay is None:
+            weight_decay = (c.train_weight_decay or 1e-5) if c.add_weight_decay is not False else 0.0
+        self.weight_decay = weight_decay
+        self.params = local_trainable_parameters(model)
+        self.wd_params = [p for n, p in model.named_parameters() if n.endswith(".W") and any(p is q for q in self.params)]
+        self.graph_step = bool(graph_step) and self.params[0].is_cuda
+        self._sched = (float(start_lr), int(decay_step), float(decay_rate))
+        self._steps_done, self._graphs, self._eager_seen, self._shape_demand = 0, {}, {}, {}
+        self._zarena = pm.ZeroArena()
+        dev = self.params[0].device
+        self._lr = torch.tensor(float(start_lr), dtype=torch.float32, device=dev)
+        self._lr_value = float(start_lr)
+        if self.params[0].is_cuda:
+            self.opt = torch.optim.Adam(self.params, lr=self._lr, capturable=True, fused=True)
+        else:
+            self.opt = torch.optim.Adam(self.params, lr=float(start_lr))
+        self.keep_grads, self.last_grads, self.last_outs = False, None, None
+
+    def _set_lr(self):
+        lr0, dstep, drate = self._sched
+        lr = lr0 * drate ** (self._steps_done // dstep)
+        if lr != self._lr_value:
+            self._lr.fill_(lr)
+            self._lr_value = lr
+
+    def forward_loss(self, points, R, sample_idx):
+        outs = local_training_outputs(self.model, points, R, sample_idx)
+        if self.keep_grads:
+            self.last_outs = outs
+        return losses.compute_loss(outs, self.cfg)
+
+    def _body(self, arena, points, R, sample_idx):
+        with pm.zero_arena(arena):
+            arena.begin(points.device)
+            loss = self.forward_loss(points, R, sample_idx)
+            loss.backward()
+        if self.wd_params and self.weight_decay:
+            gs = [p.grad for p in self.wd_params if p.grad is not None]
+            ps = [p.detach() for p in self.wd_params if p.grad is not None]
+            if gs:
+                torch._foreach_add_(gs, ps, alpha=self.weight_decay)   # d/dp [wd/2 * sum p^2] (model.py:239-243)
+        return loss
+
+    def step(self, points, R, sample_idx, sync=True):
+        """One optimisation step on (points [2B,N,3], R [B,3,3], sample_idx [2B,M] int32); returns the loss (a float, or
+        the device scalar with sync=False)."""
+        self.model.eval()  # (the module flag: the training-mode graph is built explicitly, the fused path stays usable)
+        sample_idx = sample_idx.to(torch.int32)
+        key = (tuple(points.shape), tuple(R.shape), tuple(sample_idx.shape), points.device)
+        graphed = self.graph_step and self._eager_seen.get(key, 0) >= 3 and not self.keep_grads
+        if graphed:
+            ent = self._graphs.get(key)
+            if ent is None:
+                static = (points.clone(), R.clone(), sample_idx.clone())
+                arena = pm.ZeroArena(fixed_bytes=self._shape_demand.get(key, self._zarena.peak), device=points.device)
+                self.opt.zero_grad(set_to_none=True)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    loss = self._body(arena, *static)
+                    self.opt.step()
+                ent = (graph, static, loss, arena)
+                self._graphs[key] = ent
+            graph, static, loss, _ = ent
+            for dst, src in zip(static, (points, R, sample_idx)):
+                if dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src)
+            self._set_lr()
+            graph.replay()
+        else:
+            self._eager_seen[key] = self._eager_seen.get(key, 0) + 1
+            self._set_lr()
+            self.opt.zero_grad(set_to_none=True)
+            loss = self._body(self._zarena, points, R, sample_idx)
+            self._shape_demand[key] = max(self._shape_demand.get(key, 0), self._zarena.demand)
+            if self.keep_grads:
+                self.last_grads = [None if p.grad is None else p.grad.detach().clone() for p in self.params]
+            self.opt.step()
+        self._steps_done += 1
+        self.model._bn_stale = True   # moving averages and weights moved: the inference path re-folds on its next forward
+        loss = loss.detach()
+        return float(loss) if sync else loss

@@ -289,6 +289,11 @@ int dh3d_conv_pointset_pm_fwd(const float *xyz, const int32_t *nbr, const float 
                               const float *bias, int B, int N, int K, int Dout,
                               const dh3d_epilogue *ep, float *out, void *stream);
 
+/* S[n] = sum_k (xyz[nbr[n,k]] - xyz[nbr[n,0]]) as [B*N, 4] floats (x, y, z, 0): the one 3-vector conv_pointset on
+ * coordinates is linear in (conv_pointset_kernel.cc:46-64, Din = 3) -- out = theta^T S + bias, grad_theta = S^T grad_out
+ * (ConvPointsetGrad, conv_pointset_kernel_gpu.cu.cc:157-347, as one GEMM).  K == 8. */
+int dh3d_pointset_sum_pm(const float *xyz, const int32_t *nbr, int B, int N, int K, float *S, void *stream);
+
 /* conv_pointset on the coordinates (Din = 3) -> epilogue (bias once, BatchNorm, activation) -> flex_pool over the same
  * neighbourhoods, fused (core/backbones.py:107-110; conv_pointset_kernel.cc:46-64 + flex_pool_kernel.cc:41-57): the
  * [B,N,Dout] map between the two is never materialised.  out [B,N,Dout] = max_k act(bn(conv[nbr[n,k]])).  K == 8,
@@ -495,6 +500,18 @@ int dh3d_scale_shift_act(const float *x, long long R, int C, const float *scale,
  * shortcut sum behind the last BatchNorm of the local backbone in training mode (core/backbones.py:123). */
 int dh3d_scale_shift_act_res(const float *x, long long R, int C, const float *scale, const float *shift, int relu,
                              const float *residual, float *y, void *stream);
+
+/* Element-wise / scatter passes of the LOCAL backbone's training step (stage 1-2: basic_config / detection_config,
+ * core/model.py:212-246; dh3d_amd/training.py LocalTrainer), point-major rows:
+ *   dh3d_flex_pool_pm_bwd : FlexPoolGrad (flex_pool_kernel_gpu.cu.cc:65-93) -- din[cloud(n) + argmax[n,c], c] += dout[n,c]
+ *                           with f32 atomics (as the reference); din [B*N, C] zeroed by the CALLER;
+ *   dh3d_se_gate_fwd/_bwd : y = relu(x + x * sigmoid(z)) and its gradients (se_res_bottleneck's tail, backbones.py:52-55);
+ *   dh3d_relu_fwd/_bwd    : y = relu(x);  dx = y > 0 ? dy : 0.   Element counts are multiples of 4. */
+int dh3d_flex_pool_pm_bwd(const float *dout, const int32_t *argmax, int B, int N, int C, float *din, void *stream);
+int dh3d_se_gate_fwd(const float *x, const float *z, long long n, float *y, void *stream);
+int dh3d_se_gate_bwd(const float *x, const float *z, const float *dy, long long n, float *dx, float *dz, void *stream);
+int dh3d_relu_fwd(const float *x, long long n, float *y, void *stream);
+int dh3d_relu_bwd(const float *y, const float *dy, long long n, float *dx, void *stream);
 int dh3d_row_logit_sigmoid(const float *h, long long R, int C, const float *scale, const float *shift, const float *w,
                            const float *b /* device scalar */, float *att, void *stream);
 int dh3d_bn_bwd_sums(const float *x, const float *dy, const float *rowscale, const float *colvec, long long R, int C,

@@ -291,3 +291,34 @@ def training_step_forward(points, w, batch_size=1, num_pos=2, num_neg=18, other_
     else:
         loss = losses_np.lazy_triplet_loss(desc, batch_size, num_pos, num_neg, margin1)
     return float(loss), outs, st.updates
+
+
+def local_training_step_forward(points, R, sample_idx, w, config, **fw):
+    """Forward half of the stage 1-2 training step (core/model.py:135-236 with basic_config / detection_config,
+    core/configs.py:35-102): [anchors | positives] [2B,N,3] through the local backbone (and the detector) in TRAINING mode
+    -- every BatchNorm on batch statistics --, l2-normalised descriptors (model.py:177), the rows at the loader's keypoint
+    indices `sample_idx` [2B,M] (model.py:159-163,185-196; `backbones.subsample(..., kp_idx=)` does not exist upstream:
+    with the indices given it is the gather of those rows), then the losses exactly as compute_loss assembles them
+    (model.py:212-237: every loss called with **config, scaled by its *_loss_weight).  config: a mapping with the keys of
+    core/configs.py.  Returns (loss, outs, updates): `updates` = every moving-average variable after the step."""
+    from . import losses_np
+    cfg = dict(config)
+    st = TrainState(backbone_batch_stats=True)
+    detection = bool(cfg.get("detection"))
+    net = forward(points, w, detection=detection, extract_global=False, train=st, **fw)
+    kp = np.ascontiguousarray(np.asarray(sample_idx, np.int32)[:, :, None])
+    pts = np.ascontiguousarray(points, np.float32)
+    outs = {"xyz": pts, "feat": net["feat"], "local_desc": net["feat_l2normed"], "R": np.asarray(R, np.float32),
+            "sample_nodes_concat": kp, "xyz_sampled": O.group_point(pts, kp)[:, :, 0, :],
+            "feat_sampled": O.group_point(np.ascontiguousarray(net["feat_l2normed"]), kp)[:, :, 0, :]}
+    loss = np.float32(0)
+    if cfg.get("add_local_loss"):
+        w_loc = cfg.get("local_loss_weight")
+        loss = loss + np.float32(1.0 if w_loc is None else w_loc) * losses_np.desc_local_loss(outs, **cfg)
+    if detection:
+        outs["attention"] = net["attention"]
+        outs["att_sampled"] = O.group_point(np.ascontiguousarray(net["attention"]), kp)[:, :, 0, :]
+        if cfg.get("add_det_loss"):
+            w_det = cfg.get("det_loss_weight")
+            loss = loss + np.float32(1.0 if w_det is None else w_det) * losses_np.local_detection_loss_nn(outs, **cfg)
+    return float(loss), outs, st.updates
