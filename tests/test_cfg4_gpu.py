@@ -190,3 +190,71 @@ def test_cfg4_reference_semantics_whole_step_is_replayed(dev):
     with torch.no_grad():
         o = m(batches[0][:2], fetch=("globaldesc",))
     assert torch.isfinite(o["globaldesc"]).all() and not m.__dict__.get("_bn_stale")
+
+
+def test_cfg4_gradients_vs_float64_central_differences_of_the_oracle_graph(dev):
+    """The HIP backward anchored on something that is NOT autograd: float64 central differences of the oracle's training
+    graph (oracle/fd_np.head_loss_f64: the trainable head restated in float64 numpy on the float32 oracle's frozen
+    descriptors and integer geometry; its loss agrees with oracle/model_np.training_step_forward to float32 rounding) along
+    one random direction per trainable tensor, against the projection of the HIP gradient on that direction."""
+    from dh3d_amd import ConfigFactory
+    from dh3d_amd.model import DH3D, tf_variable_name
+    from dh3d_amd.training import QuadrupletTrainer, trainable_head_parameters
+    from oracle import fd_np, model_np
+    b, p, ng, n = 1, 2, 3, 2048
+    cfg = ConfigFactory("global_config").getconfig()
+    cfg.batch_size, cfg.num_pos, cfg.num_neg, cfg.num_points = b, p, ng, n
+    m = DH3D(cfg).init_synthetic(13).to(dev).eval().prepare()
+    g = torch.Generator().manual_seed(14)
+    with torch.no_grad():
+        for name, prm in m.named_parameters():
+            if name.endswith("gamma"):
+                prm.copy_((0.75 + 0.5 * torch.rand(prm.shape, generator=g)).to(dev))
+    bt = b * (1 + p + ng + 1)
+    pts = np.random.default_rng(15).random((bt, n, 3), dtype=np.float32)
+    # HIP: loss + gradients of one step's forward / backward (no weight decay: it is added to the gradients separately)
+    tr = QuadrupletTrainer(m, sync_bn=False, impl="hip", graph_step=False, graph_backbone=False)
+    loss = tr.forward_loss(torch.from_numpy(pts).to(dev))
+    loss.backward()
+    names = {id(q): tf_variable_name(k) for k, q in m.named_parameters()}
+    grads = {names[id(q)]: q.grad.detach().double().cpu().numpy() for q in trainable_head_parameters(m) if q.grad is not None}
+    # the float32 oracle: frozen descriptors + integer geometry, and its own loss
+    w = _weights_np_fresh(m)
+    trace = {}
+    exp_loss, outs, _ = model_np.training_step_forward(pts, w, batch_size=b, num_pos=p, num_neg=ng, backbone_batch_stats=False,
+                                                       trace=trace)
+    sc = "global_before_assemble"
+    frozen = (pts, outs["feat"], trace[sc + "/fps_idx"], trace[sc + "/knn"], trace[sc + "/nn3_idx"], trace[sc + "/nn3_dist"])
+    f = lambda ww: fd_np.head_loss_f64(ww, *frozen, b, p, ng, cfg.global_triplet_margin, cfg.global_quadruplet_margin)
+    l64 = f(w)
+    assert abs(l64 - exp_loss) <= 2e-5 * max(1.0, abs(exp_loss)), (l64, exp_loss)       # the f64 graph IS the oracle's graph
+    assert abs(l64 - float(loss)) <= 1e-4 * max(1.0, abs(l64)), (l64, float(loss))
+    rng = np.random.default_rng(16)
+    report = []
+    assert len(grads) >= 18
+    gtop = max(float(np.abs(v).max()) for v in grads.values())
+    for name, gh in sorted(grads.items()):
+        d = rng.standard_normal(gh.shape)
+        d /= np.sqrt((d * d).sum())
+        h = 1e-4 * max(1.0, float(np.abs(w[name]).max()))
+        wp, wm = dict(w), dict(w)
+        wp[name] = w[name].astype(np.float64) + h * d
+        wm[name] = w[name].astype(np.float64) - h * d
+        fd = (f(wp) - f(wm)) / (2 * h)
+        proj = float((gh * d).sum())
+        # directional derivatives are compared on the scale of the gradient's norm (a random unit direction sees
+        # ~ |g| / sqrt(numel) of it): biases in front of a BatchNorm have derivative 0 and are compared on the floor
+        scale = max(float(np.sqrt((gh * gh).sum())) / np.sqrt(gh.size) * 3.0, abs(fd), 1e-5 * gtop)
+        report.append((abs(fd - proj) / scale, name, fd, proj))
+    print("cfg4 directional derivatives, float64 central differences vs HIP gradient projections:",
+          [(round(e, 5), nme, float("%.3e" % a), float("%.3e" % c)) for e, nme, a, c in sorted(report, reverse=True)[:8]])
+    for err, name, fd, proj in report:
+        assert err <= TOL_FD, (name, err, fd, proj)
+
+
+TOL_FD = 2e-2
+
+
+def _weights_np_fresh(model):
+    from dh3d_amd.model import tf_variable_name
+    return {tf_variable_name(k): v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
