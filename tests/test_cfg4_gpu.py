@@ -204,12 +204,13 @@ def test_cfg4_gradients_vs_float64_central_differences_of_the_oracle_graph(dev):
     b, p, ng, n = 1, 2, 3, 2048
     cfg = ConfigFactory("global_config").getconfig()
     cfg.batch_size, cfg.num_pos, cfg.num_neg, cfg.num_points = b, p, ng, n
-    m = DH3D(cfg).init_synthetic(13).to(dev).eval().prepare()
+    m = DH3D(cfg).init_synthetic(13)
     g = torch.Generator().manual_seed(14)
     with torch.no_grad():
         for name, prm in m.named_parameters():
             if name.endswith("gamma"):
-                prm.copy_((0.75 + 0.5 * torch.rand(prm.shape, generator=g)).to(dev))
+                prm.copy_(0.75 + 0.5 * torch.rand(prm.shape, generator=g))
+    m = m.to(dev).eval().prepare()
     bt = b * (1 + p + ng + 1)
     pts = np.random.default_rng(15).random((bt, n, 3), dtype=np.float32)
     # HIP: loss + gradients of one step's forward / backward (no weight decay: it is added to the gradients separately)
@@ -252,7 +253,7 @@ def test_cfg4_gradients_vs_float64_central_differences_of_the_oracle_graph(dev):
         assert err <= TOL_FD, (name, err, fd, proj)
 
 
-TOL_FD = 2e-2
+TOL_FD = 1e-3  # measured worst 3.1e-4 (flex_conv position_bias), every other tensor <= 1.7e-4
 
 
 def _weights_np_fresh(model):
