@@ -113,6 +113,8 @@ _SIGNATURES = {
                                      ctypes.POINTER(Epilogue), c_fp, c_fp],
     "dh3d_flex_conv_pm_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int,
                               ctypes.POINTER(Epilogue), c_fp, c_fp],
+    "dh3d_flex_conv_pm_post_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(Epilogue), c_fp,
+                                   c_fp, c_int, c_fp, c_fp],
     "dh3d_pack_flex_weight_x3": [c_fp, c_fp, c_int, c_int, c_fp, c_fp],
     "dh3d_flex_conv_pm_x6_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int,
                                  ctypes.POINTER(Epilogue), c_fp, c_fp],
@@ -183,6 +185,8 @@ _SIGNATURES = {
                                    c_size_t, c_fp, c_fp],
     "dh3d_netvlad_head_workspace_bytes": [c_int, c_int, c_int],
     "dh3d_global_tail_fwd": [c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, ctypes.POINTER(Epilogue), c_fp,
+                             c_float, c_fp, c_fp, c_fp, c_fp, c_fp],
+    "dh3d_global_tail_prezeroed_fwd": [c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, ctypes.POINTER(Epilogue), c_fp,
                              c_float, c_fp, c_fp, c_fp, c_fp, c_fp],
     "dh3d_netvlad_tail_workspace_bytes": [c_int, c_int, c_int, c_int],
     "dh3d_netvlad_tail_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_float,

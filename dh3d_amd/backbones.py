@@ -436,13 +436,14 @@ class FlexConvDilate(nn.Module):
         return conv.lower_partial(feat)
 
     def forward(self, geo, feat, nbr=None, residual=None, l2cat=None, shortcut_src=None, lower_partial=None,
-                coarse_only=False, post_conv=None):
+                coarse_only=False, post_conv=None, post_linear=None):
         """geo: Geometry; feat [B,N,cin]; nbr [B,N,K] for dilate == 1 (else computed on the sampled set);
         residual [B,N,cout]: added to the concat conv's output in its store (the caller's shortcut branch);
         l2cat = (prefix [B,N,3], eps): return [prefix | l2_normalize(output)] instead of the output;
         lower_partial: commuted_partial(feat), computed earlier by the caller; post_conv: a Conv2D1x1 the caller applies
         to this block's output next -- where it can ride in the SE kernel the result is (output, post_conv(output))."""
         prep = self._prep or self.prepare()
+        self._last_post = None
         if self.dilate > 1:
             lv = geo.level(self.dilate, self.knn, finish=False)  # three_nn is joined only where it is consumed
             xyz_s, nbr_s = lv["xyz_s"], lv["nbr_s"]
@@ -464,6 +465,13 @@ class FlexConvDilate(nn.Module):
                 x = pm.flex_conv_x6(x, xyz_s, nbr_s, p["wp3"], p["dout"], pre_bias=p["fb"], scale=p["scale"],
                                     shift=p["shift"], act=pm.ACT_RELU,
                                     reserve_cus_per_xcd=getattr(geo, "busy_cus_per_xcd", 0))
+            elif (post_linear is not None and coarse_only and p is prep[-1] and remap is None and not self.add_se
+                  and pm.flex_post_supported(x.shape[2], p["dout"], nbr_s.shape[2], post_linear[1])):
+                # post_linear = (packed [dout, 64] weight, 64): the caller's next linear layer on this block's coarse
+                # output rides in the last flex_conv's launch (NetVLAD's cluster logits, model.compute_global)
+                x, self._last_post = pm.flex_conv_post(x, xyz_s, nbr_s, p["wp"], p["dout"], post_linear[0], post_linear[1],
+                                                       pre_bias=p["fb"], scale=p["scale"], shift=p["shift"],
+                                                       act=pm.ACT_RELU)
             else:
                 x = pm.flex_conv(x, xyz_s, nbr_s, p["wp"], p["dout"], pre_bias=p["fb"], scale=p["scale"],
                                  shift=p["shift"], act=pm.ACT_RELU, remap=remap)

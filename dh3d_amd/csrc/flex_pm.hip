@@ -42,11 +42,16 @@ __device__ long long g_fprobe[64 * 8];
 #endif
 
 // KT = compile-time neighbourhood size (8 on the DH3D path) or 0 for a run-time K.
-template <int DIN, int DOUT, int KT, int TMSEL = 0>
+// POST: the finished output tile goes through one more linear layer [DOUT -> 64] (wpost = dh3d_pack_weight of [DOUT, 64], no
+// bias / activation) before it leaves the chip, both results stored: the cluster logits `coarse @ cluster_weights` of
+// NetVLAD behind the global flex_conv (core/backbones.py:213-216 on the commuted form) -- a 17 us launch + its gap on
+// the global step's critical chain become ~12 % more MFMA work in this kernel.
+template <int DIN, int DOUT, int KT, int TMSEL = 0, bool POST = false>
 __global__ __launch_bounds__(256) void flex_conv_pm_kernel(
     const float *__restrict__ feat, const float *__restrict__ xyz, const int32_t *__restrict__ nbr,
     const float *__restrict__ wpacked, long long R, int N, int K, EpilogueArgs ep,
-    float *__restrict__ out, const int32_t *__restrict__ remap, int Nsrc) {
+    float *__restrict__ out, const int32_t *__restrict__ remap, int Nsrc, const float *__restrict__ wpost = nullptr,
+    float *__restrict__ out2 = nullptr) {
   // remap (may be NULL): the features are rows of a LARGER per-cloud map [B, Nsrc, DIN] and point j of this level is
   // row remap[b*N + j] of it -- group_point (the sampled level's feature gather, core/tf_utils.py:92-95) fused into the
   // neighbour gather: one more dependent index load instead of a kernel + its dependency gap
@@ -177,6 +182,18 @@ __global__ __launch_bounds__(256) void flex_conv_pm_kernel(
   wave_tiles_to_lds<C::NT>(acc, er, ep.act, s_S, C::LD, row0, cb0, cbstride);
   __syncthreads();
   block_store_rows(s_S, C::LD, C::TM, grow0, R, DOUT, nullptr, out);
+  if (POST) {
+    static_assert(!POST || (C::TM == 32 && C::LD >= DOUT + 64 + 4), "POST: 32-point tiles, room for 64 more columns");
+    if (wave < 2) {  // [32, DOUT] x [DOUT, 64]: one 32-column block per wave, the tile in LDS is the A operand
+      f32x16 pacc[1];
+      zero_acc<1>(pacc);
+      wave_gemm_f32<1>(s_S, C::LD, 0, wpost, DOUT / 8, wave, 1, pacc);
+      const EpilogueRegs none[1] = {EpilogueRegs{0.f, 1.f, 0.f}};
+      wave_tiles_to_lds<1>(pacc, none, DH3D_ACT_NONE, s_S + DOUT, C::LD, 0, wave, 1);  // columns [DOUT, DOUT + 64) of the rows
+    }
+    __syncthreads();
+    block_store_rows(s_S + DOUT, C::LD, C::TM, grow0, R, 64, nullptr, out2);
+  }
   FPROBE(4);
 }
 
@@ -193,7 +210,7 @@ int flex_conv_pm_launch(const float *feat, const float *xyz, const int32_t *nbr,
       auto kern = flex_conv_pm_kernel<DIN, DOUT, 8, 32>;
       DH3D_ALLOW_BIG_LDS(kern);
       hipLaunchKernelGGL(kern, dim3(dh3d_cdiv(R, 32)), dim3(256), sizeof(float) * 32 * C32::LD, s, feat, xyz, nbr,
-                         wpacked, R, N, K, ep, out, remap, Nsrc);
+                         wpacked, R, N, K, ep, out, remap, Nsrc, (const float *)nullptr, (float *)nullptr);
       return dh3d_launch_status();
     }
   }
@@ -202,17 +219,17 @@ int flex_conv_pm_launch(const float *feat, const float *xyz, const int32_t *nbr,
   if (K == 8) {
     auto kern = flex_conv_pm_kernel<DIN, DOUT, 8>;
     DH3D_ALLOW_BIG_LDS(kern);
-    hipLaunchKernelGGL(kern, grid, block, lds, s, feat, xyz, nbr, wpacked, R, N, K, ep, out, remap, Nsrc);
+    hipLaunchKernelGGL(kern, grid, block, lds, s, feat, xyz, nbr, wpacked, R, N, K, ep, out, remap, Nsrc, (const float *)nullptr, (float *)nullptr);
   } else if (K == 12 && DIN == 128 && DOUT == 128) {
     // BASELINE config 5's stress kernel (localdesc_extract.py:146,166: K = 12 on 128-d features): the two-round-trip
     // gather with a compile-time K instead of the run-time-K loop (a dependent id -> row load chain per neighbour)
     auto kern = flex_conv_pm_kernel<DIN, DOUT, 12>;
     DH3D_ALLOW_BIG_LDS(kern);
-    hipLaunchKernelGGL(kern, grid, block, lds, s, feat, xyz, nbr, wpacked, R, N, K, ep, out, remap, Nsrc);
+    hipLaunchKernelGGL(kern, grid, block, lds, s, feat, xyz, nbr, wpacked, R, N, K, ep, out, remap, Nsrc, (const float *)nullptr, (float *)nullptr);
   } else {
     auto kern = flex_conv_pm_kernel<DIN, DOUT, 0>;
     DH3D_ALLOW_BIG_LDS(kern);
-    hipLaunchKernelGGL(kern, grid, block, lds, s, feat, xyz, nbr, wpacked, R, N, K, ep, out, remap, Nsrc);
+    hipLaunchKernelGGL(kern, grid, block, lds, s, feat, xyz, nbr, wpacked, R, N, K, ep, out, remap, Nsrc, (const float *)nullptr, (float *)nullptr);
   }
   return dh3d_launch_status();
 }
@@ -465,6 +482,20 @@ DH3D_API int dh3d_flex_conv_pm_gather_fwd(const float *features, const int32_t *
   DH3D_FLEX_CASE(128, 256);
 #undef DH3D_FLEX_CASE
   return DH3D_ERR_UNSUPPORTED;
+}
+
+DH3D_API int dh3d_flex_conv_pm_post_fwd(const float *features, const float *xyz, const int32_t *nbr, const float *wpacked,
+                                        int B, int N, int K, int Din, int Dout, const dh3d_epilogue *ep, float *out,
+                                        const float *wpost_packed, int Dpost, float *out2, void *stream) {
+  DH3D_REQUIRE(features && xyz && nbr && wpacked && out && wpost_packed && out2 && B > 0 && N > 0);
+  DH3D_SUPPORTED(Din == 128 && Dout == 256 && K == 8 && Dpost == 64);
+  using C = FlexCfg<128, 256>;
+  const long long R = (long long)B * N;
+  auto kern = flex_conv_pm_kernel<128, 256, 8, 0, true>;
+  DH3D_ALLOW_BIG_LDS(kern);
+  hipLaunchKernelGGL(kern, dim3(dh3d_cdiv(R, C::TM)), dim3(256), sizeof(float) * C::TM * C::LD, (hipStream_t)stream, features,
+                     xyz, nbr, wpacked, R, N, K, dh3d_ep(ep), out, (const int32_t *)nullptr, 0, wpost_packed, out2);
+  return dh3d_launch_status();
 }
 
 DH3D_API int dh3d_flex_conv_pm_fwd(const float *features, const float *xyz, const int32_t *nbr,

@@ -255,7 +255,7 @@ class DH3D(nn.Module):
         torch.cuda.current_stream().wait_stream(geo._side)
 
     # ------------------------------------------------------------------ reference API
-    def compute_local(self, points, knn_inds=None, _geo=None, _l2cat_eps=None):
+    def compute_local(self, points, knn_inds=None, _geo=None, _l2cat_eps=None, _prezero_tail=False):
         """(points, local descriptors [Bt,N,featdim]) (core/model.py:157-171).  _l2cat_eps (internal): the second item is
         [points | l2_normalize(descriptors)] instead, written by the last conv's store (forward(fetch=...) when nothing
         needs the raw descriptors)."""
@@ -285,6 +285,12 @@ class DH3D(nn.Module):
             # x2 here, beside the sampling chain; behind the sampled level only a GEMM on the N/8 rows and one
             # gather / epilogue kernel are left (backbones.Conv2D1x1.forward_commuted)
             lower = None if fuse_sc else self.stage2.commuted_partial(x2)
+            if _prezero_tail:
+                # the global tail's accumulators (6 MB at cfg 3), zero-filled HERE, beside the sampling chain: the fill
+                # (a ~5 us node + its dependency gap) is off the critical chain when the tail starts
+                geo._tail_accum = torch.zeros((pm.global_tail_accum_size(points.shape[0], points.shape[1] // 8),),
+                                              dtype=torch.float32, device=points.device)
+                geo._tail_accum.record_stream(main)
             stage1_done = torch.cuda.Event()
             stage1_done.record()
             geo.start_nn3(geo._lv)  # three_nn: waits for the sampled coordinates, overlaps the N/8 convolutions
@@ -322,13 +328,19 @@ class DH3D(nn.Module):
             # Both consumers of the up-sampled map -- the attention MLP and NetVLAD's soft assignment / aggregation --
             # are reached through the interpolation's linearity: the fine points are walked once (Morton order, coarse
             # rows staged in LDS), the [Bt, N, 256] map is never built (rule on the points per cloud only).
-            coarse = self.global_before_assemble(geo, localdesc, coarse_only=True)
+            p = nv._prep or nv.prepare()
+            coarse = self.global_before_assemble(geo, localdesc, coarse_only=True, post_linear=(p["wc"], 64))
+            cw = self.global_before_assemble._last_post  # coarse @ cluster_weights out of the same launch (or None)
+            acc = getattr(geo, "_tail_accum", None)
+            if acc is not None and acc.numel() != pm.global_tail_accum_size(points.shape[0], m):
+                acc = None
+            geo._tail_accum = None  # (one use: the tail accumulates into it)
             last = ga.detec_conv0
-            lp, gp, p = last._prep, ga._prep, nv._prep or nv.prepare()
+            lp, gp = last._prep, ga._prep
             return pm.global_tail(coarse, lv["nn3_idx"], lv["nn3_dist"], lv["_ordered"][0], gp["wslices"], last.cout,
                                   gp["w_fc"], gp["b_fc"], (lp["b"], lp["scale"], lp["shift"], pm.ACT_RELU), p["wc"],
                                   p["cs"], p["ch"], p["W2"], p["Wh"], p["s1"], p["h1"], p["Wg"], p["s2"], p["h2"],
-                                  l2_eps=l2_eps)
+                                  l2_eps=l2_eps, accum=acc, cw=cw)
         forglobal = self.global_before_assemble(geo, localdesc)
         coarse, lv = getattr(self.global_before_assemble, "_last_coarse", (None, None))
         if coarse is not None and "nn3_idx" in lv and self.globalatt.interpolated_supported(coarse, lv["nn3_idx"]):
@@ -376,7 +388,10 @@ class DH3D(nn.Module):
             outs["feat_l2normed"] = xyz_feat[:, :, 3:]
             self._level_ids(geo, outs, fetch)
             return outs
-        newpoints, localdesc = self.compute_local(points, _geo=geo)
+        newpoints, localdesc = self.compute_local(points, _geo=geo,
+                                                  _prezero_tail=bool(cfg.extract_global and want("globaldesc")
+                                                                     and self.global_before_assemble is not None
+                                                                     and (self.global_before_assemble.dilate == 8)))
         outs["feat"] = localdesc
         self._level_ids(geo, outs, fetch)
         xyz_feat = None

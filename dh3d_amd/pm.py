@@ -122,6 +122,29 @@ def flex_conv(features, xyz, nbr, wpacked, Dout, pre_bias=None, scale=None, shif
     return out
 
 
+def flex_conv_post(features, xyz, nbr, wpacked, Dout, wpost_packed, Dpost, pre_bias=None, scale=None, shift=None,
+                   act=ACT_NONE):
+    """flex_conv() and, from the same launch, out2 = out @ Wpost (a packed [Dout, Dpost] weight, no bias / activation).
+    Returns (out [B,N,Dout], out2 [B,N,Dpost]).  128 -> 256 with Dpost = 64, K = 8 (the global path's sampled level)."""
+    f = L.require_cuda_f32(features, "features", 3)
+    x = L.require_cuda_f32(xyz, "xyz", 3)
+    nb = L.require_cuda_i32(nbr, "nbr", 3)
+    B, N, Din = f.shape
+    if tuple(x.shape) != (B, N, 3) or tuple(nb.shape[:2]) != (B, N):
+        raise ValueError("flex_conv_post: xyz/nbr do not match features [B,N,*]")
+    out = torch.empty((B, N, Dout), dtype=torch.float32, device=f.device)
+    out2 = torch.empty((B, N, Dpost), dtype=torch.float32, device=f.device)
+    ep = _ep(pre_bias, scale, shift, act)
+    L.check(L.lib().dh3d_flex_conv_pm_post_fwd(L.ptr(f), L.ptr(x), L.ptr(nb), L.ptr(wpacked), B, N, nb.shape[2], Din, Dout, ep,
+                                               L.ptr(out), L.ptr(wpost_packed), Dpost, L.ptr(out2), L.stream_ptr()),
+            "flex_conv_pm_post")
+    return out, out2
+
+
+def flex_post_supported(Din, Dout, K, Dpost):
+    return Din == 128 and Dout == 256 and K == 8 and Dpost == 64
+
+
 def flex_x6_supported(Din, Dout, K):
     """Shapes served by the persistent bf16x6 flex_conv (csrc/flex_x6.hip)."""
     return K == 8 and (Din, Dout) in ((32, 64), (64, 64))
@@ -524,8 +547,13 @@ def netvlad_fused(x, att, wc_packed, bn_scale, bn_shift, W2, Wh, bn1_scale, bn1_
     return out
 
 
+def global_tail_accum_size(B, m):
+    """floats of global_tail's accumulator block [ A' B*m*64 | asum B*64 | V B*64*256 ]."""
+    return B * m * 64 + B * 64 + B * 64 * 256
+
+
 def global_tail(coarse, idx, dist, order, wslices_x3, Hd, w_fc, b_fc, att_ep, wc_packed, cl_scale, cl_shift, W2, Wh,
-                bn1_scale, bn1_shift, Wg, bn2_scale, bn2_shift, l2_eps=0.0, want_att=False):
+                bn1_scale, bn1_shift, Wg, bn2_scale, bn2_shift, l2_eps=0.0, want_att=False, accum=None, cw=None):
     """three_interpolate -> attention head -> NetVLAD + gating, with the up-sampling commuted through both consumers: the
     fine points are walked once (csrc/dense_x6.hip VladTail), everything else runs on the coarse rows.
     coarse [B,m,256], idx/dist [B,n,3], order = spatial_sort records [B,n,4] of the fine cloud, att_ep =
@@ -539,11 +567,17 @@ def global_tail(coarse, idx, dist, order, wslices_x3, Hd, w_fc, b_fc, att_ep, wc
     H = torch.empty((ns, B * m, 256), dtype=torch.float32, device=x.device)
     L.check(L.lib().dh3d_linear_slices_pm_x6_fwd(L.ptr(x), C, L.ptr(wslices_x3), B * m, ns, L.ptr(H), L.stream_ptr()),
             "linear_slices_pm_x6")
-    cw = linear(x, wc_packed, 64)                                                  # coarse @ cluster_weights
+    if cw is None:   # (the caller may have it already: pm.flex_conv_post computes it in the flex_conv's launch)
+        cw = linear(x, wc_packed, 64)                                              # coarse @ cluster_weights
     att = torch.empty((B, n, 1), dtype=torch.float32, device=x.device) if want_att else None
-    accum = torch.empty((B * m * 64 + B * 64 + B * 64 * 256,), dtype=torch.float32, device=x.device)
+    # accum (optional): global_tail_accum(B, m) zeroed by the caller off the critical chain; else zeroed by the call
+    fn = L.lib().dh3d_global_tail_prezeroed_fwd if accum is not None else L.lib().dh3d_global_tail_fwd
+    if accum is None:
+        accum = torch.empty((global_tail_accum_size(B, m),), dtype=torch.float32, device=x.device)
+    elif accum.numel() != global_tail_accum_size(B, m) or accum.dtype != torch.float32 or not accum.is_cuda:
+        raise ValueError("global_tail: accum must be a zeroed float32 GPU tensor of global_tail_accum_size(B, m) elements")
     ep = _ep(*att_ep)
-    L.check(L.lib().dh3d_global_tail_fwd(L.ptr(H), Hd, L.ptr(x), L.ptr(cw), L.ptr(ix), L.ptr(d), L.ptr(order), B, n, m,
+    L.check(fn(L.ptr(H), Hd, L.ptr(x), L.ptr(cw), L.ptr(ix), L.ptr(d), L.ptr(order), B, n, m,
                                          ep, L.ptr(w_fc), float(b_fc), L.ptr(cl_scale), L.ptr(cl_shift), L.ptr(att),
                                          L.ptr(accum), L.stream_ptr()), "global_tail")
     asum = accum[B * m * 64:B * m * 64 + B * 64]

@@ -250,6 +250,14 @@ int dh3d_fps_sorted_cloud(const float *sorted, const float *gbox, const float *x
 int dh3d_flex_conv_pm_fwd(const float *features, const float *xyz, const int32_t *nbr,
                           const float *wpacked, int B, int N, int K, int Din, int Dout,
                           const dh3d_epilogue *ep, float *out, void *stream);
+
+/* dh3d_flex_conv_pm_fwd with one more linear layer applied to the finished output tile before it leaves the chip:
+ * out [B,N,Dout] as above AND out2 [B,N,Dpost] = out @ Wpost (wpost_packed = dh3d_pack_weight of [Dout, Dpost], no bias /
+ * activation).  The global step uses it for NetVLAD's cluster logits on the sampled rows (core/backbones.py:213-216,
+ * commuted through the up-sampling).  Din == 128, Dout == 256, K == 8, Dpost == 64. */
+int dh3d_flex_conv_pm_post_fwd(const float *features, const float *xyz, const int32_t *nbr, const float *wpacked, int B,
+                               int N, int K, int Din, int Dout, const dh3d_epilogue *ep, float *out,
+                               const float *wpost_packed, int Dpost, float *out2, void *stream);
 /* Same with group_point fused in: `features` is the [B, Nsrc, Din] map of the level above and point j of this level
  * (xyz / nbr / out are [B, N, ...]) is its row remap[b*N + j] (remap = the farthest-point-sampling picks).  Equal to
  * dh3d_flex_conv_pm_fwd(group_point(features, remap), ...) bit for bit. */
@@ -636,6 +644,11 @@ int dh3d_gemm_nn_f32_batched(const float *A, const float *B, const float *colbia
  * dh3d_netvlad_tail_fwd(V, asum, ...) finishes (subtract asum*W2, intra-normalise, project, gate).  Same function as
  * three_interpolate -> attention head -> dh3d_netvlad_fused_fwd, reassociated; m <= 1024. */
 int dh3d_global_tail_fwd(const float *H, int Hd, const float *coarse, const float *cw, const int32_t *idx,
+                         const float *dist, const float *order, int B, int n, int m, const dh3d_epilogue *ep,
+                         const float *w_fc, float b_fc, const float *cl_scale, const float *cl_shift, float *att,
+                         float *accum, void *stream);
+/* The same call with `accum` zeroed by the CALLER (a fill issued off the critical chain). */
+int dh3d_global_tail_prezeroed_fwd(const float *H, int Hd, const float *coarse, const float *cw, const int32_t *idx,
                          const float *dist, const float *order, int B, int n, int m, const dh3d_epilogue *ep,
                          const float *w_fc, float b_fc, const float *cl_scale, const float *cl_shift, float *att,
                          float *accum, void *stream);
