@@ -278,22 +278,40 @@ __global__ __launch_bounds__(256) void se_res_mfma_kernel(const float *__restric
       __syncthreads();
     }
     constexpr int CVP = C / 4;
-    for (int e = tid; e < kTM * CVP; e += 256) {
-      const int p = e / CVP, c4 = (e - p * CVP) * 4;
-      const long long g = grow0 + p;
-      float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (g < R) {
-        best = make_float4(-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f);  // -FLT_MAX
-        if (k8) {
-          float4 v[8];
+    if (k8) {
+      // two points per lane and pass: their 16 row reads are requested together and none sits under a branch (rows past
+      // the end read row 0 through s_nb and are zeroed afterwards) -- the loop was kTM * CVP / 256 dependent round trips
+      constexpr int IT = kTM * CVP / 256;
+      static_assert(IT % 2 == 0, "pairs of passes");
 #pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4 *>(x + (size_t)s_nb[p * 8 + k] * C + c4);
+      for (int it = 0; it < IT; it += 2) {
+        float4 v[2][8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int e = tid + (it + u) * 256, p = e / CVP, c4 = (e - p * CVP) * 4;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[u][k] = *reinterpret_cast<const float4 *>(x + (size_t)s_nb[p * 8 + k] * C + c4);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int e = tid + (it + u) * 256, p = e / CVP, c4 = (e - p * CVP) * 4;
+          float4 best = make_float4(-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f);  // -FLT_MAX
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
-            best.x = fmaxf(best.x, v[k].x); best.y = fmaxf(best.y, v[k].y);
-            best.z = fmaxf(best.z, v[k].z); best.w = fmaxf(best.w, v[k].w);
+            best.x = fmaxf(best.x, v[u][k].x); best.y = fmaxf(best.y, v[u][k].y);
+            best.z = fmaxf(best.z, v[u][k].z); best.w = fmaxf(best.w, v[u][k].w);
           }
-        } else {
+          if (grow0 + p >= R) best = make_float4(0.f, 0.f, 0.f, 0.f);
+          *reinterpret_cast<float4 *>(s_p + (size_t)p * LDP + c4) = best;
+        }
+      }
+    } else {
+      for (int e = tid; e < kTM * CVP; e += 256) {
+        const int p = e / CVP, c4 = (e - p * CVP) * 4;
+        const long long g = grow0 + p;
+        float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g < R) {
+          best = make_float4(-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f);  // -FLT_MAX
           const long long cloud0 = (g / N) * N;
           const int32_t *nb = nbr + g * K;
 #pragma unroll 4
@@ -302,8 +320,8 @@ __global__ __launch_bounds__(256) void se_res_mfma_kernel(const float *__restric
             best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y); best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
           }
         }
+        *reinterpret_cast<float4 *>(s_p + (size_t)p * LDP + c4) = best;
       }
-      *reinterpret_cast<float4 *>(s_p + (size_t)p * LDP + c4) = best;
     }
   } else {
     stage_rows(pool, C, pool, 0, grow0, R, s_p, LDP);
@@ -337,20 +355,32 @@ __global__ __launch_bounds__(256) void se_res_mfma_kernel(const float *__restric
   }
   __syncthreads();
   constexpr int CV = C / 4;
-  for (int e = tid; e < kTM * CV; e += 256) {
-    const int p = e / CV, c4 = (e - p * CV) * 4;
-    const long long g = grow0 + p;
-    if (g < R) {
-      const float4 xv = *reinterpret_cast<const float4 *>(x + g * C + c4);
-      const float4 gt = *reinterpret_cast<const float4 *>(s_p + (size_t)p * LDP + c4);
-      float4 r;
-      r.x = xv.x + xv.x * gt.x; r.y = xv.y + xv.y * gt.y; r.z = xv.z + xv.z * gt.z; r.w = xv.w + xv.w * gt.w;
-      r.x = r.x > 0.f ? r.x : 0.f; r.y = r.y > 0.f ? r.y : 0.f;
-      r.z = r.z > 0.f ? r.z : 0.f; r.w = r.w > 0.f ? r.w : 0.f;
-      *reinterpret_cast<float4 *>(out + g * C + c4) = r;
-      if (CONV) *reinterpret_cast<float4 *>(s_p + (size_t)p * LDP + c4) = r;  // over its own gate entry
-    } else if (CONV) {
-      *reinterpret_cast<float4 *>(s_p + (size_t)p * LDP + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    // the tile's own rows: every pass's read requested before the first is used (rows past the end re-read the last row)
+    constexpr int ITG = kTM * CV / 256;
+    float4 xr[ITG];
+#pragma unroll
+    for (int it = 0; it < ITG; ++it) {
+      const int e = tid + it * 256, p = e / CV, c4 = (e - p * CV) * 4;
+      const long long g = grow0 + p < R ? grow0 + p : R - 1;
+      xr[it] = *reinterpret_cast<const float4 *>(x + g * C + c4);
+    }
+#pragma unroll
+    for (int it = 0; it < ITG; ++it) {
+      const int e = tid + it * 256, p = e / CV, c4 = (e - p * CV) * 4;
+      const long long g = grow0 + p;
+      if (g < R) {
+        const float4 xv = xr[it];
+        const float4 gt = *reinterpret_cast<const float4 *>(s_p + (size_t)p * LDP + c4);
+        float4 r;
+        r.x = xv.x + xv.x * gt.x; r.y = xv.y + xv.y * gt.y; r.z = xv.z + xv.z * gt.z; r.w = xv.w + xv.w * gt.w;
+        r.x = r.x > 0.f ? r.x : 0.f; r.y = r.y > 0.f ? r.y : 0.f;
+        r.z = r.z > 0.f ? r.z : 0.f; r.w = r.w > 0.f ? r.w : 0.f;
+        *reinterpret_cast<float4 *>(out + g * C + c4) = r;
+        if (CONV) *reinterpret_cast<float4 *>(s_p + (size_t)p * LDP + c4) = r;  // over its own gate entry
+      } else if (CONV) {
+        *reinterpret_cast<float4 *>(s_p + (size_t)p * LDP + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
   }
   if (CONV) {  // out2 = act(bn(tile @ Wconv + b)), 64 columns: one 32 x 32 accumulator per wave
