@@ -73,6 +73,7 @@ _SIGNATURES = {
     "dh3d_bn_colstats": [c_fp, c_ll, c_int, c_fp, c_int, c_fp, c_fp, c_fp],
     "dh3d_bn_finalize": [c_fp, c_fp, c_fp, c_fp, c_fp, c_float, c_float, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp],
     "dh3d_scale_shift_act": [c_fp, c_ll, c_int, c_fp, c_fp, c_int, c_fp, c_fp],
+    "dh3d_pairwise_sqdist": [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp],
     "dh3d_flex_pool_pm_bwd": [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp],
     "dh3d_se_gate_fwd": [c_fp, c_fp, c_ll, c_fp, c_fp],
     "dh3d_se_gate_bwd": [c_fp, c_fp, c_fp, c_ll, c_fp, c_fp, c_fp],

@@ -660,6 +660,43 @@ __global__ __launch_bounds__(256) void relu_kernel(const float4 *__restrict__ a,
   }
 }
 
+// pairwise_dist (core/tf_utils.py:125-136): out[b,i,j] = sum_d (A[b,i,d] - Bm[b,j,d])^2, the differences formed and squared
+// as upstream (no |a|^2 + |b|^2 - 2ab expansion: the local losses take sqrt(d + 1e-10) of values near 0).  A 32 x 32 tile of
+// pairs per workgroup, both row blocks staged through LDS 32 columns at a time; thread (ti, tj) owns 2 x 2 pairs.
+__global__ __launch_bounds__(256) void pairwise_sqdist_kernel(const float *__restrict__ A, const float *__restrict__ Bm, int n,
+                                                             int m, int D, float *__restrict__ out) {
+  __shared__ float s_a[32][33], s_b[32][33];
+  const int b = blockIdx.z, i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+  const float *Ab = A + (size_t)b * n * D, *Bb = Bm + (size_t)b * m * D;
+  float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  for (int d0 = 0; d0 < D; d0 += 32) {
+    __syncthreads();
+    for (int e = tid; e < 32 * 32; e += 256) {
+      const int r = e >> 5, c = e & 31;
+      s_a[r][c] = (i0 + r < n && d0 + c < D) ? Ab[(size_t)(i0 + r) * D + d0 + c] : 0.f;
+      s_b[r][c] = (j0 + r < m && d0 + c < D) ? Bb[(size_t)(j0 + r) * D + d0 + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int c = 0; c < 32; ++c) {
+      const float a0 = s_a[ti][c], a1 = s_a[ti + 16][c], b0 = s_b[tj][c], b1 = s_b[tj + 16][c];
+      float t;
+      t = a0 - b0; acc[0][0] = fmaf(t, t, acc[0][0]);
+      t = a0 - b1; acc[0][1] = fmaf(t, t, acc[0][1]);
+      t = a1 - b0; acc[1][0] = fmaf(t, t, acc[1][0]);
+      t = a1 - b1; acc[1][1] = fmaf(t, t, acc[1][1]);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int i = i0 + ti + 16 * u, j = j0 + tj + 16 * v;
+      if (i < n && j < m) out[((size_t)b * n + i) * m + j] = acc[u][v];
+    }
+}
+
 inline int flat_grid(long long work) {
   long long g = (work + 255) / 256;
   return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
@@ -681,6 +718,14 @@ DH3D_API int dh3d_bn_colstats(const float *x, long long R, int C, const unsigned
   const int chunks = row_chunks(R, &rows_per);
   hipLaunchKernelGGL(colstats_kernel, dim3(dh3d_cdiv(C, 64), chunks), dim3(256), 0, s, x, R, C, rows_per, mask,
                      rows_per_cloud > 0 ? rows_per_cloud : 1, sum, sumsq);
+  return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_pairwise_sqdist(const float *A, const float *Bm, int B, int n, int m, int D, float *out, void *stream) {
+  DH3D_REQUIRE(A && Bm && out && B > 0 && n > 0 && m > 0 && D > 0);
+  DH3D_SUPPORTED(B <= 65535);
+  hipLaunchKernelGGL(pairwise_sqdist_kernel, dim3(dh3d_cdiv(m, 32), dh3d_cdiv(n, 32), B), dim3(256), 0, (hipStream_t)stream, A,
+                     Bm, n, m, D, out);
   return dh3d_launch_status();
 }
 

@@ -52,7 +52,13 @@ def lazy_quadruplet_loss(global_descs, batch_size, num_pos, num_neg, global_trip
 # Local-descriptor and detector losses (core/losses.py:29-133): plain tensor math on the sampled keypoints of a
 # registered cloud pair [cloud 0 batch | cloud 1 batch]; the 16-NN of the detector loss runs on the kNN kernel.
 def _pairwise_sqdist(a, b):
-    """[B,n,D], [B,m,D] -> [B,n,m] sum of squared differences (core/tf_utils.py:125-136)."""
+    """[B,n,D], [B,m,D] -> [B,n,m] sum of squared differences (core/tf_utils.py:125-136).  float32 GPU descriptors go
+    through the HIP kernel (train_ops.pairwise_sqdist: the broadcast form materialises [B,n,m,D] -- 1.3 GB and a third of
+    the stage-1 training step at 10 x 512 x 512 x 128); anything else (float64 test restatements, coordinates) stays plain
+    tensor math."""
+    if a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape[2] >= 16 and a.shape[2] % 4 == 0:
+        from . import train_ops as T
+        return T.pairwise_sqdist(a, b)
     return ((a.unsqueeze(2) - b.unsqueeze(1)) ** 2).sum(3)
 
 

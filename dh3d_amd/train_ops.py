@@ -678,3 +678,35 @@ class _ReLU(torch.autograd.Function):
 
 def relu(x):
     return _ReLU.apply(x)
+
+
+class _PairwiseSqDist(torch.autograd.Function):
+    """pairwise_dist of the local losses (core/tf_utils.py:125-136): [B,n,D], [B,m,D] -> [B,n,m].  Forward: the HIP kernel
+    (differences formed as upstream).  Backward in closed form on the batched GEMM kernels:
+    dA = 2 (rowsum(G) * A - G B),  dB = 2 (colsum(G) * B - G^T A)."""
+
+    @staticmethod
+    def forward(ctx, A, Bm):
+        A, Bm = A.contiguous(), Bm.contiguous()
+        Bt, n, D = A.shape
+        m = Bm.shape[1]
+        out = torch.empty((Bt, n, m), dtype=torch.float32, device=A.device)
+        _L.check(_L.lib().dh3d_pairwise_sqdist(_L.ptr(A), _L.ptr(Bm), Bt, n, m, D, _L.ptr(out), _L.stream_ptr()),
+                 "pairwise_sqdist")
+        ctx.save_for_backward(A, Bm)
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        A, Bm = ctx.saved_tensors
+        G = G.contiguous()
+        dA = dB = None
+        if ctx.needs_input_grad[0]:
+            dA = 2.0 * (G.sum(2, keepdim=True) * A - pm.gemm_nn_batched(G, Bm))
+        if ctx.needs_input_grad[1]:
+            dB = 2.0 * (G.sum(1).unsqueeze(2) * Bm - pm.gemm_tn_batched(G, A))
+        return dA, dB
+
+
+def pairwise_sqdist(A, Bm):
+    return _PairwiseSqDist.apply(A, Bm)

@@ -515,6 +515,9 @@ int dh3d_scale_shift_act_res(const float *x, long long R, int C, const float *sc
  *                           with f32 atomics (as the reference); din [B*N, C] zeroed by the CALLER;
  *   dh3d_se_gate_fwd/_bwd : y = relu(x + x * sigmoid(z)) and its gradients (se_res_bottleneck's tail, backbones.py:52-55);
  *   dh3d_relu_fwd/_bwd    : y = relu(x);  dx = y > 0 ? dy : 0.   Element counts are multiples of 4. */
+/* pairwise_dist (core/tf_utils.py:125-136) of the local losses: out[b,i,j] = sum_d (A[b,i,d] - Bm[b,j,d])^2 with the
+ * differences formed as upstream; A [B,n,D], Bm [B,m,D] -> out [B,n,m]. */
+int dh3d_pairwise_sqdist(const float *A, const float *Bm, int B, int n, int m, int D, float *out, void *stream);
 int dh3d_flex_pool_pm_bwd(const float *dout, const int32_t *argmax, int B, int N, int C, float *din, void *stream);
 int dh3d_se_gate_fwd(const float *x, const float *z, long long n, float *y, void *stream);
 int dh3d_se_gate_bwd(const float *x, const float *z, const float *dy, long long n, float *dx, float *dz, void *stream);

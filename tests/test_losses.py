@@ -106,3 +106,31 @@ def test_losses_on_device_vs_oracle(dev):
         det.det_loss_weight * losses_np.local_detection_loss_nn(outs, **det)
     got = float(losses.compute_loss(_to(outs, dev), det))
     assert abs(got - exp) < 1e-5 * max(1.0, abs(exp))
+
+
+@pytest.mark.gpu
+def test_pairwise_sqdist_kernel_matches_the_broadcast_form(dev):
+    """train_ops.pairwise_sqdist (HIP forward, closed-form backward on the batched GEMM kernels) == the broadcast
+    restatement of core/tf_utils.py:125-136 in float64, values and both gradients; ragged sizes, near-identical rows
+    (the local losses take sqrt(d + 1e-10) of such entries: no |a|^2 + |b|^2 - 2ab cancellation is allowed)."""
+    import torch
+    from dh3d_amd import train_ops as T
+    g = torch.Generator().manual_seed(12)
+    for (B, n, m, D) in ((3, 70, 45, 128), (2, 512, 512, 128), (1, 33, 31, 16)):
+        a = torch.randn(B, n, D, generator=g)
+        a = a / a.norm(dim=2, keepdim=True)
+        b = torch.randn(B, m, D, generator=g)
+        b = b / b.norm(dim=2, keepdim=True)
+        k = min(n, m) // 2
+        b[:, :k] = a[:, :k] + 1e-4 * torch.randn(B, k, D, generator=g)   # near-identical pairs
+        ad, bd = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+        out = T.pairwise_sqdist(ad, bd)
+        a64, b64 = a.double().to(dev).requires_grad_(True), b.double().to(dev).requires_grad_(True)
+        ref = ((a64.unsqueeze(2) - b64.unsqueeze(1)) ** 2).sum(3)
+        err = (out.double() - ref).abs()
+        assert float((err / (ref + 1e-9)).max()) < 1e-4 and float(err.max()) < 1e-5, (float(err.max()), B, n, m, D)
+        w = torch.randn(B, n, m, generator=g).to(dev)
+        (torch.sqrt(out + 1e-10) * w).sum().backward()
+        (torch.sqrt(ref + 1e-10) * w.double()).sum().backward()
+        for x, y in ((ad.grad, a64.grad), (bd.grad, b64.grad)):
+            assert float((x.double() - y).abs().max()) <= 2e-3 * float(y.abs().max()), (B, n, m, D)
