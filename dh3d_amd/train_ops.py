@@ -701,10 +701,14 @@ class _PairwiseSqDist(torch.autograd.Function):
         A, Bm = ctx.saved_tensors
         G = G.contiguous()
         dA = dB = None
+        n, m, D = A.shape[1], Bm.shape[1], A.shape[2]
+        hip = n % 4 == 0 and m % 4 == 0 and D % 4 == 0   # the batched GEMM kernels' shapes (the losses': 512 x 512 x 128)
         if ctx.needs_input_grad[0]:
-            dA = 2.0 * (G.sum(2, keepdim=True) * A - pm.gemm_nn_batched(G, Bm))
+            GB = pm.gemm_nn_batched(G, Bm) if hip else torch.einsum("bij,bjd->bid", G, Bm)
+            dA = 2.0 * (G.sum(2, keepdim=True) * A - GB)
         if ctx.needs_input_grad[1]:
-            dB = 2.0 * (G.sum(1).unsqueeze(2) * Bm - pm.gemm_tn_batched(G, A))
+            GA = pm.gemm_tn_batched(G, A) if hip else torch.einsum("bij,bid->bjd", G, A)
+            dB = 2.0 * (G.sum(1).unsqueeze(2) * Bm - GA)
         return dA, dB
 
 
