@@ -256,10 +256,17 @@ class Geometry(object):
         self.nbr = nbr          # [B,N,K] int32
         self.levels = {}        # dilate -> dict(idx, xyz_s, nbr_s, nn3_dist, nn3_idx)
         self.sorted = None      # (records [B,N,4], gbox) from pm.spatial_sort, shared by kNN and FPS
+        self.cells = None       # [B, CELL_INTS] cell table of the sort (pm.spatial_sort_cells) or None
 
-    def ordered(self):
+    def ordered(self, cells=False):
+        """(Morton-ordered records, group boxes) of the cloud; cells=True: the sort also writes the 16^3 cell table the
+        cell-list kNN searches (self.cells)."""
         if self.sorted is None:
-            self.sorted = pm.spatial_sort(self.xyz)
+            if cells:
+                srt, gbox, self.cells = pm.spatial_sort_cells(self.xyz)
+                self.sorted = (srt, gbox)
+            else:
+                self.sorted = pm.spatial_sort(self.xyz)
         return self.sorted
 
     def level(self, dilate, knn, finish=True):

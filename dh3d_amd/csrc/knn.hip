@@ -1036,6 +1036,209 @@ DH3D_API int dh3d_knn_sorted(const float *sorted, const float *gbox, int B, int 
   return dh3d_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------ cell-list kNN
+// The same operator on the uniform 16 x 16 x 16 grid spatial_sort_kernel lays over a cloud's bounding box (the top four
+// bits per axis of the Morton key: every grid cell is ONE contiguous range of the sorted records, cells[] holds the
+// ranges).  Where the pruned scan above shares a candidate stream between 64 queries -- the union of their search balls,
+// ~1800 candidates per query at 8 x 8192 -- this one gives every query its own cells: 8 lanes per query deal the cells of
+// the 5 x 5 x 5 block around the query's cell between them (shells 0-1 first, then shell 2 against the bound that gave),
+// skip a cell whose box lies beyond the query's current K-th distance, scan the rest (~100-250 candidates per query) into
+// their own sorted K-lists and merge the eight lists with three bitonic exchange steps.  Exact: a skipped cell provably
+// holds nothing closer than the K-th (conservative box distance, ties included), and the search widens shell by shell
+// until the K-th distance is STRICTLY inside the block searched (or the block is the whole grid), so nothing outside can
+// enter or tie.  Same distances (reference rounding order, IEEE sqrt) and the same 64-bit (distance, CUB rank) order as
+// every other kernel of this file: ids and distance bits are identical.  Degenerate clouds (everything in a few cells)
+// degrade towards the brute-force pair count, never past it.
+constexpr int kCellInts = 4112;  // ints per cloud of the cell table (spatial.hip)
+
+__device__ __forceinline__ unsigned knn_spread4(unsigned v) {  // 4 bits -> every third bit (the sort's spread6 >> 6)
+  return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6);
+}
+__device__ __forceinline__ void knn_cswap(u64 &a, u64 &b) {
+  const bool lt = b < a;
+  const u64 lo = lt ? b : a, hi = lt ? a : b;
+  a = lo; b = hi;
+}
+// the eight lanes of a query end up with the same list: the 8 smallest keys of all their lists.  Three exchange steps on
+// the DPP crossbar (no LDS round trip): partner = lane ^ 1, lane ^ 2 (quad permutes), then 7 - lane within the eight
+// (row_half_mirror: every lane meets one of the other quad, whose four lanes already agree).
+template <int CTRL>
+__device__ __forceinline__ u64 knn_dpp_u64(u64 v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xF, 0xF, true);
+  return ((u64)(unsigned)hi << 32) | (unsigned)lo;
+}
+template <int CTRL>
+__device__ __forceinline__ void knn_merge_step(KnnState<8> &st) {
+  u64 c[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const u64 mine = st.keys[i], theirs = knn_dpp_u64<CTRL>(st.keys[7 - i]);
+    c[i] = mine < theirs ? mine : theirs;  // ascending list against the partner's descending one: the 8 smallest, bitonic
+  }
+  knn_cswap(c[0], c[4]); knn_cswap(c[1], c[5]); knn_cswap(c[2], c[6]); knn_cswap(c[3], c[7]);
+  knn_cswap(c[0], c[2]); knn_cswap(c[1], c[3]); knn_cswap(c[4], c[6]); knn_cswap(c[5], c[7]);
+  knn_cswap(c[0], c[1]); knn_cswap(c[2], c[3]); knn_cswap(c[4], c[5]); knn_cswap(c[6], c[7]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) st.keys[i] = c[i];
+}
+__device__ __forceinline__ void knn_merge_sublanes(KnnState<8> &st) {
+  knn_merge_step<0xB1>(st);   // quad_perm [1,0,3,2]
+  knn_merge_step<0x4E>(st);   // quad_perm [2,3,0,1]
+  knn_merge_step<0x141>(st);  // row_half_mirror
+  const unsigned hb = (unsigned)(st.keys[7] >> 32);
+  if (hb <= 0x7f800000u) {
+    const float dk = __uint_as_float(hb);
+    st.bound = __fmul_rn(__fmul_rn(dk, dk), 1.000001f);
+  }
+}
+
+__global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict__ sorted, const int *__restrict__ cells,
+                                                      int N, int K, KnnLadder lad, int32_t *__restrict__ nn,
+                                                      float *__restrict__ dist) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63, sub = lane & 7;
+  const int qi = blockIdx.x * 32 + (threadIdx.x >> 3);
+  const bool valid = qi < N;
+  const float4 *sc = sorted + (size_t)b * N;
+  const int *ct = cells + (size_t)b * kCellInts;
+  const float *hd = reinterpret_cast<const float *>(ct) + 4100;
+  const float lo[3] = {hd[0], hd[1], hd[2]}, scl[3] = {hd[3], hd[4], hd[5]};
+  const float4 qr = sc[valid ? qi : N - 1];
+  const float q[3] = {qr.x, qr.y, qr.z};
+  int cq[3];
+  float w[3], eps[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    cq[a] = min(63, max(0, (int)((q[a] - lo[a]) * scl[a]))) >> 2;  // the sort's cell arithmetic
+    w[a] = 4.f / scl[a];                                           // cell width
+    eps[a] = 2.5e-6f * w[a] * 16.f;  // a point may sit outside its cell's nominal interval by a few ulps of the extent
+  }
+  KnnState<8> st;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) st.keys[i] = ~0ull;
+  st.bound = valid ? INFINITY : -1.f;
+
+  // conservative squared distance from the query to cells cq[a] + o along one axis (0 inside the cell's own slab)
+  auto axis_d2 = [&](int a, int o) {
+    const float l = lo[a] + (float)(cq[a] + o) * w[a];
+    const float d = fmaxf(fmaxf(fmaxf(l - q[a], q[a] - (l + w[a])), 0.f) - eps[a], 0.f);
+    return d * d;
+  };
+  auto scan_range = [&](unsigned cid) {
+    const int beg = ct[cid], end = ct[cid + 1];
+    for (int j = beg; j < end; ++j) {
+      const float4 r = sc[j];
+      const float dx = r.x - q[0], dy = r.y - q[1], dz = r.z - q[2];
+      const float s2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));  // the reference's rounding order
+      knn_offer<8, false>(st, s2, __float_as_int(r.w), lad);
+    }
+  };
+  auto visit = [&](int dx, int dy, int dz) {  // the general form (the widening rounds)
+    const int ax = cq[0] + dx, ay = cq[1] + dy, az = cq[2] + dz;
+    if ((unsigned)ax > 15u || (unsigned)ay > 15u || (unsigned)az > 15u) return;
+    if ((axis_d2(0, dx) + axis_d2(1, dy) + axis_d2(2, dz)) * 0.99999f > st.bound) return;
+    scan_range(knn_spread4((unsigned)ax) | (knn_spread4((unsigned)ay) << 1) | (knn_spread4((unsigned)az) << 2));
+  };
+  // the 5 x 5 x 5 block: everything that depends on the x offset alone is computed once (five slabs: distance, cell bits,
+  // inside the grid or not); a lane then walks (dy, dz) columns and, per column, the five x offsets with constants
+  float d2x[5];
+  unsigned bitx[5];
+  bool okx[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    const int ax = cq[0] + t - 2;
+    okx[t] = (unsigned)ax <= 15u;
+    d2x[t] = okx[t] ? axis_d2(0, t - 2) : INFINITY;
+    bitx[t] = knn_spread4((unsigned)(ax & 15));
+  }
+  // is the K-th distance strictly inside the block of radius R around the query's cell?  (faces on the grid's border
+  // have nothing behind them)
+  auto inside = [&](int R) {
+    float G = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (cq[a] - R > 0) G = fminf(G, (q[a] - (lo[a] + (float)(cq[a] - R) * w[a])) - eps[a]);
+      if (cq[a] + R < 15) G = fminf(G, ((lo[a] + (float)(cq[a] + R + 1) * w[a]) - q[a]) - eps[a]);
+    }
+    if (G == INFINITY) return true;
+    G = fmaxf(G, 0.f);
+    return st.bound < G * G * 0.99999f;  // bound = the (1 + 2^-20)-inflated square of the K-th distance, inf while the list is short
+  };
+
+  // shells 0 and 1 of the 5 x 5 x 5 block (27 cells), then shell 2 (98 cells) against the merged bound
+  // after a merge all eight lanes hold the SAME list: before they scan on, seven of them empty theirs (the bound stays),
+  // or the next merge would count every entry eight times
+  auto keep_one_copy = [&]() {
+    if (sub != 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) st.keys[i] = ~0ull;
+    }
+  };
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass) keep_one_copy();
+#pragma unroll 1
+    for (int col = sub; col < 25; col += 8) {
+      const int dz = col / 5, dy = col - dz * 5;                     // offsets + 2
+      const int ay = cq[1] + dy - 2, az = cq[2] + dz - 2;
+      if ((unsigned)ay > 15u || (unsigned)az > 15u) continue;
+      const bool inner = abs(dy - 2) <= 1 && abs(dz - 2) <= 1;       // the column crosses shells 0-1 at dx in -1..1
+      if (pass == 0 && !inner) continue;
+      const float d2yz = axis_d2(1, dy - 2) + axis_d2(2, dz - 2);
+      const unsigned bityz = (knn_spread4((unsigned)ay) << 1) | (knn_spread4((unsigned)az) << 2);
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        const bool shell01 = inner && t >= 1 && t <= 3;
+        if ((pass == 0) != shell01) continue;
+        if (!okx[t] || (d2yz + d2x[t]) * 0.99999f > st.bound) continue;
+        scan_range(bityz | bitx[t]);
+      }
+    }
+    knn_merge_sublanes(st);
+  }
+  int R = 2;
+  bool done = !valid || inside(R);
+  while (__any(!done)) {  // rare: sparse corners, clustered clouds -- one more shell per round, all lanes merge
+    ++R;
+    keep_one_copy();
+    if (!done) {
+      const int side = 2 * R + 1, tot = side * side * side;
+#pragma unroll 1
+      for (int c = sub; c < tot; c += 8) {
+        const int dz = c / (side * side), rr = c - dz * side * side, dy = rr / side, dx = rr - dy * side;
+        if (max(abs(dx - R), max(abs(dy - R), abs(dz - R))) == R) visit(dx - R, dy - R, dz - R);
+      }
+    }
+    knn_merge_sublanes(st);
+    done = done || R >= 15 || inside(R);
+  }
+  if (valid && sub < K) {
+    const int y = __float_as_int(qr.w);  // the query's original index
+    u64 key = st.keys[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) key = sub == i ? st.keys[i] : key;
+    const size_t o = ((size_t)b * N + y) * K + sub;
+    if (key == ~0ull) {  // fewer than K points: reference pads with id -1 / FLT_MAX (:110-111)
+      nn[o] = -1;
+      dist[o] = FLT_MAX;
+    } else {
+      const unsigned tb = (unsigned)key;
+      nn[o] = (int)(((tb % (unsigned)lad.cv) << lad.log2ct) + tb / (unsigned)lad.cv);
+      dist[o] = __uint_as_float((unsigned)(key >> 32));
+    }
+  }
+}
+
+DH3D_API int dh3d_knn_grid(const float *sorted, const int32_t *cells, int B, int N, int K, int32_t *nn, float *dist,
+                           void *stream) {
+  DH3D_REQUIRE(sorted && cells && nn && dist && B > 0 && N > 0 && K > 0);
+  DH3D_SUPPORTED(K <= 8 && N <= 16384 && B <= 65535);
+  const KnnLadder lad = knn_ladder(N);
+  hipLaunchKernelGGL(knn_grid_kernel, dim3(dh3d_cdiv(N, 32), B), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4 *>(sorted), cells, N, K, lad, nn, dist);
+  return dh3d_launch_status();
+}
+
 #ifdef DH3D_KNN_PROBE
 DH3D_API int dh3d_knn_probe_read(long long *host, int n) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_kprobe), sizeof(long long) * n) == hipSuccess ? 0 : 3;

@@ -18,6 +18,7 @@ namespace {
 
 constexpr int kThreads = 1024;
 constexpr int kWaves = 16;
+constexpr int kCellInts = 4112;  // ints per cloud of the cell table (dh3d_spatial_sort_cells)
 
 #ifdef DH3D_SORT_PROBE  // dev instrumentation (tools/sort_probe.py): s_memtime stamps of wave 0 / wave 15 of a few clouds
 __device__ long long g_sprobe[8 * 2 * 16];
@@ -35,10 +36,14 @@ __device__ __forceinline__ unsigned spread6(unsigned v) {  // 6 bits -> every th
   return v;
 }
 
+// cells (may be NULL): per cloud kCellInts ints -- [0, 4096]: first sorted position of every 16 x 16 x 16 grid cell in
+// Morton order of the cells (the top 12 bits of the sort key; an empty cell's entry = the next cell's), [4096] = N;
+// [4100..4105] as floats: the grid's origin (x, y, z) and its cells-per-unit scale 64 / extent per axis (a cell = 4
+// Morton steps) -- the uniform grid the cell-list kNN (knn.hip: knn_grid_kernel) searches.
 template <int PPT>
 __global__ __launch_bounds__(kThreads) void spatial_sort_kernel(const float *__restrict__ xyz, int N,
                                                                int npad, float4 *__restrict__ sorted,
-                                                               float *__restrict__ gbox) {
+                                                               float *__restrict__ gbox, int *__restrict__ cells) {
   extern __shared__ __attribute__((aligned(16))) unsigned s_raw[];  // keys[2][npad] | hist[16][64] | 6*kWaves floats
   unsigned *s_hist = s_raw + 2 * npad;
   float *s_red = reinterpret_cast<float *>(s_hist + kWaves * 64);
@@ -193,17 +198,36 @@ __global__ __launch_bounds__(kThreads) void spatial_sort_kernel(const float *__r
       }
     }
   }
+  if (cells) {
+    int *ct = cells + (size_t)b * kCellInts;
+    // position i opens every cell in (cell(i - 1), cell(i)]; the cells behind the last point open at N
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const int i = wave * SEG + j * 64 + lane;
+      if (i < N) {
+        const int cur = (int)(s_keys[i] >> 20), prev = i > 0 ? (int)(s_keys[i - 1] >> 20) : -1;
+        for (int c = prev + 1; c <= cur; ++c) ct[c] = i;
+        if (i == N - 1)
+          for (int c = cur + 1; c <= 4096; ++c) ct[c] = N;
+      }
+    }
+    if (tid == 0) {
+      float *hd = reinterpret_cast<float *>(ct) + 4100;
+      hd[0] = lo[0]; hd[1] = lo[1]; hd[2] = lo[2];
+      hd[3] = scale[0]; hd[4] = scale[1]; hd[5] = scale[2];
+    }
+  }
   SPROBE(10);
 }
 
 template <int PPT>
-int sort_launch(const float *xyz, int B, int N, float4 *sorted, float *gbox, hipStream_t s) {
+int sort_launch(const float *xyz, int B, int N, float4 *sorted, float *gbox, int *cells, hipStream_t s) {
   int npad = 2;
   while (npad < N) npad <<= 1;
   if (npad < 64 * kWaves) npad = 64 * kWaves;  // one 64-key step per wave at least
   const size_t lds = sizeof(unsigned) * (2 * (size_t)npad + kWaves * 64) + sizeof(float) * 6 * kWaves;
   DH3D_ALLOW_BIG_LDS((spatial_sort_kernel<PPT>));
-  hipLaunchKernelGGL((spatial_sort_kernel<PPT>), dim3(B), dim3(kThreads), lds, s, xyz, N, npad, sorted, gbox);
+  hipLaunchKernelGGL((spatial_sort_kernel<PPT>), dim3(B), dim3(kThreads), lds, s, xyz, N, npad, sorted, gbox, cells);
   return dh3d_launch_status();
 }
 
@@ -215,14 +239,23 @@ DH3D_API int dh3d_sort_probe_read(long long *host, int n) {
 }
 #endif
 
-DH3D_API int dh3d_spatial_sort(const float *xyz, int B, int N, float *sorted, float *gbox, void *stream) {
+static int spatial_sort_any(const float *xyz, int B, int N, float *sorted, float *gbox, int *cells, void *stream) {
   DH3D_REQUIRE(xyz && sorted && gbox && B > 0 && N > 0);
   DH3D_SUPPORTED(N <= 16384);
   hipStream_t s = (hipStream_t)stream;
   float4 *so = reinterpret_cast<float4 *>(sorted);
-  if (N <= 1024) return sort_launch<1>(xyz, B, N, so, gbox, s);
-  if (N <= 2048) return sort_launch<2>(xyz, B, N, so, gbox, s);
-  if (N <= 4096) return sort_launch<4>(xyz, B, N, so, gbox, s);
-  if (N <= 8192) return sort_launch<8>(xyz, B, N, so, gbox, s);
-  return sort_launch<16>(xyz, B, N, so, gbox, s);
+  if (N <= 1024) return sort_launch<1>(xyz, B, N, so, gbox, cells, s);
+  if (N <= 2048) return sort_launch<2>(xyz, B, N, so, gbox, cells, s);
+  if (N <= 4096) return sort_launch<4>(xyz, B, N, so, gbox, cells, s);
+  if (N <= 8192) return sort_launch<8>(xyz, B, N, so, gbox, cells, s);
+  return sort_launch<16>(xyz, B, N, so, gbox, cells, s);
+}
+
+DH3D_API int dh3d_spatial_sort(const float *xyz, int B, int N, float *sorted, float *gbox, void *stream) {
+  return spatial_sort_any(xyz, B, N, sorted, gbox, nullptr, stream);
+}
+
+DH3D_API int dh3d_spatial_sort_cells(const float *xyz, int B, int N, float *sorted, float *gbox, int32_t *cells, void *stream) {
+  DH3D_REQUIRE(cells);
+  return spatial_sort_any(xyz, B, N, sorted, gbox, cells, stream);
 }

@@ -12,6 +12,8 @@ The forward is launch-bound when driven op by op from Python (about 30 short ker
 `DH3D.graphed(example)` captures it into one hipGraph (two streams: feature path + geometry path)
 and replays it with static buffers.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -25,6 +27,10 @@ def tf_variable_name(state_dict_key):
     name = state_dict_key.replace(".", "/")
     name = name.replace("mean_EMA", "mean/EMA").replace("variance_EMA", "variance/EMA")
     return name
+
+
+# dev A/B switch (DH3D_KNN_GRID=0: the Morton-pruned shared scan for every K); both kernels give identical ids
+KNN_GRID = os.environ.get("DH3D_KNN_GRID", "1") != "0"
 
 
 class DH3D(nn.Module):
@@ -204,7 +210,9 @@ class DH3D(nn.Module):
         geo = bb.Geometry(points, self.knn_num, fps_contract=self.config.fps_contract)
         main = torch.cuda.current_stream()
         if points.shape[1] <= 16384 and (knn_inds is None or (4096 <= points.shape[1] and self.config.fps_contract is None)):
-            geo.ordered()  # Morton order + group boxes: shared by the kNN (side) and the pruned FPS (here)
+            # Morton order + group boxes: shared by the kNN (side) and the pruned FPS (here); + the cell table when the
+            # kNN is the cell-list search
+            geo.ordered(cells=knn_inds is None and self.knn_num <= 8 and KNN_GRID)
         if self._geo_stream is None:
             self._geo_stream = torch.cuda.Stream(device=points.device)
         side = self._geo_stream
@@ -238,8 +246,11 @@ class DH3D(nn.Module):
                 # core/utils.py:53-57)
                 geo.nbr, _ = pm.knn_xyz(points, self.knn_num)
             else:
-                srt, gbox = geo.ordered()  # exact kNN with box pruning
-                geo.nbr, _ = pm.knn_sorted(srt, gbox, self.knn_num)  # core/model.py:157
+                srt, gbox = geo.ordered()
+                if geo.cells is not None:   # cell lists on the sort's grid, 8 lanes per query (csrc/knn.hip knn_grid_kernel)
+                    geo.nbr, _ = pm.knn_grid(srt, geo.cells, self.knn_num)  # core/model.py:157
+                else:                       # the pruned shared scan (K > 8)
+                    geo.nbr, _ = pm.knn_sorted(srt, gbox, self.knn_num)
             geo.nbr.record_stream(main)
         return geo
 

@@ -34,6 +34,30 @@ def spatial_sort(xyz):
     return srt, gbox
 
 
+CELL_INTS = 4112  # include/dh3d_hip.h DH3D_CELL_INTS
+
+
+def spatial_sort_cells(xyz):
+    """spatial_sort + the 16^3 cell table of every cloud: (sorted, gbox, cells [B, CELL_INTS] int32)."""
+    x = L.require_cuda_f32(xyz, "xyz", 3)
+    B, N, _ = x.shape
+    srt = torch.empty((B, N, 4), dtype=torch.float32, device=x.device)
+    gbox = torch.empty((B, (N + 63) // 64, 8), dtype=torch.float32, device=x.device)
+    cells = torch.empty((B, CELL_INTS), dtype=torch.int32, device=x.device)
+    L.check(L.lib().dh3d_spatial_sort_cells(L.ptr(x), B, N, L.ptr(srt), L.ptr(gbox), L.ptr(cells), L.stream_ptr()),
+            "spatial_sort_cells")
+    return srt, gbox, cells
+
+
+def knn_grid(srt, cells, k):
+    """kNN by cell lists on spatial_sort_cells() output; same (nbr [B,N,K], dist) as knn_xyz bit for bit.  K <= 8."""
+    B, N, _ = srt.shape
+    nn = torch.empty((B, N, k), dtype=torch.int32, device=srt.device)
+    dist = torch.empty((B, N, k), dtype=torch.float32, device=srt.device)
+    L.check(L.lib().dh3d_knn_grid(L.ptr(srt), L.ptr(cells), B, N, k, L.ptr(nn), L.ptr(dist), L.stream_ptr()), "knn_grid")
+    return nn, dist
+
+
 def knn_sorted(srt, gbox, k):
     """kNN from spatial_sort() output; same (nbr [B,N,K], dist) as knn_xyz, original indexing."""
     B, N, _ = srt.shape

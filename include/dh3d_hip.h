@@ -222,6 +222,17 @@ int dh3d_spatial_sort(const float *xyz, int B, int N, float *sorted, float *gbox
 int dh3d_knn_sorted(const float *sorted, const float *gbox, int B, int N, int K, int32_t *nn, float *dist,
                     void *stream);
 
+/* dh3d_spatial_sort that also writes the CELL TABLE of the 16 x 16 x 16 grid over each cloud's bounding box: cells
+ * [B, DH3D_CELL_INTS] int32 -- [0..4096] the first sorted position of every cell (cells in Morton order = the top 12 bits of
+ * the sort key; [4096] = N), [4100..4105] as floats the grid origin and its 64 / extent scale per axis. */
+#define DH3D_CELL_INTS 4112
+int dh3d_spatial_sort_cells(const float *xyz, int B, int N, float *sorted, float *gbox, int32_t *cells, void *stream);
+
+/* KnnBruteforce on that grid (cell-list search: every query scans the cells its K-th distance reaches, 8 lanes per
+ * query; csrc/knn.hip knn_grid_kernel).  Same outputs as dh3d_knn_bruteforce_xyz bit for bit -- ids in the reference's
+ * (distance, CUB rank) order, IEEE distances, original point order.  K <= 8, N <= 16384. */
+int dh3d_knn_grid(const float *sorted, const int32_t *cells, int B, int N, int K, int32_t *nn, float *dist, void *stream);
+
 /* ThreeNN on ordered clouds: identical dist / idx to dh3d_three_nn (original indexing on both sides) from the
  * dh3d_spatial_sort outputs of the query cloud (sorted1 [b,n,4], gbox1) and of the candidate set (sorted2 [b,m,4],
  * gbox2; the boxes are not needed by the current kernel and may be NULL).  Every candidate is still visited; the

@@ -470,3 +470,69 @@ def test_flex_ops_float64_forward_and_numeric_gradients(dev):
     # mixed dtypes are refused like the op registration would
     with pytest.raises(ValueError):
         ops.flex_convolution(f, p.float(), nb, th, bi)
+
+
+def _knn_clouds(name, B, N, rng):
+    if name == "uniform":
+        return rng.random((B, N, 3), dtype=np.float32)
+    if name == "oxford_extent":
+        return (rng.random((B, N, 3), dtype=np.float32) * np.array([60, 60, 8], np.float32) - 30).astype(np.float32)
+    if name == "clusters":  # a few dense blobs + sparse background: cells with hundreds of points next to empty ones
+        c = rng.random((B, 6, 3), dtype=np.float32)
+        pts = c[:, rng.integers(0, 6, N)] + rng.normal(0, 0.004, (B, N, 3)).astype(np.float32)
+        pts[:, : N // 8] = rng.random((B, N // 8, 3), dtype=np.float32)
+        return pts.astype(np.float32)
+    if name == "lattice":   # exact ties everywhere: the CUB (id mod C_THREADS, id div C_THREADS) order decides
+        g = np.stack(np.meshgrid(*[np.arange(32)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+        pts = np.stack([g[rng.permutation(len(g))[:N]] for _ in range(B)])
+        return (pts * 0.25).astype(np.float32)
+    if name == "duplicates":
+        pts = rng.random((B, N, 3), dtype=np.float32)
+        pts[:, N // 2:] = pts[:, : N - N // 2]            # every point twice
+        return pts
+    if name == "plane":     # degenerate extent along z
+        pts = rng.random((B, N, 3), dtype=np.float32)
+        pts[:, :, 2] = 0.5
+        return pts
+    if name == "one_point":  # everything in one cell: the brute-force limit of the cell search
+        return np.tile(rng.random((B, 1, 3), dtype=np.float32), (1, N, 1))
+    if name == "outliers":  # a tight cloud and a few far points: the grid is almost empty
+        pts = (rng.random((B, N, 3), dtype=np.float32) * 0.01).astype(np.float32)
+        pts[:, :5] = rng.random((B, 5, 3), dtype=np.float32) * 100
+        return pts
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name,B,N,K", [
+    ("uniform", 8, 8192, 8), ("uniform", 3, 4097, 8), ("uniform", 2, 16384, 8), ("uniform", 2, 9000, 5),
+    ("oxford_extent", 4, 4096, 8), ("clusters", 2, 8192, 8), ("lattice", 2, 8192, 8), ("lattice", 1, 4096, 3),
+    ("duplicates", 2, 4096, 8), ("plane", 2, 4096, 8), ("one_point", 1, 2100, 8), ("outliers", 2, 4096, 8),
+    ("uniform", 1, 2049, 1)])
+def test_knn_grid_cell_list_search_is_bit_equal_to_brute_force(dev, name, B, N, K):
+    """knn_grid (cell lists on the sort's 16^3 grid, 8 lanes per query) == the brute-force kernel: ids AND distance
+    bits, on uniform / anisotropic / clustered / tie-ridden / degenerate clouds; the brute-force kernel itself is pinned on
+    the oracle above."""
+    from dh3d_amd import pm
+    rng = np.random.default_rng(abs(hash((name, B, N, K))) % (2 ** 31))
+    pts = torch.from_numpy(_knn_clouds(name, B, N, rng)).to(dev)
+    srt, gbox, cells = pm.spatial_sort_cells(pts)
+    s2, g2 = pm.spatial_sort(pts)
+    assert torch.equal(srt, s2) and torch.equal(gbox, g2)      # the cell table changes nothing else
+    ct = cells[:, :4097].cpu().numpy()
+    assert (ct[:, 0] == 0).all() and (ct[:, 4096] == N).all() and (np.diff(ct, axis=1) >= 0).all()
+    nn_g, d_g = pm.knn_grid(srt, cells, K)
+    nn_b, d_b = pm.knn_xyz(pts, K)
+    assert torch.equal(nn_g, nn_b), (name, int((nn_g != nn_b).sum()))
+    assert torch.equal(d_g.view(torch.int32), d_b.view(torch.int32))
+    nn_s, d_s = pm.knn_sorted(srt, gbox, K)
+    assert torch.equal(nn_s, nn_b)
+
+
+def test_knn_grid_vs_oracle_N8192(dev, oracle):
+    from dh3d_amd import pm
+    pts = np.random.default_rng(8192).random((2, 8192, 3), dtype=np.float32)
+    srt, _, cells = pm.spatial_sort_cells(torch.from_numpy(pts).to(dev))
+    nn_g, d_g = pm.knn_grid(srt, cells, 8)
+    nn_o, d_o = oracle.knn_bruteforce(np.ascontiguousarray(pts.transpose(0, 2, 1)), 8)
+    assert np.array_equal(nn_g.cpu().numpy(), nn_o)
+    assert np.array_equal(d_g.cpu().numpy().view(np.uint32), d_o.view(np.uint32))
