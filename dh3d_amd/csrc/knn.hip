@@ -1232,334 +1232,6 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict_
   }
 }
 
-// ------------------------------------------------------------------------------------------------ block kNN
-// The pruned shared scan of knn_sorted_kernel on GRID-ALIGNED units instead of runs of 64 Morton neighbours:
-//   queries   : a wave takes (up to) 64 consecutive sorted points of ONE 4 x 4 x 4-cell block of the sort's grid (64 blocks
-//               per cloud, each a contiguous range of the order; ~N / 64 points);
-//   candidates: 2 x 2 x 2-cell BRICKS (512 per cloud, contiguous ranges, boxes known from the grid) of the 4 x 4 x 4 bricks
-//               around the block -- lane = brick: box against the chunk's own bounding box, nearest first, each one
-//               re-tested against the wave's current bound and per query before it is scanned, the next one's records
-//               already in flight.
-// A run of 64 Morton neighbours is often two or three far-apart pieces (its box spans them: ~1800 candidates per query
-// at 8 x 8192); a chunk of a cubic block reaches ~20 bricks of ~16 points.  Everything a candidate goes through -- the
-// packed-f32 screen, the per-lane queue, the 64-bit (distance, CUB rank) insertion -- is knn_sorted_kernel's, so ids and
-// distance bits are the same.  Exact: a skipped brick cannot hold anything within the K-th distance of any query of the
-// wave (conservative boxes); when a query's K-th distance is not strictly inside the brick neighbourhood (sparse corners,
-// clustered clouds) the wave goes on through every other brick of the cloud.
-__device__ __forceinline__ unsigned knn_spread3(unsigned v) { return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4); }
-__device__ __forceinline__ unsigned knn_compact3(unsigned v) { return (v & 1u) | ((v >> 2) & 2u) | ((v >> 4) & 4u); }
-
-#ifdef DH3D_KNN_BLOCK_PROBE
-__device__ unsigned long long g_kbprobe[16];
-#endif
-template <int KMAX>
-__global__ __launch_bounds__(256) void knn_block_kernel(const float4 *__restrict__ sorted, const int *__restrict__ cells,
-                                                       int N, int K, KnnLadder lad, int32_t *__restrict__ nn,
-                                                       float *__restrict__ dist) {
-  __shared__ __attribute__((aligned(16))) float s_c[4][64 * 3];  // pair-SoA image per wave
-  __shared__ uint2 s_q[4][kQueue * 64];
-  __shared__ int s_id[4][64];
-  __shared__ float s_bound[4][64];          // every wave's current per-query bound (a valid upper bound for the others)
-  __shared__ u64 s_m[3][KMAX][64];          // the lists of waves 1-3 for the final merge
-  const int b = blockIdx.y, lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int W = blockIdx.x;  // the workgroup's chunk among the cloud's: its four waves split the candidate bricks
-  const float4 *sc = sorted + (size_t)b * N;
-  const int *ct = cells + (size_t)b * kCellInts;
-  const float *hd = reinterpret_cast<const float *>(ct) + 4100;
-  float *my_c = s_c[wave];
-  uint2 *my_q = s_q[wave];
-  int *my_id = s_id[wave];
-
-  // ---- chunk -> (block, query range): lane = block, chunks per block scanned across the wave
-  const int bstart = ct[lane * 64], bend = ct[lane * 64 + 64];
-  const int nch = (bend - bstart + 63) >> 6;
-  int inc = nch;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int up = __shfl_up(inc, off, 64);
-    if (lane >= off) inc += up;
-  }
-  if (W >= __builtin_amdgcn_readlane(inc, 63)) return;  // whole workgroup
-  const int blk = __builtin_ctzll(__ballot(inc > W));
-  const int q0 = __builtin_amdgcn_readlane(bstart, blk) + (W - __builtin_amdgcn_readlane(inc - nch, blk)) * 64;
-  const int qend = min(q0 + 64, __builtin_amdgcn_readlane(bend, blk));
-  const int qi = q0 + lane;
-  const bool valid = qi < qend;
-  const float4 pad = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(-1));
-  const float4 qr = valid ? sc[qi] : pad;
-  const f32x2 qx2 = {qr.x, qr.x}, qy2 = {qr.y, qr.y}, qz2 = {qr.z, qr.z};
-  // (scalars, not arrays: anything indexed through a lambda's reference parameter went to scratch -- 423 scratch
-  //  instructions and 400 us in the first version of this kernel)
-  const float qlx = wave_min_f32(valid ? qr.x : INFINITY), qhx = wave_max_f32(valid ? qr.x : -INFINITY);
-  const float qly = wave_min_f32(valid ? qr.y : INFINITY), qhy = wave_max_f32(valid ? qr.y : -INFINITY);
-  const float qlz = wave_min_f32(valid ? qr.z : INFINITY), qhz = wave_max_f32(valid ? qr.z : -INFINITY);
-  // grid origin, BRICK width (two cells), slack of the cell arithmetic
-  const float gx = hd[0], gy = hd[1], gz = hd[2];
-  const float bwx = 8.f / hd[3], bwy = 8.f / hd[4], bwz = 8.f / hd[5];
-  const float ex = 2.5e-6f * bwx * 8.f, ey = 2.5e-6f * bwy * 8.f, ez = 2.5e-6f * bwz * 8.f;
-  const int Bx = (blk & 1) | ((blk >> 2) & 2), By = ((blk >> 1) & 1) | ((blk >> 3) & 2), Bz = ((blk >> 2) & 1) | ((blk >> 4) & 2);
-
-  KnnState<KMAX> st;
-#pragma unroll
-  for (int i = 0; i < KMAX; ++i) st.keys[i] = ~0ull;
-  st.bound = INFINITY;
-  int cnt = 0;
-  float wave_bound = INFINITY;  // max over the wave's valid lanes of st.bound (refreshed after each drain)
-  s_bound[wave][lane] = INFINITY;
-  __syncthreads();
-
-#ifdef DH3D_KNN_BLOCK_PROBE
-  long long pr_t0 = clock64(), pr_drain = 0, pr_scan = 0, pr_choose = 0;
-  int pr_ndrain = 0, pr_nslots = 0, pr_nsteps = 0;
-#define KBP(...) __VA_ARGS__
-#else
-#define KBP(...)
-#endif
-  auto drain = [&]() __attribute__((always_inline)) {
-    KBP(const long long d0 = clock64(); ++pr_ndrain;)
-    const int deepest = -wave_min_i32(-cnt);
-    KBP(pr_nslots += deepest;)
-    uint2 nxt = my_q[lane];
-#pragma unroll 1
-    for (int i = 0; i < deepest; ++i) {  // wave-uniform trip count
-      const uint2 e = nxt;
-      if (i + 1 < deepest) nxt = my_q[(i + 1) * 64 + lane];
-      if (i < cnt) knn_offer<KMAX, true>(st, __uint_as_float(e.x), (int)e.y, lad);
-    }
-    cnt = 0;
-    // publish this wave's bound per query, adopt the tightest of the four (no barrier: a stale value is still a valid
-    // upper bound of the query's K-th distance)
-    volatile float *sb = &s_bound[0][0];
-    sb[wave * 64 + lane] = st.bound;
-    st.bound = fminf(fminf(st.bound, sb[((wave + 1) & 3) * 64 + lane]),
-                     fminf(sb[((wave + 2) & 3) * 64 + lane], sb[((wave + 3) & 3) * 64 + lane]));
-    wave_bound = wave_max_f32(valid ? st.bound : 0.f);
-    KBP(pr_drain += clock64() - d0;)
-  };
-  // evaluate `clen` (<= 64) candidates whose records sit one per lane in `cr` (+inf beyond clen), 16 per step
-  auto scan_records = [&](const float4 cr, int clen) __attribute__((always_inline)) {
-    KBP(const long long s0 = clock64(), dr0 = pr_drain; pr_nsteps += (clen + 15) >> 4;)
-    my_c[cand_slot(lane, 0)] = cr.x;
-    my_c[cand_slot(lane, 1)] = cr.y;
-    my_c[cand_slot(lane, 2)] = cr.z;
-    my_id[lane] = __float_as_int(cr.w);
-    __builtin_amdgcn_wave_barrier();
-    for (int j = 0; j < clen; j += 16) {
-      f32x2 s2[2][4];
-      float mn[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        knn_dist8(my_c + ((j >> 2) + 2 * u) * 12, qx2, qy2, qz2, s2[u]);
-        mn[u] = knn_min8(s2[u]);
-      }
-      if (__any(valid && fminf(mn[0], mn[1]) <= st.bound)) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          if (valid && mn[u] <= st.bound) {
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-              const float sv = s2[u][t >> 1][t & 1];
-              if (sv <= st.bound && j + 8 * u + t < clen) {
-                my_q[cnt * 64 + lane] = make_uint2(__float_as_uint(sv), (unsigned)my_id[j + 8 * u + t]);
-                ++cnt;
-              }
-            }
-          }
-          if (__any(cnt > kQueue - 8)) drain();
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    KBP(pr_scan += (clock64() - s0) - (pr_drain - dr0);)
-  };
-  // a brick = the sorted range [kb, ke): its first 64 records may already be in `first`
-  auto scan_brick = [&](int kb, int ke, const float4 first) __attribute__((always_inline)) {
-#ifdef DH3D_KNN_BLOCK_PROBE
-    if (lane == 0) { atomicAdd(&g_kbprobe[2], 1ull); atomicAdd(&g_kbprobe[3], (unsigned long long)(ke - kb)); }
-#endif
-    scan_records(first, min(64, ke - kb));
-    for (int base = kb + 64; base < ke; base += 64)  // dense bricks
-      scan_records(base + lane < ke ? sc[base + lane] : pad, min(64, ke - base));
-  };
-  // box of brick (cx, cy, cz) against the box [lo, hi] (the chunk's, or a query as a degenerate box), conservative
-  auto axis_gap = [](float g, float w, float e, int c, float lo_, float hi_) __attribute__((always_inline)) {
-    const float l = g + (float)c * w - e, h = g + (float)(c + 1) * w + e;
-    return fmaxf(fmaxf(l - hi_, lo_ - h), 0.f);
-  };
-  auto brick_chunk_d2 = [&](int cx, int cy, int cz) __attribute__((always_inline)) {
-    const float dx = axis_gap(gx, bwx, ex, cx, qlx, qhx), dy = axis_gap(gy, bwy, ey, cy, qly, qhy),
-                dz = axis_gap(gz, bwz, ez, cz, qlz, qhz);
-    return fmaf(dz, dz, fmaf(dy, dy, dx * dx)) * 0.99999f;
-  };
-  auto brick_query_d2 = [&](int cx, int cy, int cz) __attribute__((always_inline)) {
-    const float dx = axis_gap(gx, bwx, ex, cx, qr.x, qr.x), dy = axis_gap(gy, bwy, ey, cy, qr.y, qr.y),
-                dz = axis_gap(gz, bwz, ez, cz, qr.z, qr.z);
-    return fmaf(dz, dz, fmaf(dy, dy, dx * dx)) * 0.99999f;
-  };
-
-  // ---- the 4 x 4 x 4 bricks around the block, lane = brick
-  const int kcx = 2 * Bx - 1 + (lane & 3), kcy = 2 * By - 1 + ((lane >> 2) & 3), kcz = 2 * Bz - 1 + (lane >> 4);
-  const bool inb = (unsigned)kcx <= 7u && (unsigned)kcy <= 7u && (unsigned)kcz <= 7u;
-  const unsigned kid = inb ? (knn_spread3((unsigned)kcx) | (knn_spread3((unsigned)kcy) << 1) | (knn_spread3((unsigned)kcz) << 2)) : 0u;
-  const int kbeg = ct[kid * 8], kend = inb ? ct[kid * 8 + 8] : kbeg;
-  // the 64 bricks are dealt to the four waves on diagonals ((x + y + z) mod 4): every wave gets near and far ones
-  const bool mine = (((lane & 3) + ((lane >> 2) & 3) + (lane >> 4)) & 3) == wave;
-  float bd = (mine && inb && kend > kbeg) ? brick_chunk_d2(kcx, kcy, kcz) : INFINITY;  // INFINITY = nothing (left) to scan here
-  {
-    // Nearest first, in BATCHES: up to four bricks whose points fit the 64 staging lanes are chosen together (each
-    // re-tested against the wave's bound and per query when it is chosen), their records packed densely -- one dependent
-    // round trip and full 16-candidate steps per batch instead of one round trip and a half-empty step per ~16-point
-    // brick -- and the next batch is chosen and requested before the current one is scanned.
-    // A batch: total candidates, and for lane i its record's position = base_t + i with t = #(prefixes <= i).
-    int b_total = 0, b_dense_l = -1;
-    float4 b_rec = pad;
-    bool exhausted = false;
-    auto choose = [&](int &total, int &dense_l, float4 &rec) __attribute__((always_inline)) {
-      KBP(const long long c0 = clock64();)
-      total = 0;
-      dense_l = -1;
-      int p1 = 64, p2 = 64, p3 = 64, base0 = 0, base1 = 0, base2 = 0, base3 = 0, n = 0;
-      while (n < 4 && !exhausted) {
-        const float m = wave_min_f32(bd);
-        if (!(m <= wave_bound)) { exhausted = true; break; }  // (also m == inf: nothing left) -- later bricks are farther
-        const int l = __builtin_ctzll(__ballot(bd == m));
-        const int kb = __builtin_amdgcn_readlane(kbeg, l), c = __builtin_amdgcn_readlane(kend, l) - kb;
-        if (c > 64 ? n > 0 : total + c > 64) break;            // does not fit this batch: it opens the next one
-        if (lane == l) bd = INFINITY;
-        const int ccx = __builtin_amdgcn_readlane(kcx, l), ccy = __builtin_amdgcn_readlane(kcy, l),
-                  ccz = __builtin_amdgcn_readlane(kcz, l);
-        if (!__any(valid && brick_query_d2(ccx, ccy, ccz) <= st.bound)) continue;  // no query reaches it (bounds only shrink)
-        if (c > 64) { dense_l = l; total = c; break; }        // a dense brick goes alone, 64 points at a time
-        if (n == 0) base0 = kb;
-        else if (n == 1) { p1 = total; base1 = kb - total; }
-        else if (n == 2) { p2 = total; base2 = kb - total; }
-        else { p3 = total; base3 = kb - total; }
-        total += c;
-        ++n;
-      }
-      if (dense_l < 0 && total > 0) {
-        const int base = lane >= p3 ? base3 : lane >= p2 ? base2 : lane >= p1 ? base1 : base0;
-        rec = lane < total ? sc[base + lane] : pad;
-      }
-      KBP(pr_choose += clock64() - c0;)
-    };
-    choose(b_total, b_dense_l, b_rec);
-    while (b_total > 0) {
-      const int total = b_total, dense_l = b_dense_l;
-      const float4 cr = b_rec;
-      if (dense_l >= 0) {
-        const int kb = __builtin_amdgcn_readlane(kbeg, dense_l), ke = __builtin_amdgcn_readlane(kend, dense_l);
-        scan_brick(kb, ke, kb + lane < ke ? sc[kb + lane] : pad);
-        choose(b_total, b_dense_l, b_rec);
-      } else {
-        choose(b_total, b_dense_l, b_rec);  // the next batch's records are in flight while this one is scanned
-        scan_records(cr, total);
-      }
-    }
-  }
-  if (__any(cnt > 0)) drain();
-
-  // ---- the four waves' lists -> wave 0 (keys are unique across waves: every brick was scanned by one of them)
-  if (wave > 0) {
-#pragma unroll
-    for (int i = 0; i < KMAX; ++i) s_m[wave - 1][i][lane] = st.keys[i];
-  }
-  __syncthreads();
-  if (wave > 0) return;
-#pragma unroll 1
-  for (int w2 = 0; w2 < 3; ++w2) {
-#pragma unroll
-    for (int i = 0; i < KMAX; ++i) knn_insert_key<KMAX, true>(st, s_m[w2][i][lane]);
-  }
-
-  // ---- is every query's K-th distance strictly inside the neighbourhood?  (faces on the grid's border have nothing behind)
-  bool ok = true;
-  if (valid) {
-    float G = INFINITY;
-    auto face = [&](float g, float w, float e, int Bc, float qa) __attribute__((always_inline)) {   // brick range of the neighbourhood: 2 Bc - 1 .. 2 Bc + 2
-      if (2 * Bc - 1 > 0) G = fminf(G, (qa - (g + (float)(2 * Bc - 1) * w)) - e);
-      if (2 * Bc + 2 < 7) G = fminf(G, ((g + (float)(2 * Bc + 3) * w) - qa) - e);
-    };
-    face(gx, bwx, ex, Bx, qr.x); face(gy, bwy, ey, By, qr.y); face(gz, bwz, ez, Bz, qr.z);
-    G = fmaxf(G, 0.f);
-    ok = G == INFINITY || st.bound < G * G * 0.99999f;
-  }
-#ifdef DH3D_KNN_BLOCK_PROBE
-  {
-    const bool fb = !__all(ok);
-    if (lane == 0) {
-      atomicAdd(&g_kbprobe[0], 1ull); if (fb) atomicAdd(&g_kbprobe[1], 1ull);
-      atomicAdd(&g_kbprobe[4], (unsigned long long)(clock64() - pr_t0)); atomicAdd(&g_kbprobe[5], (unsigned long long)pr_drain);
-      atomicAdd(&g_kbprobe[6], (unsigned long long)pr_scan); atomicAdd(&g_kbprobe[7], (unsigned long long)pr_choose);
-      atomicAdd(&g_kbprobe[8], (unsigned long long)pr_ndrain); atomicAdd(&g_kbprobe[9], (unsigned long long)pr_nslots);
-      atomicAdd(&g_kbprobe[10], (unsigned long long)pr_nsteps);
-    }
-  }
-#endif
-  if (!__all(ok)) {
-    // rare: every OTHER brick of the cloud, 64 per round, any order; the queries that were inside already fail every screen
-#pragma unroll 1
-    for (int round = 0; round < 8; ++round) {
-      const unsigned k2 = (unsigned)(round * 64 + lane);
-      const int c2x = (int)knn_compact3(k2), c2y = (int)knn_compact3(k2 >> 1), c2z = (int)knn_compact3(k2 >> 2);
-      const bool seen = c2x >= 2 * Bx - 1 && c2x <= 2 * Bx + 2 && c2y >= 2 * By - 1 && c2y <= 2 * By + 2 &&
-                        c2z >= 2 * Bz - 1 && c2z <= 2 * Bz + 2;
-      const int b2 = ct[k2 * 8], e2 = ct[k2 * 8 + 8];
-      unsigned long long todo = __ballot(!seen && e2 > b2);
-      while (todo) {
-        const int l2 = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        const int ccx = __builtin_amdgcn_readlane(c2x, l2), ccy = __builtin_amdgcn_readlane(c2y, l2),
-                  ccz = __builtin_amdgcn_readlane(c2z, l2);
-        if (__any(valid && brick_query_d2(ccx, ccy, ccz) <= st.bound)) {
-          const int kb = __builtin_amdgcn_readlane(b2, l2), ke = __builtin_amdgcn_readlane(e2, l2);
-          scan_brick(kb, ke, kb + lane < ke ? sc[kb + lane] : pad);
-        }
-      }
-    }
-    if (__any(cnt > 0)) drain();
-  }
-
-  if (valid) {
-    const int y = __float_as_int(qr.w);  // original index of this query
-    int32_t *o_nn = nn + ((size_t)b * N + y) * K;
-    float *o_d = dist + ((size_t)b * N + y) * K;
-#pragma unroll
-    for (int i = 0; i < KMAX; ++i) {
-      if (i < K) {
-        const unsigned tb = (unsigned)st.keys[i];
-        if (st.keys[i] == ~0ull) {
-          o_nn[i] = -1;
-          o_d[i] = FLT_MAX;
-        } else {
-          o_nn[i] = (int)(((tb % (unsigned)lad.cv) << lad.log2ct) + tb / (unsigned)lad.cv);
-          o_d[i] = __uint_as_float((unsigned)(st.keys[i] >> 32));
-        }
-      }
-    }
-  }
-}
-
-#ifdef DH3D_KNN_BLOCK_PROBE
-DH3D_API int dh3d_knn_block_probe_read(unsigned long long *host, int n) {
-  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_kbprobe), sizeof(unsigned long long) * n) == hipSuccess ? 0 : 3;
-}
-#endif
-
-DH3D_API int dh3d_knn_block(const float *sorted, const int32_t *cells, int B, int N, int K, int32_t *nn, float *dist,
-                            void *stream) {
-  DH3D_REQUIRE(sorted && cells && nn && dist && B > 0 && N > 0 && K > 0);
-  DH3D_SUPPORTED(K <= 16 && N <= 16384 && B <= 65535);
-  const KnnLadder lad = knn_ladder(N);
-  const dim3 grid(N / 64 + 64, B), block(256);  // one workgroup (four waves) per chunk; chunks per cloud <= N / 64 + 64
-  const float4 *so = reinterpret_cast<const float4 *>(sorted);
-  hipStream_t s = (hipStream_t)stream;
-  if (K <= 8) hipLaunchKernelGGL((knn_block_kernel<8>), grid, block, 0, s, so, cells, N, K, lad, nn, dist);
-  else hipLaunchKernelGGL((knn_block_kernel<16>), grid, block, 0, s, so, cells, N, K, lad, nn, dist);
-  return dh3d_launch_status();
-}
-
 DH3D_API int dh3d_knn_grid(const float *sorted, const int32_t *cells, int B, int N, int K, int32_t *nn, float *dist,
                            void *stream) {
   DH3D_REQUIRE(sorted && cells && nn && dist && B > 0 && N > 0 && K > 0);

@@ -58,16 +58,6 @@ def knn_grid(srt, cells, k):
     return nn, dist
 
 
-def knn_block(srt, cells, k):
-    """kNN as a pruned shared scan on grid-aligned blocks / bricks (spatial_sort_cells() output); same (nbr, dist) as
-    knn_xyz bit for bit.  K <= 16."""
-    B, N, _ = srt.shape
-    nn = torch.empty((B, N, k), dtype=torch.int32, device=srt.device)
-    dist = torch.empty((B, N, k), dtype=torch.float32, device=srt.device)
-    L.check(L.lib().dh3d_knn_block(L.ptr(srt), L.ptr(cells), B, N, k, L.ptr(nn), L.ptr(dist), L.stream_ptr()), "knn_block")
-    return nn, dist
-
-
 def knn_sorted(srt, gbox, k):
     """kNN from spatial_sort() output; same (nbr [B,N,K], dist) as knn_xyz, original indexing."""
     B, N, _ = srt.shape

@@ -233,10 +233,6 @@ int dh3d_spatial_sort_cells(const float *xyz, int B, int N, float *sorted, float
  * (distance, CUB rank) order, IEEE distances, original point order.  K <= 8, N <= 16384. */
 int dh3d_knn_grid(const float *sorted, const int32_t *cells, int B, int N, int K, int32_t *nn, float *dist, void *stream);
 
-/* KnnBruteforce as a pruned shared scan on grid-aligned units (csrc/knn.hip knn_block_kernel): a wave = up to 64
- * consecutive sorted points of one 4x4x4-cell block, candidates = the 2x2x2-cell bricks around it, nearest first.  Same
- * outputs as dh3d_knn_bruteforce_xyz bit for bit.  K <= 16, N <= 16384. */
-int dh3d_knn_block(const float *sorted, const int32_t *cells, int B, int N, int K, int32_t *nn, float *dist, void *stream);
 
 /* ThreeNN on ordered clouds: identical dist / idx to dh3d_three_nn (original indexing on both sides) from the
  * dh3d_spatial_sort outputs of the query cloud (sorted1 [b,n,4], gbox1) and of the candidate set (sorted2 [b,m,4],

@@ -526,9 +526,6 @@ def test_knn_grid_cell_list_search_is_bit_equal_to_brute_force(dev, name, B, N, 
     assert torch.equal(d_g.view(torch.int32), d_b.view(torch.int32))
     nn_s, d_s = pm.knn_sorted(srt, gbox, K)
     assert torch.equal(nn_s, nn_b)
-    nn_k, d_k = pm.knn_block(srt, cells, K)   # the block / brick scan on the same grid
-    assert torch.equal(nn_k, nn_b), (name, int((nn_k != nn_b).sum()))
-    assert torch.equal(d_k.view(torch.int32), d_b.view(torch.int32))
 
 
 def test_knn_grid_vs_oracle_N8192(dev, oracle):

