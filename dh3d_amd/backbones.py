@@ -147,13 +147,14 @@ class Conv2D1x1(nn.Module):
             return pm.linear_x6(x2, p["wp3_bot"], self.cout)
         return pm.linear(x2, p["wp_bot"], self.cout)
 
-    def forward_commuted(self, coarse, idx, dist, partial, act=pm.ACT_RELU, residual=None, l2cat=None):
+    def forward_commuted(self, coarse, idx, dist, partial, act=pm.ACT_RELU, residual=None, l2cat=None, cw=None):
         """forward([three_interpolate_idw(coarse) | x2]) with the upper weight block applied to the COARSE rows (the
         interpolation is linear and acts on rows, so it commutes with the conv) and `partial` = lower_partial(x2):
         a [B*M, c_top] x [c_top, 128] GEMM + one gather / epilogue kernel behind the sampled level instead of the
         [B*N, cin] x [cin, 128] GEMM with the up-sampling fused into its staging."""
         p = self._prep
-        cw = pm.linear(coarse, p["wp_top"], self.cout)
+        if cw is None:  # (the caller may have it already: it rides in the SE kernel of the sampled level)
+            cw = pm.linear(coarse, p["wp_top"], self.cout)
         return pm.interp_combine(cw, idx, dist, partial, pre_bias=p["b"], scale=p["scale"], shift=p["shift"], act=act,
                                  residual=residual, l2cat=l2cat)
 
@@ -451,6 +452,7 @@ class FlexConvDilate(nn.Module):
         to this block's output next -- where it can ride in the SE kernel the result is (output, post_conv(output))."""
         prep = self._prep or self.prepare()
         self._last_post = None
+        cw_top = None
         if self.dilate > 1:
             lv = geo.level(self.dilate, self.knn, finish=False)  # three_nn is joined only where it is consumed
             xyz_s, nbr_s = lv["xyz_s"], lv["nbr_s"]
@@ -485,9 +487,17 @@ class FlexConvDilate(nn.Module):
             remap = None
         post = None
         if self.add_se == "max_pool":
+            cconv = self.concat_conv1d.tfconv0 if self.concat else None
             if (post_conv is not None and not (self.upsample and self.dilate > 1) and not self.concat
                     and residual is None and l2cat is None and shortcut_src is None):
                 x, post = self.se.forward_on_max_pool_then_conv(x, nbr_s, post_conv)  # x is this block's output
+            elif (self.upsample and self.dilate > 1 and not coarse_only and cconv is not None and lower_partial is not None
+                  and shortcut_src is None and x.shape[2] == 128 and cconv.cout == 128
+                  and (self.se._prep or self.se.prepare())[4] is not None and cconv._prep.get("c_top") == 128):
+                # the commuted concat conv's upper block (coarse @ W_top, no bias / activation: those belong to the sum)
+                # rides in the SE kernel: one launch + its dependency gap less on the chain behind the sampling
+                sp = self.se._prep
+                x, cw_top = pm.se_res_pool_conv(x, nbr_s, *sp[4], cconv._prep["wp_top"], None, None, None, act=pm.ACT_NONE)
             else:
                 x = self.se.forward_on_max_pool(x, nbr_s)
         elif self.add_se == "avg_pool":  # flex_avg (theta 0, bias eye: the neighbour sum) * 1/knn, backbones.py:80-83
@@ -500,7 +510,7 @@ class FlexConvDilate(nn.Module):
             conv = self.concat_conv1d.tfconv0 if self.concat else None
             if conv is not None and lower_partial is not None and shortcut_src is None:
                 return conv.forward_commuted(x, lv["nn3_idx"], lv["nn3_dist"], lower_partial, act=pm.ACT_RELU,
-                                             residual=residual, l2cat=l2cat)
+                                             residual=residual, l2cat=l2cat, cw=cw_top)
             if conv is not None and conv.upsampled_supported(x, lv["nn3_idx"], feat):
                 # up-sampling fused into the concat conv's operand staging: the [B,N,C] tensor is never written
                 fuse = l2cat if conv.cout == 128 else None

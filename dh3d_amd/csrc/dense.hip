@@ -383,18 +383,20 @@ __global__ __launch_bounds__(256) void se_res_mfma_kernel(const float *__restric
       }
     }
   }
-  if (CONV) {  // out2 = act(bn(tile @ Wconv + b)), 64 columns: one 32 x 32 accumulator per wave
+  if (CONV) {  // out2 = act(bn(tile @ Wconv + b)), C columns: C / 64 accumulators of 32 x 32 per wave
+    constexpr int NTC = C / 64;
     __syncthreads();
     const int row0 = (wave & 1) * 32, cb0 = wave >> 1;
-    f32x16 acc[1];
-    zero_acc<1>(acc);
-    EpilogueRegs er[1];
-    er[0] = epilogue_prefetch(cep, cb0 * 32 + (lane & 31));
-    wave_gemm_f32<1>(s_p, LDP, row0, wconv, C / 8, cb0, 2, acc);
+    f32x16 acc[NTC];
+    zero_acc<NTC>(acc);
+    EpilogueRegs er[NTC];
+#pragma unroll
+    for (int j = 0; j < NTC; ++j) er[j] = epilogue_prefetch(cep, (cb0 + 2 * j) * 32 + (lane & 31));
+    wave_gemm_f32<NTC>(s_p, LDP, row0, wconv, C / 8, cb0, 2, acc);
     __syncthreads();
-    wave_tiles_to_lds<1>(acc, er, cep.act, s_p, LDP, row0, cb0, 2);
+    wave_tiles_to_lds<NTC>(acc, er, cep.act, s_p, LDP, row0, cb0, 2);
     __syncthreads();
-    block_store_rows(s_p, LDP, kTM, grow0, R, 64, nullptr, out2);
+    block_store_rows(s_p, LDP, kTM, grow0, R, C, nullptr, out2);
   }
 }
 
@@ -604,10 +606,14 @@ DH3D_API int dh3d_se_res_pool_conv_pm_fwd(const float *x, const int32_t *nbr, in
                                           const float *wconv_packed, const dh3d_epilogue *ep, int Dout, float *out2,
                                           void *stream) {
   DH3D_REQUIRE(x && nbr && w1packed && b1pad && w2packed && b2 && out && wconv_packed && out2 && B > 0 && N > 0 && K > 0);
-  DH3D_SUPPORTED(C == 64 && Dout == 64 && (!ep || ep->act != DH3D_ACT_SIGMOID));
+  DH3D_SUPPORTED(((C == 64 && Dout == 64) || (C == 128 && Dout == 128)) && (!ep || ep->act != DH3D_ACT_SIGMOID));
   const long long R = (long long)B * N;
-  hipLaunchKernelGGL((se_res_mfma_kernel<64, true, true>), dim3(dh3d_cdiv(R, kTM)), dim3(256), 0, (hipStream_t)stream, x,
-                     x, nbr, N, K, w1packed, b1pad, w2packed, b2, R, out, wconv_packed, dh3d_ep(ep), out2);
+  if (C == 64)
+    hipLaunchKernelGGL((se_res_mfma_kernel<64, true, true>), dim3(dh3d_cdiv(R, kTM)), dim3(256), 0, (hipStream_t)stream, x,
+                       x, nbr, N, K, w1packed, b1pad, w2packed, b2, R, out, wconv_packed, dh3d_ep(ep), out2);
+  else
+    hipLaunchKernelGGL((se_res_mfma_kernel<128, true, true>), dim3(dh3d_cdiv(R, kTM)), dim3(256), 0, (hipStream_t)stream, x,
+                       x, nbr, N, K, w1packed, b1pad, w2packed, b2, R, out, wconv_packed, dh3d_ep(ep), out2);
   return dh3d_launch_status();
 }
 

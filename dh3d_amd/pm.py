@@ -328,15 +328,15 @@ def se_res_pool_packed(x, nbr, w1packed, b1pad, w2packed, b2):
 
 
 def se_res_pool_conv(x, nbr, w1packed, b1pad, w2packed, b2, conv_wp, conv_b, conv_scale, conv_shift, act=ACT_RELU):
-    """(y, act(bn(y @ Wconv + b))) with y = se_res_packed(x, flex_pool(x, nbr)), one launch; x [B,N,64], conv 64 -> 64
-    (conv_wp = pack_weight of its [64,64] matrix)."""
+    """(y, act(bn(y @ Wconv + b))) with y = se_res_packed(x, flex_pool(x, nbr)), one launch; x [B,N,C], conv C -> C
+    (conv_wp = pack_weight of its [C,C] matrix), C = 64 or 128; conv_b / conv_scale / conv_shift may be None."""
     a = L.require_cuda_f32(x, "x", 3)
     nb = L.require_cuda_i32(nbr, "nbr", 3)
     B, N, C = a.shape
-    out, out2 = torch.empty_like(a), torch.empty((B, N, 64), dtype=torch.float32, device=a.device)
+    out, out2 = torch.empty_like(a), torch.empty((B, N, C), dtype=torch.float32, device=a.device)
     ep = _ep(conv_b, conv_scale, conv_shift, act)
     L.check(L.lib().dh3d_se_res_pool_conv_pm_fwd(L.ptr(a), L.ptr(nb), B, N, nb.shape[2], L.ptr(w1packed), L.ptr(b1pad),
-                                                 L.ptr(w2packed), L.ptr(b2), C, L.ptr(out), L.ptr(conv_wp), ep, 64,
+                                                 L.ptr(w2packed), L.ptr(b2), C, L.ptr(out), L.ptr(conv_wp), ep, C,
                                                  L.ptr(out2), L.stream_ptr()), "se_res_pool_conv_pm")
     return out, out2
 

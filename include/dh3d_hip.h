@@ -344,8 +344,9 @@ int dh3d_se_res_pm_packed_fwd(const float *x, const float *pool, const float *w1
 int dh3d_se_res_pool_pm_packed_fwd(const float *x, const int32_t *nbr, int B, int N, int K, const float *w1packed,
                                    const float *b1pad, const float *w2packed, const float *b2, int C, float *out,
                                    void *stream);
-/* ... followed by a 1x1 conv 64 -> 64 (+ bias / BatchNorm / activation `ep`) on the block's output in the same launch
- * (stage 1 -> before_stage2_conv1d, core/backbones.py:115-117): out and out2 [B*N, 64] are both stored. */
+/* ... followed by a 1x1 conv C -> C (+ bias / BatchNorm / activation `ep`) on the block's output in the same launch:
+ * out and out2 [B*N, C] are both stored.  C = Dout = 64 (stage 1 -> before_stage2_conv1d, core/backbones.py:115-117) or
+ * C = Dout = 128 (stage 2's SE block -> the upper block of its commuted concat conv on the sampled rows). */
 int dh3d_se_res_pool_conv_pm_fwd(const float *x, const int32_t *nbr, int B, int N, int K, const float *w1packed,
                                  const float *b1pad, const float *w2packed, const float *b2, int C, float *out,
                                  const float *wconv_packed, const dh3d_epilogue *ep, int Dout, float *out2, void *stream);
