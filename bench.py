@@ -255,7 +255,7 @@ def flex_conv_roofline(dev, in_step_ms=None, pmc=True, B=8, N=8192, K=8, Din=64,
         "traffic": traffic, "traffic_source": src, "launch_ms": ms, "algorithmic_bytes": fr["algorithmic_bytes"],
         "launch_ms_f32_mfma_kernel": ms_f32,
         "gather_effective": fr["gather_effective"], "f32_equivalent_flops": fr["f32_equivalent_flops"],
-        "binding_roof": "SIMD issue + FP32-VALU/MFMA exclusion (DESIGN.md 3.1)",
+        "binding_roof": "SIMD issue + FP32-VALU/MFMA exclusion (DESIGN.md 3.5)",
     }
     if in_step_ms is not None:
         Bc = fr["algorithmic_bytes"]
@@ -353,7 +353,8 @@ def step_kernel_rows(workload):
     rows = [
         ("spatial_sort_kernel<%d>" % (N // 1024), 1, "Morton sort of the clouds", 4 * R * 7 + 32 * R / 64, 0.0, "latency (one workgroup per cloud)"),
         ("fps_list_kernel", 1, "farthest point sampling N -> N/8", 16 * R + 16 * Rs, 8.0 * B * N * M, "latency (N/8 dependent picks, one CU per cloud)"),
-        ("knn_split_kernel", 1, "kNN K=8 on the full clouds", 16 * R + 8 * R * K, 8.0 * B * N * N, "f32 VALU (brute-force pair count; the kernel prunes)"),
+        ("knn_split_kernel", 1, "kNN K=8 on the full clouds (pruned shared scan)", 16 * R + 8 * R * K, 8.0 * B * N * N, "f32 VALU (brute-force pair count; the kernel prunes)"),
+        ("knn_grid_kernel", 1, "kNN K=8 on the full clouds (cell lists on the sort's grid)", 16 * R + 8 * R * K, 8.0 * B * N * N, "f32 VALU (brute-force pair count; the kernel prunes)"),
         ("pointset_sum_kernel", 1, "conv_pointset: neighbour-offset sums", 4 * R * (3 + K + 4), 6.0 * R * K, "hbm"),
         ("pointset_pool_kernel", 1, "conv_pointset 3->32 + BNReLU + flex_pool", 4 * R * (4 + K + 32), 2.0 * R * K * 32 * 3, "hbm"),
         ("conv_pointset_pm_kernel", 1, "conv_pointset 3->32 + BNReLU", 4 * R * (3 + K + 32), 2.0 * R * K * 32 * 3, "hbm"),
@@ -367,6 +368,8 @@ def step_kernel_rows(workload):
         ("flex_conv_pm_kernel<64, 128", 1, "flex_conv 64->128 @N/8", ff(B, M, K, 64, 128)[0], ff(B, M, K, 64, 128)[2], "f32 MFMA"),
         ("flex_conv_pm_kernel<128, 128", 1, "flex_conv 128->128 @N/8", ff(B, M, K, 128, 128)[0], ff(B, M, K, 128, 128)[2], "f32 MFMA"),
         ("se_res_mfma_kernel<128, true, false>", 1, "flex_pool + SE + residual @N/8", 4 * Rs * (128 + K + 128), 2.0 * Rs * 2 * 128 * 32, "hbm"),
+        ("se_res_mfma_kernel<128, true, true>", 1, "flex_pool + SE + residual + concat conv's upper block 128->128 @N/8",
+         4 * Rs * (128 + K + 128 + 128), 2.0 * Rs * (2 * 128 * 32 + 128 * 128), "hbm"),
     ]
     if workload == "global":
         rows += [
