@@ -189,11 +189,13 @@ _SIGNATURES = {
     "dh3d_netvlad_head_workspace_bytes": [c_int, c_int, c_int],
     "dh3d_global_tail_fwd": [c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, ctypes.POINTER(Epilogue), c_fp,
                              c_float, c_fp, c_fp, c_fp, c_fp, c_fp],
-    "dh3d_global_tail_prezeroed_fwd": [c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, ctypes.POINTER(Epilogue), c_fp,
-                             c_float, c_fp, c_fp, c_fp, c_fp, c_fp],
     "dh3d_netvlad_tail_workspace_bytes": [c_int, c_int, c_int, c_int],
     "dh3d_netvlad_tail_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_float,
                               c_fp, c_size_t, c_fp, c_fp],
+    "dh3d_netvlad_tail_assign_fwd": [c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int,
+                                     c_float, c_fp, c_size_t, c_fp, c_fp],
+    "dh3d_global_walk_fwd": [c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, ctypes.POINTER(Epilogue), c_fp,
+                             c_float, c_fp, c_fp, c_fp, c_fp, c_int, c_fp],
     "dh3d_netvlad_fused_workspace_bytes": [c_int, c_int, c_int, c_int, c_int],
     "dh3d_netvlad_fused_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int,
                                c_int, c_int, c_float, c_fp, c_size_t, c_fp, c_fp],

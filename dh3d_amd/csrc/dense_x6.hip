@@ -1087,13 +1087,13 @@ DH3D_API int dh3d_interp_head_sorted_fwd_dev(const float *H, int Hd, int row_maj
 static int global_tail_launch(const float *H, int Hd, const float *coarse, const float *cw, const int32_t *idx,
                               const float *dist, const float *order, int B, int n, int m, const dh3d_epilogue *ep,
                               const float *w_fc, float b_fc, const float *cl_scale, const float *cl_shift, float *att,
-                              float *accum, bool zero_here, hipStream_t s) {
+                              float *accum, bool zero_here, hipStream_t s, bool with_gemm = true) {
   DH3D_REQUIRE(H && coarse && cw && idx && dist && w_fc && cl_scale && cl_shift && accum);
   DH3D_REQUIRE(B > 0 && n > 0 && m > 0 && Hd > 0);
   DH3D_SUPPORTED(Hd % 256 == 0 && Hd <= 1024 && m <= 1024 && (!ep || ep->act != DH3D_ACT_SIGMOID));
   float *apart = accum, *asum = apart + (size_t)B * m * 64, *V = asum + (size_t)B * 64;
   if (zero_here &&
-      hipMemsetAsync(accum, 0, sizeof(float) * ((size_t)B * m * 64 + (size_t)B * 64 + (size_t)B * 64 * 256), s) != hipSuccess)
+      hipMemsetAsync(accum, 0, sizeof(float) * ((size_t)B * m * 64 + (size_t)B * 64 + (with_gemm ? (size_t)B * 64 * 256 : 0)), s) != hipSuccess)
     return DH3D_ERR_LAUNCH;
   const int nblk = dh3d_cdiv(n, kIHP);
   const int per_xcd = dh3d_cdiv(B, 8) * nblk;
@@ -1102,7 +1102,7 @@ static int global_tail_launch(const float *H, int Hd, const float *coarse, const
                      (long long)B * m, idx, dist, reinterpret_cast<const float4 *>(order), B, n, m, nblk, dh3d_ep(ep),
                      w_fc, b_fc, att, VladTail{coarse, cw, cl_scale, cl_shift, apart, asum});
   const int st = dh3d_launch_status();
-  if (st != DH3D_OK) return st;
+  if (st != DH3D_OK || !with_gemm) return st;
   return dh3d_internal_gemm_tn_batched(apart, coarse, B, m, 64, 256, V, true, s);
 }
 
@@ -1114,14 +1114,15 @@ DH3D_API int dh3d_global_tail_fwd(const float *H, int Hd, const float *coarse, c
                             true, (hipStream_t)stream);
 }
 
-// the same with `accum` ZEROED BY THE CALLER (e.g. by a fill enqueued on another stream long before the tail starts:
-// the 6 MB memset then leaves the step's critical chain)
-DH3D_API int dh3d_global_tail_prezeroed_fwd(const float *H, int Hd, const float *coarse, const float *cw, const int32_t *idx,
-                                            const float *dist, const float *order, int B, int n, int m,
-                                            const dh3d_epilogue *ep, const float *w_fc, float b_fc, const float *cl_scale,
-                                            const float *cl_shift, float *att, float *accum, void *stream) {
+// the walk alone: accum = [ apart B*m*64 | asum B*64 ] floats; zero_accum != 0: cleared here, else ZEROED BY THE CALLER (a
+// fill issued off the critical chain).  dh3d_netvlad_tail_assign_fwd(apart, coarse, asum, m, ...) finishes (it forms
+// V = apart^T coarse inside its finalize kernel).
+DH3D_API int dh3d_global_walk_fwd(const float *H, int Hd, const float *coarse, const float *cw, const int32_t *idx,
+                                  const float *dist, const float *order, int B, int n, int m, const dh3d_epilogue *ep,
+                                  const float *w_fc, float b_fc, const float *cl_scale, const float *cl_shift, float *att,
+                                  float *accum, int zero_accum, void *stream) {
   return global_tail_launch(H, Hd, coarse, cw, idx, dist, order, B, n, m, ep, w_fc, b_fc, cl_scale, cl_shift, att, accum,
-                            false, (hipStream_t)stream);
+                            zero_accum != 0, (hipStream_t)stream, false);
 }
 
 DH3D_API int dh3d_interp_head_fwd(const float *H, int Hd, const int32_t *idx, const float *dist, int B, int n, int m,

@@ -230,6 +230,91 @@ __global__ __launch_bounds__(1024) void netvlad_finalize(const float *__restrict
   *reinterpret_cast<float2 *>(o) = make_float2(v[0], v[1]);
 }
 
+// netvlad_finalize fed by the commuted aggregation directly (round 4): V[b] = A'[b]^T c[b] ([64 x m] x [m x 256], m <= 1024
+// coarse rows) is formed HERE instead of by a batched split-reduction GEMM launch of its own (19 us for 0.5 GFLOP + 7 us of
+// finalize + a dependency gap, on the global step's critical chain).  Workgroup (b, 8 clusters), 16 waves: wave w takes the
+// coarse rows of slice w & 7 and four of the eight clusters (w >> 3); a lane owns four features: per row one 16-byte read
+// of c, one LDS broadcast of the four assignment values, 16 fma.  The eight slices meet in LDS in a fixed order
+// (deterministic), then finalize as above.
+__global__ __launch_bounds__(1024) void netvlad_assign_finalize(const float *__restrict__ apart /*[B][m][Cl]*/,
+                                                               const float *__restrict__ coarse /*[B][m][D]*/,
+                                                               const float *__restrict__ asum /*[B][Cl]*/,
+                                                               const float *__restrict__ W2 /*[D][Cl]*/, int m,
+                                                               float *__restrict__ vlad /*[B][D*Cl]*/,
+                                                               float *__restrict__ tot /*[B][Cl/kCG]*/) {
+  extern __shared__ __attribute__((aligned(16))) float s_af[];
+  float *s_a = s_af;                    // [m][8]   this workgroup's eight columns of A'
+  float *s_part = s_af + (size_t)m * 8; // [8 slices][8 clusters][256]
+  __shared__ float s_csq[16][kCT];
+  __shared__ float s_red[16];
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0g = blockIdx.x * kCG;
+  const float *ab = apart + (size_t)b * m * kCl, *cb = coarse + (size_t)b * m * kD;
+  for (int e = tid; e < m * 2; e += 1024) {  // rows x two float4
+    const int j = e >> 1, h = e & 1;
+    *reinterpret_cast<float4 *>(s_a + (size_t)j * 8 + h * 4) = *reinterpret_cast<const float4 *>(ab + (size_t)j * kCl + c0g + h * 4);
+  }
+  __syncthreads();
+  {
+    const int slice = wave & 7, ch = wave >> 3, d4 = lane * 4;
+    const int per = (m + 7) >> 3, j0 = slice * per, j1 = min(m, j0 + per);
+    float4 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int j = j0; j < j1; ++j) {
+      const float4 x = *reinterpret_cast<const float4 *>(cb + (size_t)j * kD + d4);
+      const float4 a = *reinterpret_cast<const float4 *>(s_a + (size_t)j * 8 + ch * 4);
+      acc[0].x = fmaf(a.x, x.x, acc[0].x); acc[0].y = fmaf(a.x, x.y, acc[0].y); acc[0].z = fmaf(a.x, x.z, acc[0].z); acc[0].w = fmaf(a.x, x.w, acc[0].w);
+      acc[1].x = fmaf(a.y, x.x, acc[1].x); acc[1].y = fmaf(a.y, x.y, acc[1].y); acc[1].z = fmaf(a.y, x.z, acc[1].z); acc[1].w = fmaf(a.y, x.w, acc[1].w);
+      acc[2].x = fmaf(a.z, x.x, acc[2].x); acc[2].y = fmaf(a.z, x.y, acc[2].y); acc[2].z = fmaf(a.z, x.z, acc[2].z); acc[2].w = fmaf(a.z, x.w, acc[2].w);
+      acc[3].x = fmaf(a.w, x.x, acc[3].x); acc[3].y = fmaf(a.w, x.y, acc[3].y); acc[3].z = fmaf(a.w, x.z, acc[3].z); acc[3].w = fmaf(a.w, x.w, acc[3].w);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      *reinterpret_cast<float4 *>(s_part + ((size_t)slice * 8 + ch * 4 + c) * kD + d4) = acc[c];
+  }
+  __syncthreads();
+  const int d = tid & 255, g = tid >> 8;
+  float v[kCT];
+#pragma unroll
+  for (int c = 0; c < kCT; ++c) {
+    const int cl = g * kCT + c;
+    float sacc = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) sacc += s_part[((size_t)sl * 8 + cl) * kD + d];  // fixed order
+    v[c] = sacc - asum[(size_t)b * kCl + c0g + cl] * W2[(size_t)d * kCl + c0g + cl];  // backbones.py:249-256
+  }
+#pragma unroll
+  for (int c = 0; c < kCT; ++c) {
+    float sq = v[c] * v[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    if (lane == 0) s_csq[wave][c] = sq;
+  }
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int c = 0; c < kCT; ++c) {
+    const float csq = (s_csq[4 * g][c] + s_csq[4 * g + 1][c]) + (s_csq[4 * g + 2][c] + s_csq[4 * g + 3][c]);
+    v[c] *= rsqrtf(fmaxf(csq, 1e-12f));
+    t = fmaf(v[c], v[c], t);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+  if (lane == 0) s_red[wave] = t;
+  __syncthreads();
+  if (tid == 0) {
+    float all = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) all += s_red[w];
+    tot[(size_t)b * (kCl / kCG) + blockIdx.x] = all;
+  }
+  float *o = vlad + (size_t)b * kD * kCl + (size_t)d * kCl + c0g + g * kCT;  // flatten d-major: index d*Cl + c
+  *reinterpret_cast<float2 *>(o) = make_float2(v[0], v[1]);
+}
+
+
 // whole-vector L2 normalisation (backbones.py:261): grid (8, B); scale = rsqrt(max(sum of the 8 partials, eps))
 __global__ __launch_bounds__(256) void netvlad_l2scale(const float *__restrict__ tot, float *__restrict__ vlad) {
   const int b = blockIdx.y;
@@ -453,6 +538,33 @@ DH3D_API int dh3d_netvlad_tail_fwd(const float *V, const float *asum, const floa
   float *tot = vlad + (size_t)B * D * Cl;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(netvlad_finalize, dim3(kCl / kCG, B), dim3(1024), 0, s, V, asum, W2, 1, vlad, tot);
+  const int Kd = D * Cl, KS = dh3d_cdiv(Kd, kKSlice);
+  hipLaunchKernelGGL(netvlad_hidden_splitk, dim3(KS, dh3d_cdiv(B, 32), O / 64), dim3(256), 0, s, vlad, Wh, B, Kd, O,
+                     part);
+  hipLaunchKernelGGL(netvlad_gate, dim3(B), dim3(1024), 0, s, part, 2 * KS, B, O, bn1_scale, bn1_shift, Wg, bn2_scale,
+                     bn2_shift, l2_eps, static_cast<const float *>(tot), out);
+  return dh3d_launch_status();
+}
+
+// ... and the same tail fed by the assignment itself: apart [B, m, Cl] = A' (the walk's output), coarse [B, m, D], asum [B, Cl];
+// V = A'^T coarse is formed inside the finalize kernel (netvlad_assign_finalize).  m <= 1024.
+DH3D_API int dh3d_netvlad_tail_assign_fwd(const float *apart, const float *coarse, const float *asum, int m, const float *W2,
+                                          const float *Wh, const float *bn1_scale, const float *bn1_shift, const float *Wg,
+                                          const float *bn2_scale, const float *bn2_shift, int B, int D, int Cl, int O,
+                                          float l2_eps, void *workspace, size_t workspace_bytes, float *out, void *stream) {
+  DH3D_REQUIRE(apart && coarse && asum && W2 && Wh && bn1_scale && bn1_shift && workspace && out && B > 0 && m > 0);
+  DH3D_REQUIRE(!Wg || (bn2_scale && bn2_shift));
+  DH3D_SUPPORTED(D == kD && Cl == kCl && O == 256 && B <= 65535 && m <= 1024);
+  DH3D_REQUIRE(workspace_bytes >= dh3d_netvlad_tail_workspace_bytes(B, D, Cl, O));
+  const size_t hb = (dh3d_netvlad_head_workspace_bytes(B, D * Cl, O) + 255) & ~(size_t)255;
+  char *w = static_cast<char *>(workspace);
+  float *part = reinterpret_cast<float *>(w);
+  float *vlad = reinterpret_cast<float *>(w + hb);
+  float *tot = vlad + (size_t)B * D * Cl;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = sizeof(float) * ((size_t)m * 8 + 8 * 8 * kD);
+  DH3D_ALLOW_BIG_LDS(netvlad_assign_finalize);
+  hipLaunchKernelGGL(netvlad_assign_finalize, dim3(kCl / kCG, B), dim3(1024), lds, s, apart, coarse, asum, W2, m, vlad, tot);
   const int Kd = D * Cl, KS = dh3d_cdiv(Kd, kKSlice);
   hipLaunchKernelGGL(netvlad_hidden_splitk, dim3(KS, dh3d_cdiv(B, 32), O / 64), dim3(256), 0, s, vlad, Wh, B, Kd, O,
                      part);

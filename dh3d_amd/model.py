@@ -206,7 +206,7 @@ class DH3D(nn.Module):
     # where stage 2 starts.  (hipGraph replay charges ~10 us per cross-queue dependency that is last to arrive, so
     # the critical chain must not hop between queues: the earlier arrangement -- FPS on the side stream --
     # paid that twice per step.)
-    def _geometry(self, points, knn_inds=None):
+    def _geometry(self, points, knn_inds=None, prezero_tail=False):
         geo = bb.Geometry(points, self.knn_num, fps_contract=self.config.fps_contract)
         main = torch.cuda.current_stream()
         if points.shape[1] <= 16384 and (knn_inds is None or (4096 <= points.shape[1] and self.config.fps_contract is None)):
@@ -229,6 +229,9 @@ class DH3D(nn.Module):
         # are the other way round and it runs on the side stream after stage 1 (compute_local).
         if self._side_is_critical(points):
             bb.finish_level(points, geo._lv, same_stream=True)
+            if prezero_tail:  # (this stream has slack here: the side stream ends last)
+                geo._tail_accum = torch.zeros((pm.global_tail_accum_size(points.shape[0], points.shape[1] // 8),),
+                                              dtype=torch.float32, device=points.device)
             if getattr(self, "steps_in_flight", 1) > 1:  # the OTHER steps' FPS kernels hold CUs while stage 1 runs
                 geo.busy_cus_per_xcd = min(8, (self.steps_in_flight - 1) * ((points.shape[0] + 7) // 8))
         else:
@@ -296,7 +299,7 @@ class DH3D(nn.Module):
             # x2 here, beside the sampling chain; behind the sampled level only a GEMM on the N/8 rows and one
             # gather / epilogue kernel are left (backbones.Conv2D1x1.forward_commuted)
             lower = None if fuse_sc else self.stage2.commuted_partial(x2)
-            if _prezero_tail:
+            if _prezero_tail and getattr(geo, "_tail_accum", None) is None:
                 # the global tail's accumulators (6 MB at cfg 3), zero-filled HERE, beside the sampling chain: the fill
                 # (a ~5 us node + its dependency gap) is off the critical chain when the tail starts
                 geo._tail_accum = torch.zeros((pm.global_tail_accum_size(points.shape[0], points.shape[1] // 8),),
@@ -389,7 +392,9 @@ class DH3D(nn.Module):
         # num_points > 8192: the reference feeds host (sklearn) kNN indices because its op stops at 8192
         # (core/model.py:38,148-155); they are still accepted, but the device search covers every N itself.
         outs = {"pointclouds": points, "xyz": points}
-        geo = self._geometry(points, knn_inds)
+        prezero = bool(cfg.extract_global and want("globaldesc") and getattr(self, "global_before_assemble", None) is not None
+                       and self.global_before_assemble.dilate == 8)
+        geo = self._geometry(points, knn_inds, prezero_tail=prezero)
         outs["knn_inds"] = geo.nbr
         needs_raw = want("feat", "attention", "xyz_feat_att", "globaldesc")
         if fetch is not None and not needs_raw and want("xyz_feat", "feat_l2normed") and self._local.featdim == 128:
@@ -399,10 +404,7 @@ class DH3D(nn.Module):
             outs["feat_l2normed"] = xyz_feat[:, :, 3:]
             self._level_ids(geo, outs, fetch)
             return outs
-        newpoints, localdesc = self.compute_local(points, _geo=geo,
-                                                  _prezero_tail=bool(cfg.extract_global and want("globaldesc")
-                                                                     and self.global_before_assemble is not None
-                                                                     and (self.global_before_assemble.dilate == 8)))
+        newpoints, localdesc = self.compute_local(points, _geo=geo, _prezero_tail=prezero)
         outs["feat"] = localdesc
         self._level_ids(geo, outs, fetch)
         xyz_feat = None

@@ -572,8 +572,8 @@ def netvlad_fused(x, att, wc_packed, bn_scale, bn_shift, W2, Wh, bn1_scale, bn1_
 
 
 def global_tail_accum_size(B, m):
-    """floats of global_tail's accumulator block [ A' B*m*64 | asum B*64 | V B*64*256 ]."""
-    return B * m * 64 + B * 64 + B * 64 * 256
+    """floats of global_tail's accumulator block [ A' B*m*64 | asum B*64 ]."""
+    return B * m * 64 + B * 64
 
 
 def global_tail(coarse, idx, dist, order, wslices_x3, Hd, w_fc, b_fc, att_ep, wc_packed, cl_scale, cl_shift, W2, Wh,
@@ -581,7 +581,9 @@ def global_tail(coarse, idx, dist, order, wslices_x3, Hd, w_fc, b_fc, att_ep, wc
     """three_interpolate -> attention head -> NetVLAD + gating, with the up-sampling commuted through both consumers: the
     fine points are walked once (csrc/dense_x6.hip VladTail), everything else runs on the coarse rows.
     coarse [B,m,256], idx/dist [B,n,3], order = spatial_sort records [B,n,4] of the fine cloud, att_ep =
-    (pre_bias, scale, shift, act) of the attention's hidden layer.  Returns the descriptor [B,O] (, att [B,n,1])."""
+    (pre_bias, scale, shift, act) of the attention's hidden layer.  accum (optional): a ZEROED float32 tensor of
+    global_tail_accum_size(B, m) elements (the caller's fill, issued off the critical chain); cw (optional):
+    coarse @ cluster_weights if the caller has it already.  Returns the descriptor [B,O] (, att [B,n,1])."""
     x = L.require_cuda_f32(coarse, "coarse", 3)
     ix = L.require_cuda_i32(idx, "idx", 3)
     d = L.require_cuda_f32(dist, "dist", 3)
@@ -594,27 +596,27 @@ def global_tail(coarse, idx, dist, order, wslices_x3, Hd, w_fc, b_fc, att_ep, wc
     if cw is None:   # (the caller may have it already: pm.flex_conv_post computes it in the flex_conv's launch)
         cw = linear(x, wc_packed, 64)                                              # coarse @ cluster_weights
     att = torch.empty((B, n, 1), dtype=torch.float32, device=x.device) if want_att else None
-    # accum (optional): global_tail_accum(B, m) zeroed by the caller off the critical chain; else zeroed by the call
-    fn = L.lib().dh3d_global_tail_prezeroed_fwd if accum is not None else L.lib().dh3d_global_tail_fwd
+    zero_here = accum is None
     if accum is None:
         accum = torch.empty((global_tail_accum_size(B, m),), dtype=torch.float32, device=x.device)
     elif accum.numel() != global_tail_accum_size(B, m) or accum.dtype != torch.float32 or not accum.is_cuda:
         raise ValueError("global_tail: accum must be a zeroed float32 GPU tensor of global_tail_accum_size(B, m) elements")
     ep = _ep(*att_ep)
-    L.check(fn(L.ptr(H), Hd, L.ptr(x), L.ptr(cw), L.ptr(ix), L.ptr(d), L.ptr(order), B, n, m,
-                                         ep, L.ptr(w_fc), float(b_fc), L.ptr(cl_scale), L.ptr(cl_shift), L.ptr(att),
-                                         L.ptr(accum), L.stream_ptr()), "global_tail")
-    asum = accum[B * m * 64:B * m * 64 + B * 64]
-    V = accum[B * m * 64 + B * 64:]                                                # [B, 64, 256] = A'^T coarse
+    L.check(L.lib().dh3d_global_walk_fwd(L.ptr(H), Hd, L.ptr(x), L.ptr(cw), L.ptr(ix), L.ptr(d), L.ptr(order), B, n, m, ep,
+                                         L.ptr(w_fc), float(b_fc), L.ptr(cl_scale), L.ptr(cl_shift), L.ptr(att), L.ptr(accum),
+                                         1 if zero_here else 0, L.stream_ptr()), "global_walk")
+    apart, asum = accum[:B * m * 64], accum[B * m * 64:]
     O = Wh.shape[1]
     ws_bytes = L.lib().dh3d_netvlad_tail_workspace_bytes(B, C, 64, O)
     if ws_bytes == 0:
         raise ValueError("global_tail: unsupported NetVLAD shape")
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
     out = torch.empty((B, O), dtype=torch.float32, device=x.device)
-    L.check(L.lib().dh3d_netvlad_tail_fwd(L.ptr(V), L.ptr(asum), L.ptr(W2), L.ptr(Wh), L.ptr(bn1_scale), L.ptr(bn1_shift),
-                                          L.ptr(Wg), L.ptr(bn2_scale), L.ptr(bn2_shift), B, C, 64, O, float(l2_eps),
-                                          L.ptr(ws), ws_bytes, L.ptr(out), L.stream_ptr()), "netvlad_tail")
+    # V = A'^T coarse is formed inside the finalize kernel (no batched GEMM launch)
+    L.check(L.lib().dh3d_netvlad_tail_assign_fwd(L.ptr(apart), L.ptr(x), L.ptr(asum), m, L.ptr(W2), L.ptr(Wh), L.ptr(bn1_scale),
+                                                 L.ptr(bn1_shift), L.ptr(Wg), L.ptr(bn2_scale), L.ptr(bn2_shift), B, C, 64, O,
+                                                 float(l2_eps), L.ptr(ws), ws_bytes, L.ptr(out), L.stream_ptr()),
+            "netvlad_tail_assign")
     return (out, att) if want_att else out
 
 

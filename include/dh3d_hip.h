@@ -663,16 +663,23 @@ int dh3d_global_tail_fwd(const float *H, int Hd, const float *coarse, const floa
                          const float *dist, const float *order, int B, int n, int m, const dh3d_epilogue *ep,
                          const float *w_fc, float b_fc, const float *cl_scale, const float *cl_shift, float *att,
                          float *accum, void *stream);
-/* The same call with `accum` zeroed by the CALLER (a fill issued off the critical chain). */
-int dh3d_global_tail_prezeroed_fwd(const float *H, int Hd, const float *coarse, const float *cw, const int32_t *idx,
-                         const float *dist, const float *order, int B, int n, int m, const dh3d_epilogue *ep,
-                         const float *w_fc, float b_fc, const float *cl_scale, const float *cl_shift, float *att,
-                         float *accum, void *stream);
 size_t dh3d_netvlad_tail_workspace_bytes(int B, int D, int Cl, int O);
 int dh3d_netvlad_tail_fwd(const float *V, const float *asum, const float *W2, const float *Wh, const float *bn1_scale,
                           const float *bn1_shift, const float *Wg, const float *bn2_scale, const float *bn2_shift, int B,
                           int D, int Cl, int O, float l2_eps, void *workspace, size_t workspace_bytes, float *out,
                           void *stream);
+/* The two-call form the model uses since round 4: dh3d_global_walk_fwd = the walk alone, accum = [ apart B*m*64 | asum B*64 ]
+ * floats (zero_accum != 0: cleared by the call; 0: zeroed by the CALLER, e.g. by a fill issued beside the sampling chain),
+ * and dh3d_netvlad_tail_assign_fwd, which forms V = apart^T coarse inside its finalize kernel (no batched GEMM launch, a
+ * fixed summation order) and then projects and gates as dh3d_netvlad_tail_fwd.  m <= 1024; workspace:
+ * dh3d_netvlad_tail_workspace_bytes. */
+int dh3d_global_walk_fwd(const float *H, int Hd, const float *coarse, const float *cw, const int32_t *idx, const float *dist,
+                         const float *order, int B, int n, int m, const dh3d_epilogue *ep, const float *w_fc, float b_fc,
+                         const float *cl_scale, const float *cl_shift, float *att, float *accum, int zero_accum, void *stream);
+int dh3d_netvlad_tail_assign_fwd(const float *apart, const float *coarse, const float *asum, int m, const float *W2,
+                                 const float *Wh, const float *bn1_scale, const float *bn1_shift, const float *Wg,
+                                 const float *bn2_scale, const float *bn2_shift, int B, int D, int Cl, int O, float l2_eps,
+                                 void *workspace, size_t workspace_bytes, float *out, void *stream);
 
 /* NetVLAD aggregation + projection + gating in one call (what the model runs): dh3d_netvlad_aggregate_fwd followed by
  * dh3d_netvlad_head_fwd, without the separate whole-vector L2-normalisation kernel (its factor is applied to the
