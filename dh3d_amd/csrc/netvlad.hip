@@ -233,9 +233,8 @@ __global__ __launch_bounds__(1024) void netvlad_finalize(const float *__restrict
 // netvlad_finalize fed by the commuted aggregation directly (round 4): V[b] = A'[b]^T c[b] ([64 x m] x [m x 256], m <= 1024
 // coarse rows) is formed HERE instead of by a batched split-reduction GEMM launch of its own (19 us for 0.5 GFLOP + 7 us of
 // finalize + a dependency gap, on the global step's critical chain).  Workgroup (b, 8 clusters), 16 waves: wave w takes the
-// coarse rows of slice w & 7 and four of the eight clusters (w >> 3); a lane owns four features: per row one 16-byte read
-// of c, one LDS broadcast of the four assignment values, 16 fma.  The eight slices meet in LDS in a fixed order
-// (deterministic), then finalize as above.
+// coarse rows of slice w, a lane four features of all eight clusters: per row one 16-byte read of c, two LDS broadcasts
+// of the eight assignment values, 32 fma.  The slices meet in LDS in a fixed order (deterministic), then finalize as above.
 __global__ __launch_bounds__(1024) void netvlad_assign_finalize(const float *__restrict__ apart /*[B][m][Cl]*/,
                                                                const float *__restrict__ coarse /*[B][m][D]*/,
                                                                const float *__restrict__ asum /*[B][Cl]*/,
@@ -256,23 +255,39 @@ __global__ __launch_bounds__(1024) void netvlad_assign_finalize(const float *__r
   }
   __syncthreads();
   {
-    const int slice = wave & 7, ch = wave >> 3, d4 = lane * 4;
-    const int per = (m + 7) >> 3, j0 = slice * per, j1 = min(m, j0 + per);
-    float4 acc[4];
+    // 16 row slices, one per wave, all eight clusters per lane (32 accumulators): a slice is m / 16 rows = four batches of
+    // eight 16-byte reads in flight.  The 16 partial tiles meet in LDS in two rounds (waves 8-15 store, waves 0-7 add
+    // theirs on top), so that the buffer stays at 8 tiles.
+    const int d4 = lane * 4;
+    const int per = (m + 15) >> 4, j0 = wave * per, j1 = min(m, j0 + per);
+    float4 acc[8];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < 8; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
     for (int j = j0; j < j1; ++j) {
       const float4 x = *reinterpret_cast<const float4 *>(cb + (size_t)j * kD + d4);
-      const float4 a = *reinterpret_cast<const float4 *>(s_a + (size_t)j * 8 + ch * 4);
-      acc[0].x = fmaf(a.x, x.x, acc[0].x); acc[0].y = fmaf(a.x, x.y, acc[0].y); acc[0].z = fmaf(a.x, x.z, acc[0].z); acc[0].w = fmaf(a.x, x.w, acc[0].w);
-      acc[1].x = fmaf(a.y, x.x, acc[1].x); acc[1].y = fmaf(a.y, x.y, acc[1].y); acc[1].z = fmaf(a.y, x.z, acc[1].z); acc[1].w = fmaf(a.y, x.w, acc[1].w);
-      acc[2].x = fmaf(a.z, x.x, acc[2].x); acc[2].y = fmaf(a.z, x.y, acc[2].y); acc[2].z = fmaf(a.z, x.z, acc[2].z); acc[2].w = fmaf(a.z, x.w, acc[2].w);
-      acc[3].x = fmaf(a.w, x.x, acc[3].x); acc[3].y = fmaf(a.w, x.y, acc[3].y); acc[3].z = fmaf(a.w, x.z, acc[3].z); acc[3].w = fmaf(a.w, x.w, acc[3].w);
-    }
+      const float4 a0 = *reinterpret_cast<const float4 *>(s_a + (size_t)j * 8), a1 = *reinterpret_cast<const float4 *>(s_a + (size_t)j * 8 + 4);
+      const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-      *reinterpret_cast<float4 *>(s_part + ((size_t)slice * 8 + ch * 4 + c) * kD + d4) = acc[c];
+      for (int c = 0; c < 8; ++c) {
+        acc[c].x = fmaf(av[c], x.x, acc[c].x); acc[c].y = fmaf(av[c], x.y, acc[c].y);
+        acc[c].z = fmaf(av[c], x.z, acc[c].z); acc[c].w = fmaf(av[c], x.w, acc[c].w);
+      }
+    }
+    float *slot = s_part + (size_t)(wave & 7) * 8 * kD + d4;
+    if (wave >= 8) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) *reinterpret_cast<float4 *>(slot + (size_t)c * kD) = acc[c];
+    }
+    __syncthreads();
+    if (wave < 8) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float4 o = *reinterpret_cast<const float4 *>(slot + (size_t)c * kD);
+        o.x += acc[c].x; o.y += acc[c].y; o.z += acc[c].z; o.w += acc[c].w;
+        *reinterpret_cast<float4 *>(slot + (size_t)c * kD) = o;
+      }
+    }
   }
   __syncthreads();
   const int d = tid & 255, g = tid >> 8;
