@@ -25,34 +25,31 @@ __device__ __forceinline__ void wave_gemm_f32(const float *s_A, int ldA, int row
   const int lane = threadIdx.x & 63;
   const float *aptr = s_A + (size_t)(row0 + (lane & 31)) * ldA + 4 * (lane >> 5);
   const f32x4 *wp = reinterpret_cast<const f32x4 *>(wpacked) + lane;
-  // Main loop: k-blocks in groups of G with the NEXT group's B fragments already in flight.  The packed
-  // weight comes from L2 (~700 cycles under load); one group is 4*G*NT MFMAs = 64*G*NT cycles of matrix
-  // pipe, which must cover it: G = 4 does for NT >= 2 (>= 512 cycles + the LDS reads), a wave with ONE column block
-  // takes G = 8 (a 1-deep prefetch left ~450 cycles exposed per k-block: profiles/r01_c; G = 4 at NT = 1 still
-  // ~450 per group: round 4).
-  constexpr int G = NT == 1 ? 8 : 4;
-  const int KBG = KB - KB % G;
+  // Main loop: k-blocks in groups of 4 with the NEXT group's B fragments already in flight.  The packed
+  // weight comes from L2 (~700 cycles under load); one group is 16*NT MFMAs = 1024*NT cycles of matrix
+  // pipe, which covers it.  (A 1-deep prefetch left ~450 cycles exposed per k-block: profiles/r01_c.)
+  const int KB4 = KB & ~3;
   int kb = 0;
-  if (KBG > 0) {
-    f32x4 nxt[G][NT];
+  if (KB4 > 0) {
+    f32x4 nxt[4][NT];
 #pragma unroll
-    for (int u = 0; u < G; ++u)
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int j = 0; j < NT; ++j) nxt[u][j] = wp[(size_t)((cb0 + j * cbstride) * KB + u) * 64];
-    for (; kb < KBG; kb += G) {
-      f32x4 cur[G][NT];
+    for (; kb < KB4; kb += 4) {
+      f32x4 cur[4][NT];
 #pragma unroll
-      for (int u = 0; u < G; ++u)
+      for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int j = 0; j < NT; ++j) cur[u][j] = nxt[u][j];
-      if (kb + G < KBG) {
+      if (kb + 4 < KB4) {
 #pragma unroll
-        for (int u = 0; u < G; ++u)
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) nxt[u][j] = wp[(size_t)((cb0 + j * cbstride) * KB + kb + G + u) * 64];
+          for (int j = 0; j < NT; ++j) nxt[u][j] = wp[(size_t)((cb0 + j * cbstride) * KB + kb + 4 + u) * 64];
       }
 #pragma unroll
-      for (int u = 0; u < G; ++u) {
+      for (int u = 0; u < 4; ++u) {
         const f32x4 a4 = *reinterpret_cast<const f32x4 *>(aptr + (kb + u) * 8);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -65,7 +62,7 @@ __device__ __forceinline__ void wave_gemm_f32(const float *s_A, int ldA, int row
     }
   }
   if (kb >= KB) return;
-  // tail (KB not a multiple of G): one k-block at a time
+  // tail (KB not a multiple of 4): one k-block at a time
   f32x4 bnext[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) bnext[j] = wp[(size_t)((cb0 + j * cbstride) * KB + kb) * 64];
