@@ -5,6 +5,7 @@
 // kernel on [R, C] rows (R = B*N points): rows staged through LDS once, exact-f32 MFMA GEMM against a
 // fragment-packed weight, and bias + BatchNorm + activation (+ residual) applied in the store.
 #include "mfma_gemm.h"
+#include "wave_ops.h"
 
 namespace {
 
@@ -425,51 +426,73 @@ __global__ __launch_bounds__(256) void l2norm_concat_kernel(const float *__restr
 //   v = w0*Cw[i0] + w1*Cw[i1] + w2*Cw[i2] + P[n] + b  ->  BN, activation  ->  + residual  ->  out / [prefix | l2norm(v)]
 // 32 lanes x float4 per row (C == 128), a wave = two rows; the l2-normalisation's row sum is a 32-lane DPP-free
 // shuffle reduction.  HBM: P + residual + out rows (~1.5 KB per point), the coarse rows come from L2.
+// A wave takes RPW consecutive rows of one cloud: lane r < RPW loads row r's three indices and distances and turns the
+// distances into weights ONCE (the six IEEE divisions cost ~14 instructions each and were issued per two rows);
+// the row loop fetches them with ds_bpermute.  No load sits under a branch (ragged tails clamp the row, the store is
+// predicated); the cloud comes from blockIdx.y (no 64-bit division).
+// PART / RES / L2CAT / ACT (-1: read ep.act) are compile-time so that the row loop is one basic block.
+template <int RPW, bool PART, bool RES, bool L2CAT, int ACT>
 __global__ __launch_bounds__(256) void interp_combine_kernel(const float *__restrict__ cw, const int32_t *__restrict__ idx,
                                                             const float *__restrict__ dist,
-                                                            const float *__restrict__ part, long long rows, int n, int m,
+                                                            const float *__restrict__ part, int n, int m,
                                                             EpilogueArgs ep, const float *__restrict__ residual,
                                                             const float *__restrict__ prefix, float l2_eps,
                                                             float *__restrict__ out) {
   constexpr int C = 128;
-  const int sub = threadIdx.x & 31, c4 = sub * 4;
-  float4 pb = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = pb;
-  if (ep.pre_bias) pb = *reinterpret_cast<const float4 *>(ep.pre_bias + c4);
-  if (ep.scale) sc = *reinterpret_cast<const float4 *>(ep.scale + c4);
-  if (ep.shift) sh = *reinterpret_cast<const float4 *>(ep.shift + c4);
-  for (long long row = (long long)blockIdx.x * 8 + (threadIdx.x >> 5); row < rows; row += (long long)gridDim.x * 8) {
-    const long long bi = row / n;
-    const int i1 = idx[row * 3], i2 = idx[row * 3 + 1], i3 = idx[row * 3 + 2];
+  const int lane = threadIdx.x & 63, half = lane >> 5, sub = lane & 31, c4 = sub * 4;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+  if (row0 >= n) return;
+  const long long cloud = blockIdx.y;
+  const Ep4 e = ep4_prefetch(ep, c4);
+  const int act = ACT >= 0 ? ACT : ep.act;
+  int o1, o2, o3;
+  float w1, w2, w3;
+  {
+    const int r = min(row0 + (lane & (RPW - 1)), n - 1);
+    const long long g = (cloud * n + r) * 3;
+    o1 = idx[g] * C; o2 = idx[g + 1] * C; o3 = idx[g + 2] * C;
     // the inverse-distance weights of core/backbones.py:92-95, same arithmetic as three_interp_fwd_kernel<true>
-    const float r1 = 1.0f / fmaxf(dist[row * 3], 1e-10f), r2 = 1.0f / fmaxf(dist[row * 3 + 1], 1e-10f),
-                r3 = 1.0f / fmaxf(dist[row * 3 + 2], 1e-10f);
+    const float r1 = 1.0f / fmaxf(dist[g], 1e-10f), r2 = 1.0f / fmaxf(dist[g + 1], 1e-10f),
+                r3 = 1.0f / fmaxf(dist[g + 2], 1e-10f);
     const float norm = (r1 + r2) + r3;
-    const float w1 = r1 / norm, w2 = r2 / norm, w3 = r3 / norm;
-    const float4 a = *reinterpret_cast<const float4 *>(cw + (bi * m + i1) * C + c4);
-    const float4 bq = *reinterpret_cast<const float4 *>(cw + (bi * m + i2) * C + c4);
-    const float4 cq = *reinterpret_cast<const float4 *>(cw + (bi * m + i3) * C + c4);
+    w1 = r1 / norm; w2 = r2 / norm; w3 = r3 / norm;
+  }
+  const float *cwb = cw + cloud * m * C + c4;
+  const long long base = cloud * n;
+#pragma unroll 4
+  for (int t = 0; t < RPW / 2; ++t) {
+    const int src = 2 * t + half;
+    const bool live = row0 + src < n;
+    const long long row = base + min(row0 + src, n - 1);
+    const int a1 = __shfl(o1, src, 64), a2 = __shfl(o2, src, 64), a3 = __shfl(o3, src, 64);
+    const float u1 = __shfl(w1, src, 64), u2 = __shfl(w2, src, 64), u3 = __shfl(w3, src, 64);
+    const float4 a = *reinterpret_cast<const float4 *>(cwb + a1);
+    const float4 bq = *reinterpret_cast<const float4 *>(cwb + a2);
+    const float4 cq = *reinterpret_cast<const float4 *>(cwb + a3);
     float4 v;
-    v.x = (a.x * w1 + bq.x * w2) + cq.x * w3; v.y = (a.y * w1 + bq.y * w2) + cq.y * w3;
-    v.z = (a.z * w1 + bq.z * w2) + cq.z * w3; v.w = (a.w * w1 + bq.w * w2) + cq.w * w3;
-    if (part) {
+    v.x = (a.x * u1 + bq.x * u2) + cq.x * u3; v.y = (a.y * u1 + bq.y * u2) + cq.y * u3;
+    v.z = (a.z * u1 + bq.z * u2) + cq.z * u3; v.w = (a.w * u1 + bq.w * u2) + cq.w * u3;
+    if (PART) {
       const float4 p = *reinterpret_cast<const float4 *>(part + row * C + c4);
       v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
     }
-    v.x = dh3d_act((v.x + pb.x) * sc.x + sh.x, ep.act); v.y = dh3d_act((v.y + pb.y) * sc.y + sh.y, ep.act);
-    v.z = dh3d_act((v.z + pb.z) * sc.z + sh.z, ep.act); v.w = dh3d_act((v.w + pb.w) * sc.w + sh.w, ep.act);
-    if (residual) {
+    v.x = dh3d_act((v.x + e.pb.x) * e.sc.x + e.sh.x, act); v.y = dh3d_act((v.y + e.pb.y) * e.sc.y + e.sh.y, act);
+    v.z = dh3d_act((v.z + e.pb.z) * e.sc.z + e.sh.z, act); v.w = dh3d_act((v.w + e.pb.w) * e.sc.w + e.sh.w, act);
+    if (RES) {
       const float4 q = *reinterpret_cast<const float4 *>(residual + row * C + c4);
       v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
     }
-    if (prefix) {  // [xyz | l2_normalize(v)] (core/model.py:177-181)
-      float ss = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-#pragma unroll
-      for (int off = 16; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    if (L2CAT) {  // [xyz | l2_normalize(v)] (core/model.py:177-181)
+      float ss = row16_sum_f32((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+      ss += __shfl_xor(ss, 16, 64);
       const float inv = rsqrtf(fmaxf(ss, l2_eps));
-      float *o = out + row * (C + 3);
-      if (sub < 3) o[sub] = prefix[row * 3 + sub];
-      o[3 + c4] = v.x * inv; o[4 + c4] = v.y * inv; o[5 + c4] = v.z * inv; o[6 + c4] = v.w * inv;
-    } else {
+      const float pf = prefix[row * 3 + min(sub, 2)];
+      if (live) {
+        float *o = out + row * (C + 3);
+        if (sub < 3) o[sub] = pf;
+        o[3 + c4] = v.x * inv; o[4 + c4] = v.y * inv; o[5 + c4] = v.z * inv; o[6 + c4] = v.w * inv;
+      }
+    } else if (live) {
       *reinterpret_cast<float4 *>(out + row * C + c4) = v;
     }
   }
@@ -482,11 +505,33 @@ DH3D_API int dh3d_interp_combine_fwd(const float *coarse_w, const int32_t *idx, 
                                      const float *prefix, float l2_eps, float *out, void *stream) {
   DH3D_REQUIRE(coarse_w && idx && dist && out && B > 0 && N > 0 && M > 0);
   DH3D_SUPPORTED(C == 128);
-  const long long rows = (long long)B * N;
-  long long g = (rows + 7) / 8;
-  g = g > 16384 ? 16384 : g;
-  hipLaunchKernelGGL(interp_combine_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, coarse_w, idx, dist, partial,
-                     rows, N, M, dh3d_ep(ep), residual, prefix, l2_eps, out);
+  DH3D_SUPPORTED((long long)M * C < (1ll << 31) && B <= 65535);
+  constexpr int kRows = 16;  // per wave
+  const EpilogueArgs e = dh3d_ep(ep);
+  const dim3 grid(dh3d_cdiv(N, 4 * kRows), B);
+  hipStream_t s = (hipStream_t)stream;
+#define DH3D_IC_LAUNCH(PART, RES, L2, ACT)                                                                          \
+  hipLaunchKernelGGL((interp_combine_kernel<kRows, PART, RES, L2, ACT>), grid, dim3(256), 0, s, coarse_w, idx, dist, \
+                     partial, N, M, e, residual, prefix, l2_eps, out)
+#define DH3D_IC_ACT(PART, RES, L2)                                     \
+  {                                                                    \
+    if (e.act == DH3D_ACT_RELU) DH3D_IC_LAUNCH(PART, RES, L2, DH3D_ACT_RELU); \
+    else if (e.act == DH3D_ACT_NONE) DH3D_IC_LAUNCH(PART, RES, L2, DH3D_ACT_NONE); \
+    else DH3D_IC_LAUNCH(PART, RES, L2, -1);                            \
+  }
+#define DH3D_IC_RES(PART, L2)                   \
+  {                                             \
+    if (residual) DH3D_IC_ACT(PART, true, L2)   \
+    else DH3D_IC_ACT(PART, false, L2)           \
+  }
+  if (partial) {
+    if (prefix) DH3D_IC_RES(true, true) else DH3D_IC_RES(true, false)
+  } else {
+    if (prefix) DH3D_IC_RES(false, true) else DH3D_IC_RES(false, false)
+  }
+#undef DH3D_IC_RES
+#undef DH3D_IC_ACT
+#undef DH3D_IC_LAUNCH
   return dh3d_launch_status();
 }
 

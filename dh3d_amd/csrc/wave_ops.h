@@ -64,6 +64,10 @@ __device__ __forceinline__ float row16_min_f32(float v) {
 // Sums (not idempotent, but every step pairs DISJOINT partial groups, so nothing is counted twice):
 // after the four row steps every lane of a 16-lane row holds the row's sum; row_bcast:15 adds row 0's (2's) sum into
 // row 1 (3).  Result: lanes 16..31 hold the sum of lanes 0..31, lanes 48..63 the sum of lanes 32..63.
+__device__ __forceinline__ float row16_sum_f32(float v) {  // every lane: the sum over its 16-lane row
+  asm volatile(DH3D_DPP_ROW16("v_add_f32_dpp") "s_nop 1\n\t" : "+v"(v));
+  return v;
+}
 __device__ __forceinline__ float half32_sum_f32(float v) {
   asm volatile(DH3D_DPP_ROW16("v_add_f32_dpp")
                "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
