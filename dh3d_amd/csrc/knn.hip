@@ -1053,6 +1053,7 @@ DH3D_API int dh3d_knn_sorted(const float *sorted, const float *gbox, int B, int 
 // every other kernel of this file: ids and distance bits are identical.  Degenerate clouds (everything in a few cells)
 // degrade towards the brute-force pair count, never past it.
 constexpr int kCellInts = 4112;  // ints per cloud of the cell table (spatial.hip)
+constexpr int kGridCap = 256;    // pooled candidates per query and pass (knn_grid_kernel)
 
 __device__ __forceinline__ unsigned knn_spread4(unsigned v) {  // 4 bits -> every third bit (the sort's spread6 >> 6)
   return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6);
@@ -1168,8 +1169,14 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict_
     return st.bound < G * G * 0.99999f;  // bound = the (1 + 2^-20)-inflated square of the K-th distance, inf while the list is short
   };
 
-  // shells 0 and 1 of the 5 x 5 x 5 block (27 cells), then shell 2 (98 cells) against the merged bound
-  // after a merge all eight lanes hold the SAME list: before they scan on, seven of them empty theirs (the bound stays),
+  // shells 0 and 1 of the 5 x 5 x 5 block (27 cells), then shell 2 (98 cells) against the merged bound.
+  // Cells hold 0..~8 points: walking them cell by cell leaves most lanes of the wave idle in every iteration (and the
+  // ~45-instruction insertion runs for the whole wave whenever one lane inserts).  So a pass first POOLS: every lane
+  // appends the record indices of its surviving cells to its query's list in LDS (one LDS atomic per cell for the
+  // place), then the eight lanes take the pooled candidates eight apart, four per lane in flight -- every lane busy in
+  // every iteration, ~5x fewer iterations of the candidate loop.  The result does not depend on who scans what (keys
+  // are unique, the merge sorts).  A list that is full (dense clusters) sends the rest of the cell down the direct path.
+  // After a merge all eight lanes hold the SAME list: before they scan on, seven of them empty theirs (the bound stays),
   // or the next merge would count every entry eight times
   auto keep_one_copy = [&]() {
     if (sub != 0) {
@@ -1177,9 +1184,52 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict_
       for (int i = 0; i < 8; ++i) st.keys[i] = ~0ull;
     }
   };
+  __shared__ unsigned short s_list[32][kGridCap];
+  __shared__ int s_cnt[32];
+  const int qs = threadIdx.x >> 3;
+  auto direct = [&](int j) {
+    const float4 r = sc[j];
+    const float dx = r.x - q[0], dy = r.y - q[1], dz = r.z - q[2];
+    knn_offer<8, false>(st, fmaf(dz, dz, fmaf(dy, dy, dx * dx)), __float_as_int(r.w), lad);
+  };
+  auto enqueue = [&](int beg, int end) {
+    const int len = end - beg;
+    if (len <= 0) return;
+    const int off = atomicAdd(&s_cnt[qs], len);
+    const int fit = min(len, kGridCap - off);
+    for (int k = 0; k < fit; ++k) s_list[qs][off + k] = (unsigned short)(beg + k);
+    for (int k = max(fit, 0); k < len; ++k) direct(beg + k);
+  };
+  auto drain = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int total = min(s_cnt[qs], kGridCap);
+#pragma unroll 1
+    for (int base = sub; base < total; base += 32) {
+      float4 r[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = base + u * 8;
+        ok[u] = i < total;
+        r[u] = sc[s_list[qs][min(i, total - 1)]];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float dx = r[u].x - q[0], dy = r[u].y - q[1], dz = r[u].z - q[2];
+        const float s2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));  // the reference's rounding order
+        knn_offer<8, false>(st, ok[u] ? s2 : __builtin_nanf(""), __float_as_int(r[u].w), lad);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
     if (pass) keep_one_copy();
+    if (sub == 0) s_cnt[qs] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
     for (int col = sub; col < 25; col += 8) {
       const int dz = col / 5, dy = col - dz * 5;                     // offsets + 2
@@ -1189,14 +1239,21 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict_
       if (pass == 0 && !inner) continue;
       const float d2yz = axis_d2(1, dy - 2) + axis_d2(2, dz - 2);
       const unsigned bityz = (knn_spread4((unsigned)ay) << 1) | (knn_spread4((unsigned)az) << 2);
+      int beg[5], end[5];  // the five cells' ranges, all in flight together (no load under the per-cell branches)
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        beg[t] = ct[bityz | bitx[t]];
+        end[t] = ct[(bityz | bitx[t]) + 1];
+      }
 #pragma unroll
       for (int t = 0; t < 5; ++t) {
         const bool shell01 = inner && t >= 1 && t <= 3;
         if ((pass == 0) != shell01) continue;
         if (!okx[t] || (d2yz + d2x[t]) * 0.99999f > st.bound) continue;
-        scan_range(bityz | bitx[t]);
+        enqueue(beg[t], end[t]);
       }
     }
+    drain();
     knn_merge_sublanes(st);
   }
   int R = 2;
