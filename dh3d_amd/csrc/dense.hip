@@ -506,7 +506,10 @@ DH3D_API int dh3d_interp_combine_fwd(const float *coarse_w, const int32_t *idx, 
   DH3D_REQUIRE(coarse_w && idx && dist && out && B > 0 && N > 0 && M > 0);
   DH3D_SUPPORTED(C == 128);
   DH3D_SUPPORTED((long long)M * C < (1ll << 31) && B <= 65535);
-  constexpr int kRows = 16;  // per wave
+#ifndef DH3D_IC_ROWS
+#define DH3D_IC_ROWS 16
+#endif
+  constexpr int kRows = DH3D_IC_ROWS;  // per wave
   const EpilogueArgs e = dh3d_ep(ep);
   const dim3 grid(dh3d_cdiv(N, 4 * kRows), B);
   hipStream_t s = (hipStream_t)stream;
