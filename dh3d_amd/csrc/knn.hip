@@ -1086,10 +1086,11 @@ __device__ __forceinline__ void knn_merge_step(KnnState<8> &st) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) st.keys[i] = c[i];
 }
+template <int L>
 __device__ __forceinline__ void knn_merge_sublanes(KnnState<8> &st) {
-  knn_merge_step<0xB1>(st);   // quad_perm [1,0,3,2]
-  knn_merge_step<0x4E>(st);   // quad_perm [2,3,0,1]
-  knn_merge_step<0x141>(st);  // row_half_mirror
+  if (L >= 2) knn_merge_step<0xB1>(st);   // quad_perm [1,0,3,2]
+  if (L >= 4) knn_merge_step<0x4E>(st);   // quad_perm [2,3,0,1]
+  if (L >= 8) knn_merge_step<0x141>(st);  // row_half_mirror
   const unsigned hb = (unsigned)(st.keys[7] >> 32);
   if (hb <= 0x7f800000u) {
     const float dk = __uint_as_float(hb);
@@ -1097,11 +1098,15 @@ __device__ __forceinline__ void knn_merge_sublanes(KnnState<8> &st) {
   }
 }
 
+// L = lanes per query (2, 4 or 8): fewer lanes = longer private candidate streams, but an insertion round serves 64 / L
+// queries and the merge has log2(L) steps.
+template <int L>
 __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict__ sorted, const int *__restrict__ cells,
                                                       int N, int K, KnnLadder lad, int32_t *__restrict__ nn,
                                                       float *__restrict__ dist) {
-  const int b = blockIdx.y, lane = threadIdx.x & 63, sub = lane & 7;
-  const int qi = blockIdx.x * 32 + (threadIdx.x >> 3);
+  constexpr int QB = 256 / L;  // queries per workgroup
+  const int b = blockIdx.y, lane = threadIdx.x & 63, sub = lane & (L - 1);
+  const int qi = blockIdx.x * QB + threadIdx.x / L;
   const bool valid = qi < N;
   const float4 *sc = sorted + (size_t)b * N;
   const int *ct = cells + (size_t)b * kCellInts;
@@ -1184,9 +1189,9 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict_
       for (int i = 0; i < 8; ++i) st.keys[i] = ~0ull;
     }
   };
-  __shared__ unsigned short s_list[32][kGridCap];
-  __shared__ int s_cnt[32];
-  const int qs = threadIdx.x >> 3;
+  __shared__ unsigned short s_list[QB][kGridCap];
+  __shared__ int s_cnt[QB];
+  const int qs = threadIdx.x / L;
   auto direct = [&](int j) {
     const float4 r = sc[j];
     const float dx = r.x - q[0], dy = r.y - q[1], dz = r.z - q[2];
@@ -1205,12 +1210,12 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict_
     __builtin_amdgcn_wave_barrier();
     const int total = min(s_cnt[qs], kGridCap);
 #pragma unroll 1
-    for (int base = sub; base < total; base += 32) {
+    for (int base = sub; base < total; base += 4 * L) {
       float4 r[4];
       bool ok[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int i = base + u * 8;
+        const int i = base + u * L;
         ok[u] = i < total;
         r[u] = sc[s_list[qs][min(i, total - 1)]];
       }
@@ -1231,7 +1236,7 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict_
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
-    for (int col = sub; col < 25; col += 8) {
+    for (int col = sub; col < 25; col += L) {
       const int dz = col / 5, dy = col - dz * 5;                     // offsets + 2
       const int ay = cq[1] + dy - 2, az = cq[2] + dz - 2;
       if ((unsigned)ay > 15u || (unsigned)az > 15u) continue;
@@ -1254,7 +1259,7 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict_
       }
     }
     drain();
-    knn_merge_sublanes(st);
+    knn_merge_sublanes<L>(st);
   }
   int R = 2;
   bool done = !valid || inside(R);
@@ -1264,27 +1269,32 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict_
     if (!done) {
       const int side = 2 * R + 1, tot = side * side * side;
 #pragma unroll 1
-      for (int c = sub; c < tot; c += 8) {
+      for (int c = sub; c < tot; c += L) {
         const int dz = c / (side * side), rr = c - dz * side * side, dy = rr / side, dx = rr - dy * side;
         if (max(abs(dx - R), max(abs(dy - R), abs(dz - R))) == R) visit(dx - R, dy - R, dz - R);
       }
     }
-    knn_merge_sublanes(st);
+    knn_merge_sublanes<L>(st);
     done = done || R >= 15 || inside(R);
   }
-  if (valid && sub < K) {
+  if (valid) {
     const int y = __float_as_int(qr.w);  // the query's original index
-    u64 key = st.keys[0];
 #pragma unroll
-    for (int i = 1; i < 8; ++i) key = sub == i ? st.keys[i] : key;
-    const size_t o = ((size_t)b * N + y) * K + sub;
-    if (key == ~0ull) {  // fewer than K points: reference pads with id -1 / FLT_MAX (:110-111)
-      nn[o] = -1;
-      dist[o] = FLT_MAX;
-    } else {
-      const unsigned tb = (unsigned)key;
-      nn[o] = (int)(((tb % (unsigned)lad.cv) << lad.log2ct) + tb / (unsigned)lad.cv);
-      dist[o] = __uint_as_float((unsigned)(key >> 32));
+    for (int e = 0; e < 8 / L; ++e) {
+      const int slot = e * L + sub;
+      if (slot >= K) break;
+      u64 key = st.keys[0];
+#pragma unroll
+      for (int i = 1; i < 8; ++i) key = slot == i ? st.keys[i] : key;
+      const size_t o = ((size_t)b * N + y) * K + slot;
+      if (key == ~0ull) {  // fewer than K points: reference pads with id -1 / FLT_MAX (:110-111)
+        nn[o] = -1;
+        dist[o] = FLT_MAX;
+      } else {
+        const unsigned tb = (unsigned)key;
+        nn[o] = (int)(((tb % (unsigned)lad.cv) << lad.log2ct) + tb / (unsigned)lad.cv);
+        dist[o] = __uint_as_float((unsigned)(key >> 32));
+      }
     }
   }
 }
@@ -1294,7 +1304,11 @@ DH3D_API int dh3d_knn_grid(const float *sorted, const int32_t *cells, int B, int
   DH3D_REQUIRE(sorted && cells && nn && dist && B > 0 && N > 0 && K > 0);
   DH3D_SUPPORTED(K <= 8 && N <= 16384 && B <= 65535);
   const KnnLadder lad = knn_ladder(N);
-  hipLaunchKernelGGL(knn_grid_kernel, dim3(dh3d_cdiv(N, 32), B), dim3(256), 0, (hipStream_t)stream,
+#ifndef DH3D_GRID_LANES
+#define DH3D_GRID_LANES 4
+#endif
+  constexpr int kLanes = DH3D_GRID_LANES;  // per query
+  hipLaunchKernelGGL(knn_grid_kernel<kLanes>, dim3(dh3d_cdiv(N, 256 / kLanes), B), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const float4 *>(sorted), cells, N, K, lad, nn, dist);
   return dh3d_launch_status();
 }
