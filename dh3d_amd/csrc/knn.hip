@@ -1102,8 +1102,8 @@ __device__ __forceinline__ void knn_merge_sublanes(KnnState<8> &st) {
 // queries and the merge has log2(L) steps.
 template <int L>
 __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict__ sorted, const int *__restrict__ cells,
-                                                      int N, int K, KnnLadder lad, int32_t *__restrict__ nn,
-                                                      float *__restrict__ dist) {
+                                                      int N, int K, int D, KnnLadder lad,
+                                                      int32_t *__restrict__ nn, float *__restrict__ dist) {
   constexpr int QB = 256 / L;  // queries per workgroup
   const int b = blockIdx.y, lane = threadIdx.x & 63, sub = lane & (L - 1);
   const int qi = blockIdx.x * QB + threadIdx.x / L;
@@ -1114,14 +1114,24 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict_
   const float lo[3] = {hd[0], hd[1], hd[2]}, scl[3] = {hd[3], hd[4], hd[5]};
   const float4 qr = sc[valid ? qi : N - 1];
   const float q[3] = {qr.x, qr.y, qr.z};
-  int cq[3];
+  // D = low bits of the 12-bit cell code left out (x0, y0, z0, x1, ...): a coarser grid whose cells are still contiguous
+  // ranges of the order -- 2^D consecutive cells of the table
+  const int drop[3] = {(D + 2) / 3, (D + 1) / 3, D / 3};
+  const int span = 1 << D;
+  int cq[3], gmax[3];
   float w[3], eps[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    cq[a] = min(63, max(0, (int)((q[a] - lo[a]) * scl[a]))) >> 2;  // the sort's cell arithmetic
-    w[a] = 4.f / scl[a];                                           // cell width
-    eps[a] = 2.5e-6f * w[a] * 16.f;  // a point may sit outside its cell's nominal interval by a few ulps of the extent
+    cq[a] = min(63, max(0, (int)((q[a] - lo[a]) * scl[a]))) >> (2 + drop[a]);  // the sort's cell arithmetic
+    gmax[a] = (16 >> drop[a]) - 1;
+    w[a] = (float)(4 << drop[a]) / scl[a];  // cell width
+    eps[a] = 2.5e-6f * (4.f / scl[a]) * 16.f;  // a point may sit outside its cell's nominal interval by a few ulps of the extent
   }
+  // the table index of cell (ax, ay, az)
+  auto cell_code = [&](int ax, int ay, int az) {
+    return knn_spread4((unsigned)(ax << drop[0]) & 15u) | (knn_spread4((unsigned)(ay << drop[1]) & 15u) << 1) |
+           (knn_spread4((unsigned)(az << drop[2]) & 15u) << 2);
+  };
   KnnState<8> st;
 #pragma unroll
   for (int i = 0; i < 8; ++i) st.keys[i] = ~0ull;
@@ -1134,7 +1144,7 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict_
     return d * d;
   };
   auto scan_range = [&](unsigned cid) {
-    const int beg = ct[cid], end = ct[cid + 1];
+    const int beg = ct[cid], end = ct[cid + span];
     for (int j = beg; j < end; ++j) {
       const float4 r = sc[j];
       const float dx = r.x - q[0], dy = r.y - q[1], dz = r.z - q[2];
@@ -1144,9 +1154,9 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict_
   };
   auto visit = [&](int dx, int dy, int dz) {  // the general form (the widening rounds)
     const int ax = cq[0] + dx, ay = cq[1] + dy, az = cq[2] + dz;
-    if ((unsigned)ax > 15u || (unsigned)ay > 15u || (unsigned)az > 15u) return;
+    if ((unsigned)ax > (unsigned)gmax[0] || (unsigned)ay > (unsigned)gmax[1] || (unsigned)az > (unsigned)gmax[2]) return;
     if ((axis_d2(0, dx) + axis_d2(1, dy) + axis_d2(2, dz)) * 0.99999f > st.bound) return;
-    scan_range(knn_spread4((unsigned)ax) | (knn_spread4((unsigned)ay) << 1) | (knn_spread4((unsigned)az) << 2));
+    scan_range(cell_code(ax, ay, az));
   };
   // the 5 x 5 x 5 block: everything that depends on the x offset alone is computed once (five slabs: distance, cell bits,
   // inside the grid or not); a lane then walks (dy, dz) columns and, per column, the five x offsets with constants
@@ -1156,9 +1166,9 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict_
 #pragma unroll
   for (int t = 0; t < 5; ++t) {
     const int ax = cq[0] + t - 2;
-    okx[t] = (unsigned)ax <= 15u;
+    okx[t] = (unsigned)ax <= (unsigned)gmax[0];
     d2x[t] = okx[t] ? axis_d2(0, t - 2) : INFINITY;
-    bitx[t] = knn_spread4((unsigned)(ax & 15));
+    bitx[t] = knn_spread4((unsigned)(ax << drop[0]) & 15u);
   }
   // is the K-th distance strictly inside the block of radius R around the query's cell?  (faces on the grid's border
   // have nothing behind them)
@@ -1167,7 +1177,7 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict_
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       if (cq[a] - R > 0) G = fminf(G, (q[a] - (lo[a] + (float)(cq[a] - R) * w[a])) - eps[a]);
-      if (cq[a] + R < 15) G = fminf(G, ((lo[a] + (float)(cq[a] + R + 1) * w[a]) - q[a]) - eps[a]);
+      if (cq[a] + R < gmax[a]) G = fminf(G, ((lo[a] + (float)(cq[a] + R + 1) * w[a]) - q[a]) - eps[a]);
     }
     if (G == INFINITY) return true;
     G = fmaxf(G, 0.f);
@@ -1239,16 +1249,16 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict_
     for (int col = sub; col < 25; col += L) {
       const int dz = col / 5, dy = col - dz * 5;                     // offsets + 2
       const int ay = cq[1] + dy - 2, az = cq[2] + dz - 2;
-      if ((unsigned)ay > 15u || (unsigned)az > 15u) continue;
+      if ((unsigned)ay > (unsigned)gmax[1] || (unsigned)az > (unsigned)gmax[2]) continue;
       const bool inner = abs(dy - 2) <= 1 && abs(dz - 2) <= 1;       // the column crosses shells 0-1 at dx in -1..1
       if (pass == 0 && !inner) continue;
       const float d2yz = axis_d2(1, dy - 2) + axis_d2(2, dz - 2);
-      const unsigned bityz = (knn_spread4((unsigned)ay) << 1) | (knn_spread4((unsigned)az) << 2);
+      const unsigned bityz = cell_code(0, ay, az);
       int beg[5], end[5];  // the five cells' ranges, all in flight together (no load under the per-cell branches)
 #pragma unroll
       for (int t = 0; t < 5; ++t) {
         beg[t] = ct[bityz | bitx[t]];
-        end[t] = ct[(bityz | bitx[t]) + 1];
+        end[t] = ct[(bityz | bitx[t]) + span];
       }
 #pragma unroll
       for (int t = 0; t < 5; ++t) {
@@ -1308,8 +1318,14 @@ DH3D_API int dh3d_knn_grid(const float *sorted, const int32_t *cells, int B, int
 #define DH3D_GRID_LANES 4
 #endif
   constexpr int kLanes = DH3D_GRID_LANES;  // per query
+  // about two points per cell: 4096 cells from 8192 points, one bit of the cell code less for every halving
+  int D = 0;
+  while (D < 6 && ((long long)N << D) <= 4096 + 2048) ++D;
+#ifdef DH3D_GRID_DROP_BIAS
+  D = D + (DH3D_GRID_DROP_BIAS) < 0 ? 0 : D + (DH3D_GRID_DROP_BIAS);
+#endif
   hipLaunchKernelGGL(knn_grid_kernel<kLanes>, dim3(dh3d_cdiv(N, 256 / kLanes), B), dim3(256), 0, (hipStream_t)stream,
-                     reinterpret_cast<const float4 *>(sorted), cells, N, K, lad, nn, dist);
+                     reinterpret_cast<const float4 *>(sorted), cells, N, K, D, lad, nn, dist);
   return dh3d_launch_status();
 }
 

@@ -29,8 +29,7 @@ def tf_variable_name(state_dict_key):
     return name
 
 
-# dev A/B switch (DH3D_KNN_GRID=0: the Morton-pruned shared scan for every K); both kernels give identical ids
-KNN_GRID = os.environ.get("DH3D_KNN_GRID", "1") != "0"
+KNN_GRID = pm.KNN_GRID
 
 
 class DH3D(nn.Module):

@@ -3,6 +3,8 @@
 Thin, allocation-only wrappers: each function validates shapes, allocates the output with torch and
 enqueues one C-ABI call on the current stream.  No function here has a CPU or eager-torch fallback.
 """
+import os
+
 import torch
 
 from . import _lib as L
@@ -35,6 +37,10 @@ def spatial_sort(xyz):
 
 
 CELL_INTS = 4112  # include/dh3d_hip.h DH3D_CELL_INTS
+
+
+# dev A/B switch (DH3D_KNN_GRID=0: the Morton-pruned shared scan / brute force for every K); identical ids either way
+KNN_GRID = os.environ.get("DH3D_KNN_GRID", "1") != "0"
 
 
 def spatial_sort_cells(xyz):

@@ -507,11 +507,16 @@ def _knn_clouds(name, B, N, rng):
     ("uniform", 8, 8192, 8), ("uniform", 3, 4097, 8), ("uniform", 2, 16384, 8), ("uniform", 2, 9000, 5),
     ("oxford_extent", 4, 4096, 8), ("clusters", 2, 8192, 8), ("lattice", 2, 8192, 8), ("lattice", 1, 4096, 3),
     ("duplicates", 2, 4096, 8), ("plane", 2, 4096, 8), ("one_point", 1, 2100, 8), ("outliers", 2, 4096, 8),
-    ("uniform", 1, 2049, 1)])
+    ("uniform", 1, 2049, 1),
+    # smaller sets: coarser grids (one bit of the cell code less per halving, down to 4 x 4 x 4 cells)
+    ("uniform", 8, 1024, 8), ("uniform", 32, 512, 8), ("uniform", 4, 2048, 8), ("uniform", 3, 300, 8),
+    ("uniform", 2, 128, 8), ("uniform", 2, 40, 8), ("uniform", 2, 5, 8), ("clusters", 2, 1024, 8),
+    ("lattice", 2, 1000, 8), ("duplicates", 2, 512, 8), ("plane", 2, 1024, 8), ("one_point", 1, 600, 8),
+    ("outliers", 2, 1024, 8), ("oxford_extent", 4, 2048, 8), ("oxford_extent", 8, 1024, 8)])
 def test_knn_grid_cell_list_search_is_bit_equal_to_brute_force(dev, name, B, N, K):
-    """knn_grid (cell lists on the sort's 16^3 grid, 8 lanes per query) == the brute-force kernel: ids AND distance
-    bits, on uniform / anisotropic / clustered / tie-ridden / degenerate clouds; the brute-force kernel itself is pinned on
-    the oracle above."""
+    """knn_grid (cell lists on the sort's Morton grid, candidates pooled per query) == the brute-force kernel: ids AND
+    distance bits, on uniform / anisotropic / clustered / tie-ridden / degenerate clouds at every grid resolution; the
+    brute-force kernel itself is pinned on the oracle above."""
     from dh3d_amd import pm
     rng = np.random.default_rng(abs(hash((name, B, N, K))) % (2 ** 31))
     pts = torch.from_numpy(_knn_clouds(name, B, N, rng)).to(dev)
