@@ -325,22 +325,20 @@ def compute_level(xyz, dilate, knn, ordered=None, fps_contract=None):
         idx = ops.farthest_point_sample(npoint, xyz, contract=fps_contract)  # any N (scratch distances above 16384)
         xyz_s = gather_rows(xyz, idx)
     ready = torch.cuda.Event()
+    ready.record()  # xyz_s exists: three_nn may start on another stream while the sampled-set kNN runs here
     ordered_s = None
-    if knn <= 8 and 128 <= npoint <= 16384 and pm.KNN_GRID:
-        # cell lists on the sampled set's own Morton grid (csrc/knn.hip knn_grid_kernel: 2-3 points per cell at any size);
-        # the order + boxes are what three_nn wants of the sampled set, so it waits for the sort instead of repeating it
+    # (cell lists on the sampled set -- spatial_sort_cells + knn_grid, which serves any size -- were measured here: the
+    #  sort joins the critical chain behind the FPS, local serial 0.532 -> 0.539 ms, in flight unchanged: DEADENDS.md)
+    if npoint <= 2048 or npoint > 16384:  # small sets: the brute-force kernel beats sort + pruned search (launch /
+        nbr_s, _ = pm.knn_xyz(xyz_s, knn)  # latency bound); sets beyond the Morton sort's 14-bit ids: it is what serves any N
+    elif knn <= 8 and pm.KNN_GRID:
         srt_s, gbox_s, cells_s = pm.spatial_sort_cells(xyz_s)
-        ready.record()
         nbr_s, _ = pm.knn_grid(srt_s, cells_s, knn)
         ordered_s = (srt_s, gbox_s)
     else:
-        ready.record()  # xyz_s exists: three_nn may start on another stream while the sampled-set kNN runs here
-        if npoint <= 2048 or npoint > 16384:  # small sets: the brute-force kernel beats sort + pruned search (launch /
-            nbr_s, _ = pm.knn_xyz(xyz_s, knn)  # latency bound); sets beyond the Morton sort's 14-bit ids: it serves any N
-        else:
-            srt_s, gbox_s = pm.spatial_sort(xyz_s)
-            nbr_s, _ = pm.knn_sorted(srt_s, gbox_s, knn)
-            ordered_s = (srt_s, gbox_s)
+        srt_s, gbox_s = pm.spatial_sort(xyz_s)
+        nbr_s, _ = pm.knn_sorted(srt_s, gbox_s, knn)
+        ordered_s = (srt_s, gbox_s)
     level_ready = torch.cuda.Event()
     level_ready.record()  # idx / xyz_s / nbr_s exist
     lv = {"idx": idx, "xyz_s": xyz_s, "nbr_s": nbr_s, "_xyz_ready": ready, "_level_ready": level_ready}

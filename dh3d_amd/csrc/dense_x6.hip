@@ -470,6 +470,98 @@ __global__ __launch_bounds__(512) void linear_x6_kernel(const float *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// 64 -> 128 (the local step's two full-resolution 1x1 convs: 65536 rows, K = 64) without LDS, barriers or a K pipeline.
+// linear_x6_kernel is built for long K: 110 KB of staging per 128-row workgroup = ONE workgroup per CU, and with two
+// K-chunks its prologue / epilogue latency is the whole kernel (18.6 us for 50 MB).  Here a wave owns 32 rows x 128
+// columns: every lane loads the 8 floats per K-step its MFMA A operand wants straight from the row (32 B pieces, the
+// whole 256 B row over the four K-steps), splits them in registers, takes the weight fragments (packed in fragment
+// order, 48 KB, L2-resident) one K-step ahead, and stores from the accumulators -- 128 B row segments per column block.
+template <bool RES, int NCB, int ACT>  // ACT: DH3D_ACT_NONE / DH3D_ACT_RELU at compile time, -1 = read ep.act
+__global__ __launch_bounds__(256) void linear_k64_x6_kernel(const float *__restrict__ x, const uint4 *__restrict__ wp,
+                                                            EpilogueArgs ep, const float *__restrict__ residual,
+                                                            long long R, float *__restrict__ out) {
+  constexpr int C = 64, KB = C / 16, DOUT = 128, WPR = 4 / NCB;  // WPR waves share a 32-row tile (column blocks each)
+  const int lane = threadIdx.x & 63, half = lane >> 5, lr = lane & 31;
+  const int wave = threadIdx.x >> 6, cb0 = (wave % WPR) * NCB;
+  const long long row0 = ((long long)blockIdx.x * NCB + wave / WPR) * 32;
+  if (row0 >= R) return;
+  long long arow = row0 + lr;
+  if (arow >= R) arow = R - 1;  // rows past R repeat the last row; they are not stored
+  const float4 *ap = reinterpret_cast<const float4 *>(x + arow * C + 8 * half);
+  float4 av[KB][2];
+#pragma unroll
+  for (int ks = 0; ks < KB; ++ks) {
+    av[ks][0] = ap[ks * 4];
+    av[ks][1] = ap[ks * 4 + 1];
+  }
+  uint4 bq[2][NCB][3];  // this K-step's fragments and the next one's (all four at once would be 192 VGPRs: one wave per SIMD)
+  auto load_b = [&](int ks) __attribute__((always_inline)) {
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bq[ks & 1][cb][p] = wp[((size_t)((cb0 + cb) * KB + ks) * 3 + p) * 64 + lane];
+  };
+  load_b(0);
+  float pb[NCB], scl[NCB], sh[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    const int col = (cb0 + cb) * 32 + lr;
+    pb[cb] = ep.pre_bias ? ep.pre_bias[col] : 0.f;
+    scl[cb] = ep.scale ? ep.scale[col] : 1.f;
+    sh[cb] = ep.shift ? ep.shift[col] : 0.f;
+  }
+  f32x16 acc[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < KB; ++ks) {
+    if (ks + 1 < KB) load_b(ks + 1);
+    asm volatile("" ::: "memory");  // (keeps the compiler from issuing every K-step's fragments up front)
+    uint2 c1[2], c2[2], c3[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) split3x4(av[ks][j], c1[j], c2[j], c3[j]);
+    bf16x8 a[3];
+    a[0] = __builtin_bit_cast(bf16x8, make_uint4(c1[0].x, c1[0].y, c1[1].x, c1[1].y));
+    a[1] = __builtin_bit_cast(bf16x8, make_uint4(c2[0].x, c2[0].y, c2[1].x, c2[1].y));
+    a[2] = __builtin_bit_cast(bf16x8, make_uint4(c3[0].x, c3[0].y, c3[1].x, c3[1].y));
+#define DH3D_K64_PRODUCT(PA, PB)                                                                      \
+  _Pragma("unroll") for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16( \
+      a[PA], __builtin_bit_cast(bf16x8, bq[ks & 1][cb][PB]), acc[cb], 0, 0, 0);
+    DH3D_K64_PRODUCT(2, 0) DH3D_K64_PRODUCT(0, 2) DH3D_K64_PRODUCT(1, 1)
+    DH3D_K64_PRODUCT(1, 0) DH3D_K64_PRODUCT(0, 1) DH3D_K64_PRODUCT(0, 0)
+#undef DH3D_K64_PRODUCT
+  }
+  // epilogue from the accumulators: two rows at a time in packed f32 (a lane's column is fixed per block), one pointer
+  // per column block with the row offsets as immediates
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const int act = ACT >= 0 ? ACT : ep.act;
+  auto store_tile = [&](auto ragged) __attribute__((always_inline)) {
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      const long long e0 = (row0 + 4 * half) * DOUT + (cb0 + cb) * 32 + lr;
+      float *op = out + e0;
+      const float *rp = RES ? residual + e0 : nullptr;
+      const v2f pb2 = {pb[cb], pb[cb]}, sc2 = {scl[cb], scl[cb]}, sh2 = {sh[cb], sh[cb]};
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        v2f y = {acc[cb][r], acc[cb][r + 1]};
+        y = __builtin_elementwise_fma(y + pb2, sc2, sh2);
+        if (ACT == DH3D_ACT_RELU) y = __builtin_elementwise_max(y, v2f{0.f, 0.f});
+        else if (ACT < 0) y = v2f{dh3d_act(y[0], act), dh3d_act(y[1], act)};
+        const int t0 = (r & 3) + 8 * (r >> 2);  // rows t0 + 4 half and the next one of the tile
+        if (!decltype(ragged)::value || row0 + 4 * half + t0 < R) op[t0 * DOUT] = RES ? y[0] + rp[t0 * DOUT] : y[0];
+        if (!decltype(ragged)::value || row0 + 4 * half + t0 + 1 < R)
+          op[(t0 + 1) * DOUT] = RES ? y[1] + rp[(t0 + 1) * DOUT] : y[1];
+      }
+    }
+  };
+  if (row0 + 32 <= R) store_tile(std::false_type{});
+  else store_tile(std::true_type{});
+}
+
+// ------------------------------------------------------------------------------------------------
 // The attention head on an UP-SAMPLED input, with the wide 1x1 conv commuted through the interpolation.
 // globalatt_block (core/backbones.py:156-173) is  sigmoid(w_fc . relu(BN(W x + b)) + b_fc)  on x = the 3-NN inverse-
 // distance interpolation of the N/8-level features (backbones.py:91-95).  Interpolation and conv are both linear and
@@ -598,6 +690,25 @@ static int linear_x6_launch(const float *x1, int C1, const float *x2, int C2, co
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(dh3d_cdiv(R, HTM), slices), block(512);
   const uint4 *wp = static_cast<const uint4 *>(wpacked_x3);
+  if (C1 == 64 && C2 == 0 && Dout == 128 && slices == 1 && !up.points && !l2.out && !sc.x3) {
+#ifndef DH3D_K64_NCB
+#define DH3D_K64_NCB 4
+#endif
+    constexpr int kNcb = DH3D_K64_NCB;  // column blocks per wave
+    const dim3 g64(dh3d_cdiv(R, 32 * kNcb));
+#define DH3D_K64_LAUNCH(RES, ACT) \
+  hipLaunchKernelGGL((linear_k64_x6_kernel<RES, kNcb, ACT>), g64, dim3(256), 0, s, x1, wp, e, residual, (long long)R, out)
+#define DH3D_K64_ACT(RES)                                                \
+  {                                                                      \
+    if (e.act == DH3D_ACT_RELU) DH3D_K64_LAUNCH(RES, DH3D_ACT_RELU);     \
+    else if (e.act == DH3D_ACT_NONE) DH3D_K64_LAUNCH(RES, DH3D_ACT_NONE); \
+    else DH3D_K64_LAUNCH(RES, -1);                                       \
+  }
+    if (residual) DH3D_K64_ACT(true) else DH3D_K64_ACT(false)
+#undef DH3D_K64_ACT
+#undef DH3D_K64_LAUNCH
+    return dh3d_launch_status();
+  }
   const long long wslice = (long long)3 * (C1 + C2 + sc.C3) * Dout * 2 / 16;  // uint4 per packed slice
   const long long oslice = (long long)R * Dout;
   if (Dout == 128) {
