@@ -382,15 +382,18 @@ def step_kernel_rows(workload):
             ("fillBufferAligned", 1, "zero fill of the walk's accumulators", 4.0 * B * M * 64, 0.0, "hbm"),
             ("interp_head_lds_kernel", 1, "walk: interpolated attention logit + NetVLAD assignment -> A'",
              4 * Rs * (1024 + 64) + 4 * R * (6 + 4) + 4.0 * B * M * 64, 2.0 * R * 3 * (1024 + 64) + 2.0 * R * 1024 + 2.0 * R * 64 * 64, "L2 gather + VALU"),
-            ("gemm_x6_kernel", 1, "VLAD = A'^T c", 4.0 * B * (M * 64 + M * 256 + 64 * 256), 2.0 * B * 64 * M * 256, "matrix pipe"),
-            ("netvlad_finalize", 1, "VLAD residual + intra-normalise", 4.0 * B * 64 * 256 * 2, 0.0, "hbm"),
+            ("netvlad_assign_finalize", 1, "VLAD = A'^T c on the coarse rows + residual + intra-normalise",
+             4.0 * B * (M * 64 + M * 256 + 64 * 256), 2.0 * B * 64 * M * 256, "f32 VALU / L2"),
+            ("gemm_x6_kernel", 1, "VLAD = A'^T c (rounds 2-3: its own launch)", 4.0 * B * (M * 64 + M * 256 + 64 * 256), 2.0 * B * 64 * M * 256, "matrix pipe"),
+            ("netvlad_finalize", 1, "VLAD residual + intra-normalise (rounds 2-3)", 4.0 * B * 64 * 256 * 2, 0.0, "hbm"),
             ("netvlad_hidden_splitk", 1, "hidden projection 16384->256", 4.0 * 16384 * 256 + 4.0 * B * 16384, 2.0 * B * 16384 * 256, "hbm (16.8 MB of weights)"),
             ("netvlad_gate", 1, "BN + context gating", 4.0 * 256 * 256 + 4.0 * B * 512, 2.0 * B * 256 * 256, "latency"),
         ]
     else:
         rows += [
             ("group_point_fwd4_kernel", 1, "group_point of the sampled rows (C=64)", 4 * Rs * (1 + 2 * 64), 0.0, "hbm"),
-            ("linear_x6_kernel<1, false>", 2, "shortcut conv 64->128 and concat conv's lower block 64->128 @N", 2 * 4 * R * (64 + 128), 2 * 2.0 * R * 64 * 128, "hbm"),
+            ("linear_k64_x6_kernel", 2, "shortcut conv 64->128 and concat conv's lower block 64->128 @N", 2 * 4 * R * (64 + 128), 2 * 2.0 * R * 64 * 128, "hbm"),
+            ("linear_x6_kernel<1, false>", 2, "the same two convs on the long-K kernel (rounds 1-3)", 2 * 4 * R * (64 + 128), 2 * 2.0 * R * 64 * 128, "hbm"),
             ("linear_x6_kernel<2, false>", 1, "shortcut + lower block in one launch @N", 4 * R * (64 + 64 + 256), 2 * 2.0 * R * 64 * 128, "hbm"),
             ("linear_pm_kernel<2>", 1, "concat conv's upper block 128->128 on the coarse rows", 4 * Rs * 256, 2.0 * Rs * 128 * 128, "hbm"),
             ("interp_combine_kernel", 1, "up-sampling + bias/BN/ReLU + shortcut + l2-normalise/concat store @N",
