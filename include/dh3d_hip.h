@@ -228,9 +228,10 @@ int dh3d_knn_sorted(const float *sorted, const float *gbox, int B, int N, int K,
 #define DH3D_CELL_INTS 4112
 int dh3d_spatial_sort_cells(const float *xyz, int B, int N, float *sorted, float *gbox, int32_t *cells, void *stream);
 
-/* KnnBruteforce on that grid (cell-list search: every query scans the cells its K-th distance reaches, 8 lanes per
- * query; csrc/knn.hip knn_grid_kernel).  Same outputs as dh3d_knn_bruteforce_xyz bit for bit -- ids in the reference's
- * (distance, CUB rank) order, IEEE distances, original point order.  K <= 8, N <= 16384. */
+/* KnnBruteforce on that grid (cell-list search: every query scans the cells its K-th distance reaches, candidates pooled
+ * per query in LDS, 4 lanes per query; csrc/knn.hip knn_grid_kernel).  Same outputs as dh3d_knn_bruteforce_xyz bit for
+ * bit -- ids in the reference's (distance, CUB rank) order, IEEE distances, original point order.  K <= 8, any
+ * N <= 16384 (small sets search a coarser grid: 2^D consecutive cells of the same table). */
 int dh3d_knn_grid(const float *sorted, const int32_t *cells, int B, int N, int K, int32_t *nn, float *dist, void *stream);
 
 
