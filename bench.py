@@ -365,8 +365,10 @@ def step_kernel_rows(workload):
         ("knn_small_kernel", 1, "kNN K=8 on the sampled sets", 12 * Rs + 8 * Rs * K, 8.0 * B * M * M, "latency / VALU issue"),
         ("spatial_sort_kernel<1>", 1, "Morton sort of the sampled sets", 4 * Rs * 7 + 32 * Rs / 64, 0.0, "latency"),
         ("three_nn_pruned_kernel", 1, "three_nn N vs N/8", 16 * R + 16 * Rs + 24 * R, 8.0 * B * N * M, "f32 VALU (brute-force pair count; the kernel prunes)"),
-        ("flex_conv_pm_kernel<64, 128", 1, "flex_conv 64->128 @N/8", ff(B, M, K, 64, 128)[0], ff(B, M, K, 64, 128)[2], "f32 MFMA"),
-        ("flex_conv_pm_kernel<128, 128", 1, "flex_conv 128->128 @N/8", ff(B, M, K, 128, 128)[0], ff(B, M, K, 128, 128)[2], "f32 MFMA"),
+        ("flex_conv_tx6_kernel<64, 128", 1, "flex_conv 64->128 @N/8 (32-point tiles, bf16x6 tile GEMM)", ff(B, M, K, 64, 128)[0], ff(B, M, K, 64, 128)[2], "gather + matrix pipe / L2 (weights)"),
+        ("flex_conv_tx6_kernel<128, 128", 1, "flex_conv 128->128 @N/8 (32-point tiles, bf16x6 tile GEMM)", ff(B, M, K, 128, 128)[0], ff(B, M, K, 128, 128)[2], "gather + matrix pipe / L2 (weights)"),
+        ("flex_conv_pm_kernel<64, 128", 1, "flex_conv 64->128 @N/8 (exact-f32 tiles: rounds 1-3)", ff(B, M, K, 64, 128)[0], ff(B, M, K, 64, 128)[2], "f32 MFMA"),
+        ("flex_conv_pm_kernel<128, 128", 1, "flex_conv 128->128 @N/8 (exact-f32 tiles: rounds 1-3)", ff(B, M, K, 128, 128)[0], ff(B, M, K, 128, 128)[2], "f32 MFMA"),
         ("se_res_mfma_kernel<128, true, false>", 1, "flex_pool + SE + residual @N/8", 4 * Rs * (128 + K + 128), 2.0 * Rs * 2 * 128 * 32, "hbm"),
         ("se_res_mfma_kernel<128, true, true>", 1, "flex_pool + SE + residual + concat conv's upper block 128->128 @N/8",
          4 * Rs * (128 + K + 128 + 128), 2.0 * Rs * (2 * 128 * 32 + 128 * 128), "hbm"),
@@ -376,7 +378,8 @@ def step_kernel_rows(workload):
             ("group_point_fwd4_kernel", 2, "group_point of the sampled rows (C=64, C=128)", 4 * Rs * (2 + 2 * 64 + 2 * 128), 0.0, "hbm"),
             ("linear_x6_kernel<1, true>", 1, "concat conv [interp(c)|x2] + shortcut conv -> 128 @N (fused up-sampling)",
              4 * R * (64 + 64 + 6 + 128) + 4 * Rs * 128, 2.0 * R * 256 * 128, "hbm / matrix pipe"),
-            ("flex_conv_pm_kernel<128, 256", 1, "flex_conv 128->256 @N/8 (global)", ff(B, M, K, 128, 256)[0], ff(B, M, K, 128, 256)[2], "f32 MFMA"),
+            ("flex_conv_tx6_kernel<128, 256", 1, "flex_conv 128->256 @N/8 + cluster logits (global; bf16x6 tile GEMM)", ff(B, M, K, 128, 256)[0], ff(B, M, K, 128, 256)[2], "gather + matrix pipe / L2 (weights)"),
+            ("flex_conv_pm_kernel<128, 256", 1, "flex_conv 128->256 @N/8 (global; exact-f32 tiles: rounds 1-3)", ff(B, M, K, 128, 256)[0], ff(B, M, K, 128, 256)[2], "f32 MFMA"),
             ("linear_x6_kernel<2, false>", 1, "attention conv 256->1024 on the coarse rows (commuted)", 4 * Rs * (256 + 1024), 2.0 * Rs * 256 * 1024, "matrix pipe"),
             ("linear_pm_kernel<1>", 1, "cluster logits 256->64 on the coarse rows", 4 * Rs * (256 + 64), 2.0 * Rs * 256 * 64, "hbm"),
             ("fillBufferAligned", 1, "zero fill of the walk's accumulators", 4.0 * B * M * 64, 0.0, "hbm"),
@@ -505,11 +508,13 @@ def cfg5_kernel_line(dev):
     from dh3d_amd import pm
     B, N, K, Din, Dout = 1, 16384, 12, 128, 128
     xyz, f, nbr, theta, bias = _flex_inputs(dev, B, N, K, Din, Dout)
-    wp = pm.pack_flex_weight(theta, bias)
+    wp, wp3 = pm.pack_flex_weight(theta, bias), pm.pack_flex_weight_x3(theta, bias)
     fb = torch.zeros(Dout, device=dev)
-    ms = event_time_ms(lambda: pm.flex_conv(f, xyz, nbr, wp, Dout, pre_bias=fb, scale=fb + 1, shift=fb, act=pm.ACT_RELU))
+    kw = dict(pre_bias=fb, scale=fb + 1, shift=fb, act=pm.ACT_RELU)
+    ms = event_time_ms(lambda: pm.flex_conv_tile_x6(f, xyz, nbr, wp3, Dout, **kw))  # what the model launches (backbones.py)
     out = three_fractions(ms, B, N, K, Din, Dout)
-    out["kernel"] = "flex_conv_pm_kernel<128,128> B=1 N=16384 K=12 (exact-f32 MFMA)"
+    out["kernel"] = "flex_conv_tx6_kernel<128,128,12> B=1 N=16384 K=12 (32-point tiles, bf16x6 tile GEMM)"
+    out["exact_f32_kernel_launch_ms"] = event_time_ms(lambda: pm.flex_conv(f, xyz, nbr, wp, Dout, **kw))
     return out
 
 

@@ -118,6 +118,8 @@ _SIGNATURES = {
                               ctypes.POINTER(Epilogue), c_fp, c_fp],
     "dh3d_flex_conv_pm_post_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(Epilogue), c_fp,
                                    c_fp, c_int, c_fp, c_fp],
+    "dh3d_flex_conv_pm_tile_x6_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(Epilogue), c_fp,
+                                   c_fp, c_int, c_fp, c_fp],
     "dh3d_pack_flex_weight_x3": [c_fp, c_fp, c_int, c_int, c_fp, c_fp],
     "dh3d_flex_conv_pm_x6_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int,
                                  ctypes.POINTER(Epilogue), c_fp, c_fp],
@@ -216,7 +218,7 @@ _RESTYPES = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
-ABI_VERSION = 2  # include/dh3d_hip.h DH3D_ABI_VERSION: the semantics (not just the signatures) this file was written against
+ABI_VERSION = 3  # include/dh3d_hip.h DH3D_ABI_VERSION: the semantics (not just the signatures) this file was written against
 
 
 def lib():

@@ -18,6 +18,7 @@ Parameter names follow the checkpoint variable names ('/' -> '.', 'mean/EMA' -> 
 dh3d_amd.model.tf_variable_name.
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -307,6 +308,10 @@ def gather_rows(points, idx):
     return out
 
 
+# dev A/B switch (DH3D_FLEX_TX6=0: the exact-f32 MFMA tile kernel for the sampled levels)
+FLEX_TX6 = os.environ.get("DH3D_FLEX_TX6", "1") != "0"
+
+
 def compute_level(xyz, dilate, knn, ordered=None, fps_contract=None):
     """FPS -> gather xyz -> kNN on the sampled set (three_nn back to the full set: finish_level).
 
@@ -421,9 +426,11 @@ class FlexConvDilate(nn.Module):
                 })
                 continue
             x6 = pm.flex_x6_supported(theta.shape[1], d, 8)  # full-resolution shapes: bf16x6 pipeline (K == 8)
+            tx6 = any(pm.flex_tile_x6_supported(theta.shape[1], d, k) for k in (8, 12))  # 32-point tiles, bf16x6 tile GEMM
             prep.append({
                 "wp": pm.pack_flex_weight(theta, bias),
                 "wp3": pm.pack_flex_weight_x3(theta, bias) if x6 else None,
+                "wp3t": pm.pack_flex_weight_x3(theta, bias) if tx6 else None,
                 "fb": fc.feature_bias.detach().reshape(-1).contiguous(),
                 "scale": scale, "shift": shift, "dout": d,
             })
@@ -486,9 +493,19 @@ class FlexConvDilate(nn.Module):
                   and pm.flex_post_supported(x.shape[2], p["dout"], nbr_s.shape[2], post_linear[1])):
                 # post_linear = (packed [dout, 64] weight, 64): the caller's next linear layer on this block's coarse
                 # output rides in the last flex_conv's launch (NetVLAD's cluster logits, model.compute_global)
-                x, self._last_post = pm.flex_conv_post(x, xyz_s, nbr_s, p["wp"], p["dout"], post_linear[0], post_linear[1],
-                                                       pre_bias=p["fb"], scale=p["scale"], shift=p["shift"],
-                                                       act=pm.ACT_RELU)
+                if FLEX_TX6 and p.get("wp3t") is not None:
+                    x, self._last_post = pm.flex_conv_tile_x6(x, xyz_s, nbr_s, p["wp3t"], p["dout"], pre_bias=p["fb"],
+                                                              scale=p["scale"], shift=p["shift"], act=pm.ACT_RELU,
+                                                              wpost_packed=post_linear[0], Dpost=post_linear[1])
+                else:
+                    x, self._last_post = pm.flex_conv_post(x, xyz_s, nbr_s, p["wp"], p["dout"], post_linear[0],
+                                                           post_linear[1], pre_bias=p["fb"], scale=p["scale"],
+                                                           shift=p["shift"], act=pm.ACT_RELU)
+            elif (FLEX_TX6 and p.get("wp3t") is not None and remap is None
+                  and pm.flex_tile_x6_supported(x.shape[2], p["dout"], nbr_s.shape[2])):
+                # the sampled levels (and cfg 5's K = 12 layer): 32-point tiles, tile GEMM on the bf16 pipe (csrc/flex_tx6.hip)
+                x = pm.flex_conv_tile_x6(x, xyz_s, nbr_s, p["wp3t"], p["dout"], pre_bias=p["fb"], scale=p["scale"],
+                                         shift=p["shift"], act=pm.ACT_RELU)
             else:
                 x = pm.flex_conv(x, xyz_s, nbr_s, p["wp"], p["dout"], pre_bias=p["fb"], scale=p["scale"],
                                  shift=p["shift"], act=pm.ACT_RELU, remap=remap)

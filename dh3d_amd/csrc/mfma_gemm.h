@@ -25,41 +25,48 @@ __device__ __forceinline__ void wave_gemm_f32(const float *s_A, int ldA, int row
   const int lane = threadIdx.x & 63;
   const float *aptr = s_A + (size_t)(row0 + (lane & 31)) * ldA + 4 * (lane >> 5);
   const f32x4 *wp = reinterpret_cast<const f32x4 *>(wpacked) + lane;
-  // Main loop: k-blocks in groups of 4 with the NEXT group's B fragments already in flight.  The packed
-  // weight comes from L2 (~700 cycles under load); one group is 16*NT MFMAs = 1024*NT cycles of matrix
-  // pipe, which covers it.  (A 1-deep prefetch left ~450 cycles exposed per k-block: profiles/r01_c.)
-  const int KB4 = KB & ~3;
-  int kb = 0;
-  if (KB4 > 0) {
-    f32x4 nxt[4][NT];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) nxt[u][j] = wp[(size_t)((cb0 + j * cbstride) * KB + u) * 64];
-    for (; kb < KB4; kb += 4) {
-      f32x4 cur[4][NT];
+  // Main loop: k-blocks in groups of 4 with the NEXT group's B fragments already in flight.  The packed weight comes
+  // from L2 (~700 cycles under load); one group is 16*NT MFMAs = 1024*NT cycles of matrix pipe, which covers it.
+  // Two buffers that swap roles inside ONE loop body (no copy between them), requests unconditional (the last one a
+  // harmless repeat) and fenced off from the products with a scheduling barrier.  (Rounds 1-3 had `cur = nxt` copies
+  // and a conditional request: with KB a compile-time constant the loop was unrolled and the scheduler sank every
+  // request next to its use -- one fragment in flight, s_waitcnt vmcnt(1) in front of every fourth MFMA; rolled, the
+  // copies made the products wait for the requests just issued.  Found in the ISA, round 4.)
+  const int NG = KB >> 2;
+  int kb = NG * 4;
+  if (NG > 0) {
+    auto request = [&](f32x4 (&b)[4][NT], int g) __attribute__((always_inline)) {
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) cur[u][j] = nxt[u][j];
-      if (kb + 4 < KB4) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) nxt[u][j] = wp[(size_t)((cb0 + j * cbstride) * KB + kb + 4 + u) * 64];
-      }
+        for (int j = 0; j < NT; ++j) b[u][j] = wp[(size_t)((cb0 + j * cbstride) * KB + g * 4 + u) * 64];
+    };
+    auto multiply = [&](const f32x4 (&b)[4][NT], int g) __attribute__((always_inline)) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const f32x4 a4 = *reinterpret_cast<const f32x4 *>(aptr + (kb + u) * 8);
+        const f32x4 a4 = *reinterpret_cast<const f32x4 *>(aptr + (g * 4 + u) * 8);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0], cur[u][j][0], acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1], cur[u][j][1], acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[2], cur[u][j][2], acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[3], cur[u][j][3], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[0], b[u][j][0], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[1], b[u][j][1], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[2], b[u][j][2], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[3], b[u][j][3], acc[j], 0, 0, 0);
         }
       }
+    };
+    f32x4 b0[4][NT], b1[4][NT];
+    request(b0, 0);
+    int g = 0;
+#pragma unroll 1
+    for (; g + 1 < NG; g += 2) {
+      request(b1, g + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(b0, g);
+      request(b0, g + 2 < NG ? g + 2 : g + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(b1, g + 1);
     }
+    if (g < NG) multiply(b0, g);  // an odd number of groups: the last one is already in b0
   }
   if (kb >= KB) return;
   // tail (KB not a multiple of 4): one k-block at a time

@@ -171,6 +171,30 @@ def flex_conv_post(features, xyz, nbr, wpacked, Dout, wpost_packed, Dpost, pre_b
     return out, out2
 
 
+def flex_tile_x6_supported(Din, Dout, K):
+    """Shapes served by the 32-point-tile bf16x6 flex_conv (csrc/flex_tx6.hip): the sampled levels, cfg 5's K = 12."""
+    return (Din, Dout, K) in ((64, 128, 8), (128, 128, 8), (128, 256, 8), (128, 128, 12))
+
+
+def flex_conv_tile_x6(features, xyz, nbr, wpacked_x3, Dout, pre_bias=None, scale=None, shift=None, act=ACT_NONE,
+                      wpost_packed=None, Dpost=0):
+    """flex_conv on 32-point tiles, tile GEMM on the bf16 matrix pipe at f32 accuracy.  With wpost_packed (a packed
+    [Dout, 64] weight): returns (out, out @ Wpost) from the same launch, like flex_conv_post."""
+    f = L.require_cuda_f32(features, "features", 3)
+    x = L.require_cuda_f32(xyz, "xyz", 3)
+    nb = L.require_cuda_i32(nbr, "nbr", 3)
+    B, N, Din = f.shape
+    if tuple(x.shape) != (B, N, 3) or tuple(nb.shape[:2]) != (B, N):
+        raise ValueError("flex_conv_tile_x6: xyz/nbr do not match features [B,N,*]")
+    out = torch.empty((B, N, Dout), dtype=torch.float32, device=f.device)
+    out2 = torch.empty((B, N, Dpost), dtype=torch.float32, device=f.device) if wpost_packed is not None else None
+    ep = _ep(pre_bias, scale, shift, act)
+    L.check(L.lib().dh3d_flex_conv_pm_tile_x6_fwd(L.ptr(f), L.ptr(x), L.ptr(nb), L.ptr(wpacked_x3), B, N, nb.shape[2], Din,
+                                                  Dout, ep, L.ptr(out), L.ptr(wpost_packed), int(Dpost), L.ptr(out2),
+                                                  L.stream_ptr()), "flex_conv_pm_tile_x6")
+    return out if wpost_packed is None else (out, out2)
+
+
 def flex_post_supported(Din, Dout, K, Dpost):
     return Din == 128 and Dout == 256 and K == 8 and Dpost == 64
 

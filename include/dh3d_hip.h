@@ -47,7 +47,7 @@ int dh3d_version(void);                 /* 100*major + minor */
  * dh3d_interp_bn_bwd_sums / dh3d_interp_bn_bwd_apply are no longer zeroed by the library ("zeroed by the CALLER").
  * A binding compares it with the DH3D_ABI_VERSION it was written against and refuses to run on a mismatch
  * (dh3d_amd/_lib.py does). */
-#define DH3D_ABI_VERSION 2
+#define DH3D_ABI_VERSION 3
 int dh3d_abi_version(void);
 const char *dh3d_arch(void);            /* "gfx950" */
 const char *dh3d_status_string(int st); /* static string */
@@ -271,6 +271,14 @@ int dh3d_flex_conv_pm_fwd(const float *features, const float *xyz, const int32_t
 int dh3d_flex_conv_pm_post_fwd(const float *features, const float *xyz, const int32_t *nbr, const float *wpacked, int B,
                                int N, int K, int Din, int Dout, const dh3d_epilogue *ep, float *out,
                                const float *wpost_packed, int Dpost, float *out2, void *stream);
+/* The same operator on 32-point tiles with the tile GEMM on the bf16 matrix pipe at f32 accuracy (six bf16 products per
+ * f32 product, like dh3d_flex_conv_pm_x6_fwd; csrc/flex_tx6.hip): the sampled levels' layers, whose f32-MFMA GEMM phase
+ * sits at the f32 pipe's floor for one tile per CU.  wpacked_x3 from dh3d_pack_flex_weight_x3.  wpost_packed (may be
+ * NULL; then Dpost / out2 are ignored) as in dh3d_flex_conv_pm_post_fwd (Din == 128, Dout == 256, Dpost == 64).
+ * (Din, Dout, K) in {(64,128,8), (128,128,8), (128,256,8), (128,128,12)}. */
+int dh3d_flex_conv_pm_tile_x6_fwd(const float *features, const float *xyz, const int32_t *nbr, const void *wpacked_x3,
+                                  int B, int N, int K, int Din, int Dout, const dh3d_epilogue *ep, float *out,
+                                  const float *wpost_packed, int Dpost, float *out2, void *stream);
 /* Same with group_point fused in: `features` is the [B, Nsrc, Din] map of the level above and point j of this level
  * (xyz / nbr / out are [B, N, ...]) is its row remap[b*N + j] (remap = the farthest-point-sampling picks).  Equal to
  * dh3d_flex_conv_pm_fwd(group_point(features, remap), ...) bit for bit. */

@@ -87,6 +87,64 @@ def test_flex_conv_x6_vs_oracle(dev, oracle, Din, Dout, B, N):
     assert close(fused, np.maximum((exp + fb) * sc + sh, 0), 1e-4, 1e-4 * np.abs(exp).max())
 
 
+@pytest.mark.parametrize("Din,Dout,B,N", [(64, 128, 2, 512), (128, 128, 2, 300), (128, 256, 2, 512), (64, 128, 3, 45),
+                                          (128, 128, 1, 17), (128, 256, 3, 1000)])
+def test_flex_conv_tile_x6_vs_oracle(dev, oracle, Din, Dout, B, N):
+    """32-point tiles with the tile GEMM on the bf16 pipe (the sampled levels): f32-accurate against the oracle -- ragged
+    last tiles, tiles straddling clouds, clouds smaller than a tile -- with and without the fused epilogue."""
+    from dh3d_amd import pm
+    rng = np.random.default_rng(Din + Dout + N)
+    K = 8
+    xyz, nn = _cloud(rng, B, N, K, oracle)
+    f = rng.standard_normal((B, N, Din)).astype(np.float32)
+    theta = (rng.standard_normal((3, Din, Dout)) / np.sqrt(Din)).astype(np.float32)
+    bias = (rng.standard_normal((Din, Dout)) / np.sqrt(8 * Din)).astype(np.float32)
+    fb = rng.standard_normal(Dout).astype(np.float32)
+    sc = (0.5 + rng.random(Dout)).astype(np.float32)
+    sh = rng.standard_normal(Dout).astype(np.float32)
+    assert pm.flex_tile_x6_supported(Din, Dout, K)
+    wp3 = pm.pack_flex_weight_x3(T(theta, dev), T(bias, dev))
+    raw = pm.flex_conv_tile_x6(T(f, dev), T(xyz, dev), T(nn, dev), wp3, Dout).cpu().numpy()
+    exp = oracle.flex_convolution(f.transpose(0, 2, 1), xyz.transpose(0, 2, 1), nn.transpose(0, 2, 1), theta, bias,
+                                  True).transpose(0, 2, 1)
+    assert relerr(raw, exp) < 2e-6 and close(raw, exp, 1e-4, 1e-4 * np.abs(exp).max())
+    fused = pm.flex_conv_tile_x6(T(f, dev), T(xyz, dev), T(nn, dev), wp3, Dout, pre_bias=T(fb, dev), scale=T(sc, dev),
+                                 shift=T(sh, dev), act=pm.ACT_RELU).cpu().numpy()
+    assert close(fused, np.maximum((exp + fb) * sc + sh, 0), 1e-4, 1e-4 * np.abs(exp).max())
+
+
+def test_flex_conv_tile_x6_post_linear_and_k12(dev):
+    """(a) the global step's 128 -> 256 with NetVLAD's cluster logits riding in the launch == the exact-f32 kernel's two
+    outputs to rounding; (b) cfg 5's 128 -> 128, K = 12 at 16384 points == the exact-f32 kernel; both deterministic."""
+    from dh3d_amd import pm
+    g = torch.Generator().manual_seed(11)
+    B, N, K, Din, Dout = 4, 512, 8, 128, 256
+    xyz = torch.rand(B, N, 3, generator=g).to(dev)
+    nbr, _ = pm.knn_xyz(xyz, K)
+    f = torch.randn(B, N, Din, generator=g).to(dev)
+    theta = (torch.randn(3, Din, Dout, generator=g) / Din ** 0.5).to(dev)
+    bias = (torch.randn(Din, Dout, generator=g) / (8 * Din) ** 0.5).to(dev)
+    wpost = pm.pack_weight((torch.randn(Dout, 64, generator=g) / Dout ** 0.5).to(dev))
+    fb, sc = torch.randn(Dout, generator=g).to(dev), (0.5 + torch.rand(Dout, generator=g)).to(dev)
+    kw = dict(pre_bias=fb, scale=sc, shift=fb, act=pm.ACT_RELU)
+    a, a2 = pm.flex_conv_post(f, xyz, nbr, pm.pack_flex_weight(theta, bias), Dout, wpost, 64, **kw)
+    wp3 = pm.pack_flex_weight_x3(theta, bias)
+    b, b2 = pm.flex_conv_tile_x6(f, xyz, nbr, wp3, Dout, wpost_packed=wpost, Dpost=64, **kw)
+    c, c2 = pm.flex_conv_tile_x6(f, xyz, nbr, wp3, Dout, wpost_packed=wpost, Dpost=64, **kw)
+    assert torch.equal(b, c) and torch.equal(b2, c2)
+    assert (a - b).abs().max().item() / a.abs().max().item() < 2e-6
+    assert (a2 - b2).abs().max().item() / a2.abs().max().item() < 4e-6
+    B, N, K, Din, Dout = 1, 16384, 12, 128, 128
+    xyz = torch.rand(B, N, 3, generator=g).to(dev)
+    nbr, _ = pm.knn_xyz(xyz, K)
+    f = torch.randn(B, N, Din, generator=g).to(dev)
+    theta = (torch.randn(3, Din, Dout, generator=g) / Din ** 0.5).to(dev)
+    bias = (torch.randn(Din, Dout, generator=g) / (K * Din) ** 0.5).to(dev)
+    a = pm.flex_conv(f, xyz, nbr, pm.pack_flex_weight(theta, bias), Dout)
+    b = pm.flex_conv_tile_x6(f, xyz, nbr, pm.pack_flex_weight_x3(theta, bias), Dout)
+    assert (a - b).abs().max().item() / a.abs().max().item() < 2e-6
+
+
 @pytest.mark.parametrize("Din", [32, 64])
 def test_flex_conv_x6_full_size_matches_f32_kernel(dev, Din):
     """BASELINE shape (B=8, N=8192, K=8): eight tiles per workgroup; bf16x6 == exact-f32 MFMA kernel to rounding."""
