@@ -249,7 +249,9 @@ __global__ __launch_bounds__(256) void se_res_pm_kernel(const float *__restrict_
 // CONV: the block's output tile goes through one more 1x1 conv (C -> 64, its own bias / BatchNorm / activation)
 // before it leaves the chip: `before_stage2_conv1d` behind stage 1 (core/backbones.py:117) -- both results are stored,
 // the tile is not read back and a launch on the global path's critical chain disappears.
-template <int C, bool POOL, bool CONV>
+// TMR: rows per workgroup -- 64, or 32 (C == 128) for launches with fewer 64-row tiles than CUs (the sampled levels:
+// 8192 rows = 128 tiles on 256 CUs, every phase of the tile behind a barrier).
+template <int C, bool POOL, bool CONV, int TMR = kTM>
 __global__ __launch_bounds__(256) void se_res_mfma_kernel(const float *__restrict__ x, const float *__restrict__ pool,
                                                          const int32_t *__restrict__ nbr, int N, int K,
                                                          const float *__restrict__ w1p, const float *__restrict__ b1p,
@@ -259,20 +261,22 @@ __global__ __launch_bounds__(256) void se_res_mfma_kernel(const float *__restric
                                                          float *__restrict__ out2) {
   constexpr int LDP = C + 4;   // pooled rows, later the gate tile
   constexpr int LDH = 32 + 4;  // hidden rows
-  __shared__ __attribute__((aligned(16))) float s_p[kTM * LDP];
-  __shared__ __attribute__((aligned(16))) float s_h[kTM * LDH];
+  static_assert(TMR == 64 || (TMR == 32 && C == 128 && POOL), "32-row tiles: four column blocks for four waves; pooled staging only");
+  constexpr int RB = TMR / 32;  // 32-row blocks
+  __shared__ __attribute__((aligned(16))) float s_p[TMR * LDP];
+  __shared__ __attribute__((aligned(16))) float s_h[TMR * LDH];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // POOL gathers neighbour rows of the tile's own cloud: every XCD gets a CONTIGUOUS range of tiles, so a cloud's map is
   // fetched into one L2 instead of all eight (PMC, 8 x 8192 x 64: FETCH_SIZE 57.9 MB raw with the round-robin order)
-  const long long grow0 = (long long)(POOL ? dh3d_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x) * kTM;
+  const long long grow0 = (long long)(POOL ? dh3d_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x) * TMR;
   if (POOL) {
     // the tile's neighbour ids once into LDS (as row offsets; every id is used by C/4 lanes), then all K row reads of a
     // lane in flight together
-    int *s_nb = reinterpret_cast<int *>(s_h);  // [kTM][K <= 9] ints: the hidden tile is not live yet
+    int *s_nb = reinterpret_cast<int *>(s_h);  // [TMR][K <= 9] ints: the hidden tile is not live yet
     const bool k8 = K == 8;
     if (k8) {
-      for (int e = tid; e < kTM * 8; e += 256) {
+      for (int e = tid; e < TMR * 8; e += 256) {
         const long long g = grow0 + (e >> 3);
         s_nb[e] = g < R ? (int)((g / N) * N) + nbr[g * 8 + (e & 7)] : 0;
       }
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(256) void se_res_mfma_kernel(const float *__restric
     if (k8) {
       // two points per lane and pass: their 16 row reads are requested together and none sits under a branch (rows past
       // the end read row 0 through s_nb and are zeroed afterwards) -- the loop was kTM * CVP / 256 dependent round trips
-      constexpr int IT = kTM * CVP / 256;
+      constexpr int IT = TMR * CVP / 256;
       static_assert(IT % 2 == 0, "pairs of passes");
 #pragma unroll
       for (int it = 0; it < IT; it += 2) {
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(256) void se_res_mfma_kernel(const float *__restric
         }
       }
     } else {
-      for (int e = tid; e < kTM * CVP; e += 256) {
+      for (int e = tid; e < TMR * CVP; e += 256) {
         const int p = e / CVP, c4 = (e - p * CVP) * 4;
         const long long g = grow0 + p;
         float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(256) void se_res_mfma_kernel(const float *__restric
     stage_rows(pool, C, pool, 0, grow0, R, s_p, LDP);
   }
   __syncthreads();
-  if (wave < 2) {  // squeeze: relu(pool @ W1 + b1)
+  if (wave < RB) {  // squeeze: relu(pool @ W1 + b1)
     f32x16 acc[1];
     zero_acc<1>(acc);
     wave_gemm_f32<1>(s_p, LDP, wave * 32, w1p, C / 8, 0, 1, acc);
@@ -341,24 +345,26 @@ __global__ __launch_bounds__(256) void se_res_mfma_kernel(const float *__restric
   }
   __syncthreads();
   {  // excite: sigmoid(h @ W2 + b2) -> gate tile over the (dead) pooled rows
-    constexpr int NT = C / 64;  // column blocks per wave: (row block = wave & 1, column blocks (wave >> 1) + 2 j)
+    // column blocks per wave: (row block = wave & 1, column blocks (wave >> 1) + 2 j), or with one row block: wave + 4 j
+    constexpr int NT = C / 32 * RB / 4, CBS = 4 / RB;
+    const int rb0 = RB == 2 ? (wave & 1) * 32 : 0, cbf = RB == 2 ? wave >> 1 : wave;
     f32x16 acc[NT];
     zero_acc<NT>(acc);
-    wave_gemm_f32<NT>(s_h, LDH, (wave & 1) * 32, w2p, 32 / 8, wave >> 1, 2, acc);
+    wave_gemm_f32<NT>(s_h, LDH, rb0, w2p, 32 / 8, cbf, CBS, acc);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int col = ((wave >> 1) + 2 * j) * 32 + (lane & 31);
+      const int col = (cbf + CBS * j) * 32 + (lane & 31);
       const float bb = b2[col];
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        s_p[(size_t)((wave & 1) * 32 + mfma_row(r, lane)) * LDP + col] = 1.f / (1.f + expf(-(acc[j][r] + bb)));
+        s_p[(size_t)(rb0 + mfma_row(r, lane)) * LDP + col] = 1.f / (1.f + expf(-(acc[j][r] + bb)));
     }
   }
   __syncthreads();
   constexpr int CV = C / 4;
   {
     // the tile's own rows: every pass's read requested before the first is used (rows past the end re-read the last row)
-    constexpr int ITG = kTM * CV / 256;
+    constexpr int ITG = TMR * CV / 256;
     float4 xr[ITG];
 #pragma unroll
     for (int it = 0; it < ITG; ++it) {
@@ -385,19 +391,19 @@ __global__ __launch_bounds__(256) void se_res_mfma_kernel(const float *__restric
     }
   }
   if (CONV) {  // out2 = act(bn(tile @ Wconv + b)), C columns: C / 64 accumulators of 32 x 32 per wave
-    constexpr int NTC = C / 64;
+    constexpr int NTC = C / 32 * RB / 4, CBC = 4 / RB;
     __syncthreads();
-    const int row0 = (wave & 1) * 32, cb0 = wave >> 1;
+    const int row0 = RB == 2 ? (wave & 1) * 32 : 0, cb0 = RB == 2 ? wave >> 1 : wave;
     f32x16 acc[NTC];
     zero_acc<NTC>(acc);
     EpilogueRegs er[NTC];
 #pragma unroll
-    for (int j = 0; j < NTC; ++j) er[j] = epilogue_prefetch(cep, (cb0 + 2 * j) * 32 + (lane & 31));
-    wave_gemm_f32<NTC>(s_p, LDP, row0, wconv, C / 8, cb0, 2, acc);
+    for (int j = 0; j < NTC; ++j) er[j] = epilogue_prefetch(cep, (cb0 + CBC * j) * 32 + (lane & 31));
+    wave_gemm_f32<NTC>(s_p, LDP, row0, wconv, C / 8, cb0, CBC, acc);
     __syncthreads();
-    wave_tiles_to_lds<NTC>(acc, er, cep.act, s_p, LDP, row0, cb0, 2);
+    wave_tiles_to_lds<NTC>(acc, er, cep.act, s_p, LDP, row0, cb0, CBC);
     __syncthreads();
-    block_store_rows(s_p, LDP, kTM, grow0, R, C, nullptr, out2);
+    block_store_rows(s_p, LDP, TMR, grow0, R, C, nullptr, out2);
   }
 }
 
@@ -639,6 +645,9 @@ DH3D_API int dh3d_se_res_pool_pm_packed_fwd(const float *x, const int32_t *nbr, 
   if (C == 64)
     hipLaunchKernelGGL((se_res_mfma_kernel<64, true, false>), grid, block, 0, s, x, x, nbr, N, K, w1packed, b1pad, w2packed, b2,
                        R, out, nullptr, EpilogueArgs{}, nullptr);
+  else if (C == 128 && R <= kTM * 256)  // fewer 64-row tiles than CUs (the sampled levels): 32-row tiles
+    hipLaunchKernelGGL((se_res_mfma_kernel<128, true, false, 32>), dim3(dh3d_cdiv(R, 32)), block, 0, s, x, x, nbr, N, K,
+                       w1packed, b1pad, w2packed, b2, R, out, nullptr, EpilogueArgs{}, nullptr);
   else if (C == 128)
     hipLaunchKernelGGL((se_res_mfma_kernel<128, true, false>), grid, block, 0, s, x, x, nbr, N, K, w1packed, b1pad, w2packed, b2,
                        R, out, nullptr, EpilogueArgs{}, nullptr);
@@ -659,6 +668,9 @@ DH3D_API int dh3d_se_res_pool_conv_pm_fwd(const float *x, const int32_t *nbr, in
   if (C == 64)
     hipLaunchKernelGGL((se_res_mfma_kernel<64, true, true>), dim3(dh3d_cdiv(R, kTM)), dim3(256), 0, (hipStream_t)stream, x,
                        x, nbr, N, K, w1packed, b1pad, w2packed, b2, R, out, wconv_packed, dh3d_ep(ep), out2);
+  else if (R <= kTM * 256)  // fewer 64-row tiles than CUs (the sampled levels): 32-row tiles
+    hipLaunchKernelGGL((se_res_mfma_kernel<128, true, true, 32>), dim3(dh3d_cdiv(R, 32)), dim3(256), 0, (hipStream_t)stream,
+                       x, x, nbr, N, K, w1packed, b1pad, w2packed, b2, R, out, wconv_packed, dh3d_ep(ep), out2);
   else
     hipLaunchKernelGGL((se_res_mfma_kernel<128, true, true>), dim3(dh3d_cdiv(R, kTM)), dim3(256), 0, (hipStream_t)stream, x,
                        x, nbr, N, K, w1packed, b1pad, w2packed, b2, R, out, wconv_packed, dh3d_ep(ep), out2);

@@ -518,7 +518,8 @@ __global__ __launch_bounds__(256) void linear_k64_x6_kernel(const float *__restr
 #pragma unroll
   for (int ks = 0; ks < KB; ++ks) {
     if (ks + 1 < KB) load_b(ks + 1);
-    asm volatile("" ::: "memory");  // (keeps the compiler from issuing every K-step's fragments up front)
+    asm volatile("" ::: "memory");  // (keeps the compiler from issuing every K-step's fragments up front ...
+    __builtin_amdgcn_sched_barrier(0);  //  ... and from sinking them between this K-step's products: then the next step waits on the last of them)
     uint2 c1[2], c2[2], c3[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) split3x4(av[ks][j], c1[j], c2[j], c3[j]);

@@ -331,7 +331,7 @@ def test_se_res_pm(dev, C):
     assert close(out2, np.maximum(x + x * g, 0), 1e-4, 1e-5)
 
 
-@pytest.mark.parametrize("C,B,N", [(64, 2, 1000), (128, 3, 333), (64, 8, 8192)])
+@pytest.mark.parametrize("C,B,N", [(64, 2, 1000), (128, 3, 333), (64, 8, 8192), (128, 8, 1024), (128, 5, 4100)])
 def test_se_res_on_max_pool_fused_equals_two_kernels(dev, C, B, N):
     """SE-residual block on flex_pool(x) in one launch (pooled rows formed while staging) == flex_pool_pm then
     se_res_packed, bit for bit (a maximum is order-independent, the rest is the same code)."""
@@ -348,21 +348,22 @@ def test_se_res_on_max_pool_fused_equals_two_kernels(dev, C, B, N):
     assert torch.equal(one, two)
 
 
-def test_se_res_pool_conv_fused_equals_separate_kernels(dev):
-    """... and with the following 64 -> 64 conv (+ BatchNorm + ReLU) in the same launch: the block's output bit for bit,
-    the conv's output equal to linear() of it (same MFMA code on the same tile)."""
+@pytest.mark.parametrize("B,N,C", [(3, 2000, 64), (3, 701, 128), (8, 1024, 128), (5, 4100, 128)])
+def test_se_res_pool_conv_fused_equals_separate_kernels(dev, B, N, C):
+    """... and with the following C -> C conv (+ BatchNorm + ReLU) in the same launch: the block's output bit for bit,
+    the conv's output equal to linear() of it (same MFMA code on the same tile) -- 64-row tiles and, for C = 128 on fewer
+    rows than 64-row tiles would fill the chip with, 32-row tiles."""
     from dh3d_amd import pm
     g = torch.Generator().manual_seed(5)
-    B, N, C = 3, 2000, 64
     x = torch.randn(B, N, C, generator=g).to(dev)
     nbr, _ = pm.knn_xyz(torch.rand(B, N, 3, generator=g).to(dev), 8)
     W1 = (torch.randn(C, C // 4, generator=g) / 8).to(dev); b1 = torch.randn(C // 4, generator=g).to(dev)
     W2 = (torch.randn(C // 4, C, generator=g) / 4).to(dev); b2 = torch.randn(C, generator=g).to(dev)
-    Wc = (torch.randn(C, 64, generator=g) / 8).to(dev); bc = torch.randn(64, generator=g).to(dev)
-    sc = (0.5 + torch.rand(64, generator=g)).to(dev); sh = torch.randn(64, generator=g).to(dev)
+    Wc = (torch.randn(C, C, generator=g) / 8).to(dev); bc = torch.randn(C, generator=g).to(dev)
+    sc = (0.5 + torch.rand(C, generator=g)).to(dev); sh = torch.randn(C, generator=g).to(dev)
     packed = pm.se_res_pack(W1, b1, W2)
     y_ref = pm.se_res_pool_packed(x, nbr, *packed, b2)
-    z_ref = pm.linear(y_ref, pm.pack_weight(Wc), 64, pre_bias=bc, scale=sc, shift=sh, act=pm.ACT_RELU)
+    z_ref = pm.linear(y_ref, pm.pack_weight(Wc), C, pre_bias=bc, scale=sc, shift=sh, act=pm.ACT_RELU)
     y, z = pm.se_res_pool_conv(x, nbr, *packed, b2, pm.pack_weight(Wc), bc, sc, sh)
     assert torch.equal(y, y_ref)
     assert torch.equal(z, z_ref)
