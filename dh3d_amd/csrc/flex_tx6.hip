@@ -37,7 +37,10 @@ struct TileCfg {
 
 // POST: the finished tile goes through one more linear layer [DOUT -> 64] on the f32 pipe (wpost = dh3d_pack_weight of
 // [DOUT, 64]) before it leaves the chip, both results stored (see flex_conv_pm_kernel).
-template <int DIN, int DOUT, int KT, bool POST>
+// HALF: the planes hold one half of K at a time -- [S0|Sx], then [Sy|Sz], which wait in the registers of the threads that
+// reduced them: 51 KB of LDS instead of 100 at Din = 128, so that TWO workgroups share a CU and one's gather runs under the
+// other's products.  For launches with more tiles than CUs (cfg 5's 512 tiles, the global step's sampled level).
+template <int DIN, int DOUT, int KT, bool POST, bool HALF>
 __global__ __launch_bounds__(256) void flex_conv_tx6_kernel(const float *__restrict__ feat, const float *__restrict__ xyz,
                                                            const int32_t *__restrict__ nbr,
                                                            const uint4 *__restrict__ wp3, long long R, int N,
@@ -45,30 +48,41 @@ __global__ __launch_bounds__(256) void flex_conv_tx6_kernel(const float *__restr
                                                            const float *__restrict__ wpost, float *__restrict__ out2) {
   using C = TileCfg<DIN, DOUT>;
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-  unsigned short *s_P = reinterpret_cast<unsigned short *>(s_raw);  // [3][TM][LDB] bf16 planes of S = [S0|Sx|Sy|Sz]
+  unsigned short *s_P = reinterpret_cast<unsigned short *>(s_raw);  // [3][TM][LDP] bf16 planes of S = [S0|Sx|Sy|Sz] (or a half)
   float *s_out = reinterpret_cast<float *>(s_raw);                  // [TM][LDO] after the GEMM
   constexpr int LDO = DOUT + (POST ? 64 : 0) + 4;
-  static_assert((size_t)C::TM * LDO * 4 <= (size_t)3 * C::TM * C::LDB * 2, "the output tile reuses the planes");
+  constexpr int LDP = HALF ? C::KD / 2 + 8 : C::LDB;  // bf16 per plane row
+  constexpr int PLANE = C::TM * LDP;
+  static_assert((LDP * 2 / 16) % 2 == 1, "plane rows: an odd number of 16-byte units");
+  static_assert((size_t)C::TM * LDO * 4 <= (size_t)3 * PLANE * 2, "the output tile reuses the planes");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long grow0 = (long long)dh3d_xcd_remap(blockIdx.x, gridDim.x) * C::TM;
 
   // ---- phase A: gather-reduce S for TM points (two dependent round trips for the whole tile), split, planes
   TPROBE(0);
   const int r4 = (tid % C::LPR) * 4;
+  float4 keep[HALF ? C::ROUNDS : 1][2];  // HALF: [Sy|Sz] of this thread's rows until the planes are free again
+  auto to_planes = [&](const float4 v, unsigned short *dst) __attribute__((always_inline)) {
+    uint2 c1, c2, c3;
+    split3x4(v, c1, c2, c3);
+    *reinterpret_cast<uint2 *>(dst) = c1;
+    *reinterpret_cast<uint2 *>(dst + PLANE) = c2;
+    *reinterpret_cast<uint2 *>(dst + 2 * PLANE) = c3;
+  };
   {
     constexpr int HF = KT <= 8 ? 2 : 1;  // rounds whose neighbour rows are in flight together
     int nid[C::ROUNDS][KT];
     float pxyz[C::ROUNDS][3];
     long long cloud0[C::ROUNDS];
     bool ok[C::ROUNDS];
-    const unsigned b0 = (unsigned)(grow0 / N);  // (uniform: one division per workgroup, then at most a step per point)
+    const unsigned bq0 = (unsigned)(grow0 / N);  // (uniform: one division per workgroup, then at most a step per point)
 #pragma unroll
     for (int rd = 0; rd < C::ROUNDS; ++rd) {
       const long long n = grow0 + rd * C::PPR + tid / C::LPR;
       ok[rd] = n < R;
       const long long nn = ok[rd] ? n : grow0;
-      unsigned b = b0;
-      long long off = nn - (long long)b0 * N;
+      unsigned b = bq0;
+      long long off = nn - (long long)bq0 * N;
       while (off >= N) { off -= N; ++b; }
       cloud0[rd] = (long long)b * N;
       const int4 *ip = reinterpret_cast<const int4 *>(nbr + nn * KT);
@@ -105,15 +119,12 @@ __global__ __launch_bounds__(256) void flex_conv_tx6_kernel(const float *__restr
           s[2].x = fmaf(dy, f.x, s[2].x); s[2].y = fmaf(dy, f.y, s[2].y); s[2].z = fmaf(dy, f.z, s[2].z); s[2].w = fmaf(dy, f.w, s[2].w);
           s[3].x = fmaf(dz, f.x, s[3].x); s[3].y = fmaf(dz, f.y, s[3].y); s[3].z = fmaf(dz, f.z, s[3].z); s[3].w = fmaf(dz, f.w, s[3].w);
         }
-        unsigned short *row = s_P + (size_t)(rd * C::PPR + tid / C::LPR) * C::LDB + r4;
+        unsigned short *row = s_P + (size_t)(rd * C::PPR + tid / C::LPR) * LDP + r4;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           if (!ok[rd]) s[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-          uint2 c1, c2, c3;
-          split3x4(s[c], c1, c2, c3);
-          *reinterpret_cast<uint2 *>(row + c * DIN) = c1;
-          *reinterpret_cast<uint2 *>(row + c * DIN + C::TM * C::LDB) = c2;
-          *reinterpret_cast<uint2 *>(row + c * DIN + 2 * C::TM * C::LDB) = c3;
+          if (HALF && c >= 2) keep[HALF ? rd : 0][c - 2] = s[c];
+          else to_planes(s[c], row + c * DIN);
         }
       }
     }
@@ -129,9 +140,9 @@ __global__ __launch_bounds__(256) void flex_conv_tx6_kernel(const float *__restr
 #pragma unroll
   for (int j = 0; j < C::NT; ++j) er[j] = epilogue_prefetch(ep, (wave + j * 4) * 32 + (lane & 31));
   {
-    const unsigned short *abase = s_P + (size_t)(lane & 31) * C::LDB + 8 * (lane >> 5);
+    const unsigned short *abase = s_P + (size_t)(lane & 31) * LDP + 8 * (lane >> 5);
     const uint4 *wl = wp3 + lane;
-    constexpr int G = 4;  // K-steps per group
+    constexpr int G = C::NT == 1 ? 4 : 2;  // K-steps per group: 24 products = 768 cycles of matrix pipe either way
     static_assert(C::KS % G == 0, "whole groups");
     static_assert((C::KS / G) % 2 == 0, "an even number of groups: two buffers swap roles inside one loop body");
     auto request = [&](uint4 (&b)[G][C::NT][3], int ks) __attribute__((always_inline)) {
@@ -144,13 +155,13 @@ __global__ __launch_bounds__(256) void flex_conv_tx6_kernel(const float *__restr
     };
     // the group's A fragments are all requested before its first product (one LDS latency per group, not three reads
     // waited for in front of every K-step: with ONE wave per SIMD nothing else hides them)
-    auto multiply = [&](const uint4 (&b)[G][C::NT][3], int ks) __attribute__((always_inline)) {
+    auto multiply = [&](const uint4 (&b)[G][C::NT][3], int ks) __attribute__((always_inline)) {  // ks: within the planes
       bf16x8 a[G][3];
 #pragma unroll
       for (int u = 0; u < G; ++u)
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-          a[u][p] = *reinterpret_cast<const bf16x8 *>(abase + (size_t)p * C::TM * C::LDB + (ks + u) * 16);
+          a[u][p] = *reinterpret_cast<const bf16x8 *>(abase + (size_t)p * PLANE + (ks + u) * 16);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < G; ++u) {
@@ -165,15 +176,36 @@ __global__ __launch_bounds__(256) void flex_conv_tx6_kernel(const float *__restr
     // two buffers that swap roles inside one loop body (no copies), requests unconditional (the last one a harmless
     // repeat) and fenced off from the products: see wave_gemm_f32 (mfma_gemm.h) for what the compiler does otherwise
     uint4 b0[G][C::NT][3], b1[G][C::NT][3];
+    constexpr int KSP = HALF ? C::KS / 2 : C::KS;  // K-steps per fill of the planes
+    static_assert((KSP / G) % 2 == 0, "an even number of groups per fill");
     request(b0, 0);
 #pragma unroll 1
-    for (int ks = 0; ks < C::KS; ks += 2 * G) {
+    for (int ks = 0; ks < KSP; ks += 2 * G) {
       request(b1, ks + G);
       __builtin_amdgcn_sched_barrier(0);
       multiply(b0, ks);
-      request(b0, ks + 2 * G < C::KS ? ks + 2 * G : ks + G);
+      request(b0, ks + 2 * G < C::KS ? ks + 2 * G : ks + G);  // (HALF: the last one is the second fill's first group)
       __builtin_amdgcn_sched_barrier(0);
       multiply(b1, ks + G);
+    }
+    if (HALF) {
+      __syncthreads();  // every wave is done with [S0|Sx]
+#pragma unroll
+      for (int rd = 0; rd < C::ROUNDS; ++rd) {
+        unsigned short *row = s_P + (size_t)(rd * C::PPR + tid / C::LPR) * LDP + r4;
+        to_planes(keep[HALF ? rd : 0][0], row);
+        to_planes(keep[HALF ? rd : 0][1], row + DIN);
+      }
+      __syncthreads();
+#pragma unroll 1
+      for (int ks = KSP; ks < C::KS; ks += 2 * G) {
+        request(b1, ks + G);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(b0, ks - KSP);
+        request(b0, ks + 2 * G < C::KS ? ks + 2 * G : ks + G);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(b1, ks + G - KSP);
+      }
     }
   }
 #ifdef DH3D_FLEX_PROBE
@@ -199,16 +231,28 @@ __global__ __launch_bounds__(256) void flex_conv_tx6_kernel(const float *__restr
   TPROBE(4);
 }
 
-template <int DIN, int DOUT, int KT, bool POST>
-int tx6_launch(const float *feat, const float *xyz, const int32_t *nbr, const void *wp3, int B, int N,
+template <int DIN, int DOUT, int KT, bool POST, bool HALF>
+int tx6_launch_h(const float *feat, const float *xyz, const int32_t *nbr, const void *wp3, int B, int N,
                const EpilogueArgs &ep, float *out, const float *wpost, float *out2, hipStream_t s) {
   using C = TileCfg<DIN, DOUT>;
   const long long R = (long long)B * N;
-  auto kern = flex_conv_tx6_kernel<DIN, DOUT, KT, POST>;
+  auto kern = flex_conv_tx6_kernel<DIN, DOUT, KT, POST, HALF>;
   DH3D_ALLOW_BIG_LDS(kern);
-  hipLaunchKernelGGL(kern, dim3(dh3d_cdiv(R, C::TM)), dim3(256), (size_t)3 * C::TM * C::LDB * 2, s, feat, xyz, nbr,
-                     static_cast<const uint4 *>(wp3), R, N, ep, out, wpost, out2);
+  hipLaunchKernelGGL(kern, dim3(dh3d_cdiv(R, C::TM)), dim3(256), (size_t)3 * C::TM * (HALF ? C::KD / 2 + 8 : C::LDB) * 2,
+                     s, feat, xyz, nbr, static_cast<const uint4 *>(wp3), R, N, ep, out, wpost, out2);
   return dh3d_launch_status();
+}
+
+template <int DIN, int DOUT, int KT, bool POST>
+int tx6_launch(const float *feat, const float *xyz, const int32_t *nbr, const void *wp3, int B, int N,
+               const EpilogueArgs &ep, float *out, const float *wpost, float *out2, hipStream_t s) {
+  // more tiles than CUs: half-K planes, two workgroups per CU (Din = 128: 51 KB each instead of 100)
+#ifndef DH3D_TX6_HALF_TILES
+#define DH3D_TX6_HALF_TILES 256
+#endif
+  if (DIN == 128 && (long long)B * N > 32ll * DH3D_TX6_HALF_TILES)
+    return tx6_launch_h<DIN, DOUT, KT, POST, true>(feat, xyz, nbr, wp3, B, N, ep, out, wpost, out2, s);
+  return tx6_launch_h<DIN, DOUT, KT, POST, false>(feat, xyz, nbr, wp3, B, N, ep, out, wpost, out2, s);
 }
 
 }  // namespace

@@ -118,7 +118,39 @@ def test_flex_conv_tile_x6_post_linear_and_k12(dev):
     outputs to rounding; (b) cfg 5's 128 -> 128, K = 12 at 16384 points == the exact-f32 kernel; both deterministic."""
     from dh3d_amd import pm
     g = torch.Generator().manual_seed(11)
-    B, N, K, Din, Dout = 4, 512, 8, 128, 256
+    for B, N in ((4, 512), (20, 512)):  # 64 tiles; 320 tiles (more than CUs: the half-K planes, two workgroups per CU)
+        _tile_x6_post_case(dev, g, B, N)
+    B, N, K, Din, Dout = 10, 1024, 8, 128, 128  # 320 tiles, half-K planes
+    xyz = torch.rand(B, N, 3, generator=g).to(dev)
+    nbr, _ = pm.knn_xyz(xyz, K)
+    f = torch.randn(B, N, Din, generator=g).to(dev)
+    theta = (torch.randn(3, Din, Dout, generator=g) / Din ** 0.5).to(dev)
+    bias = (torch.randn(Din, Dout, generator=g) / (K * Din) ** 0.5).to(dev)
+    a = pm.flex_conv(f, xyz, nbr, pm.pack_flex_weight(theta, bias), Dout)
+    b = pm.flex_conv_tile_x6(f, xyz, nbr, pm.pack_flex_weight_x3(theta, bias), Dout)
+    assert (a - b).abs().max().item() / a.abs().max().item() < 2e-6
+    # cfg 5 (512 tiles, half-K planes): both kernels against the float64 generic kernel -- two f32-accurate results may
+    # differ from each other by the sum of their errors
+    from dh3d_amd import ops
+    B, N, K, Din, Dout = 1, 16384, 12, 128, 128
+    xyz = torch.rand(B, N, 3, generator=g).to(dev)
+    nbr, _ = pm.knn_xyz(xyz, K)
+    f = torch.randn(B, N, Din, generator=g).to(dev)
+    theta = (torch.randn(3, Din, Dout, generator=g) / Din ** 0.5).to(dev)
+    bias = (torch.randn(Din, Dout, generator=g) / (K * Din) ** 0.5).to(dev)
+    a = pm.flex_conv(f, xyz, nbr, pm.pack_flex_weight(theta, bias), Dout)
+    b = pm.flex_conv_tile_x6(f, xyz, nbr, pm.pack_flex_weight_x3(theta, bias), Dout)
+    ref = ops.flex_convolution(f.double().transpose(1, 2).contiguous(), xyz.double().transpose(1, 2).contiguous(),
+                               nbr.transpose(1, 2).contiguous(), theta.double(), bias.double()).transpose(1, 2)
+    scale = ref.abs().max().item()
+    assert (b.double() - ref).abs().max().item() / scale < 2e-6
+    assert (a.double() - ref).abs().max().item() / scale < 2e-6
+    assert torch.equal(b, pm.flex_conv_tile_x6(f, xyz, nbr, pm.pack_flex_weight_x3(theta, bias), Dout))
+
+
+def _tile_x6_post_case(dev, g, B, N):
+    from dh3d_amd import pm
+    K, Din, Dout = 8, 128, 256
     xyz = torch.rand(B, N, 3, generator=g).to(dev)
     nbr, _ = pm.knn_xyz(xyz, K)
     f = torch.randn(B, N, Din, generator=g).to(dev)
@@ -134,15 +166,6 @@ def test_flex_conv_tile_x6_post_linear_and_k12(dev):
     assert torch.equal(b, c) and torch.equal(b2, c2)
     assert (a - b).abs().max().item() / a.abs().max().item() < 2e-6
     assert (a2 - b2).abs().max().item() / a2.abs().max().item() < 4e-6
-    B, N, K, Din, Dout = 1, 16384, 12, 128, 128
-    xyz = torch.rand(B, N, 3, generator=g).to(dev)
-    nbr, _ = pm.knn_xyz(xyz, K)
-    f = torch.randn(B, N, Din, generator=g).to(dev)
-    theta = (torch.randn(3, Din, Dout, generator=g) / Din ** 0.5).to(dev)
-    bias = (torch.randn(Din, Dout, generator=g) / (K * Din) ** 0.5).to(dev)
-    a = pm.flex_conv(f, xyz, nbr, pm.pack_flex_weight(theta, bias), Dout)
-    b = pm.flex_conv_tile_x6(f, xyz, nbr, pm.pack_flex_weight_x3(theta, bias), Dout)
-    assert (a - b).abs().max().item() / a.abs().max().item() < 2e-6
 
 
 @pytest.mark.parametrize("Din", [32, 64])
