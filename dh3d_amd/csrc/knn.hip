@@ -22,6 +22,8 @@
 #include <float.h>
 #include <limits.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "wave_ops.h"
 
@@ -1098,6 +1100,13 @@ __device__ __forceinline__ void knn_merge_sublanes(KnnState<8> &st) {
   }
 }
 
+#ifdef DH3D_GRID_PROBE  // dev instrumentation (tools/knn_grid_probe.py): cycle stamps of the first wave of 64 workgroups
+__device__ long long g_gprobe[64 * 8];
+#define GPROBE(i) do { if (threadIdx.x == 0 && blockIdx.x < 64 && blockIdx.y == 0) g_gprobe[blockIdx.x * 8 + (i)] = clock64(); } while (0)
+#else
+#define GPROBE(i) do { } while (0)
+#endif
+
 // L = lanes per query (2, 4 or 8): fewer lanes = longer private candidate streams, but an insertion round serves 64 / L
 // queries and the merge has log2(L) steps.
 template <int L>
@@ -1239,38 +1248,89 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict_
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
   };
-#pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-    if (pass) keep_one_copy();
-    if (sub == 0) s_cnt[qs] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
-    for (int col = sub; col < 25; col += L) {
-      const int dz = col / 5, dy = col - dz * 5;                     // offsets + 2
-      const int ay = cq[1] + dy - 2, az = cq[2] + dz - 2;
-      if ((unsigned)ay > (unsigned)gmax[1] || (unsigned)az > (unsigned)gmax[2]) continue;
-      const bool inner = abs(dy - 2) <= 1 && abs(dz - 2) <= 1;       // the column crosses shells 0-1 at dx in -1..1
-      if (pass == 0 && !inner) continue;
-      const float d2yz = axis_d2(1, dy - 2) + axis_d2(2, dz - 2);
-      const unsigned bityz = cell_code(0, ay, az);
-      int beg[5], end[5];  // the five cells' ranges, all in flight together (no load under the per-cell branches)
+  // One column (dy, dz: offsets + 2) of the 5 x 5 x 5 block, the cells at the x offsets of TMASK: ranges of all of them in
+  // flight together (no load under the per-cell branches), then the box tests and the pooling.
+  auto column = [&](auto tmask, int dy, int dz) __attribute__((always_inline)) {
+    constexpr int TMASK = decltype(tmask)::value;
+    const int ay = cq[1] + dy - 2, az = cq[2] + dz - 2;
+    if ((unsigned)ay > (unsigned)gmax[1] || (unsigned)az > (unsigned)gmax[2]) return;
+    const float d2yz = axis_d2(1, dy - 2) + axis_d2(2, dz - 2);
+    const unsigned bityz = cell_code(0, ay, az);
+    int beg[5], end[5];
 #pragma unroll
-      for (int t = 0; t < 5; ++t) {
+    for (int t = 0; t < 5; ++t)
+      if (TMASK >> t & 1) {
         beg[t] = ct[bityz | bitx[t]];
         end[t] = ct[(bityz | bitx[t]) + span];
       }
+    if constexpr (TMASK != 0b01110) {  // shell 2: most cells fail the box test -- the few that pass one by one
 #pragma unroll
-      for (int t = 0; t < 5; ++t) {
-        const bool shell01 = inner && t >= 1 && t <= 3;
-        if ((pass == 0) != shell01) continue;
-        if (!okx[t] || (d2yz + d2x[t]) * 0.99999f > st.bound) continue;
-        enqueue(beg[t], end[t]);
-      }
+      for (int t = 0; t < 5; ++t)
+        if (TMASK >> t & 1) {
+          if (!okx[t] || (d2yz + d2x[t]) * 0.99999f > st.bound) continue;
+          enqueue(beg[t], end[t]);
+        }
+    } else {
+      // shells 0-1: (nearly) every cell is taken -- they reserve their places in the query's list together (one LDS atomic,
+      // not one per cell); cells hold 0..~8 records: the first four places are written without a loop
+      int len[5], tot = 0;
+#pragma unroll
+      for (int t = 0; t < 5; ++t)
+        if (TMASK >> t & 1) {
+          len[t] = okx[t] && !((d2yz + d2x[t]) * 0.99999f > st.bound) ? end[t] - beg[t] : 0;
+          tot += len[t];
+        }
+      if (tot == 0) return;
+      int off = atomicAdd(&s_cnt[qs], tot);
+#pragma unroll
+      for (int t = 0; t < 5; ++t)
+        if (TMASK >> t & 1) {
+          const int fit = min(len[t], kGridCap - off);  // (a full list sends the rest of the cell down the direct path)
+          unsigned short *dst = &s_list[qs][off];
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (k < fit) dst[k] = (unsigned short)(beg[t] + k);
+          for (int k = 4; k < fit; ++k) dst[k] = (unsigned short)(beg[t] + k);
+          for (int k = max(fit, 0); k < len[t]; ++k) direct(beg[t] + k);
+          off += len[t];
+        }
     }
-    drain();
-    knn_merge_sublanes<L>(st);
+  };
+  auto begin_pass = [&]() __attribute__((always_inline)) {
+    if (sub == 0) s_cnt[qs] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  // The columns are dealt DENSELY: walking all 25 with the other pass's columns skipped cost the wave the full body in
+  // nearly every iteration (some lane always had a live column) -- clock stamps: the first pass's 27 cells took as long
+  // as the second's 98 (tools/knn_grid_probe.py), and the two together two thirds of the kernel.
+  GPROBE(0);
+  // pass 0: shells 0-1 = the nine inner columns at dx in -1..1
+  begin_pass();
+#pragma unroll 1
+  for (int ci = sub; ci < 9; ci += L) column(std::integral_constant<int, 0b01110>{}, 1 + ci % 3, 1 + ci / 3);
+  GPROBE(1);
+  drain();
+  GPROBE(2);
+  knn_merge_sublanes<L>(st);
+  GPROBE(3);
+  // pass 1: shell 2 against the merged bound = the sixteen outer columns whole, then the inner ones at dx = -2, 2
+  keep_one_copy();
+  begin_pass();
+#pragma unroll 1
+  for (int oi = sub; oi < 16; oi += L) {
+    const int r = oi;  // the ring of outer columns -- 0..4: dz = 0, dy = r; 5..9: dz = 4, dy = r - 5; 10..12: dy = 0, dz = r - 9; 13..15: dy = 4, dz = r - 12
+    const int cy = r < 5 ? r : r < 10 ? r - 5 : r < 13 ? 0 : 4;
+    const int cz = r < 5 ? 0 : r < 10 ? 4 : r < 13 ? r - 9 : r - 12;
+    column(std::integral_constant<int, 0b11111>{}, cy, cz);
   }
+#pragma unroll 1
+  for (int ci = sub; ci < 9; ci += L) column(std::integral_constant<int, 0b10001>{}, 1 + ci % 3, 1 + ci / 3);
+  GPROBE(4);
+  drain();
+  GPROBE(5);
+  knn_merge_sublanes<L>(st);
+  GPROBE(6);
   int R = 2;
   bool done = !valid || inside(R);
   while (__any(!done)) {  // rare: sparse corners, clustered clouds -- one more shell per round, all lanes merge
@@ -1329,6 +1389,12 @@ DH3D_API int dh3d_knn_grid(const float *sorted, const int32_t *cells, int B, int
                      reinterpret_cast<const float4 *>(sorted), cells, N, K, D, lad, nn, dist);
   return dh3d_launch_status();
 }
+
+#ifdef DH3D_GRID_PROBE
+DH3D_API int dh3d_grid_probe_read(long long *host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gprobe), sizeof(long long) * n) == hipSuccess ? 0 : 3;
+}
+#endif
 
 #ifdef DH3D_KNN_PROBE
 DH3D_API int dh3d_knn_probe_read(long long *host, int n) {
