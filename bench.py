@@ -361,7 +361,7 @@ def step_kernel_rows(workload):
         ("flex_pool_pm_kernel", 1, "flex_pool D=32", 4 * R * (2 * 32 + K), 0.0, "hbm"),
         ("flex_conv_x6_kernel<32, 64", 1, "flex_conv 32->64 @N", ff(B, N, K, 32, 64)[0], ff(B, N, K, 32, 64)[2], "hbm (contract) / matrix pipe"),
         ("flex_conv_x6_kernel<64, 64", 1, "flex_conv 64->64 @N", ff(B, N, K, 64, 64)[0], ff(B, N, K, 64, 64)[2], "hbm (contract) / matrix pipe"),
-        ("se_res_mfma_kernel<64, true, true>", 1, "flex_pool + SE + residual + 1x1 conv 64->64 @N", 4 * R * (64 + K + 64 + 64), 2.0 * R * (2 * 64 * 16 + 64 * 64), "hbm"),
+        ("se_res_mfma_kernel<64, true, true", 1, "flex_pool + SE + residual + 1x1 conv 64->64 @N", 4 * R * (64 + K + 64 + 64), 2.0 * R * (2 * 64 * 16 + 64 * 64), "hbm"),
         ("knn_small_kernel", 1, "kNN K=8 on the sampled sets", 12 * Rs + 8 * Rs * K, 8.0 * B * M * M, "latency / VALU issue"),
         ("spatial_sort_kernel<1>", 1, "Morton sort of the sampled sets", 4 * Rs * 7 + 32 * Rs / 64, 0.0, "latency"),
         ("three_nn_pruned_kernel", 1, "three_nn N vs N/8", 16 * R + 16 * Rs + 24 * R, 8.0 * B * N * M, "f32 VALU (brute-force pair count; the kernel prunes)"),
@@ -369,8 +369,8 @@ def step_kernel_rows(workload):
         ("flex_conv_tx6_kernel<128, 128", 1, "flex_conv 128->128 @N/8 (32-point tiles, bf16x6 tile GEMM)", ff(B, M, K, 128, 128)[0], ff(B, M, K, 128, 128)[2], "gather + matrix pipe / L2 (weights)"),
         ("flex_conv_pm_kernel<64, 128", 1, "flex_conv 64->128 @N/8 (exact-f32 tiles: rounds 1-3)", ff(B, M, K, 64, 128)[0], ff(B, M, K, 64, 128)[2], "f32 MFMA"),
         ("flex_conv_pm_kernel<128, 128", 1, "flex_conv 128->128 @N/8 (exact-f32 tiles: rounds 1-3)", ff(B, M, K, 128, 128)[0], ff(B, M, K, 128, 128)[2], "f32 MFMA"),
-        ("se_res_mfma_kernel<128, true, false>", 1, "flex_pool + SE + residual @N/8", 4 * Rs * (128 + K + 128), 2.0 * Rs * 2 * 128 * 32, "hbm"),
-        ("se_res_mfma_kernel<128, true, true>", 1, "flex_pool + SE + residual + concat conv's upper block 128->128 @N/8",
+        ("se_res_mfma_kernel<128, true, false", 1, "flex_pool + SE + residual @N/8", 4 * Rs * (128 + K + 128), 2.0 * Rs * 2 * 128 * 32, "hbm"),
+        ("se_res_mfma_kernel<128, true, true", 1, "flex_pool + SE + residual + concat conv's upper block 128->128 @N/8",
          4 * Rs * (128 + K + 128 + 128), 2.0 * Rs * (2 * 128 * 32 + 128 * 128), "hbm"),
     ]
     if workload == "global":
