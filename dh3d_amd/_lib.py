@@ -105,7 +105,7 @@ _SIGNATURES = {
     "dh3d_spatial_sort": [c_fp, c_int, c_int, c_fp, c_fp, c_fp],
     "dh3d_knn_sorted": [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp],
     "dh3d_spatial_sort_cells": [c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_fp],
-    "dh3d_knn_grid": [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp],
+    "dh3d_knn_grid": [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp],
     "dh3d_fps_sorted": [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp],
     "dh3d_three_nn_sorted": [c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp],
     "dh3d_fps_sorted_xyz": [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp],

@@ -338,7 +338,7 @@ def compute_level(xyz, dilate, knn, ordered=None, fps_contract=None):
         nbr_s, _ = pm.knn_xyz(xyz_s, knn)  # latency bound); sets beyond the Morton sort's 14-bit ids: it is what serves any N
     elif knn <= 8 and pm.KNN_GRID:
         srt_s, gbox_s, cells_s = pm.spatial_sort_cells(xyz_s)
-        nbr_s, _ = pm.knn_grid(srt_s, cells_s, knn)
+        nbr_s, _ = pm.knn_grid(srt_s, gbox_s, cells_s, knn)
         ordered_s = (srt_s, gbox_s)
     else:
         srt_s, gbox_s = pm.spatial_sort(xyz_s)

@@ -288,6 +288,8 @@ __global__ __launch_bounds__(kQueriesPerBlock) void knn_kernel(const float *__re
 // exactly the same screen / queue / 64-bit-key insertion as knn_kernel, so ids and distances are
 // bit-identical to it (tests).  Waves are independent: no block-level barrier.
 constexpr int kSortedWaves = 4;
+constexpr int kCellInts = 4112;  // ints per cloud of the cell table (spatial.hip)
+constexpr int kCellFlag = 4106;  // ... [kCellFlag]: 1 = not a cloud for cell lists (dense cells), the pruned scan takes it
 #ifdef DH3D_KNN_PROBE  // dev instrumentation (tools/knn_probe.py): per-wave cycle / event counters
 __device__ long long g_kprobe[8 * 4096];
 #endif
@@ -297,7 +299,8 @@ __global__ __launch_bounds__(64 * kSortedWaves) void knn_sorted_kernel(const flo
                                                                     const float *__restrict__ gbox, int N,
                                                                     int K, KnnLadder lad,
                                                                     int32_t *__restrict__ nn,
-                                                                    float *__restrict__ dist) {
+                                                                    float *__restrict__ dist, const int *__restrict__ gate) {
+  if (gate && !gate[(size_t)blockIdx.y * kCellInts + kCellFlag]) return;  // (dh3d_knn_grid: only the clouds the cell lists left)
   __shared__ __attribute__((aligned(16))) float s_c[kSortedWaves][64 * 3];  // pair-SoA image per wave
   __shared__ uint2 s_q[kSortedWaves][kQueue * 64];
   __shared__ int s_id[kSortedWaves][64];  // original ids of the staged candidates
@@ -499,7 +502,8 @@ template <int KMAX, int S>
 __global__ __launch_bounds__(64 * S) void knn_split_kernel(const float4 *__restrict__ sorted,
                                                          const float *__restrict__ gbox, int N, int K,
                                                          KnnLadder lad, int32_t *__restrict__ nn,
-                                                         float *__restrict__ dist) {
+                                                         float *__restrict__ dist, const int *__restrict__ gate) {
+  if (gate && !gate[(size_t)blockIdx.y * kCellInts + kCellFlag]) return;  // (dh3d_knn_grid: only the clouds the cell lists left)
   static_assert(KMAX * 64 * sizeof(u64) <= kQueue * 64 * sizeof(uint2), "a K-list fits its wave's survivor queue");
   __shared__ __attribute__((aligned(16))) float s_c[S][64 * 3];  // pair-SoA image per wave
   __shared__ uint2 s_q[S][kQueue * 64];
@@ -1008,8 +1012,8 @@ DH3D_API void dh3d_dev_set_knn_split(int s) { g_knn_split = s; }
 static constexpr int g_knn_split = -1;
 #endif
 
-DH3D_API int dh3d_knn_sorted(const float *sorted, const float *gbox, int B, int N, int K, int32_t *nn,
-                             float *dist, void *stream) {
+static int knn_sorted_launch(const float *sorted, const float *gbox, int B, int N, int K, int32_t *nn, float *dist,
+                             const int *gate, void *stream) {
   DH3D_REQUIRE(sorted && gbox && nn && dist && B > 0 && N > 0 && K > 0);
   DH3D_SUPPORTED(K <= 64 && B <= 65535);
   const KnnLadder lad = knn_ladder(N);
@@ -1025,7 +1029,7 @@ DH3D_API int dh3d_knn_sorted(const float *sorted, const float *gbox, int B, int 
     dim3 sgrid(NG, B);
 #define DH3D_SPLIT_CASE(KM, SS)                                                                               \
   if (K <= KM && S == SS) {                                                                                  \
-    hipLaunchKernelGGL((knn_split_kernel<KM, SS>), sgrid, dim3(64 * SS), 0, s, so, gbox, N, K, lad, nn, dist); \
+    hipLaunchKernelGGL((knn_split_kernel<KM, SS>), sgrid, dim3(64 * SS), 0, s, so, gbox, N, K, lad, nn, dist, gate); \
     return dh3d_launch_status();                                                                             \
   }
     DH3D_SPLIT_CASE(4, 2) DH3D_SPLIT_CASE(4, 4)
@@ -1033,12 +1037,17 @@ DH3D_API int dh3d_knn_sorted(const float *sorted, const float *gbox, int B, int 
     DH3D_SPLIT_CASE(16, 2) DH3D_SPLIT_CASE(16, 4) DH3D_SPLIT_CASE(16, 8)
 #undef DH3D_SPLIT_CASE
   }
-  if (K <= 4) hipLaunchKernelGGL((knn_sorted_kernel<4>), grid, block, 0, s, so, gbox, N, K, lad, nn, dist);
-  else if (K <= 8) hipLaunchKernelGGL((knn_sorted_kernel<8>), grid, block, 0, s, so, gbox, N, K, lad, nn, dist);
-  else if (K <= 16) hipLaunchKernelGGL((knn_sorted_kernel<16>), grid, block, 0, s, so, gbox, N, K, lad, nn, dist);
-  else if (K <= 32) hipLaunchKernelGGL((knn_sorted_kernel<32>), grid, block, 0, s, so, gbox, N, K, lad, nn, dist);
-  else hipLaunchKernelGGL((knn_sorted_kernel<64>), grid, block, 0, s, so, gbox, N, K, lad, nn, dist);
+  if (K <= 4) hipLaunchKernelGGL((knn_sorted_kernel<4>), grid, block, 0, s, so, gbox, N, K, lad, nn, dist, gate);
+  else if (K <= 8) hipLaunchKernelGGL((knn_sorted_kernel<8>), grid, block, 0, s, so, gbox, N, K, lad, nn, dist, gate);
+  else if (K <= 16) hipLaunchKernelGGL((knn_sorted_kernel<16>), grid, block, 0, s, so, gbox, N, K, lad, nn, dist, gate);
+  else if (K <= 32) hipLaunchKernelGGL((knn_sorted_kernel<32>), grid, block, 0, s, so, gbox, N, K, lad, nn, dist, gate);
+  else hipLaunchKernelGGL((knn_sorted_kernel<64>), grid, block, 0, s, so, gbox, N, K, lad, nn, dist, gate);
   return dh3d_launch_status();
+}
+
+DH3D_API int dh3d_knn_sorted(const float *sorted, const float *gbox, int B, int N, int K, int32_t *nn,
+                             float *dist, void *stream) {
+  return knn_sorted_launch(sorted, gbox, B, N, K, nn, dist, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ cell-list kNN
@@ -1054,7 +1063,6 @@ DH3D_API int dh3d_knn_sorted(const float *sorted, const float *gbox, int B, int 
 // enter or tie.  Same distances (reference rounding order, IEEE sqrt) and the same 64-bit (distance, CUB rank) order as
 // every other kernel of this file: ids and distance bits are identical.  Degenerate clouds (everything in a few cells)
 // degrade towards the brute-force pair count, never past it.
-constexpr int kCellInts = 4112;  // ints per cloud of the cell table (spatial.hip)
 constexpr int kGridCap = 256;    // pooled candidates per query and pass (knn_grid_kernel)
 
 __device__ __forceinline__ unsigned knn_spread4(unsigned v) {  // 4 bits -> every third bit (the sort's spread6 >> 6)
@@ -1110,11 +1118,12 @@ __device__ long long g_gprobe[64 * 8];
 // L = lanes per query (2, 4 or 8): fewer lanes = longer private candidate streams, but an insertion round serves 64 / L
 // queries and the merge has log2(L) steps.
 template <int L>
-__global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict__ sorted, const int *__restrict__ cells,
-                                                      int N, int K, int D, KnnLadder lad,
+__global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict__ sorted, const float *__restrict__ gbox,
+                                                      const int *__restrict__ cells, int N, int K, int D, KnnLadder lad,
                                                       int32_t *__restrict__ nn, float *__restrict__ dist) {
   constexpr int QB = 256 / L;  // queries per workgroup
   const int b = blockIdx.y, lane = threadIdx.x & 63, sub = lane & (L - 1);
+  if (cells[(size_t)b * kCellInts + kCellFlag]) return;  // dense cells: the pruned scan takes this cloud (dh3d_knn_grid)
   const int qi = blockIdx.x * QB + threadIdx.x / L;
   const bool valid = qi < N;
   const float4 *sc = sorted + (size_t)b * N;
@@ -1151,21 +1160,6 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict_
     const float l = lo[a] + (float)(cq[a] + o) * w[a];
     const float d = fmaxf(fmaxf(fmaxf(l - q[a], q[a] - (l + w[a])), 0.f) - eps[a], 0.f);
     return d * d;
-  };
-  auto scan_range = [&](unsigned cid) {
-    const int beg = ct[cid], end = ct[cid + span];
-    for (int j = beg; j < end; ++j) {
-      const float4 r = sc[j];
-      const float dx = r.x - q[0], dy = r.y - q[1], dz = r.z - q[2];
-      const float s2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));  // the reference's rounding order
-      knn_offer<8, false>(st, s2, __float_as_int(r.w), lad);
-    }
-  };
-  auto visit = [&](int dx, int dy, int dz) {  // the general form (the widening rounds)
-    const int ax = cq[0] + dx, ay = cq[1] + dy, az = cq[2] + dz;
-    if ((unsigned)ax > (unsigned)gmax[0] || (unsigned)ay > (unsigned)gmax[1] || (unsigned)az > (unsigned)gmax[2]) return;
-    if ((axis_d2(0, dx) + axis_d2(1, dy) + axis_d2(2, dz)) * 0.99999f > st.bound) return;
-    scan_range(cell_code(ax, ay, az));
   };
   // the 5 x 5 x 5 block: everything that depends on the x offset alone is computed once (five slabs: distance, cell bits,
   // inside the grid or not); a lane then walks (dy, dz) columns and, per column, the five x offsets with constants
@@ -1314,38 +1308,79 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict_
   GPROBE(2);
   knn_merge_sublanes<L>(st);
   GPROBE(3);
-  // pass 1: shell 2 against the merged bound = the sixteen outer columns whole, then the inner ones at dx = -2, 2
+  // pass 1: every other cell the ball of the merged bound meets.  The K nearest neighbours all lie within the K-th distance
+  // seen so far, so the cells to look at are a BOX with its own radius per axis -- two cells each way in a uniform cloud
+  // (the 5 x 5 x 5 block of the first versions of this kernel), one cell in x / y and four thin layers in z on the ground
+  // plane of a street scene whose bounding box is a tenth as high as wide.  Exact after this pass: nothing outside the box
+  // is within the bound.  (The fixed block + shell-by-shell widening of the first version took 5.9 ms instead of 30 us
+  // on such a scene, tools/knn_scene_bench.py.)  Columns (dy, dz) of the box are dealt over the query's lanes, the five x
+  // offsets of a column are compile-time; a ball that is wider than that in x, or a box of more than 128 columns, or no
+  // K-th distance yet (fewer than K points in the 27 cells) goes to the restart below.
   keep_one_copy();
   begin_pass();
-#pragma unroll 1
-  for (int oi = sub; oi < 16; oi += L) {
-    const int r = oi;  // the ring of outer columns -- 0..4: dz = 0, dy = r; 5..9: dz = 4, dy = r - 5; 10..12: dy = 0, dz = r - 9; 13..15: dy = 4, dz = r - 12
-    const int cy = r < 5 ? r : r < 10 ? r - 5 : r < 13 ? 0 : 4;
-    const int cz = r < 5 ? 0 : r < 10 ? 4 : r < 13 ? r - 9 : r - 12;
-    column(std::integral_constant<int, 0b11111>{}, cy, cz);
+  bool exact = false;
+  int ylo = -2, zlo = -2, ny = 5, ncol = valid ? 25 : 0;  // (no K-th distance yet, or a ball too wide for this pass: the 5 x 5 x 5 block)
+  if (valid && st.bound < INFINITY) {
+    const float r = sqrtf(st.bound) * 1.0001f;
+    int dlo[3], dhi[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float inv = scl[a] / (float)(4 << drop[a]);  // cells per unit length
+      dlo[a] = min(0, max(0, (int)floorf((q[a] - r - eps[a] - lo[a]) * inv)) - cq[a]);
+      dhi[a] = max(0, min(gmax[a], (int)floorf((q[a] + r + eps[a] - lo[a]) * inv)) - cq[a]);
+    }
+    const int by = dhi[1] - dlo[1] + 1, bc = by * (dhi[2] - dlo[2] + 1);
+    if (dlo[0] >= -2 && dhi[0] <= 2 && bc <= 128) {
+      exact = true;
+      ylo = dlo[1]; zlo = dlo[2]; ny = by; ncol = bc;
+    }
   }
 #pragma unroll 1
-  for (int ci = sub; ci < 9; ci += L) column(std::integral_constant<int, 0b10001>{}, 1 + ci % 3, 1 + ci / 3);
+  for (int ci = sub; ci < ncol; ci += L) {
+    const int iz = ci / ny, dy = ylo + (ci - iz * ny), dz = zlo + iz;
+    if (abs(dy) <= 1 && abs(dz) <= 1) column(std::integral_constant<int, 0b10001>{}, dy + 2, dz + 2);  // (dx in -1..1: pass 0)
+    else column(std::integral_constant<int, 0b11111>{}, dy + 2, dz + 2);
+  }
   GPROBE(4);
   drain();
   GPROBE(5);
   knn_merge_sublanes<L>(st);
   GPROBE(6);
-  int R = 2;
-  bool done = !valid || inside(R);
-  while (__any(!done)) {  // rare: sparse corners, clustered clouds -- one more shell per round, all lanes merge
-    ++R;
-    keep_one_copy();
-    if (!done) {
-      const int side = 2 * R + 1, tot = side * side * side;
+  // What is left -- sparse corners, outliers, clusters that put everything into a few cells -- restarts against the bound
+  // it has, over the 64-point groups of the Morton order whose box the search ball meets (the sort's group boxes): exact
+  // (the list is emptied first, every point within the bound is offered again, nothing twice) and bounded: N / 64 box
+  // tests per query dealt over its lanes.
+  const bool done = !valid || exact || inside(2);
+  if (__any(!done)) {
+    if (done) {
+      keep_one_copy();
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) st.keys[i] = ~0ull;  // (the bound stays: it is the K-th distance of a superset of nothing less)
+      const int NG = (N + 63) >> 6;
+      const float4 *gb = reinterpret_cast<const float4 *>(gbox) + (size_t)b * NG * 2;  // [lo.xyz,_ | hi.xyz,_]
 #pragma unroll 1
-      for (int c = sub; c < tot; c += L) {
-        const int dz = c / (side * side), rr = c - dz * side * side, dy = rr / side, dx = rr - dy * side;
-        if (max(abs(dx - R), max(abs(dy - R), abs(dz - R))) == R) visit(dx - R, dy - R, dz - R);
+      for (int g = sub; g < NG; g += L) {
+        const float4 lo4 = gb[2 * g], hi4 = gb[2 * g + 1];
+        const float ex = fmaxf(fmaxf(lo4.x - q[0], q[0] - hi4.x), 0.f), ey = fmaxf(fmaxf(lo4.y - q[1], q[1] - hi4.y), 0.f),
+                    ez = fmaxf(fmaxf(lo4.z - q[2], q[2] - hi4.z), 0.f);
+        if ((ex * ex + ey * ey + ez * ez) * 0.99999f > st.bound) continue;
+        const int j1 = min(N, g * 64 + 64);
+#pragma unroll 1
+        for (int j = g * 64; j < j1; j += 8) {  // eight records in flight
+          float4 r8[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) r8[u] = sc[min(j + u, j1 - 1)];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const float dx = r8[u].x - q[0], dy = r8[u].y - q[1], dz = r8[u].z - q[2];
+            const float s2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+            knn_offer<8, false>(st, j + u < j1 ? s2 : __builtin_nanf(""), __float_as_int(r8[u].w), lad);
+          }
+        }
       }
     }
     knn_merge_sublanes<L>(st);
-    done = done || R >= 15 || inside(R);
   }
   if (valid) {
     const int y = __float_as_int(qr.w);  // the query's original index
@@ -1369,9 +1404,9 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict_
   }
 }
 
-DH3D_API int dh3d_knn_grid(const float *sorted, const int32_t *cells, int B, int N, int K, int32_t *nn, float *dist,
-                           void *stream) {
-  DH3D_REQUIRE(sorted && cells && nn && dist && B > 0 && N > 0 && K > 0);
+DH3D_API int dh3d_knn_grid(const float *sorted, const float *gbox, const int32_t *cells, int B, int N, int K, int32_t *nn,
+                           float *dist, void *stream) {
+  DH3D_REQUIRE(sorted && gbox && cells && nn && dist && B > 0 && N > 0 && K > 0);
   DH3D_SUPPORTED(K <= 8 && N <= 16384 && B <= 65535);
   const KnnLadder lad = knn_ladder(N);
 #ifndef DH3D_GRID_LANES
@@ -1386,8 +1421,11 @@ DH3D_API int dh3d_knn_grid(const float *sorted, const int32_t *cells, int B, int
   D = D + (DH3D_GRID_DROP_BIAS) < 0 ? 0 : D + (DH3D_GRID_DROP_BIAS);
 #endif
   hipLaunchKernelGGL(knn_grid_kernel<kLanes>, dim3(dh3d_cdiv(N, 256 / kLanes), B), dim3(256), 0, (hipStream_t)stream,
-                     reinterpret_cast<const float4 *>(sorted), cells, N, K, D, lad, nn, dist);
-  return dh3d_launch_status();
+                     reinterpret_cast<const float4 *>(sorted), gbox, cells, N, K, D, lad, nn, dist);
+  if (dh3d_launch_status() != DH3D_OK) return DH3D_ERR_LAUNCH;
+  // ... and the clouds whose points crowd into few cells (the sort's verdict, cells[kCellFlag]) on the pruned scan: every
+  // workgroup of the other clouds leaves at its first instruction
+  return knn_sorted_launch(sorted, gbox, B, N, K, nn, dist, cells, stream);
 }
 
 #ifdef DH3D_GRID_PROBE

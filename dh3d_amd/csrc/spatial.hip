@@ -11,6 +11,8 @@
 // passes -> sorted float4 records (x, y, z, bits(original index)) and one box per group of 64.
 // (The first version was a bitonic network: 91 barrier-separated stages, 70 us for 8 x 8192 -- on the critical
 //  path of both the kNN and the FPS.  The radix sort produces the identical order: stable by cell = (cell, index).)
+#include <math.h>
+
 #include "common.h"
 #include "wave_ops.h"
 
@@ -43,7 +45,8 @@ __device__ __forceinline__ unsigned spread6(unsigned v) {  // 6 bits -> every th
 template <int PPT>
 __global__ __launch_bounds__(kThreads) void spatial_sort_kernel(const float *__restrict__ xyz, int N,
                                                                int npad, float4 *__restrict__ sorted,
-                                                               float *__restrict__ gbox, int *__restrict__ cells) {
+                                                               float *__restrict__ gbox, int *__restrict__ cells,
+                                                               int occ_min) {
   extern __shared__ __attribute__((aligned(16))) unsigned s_raw[];  // keys[2][npad] | hist[16][64] | 6*kWaves floats
   unsigned *s_hist = s_raw + 2 * npad;
   float *s_red = reinterpret_cast<float *>(s_hist + kWaves * 64);
@@ -211,10 +214,29 @@ __global__ __launch_bounds__(kThreads) void spatial_sort_kernel(const float *__r
           for (int c = cur + 1; c <= 4096; ++c) ct[c] = N;
       }
     }
+    // [4106]: is this cloud one for cell lists?  Not when its points crowd into far fewer cells than a uniform cloud of the
+    // same size would occupy (street scenes: ground plane + walls in a bounding box a tenth as high as wide; clusters) --
+    // dh3d_knn_grid then runs the pruned scan of the Morton order for this cloud (tools/knn_scene_bench.py, 8 x 8192: cell
+    // lists 30 us on a uniform cloud, 66 on a uniform 60 x 60 x 8 slab, 410 on a scene where the scan takes 190; occupied
+    // cells 3550 / 3535 / 1520 of 4096).
+    int occupied = 0;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const int i = wave * SEG + j * 64 + lane;
+      if (i < N) occupied += (int)(i == 0 || (s_keys[i] >> 20) != (s_keys[i - 1] >> 20));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) occupied += __shfl_xor(occupied, off, 64);
+    __shared__ int s_occupied;
+    if (tid == 0) s_occupied = 0;
+    __syncthreads();
+    if (lane == 0) atomicAdd(&s_occupied, occupied);
+    __syncthreads();
     if (tid == 0) {
       float *hd = reinterpret_cast<float *>(ct) + 4100;
       hd[0] = lo[0]; hd[1] = lo[1]; hd[2] = lo[2];
       hd[3] = scale[0]; hd[4] = scale[1]; hd[5] = scale[2];
+      ct[4106] = s_occupied < occ_min ? 1 : 0;
     }
   }
   SPROBE(10);
@@ -227,7 +249,10 @@ int sort_launch(const float *xyz, int B, int N, float4 *sorted, float *gbox, int
   if (npad < 64 * kWaves) npad = 64 * kWaves;  // one 64-key step per wave at least
   const size_t lds = sizeof(unsigned) * (2 * (size_t)npad + kWaves * 64) + sizeof(float) * 6 * kWaves;
   DH3D_ALLOW_BIG_LDS((spatial_sort_kernel<PPT>));
-  hipLaunchKernelGGL((spatial_sort_kernel<PPT>), dim3(B), dim3(kThreads), lds, s, xyz, N, npad, sorted, gbox, cells);
+  // fewer occupied cells than 0.6 x what a uniform cloud of N points leaves non-empty: not a cloud for cell lists (cells[4106])
+  const int occ_min = (int)(0.6 * 4096.0 * (1.0 - exp(-(double)N / 4096.0)));
+  hipLaunchKernelGGL((spatial_sort_kernel<PPT>), dim3(B), dim3(kThreads), lds, s, xyz, N, npad, sorted, gbox, cells,
+                     occ_min);
   return dh3d_launch_status();
 }
 

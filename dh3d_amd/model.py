@@ -250,7 +250,7 @@ class DH3D(nn.Module):
             else:
                 srt, gbox = geo.ordered()
                 if geo.cells is not None:   # cell lists on the sort's grid, 8 lanes per query (csrc/knn.hip knn_grid_kernel)
-                    geo.nbr, _ = pm.knn_grid(srt, geo.cells, self.knn_num)  # core/model.py:157
+                    geo.nbr, _ = pm.knn_grid(srt, gbox, geo.cells, self.knn_num)  # core/model.py:157
                 else:                       # the pruned shared scan (K > 8)
                     geo.nbr, _ = pm.knn_sorted(srt, gbox, self.knn_num)
             geo.nbr.record_stream(main)

@@ -55,12 +55,13 @@ def spatial_sort_cells(xyz):
     return srt, gbox, cells
 
 
-def knn_grid(srt, cells, k):
-    """kNN by cell lists on spatial_sort_cells() output; same (nbr [B,N,K], dist) as knn_xyz bit for bit.  K <= 8."""
+def knn_grid(srt, gbox, cells, k):
+    """kNN by cell lists on the three outputs of spatial_sort_cells(); same (nbr [B,N,K], dist) as knn_xyz bit for bit.
+    K <= 8."""
     B, N, _ = srt.shape
     nn = torch.empty((B, N, k), dtype=torch.int32, device=srt.device)
     dist = torch.empty((B, N, k), dtype=torch.float32, device=srt.device)
-    L.check(L.lib().dh3d_knn_grid(L.ptr(srt), L.ptr(cells), B, N, k, L.ptr(nn), L.ptr(dist), L.stream_ptr()), "knn_grid")
+    L.check(L.lib().dh3d_knn_grid(L.ptr(srt), L.ptr(gbox), L.ptr(cells), B, N, k, L.ptr(nn), L.ptr(dist), L.stream_ptr()), "knn_grid")
     return nn, dist
 
 

@@ -224,15 +224,22 @@ int dh3d_knn_sorted(const float *sorted, const float *gbox, int B, int N, int K,
 
 /* dh3d_spatial_sort that also writes the CELL TABLE of the 16 x 16 x 16 grid over each cloud's bounding box: cells
  * [B, DH3D_CELL_INTS] int32 -- [0..4096] the first sorted position of every cell (cells in Morton order = the top 12 bits of
- * the sort key; [4096] = N), [4100..4105] as floats the grid origin and its 64 / extent scale per axis. */
+ * the sort key; [4096] = N), [4100..4105] as floats the grid origin and its 64 / extent scale per axis, [4106] = 1 when the
+ * cloud's points crowd into fewer than 0.6 x the cells a uniform cloud of N points would occupy (street scenes, clusters:
+ * dh3d_knn_grid then serves this cloud with the pruned scan of dh3d_knn_sorted), else 0. */
 #define DH3D_CELL_INTS 4112
 int dh3d_spatial_sort_cells(const float *xyz, int B, int N, float *sorted, float *gbox, int32_t *cells, void *stream);
 
 /* KnnBruteforce on that grid (cell-list search: every query scans the cells its K-th distance reaches, candidates pooled
  * per query in LDS, 4 lanes per query; csrc/knn.hip knn_grid_kernel).  Same outputs as dh3d_knn_bruteforce_xyz bit for
  * bit -- ids in the reference's (distance, CUB rank) order, IEEE distances, original point order.  K <= 8, any
- * N <= 16384 (small sets search a coarser grid: 2^D consecutive cells of the same table). */
-int dh3d_knn_grid(const float *sorted, const int32_t *cells, int B, int N, int K, int32_t *nn, float *dist, void *stream);
+ * N <= 16384 (small sets search a coarser grid: 2^D consecutive cells of the same table).  sorted / gbox / cells are the
+ * three outputs of dh3d_spatial_sort_cells: a query whose K-th distance reaches beyond the 5 x 5 x 5 cells around it
+ * (sparse corners; most queries of an anisotropic or clustered cloud) restarts over the 64-point groups whose box
+ * (gbox) its search ball meets; a cloud the sort flagged as crowded (cells[4106]) is served by dh3d_knn_sorted's
+ * kernels instead, from the same launch sequence (same results either way). */
+int dh3d_knn_grid(const float *sorted, const float *gbox, const int32_t *cells, int B, int N, int K, int32_t *nn, float *dist,
+                  void *stream);
 
 
 /* ThreeNN on ordered clouds: identical dist / idx to dh3d_three_nn (original indexing on both sides) from the

@@ -500,10 +500,27 @@ def _knn_clouds(name, B, N, rng):
         pts = (rng.random((B, N, 3), dtype=np.float32) * 0.01).astype(np.float32)
         pts[:, :5] = rng.random((B, 5, 3), dtype=np.float32) * 100
         return pts
+    if name == "scene":     # a street scene normalised to [-1, 1]: ground plane + walls + clutter, z extent a tenth of x / y --
+        out = np.empty((B, N, 3), np.float32)  # the grid's cells are a tenth as high as wide, occupied ones hold dozens of points
+        for b in range(B):
+            n_g, n_w = int(N * 0.55), int(N * 0.35)
+            g = np.stack([rng.uniform(-1, 1, n_g), rng.uniform(-1, 1, n_g), rng.normal(-0.08, 0.004, n_g)], 1)
+            walls = []
+            for _ in range(6):
+                m = n_w // 6
+                x0, y0, ang, ln = rng.uniform(-0.8, 0.8), rng.uniform(-0.8, 0.8), rng.uniform(0, np.pi), rng.uniform(0.3, 0.9)
+                tt = rng.uniform(0, ln, m)
+                walls.append(np.stack([x0 + tt * np.cos(ang), y0 + tt * np.sin(ang), rng.uniform(-0.08, 0.12, m)], 1)
+                             + rng.normal(0, 0.003, (m, 3)))
+            w = np.concatenate(walls)
+            c = rng.uniform(-1, 1, (N - n_g - len(w), 3)) * np.array([1, 1, 0.1])
+            out[b] = np.clip(np.concatenate([g, w, c])[rng.permutation(N)], -1, 1)
+        return out
     raise KeyError(name)
 
 
 @pytest.mark.parametrize("name,B,N,K", [
+    ("scene", 4, 8192, 8), ("scene", 4, 4096, 8), ("scene", 2, 16384, 5), ("scene", 3, 1000, 8),
     ("uniform", 8, 8192, 8), ("uniform", 3, 4097, 8), ("uniform", 2, 16384, 8), ("uniform", 2, 9000, 5),
     ("oxford_extent", 4, 4096, 8), ("clusters", 2, 8192, 8), ("lattice", 2, 8192, 8), ("lattice", 1, 4096, 3),
     ("duplicates", 2, 4096, 8), ("plane", 2, 4096, 8), ("one_point", 1, 2100, 8), ("outliers", 2, 4096, 8),
@@ -525,7 +542,15 @@ def test_knn_grid_cell_list_search_is_bit_equal_to_brute_force(dev, name, B, N, 
     assert torch.equal(srt, s2) and torch.equal(gbox, g2)      # the cell table changes nothing else
     ct = cells[:, :4097].cpu().numpy()
     assert (ct[:, 0] == 0).all() and (ct[:, 4096] == N).all() and (np.diff(ct, axis=1) >= 0).all()
-    nn_g, d_g = pm.knn_grid(srt, cells, K)
+    # the sort's verdict: far fewer occupied cells than a uniform cloud of N points leaves -> the pruned scan serves the cloud
+    flag = cells[:, 4106].cpu().numpy()
+    occupied = (np.diff(ct, axis=1) > 0).sum(1)
+    assert np.array_equal(flag != 0, occupied < int(0.6 * 4096.0 * (1.0 - np.exp(-N / 4096.0)))), (name, flag, occupied)
+    if name in ("uniform", "oxford_extent"):
+        assert not flag.any()
+    if name in ("scene", "one_point", "clusters", "outliers") and N >= 4096:
+        assert flag.all()
+    nn_g, d_g = pm.knn_grid(srt, gbox, cells, K)
     nn_b, d_b = pm.knn_xyz(pts, K)
     assert torch.equal(nn_g, nn_b), (name, int((nn_g != nn_b).sum()))
     assert torch.equal(d_g.view(torch.int32), d_b.view(torch.int32))
@@ -536,8 +561,8 @@ def test_knn_grid_cell_list_search_is_bit_equal_to_brute_force(dev, name, B, N, 
 def test_knn_grid_vs_oracle_N8192(dev, oracle):
     from dh3d_amd import pm
     pts = np.random.default_rng(8192).random((2, 8192, 3), dtype=np.float32)
-    srt, _, cells = pm.spatial_sort_cells(torch.from_numpy(pts).to(dev))
-    nn_g, d_g = pm.knn_grid(srt, cells, 8)
+    srt, gbox, cells = pm.spatial_sort_cells(torch.from_numpy(pts).to(dev))
+    nn_g, d_g = pm.knn_grid(srt, gbox, cells, 8)
     nn_o, d_o = oracle.knn_bruteforce(np.ascontiguousarray(pts.transpose(0, 2, 1)), 8)
     assert np.array_equal(nn_g.cpu().numpy(), nn_o)
     assert np.array_equal(d_g.cpu().numpy().view(np.uint32), d_o.view(np.uint32))

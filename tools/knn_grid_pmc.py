@@ -6,5 +6,5 @@ dev = torch.device("cuda")
 pts = bench.synthetic_clouds(8, 8192, 2002, dev, 0)
 srt, gbox, cells = pm.spatial_sort_cells(pts)
 for _ in range(3):
-    pm.knn_sorted(srt, gbox, 8); pm.knn_grid(srt, cells, 8)
+    pm.knn_sorted(srt, gbox, 8); pm.knn_grid(srt, gbox, cells, 8)
 torch.cuda.synchronize()

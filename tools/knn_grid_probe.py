@@ -9,7 +9,7 @@ for B, N in ((8, 8192), (32, 4096)):
     pts = bench.synthetic_clouds(B, N, 2002, dev, 0)
     srt, gbox, cells = pm.spatial_sort_cells(pts)
     for _ in range(3):
-        pm.knn_grid(srt, cells, 8)
+        pm.knn_grid(srt, gbox, cells, 8)
     torch.cuda.synchronize()
     h = (ctypes.c_longlong * 512)()
     L.lib().dh3d_grid_probe_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
