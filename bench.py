@@ -94,6 +94,28 @@ def synthetic_clouds(B, N, seed, dev, rank=0):
     return torch.from_numpy(rng.random((B, N, 3), dtype=np.float32)).to(dev)
 
 
+def scene_like_clouds(B, N, seed, dev):
+    """A street scene normalised to [-1, 1] -- 55 % ground plane, 35 % on six walls, 10 % clutter; z extent a tenth of x / y,
+    a third of the 16^3 cells occupied -- for the `data_sensitivity` key: the data-dependent kernels (FPS box pruning,
+    kNN, three_nn) are timed on the uniform cube everywhere else."""
+    rng = np.random.default_rng(seed)
+    out = np.empty((B, N, 3), np.float32)
+    for b in range(B):
+        n_g, n_w = int(N * 0.55), int(N * 0.35)
+        g = np.stack([rng.uniform(-1, 1, n_g), rng.uniform(-1, 1, n_g), rng.normal(-0.08, 0.004, n_g)], 1)
+        walls = []
+        for _ in range(6):
+            m = n_w // 6
+            x0, y0, ang, ln = rng.uniform(-0.8, 0.8), rng.uniform(-0.8, 0.8), rng.uniform(0, np.pi), rng.uniform(0.3, 0.9)
+            t = rng.uniform(0, ln, m)
+            walls.append(np.stack([x0 + t * np.cos(ang), y0 + t * np.sin(ang), rng.uniform(-0.08, 0.12, m)], 1)
+                         + rng.normal(0, 0.003, (m, 3)))
+        w = np.concatenate(walls)
+        c = rng.uniform(-1, 1, (N - n_g - len(w), 3)) * np.array([1, 1, 0.1])
+        out[b] = np.clip(np.concatenate([g, w, c])[rng.permutation(N)], -1, 1)
+    return torch.from_numpy(out).to(dev)
+
+
 def time_steps(run, pts, steps, warmup, dev):
     from dh3d_amd import dist as D
     # clock ramp: a fresh process finds the GPU in a low power state and a millisecond-scale step does not pull it
@@ -1034,6 +1056,31 @@ def main():
             if b >= 1:
                 v, m_, _ = measure(args.workload, batch=b)
                 sweep.append({"clouds_per_gpu": b, "value": v, "ms_per_step": m_})
+        if args.workload in ("local", "global", "cfg5"):
+            try:  # the same graphed step on scene-like clouds (informational: every other number is on the uniform cube)
+                from dh3d_amd import pm
+                model = build_model(wl["preset"], dev, seed=0, num_points=wl["N"])
+                sp = scene_like_clouds(wl["B"], wl["N"], wl["seed"], dev)
+                up = synthetic_clouds(wl["B"], wl["N"], wl["seed"], dev, 0)
+                with torch.no_grad():
+                    run = model.graphed(sp, outputs=(wl["out"],))
+                    run.static_input.copy_(sp)
+                    dts = time_steps(run, run.static_input, args.steps, args.warmup, dev)
+                    knn = {}
+                    for nm, p_ in (("uniform_cube", up), ("scene_like", sp)):
+                        srt, gbox, cells = pm.spatial_sort_cells(p_)
+                        knn[nm] = {"dh3d_knn_grid_ms": event_time_ms(lambda: pm.knn_grid(srt, gbox, cells, 8), iters=20, warm=3),
+                                   "pruned_scan_ms": event_time_ms(lambda: pm.knn_sorted(srt, gbox, 8), iters=20, warm=3),
+                                   "clouds_sent_to_the_scan": int((cells[:, 4106] != 0).sum())}
+                line["data_sensitivity"] = {
+                    "input": "scene-like clouds (bench.scene_like_clouds: ground plane + walls + clutter in [-1, 1], z extent a tenth of x / y)",
+                    "one_step_at_a_time": {"ms_per_step": dts / args.steps * 1e3, "value": wl["B"] * args.steps / dts,
+                                           "ratio_to_uniform_cube": (dts / args.steps * 1e3) / serial["ms_per_step"]},
+                    "knn_K8": knn,
+                    "note": "FPS box pruning, kNN and three_nn are data dependent; results are bit-equal on either input "
+                            "(tests/test_ops_gpu.py), DESIGN.md 3.0 'Data dependence'"}
+            except Exception as e:  # noqa: BLE001 -- informational key
+                line["data_sensitivity"] = {"error": repr(e)[:200]}
         line["batch_sweep_1gpu"] = {"workload": args.workload, "points": sweep,
                                     "predicted_strong_scaling_8gpu": (8 * sweep[-1]["value"] / sweep[0]["value"])
                                     if len(sweep) == 4 else None}

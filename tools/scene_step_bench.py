@@ -8,20 +8,7 @@ from dh3d_amd import pm
 dev = torch.device("cuda")
 
 def scene(B, N, rng):
-    out = np.empty((B, N, 3), np.float32)
-    for b in range(B):
-        n_g, n_w = int(N * 0.55), int(N * 0.35)
-        g = np.stack([rng.uniform(-1, 1, n_g), rng.uniform(-1, 1, n_g), rng.normal(-0.08, 0.004, n_g)], 1)
-        walls = []
-        for _ in range(6):
-            m = n_w // 6
-            x0, y0, ang, L = rng.uniform(-0.8, 0.8), rng.uniform(-0.8, 0.8), rng.uniform(0, np.pi), rng.uniform(0.3, 0.9)
-            t = rng.uniform(0, L, m)
-            walls.append(np.stack([x0 + t * np.cos(ang), y0 + t * np.sin(ang), rng.uniform(-0.08, 0.12, m)], 1) + rng.normal(0, 0.003, (m, 3)))
-        w = np.concatenate(walls)
-        c = rng.uniform(-1, 1, (N - n_g - len(w), 3)) * np.array([1, 1, 0.1])
-        out[b] = np.clip(np.concatenate([g, w, c])[rng.permutation(N)], -1, 1)
-    return out
+    return bench.scene_like_clouds(B, N, int(rng.integers(1 << 30)), "cpu").numpy()
 
 def timed(fn, steps=20):
     for _ in range(5): fn()
