@@ -8,7 +8,7 @@ def show(rs):
     if not rs or 'error' in rs:
         print(rs); return
     for r in rs['kernels']:
-        print("  %-40s x%d floor %7.2f (hbm %6.2f f32 %6.2f) meas %7.2f frac %.3f" % (r['kernel'][:40], r['launches'], r['floor_us'], r['floor_hbm_us'], r['floor_f32_us'], r['measured_us'], r['frac']))
+        print("  %-40s x%d floor %7.2f (hbm %6.2f f32 %6.2f) meas %7.2f frac %.3f" % (r['kernel'][:40], r['launches'], r['floor_us'], r['floor_hbm_us'], r['floor_f32_us'], r['measured_us'], r['frac'] or 0.0))
     print("  ", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in rs.items() if k not in ('kernels', 'note', 'peaks', 'workload', 'unlisted_kernel_names')})
 print("value %.0f  ms %.4f | serial %.0f ms %.4f" % (d['value'], d['ms_per_step'], d['one_step_at_a_time']['value'], d['one_step_at_a_time']['ms_per_step']))
 if 'repeats' in d: print("  repeats in flight:", d['repeats']['ms_per_step'])
