@@ -1054,15 +1054,18 @@ DH3D_API int dh3d_knn_sorted(const float *sorted, const float *gbox, int B, int 
 // The same operator on the uniform 16 x 16 x 16 grid spatial_sort_kernel lays over a cloud's bounding box (the top four
 // bits per axis of the Morton key: every grid cell is ONE contiguous range of the sorted records, cells[] holds the
 // ranges).  Where the pruned scan above shares a candidate stream between 64 queries -- the union of their search balls,
-// ~1800 candidates per query at 8 x 8192 -- this one gives every query its own cells: 8 lanes per query deal the cells of
-// the 5 x 5 x 5 block around the query's cell between them (shells 0-1 first, then shell 2 against the bound that gave),
-// skip a cell whose box lies beyond the query's current K-th distance, scan the rest (~100-250 candidates per query) into
-// their own sorted K-lists and merge the eight lists with three bitonic exchange steps.  Exact: a skipped cell provably
-// holds nothing closer than the K-th (conservative box distance, ties included), and the search widens shell by shell
-// until the K-th distance is STRICTLY inside the block searched (or the block is the whole grid), so nothing outside can
-// enter or tie.  Same distances (reference rounding order, IEEE sqrt) and the same 64-bit (distance, CUB rank) order as
-// every other kernel of this file: ids and distance bits are identical.  Degenerate clouds (everything in a few cells)
-// degrade towards the brute-force pair count, never past it.
+// ~1800 candidates per query at 8 x 8192 -- this one gives every query its own cells.  L lanes per query, two passes:
+//   (0) the 27 cells around the query's cell;
+//   (1) every other cell of the BOX the ball of the K-th distance seen so far meets (its own radius per axis), skipping a
+//       cell whose box lies beyond that distance.
+// Each pass pools the surviving cells' records per query in LDS, the query's lanes then take the pooled candidates L apart
+// into their own sorted K-lists, and the lists are merged with log2(L) bitonic exchange steps.  Exact after pass 1: the K
+// nearest neighbours all lie within the K-th distance seen after pass 0, i.e. inside the box, and a skipped cell provably
+// holds nothing closer (conservative box distance, ties included).  What the box pass cannot serve (no K-th distance after
+// 27 cells, a ball wider than +-2 cells in x, more than 128 columns) restarts over the sort's 64-point group boxes; clouds
+// whose points crowd into few cells (the sort's verdict, cells[kCellFlag]) are left to the pruned scan (dh3d_knn_grid).
+// Same distances (reference rounding order, IEEE sqrt) and the same 64-bit (distance, CUB rank) order as every other
+// kernel of this file: ids and distance bits are identical.
 constexpr int kGridCap = 256;    // pooled candidates per query and pass (knn_grid_kernel)
 
 __device__ __forceinline__ unsigned knn_spread4(unsigned v) {  // 4 bits -> every third bit (the sort's spread6 >> 6)
@@ -1073,9 +1076,9 @@ __device__ __forceinline__ void knn_cswap(u64 &a, u64 &b) {
   const u64 lo = lt ? b : a, hi = lt ? a : b;
   a = lo; b = hi;
 }
-// the eight lanes of a query end up with the same list: the 8 smallest keys of all their lists.  Three exchange steps on
-// the DPP crossbar (no LDS round trip): partner = lane ^ 1, lane ^ 2 (quad permutes), then 7 - lane within the eight
-// (row_half_mirror: every lane meets one of the other quad, whose four lanes already agree).
+// the L lanes of a query end up with the same list: the 8 smallest keys of all their lists.  log2(L) exchange steps on
+// the DPP crossbar (no LDS round trip): partner = lane ^ 1, lane ^ 2 (quad permutes), then (L = 8) 7 - lane within the
+// eight (row_half_mirror: every lane meets one of the other quad, whose four lanes already agree).
 template <int CTRL>
 __device__ __forceinline__ u64 knn_dpp_u64(u64 v) {
   const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xF, 0xF, true);
@@ -1187,15 +1190,14 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict_
     return st.bound < G * G * 0.99999f;  // bound = the (1 + 2^-20)-inflated square of the K-th distance, inf while the list is short
   };
 
-  // shells 0 and 1 of the 5 x 5 x 5 block (27 cells), then shell 2 (98 cells) against the merged bound.
   // Cells hold 0..~8 points: walking them cell by cell leaves most lanes of the wave idle in every iteration (and the
   // ~45-instruction insertion runs for the whole wave whenever one lane inserts).  So a pass first POOLS: every lane
   // appends the record indices of its surviving cells to its query's list in LDS (one LDS atomic per cell for the
-  // place), then the eight lanes take the pooled candidates eight apart, four per lane in flight -- every lane busy in
+  // place), then the query's lanes take the pooled candidates L apart, four per lane in flight -- every lane busy in
   // every iteration, ~5x fewer iterations of the candidate loop.  The result does not depend on who scans what (keys
   // are unique, the merge sorts).  A list that is full (dense clusters) sends the rest of the cell down the direct path.
-  // After a merge all eight lanes hold the SAME list: before they scan on, seven of them empty theirs (the bound stays),
-  // or the next merge would count every entry eight times
+  // After a merge all L lanes hold the SAME list: before they scan on, all but one empty theirs (the bound stays), or the
+  // next merge would count every entry L times
   auto keep_one_copy = [&]() {
     if (sub != 0) {
 #pragma unroll

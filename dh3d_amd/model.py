@@ -249,7 +249,7 @@ class DH3D(nn.Module):
                 geo.nbr, _ = pm.knn_xyz(points, self.knn_num)
             else:
                 srt, gbox = geo.ordered()
-                if geo.cells is not None:   # cell lists on the sort's grid, 8 lanes per query (csrc/knn.hip knn_grid_kernel)
+                if geo.cells is not None:   # cell lists on the sort's grid; crowded clouds: the pruned scan (csrc/knn.hip dh3d_knn_grid)
                     geo.nbr, _ = pm.knn_grid(srt, gbox, geo.cells, self.knn_num)  # core/model.py:157
                 else:                       # the pruned shared scan (K > 8)
                     geo.nbr, _ = pm.knn_sorted(srt, gbox, self.knn_num)

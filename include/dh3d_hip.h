@@ -234,8 +234,8 @@ int dh3d_spatial_sort_cells(const float *xyz, int B, int N, float *sorted, float
  * per query in LDS, 4 lanes per query; csrc/knn.hip knn_grid_kernel).  Same outputs as dh3d_knn_bruteforce_xyz bit for
  * bit -- ids in the reference's (distance, CUB rank) order, IEEE distances, original point order.  K <= 8, any
  * N <= 16384 (small sets search a coarser grid: 2^D consecutive cells of the same table).  sorted / gbox / cells are the
- * three outputs of dh3d_spatial_sort_cells: a query whose K-th distance reaches beyond the 5 x 5 x 5 cells around it
- * (sparse corners; most queries of an anisotropic or clustered cloud) restarts over the 64-point groups whose box
+ * three outputs of dh3d_spatial_sort_cells: a query the two cell passes cannot serve (no K-th distance after 27
+ * cells, a search ball wider than two cells in x: sparse corners, outliers) restarts over the 64-point groups whose box
  * (gbox) its search ball meets; a cloud the sort flagged as crowded (cells[4106]) is served by dh3d_knn_sorted's
  * kernels instead, from the same launch sequence (same results either way). */
 int dh3d_knn_grid(const float *sorted, const float *gbox, const int32_t *cells, int B, int N, int K, int32_t *nn, float *dist,
