@@ -130,6 +130,44 @@ def test_cfg3_global_forward_N4096_vs_oracle(dev):
     assert e < 1e-4, ("graph replay globaldesc", e)
 
 
+def _scene(B, N, seed):
+    """A street scene normalised to [-1, 1] (ground plane + six walls + clutter, z extent a tenth of x / y): the shape of the
+    reference's data, where the sort flags the cloud as crowded (kNN on the pruned scan), FPS picks meet near-ties on the
+    plane and the Morton boxes are flat -- every other end-to-end test runs on the uniform cube."""
+    rng = np.random.default_rng(seed)
+    out = np.empty((B, N, 3), np.float32)
+    for b in range(B):
+        n_g, n_w = int(N * 0.55), int(N * 0.35)
+        g = np.stack([rng.uniform(-1, 1, n_g), rng.uniform(-1, 1, n_g), rng.normal(-0.08, 0.004, n_g)], 1)
+        walls = []
+        for _ in range(6):
+            m = n_w // 6
+            x0, y0, ang, ln = rng.uniform(-0.8, 0.8), rng.uniform(-0.8, 0.8), rng.uniform(0, np.pi), rng.uniform(0.3, 0.9)
+            t = rng.uniform(0, ln, m)
+            walls.append(np.stack([x0 + t * np.cos(ang), y0 + t * np.sin(ang), rng.uniform(-0.08, 0.12, m)], 1)
+                         + rng.normal(0, 0.003, (m, 3)))
+        w = np.concatenate(walls)
+        c = rng.uniform(-1, 1, (N - n_g - len(w), 3)) * np.array([1, 1, 0.1])
+        out[b] = np.clip(np.concatenate([g, w, c])[rng.permutation(N)], -1, 1)
+    return out
+
+
+def test_scene_like_clouds_local_N8192_and_global_N4096_vs_oracle(dev):
+    """The same end-to-end bars on scene-like clouds: kNN / FPS / sampled-set kNN / three_nn ids bit-equal, descriptors
+    within 1e-4 -- the local forward at N = 8192 and the global forward at N = 4096 (one scene and one uniform cloud in a
+    batch: the sort's per-cloud verdict sends one to the pruned scan and the other to the cell lists)."""
+    from dh3d_amd import pm
+    m = _build("basic_config", dev, seed=31)
+    pts = _scene(1, 8192, 77)
+    _run_and_compare(m, pts, dev)
+    assert int(pm.spatial_sort_cells(torch.from_numpy(pts).to(dev))[2][0, 4106]) == 1  # (this IS a crowded cloud)
+    m = _build("global_config", dev, seed=32)
+    pts = np.concatenate([_scene(1, 4096, 78), np.random.default_rng(79).random((1, 4096, 3), dtype=np.float32)])
+    flags = pm.spatial_sort_cells(torch.from_numpy(pts).to(dev))[2][:, 4106].cpu().tolist()
+    assert flags == [1, 0]
+    _run_and_compare(m, pts, dev)
+
+
 def test_cfg5_save_all_forward_N16384_vs_oracle(dev):
     """BASELINE config[4]: N=16384 (save_all path, localdesc_extract.py:146,166): with host-style kNN indices as the
     reference requires above 8192 points (core/model.py:148-155) and with the device kNN (superset)."""
