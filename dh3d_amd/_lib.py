@@ -169,6 +169,9 @@ _SIGNATURES = {
     "dh3d_se_res_pool_pm_packed_fwd": [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp],
     "dh3d_se_res_pool_conv_pm_fwd": [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp,
                                      ctypes.POINTER(Epilogue), c_int, c_fp, c_fp],
+    "dh3d_se_res_pool_conv_tails_pm_fwd": [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
+                                           ctypes.POINTER(Epilogue), c_fp, c_fp, ctypes.POINTER(Epilogue), c_fp, c_fp,
+                                           ctypes.POINTER(Epilogue), c_fp, c_fp],
     "dh3d_flex_pool_pm_fwd": [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp],
     "dh3d_flex_avg_pm_fwd": [c_fp, c_fp, c_int, c_int, c_int, c_int, c_float, c_fp, c_fp],
     "dh3d_conv_pointset_pm_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, ctypes.POINTER(Epilogue),

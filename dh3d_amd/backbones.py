@@ -234,14 +234,20 @@ class SEBlock(nn.Module):
             return pm.se_res_pool_packed(x, nbr, *packed)
         return self.forward(x, pm.flex_pool(x, nbr))
 
-    def forward_on_max_pool_then_conv(self, x, nbr, conv, act=pm.ACT_RELU):
+    def forward_on_max_pool_then_conv(self, x, nbr, conv, act=pm.ACT_RELU, tails=None):
         """(y, conv(y)) with y = forward_on_max_pool(x, nbr): one launch when the block is 64 wide and `conv` a 64 -> 64
-        Conv2D1x1 (stage 1 -> before_stage2_conv1d, core/backbones.py:115-117); same values either way."""
+        Conv2D1x1 (stage 1 -> before_stage2_conv1d, core/backbones.py:115-117); same values either way.
+        tails = (tail on y, tail on conv(y)), each (x3-packed [64,128] weight, pre_bias, scale, shift, act): two more 1x1
+        convs in the same launch -- returns (None, conv(y), tail outputs...) then (y is not stored), or the 2-tuple when
+        the fused kernel does not apply (the caller then runs the tails itself)."""
         W1, b1, W2, b2, packed = self._prep or self.prepare()
         inner = getattr(conv, "tfconv0", conv)  # FeatureConv1d wraps its Conv2D1x1
         cp = inner._prep or inner.prepare()
         if (packed is not None and x.dim() == 3 and x.shape[2] == 64 and inner.cin == 64 and inner.cout == 64
                 and "wp" in cp and not cp.get("pad")):
+            if tails is not None and SE_TAILS:
+                return pm.se_res_pool_conv_tails(x, nbr, *packed, cp["wp"], cp["b"], cp["scale"], cp["shift"], tails[0],
+                                                 tails[1], act=act, store_y=False)
             return pm.se_res_pool_conv(x, nbr, *packed, cp["wp"], cp["b"], cp["scale"], cp["shift"], act=act)
         y = self.forward_on_max_pool(x, nbr)
         return y, conv(y, act=act)
@@ -308,6 +314,9 @@ def gather_rows(points, idx):
     return out
 
 
+# dev A/B switch (DH3D_SE_TAILS=1: the local step's shortcut conv and the lower concat block ride in stage 1's SE kernel.
+# Measured slower than the three launches -- DEADENDS.md -- so off by default; the kernel stays tested)
+SE_TAILS = os.environ.get("DH3D_SE_TAILS", "0") == "1"
 # dev A/B switch (DH3D_FLEX_TX6=0: the exact-f32 MFMA tile kernel for the sampled levels)
 FLEX_TX6 = os.environ.get("DH3D_FLEX_TX6", "1") != "0"
 
@@ -459,7 +468,7 @@ class FlexConvDilate(nn.Module):
         return conv.lower_partial(feat)
 
     def forward(self, geo, feat, nbr=None, residual=None, l2cat=None, shortcut_src=None, lower_partial=None,
-                coarse_only=False, post_conv=None, post_linear=None):
+                coarse_only=False, post_conv=None, post_linear=None, post_tails=None):
         """geo: Geometry; feat [B,N,cin]; nbr [B,N,K] for dilate == 1 (else computed on the sampled set);
         residual [B,N,cout]: added to the concat conv's output in its store (the caller's shortcut branch);
         l2cat = (prefix [B,N,3], eps): return [prefix | l2_normalize(output)] instead of the output;
@@ -515,7 +524,10 @@ class FlexConvDilate(nn.Module):
             cconv = self.concat_conv1d.tfconv0 if self.concat else None
             if (post_conv is not None and not (self.upsample and self.dilate > 1) and not self.concat
                     and residual is None and l2cat is None and shortcut_src is None):
-                x, post = self.se.forward_on_max_pool_then_conv(x, nbr_s, post_conv)  # x is this block's output
+                r = self.se.forward_on_max_pool_then_conv(x, nbr_s, post_conv, tails=post_tails)
+                if len(r) == 4:  # (None, post_conv(output), tail on the output, tail on post_conv(output)): one launch
+                    return r
+                x, post = r  # x is this block's output
             elif (self.upsample and self.dilate > 1 and not coarse_only and cconv is not None and lower_partial is not None
                   and shortcut_src is None and x.shape[2] == 128 and cconv.cout == 128
                   and (self.se._prep or self.se.prepare())[4] is not None and cconv._prep.get("c_top") == 128):

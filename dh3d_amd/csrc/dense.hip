@@ -6,6 +6,7 @@
 // fragment-packed weight, and bias + BatchNorm + activation (+ residual) applied in the store.
 #include "mfma_gemm.h"
 #include "wave_ops.h"
+#include "bf16x3.h"
 
 namespace {
 
@@ -237,6 +238,78 @@ __global__ __launch_bounds__(256) void se_res_pm_kernel(const float *__restrict_
   }
 }
 
+// A 64-row f32 tile in LDS (leading dimension LDT, K = 64 columns) through one more 1x1 conv 64 -> 128 on the bf16 pipe at
+// f32 accuracy (bf16x6, as linear_k64_x6_kernel) without leaving the workgroup: wave w owns row block w & 1 and the column
+// blocks 2 (w >> 1), 2 (w >> 1) + 1; the A fragments are split in registers on their way out of LDS, the weight
+// fragments (dh3d_pack_weight_x3, L2-resident) come one K-step ahead, the result leaves from the accumulators (bias /
+// BatchNorm / ReLU in packed f32).  `tail`: {weight, epilogue, output [R, 128]}.
+struct TileTail {
+  const uint4 *wp3;
+  EpilogueArgs ep;  // act: DH3D_ACT_NONE or DH3D_ACT_RELU
+  float *out;
+};
+template <int LDT>
+__device__ __forceinline__ void tile_tail_k64_x6(const float *s_tile, const TileTail &t, long long grow0, long long R) {
+  constexpr int KB = 4, DOUT = 128;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, lr = lane & 31;
+  const int rb = wave & 1, cb0 = (wave >> 1) * 2;
+  const float *ap = s_tile + (size_t)(rb * 32 + lr) * LDT + 8 * half;
+  const uint4 *wl = t.wp3 + lane;
+  uint4 bq[2][2][3];
+  auto load_b = [&](int ks) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bq[ks & 1][c][p] = wl[((size_t)((cb0 + c) * KB + ks) * 3 + p) * 64];
+  };
+  load_b(0);
+  float pb[2], sc[2], sh[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int col = (cb0 + c) * 32 + lr;
+    pb[c] = t.ep.pre_bias ? t.ep.pre_bias[col] : 0.f;
+    sc[c] = t.ep.scale ? t.ep.scale[col] : 1.f;
+    sh[c] = t.ep.shift ? t.ep.shift[col] : 0.f;
+  }
+  f32x16 acc[2];
+  zero_acc<2>(acc);
+#pragma unroll
+  for (int ks = 0; ks < KB; ++ks) {
+    if (ks + 1 < KB) load_b(ks + 1);
+    const float4 a0 = *reinterpret_cast<const float4 *>(ap + ks * 16), a1 = *reinterpret_cast<const float4 *>(ap + ks * 16 + 4);
+    __builtin_amdgcn_sched_barrier(0);
+    uint2 c1[2], c2[2], c3[2];
+    split3x4(a0, c1[0], c2[0], c3[0]);
+    split3x4(a1, c1[1], c2[1], c3[1]);
+    bf16x8 a[3];
+    a[0] = __builtin_bit_cast(bf16x8, make_uint4(c1[0].x, c1[0].y, c1[1].x, c1[1].y));
+    a[1] = __builtin_bit_cast(bf16x8, make_uint4(c2[0].x, c2[0].y, c2[1].x, c2[1].y));
+    a[2] = __builtin_bit_cast(bf16x8, make_uint4(c3[0].x, c3[0].y, c3[1].x, c3[1].y));
+#define DH3D_TT_PRODUCT(PA, PB)                                                                           \
+  _Pragma("unroll") for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(        \
+      a[PA], __builtin_bit_cast(bf16x8, bq[ks & 1][c][PB]), acc[c], 0, 0, 0);
+    DH3D_TT_PRODUCT(2, 0) DH3D_TT_PRODUCT(0, 2) DH3D_TT_PRODUCT(1, 1)
+    DH3D_TT_PRODUCT(1, 0) DH3D_TT_PRODUCT(0, 1) DH3D_TT_PRODUCT(0, 0)
+#undef DH3D_TT_PRODUCT
+  }
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const float lo = t.ep.act == DH3D_ACT_RELU ? 0.f : -__builtin_inff();  // ReLU as a clamp, or no activation
+  const long long row0 = grow0 + rb * 32 + 4 * half;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    float *op = t.out + row0 * DOUT + (cb0 + c) * 32 + lr;
+    const v2f pb2 = {pb[c], pb[c]}, sc2 = {sc[c], sc[c]}, sh2 = {sh[c], sh[c]}, lo2 = {lo, lo};
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      v2f y = {acc[c][r], acc[c][r + 1]};
+      y = __builtin_elementwise_max(__builtin_elementwise_fma(y + pb2, sc2, sh2), lo2);
+      const int t0 = (r & 3) + 8 * (r >> 2);
+      if (row0 + t0 < R) op[t0 * DOUT] = y[0];
+      if (row0 + t0 + 1 < R) op[(t0 + 1) * DOUT] = y[1];
+    }
+  }
+}
+
 // The same block on the matrix pipe.  The VALU version above issues ~1700 ds_read_b32 per lane (one per weight) and
 // needs 25-30 us per 64-row tile; here the two small GEMMs run on v_mfma_f32_32x32x2_f32 against weights packed with
 // dh3d_pack_weight (W1 padded to 32 columns, W2 to 32 rows: the padding contributes exact zeros):
@@ -251,14 +324,19 @@ __global__ __launch_bounds__(256) void se_res_pm_kernel(const float *__restrict_
 // the tile is not read back and a launch on the global path's critical chain disappears.
 // TMR: rows per workgroup -- 64, or 32 (C == 128) for launches with fewer 64-row tiles than CUs (the sampled levels:
 // 8192 rows = 128 tiles on 256 CUs, every phase of the tile behind a barrier).
-template <int C, bool POOL, bool CONV, int TMR = kTM>
+// TAILS (C = 64, CONV): two more 64 -> 128 convs ride in the launch -- tail A on the block's output, tail B on the conv's
+// output (the local step's shortcut conv and the commuted concat conv's lower block: two launches over the tiles this
+// kernel already holds); `out` may then be NULL (nothing else reads the block's output).
+template <int C, bool POOL, bool CONV, int TMR = kTM, bool TAILS = false>
 __global__ __launch_bounds__(256) void se_res_mfma_kernel(const float *__restrict__ x, const float *__restrict__ pool,
                                                          const int32_t *__restrict__ nbr, int N, int K,
                                                          const float *__restrict__ w1p, const float *__restrict__ b1p,
                                                          const float *__restrict__ w2p, const float *__restrict__ b2,
                                                          long long R, float *__restrict__ out,
                                                          const float *__restrict__ wconv, EpilogueArgs cep,
-                                                         float *__restrict__ out2) {
+                                                         float *__restrict__ out2, TileTail ta = TileTail{},
+                                                         TileTail tb = TileTail{}) {
+  static_assert(!TAILS || (C == 64 && CONV && TMR == 64), "tails: the 64-wide block with its conv, 64-row tiles");
   constexpr int LDP = C + 4;   // pooled rows, later the gate tile
   constexpr int LDH = 32 + 4;  // hidden rows
   static_assert(TMR == 64 || (TMR == 32 && C == 128 && POOL), "32-row tiles: four column blocks for four waves; pooled staging only");
@@ -383,7 +461,7 @@ __global__ __launch_bounds__(256) void se_res_mfma_kernel(const float *__restric
         r.x = xv.x + xv.x * gt.x; r.y = xv.y + xv.y * gt.y; r.z = xv.z + xv.z * gt.z; r.w = xv.w + xv.w * gt.w;
         r.x = r.x > 0.f ? r.x : 0.f; r.y = r.y > 0.f ? r.y : 0.f;
         r.z = r.z > 0.f ? r.z : 0.f; r.w = r.w > 0.f ? r.w : 0.f;
-        *reinterpret_cast<float4 *>(out + g * C + c4) = r;
+        if (!TAILS || out) *reinterpret_cast<float4 *>(out + g * C + c4) = r;
         if (CONV) *reinterpret_cast<float4 *>(s_p + (size_t)p * LDP + c4) = r;  // over its own gate entry
       } else if (CONV) {
         *reinterpret_cast<float4 *>(s_p + (size_t)p * LDP + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -399,11 +477,13 @@ __global__ __launch_bounds__(256) void se_res_mfma_kernel(const float *__restric
     EpilogueRegs er[NTC];
 #pragma unroll
     for (int j = 0; j < NTC; ++j) er[j] = epilogue_prefetch(cep, (cb0 + CBC * j) * 32 + (lane & 31));
+    if constexpr (TAILS) tile_tail_k64_x6<LDP>(s_p, ta, grow0, R);  // on the block's output tile
     wave_gemm_f32<NTC>(s_p, LDP, row0, wconv, C / 8, cb0, CBC, acc);
     __syncthreads();
     wave_tiles_to_lds<NTC>(acc, er, cep.act, s_p, LDP, row0, cb0, CBC);
     __syncthreads();
     block_store_rows(s_p, LDP, TMR, grow0, R, C, nullptr, out2);
+    if constexpr (TAILS) tile_tail_k64_x6<LDP>(s_p, tb, grow0, R);  // on the conv's output tile
   }
 }
 
@@ -674,6 +754,26 @@ DH3D_API int dh3d_se_res_pool_conv_pm_fwd(const float *x, const int32_t *nbr, in
   else
     hipLaunchKernelGGL((se_res_mfma_kernel<128, true, true>), dim3(dh3d_cdiv(R, kTM)), dim3(256), 0, (hipStream_t)stream, x,
                        x, nbr, N, K, w1packed, b1pad, w2packed, b2, R, out, wconv_packed, dh3d_ep(ep), out2);
+  return dh3d_launch_status();
+}
+
+// dh3d_se_res_pool_conv_pm_fwd (C = 64) with two more 1x1 convs 64 -> 128 in the launch, on the bf16 pipe at f32 accuracy:
+// out_a = act_a(bn_a(y @ Wa)) on the block's output y, out_b = act_b(bn_b(z @ Wb)) on z = the 64 -> 64 conv's output
+// (Wa / Wb = dh3d_pack_weight_x3 of [64, 128]; act NONE or RELU).  `out` (y) may be NULL: not stored.
+DH3D_API int dh3d_se_res_pool_conv_tails_pm_fwd(const float *x, const int32_t *nbr, int B, int N, int K, const float *w1packed,
+                                                const float *b1pad, const float *w2packed, const float *b2, float *out,
+                                                const float *wconv_packed, const dh3d_epilogue *ep, float *out2,
+                                                const void *wa_x3, const dh3d_epilogue *ep_a, float *out_a,
+                                                const void *wb_x3, const dh3d_epilogue *ep_b, float *out_b, void *stream) {
+  DH3D_REQUIRE(x && nbr && w1packed && b1pad && w2packed && b2 && wconv_packed && out2 && wa_x3 && out_a && wb_x3 && out_b &&
+               B > 0 && N > 0 && K > 0);
+  const EpilogueArgs ea = dh3d_ep(ep_a), eb = dh3d_ep(ep_b);
+  DH3D_SUPPORTED((!ep || ep->act != DH3D_ACT_SIGMOID) && ea.act != DH3D_ACT_SIGMOID && eb.act != DH3D_ACT_SIGMOID);
+  const long long R = (long long)B * N;
+  const TileTail ta{static_cast<const uint4 *>(wa_x3), ea, out_a}, tb{static_cast<const uint4 *>(wb_x3), eb, out_b};
+  hipLaunchKernelGGL((se_res_mfma_kernel<64, true, true, 64, true>), dim3(dh3d_cdiv(R, kTM)), dim3(256), 0,
+                     (hipStream_t)stream, x, x, nbr, N, K, w1packed, b1pad, w2packed, b2, R, out, wconv_packed, dh3d_ep(ep),
+                     out2, ta, tb);
   return dh3d_launch_status();
 }
 

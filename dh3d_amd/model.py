@@ -256,6 +256,20 @@ class DH3D(nn.Module):
             geo.nbr.record_stream(main)
         return geo
 
+    def _stage1_tails(self, n_per_cloud):
+        """(tail on stage 1's output, tail on before_stage2_conv1d's output) for FlexConvDilate.forward(post_tails=...), or
+        None where the separate launches are what applies (the same rules as Conv2D1x1.forward / commuted_partial: the
+        points per cloud only, never the batch)."""
+        sc = self.local_stage1_shortcut.tfconv0
+        cc = self.stage2.concat_conv1d.tfconv0 if self.stage2.concat else None
+        if (cc is None or n_per_cloud <= 4096 or not (self.stage2.upsample and self.stage2.dilate > 1)
+                or not cc.commuted_supported(self.stage2.outdims[-1]) or sc.cin != 64 or sc.cout != 128):
+            return None
+        ps, pc = sc._prep or sc.prepare(), cc._prep or cc.prepare()
+        if "wp3" not in ps or "wp3_bot" not in pc or pc["W2"].shape[0] - pc.get("c_top", 0) != 64 or cc.cout != 128:
+            return None
+        return ((ps["wp3"], ps["b"], ps["scale"], ps["shift"], pm.ACT_RELU), (pc["wp3_bot"], None, None, None, pm.ACT_NONE))
+
     @staticmethod
     def _side_is_critical(points):
         """Which of the step's two chains ends last (measured model, MI355X): the FPS chain costs ~0.05 us per point of
@@ -281,8 +295,16 @@ class DH3D(nn.Module):
             # conv_pointset 3 -> 32, BNReLU, flex_pool (backbones.py:107-110) fused: the map between them is not built
             init = pm.conv_pointset_pool_xyz(geo.xyz, nn_8, p["theta"], p["bias"], scale=p["scale"], shift=p["shift"],
                                              act=pm.ACT_RELU)
-            r = self.stage1(geo, init, nbr=nn_8, post_conv=self.before_stage2_conv1d)
-            x1, x2 = r if isinstance(r, tuple) else (r, self.before_stage2_conv1d(r, act=pm.ACT_RELU))
+            # larger clouds: the shortcut conv (on stage 1's output) and the lower block of stage 2's commuted concat conv
+            # (on before_stage2_conv1d's output) ride in stage 1's SE kernel -- two launches over tiles it already holds
+            fuse_sc = points.shape[1] <= 4096 and self.stage2.shortcut_fusable(points.shape[1])
+            tails = None if fuse_sc else self._stage1_tails(points.shape[1])
+            r = self.stage1(geo, init, nbr=nn_8, post_conv=self.before_stage2_conv1d, post_tails=tails)
+            shortcut = lower = None
+            if isinstance(r, tuple) and len(r) == 4:
+                x1, x2, shortcut, lower = r
+            else:
+                x1, x2 = r if isinstance(r, tuple) else (r, self.before_stage2_conv1d(r, act=pm.ACT_RELU))
             # BNReLU(conv(x1)) + stage2 (backbones.py:123).  Large clouds: the shortcut conv runs INSIDE stage 2's last
             # conv (its input x1 is just more K for that GEMM, with its own accumulators and epilogue), so its
             # [Bt,N,128] result is never written or read back.  Otherwise it runs here, beside the FPS chain, and its
@@ -292,12 +314,13 @@ class DH3D(nn.Module):
             #  A/B: cfg 3 -23 us, cfg 2 +6 us.  The rule looks at the points per cloud only, never at the batch: the
             #  two forms differ in the rounding of the final sum and a sharded batch must reproduce the unsharded
             #  result bit for bit.)
-            fuse_sc = points.shape[1] <= 4096 and self.stage2.shortcut_fusable(points.shape[1])
-            shortcut = None if fuse_sc else self.local_stage1_shortcut(x1, act=pm.ACT_RELU)
+            if shortcut is None and not fuse_sc:
+                shortcut = self.local_stage1_shortcut(x1, act=pm.ACT_RELU)
             # larger clouds: stage 2's concat conv is commuted through its up-sampling -- its lower weight block meets
             # x2 here, beside the sampling chain; behind the sampled level only a GEMM on the N/8 rows and one
             # gather / epilogue kernel are left (backbones.Conv2D1x1.forward_commuted)
-            lower = None if fuse_sc else self.stage2.commuted_partial(x2)
+            if lower is None and not fuse_sc:
+                lower = self.stage2.commuted_partial(x2)
             if _prezero_tail and getattr(geo, "_tail_accum", None) is None:
                 # the global tail's accumulators (6 MB at cfg 3), zero-filled HERE, beside the sampling chain: the fill
                 # (a ~5 us node + its dependency gap) is off the critical chain when the tail starts

@@ -372,6 +372,29 @@ def se_res_pool_conv(x, nbr, w1packed, b1pad, w2packed, b2, conv_wp, conv_b, con
     return out, out2
 
 
+def se_res_pool_conv_tails(x, nbr, w1packed, b1pad, w2packed, b2, conv_wp, conv_b, conv_scale, conv_shift, tail_a, tail_b,
+                           act=ACT_RELU, store_y=True):
+    """se_res_pool_conv (C = 64) with two more 1x1 convs 64 -> 128 in the launch (bf16x6): tail_a on the block's output y,
+    tail_b on z = conv(y); a tail = (pack_weight_x3 of [64, 128], pre_bias, scale, shift, act) with act NONE or RELU.
+    Returns (y or None, z, out_a [B,N,128], out_b [B,N,128])."""
+    a = L.require_cuda_f32(x, "x", 3)
+    nb = L.require_cuda_i32(nbr, "nbr", 3)
+    B, N, C = a.shape
+    if C != 64:
+        raise ValueError("se_res_pool_conv_tails: C == 64")
+    y = torch.empty_like(a) if store_y else None
+    z = torch.empty((B, N, C), dtype=torch.float32, device=a.device)
+    oa = torch.empty((B, N, 128), dtype=torch.float32, device=a.device)
+    ob = torch.empty((B, N, 128), dtype=torch.float32, device=a.device)
+    ep = _ep(conv_b, conv_scale, conv_shift, act)
+    ea, eb = _ep(*tail_a[1:5]), _ep(*tail_b[1:5])
+    L.check(L.lib().dh3d_se_res_pool_conv_tails_pm_fwd(L.ptr(a), L.ptr(nb), B, N, nb.shape[2], L.ptr(w1packed), L.ptr(b1pad),
+                                                       L.ptr(w2packed), L.ptr(b2), L.ptr(y), L.ptr(conv_wp), ep, L.ptr(z),
+                                                       L.ptr(tail_a[0]), ea, L.ptr(oa), L.ptr(tail_b[0]), eb, L.ptr(ob),
+                                                       L.stream_ptr()), "se_res_pool_conv_tails_pm")
+    return y, z, oa, ob
+
+
 def three_interpolate_idw(points, idx, dist):
     p = L.require_cuda_f32(points, "points", 3)
     ix = L.require_cuda_i32(idx, "idx", 3)

@@ -367,6 +367,17 @@ int dh3d_se_res_pool_conv_pm_fwd(const float *x, const int32_t *nbr, int B, int 
                                  const float *b1pad, const float *w2packed, const float *b2, int C, float *out,
                                  const float *wconv_packed, const dh3d_epilogue *ep, int Dout, float *out2, void *stream);
 
+/* dh3d_se_res_pool_conv_pm_fwd for C = Dout = 64 with two more 1x1 convs 64 -> 128 riding in the launch, on the bf16 pipe at
+ * f32 accuracy: out_a = act_a(bn_a(y @ Wa)) on the block's output y (out), out_b = act_b(bn_b(z @ Wb)) on z = the 64 -> 64
+ * conv's output (out2).  wa_x3 / wb_x3 = dh3d_pack_weight_x3 of [64, 128]; act NONE or RELU.  out may be NULL (y is not
+ * stored).  The local step: stage 1's SE block + before_stage2_conv1d + local_stage1_shortcut + the lower block of stage 2's
+ * commuted concat conv (core/backbones.py:115-123) -- one launch instead of three over the same tiles. */
+int dh3d_se_res_pool_conv_tails_pm_fwd(const float *x, const int32_t *nbr, int B, int N, int K, const float *w1packed,
+                                       const float *b1pad, const float *w2packed, const float *b2, float *out,
+                                       const float *wconv_packed, const dh3d_epilogue *ep, float *out2, const void *wa_x3,
+                                       const dh3d_epilogue *ep_a, float *out_a, const void *wb_x3,
+                                       const dh3d_epilogue *ep_b, float *out_b, void *stream);
+
 /* three_nn + inverse-distance weights + three_interpolate (core/backbones.py:90-96) fused:
  * weight = (1/max(d,1e-10)) / sum(1/max(d,1e-10)).  idx/dist from dh3d_three_nn.
  * points [b,m,c] -> out [b,n,c]; c % 4 == 0. */

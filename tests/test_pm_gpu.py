@@ -392,6 +392,37 @@ def test_se_res_pool_conv_fused_equals_separate_kernels(dev, B, N, C):
     assert torch.equal(z, z_ref)
 
 
+@pytest.mark.parametrize("B,N", [(3, 2000), (8, 8192), (2, 77)])
+def test_se_res_pool_conv_with_two_tails_equals_separate_kernels(dev, B, N):
+    """Stage 1's SE block + before_stage2_conv1d + the shortcut conv (on the block's output) + the commuted concat conv's
+    lower block (on the conv's output) in ONE launch == the fused SE + conv kernel followed by linear_x6 twice: the conv's
+    output bit for bit, the tails to rounding of the same bf16x6 products (ragged last tile, clouds smaller than a tile)."""
+    from dh3d_amd import pm
+    g = torch.Generator().manual_seed(N)
+    C = 64
+    x = torch.randn(B, N, C, generator=g).to(dev)
+    nbr, _ = pm.knn_xyz(torch.rand(B, N, 3, generator=g).to(dev), 8)
+    W1 = (torch.randn(C, C // 4, generator=g) / 8).to(dev); b1 = torch.randn(C // 4, generator=g).to(dev)
+    W2 = (torch.randn(C // 4, C, generator=g) / 4).to(dev); b2 = torch.randn(C, generator=g).to(dev)
+    Wc = (torch.randn(C, C, generator=g) / 8).to(dev); bc = torch.randn(C, generator=g).to(dev)
+    sc = (0.5 + torch.rand(C, generator=g)).to(dev); sh = torch.randn(C, generator=g).to(dev)
+    Wa = (torch.randn(C, 128, generator=g) / 8).to(dev); ba = torch.randn(128, generator=g).to(dev)
+    sa = (0.5 + torch.rand(128, generator=g)).to(dev); ha = torch.randn(128, generator=g).to(dev)
+    Wb = (torch.randn(C, 128, generator=g) / 8).to(dev)
+    packed = pm.se_res_pack(W1, b1, W2)
+    y_ref, z_ref = pm.se_res_pool_conv(x, nbr, *packed, b2, pm.pack_weight(Wc), bc, sc, sh)
+    a_ref = pm.linear_x6(y_ref, pm.pack_weight_x3(Wa), 128, pre_bias=ba, scale=sa, shift=ha, act=pm.ACT_RELU)
+    b_ref = pm.linear_x6(z_ref, pm.pack_weight_x3(Wb), 128)
+    ta = (pm.pack_weight_x3(Wa), ba, sa, ha, pm.ACT_RELU)
+    tb = (pm.pack_weight_x3(Wb), None, None, None, pm.ACT_NONE)
+    y, z, oa, ob = pm.se_res_pool_conv_tails(x, nbr, *packed, b2, pm.pack_weight(Wc), bc, sc, sh, ta, tb)
+    assert torch.equal(y, y_ref) and torch.equal(z, z_ref)
+    for got, ref in ((oa, a_ref), (ob, b_ref)):
+        assert (got - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    y2, z2, oa2, ob2 = pm.se_res_pool_conv_tails(x, nbr, *packed, b2, pm.pack_weight(Wc), bc, sc, sh, ta, tb, store_y=False)
+    assert y2 is None and torch.equal(z2, z) and torch.equal(oa2, oa) and torch.equal(ob2, ob)
+
+
 def test_interpolate_idw_l2norm_and_head(dev, oracle):
     from dh3d_amd import ops, pm
     rng = np.random.default_rng(6)
