@@ -444,16 +444,29 @@ __global__ __launch_bounds__(256) void pointset_pool_kernel(const float4 *__rest
   float4 s[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) s[k] = S[cloud0 + (unsigned)id[k]];
-  float4 best = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+  // max_k act(sc * ((theta . S_k + bias) + pb) + sh): every step after theta . S_k is a monotone function of it (rounded
+  // additions and multiplications by a constant are monotone; relu / sigmoid / identity too) -- non-decreasing for
+  // sc >= 0, non-increasing for sc < 0 -- so the maximum over the neighbours is that function of the largest (smallest)
+  // theta . S_k: three products and one max per (neighbour, channel), the epilogue ONCE per channel.  Bit-identical to
+  // evaluating it per neighbour (the same operations meet the same operand).
+  const float4 sg = make_float4(q.sc.x < 0.f ? -1.f : 1.f, q.sc.y < 0.f ? -1.f : 1.f, q.sc.z < 0.f ? -1.f : 1.f,
+                                q.sc.w < 0.f ? -1.f : 1.f);
+  const float4 ux = make_float4(tx.x * sg.x, tx.y * sg.y, tx.z * sg.z, tx.w * sg.w);  // (exact sign flips)
+  const float4 uy = make_float4(ty.x * sg.x, ty.y * sg.y, ty.z * sg.z, ty.w * sg.w);
+  const float4 uz = make_float4(tz.x * sg.x, tz.y * sg.y, tz.z * sg.z, tz.w * sg.w);
+  float4 m = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    float4 v;
-    v.x = dh3d_act(((fmaf(tz.x, s[k].z, fmaf(ty.x, s[k].y, tx.x * s[k].x)) + bq.x) + q.pb.x) * q.sc.x + q.sh.x, act);
-    v.y = dh3d_act(((fmaf(tz.y, s[k].z, fmaf(ty.y, s[k].y, tx.y * s[k].x)) + bq.y) + q.pb.y) * q.sc.y + q.sh.y, act);
-    v.z = dh3d_act(((fmaf(tz.z, s[k].z, fmaf(ty.z, s[k].y, tx.z * s[k].x)) + bq.z) + q.pb.z) * q.sc.z + q.sh.z, act);
-    v.w = dh3d_act(((fmaf(tz.w, s[k].z, fmaf(ty.w, s[k].y, tx.w * s[k].x)) + bq.w) + q.pb.w) * q.sc.w + q.sh.w, act);
-    best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y); best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
+    m.x = fmaxf(m.x, fmaf(uz.x, s[k].z, fmaf(uy.x, s[k].y, ux.x * s[k].x)));
+    m.y = fmaxf(m.y, fmaf(uz.y, s[k].z, fmaf(uy.y, s[k].y, ux.y * s[k].x)));
+    m.z = fmaxf(m.z, fmaf(uz.z, s[k].z, fmaf(uy.z, s[k].y, ux.z * s[k].x)));
+    m.w = fmaxf(m.w, fmaf(uz.w, s[k].z, fmaf(uy.w, s[k].y, ux.w * s[k].x)));
   }
+  float4 best;
+  best.x = dh3d_act(((m.x * sg.x + bq.x) + q.pb.x) * q.sc.x + q.sh.x, act);
+  best.y = dh3d_act(((m.y * sg.y + bq.y) + q.pb.y) * q.sc.y + q.sh.y, act);
+  best.z = dh3d_act(((m.z * sg.z + bq.z) + q.pb.z) * q.sc.z + q.sh.z, act);
+  best.w = dh3d_act(((m.w * sg.w + bq.w) + q.pb.w) * q.sc.w + q.sh.w, act);
   *reinterpret_cast<float4 *>(out + (size_t)n * Dout + c4) = best;
 }
 
