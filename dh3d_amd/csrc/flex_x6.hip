@@ -21,12 +21,14 @@
 // instructions: neighbour offsets are computed ONCE per (point, neighbour) by one lane and broadcast with DPP
 // moves (not 16x redundantly), the bf16 split uses packed subtracts, and everything else the producers do
 // (addresses, masks, byte permutes, LDS writes, loads) runs in the shadow of the consumers' MFMAs.
+#include <type_traits>
+
 #include "bf16x3.h"
 
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x3 __attribute__((ext_vector_type(3)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kTM = 32;   // points per tile
 constexpr int kPPR = 32;  // points per producer round (16 lanes per point, 8 producer waves)
 constexpr int kProducers = 8 * 64, kThreads = kProducers + 256;
@@ -39,13 +41,11 @@ struct X6Cfg {
   static constexpr int KBH = KB / 2;                 // k-blocks per consumer wave (one K-half)
   static constexpr int VEC = DIN / 16;               // channels per producer lane
   static constexpr int ROUNDS = kTM / kPPR;          // rounds per tile
-  static constexpr int PLD = DOUT + 4;               // leading dimension of a partial tile (floats)
   static constexpr int A_ELEMS = 3 * kTM * LD;       // bf16 elements per S buffer
-  static constexpr int P_FLOATS = 2 * kTM * PLD;     // floats per partial buffer (two K-halves)
-  static constexpr int CV = DOUT / 4;                // float4 per output row
-  static constexpr int RP = 256 / CV;                // rows per reduce pass
-  static constexpr size_t LDS_BYTES = (size_t)2 * A_ELEMS * 2 + (size_t)2 * P_FLOATS * 4;
-  static_assert(DOUT == 64 && (VEC == 2 || VEC == 4) && KBH % 2 == 0 && kTM % RP == 0, "shape");
+  static constexpr int P_FLOATS = 4 * 8 * 64;        // floats per partial buffer: four consumer waves x half an accumulator tile
+  static constexpr int B3_VEC = 2 * KB * 64;         // uint4 per third weight plane (two column blocks x KB fragments)
+  static constexpr size_t LDS_BYTES = (size_t)2 * A_ELEMS * 2 + (size_t)2 * P_FLOATS * 4 + (size_t)B3_VEC * 16;
+  static_assert(DOUT == 64 && (VEC == 2 || VEC == 4) && KBH % 2 == 0 && LDS_BYTES <= 159 * 1024, "shape");
 };
 
 #ifdef DH3D_X6_PROBE  // dev instrumentation (tools/x6_probe.py): cycle stamps of one workgroup's two roles
@@ -80,15 +80,15 @@ __device__ __forceinline__ float row_bcast(float v) {
 
 __device__ __forceinline__ float hi16_of(float a) { return __uint_as_float(__float_as_uint(a) & 0xFFFF0000u); }
 
-// two f32 -> three dwords of two bf16 each; the subtractions are packed (one FP instruction per pair)
+// two f32 -> three dwords of two bf16 each.  The subtractions are SCALAR f32 instructions on purpose: on gfx950 a
+// packed-f32 VALU instruction (v_pk_add_f32 / v_pk_fma_f32) occupies the matrix pipe -- it serialises with every
+// wave's MFMAs on the SIMD -- while scalar f32 VALU work runs beside them (tools/coissue_probe2.hip, profiles/r05_a_*)
 __device__ __forceinline__ void split3x2(const f32x2 v, unsigned &c1, unsigned &c2, unsigned &c3) {
-  const f32x2 a = {hi16_of(v[0]), hi16_of(v[1])};
-  const f32x2 r = v - a;
-  const f32x2 b = {hi16_of(r[0]), hi16_of(r[1])};
-  const f32x2 t = r - b;
+  const float r0 = v[0] - hi16_of(v[0]), r1 = v[1] - hi16_of(v[1]);
+  const float t0 = r0 - hi16_of(r0), t1 = r1 - hi16_of(r1);
   c1 = pack_hi16(v[0], v[1]);
-  c2 = pack_hi16(r[0], r[1]);
-  c3 = pack_hi16(t[0], t[1]);
+  c2 = pack_hi16(r0, r1);
+  c3 = pack_hi16(t0, t1);
 }
 
 template <int VEC> struct LaneVec;
@@ -121,14 +121,21 @@ __global__ __launch_bounds__(kThreads) void flex_conv_x6_kernel(
     // FP32 VALU work only issues in the gaps of the consumers' MFMA stream: with the producers ahead in the issue
     // arbitration those gaps open as soon as an FP instruction is ready instead of at the end of a GEMM burst
     // (measured 26.9 -> 25.9 us per launch)
-    __builtin_amdgcn_s_setprio(3);
+#ifndef DH3D_X6_PRIO
+#define DH3D_X6_PRIO 1
+#endif
+    if (DH3D_X6_PRIO & 1) __builtin_amdgcn_s_setprio(3);
     const int prow = tid >> 4, lj = tid & 15;
     const int c0 = lj * C::VEC;  // first channel of this lane
     const unsigned mrec = (unsigned)(0x100000000ULL / N);
     const int G = cnt * C::ROUNDS;  // rounds of this workgroup
-    int nid[2][8], myid[2];
+    int nid[2][8], myid[2][2];
     FV fv[2][8];
-    f32x3 qv[2], pc[2];  // whole 12-byte vectors: a loop-carried load result must stay one register tuple
+    float qd[2][2], pcd[2];
+    // neighbour offsets, one dword per lane (see compute): lane l of a point's 16 lanes is (slot a = (l >> 2) & 3,
+    // component i = l & 3) and holds [-, dx, dy, dz][i] of neighbours a and a + 4
+    const int da = (tid >> 2) & 3, di = tid & 3;
+    const int dcomp = di > 0 ? di - 1 : 0;   // (lanes with i = 0 are never read)
 
     // rounds at or past G are dummies (row 0 again, into the idle buffer): the pipeline below then has no
     // conditional loads -- a load under a branch is merged through register copies that wait for it
@@ -145,7 +152,8 @@ __global__ __launch_bounds__(kThreads) void flex_conv_x6_kernel(
       const int4 a = ip[0], b = ip[1];
       nid[s][0] = a.x; nid[s][1] = a.y; nid[s][2] = a.z; nid[s][3] = a.w;
       nid[s][4] = b.x; nid[s][5] = b.y; nid[s][6] = b.z; nid[s][7] = b.w;
-      myid[s] = nbr[(size_t)n * 8 + (lj & 7)];  // lane j (and j+8) looks after neighbour j's coordinates
+      myid[s][0] = nbr[(size_t)n * 8 + da];
+      myid[s][1] = nbr[(size_t)n * 8 + 4 + da];
     };
     auto issue_feat = [&](int s, int g) {
       unsigned n; bool ok;
@@ -153,8 +161,9 @@ __global__ __launch_bounds__(kThreads) void flex_conv_x6_kernel(
       unsigned q = __umulhi(n, mrec);  // floor(n / N) or one less
       if (n - q * N >= N) ++q;
       const unsigned cloud0 = q * N;
-      __builtin_memcpy(&pc[s], xyz + (size_t)n * 3, 12);
-      __builtin_memcpy(&qv[s], reinterpret_cast<const char *>(xyz) + (size_t)((cloud0 + (unsigned)myid[s]) * 12u), 12);
+      pcd[s] = xyz[(size_t)n * 3 + dcomp];
+      qd[s][0] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(xyz) + (size_t)((cloud0 + (unsigned)myid[s][0]) * 12u + (unsigned)dcomp * 4u));
+      qd[s][1] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(xyz) + (size_t)((cloud0 + (unsigned)myid[s][1]) * 12u + (unsigned)dcomp * 4u));
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const unsigned g2 = cloud0 + (unsigned)nid[s][k];
@@ -165,32 +174,55 @@ __global__ __launch_bounds__(kThreads) void flex_conv_x6_kernel(
     auto compute = [&](int s, int g) {
       // (rows past R and dummy rounds read point 0: finite values in S rows whose outputs are never stored)
       const int i = g / C::ROUNDS, r = g % C::ROUNDS;
-      // neighbour offsets: once per (point, neighbour), then broadcast along the point's 16 lanes
-      const float rx = qv[s][0] - pc[s][0], ry = qv[s][1] - pc[s][1], rz = qv[s][2] - pc[s][2];
+      // The K-neighbour reduce  S_c[ch] = sum_k [1, dx, dy, dz]_k[c] * f_k[ch]  in SCALAR f32 VALU instructions.  Measured
+      // on gfx950 (tools/coissue_probe2.hip, profiles/r05_*_coissue_probe2.txt): scalar-f32 and integer VALU work of
+      // one wave issues freely while another wave's MFMAs run; a packed-f32 instruction (v_pk_fma_f32) occupies the
+      // matrix pipe; and ANY matrix-pipe instruction of a second wave (packed f32, or this reduce as
+      // v_mfma_f32_4x4x1_16b_f32: 4x fewer issue slots) starves behind a wave that streams MFMAs back to back -- the
+      // two waves' times add.  So the producers stay off the matrix pipe entirely.
+      // Lane (a, i) of a point's 16 lanes holds component i of [1, dx, dy, dz] for neighbours a (d0) and a + 4 (d1);
+      // component c of neighbour k is broadcast along the row from lane 4 (k & 3) + c.
+      float d0 = qd[s][0] - pcd[s], d1 = qd[s][1] - pcd[s];
+      // (a DPP read of a VGPR needs two wait states after the VALU write; the compiler cannot see into the asm below)
+      asm volatile("s_nop 1" : "+v"(d0), "+v"(d1));
       f32x2 acc[4][C::VEC / 2];  // [S0, Sx, Sy, Sz][channel pair]
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int h = 0; h < C::VEC / 2; ++h) acc[c][h] = f32x2{0.f, 0.f};
-#define X6_ACC(a0, a1, a2, a3, f, dx2, dy2, dz2)                                                                \
-  a0 += f;                                                                                                      \
-  a1 = __builtin_elementwise_fma(dx2, f, a1);                                                                   \
-  a2 = __builtin_elementwise_fma(dy2, f, a2);                                                                   \
-  a3 = __builtin_elementwise_fma(dz2, f, a3);
-#define DH3D_X6_NEIGHBOUR(KI)                                                                                    \
+      // acc += bcast(row lane L of d) * f as ONE instruction: v_fmac_f32 with the DPP row broadcast on its first
+      // source (the compiler keeps a separate v_mov_b32_dpp per broadcast value: 24 more VALU issue slots per round)
+#define DH3D_X6_FMAC_BCAST(ACC, D, F, L) \
+  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:" #L " row_mask:0xf bank_mask:0xf" : "+v"(ACC) : "v"(D), "v"(F))
+#define DH3D_X6_MUL_BCAST(ACC, D, F, L) \
+  asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:" #L " row_mask:0xf bank_mask:0xf" : "=v"(ACC) : "v"(D), "v"(F))
+#define DH3D_X6_NEIGHBOUR_(KI, DS, LX, LY, LZ)                                                                   \
   {                                                                                                              \
-    const float dx = row_bcast<KI>(rx), dy = row_bcast<KI>(ry), dz = row_bcast<KI>(rz);                          \
-    const f32x2 dx2 = {dx, dx}, dy2 = {dy, dy}, dz2 = {dz, dz};                                                  \
     const float *fp = reinterpret_cast<const float *>(&fv[s][KI]);                                               \
     _Pragma("unroll") for (int h = 0; h < C::VEC / 2; ++h) {                                                     \
-      const f32x2 f = {fp[2 * h], fp[2 * h + 1]};                                                                \
-      X6_ACC(acc[0][h], acc[1][h], acc[2][h], acc[3][h], f, dx2, dy2, dz2)                                       \
+      _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                            \
+        const float f = fp[2 * h + e];                                                                           \
+        if ((KI) == 0) {  /* (fma(d, f, 0) == d * f exactly) */                                                  \
+          acc[0][h][e] = f;                                                                                      \
+          DH3D_X6_MUL_BCAST(acc[1][h][e], DS, f, LX);                                                            \
+          DH3D_X6_MUL_BCAST(acc[2][h][e], DS, f, LY);                                                            \
+          DH3D_X6_MUL_BCAST(acc[3][h][e], DS, f, LZ);                                                            \
+        } else {                                                                                                 \
+          acc[0][h][e] += f;                                                                                     \
+          DH3D_X6_FMAC_BCAST(acc[1][h][e], DS, f, LX);                                                           \
+          DH3D_X6_FMAC_BCAST(acc[2][h][e], DS, f, LY);                                                           \
+          DH3D_X6_FMAC_BCAST(acc[3][h][e], DS, f, LZ);                                                           \
+        }                                                                                                        \
+      }                                                                                                          \
     }                                                                                                            \
   }
+#define DH3D_X6_NEIGHBOUR(KI)                                                                                    \
+  if (((KI) & 3) == 0) DH3D_X6_NEIGHBOUR_(KI, ((KI) < 4 ? d0 : d1), 1, 2, 3)                                      \
+  else if (((KI) & 3) == 1) DH3D_X6_NEIGHBOUR_(KI, ((KI) < 4 ? d0 : d1), 5, 6, 7)                                 \
+  else if (((KI) & 3) == 2) DH3D_X6_NEIGHBOUR_(KI, ((KI) < 4 ? d0 : d1), 9, 10, 11)                               \
+  else DH3D_X6_NEIGHBOUR_(KI, ((KI) < 4 ? d0 : d1), 13, 14, 15)
       DH3D_X6_NEIGHBOUR(0) DH3D_X6_NEIGHBOUR(1) DH3D_X6_NEIGHBOUR(2) DH3D_X6_NEIGHBOUR(3)
       DH3D_X6_NEIGHBOUR(4) DH3D_X6_NEIGHBOUR(5) DH3D_X6_NEIGHBOUR(6) DH3D_X6_NEIGHBOUR(7)
 #undef DH3D_X6_NEIGHBOUR
-#undef X6_ACC
+#undef DH3D_X6_NEIGHBOUR_
+#undef DH3D_X6_FMAC_BCAST
+#undef DH3D_X6_MUL_BCAST
       unsigned short *row = s_A + (size_t)(i & 1) * C::A_ELEMS + (size_t)(r * kPPR + prow) * C::LD + c0;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -211,150 +243,210 @@ __global__ __launch_bounds__(kThreads) void flex_conv_x6_kernel(
       }
     };
 
-    issue_ids(0, 0);
-    issue_ids(1, 1);
-    issue_feat(0, 0);
-    issue_ids(0, 2);
-    issue_feat(1, 1);
-    issue_ids(1, 3);
-    for (int g = 0; g < G; g += 2) {
+    // Two schedules, one producer of each per SIMD.  Every producer does the same work per round -- reduce + split (VALU and matrix
+    // pipe), then the gathers of a later round (address arithmetic, then the CU's one texture-address path) -- and the
+    // workgroup barrier keeps the eight of them in step: with one schedule they all want the VALU in the first half of
+    // a tile period and the load path in the second.  Odd waves issue their loads FIRST (for the next round, into the
+    // slot the previous round freed) and reduce afterwards, so the two resources are used side by side.
+    // (Two separate loops, not one loop with a branch: a load under a branch is merged through register copies.)
+    if ((wave >> 2) & 1) {  // (waves w and w + 4 share SIMD w % 4: one of each schedule per SIMD)
+      issue_ids(0, 0);
+      issue_ids(1, 1);
+      issue_feat(0, 0);
+      issue_ids(0, 2);
+      for (int g = 0; g < G; g += 2) {
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int gg = g + s;
-        XPROBE(0, gg, 0);
-#if defined(DH3D_X6_PROBE) && DH3D_X6_PROBE == 2
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        XPROBE(0, gg, 1);
-#if (!defined(DH3D_X6_PROBE) || DH3D_X6_PROBE != 3) && !(defined(DH3D_X6_EXP) && (DH3D_X6_EXP & 4))   // probe 3 / exp 4: producers only load (timing experiment)
-        compute(s, gg);
+        for (int s = 0; s < 2; ++s) {
+          const int gg = g + s;
+          issue_feat(s ^ 1, gg + 1);
+          issue_ids(s ^ 1, gg + 3);
+#if !(defined(DH3D_X6_EXP) && (DH3D_X6_EXP & 4))
+          compute(s, gg);
 #else
-        asm volatile("" :: "v"(reinterpret_cast<const float *>(&fv[s][0])[0]), "v"(reinterpret_cast<const float *>(&fv[s][7])[1]),
-                     "v"(qv[s][0]), "v"(pc[s][2]));
+          asm volatile("" :: "v"(reinterpret_cast<const float *>(&fv[s][0])[0]), "v"(reinterpret_cast<const float *>(&fv[s][7])[1]),
+                       "v"(qd[s][0]), "v"(pcd[s]));
 #endif
-        XPROBE(0, gg, 2);
-        issue_feat(s, gg + 2);
-        issue_ids(s, gg + 4);
-        XPROBE(0, gg, 3);
-        if (gg % C::ROUNDS == C::ROUNDS - 1 && gg < G) wg_barrier(gg / C::ROUNDS);  // tile gg / ROUNDS is staged
-        XPROBE(0, gg, 4);
+          if (gg % C::ROUNDS == C::ROUNDS - 1 && gg < G) wg_barrier(gg / C::ROUNDS);
+        }
+      }
+    } else {
+      issue_ids(0, 0);
+      issue_ids(1, 1);
+      issue_feat(0, 0);
+      issue_ids(0, 2);
+      issue_feat(1, 1);
+      issue_ids(1, 3);
+      for (int g = 0; g < G; g += 2) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int gg = g + s;
+          XPROBE(0, gg, 0);
+#if defined(DH3D_X6_PROBE) && DH3D_X6_PROBE == 2
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+          XPROBE(0, gg, 1);
+#if (!defined(DH3D_X6_PROBE) || DH3D_X6_PROBE != 3) && !(defined(DH3D_X6_EXP) && (DH3D_X6_EXP & 4))   // probe 3 / exp 4: producers only load (timing experiment)
+          compute(s, gg);
+#else
+          asm volatile("" :: "v"(reinterpret_cast<const float *>(&fv[s][0])[0]), "v"(reinterpret_cast<const float *>(&fv[s][7])[1]),
+                       "v"(qd[s][0]), "v"(pcd[s]));
+#endif
+          XPROBE(0, gg, 2);
+          issue_feat(s, gg + 2);
+          issue_ids(s, gg + 4);
+          XPROBE(0, gg, 3);
+          if (gg % C::ROUNDS == C::ROUNDS - 1 && gg < G) wg_barrier(gg / C::ROUNDS);  // tile gg / ROUNDS is staged
+          XPROBE(0, gg, 4);
+        }
       }
     }
     wg_barrier(cnt);  // the consumers' last partial tiles
   } else {
     // ------------------------------------------------------------------ consumers
-    const int cw = wave - kProducers / 64, lane = tid & 63, ctid = tid - kProducers;
+    if (DH3D_X6_PRIO & 2) __builtin_amdgcn_s_setprio(3);
+    const int cw = wave - kProducers / 64, lane = tid & 63;
     const int cb = cw & 1, kh = cw >> 1;
-    uint4 breg[C::KBH][3];
+    // Weights: the two large bf16 planes of this wave's (K-half, column block) quarter live in registers for the
+    // lifetime of the workgroup; the third plane (used by one product in six) is parked in LDS in fragment order and
+    // read back per k-block beside the A fragments -- with all three in registers (96 + 32 accumulator + A fragments)
+    // a 168-register wave has no room to double-buffer the A fragments, and an A fragment requested just before its
+    // MFMA costs an LDS round trip per k-block.
+    uint4 breg[C::KBH][2];
+    uint4 *const s_b3 = reinterpret_cast<uint4 *>(s_raw + (size_t)2 * C::A_ELEMS * 2 + (size_t)2 * C::P_FLOATS * 4) +
+                        (size_t)(cb * C::KB + kh * C::KBH) * 64 + lane;
 #pragma unroll
-    for (int kb = 0; kb < C::KBH; ++kb)
+    for (int kb = 0; kb < C::KBH; ++kb) {
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < 2; ++p)
         breg[kb][p] = wp3[((size_t)(cb * C::KB + kh * C::KBH + kb) * 3 + p) * 64 + lane];
-    const int c4 = (ctid % C::CV) * 4, prow = ctid / C::CV;
-    float4 pb = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = pb;
-    if (ep.pre_bias) pb = *reinterpret_cast<const float4 *>(ep.pre_bias + c4);
-    if (ep.scale) sc = *reinterpret_cast<const float4 *>(ep.scale + c4);
-    if (ep.shift) sh = *reinterpret_cast<const float4 *>(ep.shift + c4);
-    sh.x = fmaf(pb.x, sc.x, sh.x); sh.y = fmaf(pb.y, sc.y, sh.y); sh.z = fmaf(pb.z, sc.z, sh.z); sh.w = fmaf(pb.w, sc.w, sh.w);
+      s_b3[(size_t)kb * 64] = wp3[((size_t)(cb * C::KB + kh * C::KBH + kb) * 3 + 2) * 64 + lane];  // (read back by this wave only)
+    }
+    // epilogue operands of this lane's output column (the pre-bias folded into the shift)
+    const int col = cb * 32 + (lane & 31);
+    float sc = 1.f, sh = 0.f;
+    if (ep.scale) sc = ep.scale[col];
+    if (ep.shift) sh = ep.shift[col];
+    if (ep.pre_bias) sh = fmaf(ep.pre_bias[col], sc, sh);
     const int lo = ep.act == DH3D_ACT_RELU ? 0 : INT_MIN;
-    // GEMM of tile i: this wave's K-half x column block.  The six products of a k-block go to two independent
-    // accumulator chains (a dependent MFMA would wait ~12 cycles on its predecessor), small terms first.  The
-    // trailing scheduling hints pin the issue order: chains alternating, the A fragments of the next k-block
-    // and one slot for an independent VALU instruction / store (the caller's reduce) behind every MFMA.
-    auto gemm = [&](int i, f32x16 &acc0, f32x16 &acc1) {
-      const unsigned short *abase = s_A + (size_t)(i & 1) * C::A_ELEMS + (size_t)(lane & 31) * C::LD +
-                                    8 * (lane >> 5) + kh * C::KBH * 16;
+    // The two K-half waves of a column block each keep HALF of the summed 32x32 tile (kh 0: accumulator registers
+    // 0-7 = rows 0-15, kh 1: registers 8-15 = rows 16-31) and hand the other half to the partner through LDS in the
+    // accumulator's own layout (two 16-byte writes per lane, no transposition, no bank conflicts).  The partner's
+    // half of tile i-1 is read back, added, put through the epilogue and stored in the gaps of tile i's MFMAs:
+    // accumulator register r of lane l is output (row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31), so one
+    // 4-byte store per register writes two full 128-byte lines.
+    float4 *const s_P4 = reinterpret_cast<float4 *>(s_P);
+    float4 *const p_mine = s_P4 + (size_t)(cw * 2) * 64 + lane;           // what this wave writes (+ parity * 512, + j * 64)
+    const float4 *const p_partner = s_P4 + (size_t)((cw ^ 2) * 2) * 64 + lane;
+    const unsigned voff = (unsigned)(((4 * (lane >> 5) + 16 * kh) * DOUT + col) * 4);  // byte offset of (row 0 of this half, col)
+    float keep[8];
+    const unsigned short *const abase0 = s_A + (size_t)(lane & 31) * C::LD + 8 * (lane >> 5) + kh * C::KBH * 16;
+
+    // One tile: GEMM of this wave's K-half x column block, six bf16 products per k-block on two independent
+    // accumulator chains (small terms first).  The A fragments of k-block kb + 1 are requested BEFORE the MFMAs of
+    // k-block kb (an LDS round trip is ~100+ cycles, a k-block's MFMAs are 192), and every k-block is a scheduling
+    // region of its own, so the order below is the order issued.  PREV: the epilogue of tile i - 1 rides along, 8 / KBH values per k-block.
+    auto tile = [&](int i, auto prev_tag) {
+      constexpr bool PREV = decltype(prev_tag)::value;
+      const unsigned short *abase = abase0 + (size_t)(i & 1) * C::A_ELEMS;
+      f32x16 acc0, acc1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+      bf16x8 a[2][3];
+      uint4 b3r[2];
+      float4 pp[2];
 #pragma unroll
-#if (defined(DH3D_X6_PROBE) && DH3D_X6_PROBE == 4) || (defined(DH3D_X6_EXP) && (DH3D_X6_EXP & 8))     // probe 4 / exp 8: consumers skip the MFMAs (timing experiment)
-      for (int kb = 0; kb < 0; ++kb) {
-#else
+      for (int p = 0; p < 3; ++p) a[0][p] = *reinterpret_cast<const bf16x8 *>(abase + p * kTM * C::LD);
+      b3r[0] = s_b3[0];
+      if (PREV) {
+        pp[0] = p_partner[(size_t)((i - 1) & 1) * 512];
+        pp[1] = p_partner[(size_t)((i - 1) & 1) * 512 + 64];
+      }
+      float *const orow = reinterpret_cast<float *>(reinterpret_cast<char *>(out + (size_t)(tbeg + (i - 1) * S) * kTM * DOUT) + voff);
+      const unsigned grow_prev = (unsigned)(tbeg + (i - 1) * S) * kTM + 4 * (lane >> 5) + 16 * kh;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
       for (int kb = 0; kb < C::KBH; ++kb) {
-#endif
-#if defined(DH3D_X6_EXP) && (DH3D_X6_EXP & 1)   // timing experiment: one set of A fragments per tile (results wrong)
-        const int kbo = 0;
-#else
-        const int kbo = kb * 16;
-#endif
-        const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(abase + kbo);
-        const bf16x8 a2 = *reinterpret_cast<const bf16x8 *>(abase + kTM * C::LD + kbo);
-        const bf16x8 a3 = *reinterpret_cast<const bf16x8 *>(abase + 2 * kTM * C::LD + kbo);
+        if (kb + 1 < C::KBH) {
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            a[(kb + 1) & 1][p] = *reinterpret_cast<const bf16x8 *>(abase + p * kTM * C::LD + (kb + 1) * 16);
+          b3r[(kb + 1) & 1] = s_b3[(size_t)(kb + 1) * 64];
+        }
+#if !((defined(DH3D_X6_PROBE) && DH3D_X6_PROBE == 4) || (defined(DH3D_X6_EXP) && (DH3D_X6_EXP & 8)))  // probe 4 / exp 8: no MFMAs (timing experiment)
+        const bf16x8 a1 = a[kb & 1][0], a2 = a[kb & 1][1], a3 = a[kb & 1][2];
         const bf16x8 b1 = __builtin_bit_cast(bf16x8, breg[kb][0]), b2 = __builtin_bit_cast(bf16x8, breg[kb][1]),
-                     b3 = __builtin_bit_cast(bf16x8, breg[kb][2]);
+                     b3 = __builtin_bit_cast(bf16x8, b3r[kb & 1]);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc1, 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);  // first A fragments (+ the reduce's partial tiles)
+#endif
+#if !(defined(DH3D_X6_EXP) && (DH3D_X6_EXP & 2))   // exp 2: no partial exchange / epilogue / store (timing experiment, results wrong)
+        if (PREV) {
 #pragma unroll
-      for (int m = 0; m < 6 * C::KBH; ++m) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-        if (m % 6 == 1 && m + 6 < 6 * C::KBH) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-        if (m % 6 == 3) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
-      }
-    };
-    auto write_partial = [&](int i, const f32x16 &acc0, const f32x16 &acc1) {
-      float *part = s_P + (size_t)(i & 1) * C::P_FLOATS + (size_t)kh * kTM * C::PLD + cb * 32 + (lane & 31);
-      // packed adds: an FP32 VALU instruction holds up the SIMD's matrix pipe (see above), so half as many of them
+          for (int jj = 0; jj < 8 / C::KBH; ++jj) {
+            const int j = (8 / C::KBH) * kb + jj;
+            const float part = reinterpret_cast<const float *>(&pp[j >> 2])[j & 3];
+            const int vi = max(__float_as_int(fmaf(keep[j] + part, sc, sh)), lo);
+            const int rowoff = (j & 3) + 8 * (j >> 2);
+            if (!RAGGED || grow_prev + rowoff < R) reinterpret_cast<int *>(orow)[rowoff * DOUT] = vi;
+          }
+        }
+#endif
+        // the order above within the k-block: loads first, then MFMAs with one independent instruction behind each
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const f32x2 sum = f32x2{acc0[r], acc0[r + 1]} + f32x2{acc1[r], acc1[r + 1]};
-        part[(size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * C::PLD] = sum[0];
-        part[(size_t)(((r + 1) & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * C::PLD] = sum[1];
+        for (int m = 0; m < 6; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+          if (m % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-    };
-    // sum of the two K-half partial tiles of tile i, epilogue, 16-byte stores
-    auto reduce_store = [&](int i) {
-      const unsigned grow0 = (unsigned)(tbeg + i * S) * kTM;
+#if !(defined(DH3D_X6_EXP) && (DH3D_X6_EXP & 2))
+      // K-half sum of the two chains; own half stays in registers, the other half goes to the partner
+      float sum[16];
 #pragma unroll
-      for (int ps = 0; ps < kTM / C::RP; ++ps) {
-        const int p = ps * C::RP + prow;
-        const float *q = s_P + (size_t)(i & 1) * C::P_FLOATS + (size_t)p * C::PLD + c4;
-        const float4 v0 = *reinterpret_cast<const float4 *>(q);
-        const float4 v1 = *reinterpret_cast<const float4 *>(q + kTM * C::PLD);
-        // four packed FP instructions per row segment (the pre-bias is folded into the shift); relu / no activation
-        // as an INTEGER max on the bit patterns (max(bits, 0) clamps negative floats to +0, max(bits, INT_MIN) is the
-        // identity): integer VALU work does overlap the matrix pipe
-        const f32x2 t0 = f32x2{v0.x, v0.y} + f32x2{v1.x, v1.y}, t1 = f32x2{v0.z, v0.w} + f32x2{v1.z, v1.w};
-        const f32x2 r0 = __builtin_elementwise_fma(t0, f32x2{sc.x, sc.y}, f32x2{sh.x, sh.y});
-        const f32x2 r1 = __builtin_elementwise_fma(t1, f32x2{sc.z, sc.w}, f32x2{sh.z, sh.w});
-        int4 vi;
-        vi.x = max(__float_as_int(r0[0]), lo); vi.y = max(__float_as_int(r0[1]), lo);
-        vi.z = max(__float_as_int(r1[0]), lo); vi.w = max(__float_as_int(r1[1]), lo);
-        if (!RAGGED || grow0 + p < R) *reinterpret_cast<int4 *>(out + (size_t)(grow0 + p) * DOUT + c4) = vi;
-      }
+      for (int r = 0; r < 16; ++r) sum[r] = acc0[r] + acc1[r];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) keep[j] = kh ? sum[8 + j] : sum[j];
+      p_mine[(size_t)(i & 1) * 512] = kh ? make_float4(sum[0], sum[1], sum[2], sum[3]) : make_float4(sum[8], sum[9], sum[10], sum[11]);
+      p_mine[(size_t)(i & 1) * 512 + 64] = kh ? make_float4(sum[4], sum[5], sum[6], sum[7]) : make_float4(sum[12], sum[13], sum[14], sum[15]);
+#else
+      asm volatile("" :: "v"(acc0), "v"(acc1));
+#endif
     };
-    // The reduce + store of tile i-1 is issued in the shadow of tile i's MFMAs (an MFMA holds the matrix pipe
-    // for 32 cycles; the wave issues in order, so independent instructions between two MFMAs are free).
-    f32x16 acc0, acc1;
+
     wg_barrier(0);  // tile 0 staged
     XPROBE(1, 0, 0);
-    gemm(0, acc0, acc1);
-    write_partial(0, acc0, acc1);
+    tile(0, std::false_type{});
     XPROBE(1, 0, 1);
-    wg_barrier(1);  // partials of tile 0 complete, tile 1 staged
+    wg_barrier(1);  // halves of tile 0 exchanged, tile 1 staged
     XPROBE(1, 0, 2);
     for (int i = 1; i < cnt; ++i) {
       XPROBE(1, i, 0);
-#if defined(DH3D_X6_EXP) && (DH3D_X6_EXP & 2)   // timing experiment: no partial tiles, no reduce + store (results wrong)
-      gemm(i, acc0, acc1);
-      asm volatile("" :: "v"(acc0), "v"(acc1));
-#else
-      reduce_store(i - 1);
-      gemm(i, acc0, acc1);
-      write_partial(i, acc0, acc1);
-#endif
+      tile(i, std::true_type{});
       XPROBE(1, i, 1);
-      wg_barrier(i + 1);  // partials of tile i complete, tile i+1 staged
+      wg_barrier(i + 1);  // halves of tile i exchanged, tile i+1 staged
       XPROBE(1, i, 2);
     }
-    reduce_store(cnt - 1);
+#if !(defined(DH3D_X6_EXP) && (DH3D_X6_EXP & 2))
+    {  // the last tile's epilogue
+      const int i = cnt;
+      const float4 pp0 = p_partner[(size_t)((i - 1) & 1) * 512], pp1 = p_partner[(size_t)((i - 1) & 1) * 512 + 64];
+      float *const orow = reinterpret_cast<float *>(reinterpret_cast<char *>(out + (size_t)(tbeg + (i - 1) * S) * kTM * DOUT) + voff);
+      const unsigned grow_prev = (unsigned)(tbeg + (i - 1) * S) * kTM + 4 * (lane >> 5) + 16 * kh;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float part = j < 4 ? reinterpret_cast<const float *>(&pp0)[j & 3] : reinterpret_cast<const float *>(&pp1)[j & 3];
+        const int vi = max(__float_as_int(fmaf(keep[j] + part, sc, sh)), lo);
+        const int rowoff = (j & 3) + 8 * (j >> 2);
+        if (!RAGGED || grow_prev + rowoff < R) reinterpret_cast<int *>(orow)[rowoff * DOUT] = vi;
+      }
+    }
+#endif
   }
 }
 
