@@ -13,7 +13,8 @@ exactly that graph, so a slot's outputs are bit-equal to the serial forward of t
     outs = pipe.result(t)             # the CURRENT stream waits for that step; dict of the slot's static buffers
 
 Zero-copy hand-over: write the batch into `pipe.input_buffer(slot)` (e.g. as the destination of the host-to-device
-copy, enqueued on `pipe.stream(slot)` or ordered before the submit) and call `pipe.submit()` without an argument.
+copy, enqueued on `pipe.stream(slot)` or on the current stream before the submit -- submit() always orders the slot's
+stream behind the current one) and call `pipe.submit()` without an argument.
 """
 import torch
 
@@ -49,7 +50,7 @@ class Pipeline:
                               for k in range(self.depth)]
         finally:
             model.steps_in_flight = hint
-        self._version = getattr(model, "_backbone_version", 0)
+        self._version = model.weights_version
         self._events = [torch.cuda.Event() for _ in range(self.depth)]
         self._consumed = [None] * self.depth  # event after which slot k's buffers may be overwritten
         self._seq = 0
@@ -77,13 +78,19 @@ class Pipeline:
         """Enqueue one full forward on the next slot.  `points` (optional) is copied into the slot's input buffer on the
         slot's stream, after the caller's stream has reached this point (so a batch produced on the current stream is
         complete) and after the previous consumer of this slot's outputs (result()) is done with them."""
-        if getattr(self.model, "_backbone_version", 0) != self._version:
-            raise RuntimeError("the model's weights changed (invalidate / load_state_dict) after this pipeline was "
-                               "captured: build a new one")
+        if self.model.weights_version != self._version:
+            raise RuntimeError("the model's weights changed (optimiser step / invalidate / load_state_dict) after this "
+                               "pipeline was captured: build a new one")
         k = self._seq % self.depth
         run, st = self._runs[k], self._streams[k]
-        if points is not None or knn_inds is not None:
-            st.wait_stream(torch.cuda.current_stream(run.static_input.device))
+        # ALWAYS ordered behind the caller's stream: a batch written into input_buffer(slot) on the current stream
+        # (the zero-copy hand-over) is complete before the slot's graph reads it -- an event wait, no host block
+        st.wait_stream(torch.cuda.current_stream(run.static_input.device))
+        # the copies below run on the slot's stream: tell the caching allocator, or a caller that drops `points`
+        # right after submit() may see its block handed out again (on ITS stream) before the copy has read it
+        for t in (points, knn_inds):
+            if t is not None and t.is_cuda:
+                t.record_stream(st)
         if self._consumed[k] is not None:
             st.wait_event(self._consumed[k])
             self._consumed[k] = None

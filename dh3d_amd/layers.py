@@ -137,12 +137,20 @@ class Flex_Avg(nn.Module):
         self.position_theta = nn.Parameter(torch.zeros(dp, in_channels, filters), requires_grad=False)
         self.register_buffer("position_bias", torch.eye(filters), persistent=False)  # not a variable upstream
 
+    def _theta_is_zero(self):
+        """position_theta == 0 (what the reference initialises it to and never trains), looked up ONCE per version of
+        the tensor: asking the device on every call would be a host sync per forward and break hipGraph capture."""
+        key = (self.position_theta.data_ptr(), self.position_theta._version)
+        if self.__dict__.get("_zero_key") != key:
+            self._zero_key, self._zero = key, not bool(self.position_theta.any())
+        return self._zero
+
     def forward(self, features, positions, neighborhoods):
         from . import pm
         if self.data_format == "expanded":
             features, positions, neighborhoods = features.squeeze(2), positions.squeeze(2), neighborhoods.squeeze(2)
         plain_sum = (not features.requires_grad and features.dtype == torch.float32 and features.shape[1] % 4 == 0
-                     and not bool(self.position_theta.any()))
+                     and self._theta_is_zero())
         if plain_sum:
             f_pm = pm.transpose_last2(features)                                   # [B, N, C]
             nb_pm = pm.transpose_last2(neighborhoods.to(torch.int32))             # [B, N, K]

@@ -158,6 +158,7 @@ class DH3D(nn.Module):
         may have changed -- load_state_dict, .to()/.cuda()/.float() (_apply), init_synthetic, an optimiser step
         (head_only: the global head that global_config trains; the frozen backbone's copies stay)."""
         self._head_prepared = False
+        self._weights_version = self.__dict__.get("_weights_version", 0) + 1  # replays captured before this are stale
         mods = []
         if self.config.extract_global:
             for top in self._global_front() + [self.globalatt, self.__dict__.get("_netvlad")]:
@@ -169,6 +170,18 @@ class DH3D(nn.Module):
         for m in mods:
             if m is not None and getattr(m, "_prep", None) is not None:
                 m._prep = None
+
+    def mark_weights_changed(self, bn_stale=True):
+        """A trainer moved weights (or BatchNorm moving averages) on the device without going through invalidate():
+        every replay captured before this (graphed(), Pipeline) refuses to run again, and -- bn_stale -- the folded
+        BatchNorm copies of the inference path are rebuilt by the next forward."""
+        self._weights_version = self.__dict__.get("_weights_version", 0) + 1
+        if bn_stale:
+            self._bn_stale = True
+
+    @property
+    def weights_version(self):
+        return self.__dict__.get("_weights_version", 0)
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
@@ -293,8 +306,12 @@ class DH3D(nn.Module):
         with torch.cuda.stream(geo._side):  # behind kNN(N), beside the FPS chain
             nn_8 = geo.nbr if geo.nbr.shape[2] == 8 else geo.nbr[:, :, 0:8].contiguous()
             # conv_pointset 3 -> 32, BNReLU, flex_pool (backbones.py:107-110) fused: the map between them is not built
-            init = pm.conv_pointset_pool_xyz(geo.xyz, nn_8, p["theta"], p["bias"], scale=p["scale"], shift=p["shift"],
-                                             act=pm.ACT_RELU)
+            if nn_8.shape[2] == 8 and p["theta"].shape[1] in (32, 64, 128):
+                init = pm.conv_pointset_pool_xyz(geo.xyz, nn_8, p["theta"], p["bias"], scale=p["scale"], shift=p["shift"],
+                                                 act=pm.ACT_RELU)
+            else:   # other init_feat_dim (e.g. 16): the fused pair covers Dout 32 / 64 / 128 -- the two operators apart
+                init = pm.flex_pool(pm.conv_pointset_xyz(geo.xyz, nn_8, p["theta"], p["bias"], scale=p["scale"],
+                                                         shift=p["shift"], act=pm.ACT_RELU), nn_8)
             # larger clouds: the shortcut conv (on stage 1's output) and the lower block of stage 2's commuted concat conv
             # (on before_stage2_conv1d's output) ride in stage 1's SE kernel -- two launches over tiles it already holds
             fuse_sc = points.shape[1] <= 4096 and self.stage2.shortcut_fusable(points.shape[1])
@@ -486,8 +503,12 @@ class DH3D(nn.Module):
             outs = self.forward(static_in, static_knn, fetch=keep)
         if keep is not None:
             outs = {k: v for k, v in outs.items() if k in keep}
+        version = self.weights_version
 
         def run(points=None, knn_inds=None):
+            if self.weights_version != version:
+                raise RuntimeError("the model's weights changed (optimiser step / invalidate / load_state_dict) after this "
+                                   "forward was captured: the graph holds packed copies of the old ones -- capture again")
             if points is not None and points is not static_in:
                 static_in.copy_(points)
             if static_knn is not None and knn_inds is not None and knn_inds is not static_knn:

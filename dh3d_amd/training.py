@@ -216,7 +216,7 @@ def backbone_local_batch_stats_hip(model, points, geo, sync_bn=False, mask=None)
     up = pm.three_interpolate_idw(y, lv["nn3_idx"], lv["nn3_dist"])
     shortcut = bn_relu(conv_raw(x1, model.local_stage1_shortcut), model.local_stage1_shortcut.tfconv0.bn)
     feat = bn_relu(conv_raw(up, s2.concat_conv1d, x2=x2), s2.concat_conv1d.tfconv0.bn, residual=shortcut)
-    model._bn_stale = True
+    model.mark_weights_changed(bn_stale=True)
     return feat, lv
 
 
@@ -690,6 +690,8 @@ class QuadrupletTrainer(object):
         graph.replay()
         self._steps_done += 1
         self.model.invalidate(head_only=True)
+        if self.backbone_bn == "batch":   # the replay moved the backbone's moving averages on the device
+            self.model._bn_stale = True
         return loss.detach()
 
     def step(self, points, sync=True):
@@ -831,17 +833,22 @@ def local_training_outputs(model, points, R, sample_idx, sync_bn=False, mask=Non
     outs = {"xyz": points, "feat": feat, "local_desc": desc, "R": R, "sample_nodes_concat": kp,
             "xyz_sampled": ops.group_point(points, kp).squeeze(2), "feat_sampled": ops.group_point(desc, kp).squeeze(2)}
     if cfg.detection:
-        freeze_det = bool(cfg.get("freezedetection"))
-        att = detection_block_train(model, feat.detach() if freeze_det else feat, sync_bn, mask)
+        # freezedetection (core/backbones.py:136, tf_utils.py:144-153) is freeze_variables(stop_gradient=False,
+        # skip_collection=True): the detector's VARIABLES leave the trainable set (local_trainable_parameters), the
+        # detection loss's gradient still flows through the detector into the backbone -- so no detach here
+        att = detection_block_train(model, feat, sync_bn, mask)
         outs["attention"] = att
         outs["att_sampled"] = ops.group_point(att, kp).squeeze(2)                            # model.py:196
     return outs
 
 
 def local_trainable_parameters(model):
-    """Everything basic_config / detection_config train (freezebackbone / freezedetection False, configs.py:41-43): the
-    local backbone and, with config.detection, the detector."""
-    mods = [model._local] + ([model.detection_block_reliable] if model.config.detection else [])
+    """Everything basic_config / detection_config train (configs.py:41-43): the local backbone unless `freezebackbone`,
+    and, with config.detection, the detector unless `freezedetection` (frozen variables are skipped by the optimiser
+    and by the weight decay, core/tf_utils.py:144-153)."""
+    cfg = model.config
+    mods = ([] if cfg.get("freezebackbone") else [model._local]) + \
+           ([model.detection_block_reliable] if cfg.detection and not cfg.get("freezedetection") else [])
     seen, out = set(), []
     for mod in mods:
         for p in mod.parameters():
@@ -945,6 +952,6 @@ class LocalTrainer(object):
                 self.last_grads = [None if p.grad is None else p.grad.detach().clone() for p in self.params]
             self.opt.step()
         self._steps_done += 1
-        self.model._bn_stale = True   # moving averages and weights moved: the inference path re-folds on its next forward
+        self.model.mark_weights_changed(bn_stale=True)   # moving averages and weights moved: the inference path re-folds on its next forward; older replays refuse to run
         loss = loss.detach()
         return float(loss) if sync else loss

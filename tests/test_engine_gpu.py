@@ -161,3 +161,58 @@ def test_global_pipeline_depth2_B32_N4096_slots_equal_serial_and_oracle(dev):
         exp = model_np.forward(pts, w, detection=False, extract_global=True)
         err = float(np.abs(got[i]["globaldesc"][c:c + 1].cpu().numpy() - exp["globaldesc"]).max())
         assert err < 1e-4, (slot, err)
+
+
+def test_replays_refuse_to_run_on_weights_that_moved(dev):
+    """A graphed() forward / a Pipeline holds packed and BatchNorm-folded COPIES of the weights: after an optimiser step
+    (QuadrupletTrainer: invalidate(head_only=True); LocalTrainer: mark_weights_changed) or load_state_dict a replay
+    would silently compute with the old ones -- it raises instead."""
+    from dh3d_amd import ConfigFactory
+    from dh3d_amd.model import DH3D
+    m = DH3D(ConfigFactory("global_config").getconfig()).init_synthetic(0).to(dev).eval().prepare()
+    pts = torch.rand(2, 1024, 3, device=dev)
+    with torch.no_grad():
+        run = m.graphed(pts, outputs=("globaldesc",))
+        pipe = m.pipeline(pts, depth=2, outputs=("globaldesc",))
+        a = run()["globaldesc"].clone()
+        t = pipe.submit(pts)
+        assert torch.equal(pipe.result(t, wait="host")["globaldesc"], a)
+        m.invalidate(head_only=True)            # what every QuadrupletTrainer step does
+        with pytest.raises(RuntimeError):
+            run()
+        with pytest.raises(RuntimeError):
+            pipe.submit(pts)
+        run2 = m.graphed(pts, outputs=("globaldesc",))
+        assert torch.equal(run2()["globaldesc"], a)
+        m.mark_weights_changed()                # what every LocalTrainer step does
+        with pytest.raises(RuntimeError):
+            run2()
+
+
+def test_submit_copies_a_batch_the_caller_drops_at_once(dev):
+    """submit(batch) copies on the slot's stream: the batch is recorded on that stream, so dropping it right after the
+    call (the usual `b = cpu.to(dev, non_blocking=True); pipe.submit(b)` loop) cannot hand its block to the next
+    allocation before the copy has read it."""
+    from dh3d_amd import ConfigFactory
+    from dh3d_amd.model import DH3D
+    m = DH3D(ConfigFactory("basic_config").getconfig()).init_synthetic(0).to(dev).eval().prepare()
+    rng = np.random.default_rng(5)
+    host = [torch.from_numpy(rng.random((2, 2048, 3), dtype=np.float32)) for _ in range(6)]
+    with torch.no_grad():
+        exp = [m(h.to(dev), fetch=("xyz_feat",))["xyz_feat"].clone() for h in host]
+        pipe = m.pipeline(host[0].to(dev), depth=3, outputs=("xyz_feat",))
+        tickets, got = [], []
+        for h in host:
+            if len(tickets) == 3:
+                tk = tickets.pop(0)
+                got.append(pipe.result(tk)["xyz_feat"].clone()); pipe.release(tk)
+            b = h.to(dev, non_blocking=True)
+            tickets.append(pipe.submit(b))
+            del b
+            junk = torch.full((2, 2048, 3), 7.0, device=dev)   # the allocator's next hand-out of that size
+            del junk
+        for tk in tickets:
+            got.append(pipe.result(tk)["xyz_feat"].clone()); pipe.release(tk)
+    torch.cuda.synchronize()
+    for g, e in zip(got, exp):
+        assert torch.equal(g, e)

@@ -172,3 +172,33 @@ def test_zero_arena_hands_out_zeroed_independent_tensors():
         a.begin(cpu)
         assert float(w.sum()) == 0.0                  # same buffer this time: cleared by ONE fill
     assert pm.zeros((2,), torch.float32, cpu).data_ptr() != a.buf.data_ptr()   # outside the context: no arena
+
+
+def test_frozen_scopes_leave_the_trainable_set():
+    """backbone_scope(freeze) is freeze_variables(stop_gradient=False, skip_collection=True) (core/tf_utils.py:144-153):
+    frozen variables are not handed to the optimiser (the gradient still flows through them)."""
+    from dh3d_amd import ConfigFactory
+    from dh3d_amd.model import DH3D
+    from dh3d_amd.training import local_trainable_parameters
+    cfg = ConfigFactory("detection_config").getconfig()
+    m = DH3D(cfg).init_synthetic(0)
+    det = {id(p) for p in m.detection_block_reliable.parameters()}
+    both = {id(p) for p in local_trainable_parameters(m)}
+    assert det and det <= both
+    m.config.freezedetection = True
+    assert not (det & {id(p) for p in local_trainable_parameters(m)})
+    m.config.freezedetection, m.config.freezebackbone = False, True
+    assert {id(p) for p in local_trainable_parameters(m)} == det
+
+
+def test_weights_version_moves_with_every_kind_of_weight_change():
+    from dh3d_amd import ConfigFactory
+    from dh3d_amd.model import DH3D
+    m = DH3D(ConfigFactory("global_config").getconfig()).init_synthetic(0)
+    v0 = m.weights_version
+    m.invalidate(head_only=True)
+    v1 = m.weights_version
+    m.mark_weights_changed()
+    v2 = m.weights_version
+    m.load_state_dict(m.state_dict())
+    assert v0 < v1 < v2 < m.weights_version and m.__dict__.get("_bn_stale")
