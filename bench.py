@@ -116,6 +116,21 @@ def scene_like_clouds(B, N, seed, dev):
     return torch.from_numpy(out).to(dev)
 
 
+def real_oxford_clouds(B, N, dev):
+    """B clouds of N points from the reference's own demo inputs (tests/golden/demo_clouds.npz: 268.bin / 642.bin, Oxford
+    LiDAR sub-maps in metres): the N points nearest to the centroid in a seeded random order, as Global_test_dataset /
+    get_fixednum_pcd crop them (core/utils.py:92-99); N = 16384 takes the clouds whole.  None if the fixture is missing."""
+    path = os.path.join(ROOT, "tests", "golden", "demo_clouds.npz")
+    if not os.path.isfile(path):
+        return None
+    from dh3d_amd.utils import get_fixednum_pcd
+    z = np.load(path)
+    src = [z["local_268"], z["local_642"]]
+    out = np.stack([np.ascontiguousarray(get_fixednum_pcd(src[b % 2], N, rng=np.random.default_rng(1000 + b))[0], np.float32)
+                    for b in range(B)])
+    return torch.from_numpy(out).to(dev)
+
+
 def time_steps(run, pts, steps, warmup, dev):
     from dh3d_amd import dist as D
     # clock ramp: a fresh process finds the GPU in a low power state and a millisecond-scale step does not pull it
@@ -332,8 +347,9 @@ def global_tail_roofline(dev, B=32, N=4096):
                 "kernels": "linear_x6 slices (attention GEMM on coarse rows) + interp_head_lds_kernel<true> (walk) + "
                            "gemm_x6 (A'^T c) + netvlad_finalize / hidden_splitk / gate",
                 "launch_ms": ms, "flops_reference": f_att_ref + f_vlad, "flops_executed": f_exec,
-                "reference_flops_rate": {"achieved": (f_att_ref + f_vlad) / t / 1e12, "peak": F32_MFMA_PEAK_TF,
-                                         "unit": "TFLOP/s", "frac": (f_att_ref + f_vlad) / t / 1e12 / F32_MFMA_PEAK_TF},
+                "reference_flops_rate": {"achieved": (f_att_ref + f_vlad) / t / 1e12, "unit": "TFLOP/s",
+                                         "note": "the REFERENCE formulation's flops over this time: informational, no fraction -- "
+                                                 "the commuted form never executes the attention conv on the fine rows"},
                 "executed_flops_rate": {"achieved": f_exec / t / 1e12, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                                         "frac": f_exec / t / 1e12 / F32_MFMA_PEAK_TF},
                 "binding_roof": "L2 gather of the walk (12 KB of coarse rows per fine point) + VALU; the GEMMs are 1/8 of "
@@ -374,10 +390,10 @@ def step_kernel_rows(workload):
     ff = flex_figures
     rows = [
         ("spatial_sort_kernel<%d>" % (N // 1024), 1, "Morton sort of the clouds", 4 * R * 7 + 32 * R / 64, 0.0, "latency (one workgroup per cloud)"),
-        ("fps_list_kernel", 1, "farthest point sampling N -> N/8", 16 * R + 16 * Rs, 8.0 * B * N * M, "latency (N/8 dependent picks, one CU per cloud)"),
+        ("fps_list_kernel", 1, "farthest point sampling N -> N/8", 16 * R + 16 * Rs, 0.0, "latency (N/8 dependent picks, one CU per cloud; the box lists prune most of the 8*B*N*N/8 brute-force flops: executed work not counted, floor = bytes only)"),
         ("knn_split_kernel", 1, "the pruned scan's launch behind the cell lists: serves the clouds the sort flags as crowded -- none of the "
                                 "uniform bench input, every workgroup leaves at its first instruction (no work, no floor)", 0.0, 0.0, "launch"),
-        ("knn_grid_kernel", 1, "kNN K=8 on the full clouds (cell lists on the sort's grid)", 16 * R + 8 * R * K, 8.0 * B * N * N, "f32 VALU (brute-force pair count; the kernel prunes)"),
+        ("knn_grid_kernel", 1, "kNN K=8 on the full clouds (cell lists on the sort's grid)", 16 * R + 8 * R * K, "knn_grid_executed", "f32 VALU on the candidates VISITED (lower bound: every point of the 3x3x3 cell block around the query, 8 flop each) -- not the 8*B*N*N brute-force count"),
         ("pointset_sum_kernel", 1, "conv_pointset: neighbour-offset sums", 4 * R * (3 + K + 4), 6.0 * R * K, "hbm"),
         ("pointset_pool_kernel", 1, "conv_pointset 3->32 + BNReLU + flex_pool", 4 * R * (4 + K + 32), 2.0 * R * K * 32 * 3, "hbm"),
         ("conv_pointset_pm_kernel", 1, "conv_pointset 3->32 + BNReLU", 4 * R * (3 + K + 32), 2.0 * R * K * 32 * 3, "hbm"),
@@ -385,9 +401,9 @@ def step_kernel_rows(workload):
         ("flex_conv_x6_kernel<32, 64", 1, "flex_conv 32->64 @N", ff(B, N, K, 32, 64)[0], ff(B, N, K, 32, 64)[2], "hbm (contract) / matrix pipe"),
         ("flex_conv_x6_kernel<64, 64", 1, "flex_conv 64->64 @N", ff(B, N, K, 64, 64)[0], ff(B, N, K, 64, 64)[2], "hbm (contract) / matrix pipe"),
         ("se_res_mfma_kernel<64, true, true", 1, "flex_pool + SE + residual + 1x1 conv 64->64 @N", 4 * R * (64 + K + 64 + 64), 2.0 * R * (2 * 64 * 16 + 64 * 64), "hbm"),
-        ("knn_small_kernel", 1, "kNN K=8 on the sampled sets", 12 * Rs + 8 * Rs * K, 8.0 * B * M * M, "latency / VALU issue"),
+        ("knn_small_kernel", 1, "kNN K=8 on the sampled sets", 12 * Rs + 8 * Rs * K, 0.0, "latency / VALU issue (pruned scan: executed work not counted, floor = bytes only)"),
         ("spatial_sort_kernel<1>", 1, "Morton sort of the sampled sets", 4 * Rs * 7 + 32 * Rs / 64, 0.0, "latency"),
-        ("three_nn_pruned_kernel", 1, "three_nn N vs N/8", 16 * R + 16 * Rs + 24 * R, 8.0 * B * N * M, "f32 VALU (brute-force pair count; the kernel prunes)"),
+        ("three_nn_pruned_kernel", 1, "three_nn N vs N/8", 16 * R + 16 * Rs + 24 * R, 0.0, "latency / VALU issue (pruned scan: executed work not counted, floor = bytes only)"),
         ("flex_conv_tx6_kernel<64, 128", 1, "flex_conv 64->128 @N/8 (32-point tiles, bf16x6 tile GEMM)", ff(B, M, K, 64, 128)[0], ff(B, M, K, 64, 128)[2], "gather + matrix pipe / L2 (weights)"),
         ("flex_conv_tx6_kernel<128, 128", 1, "flex_conv 128->128 @N/8 (32-point tiles, bf16x6 tile GEMM)", ff(B, M, K, 128, 128)[0], ff(B, M, K, 128, 128)[2], "gather + matrix pipe / L2 (weights)"),
         ("flex_conv_pm_kernel<64, 128", 1, "flex_conv 64->128 @N/8 (exact-f32 tiles: rounds 1-3)", ff(B, M, K, 64, 128)[0], ff(B, M, K, 64, 128)[2], "f32 MFMA"),
@@ -428,7 +444,30 @@ def step_kernel_rows(workload):
     return rows
 
 
-def step_roofline(workload, serial_ms=None, in_flight_ms=None, depth=None, timeout=240):
+def knn_grid_executed_flops(workload, dev):
+    """Lower bound of what knn_grid_kernel executes on the bench input: 8 flop (3 sub, 3 fma-class, compare/insert not
+    counted) for every point of the 3 x 3 x 3 block of grid cells around each query -- the first two shells, which the
+    kernel always pools (csrc/knn.hip) -- from the sort's own cell table.  The brute-force count 8*B*N*N is NOT executed."""
+    from dh3d_amd import pm
+    wl = WORKLOADS[workload]
+    pts = synthetic_clouds(wl["B"], wl["N"], wl["seed"], dev, 0)
+    _, _, cells = pm.spatial_sort_cells(pts)
+    ct = cells[:, :4097].to(torch.int64).cpu().numpy()
+    cnt = np.diff(ct, axis=1)                                   # points per Morton-coded cell [B, 4096]
+    code = np.arange(4096)
+    def compact(v):                                             # every third bit of a 12-bit Morton code
+        return ((v >> 0) & 1) | ((v >> 2) & 2) | ((v >> 4) & 4) | ((v >> 6) & 8)
+    x, y, z = compact(code), compact(code >> 1), compact(code >> 2)
+    total = 0.0
+    for b in range(cnt.shape[0]):
+        g = np.zeros((18, 18, 18))
+        g[x + 1, y + 1, z + 1] = cnt[b]
+        box = sum(g[1 + dx:17 + dx, 1 + dy:17 + dy, 1 + dz:17 + dz] for dx in (-1, 0, 1) for dy in (-1, 0, 1) for dz in (-1, 0, 1))
+        total += float((g[1:17, 1:17, 1:17] * box).sum())
+    return 8.0 * total, total / (wl["B"] * wl["N"])
+
+
+def step_roofline(workload, serial_ms=None, in_flight_ms=None, depth=None, timeout=240, dev=None):
     """Step-level roofline: every kernel of one step -- algorithmic bytes / flops (step_kernel_rows), its floor at 8 TB/s
     and 157.3 TF (f32 MFMA = f32 VALU peak), its stand-alone duration measured NOW by `rocprofv3 --kernel-trace` over
     tools/step_forward.py (the eager forward on ONE stream: no kernel overlaps another) -- and how far the whole step is
@@ -470,6 +509,14 @@ def step_roofline(workload, serial_ms=None, in_flight_ms=None, depth=None, timeo
         durs = [(e - s) / 1e3 for n, s, e in last if pat in n]
         if not durs:
             continue
+        extra = {}
+        if flops == "knn_grid_executed":
+            try:
+                flops, per_query = knn_grid_executed_flops(workload, dev or torch.device("cuda"))
+                extra = {"candidates_per_query_lower_bound": round(per_query, 1),
+                         "bruteforce_flops_not_executed": 8.0 * WORKLOADS[workload]["B"] * WORKLOADS[workload]["N"] ** 2}
+            except Exception as e:  # noqa: BLE001
+                flops, extra = 0.0, {"executed_flops_error": repr(e)[:120]}
         listed += len(durs)
         meas = sum(durs)
         f_hbm, f_fl = nbytes / (HBM_PEAK_GBS * 1e9) * 1e6, flops / (F32_MFMA_PEAK_TF * 1e12) * 1e6
@@ -479,6 +526,7 @@ def step_roofline(workload, serial_ms=None, in_flight_ms=None, depth=None, timeo
         rows.append({"kernel": pat, "launches": len(durs), "what": what, "bytes": nbytes, "flops": flops, "bound": bound,
                      "floor_us": round(floor, 2), "floor_hbm_us": round(f_hbm, 2), "floor_f32_us": round(f_fl, 2),
                      "measured_us": round(meas, 2), "frac": round(floor / meas, 4) if meas > 0 and floor > 0 else None})
+        rows[-1].update(extra)
     other = [(n, (e - s) / 1e3) for n, s, e in last if not any(r["kernel"] in n for r in rows)]
     out["kernels"] = rows
     out["unlisted_kernels_us"] = round(sum(t for _, t in other), 2)
@@ -490,7 +538,9 @@ def step_roofline(workload, serial_ms=None, in_flight_ms=None, depth=None, timeo
         out["one_step_at_a_time"] = {"ms_per_step": serial_ms, "frac_step": tot_floor / 1e3 / serial_ms}
     if in_flight_ms:
         out["in_flight"] = {"steps_in_flight": depth, "ms_per_step": in_flight_ms, "frac_step": tot_floor / 1e3 / in_flight_ms}
-    out["note"] = ("floor_us = max(bytes / 8 TB/s, flops / 157.3 TF) per kernel; FPS and the sorts are latency chains on "
+    out["note"] = ("floor_us = max(bytes / 8 TB/s, EXECUTED flops / 157.3 TF) per kernel -- the pruned searches (FPS box lists, "
+                   "kNN of the sampled sets, three_nn) carry a bytes-only floor, knn_grid a lower bound of the candidates it "
+                   "visits: no fraction is taken against brute-force pairs that are never computed; FPS and the sorts are latency chains on "
                    "one CU per cloud -- their floors assume the whole chip and are never reached by one step, which is "
                    "why steps run in flight; PMC utilisation of the same forward: profiles/r04_*_pmc_step_*.txt")
     return out
@@ -1208,6 +1258,25 @@ def main():
                         knn[nm] = {"dh3d_knn_grid_ms": event_time_ms(lambda: pm.knn_grid(srt, gbox, cells, 8), iters=20, warm=3),
                                    "pruned_scan_ms": event_time_ms(lambda: pm.knn_sorted(srt, gbox, 8), iters=20, warm=3),
                                    "clouds_sent_to_the_scan": int((cells[:, 4106] != 0).sum())}
+                real = {}
+                try:  # the reference's own demo clouds (fixture): the same step and the same kNN launches
+                    rp = real_oxford_clouds(wl["B"], wl["N"], dev)
+                    if rp is not None:
+                        with torch.no_grad():
+                            rrun = model.graphed(rp, outputs=(wl["out"],))
+                            rrun.static_input.copy_(rp)
+                            dtr = time_steps(rrun, rrun.static_input, args.steps, args.warmup, dev)
+                            srt, gbox, cells = pm.spatial_sort_cells(rp)
+                            real = {"input": "evaluate/local_eval/demo_data/{268,642}.bin (Oxford LiDAR, metres), the %d points "
+                                             "nearest to the centroid, %d clouds" % (wl["N"], wl["B"]),
+                                    "one_step_at_a_time": {"ms_per_step": dtr / args.steps * 1e3, "value": wl["B"] * args.steps / dtr,
+                                                           "ratio_to_uniform_cube": (dtr / args.steps * 1e3) / serial["ms_per_step"]},
+                                    "knn_K8": {"dh3d_knn_grid_ms": event_time_ms(lambda: pm.knn_grid(srt, gbox, cells, 8), iters=20, warm=3),
+                                               "pruned_scan_ms": event_time_ms(lambda: pm.knn_sorted(srt, gbox, 8), iters=20, warm=3),
+                                               "clouds_sent_to_the_scan": int((cells[:, 4106] != 0).sum())}}
+                except Exception as e:  # noqa: BLE001
+                    real = {"error": repr(e)[:200]}
+                line["data_sensitivity_real_oxford"] = real
                 line["data_sensitivity"] = {
                     "input": "scene-like clouds (bench.scene_like_clouds: ground plane + walls + clutter in [-1, 1], z extent a tenth of x / y)",
                     "one_step_at_a_time": {"ms_per_step": dts / args.steps * 1e3, "value": wl["B"] * args.steps / dts,

@@ -240,6 +240,17 @@ __device__ __forceinline__ float4 idw_mix(const float4 a, const float4 b, const 
   return r;
 }
 #pragma clang fp contract(fast)
+// the same mix with fused multiply-adds (3 instructions per channel instead of 5): for the COMMUTED walks, whose
+// arithmetic is not the reference's association anyway (the interpolation there runs on rows a linear layer has
+// already been applied to)
+__device__ __forceinline__ float4 idw_mix_fma(const float4 a, const float4 b, const float4 c, float w1, float w2, float w3) {
+  float4 r;
+  r.x = fmaf(c.x, w3, fmaf(b.x, w2, a.x * w1));
+  r.y = fmaf(c.y, w3, fmaf(b.y, w2, a.y * w1));
+  r.z = fmaf(c.z, w3, fmaf(b.z, w2, a.z * w1));
+  r.w = fmaf(c.w, w3, fmaf(b.w, w2, a.w * w1));
+  return r;
+}
 
 // Up-sampling source for the x1 half (three_interpolate with inverse-distance weights, core/backbones.py:91-95,
 // fused into the A staging): x1[r, :] = sum_t w[r,t] * points[cloud(r), idx[r,t], :], exactly the arithmetic of
@@ -972,11 +983,15 @@ __global__ __launch_bounds__(256) void interp_head_lds_kernel(const float *__res
     if (ep.pre_bias) pb = *reinterpret_cast<const float4 *>(ep.pre_bias + c);
     if (ep.scale) sc = *reinterpret_cast<const float4 *>(ep.scale + c);
     if (ep.shift) sh = *reinterpret_cast<const float4 *>(ep.shift + c);
+    sh.x = fmaf(pb.x, sc.x, sh.x); sh.y = fmaf(pb.y, sc.y, sh.y); sh.z = fmaf(pb.z, sc.z, sh.z); sh.w = fmaf(pb.w, sc.w, sh.w);
     const float4 wf = *reinterpret_cast<const float4 *>(w_fc + c);
     __syncthreads();
-    // ---- the wave's 32 points, two at a time (a plain loop: small code, bounded registers).  Slots and weights are
+    // ---- the wave's 32 points, four at a time (a plain loop: small code, bounded registers).  Slots and weights are
     // wave-uniform: through the scalar unit, so a row address is scalar base + lane offset and the rare overflow test
-    // (a row beyond the slot capacity: read from global memory) is a scalar branch.
+    // (a row beyond the slot capacity: read from global memory) is a scalar branch.  Per point and slice: three 16-byte
+    // LDS reads, 12 fma-class instructions for the mix, 4 x (fma, max, fma) for BatchNorm (pre-bias folded into the
+    // shift) + ReLU + the fc dot.  (Keeping the 32 per-lane partial sums in registers across the slices -- one
+    // cross-lane reduction per point instead of one per point and slice -- needs the loop unrolled 32 x: 280 VGPRs, spills.)
     auto slice_points = [&](auto ovf) __attribute__((always_inline)) {
       constexpr bool OVF = decltype(ovf)::value;
       for (int p = 0; p < kIHPW; p += 4) {
@@ -988,12 +1003,12 @@ __global__ __launch_bounds__(256) void interp_head_lds_kernel(const float *__res
           const float4 sw = *reinterpret_cast<const float4 *>(s_w + pt * 4);
           const int s0 = __builtin_amdgcn_readfirstlane(si.x), s1 = __builtin_amdgcn_readfirstlane(si.y),
                     s2 = __builtin_amdgcn_readfirstlane(si.z);
-          const float4 v = idw_mix(ih_row4<OVF>(s_rows, Hs, s0, lane, RS), ih_row4<OVF>(s_rows, Hs, s1, lane, RS),
-                                   ih_row4<OVF>(s_rows, Hs, s2, lane, RS), sw.x, sw.y, sw.z);  // padding: weight 0
-          float a = fmaxf((v.x + pb.x) * sc.x + sh.x, lo) * wf.x;
-          a = fmaf(fmaxf((v.y + pb.y) * sc.y + sh.y, lo), wf.y, a);
-          a = fmaf(fmaxf((v.z + pb.z) * sc.z + sh.z, lo), wf.z, a);
-          a = fmaf(fmaxf((v.w + pb.w) * sc.w + sh.w, lo), wf.w, a);
+          const float4 v = idw_mix_fma(ih_row4<OVF>(s_rows, Hs, s0, lane, RS), ih_row4<OVF>(s_rows, Hs, s1, lane, RS),
+                                       ih_row4<OVF>(s_rows, Hs, s2, lane, RS), sw.x, sw.y, sw.z);  // padding: weight 0
+          float a = fmaxf(fmaf(v.x, sc.x, sh.x), lo) * wf.x;
+          a = fmaf(fmaxf(fmaf(v.y, sc.y, sh.y), lo), wf.y, a);
+          a = fmaf(fmaxf(fmaf(v.z, sc.z, sh.z), lo), wf.z, a);
+          a = fmaf(fmaxf(fmaf(v.w, sc.w, sh.w), lo), wf.w, a);
           part[h] = a;
         }
         // row sums of two points per reduction: one half-swap + five DPP adds, no LDS crossbar (wave_ops.h)
@@ -1044,8 +1059,8 @@ __global__ __launch_bounds__(256) void interp_head_lds_kernel(const float *__res
           const float4 sw = *reinterpret_cast<const float4 *>(s_w + pt * 4);
           const int s0 = __builtin_amdgcn_readfirstlane(si.x), s1 = __builtin_amdgcn_readfirstlane(si.y),
                     s2 = __builtin_amdgcn_readfirstlane(si.z);
-          const float4 v = idw_mix(ih_row4<OVF>(s_rows, Cs, s0, lane), ih_row4<OVF>(s_rows, Cs, s1, lane),
-                                   ih_row4<OVF>(s_rows, Cs, s2, lane), sw.x, sw.y, sw.z);
+          const float4 v = idw_mix_fma(ih_row4<OVF>(s_rows, Cs, s0, lane), ih_row4<OVF>(s_rows, Cs, s1, lane),
+                                       ih_row4<OVF>(s_rows, Cs, s2, lane), sw.x, sw.y, sw.z);
           part[h] = fmaf(v.w, v.w, fmaf(v.z, v.z, fmaf(v.y, v.y, v.x * v.x)));
         }
         const float t01 = pair_wave_sum_f32(part[0], part[1]), t23 = pair_wave_sum_f32(part[2], part[3]);

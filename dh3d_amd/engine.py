@@ -12,9 +12,9 @@ exactly that graph, so a slot's outputs are bit-equal to the serial forward of t
     ...                               # up to depth-1 further submits before the slot is reused
     outs = pipe.result(t)             # the CURRENT stream waits for that step; dict of the slot's static buffers
 
-Zero-copy hand-over: write the batch into `pipe.input_buffer(slot)` (e.g. as the destination of the host-to-device
-copy, enqueued on `pipe.stream(slot)` or on the current stream before the submit -- submit() always orders the slot's
-stream behind the current one) and call `pipe.submit()` without an argument.
+Zero-copy hand-over: write the batch into `pipe.input_buffer(slot)` ON `pipe.stream(slot)` (e.g. as the destination of
+the host-to-device copy enqueued there) and call `pipe.submit()` without an argument; a batch written on the current
+stream instead needs `pipe.submit(after_current=True)`.
 """
 import torch
 
@@ -74,18 +74,22 @@ class Pipeline:
         return self._seq % self.depth
 
     # ------------------------------------------------------------------ steps
-    def submit(self, points=None, knn_inds=None):
+    def submit(self, points=None, knn_inds=None, after_current=None):
         """Enqueue one full forward on the next slot.  `points` (optional) is copied into the slot's input buffer on the
         slot's stream, after the caller's stream has reached this point (so a batch produced on the current stream is
-        complete) and after the previous consumer of this slot's outputs (result()) is done with them."""
+        complete) and after the previous consumer of this slot's outputs (result()) is done with them.
+
+        Zero-copy (no `points`): the batch must already be in `input_buffer(slot)`, written ON `stream(slot)` -- or on
+        the current stream with `after_current=True`, which orders the slot's stream behind the current one first (an
+        event record + wait per submit: measured 31.1 k -> 26.4 k clouds/s on the local workload four deep, which is why
+        it is not the default for the zero-copy path).  With `points` given the order is always established."""
         if self.model.weights_version != self._version:
             raise RuntimeError("the model's weights changed (optimiser step / invalidate / load_state_dict) after this "
                                "pipeline was captured: build a new one")
         k = self._seq % self.depth
         run, st = self._runs[k], self._streams[k]
-        # ALWAYS ordered behind the caller's stream: a batch written into input_buffer(slot) on the current stream
-        # (the zero-copy hand-over) is complete before the slot's graph reads it -- an event wait, no host block
-        st.wait_stream(torch.cuda.current_stream(run.static_input.device))
+        if after_current or (after_current is None and (points is not None or knn_inds is not None)):
+            st.wait_stream(torch.cuda.current_stream(run.static_input.device))
         # the copies below run on the slot's stream: tell the caching allocator, or a caller that drops `points`
         # right after submit() may see its block handed out again (on ITS stream) before the copy has read it
         for t in (points, knn_inds):
