@@ -292,7 +292,7 @@ def flex_conv_roofline(dev, in_step_ms=None, pmc=True, B=8, N=8192, K=8, Din=64,
         "traffic": traffic, "traffic_source": src, "launch_ms": ms, "algorithmic_bytes": fr["algorithmic_bytes"],
         "launch_ms_f32_mfma_kernel": ms_f32,
         "gather_effective": fr["gather_effective"], "f32_equivalent_flops": fr["f32_equivalent_flops"],
-        "binding_roof": "SIMD issue + FP32-VALU/MFMA exclusion (DESIGN.md 3.5)",
+        "binding_roof": "VALU issue port (one instruction per ~4.7 cycles per SIMD) + matrix pipe (DESIGN.md 3.5)",
     }
     if in_step_ms is not None:
         Bc = fr["algorithmic_bytes"]
