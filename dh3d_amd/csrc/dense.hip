@@ -526,6 +526,7 @@ __global__ __launch_bounds__(256) void interp_combine_kernel(const float *__rest
                                                             const float *__restrict__ prefix, float l2_eps,
                                                             float *__restrict__ out) {
   constexpr int C = 128;
+  __shared__ float s_cat[L2CAT ? 4 * RPW * (C + 3) : 1];   // L2CAT: the four waves' output rows, staged for contiguous stores
   const int lane = threadIdx.x & 63, half = lane >> 5, sub = lane & 31, c4 = sub * 4;
   const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
   if (row0 >= n) return;
@@ -574,14 +575,25 @@ __global__ __launch_bounds__(256) void interp_combine_kernel(const float *__rest
       ss += __shfl_xor(ss, 16, 64);
       const float inv = rsqrtf(fmaxf(ss, l2_eps));
       const float pf = prefix[row * 3 + min(sub, 2)];
-      if (live) {
-        float *o = out + row * (C + 3);
-        if (sub < 3) o[sub] = pf;
-        o[3 + c4] = v.x * inv; o[4 + c4] = v.y * inv; o[5 + c4] = v.z * inv; o[6 + c4] = v.w * inv;
-      }
+      // 131-float rows: a lane's four channels start at byte 524 row + 12 + 16 sub -- stored from here they are four
+      // 4-byte stores per lane with a 16-byte stride (a quarter of every line per instruction).  The wave's RPW rows are
+      // ONE contiguous run of 524 RPW bytes: staged in LDS (the wave's own region) and written as consecutive dwords below.
+      float *so = s_cat + (size_t)(threadIdx.x >> 6) * (RPW * (C + 3)) + (size_t)src * (C + 3);
+      if (sub < 3) so[sub] = pf;
+      so[3 + c4] = v.x * inv; so[4 + c4] = v.y * inv; so[5 + c4] = v.z * inv; so[6 + c4] = v.w * inv;
     } else if (live) {
       *reinterpret_cast<float4 *>(out + row * C + c4) = v;
     }
+  }
+  if (L2CAT) {
+    const int rows = min(RPW, n - row0);                  // wave-uniform
+    const float *sw = s_cat + (size_t)(threadIdx.x >> 6) * (RPW * (C + 3));
+    float *ow = out + (base + row0) * (C + 3);
+    const int total = rows * (C + 3);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // this wave's LDS writes above, read back by other lanes
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+    for (int e = lane; e < total; e += 64) ow[e] = sw[e];
   }
 }
 
