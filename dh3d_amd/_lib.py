@@ -134,6 +134,8 @@ _SIGNATURES = {
                                                 c_fp, c_float, c_fp, c_fp],
     "dh3d_interp_combine_fwd": [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, ctypes.POINTER(Epilogue), c_fp, c_fp,
                                 c_float, c_fp, c_fp],
+    "dh3d_local_tail_fused_fwd": [c_fp, c_fp, c_fp, c_fp, ctypes.POINTER(Epilogue), ctypes.POINTER(Epilogue), c_fp, c_fp,
+                                  c_fp, c_fp, c_float, c_int, c_int, c_int, c_fp, c_fp],
     "dh3d_linear_slices_pm_x6_fwd": [c_fp, c_int, c_fp, c_int, c_int, c_fp, c_fp],
     "dh3d_interp_head_fwd": [c_fp, c_int, c_fp, c_fp, c_int, c_int, c_int, ctypes.POINTER(Epilogue), c_fp, c_float,
                              c_fp, c_fp],

@@ -159,6 +159,22 @@ class Conv2D1x1(nn.Module):
         return pm.interp_combine(cw, idx, dist, partial, pre_bias=p["b"], scale=p["scale"], shift=p["shift"], act=act,
                                  residual=residual, l2cat=l2cat)
 
+    def tail_fusable(self, shortcut_conv, n):
+        """forward_commuted_fused available: this (commuted) concat conv and the caller's shortcut conv are both
+        64 -> 128 on full-resolution rows of n points per cloud (rule on the points per cloud only, never the batch)."""
+        p, q = self._prep or self.prepare(), shortcut_conv._prep or shortcut_conv.prepare()
+        return (TAIL_FUSED and self.cout == 128 and p.get("c_top") == 128 and self.cin - 128 == 64 and "wp3_bot" in p
+                and shortcut_conv.cin == 64 and shortcut_conv.cout == 128 and "wp3" in q and n % 32 == 0 and n > 4096)
+
+    def forward_commuted_fused(self, coarse, idx, dist, x2, x1, shortcut_conv, l2cat, cw=None):
+        """forward_commuted(partial = lower_partial(x2), residual = relu(BN(shortcut_conv(x1))), l2cat) with both 64 -> 128
+        GEMMs inside the tail kernel: their [B,N,128] outputs are never written (pm.local_tail_fused)."""
+        p, q = self._prep, shortcut_conv._prep
+        if cw is None:
+            cw = pm.linear(coarse, p["wp_top"], self.cout)
+        return pm.local_tail_fused(x1, x2, q["wp3"], p["wp3_bot"], (q["b"], q["scale"], q["shift"]),
+                                   (p["b"], p["scale"], p["shift"]), cw, idx, dist, l2cat[0], l2cat[1])
+
     def upsampled_supported(self, coarse, idx, x2):
         """Can forward_upsampled serve this call?  (same batch-independent rule as forward's x6 choice)"""
         p = self._prep or self.prepare()
@@ -319,6 +335,11 @@ def gather_rows(points, idx):
 SE_TAILS = os.environ.get("DH3D_SE_TAILS", "0") == "1"
 # dev A/B switch (DH3D_FLEX_TX6=0: the exact-f32 MFMA tile kernel for the sampled levels)
 FLEX_TX6 = os.environ.get("DH3D_FLEX_TX6", "1") != "0"
+# dev A/B switch (DH3D_TAIL_FUSED=1: the local step's tail -- shortcut conv, the concat conv's lower block, up-sampling,
+# epilogue, l2-normalised rows -- as ONE launch, csrc/dense_tail.hip.  Measured: 27.5 us instead of 52 us of kernels and
+# 130 MB less HBM traffic per step, but the two GEMMs move from beside the sampling chain to behind it: one step at a
+# time 0.500 -> 0.507 ms, four in flight 0.252 vs 0.252-0.261 -- DEADENDS.md -- so off by default; the kernel stays tested)
+TAIL_FUSED = os.environ.get("DH3D_TAIL_FUSED", "0") == "1"
 
 
 def compute_level(xyz, dilate, knn, ordered=None, fps_contract=None):
@@ -468,11 +489,13 @@ class FlexConvDilate(nn.Module):
         return conv.lower_partial(feat)
 
     def forward(self, geo, feat, nbr=None, residual=None, l2cat=None, shortcut_src=None, lower_partial=None,
-                coarse_only=False, post_conv=None, post_linear=None, post_tails=None):
+                coarse_only=False, post_conv=None, post_linear=None, post_tails=None, fused_tail=None):
         """geo: Geometry; feat [B,N,cin]; nbr [B,N,K] for dilate == 1 (else computed on the sampled set);
         residual [B,N,cout]: added to the concat conv's output in its store (the caller's shortcut branch);
         l2cat = (prefix [B,N,3], eps): return [prefix | l2_normalize(output)] instead of the output;
-        lower_partial: commuted_partial(feat), computed earlier by the caller; post_conv: a Conv2D1x1 the caller applies
+        lower_partial: commuted_partial(feat), computed earlier by the caller; fused_tail = (x1, shortcut conv): instead of
+        lower_partial / residual, both GEMMs run inside the tail kernel (Conv2D1x1.forward_commuted_fused; needs l2cat);
+        post_conv: a Conv2D1x1 the caller applies
         to this block's output next -- where it can ride in the SE kernel the result is (output, post_conv(output))."""
         prep = self._prep or self.prepare()
         self._last_post = None
@@ -528,8 +551,8 @@ class FlexConvDilate(nn.Module):
                 if len(r) == 4:  # (None, post_conv(output), tail on the output, tail on post_conv(output)): one launch
                     return r
                 x, post = r  # x is this block's output
-            elif (self.upsample and self.dilate > 1 and not coarse_only and cconv is not None and lower_partial is not None
-                  and shortcut_src is None and x.shape[2] == 128 and cconv.cout == 128
+            elif (self.upsample and self.dilate > 1 and not coarse_only and cconv is not None
+                  and (lower_partial is not None or fused_tail is not None) and shortcut_src is None and x.shape[2] == 128 and cconv.cout == 128
                   and (self.se._prep or self.se.prepare())[4] is not None and cconv._prep.get("c_top") == 128):
                 # the commuted concat conv's upper block (coarse @ W_top, no bias / activation: those belong to the sum)
                 # rides in the SE kernel: one launch + its dependency gap less on the chain behind the sampling
@@ -545,6 +568,9 @@ class FlexConvDilate(nn.Module):
             if coarse_only:  # the caller commutes the up-sampling through whatever consumes it (model.compute_global)
                 return x
             conv = self.concat_conv1d.tfconv0 if self.concat else None
+            if conv is not None and fused_tail is not None:
+                return conv.forward_commuted_fused(x, lv["nn3_idx"], lv["nn3_dist"], feat, fused_tail[0], fused_tail[1],
+                                                   l2cat, cw=cw_top)
             if conv is not None and lower_partial is not None and shortcut_src is None:
                 return conv.forward_commuted(x, lv["nn3_idx"], lv["nn3_dist"], lower_partial, act=pm.ACT_RELU,
                                              residual=residual, l2cat=l2cat, cw=cw_top)

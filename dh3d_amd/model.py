@@ -331,12 +331,19 @@ class DH3D(nn.Module):
             #  A/B: cfg 3 -23 us, cfg 2 +6 us.  The rule looks at the points per cloud only, never at the batch: the
             #  two forms differ in the rounding of the final sum and a sharded batch must reproduce the unsharded
             #  result bit for bit.)
-            if shortcut is None and not fuse_sc:
+            # the step's tail as ONE launch (csrc/dense_tail.hip): when only [xyz | l2-normalised descriptors] are wanted
+            # the shortcut conv and the concat conv's lower block run INSIDE the gather / epilogue kernel behind the
+            # sampled level -- their two [Bt,N,128] maps (67 MB written and read back at 8 x 8192) never exist
+            cconv = self.stage2.concat_conv1d.tfconv0 if getattr(self.stage2, "concat", False) else None
+            fused_tail = (_l2cat_eps is not None and not fuse_sc and shortcut is None and lower is None and cconv is not None
+                          and self._local.featdim == 128 and cconv.commuted_supported(128)
+                          and cconv.tail_fusable(self.local_stage1_shortcut.tfconv0, points.shape[1]))
+            if shortcut is None and not fuse_sc and not fused_tail:
                 shortcut = self.local_stage1_shortcut(x1, act=pm.ACT_RELU)
             # larger clouds: stage 2's concat conv is commuted through its up-sampling -- its lower weight block meets
             # x2 here, beside the sampling chain; behind the sampled level only a GEMM on the N/8 rows and one
             # gather / epilogue kernel are left (backbones.Conv2D1x1.forward_commuted)
-            if lower is None and not fuse_sc:
+            if lower is None and not fuse_sc and not fused_tail:
                 lower = self.stage2.commuted_partial(x2)
             if _prezero_tail and getattr(geo, "_tail_accum", None) is None:
                 # the global tail's accumulators (6 MB at cfg 3), zero-filled HERE, beside the sampling chain: the fill
@@ -347,13 +354,14 @@ class DH3D(nn.Module):
             stage1_done = torch.cuda.Event()
             stage1_done.record()
             geo.start_nn3(geo._lv)  # three_nn: waits for the sampled coordinates, overlaps the N/8 convolutions
-            for t in (x2, x1 if fuse_sc else shortcut, geo._lv["nn3_dist"], geo._lv["nn3_idx"], lower):
+            for t in (x2, x1 if (fuse_sc or fused_tail) else shortcut, geo._lv["nn3_dist"], geo._lv["nn3_idx"], lower):
                 if t is not None:
                     t.record_stream(main)
         main.wait_event(stage1_done)  # not the whole side stream: three_nn is joined at the interpolation (geo.finish)
         l2cat = (points, _l2cat_eps) if _l2cat_eps is not None else None
         feat = self.stage2(geo, x2, residual=shortcut, l2cat=l2cat,  # gather, N/8 convs, SE, interpolation, concat conv
-                           shortcut_src=x1 if fuse_sc else None, lower_partial=lower)
+                           shortcut_src=x1 if fuse_sc else None, lower_partial=lower,
+                           fused_tail=(x1, self.local_stage1_shortcut.tfconv0) if fused_tail else None)
         if self._local.featdim < 128:  # core/backbones.py:125-126
             feat = self.final_fc(feat, act=pm.ACT_RELU)
         self._last_geo = geo

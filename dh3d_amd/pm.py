@@ -540,6 +540,27 @@ def interp_combine(coarse_w, idx, dist, partial=None, pre_bias=None, scale=None,
     return out
 
 
+def local_tail_fused(x1, x2, wp3_shortcut, wp3_lower, ep_shortcut, ep_concat, coarse_w, idx, dist, prefix, l2_eps):
+    """[prefix | l2_normalize(relu(BN_c(interp3(coarse_w) + x2 W_lower + b_c)) + relu(BN_s(x1 W_s + b_s)))] [B,N,131] in one
+    launch (csrc/dense_tail.hip): interp_combine with the lower-block and shortcut GEMMs done on the fly.
+    ep_* = (bias, scale, shift) tuples (activation ReLU)."""
+    a = L.require_cuda_f32(x1, "x1", 3)
+    b = L.require_cuda_f32(x2, "x2", 3)
+    cw = L.require_cuda_f32(coarse_w, "coarse_w", 3)
+    ix = L.require_cuda_i32(idx, "idx", 3)
+    d = L.require_cuda_f32(dist, "dist", 3)
+    pf = L.require_cuda_f32(prefix, "prefix", 3)
+    B, N, C = a.shape
+    if C != 64 or b.shape != a.shape or cw.shape[2] != 128 or N % 32:
+        raise ValueError("local_tail_fused: x1 / x2 [B,N,64], coarse_w [B,M,128], N % 32 == 0")
+    out = torch.empty((B, N, 131), dtype=torch.float32, device=a.device)
+    e1, e2 = _ep(*ep_shortcut, ACT_RELU), _ep(*ep_concat, ACT_RELU)
+    L.check(L.lib().dh3d_local_tail_fused_fwd(L.ptr(a), L.ptr(b), L.ptr(wp3_shortcut), L.ptr(wp3_lower), e1, e2, L.ptr(cw),
+                                              L.ptr(ix), L.ptr(d), L.ptr(pf), float(l2_eps), B, N, cw.shape[1], L.ptr(out),
+                                              L.stream_ptr()), "local_tail_fused")
+    return out
+
+
 def pack_weight_x3(W):
     """W [Kd, Dout] f32 -> three exact bf16 chunk planes in MFMA fragment order (csrc/dense_x6.hip)."""
     W = L.require_cuda_f32(W, "W", 2)

@@ -457,6 +457,17 @@ int dh3d_interp_head_sorted_fwd_dev(const float *H, int Hd, int row_major, const
 int dh3d_interp_combine_fwd(const float *coarse_w, const int32_t *idx, const float *dist, const float *partial, int B,
                             int N, int M, int C, const dh3d_epilogue *ep, const float *residual, const float *prefix,
                             float l2_eps, float *out, void *stream);
+/* The whole tail of the local-descriptor forward behind the sampled level in one launch (core/backbones.py:89-100,
+ * 117-123; core/model.py:177-181) -- dh3d_interp_combine_fwd with its `partial` and `residual` operands computed on the
+ * fly instead of read back from memory:
+ *   out[n] = [ prefix[n] | l2_normalize( relu(BN_c(interp3(coarse_w)[n] + x2[n] W_lower + b_c)) + relu(BN_s(x1[n] W_s + b_s)) ) ]
+ * x1, x2 [B,N,64]; wpacked_x3_* = dh3d_pack_weight_x3 of the [64,128] shortcut weight / of the concat conv's lower block
+ * (f32-accurate bf16x6 products); ep_shortcut / ep_concat: bias + folded BatchNorm, activation ReLU; coarse_w [B,M,128];
+ * idx / dist [B,N,3] from three_nn; prefix [B,N,3]; out [B,N,131].  N % 32 == 0. */
+int dh3d_local_tail_fused_fwd(const float *x1, const float *x2, const void *wpacked_x3_shortcut,
+                              const void *wpacked_x3_lower, const dh3d_epilogue *ep_shortcut,
+                              const dh3d_epilogue *ep_concat, const float *coarse_w, const int32_t *idx, const float *dist,
+                              const float *prefix, float l2_eps, int B, int N, int M, float *out, void *stream);
 
 /* a layer wider than 256 as `slices` column slices of 256 in one launch: out [slices][R][256] = x1 @ W[:, 256 j ..],
  * wpacked_x3 = the dh3d_pack_weight_x3 images of the slices back to back (the H operand of dh3d_interp_head_fwd) */

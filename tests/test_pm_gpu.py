@@ -710,3 +710,43 @@ def test_global_tail_equals_upsample_attention_netvlad(dev, B, n, clustered):
     again = pm.global_tail(coarse, i3, d3, srt, slices, Hd, wfc, 0.2, (b, sc, sh, pm.ACT_RELU), wc, cs, ch, W2, Wh, s1, h1,
                            Wg, s2, h2, l2_eps=1e-8)
     assert float((again - got).abs().max()) <= 1e-6 * float(got.abs().max())
+
+
+def test_local_tail_fused_vs_float64_and_vs_the_three_launch_form(dev):
+    """csrc/dense_tail.hip: [xyz | l2norm(relu(BN_c(interp3(cw) + x2 Wl + b_c)) + relu(BN_s(x1 Ws + b_s)))] in one launch
+    against a float64 restatement and against the three launches it replaces (two 64 -> 128 GEMMs + interp_combine)."""
+    from dh3d_amd import pm
+    rng = np.random.default_rng(4242)
+    B, N, M = 2, 4128, 516          # (N % 32 == 0, not a multiple of the 8-wave workgroup's 256 rows)
+    x1 = rng.standard_normal((B, N, 64)).astype(np.float32)
+    x2 = rng.standard_normal((B, N, 64)).astype(np.float32)
+    cw = rng.standard_normal((B, M, 128)).astype(np.float32)
+    Ws = (rng.standard_normal((64, 128)) / 8).astype(np.float32)
+    Wl = (rng.standard_normal((64, 128)) / 8).astype(np.float32)
+    idx = rng.integers(0, M, (B, N, 3)).astype(np.int32)
+    dist = (rng.random((B, N, 3)) * 0.01 + 1e-4).astype(np.float32)
+    dist[0, :5, 0] = 0.0             # coincident sample: weight 1e10 / (1e10 + ...)
+    xyz = rng.random((B, N, 3)).astype(np.float32)
+    eps = [(0.1 * rng.standard_normal(128)).astype(np.float32), (0.5 + rng.random(128)).astype(np.float32),
+           (0.1 * rng.standard_normal(128)).astype(np.float32)]
+    epc = [(0.1 * rng.standard_normal(128)).astype(np.float32), (0.5 + rng.random(128)).astype(np.float32),
+           (0.1 * rng.standard_normal(128)).astype(np.float32)]
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    got = pm.local_tail_fused(T(x1), T(x2), pm.pack_weight_x3(T(Ws)), pm.pack_weight_x3(T(Wl)), tuple(map(T, eps)),
+                              tuple(map(T, epc)), T(cw), T(idx), T(dist), T(xyz), 1e-8).cpu().numpy()
+    # float64 restatement
+    d = np.maximum(dist.astype(np.float64), 1e-10)
+    w = (1.0 / d) / (1.0 / d).sum(-1, keepdims=True)
+    up = sum(w[..., t:t + 1] * np.take_along_axis(cw.astype(np.float64), idx[..., t:t + 1].astype(np.int64), 1) for t in range(3))
+    yc = np.maximum((up + x2.astype(np.float64) @ Wl + epc[0]) * epc[1] + epc[2], 0)
+    ys = np.maximum((x1.astype(np.float64) @ Ws + eps[0]) * eps[1] + eps[2], 0)
+    y = yc + ys
+    exp = np.concatenate([xyz, y / np.sqrt(np.maximum((y * y).sum(-1, keepdims=True), 1e-8))], -1)
+    assert got.shape == (B, N, 131) and np.array_equal(got[..., :3], xyz)
+    assert np.abs(got - exp).max() < 2e-6, np.abs(got - exp).max()
+    # the three-launch form
+    sc = pm.linear_x6(T(x1), pm.pack_weight_x3(T(Ws)), 128, pre_bias=T(eps[0]), scale=T(eps[1]), shift=T(eps[2]), act=pm.ACT_RELU)
+    lo = pm.linear_x6(T(x2), pm.pack_weight_x3(T(Wl)), 128)
+    ref = pm.interp_combine(T(cw), T(idx), T(dist), lo, pre_bias=T(epc[0]), scale=T(epc[1]), shift=T(epc[2]),
+                            act=pm.ACT_RELU, residual=sc, l2cat=(T(xyz), 1e-8)).cpu().numpy()
+    assert np.abs(got - ref).max() < 2e-6, np.abs(got - ref).max()
