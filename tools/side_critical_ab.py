@@ -1,0 +1,33 @@
+"""Dev: the global step (one at a time and two in flight) with three_nn on the main stream in front of the sampled level
+(model._side_is_critical -> True, what cfg 3 takes today) against three_nn on the side stream behind stage 1."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch, bench
+from dh3d_amd.model import DH3D
+dev = torch.device("cuda")
+wl = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "global"]
+orig = DH3D._side_is_critical
+for name, fn in (("rule (as shipped)", orig), ("forced True", staticmethod(lambda p: True)), ("forced False", staticmethod(lambda p: False))):
+    DH3D._side_is_critical = fn
+    model = bench.build_model(wl["preset"], dev, seed=0, num_points=wl["N"])
+    pts = bench.synthetic_clouds(wl["B"], wl["N"], wl["seed"], dev, 0)
+    with torch.no_grad():
+        run = model.graphed(pts, outputs=(wl["out"],))
+        for _ in range(40): run()
+        torch.cuda.synchronize()
+        best = 1e9
+        for rep in range(7):
+            t0 = time.perf_counter()
+            for _ in range(40): run()
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) / 40)
+        pipe = model.pipeline(pts, depth=wl["inflight"], outputs=(wl["out"],))
+        for _ in range(40): pipe.submit()
+        torch.cuda.synchronize()
+        bestp = 1e9
+        for rep in range(7):
+            t0 = time.perf_counter()
+            for _ in range(40): pipe.submit()
+            torch.cuda.synchronize()
+            bestp = min(bestp, (time.perf_counter() - t0) / 40)
+    print("%-18s one at a time %.4f ms   %d in flight %.4f ms" % (name, best * 1e3, wl["inflight"], bestp * 1e3), flush=True)
