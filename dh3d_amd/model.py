@@ -239,7 +239,7 @@ class DH3D(nn.Module):
         # batch -- big batches of small clouds (cfg 3) leave this stream waiting for stage 1, and three_nn beside
         # the N/8 convolutions would slow those down (42 vs 17 us for 64->128 at 32x512); a few big clouds (cfg 2)
         # are the other way round and it runs on the side stream after stage 1 (compute_local).
-        if self._side_is_critical(points):
+        if self._three_nn_before_sampled_level(points):
             bb.finish_level(points, geo._lv, same_stream=True)
             if prezero_tail:  # (this stream has slack here: the side stream ends last)
                 geo._tail_accum = torch.zeros((pm.global_tail_accum_size(points.shape[0], points.shape[1] // 8),),
@@ -285,10 +285,22 @@ class DH3D(nn.Module):
 
     @staticmethod
     def _side_is_critical(points):
-        """Which of the step's two chains ends last (measured model, MI355X): the FPS chain costs ~0.05 us per point of
-        a cloud whatever the batch, kNN(N) + stage 1 on the side stream ~2.5 us per 1000 points of the batch."""
+        """Which of the step's two chains ends last (measured model, MI355X, rounds 2-4): the FPS chain costs ~0.05 us per
+        point of a cloud whatever the batch, kNN(N) + stage 1 on the side stream ~2.5 us per 1000 points of the batch."""
         B, N = points.shape[0], points.shape[1]
         return 80.0 + 2.5e-3 * B * N - 0.05 * N > 60.0
+
+    def _three_nn_before_sampled_level(self, points):
+        """Where three_nn (+ the sampled set's sort) is enqueued: on the MAIN stream between the sampled set's kNN and its
+        convolutions, or on the side stream behind stage 1 (beside those convolutions).  Placement only -- the results
+        are the same bits.  Measured on the same box (tools/side_critical_ab.py, round 5):
+                                   one step at a time          steps in flight (global 2, local 4)
+            global  main / side    0.7238 / 0.7025 ms          0.5935 / 0.6697 ms
+            local   main / side    0.5217 / 0.4996 ms          0.2322 / 0.2797 ms
+        One step alone wants it on the side stream (it leaves the critical chain); with other steps in flight the
+        side stream's slack belongs to THEIR chip-wide kernels and the shorter side chain wins.  So the engine's mode
+        decides (DH3D.steps_in_flight, set by Pipeline while it captures its slots)."""
+        return getattr(self, "steps_in_flight", 1) > 1
 
     def _join_side(self, geo):
         """Everything enqueued on the side stream so far is visible to the current stream."""
