@@ -32,6 +32,9 @@ def tf_variable_name(state_dict_key):
 KNN_GRID = pm.KNN_GRID
 
 
+_DEV_RESERVE = int(os.environ["DH3D_DEV_RESERVE"]) if os.environ.get("DH3D_DEV_RESERVE") else None
+
+
 class DH3D(nn.Module):
     def __init__(self, config=None):
         super().__init__()
@@ -227,7 +230,7 @@ class DH3D(nn.Module):
             geo.ordered(cells=knn_inds is None and self.knn_num <= 8 and KNN_GRID)
         if self._geo_stream is None:
             self._geo_stream = torch.cuda.Stream(device=points.device)
-        side = self._geo_stream
+        side = main if getattr(self, "_single_stream", False) else self._geo_stream  # (dev: tools/single_stream_ab.py)
         fork = torch.cuda.Event()
         fork.record()  # the side stream needs the input (and the ordering) only
         geo._side = side
@@ -251,6 +254,8 @@ class DH3D(nn.Module):
             # the persistent flex_conv kernels of stage 1 run -- they leave those CUs out (placement hint, speed only)
             # (steps_in_flight: a serving loop that overlaps consecutive batches has that many FPS kernels on the chip)
             geo.busy_cus_per_xcd = min(8, getattr(self, "steps_in_flight", 1) * ((points.shape[0] + 7) // 8))
+        if _DEV_RESERVE is not None:  # dev A/B (DH3D_DEV_RESERVE=n: the placement hint of the persistent kernels)
+            geo.busy_cus_per_xcd = _DEV_RESERVE
         side.wait_event(fork)
         with torch.cuda.stream(side):
             if knn_inds is not None:
