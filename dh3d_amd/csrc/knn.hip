@@ -1051,9 +1051,9 @@ DH3D_API int dh3d_knn_sorted(const float *sorted, const float *gbox, int B, int 
 }
 
 // ------------------------------------------------------------------------------------------------ cell-list kNN
-// The same operator on the uniform 16 x 16 x 16 grid spatial_sort_kernel lays over a cloud's bounding box (the top four
-// bits per axis of the Morton key: every grid cell is ONE contiguous range of the sorted records, cells[] holds the
-// ranges).  Where the pruned scan above shares a candidate stream between 64 queries -- the union of their search balls,
+// The same operator on the grid spatial_sort_kernel lays over a cloud's bounding box (the top 12 bits of the sort key,
+// dealt to the axes by extent: 16 x 16 x 16 on a cube, 32 x 32 x 4 on a street scene -- every grid cell is ONE contiguous
+// range of the sorted records, cells[] holds the ranges).  Where the pruned scan above shares a candidate stream between 64 queries -- the union of their search balls,
 // ~1800 candidates per query at 8 x 8192 -- this one gives every query its own cells.  L lanes per query, two passes:
 //   (0) the 27 cells around the query's cell;
 //   (1) every other cell of the BOX the ball of the K-th distance seen so far meets (its own radius per axis), skipping a
@@ -1135,24 +1135,46 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict_
   const float lo[3] = {hd[0], hd[1], hd[2]}, scl[3] = {hd[3], hd[4], hd[5]};
   const float4 qr = sc[valid ? qi : N - 1];
   const float q[3] = {qr.x, qr.y, qr.z};
-  // D = low bits of the 12-bit cell code left out (x0, y0, z0, x1, ...): a coarser grid whose cells are still contiguous
-  // ranges of the order -- 2^D consecutive cells of the table
-  const int drop[3] = {(D + 2) / 3, (D + 1) / 3, D / 3};
+  // The grid: the sort dealt the cell code's 12 bits to the axes by extent (spatial.hip: `sched`, step 0 = the top bit;
+  // a cube: z y x z y x ... = 16 x 16 x 16).  D = low bits of the code left out: a coarser grid whose cells are still
+  // contiguous ranges of the order -- 2^D consecutive cells of the table.
+  const unsigned sched = (unsigned)ct[4107];
+  int nb[3] = {0, 0, 0}, drop[3] = {0, 0, 0};
+#pragma unroll
+  for (int s = 0; s < 12; ++s) {
+    const int a = (int)((sched >> (2 * s)) & 3u);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      nb[c] += (int)(a == c);
+      drop[c] += (int)(a == c && s >= 12 - D);
+    }
+  }
   const int span = 1 << D;
   int cq[3], gmax[3];
   float w[3], eps[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    cq[a] = min(63, max(0, (int)((q[a] - lo[a]) * scl[a]))) >> (2 + drop[a]);  // the sort's cell arithmetic
-    gmax[a] = (16 >> drop[a]) - 1;
+    cq[a] = min((4 << nb[a]) - 1, max(0, (int)((q[a] - lo[a]) * scl[a]))) >> (2 + drop[a]);  // the sort's cell arithmetic
+    gmax[a] = ((1 << nb[a]) >> drop[a]) - 1;
     w[a] = (float)(4 << drop[a]) / scl[a];  // cell width
-    eps[a] = 2.5e-6f * (4.f / scl[a]) * 16.f;  // a point may sit outside its cell's nominal interval by a few ulps of the extent
+    eps[a] = 2.5e-6f * ((float)(4 << nb[a]) / scl[a]);  // a point may sit outside its cell's nominal interval by a few ulps of the extent
   }
-  // the table index of cell (ax, ay, az)
-  auto cell_code = [&](int ax, int ay, int az) {
-    return knn_spread4((unsigned)(ax << drop[0]) & 15u) | (knn_spread4((unsigned)(ay << drop[1]) & 15u) << 1) |
-           (knn_spread4((unsigned)(az << drop[2]) & 15u) << 2);
-  };
+  // the table index of cell (ax, ay, az): every axis' cell number with its bits at their places in the code (per
+  // workgroup, in LDS: 64 entries per axis)
+  __shared__ unsigned s_ctab[3][64];
+  if (threadIdx.x < 192) {
+    const int a = threadIdx.x >> 6, v = threadIdx.x & 63;
+    unsigned code = 0;
+    int rem = nb[a] - drop[a];
+    for (int s = 0; s < 12 - D; ++s)
+      if ((int)((sched >> (2 * s)) & 3u) == a && rem > 0) {
+        --rem;
+        code |= (unsigned)((v >> rem) & 1) << (11 - s);
+      }
+    s_ctab[a][v] = code;
+  }
+  __syncthreads();
+  auto cell_code = [&](int ax, int ay, int az) { return s_ctab[0][ax & 63] | s_ctab[1][ay & 63] | s_ctab[2][az & 63]; };
   KnnState<8> st;
 #pragma unroll
   for (int i = 0; i < 8; ++i) st.keys[i] = ~0ull;
@@ -1174,7 +1196,7 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict_
     const int ax = cq[0] + t - 2;
     okx[t] = (unsigned)ax <= (unsigned)gmax[0];
     d2x[t] = okx[t] ? axis_d2(0, t - 2) : INFINITY;
-    bitx[t] = knn_spread4((unsigned)(ax << drop[0]) & 15u);
+    bitx[t] = s_ctab[0][ax & 63];
   }
   // is the K-th distance strictly inside the block of radius R around the query's cell?  (faces on the grid's border
   // have nothing behind them)

@@ -6,9 +6,15 @@
 //     box is farther from the query group's box than every lane's current K-th distance;
 //   * fps_sorted_kernel (fps.hip) re-evaluates a group's min-distances only when the new sample is
 //     closer to the group's box than the group's current maximum.
-// One 1024-lane workgroup per cloud: cloud bounding box -> 18-bit Morton cell (6 bits per axis) ->
-// stable in-LDS radix sort of 32-bit keys (cell << 14 | original index; N <= 16384) by cell, three 6-bit
-// passes -> sorted float4 records (x, y, z, bits(original index)) and one box per group of 64.
+// One 1024-lane workgroup per cloud: cloud bounding box -> 18-bit cell code -> stable in-LDS radix sort of 32-bit
+// keys (cell << 14 | original index; N <= 16384) by cell, three 6-bit passes -> sorted float4 records (x, y, z,
+// bits(original index)) and one box per group of 64.
+// The cell code (round 5) is a Morton code whose bits are dealt to the axes BY EXTENT: the top 12 bits (the grid of the
+// cell-list kNN) go one at a time to the axis whose cells are currently the widest (ties: z, y, x -- a cube gets 4 + 4 + 4
+// bits interleaved z y x z y x ..., exactly the plain Morton code of rounds 1-4), two more bits per axis follow.  A street
+// scene 36 x 36 x 8 m gets 5 + 5 + 2: 32 x 32 x 4 cells of 1.1 x 1.1 x 2 m instead of 16 x 16 x 16 cells of
+// 2.25 x 2.25 x 0.5 m -- with the ground plane in one or two layers either way, the 27 cells around a query then hold ~60
+// points instead of ~230.  The schedule (which axis every one of the 12 bits belongs to) travels in the cell table's header.
 // (The first version was a bitonic network: 91 barrier-separated stages, 70 us for 8 x 8192 -- on the critical
 //  path of both the kNN and the FPS.  The radix sort produces the identical order: stable by cell = (cell, index).)
 #include <math.h>
@@ -37,19 +43,48 @@ __device__ __forceinline__ unsigned spread6(unsigned v) {  // 6 bits -> every th
   v = (v | (v << 2)) & 0x9249u;
   return v;
 }
+constexpr unsigned kSchedCube = 0x186186u;  // z y x z y x ... : 2 1 0 repeated, step 0 in the low bits
 
-// cells (may be NULL): per cloud kCellInts ints -- [0, 4096]: first sorted position of every 16 x 16 x 16 grid cell in
-// Morton order of the cells (the top 12 bits of the sort key; an empty cell's entry = the next cell's), [4096] = N;
-// [4100..4105] as floats: the grid's origin (x, y, z) and its cells-per-unit scale 64 / extent per axis (a cell = 4
-// Morton steps) -- the uniform grid the cell-list kNN (knn.hip: knn_grid_kernel) searches.
+// Axis of step s of the 18-step bit schedule (step 0 = the code's most significant bit): the 12 grid steps from `sched`
+// (2 bits each), then z y x z y x.
+__device__ __forceinline__ int sched_axis(unsigned sched, int s) { return s < 12 ? (int)((sched >> (2 * s)) & 3u) : 2 - (s - 12) % 3; }
+
+// The 12 grid bits dealt by extent: every step goes to the axis whose cells are the widest so far (at most 6 per axis;
+// ties -- cell widths within 25 % of each other -- go to the highest axis first, so a (near-)cube gets z y x z y x ...).  nb[a] = grid bits of axis a.
+__device__ __forceinline__ unsigned deal_grid_bits(const float ext[3], int nb[3]) {
+  // (scalars and selects only: an array indexed by the winning axis would live in scratch memory)
+  float c0 = ext[0], c1 = ext[1], c2 = ext[2];
+  int n0 = 0, n1 = 0, n2 = 0;
+  unsigned sched = 0;
+#pragma unroll
+  for (int s = 0; s < 12; ++s) {
+    int a = -1;
+    float best = -1.f;
+    if (n2 < 6) { a = 2; best = c2; }
+    if (n1 < 6 && (a < 0 || c1 > best * 1.25f)) { best = a < 0 ? c1 : fmaxf(best, c1); a = 1; }
+    if (n0 < 6 && (a < 0 || c0 > best * 1.25f)) { best = a < 0 ? c0 : fmaxf(best, c0); a = 0; }
+    n0 += (int)(a == 0); n1 += (int)(a == 1); n2 += (int)(a == 2);
+    c0 = a == 0 ? c0 * 0.5f : c0; c1 = a == 1 ? c1 * 0.5f : c1; c2 = a == 2 ? c2 * 0.5f : c2;
+    sched |= (unsigned)a << (2 * s);
+  }
+  nb[0] = n0; nb[1] = n1; nb[2] = n2;
+  return sched;
+}
+
+// cells (may be NULL): per cloud kCellInts ints -- [0, 4096]: first sorted position of every grid cell in the order of
+// the cells' 12-bit codes (the top 12 bits of the sort key; an empty cell's entry = the next cell's), [4096] = N;
+// [4100..4105] as floats: the grid's origin (x, y, z) and the quantisation scale 2^(nb + 2) / extent per axis (a cell = 4
+// quantisation steps); [4107]: the bit schedule (12 x 2 bits, step 0 = the code's top bit) -- the grid the cell-list kNN
+// (knn.hip: knn_grid_kernel) searches.
 template <int PPT>
 __global__ __launch_bounds__(kThreads) void spatial_sort_kernel(const float *__restrict__ xyz, int N,
                                                                int npad, float4 *__restrict__ sorted,
                                                                float *__restrict__ gbox, int *__restrict__ cells,
                                                                int occ_min) {
-  extern __shared__ __attribute__((aligned(16))) unsigned s_raw[];  // keys[2][npad] | hist[16][64] | 6*kWaves floats
+  extern __shared__ __attribute__((aligned(16))) unsigned s_raw[];  // keys[2][npad] | hist[16][64] | 6*kWaves floats | tab[3][256]
   unsigned *s_hist = s_raw + 2 * npad;
   float *s_red = reinterpret_cast<float *>(s_hist + kWaves * 64);
+  unsigned *s_tab = reinterpret_cast<unsigned *>(s_red + 6 * kWaves);  // axis value -> its bits at their places in the code
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const float *pc = xyz + (size_t)b * N * 3;
@@ -82,27 +117,72 @@ __global__ __launch_bounds__(kThreads) void spatial_sort_kernel(const float *__r
     if (lane == 0) { s_red[wave * 6 + a] = wl; s_red[wave * 6 + 3 + a] = wh; }
   }
   __syncthreads();
-  float scale[3];
+  float scale[3], ext[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     float l = INFINITY, h = -INFINITY;
     for (int w = 0; w < kWaves; ++w) { l = fminf(l, s_red[w * 6 + a]); h = fmaxf(h, s_red[w * 6 + 3 + a]); }
     lo[a] = l;
-    scale[a] = 64.f / fmaxf(h - l, 1e-30f);
+    ext[a] = h - l;
   }
-  // ---- keys (registers): cell << 14 | original index; padding sorts last
-  unsigned key[PPT];
+  int nb[3];
+  const unsigned sched = deal_grid_bits(ext, nb);  // (every thread: 36 compares)
 #pragma unroll
-  for (int j = 0; j < PPT; ++j) {
-    const int k = wave * SEG + j * 64 + lane;
-    key[j] = 0xFFFFFFFFu;
-    if (k < N) {
-      const unsigned cx = (unsigned)min(63, max(0, (int)((px[j] - lo[0]) * scale[0])));
-      const unsigned cy = (unsigned)min(63, max(0, (int)((py[j] - lo[1]) * scale[1])));
-      const unsigned cz = (unsigned)min(63, max(0, (int)((pz[j] - lo[2]) * scale[2])));
-      const unsigned cell = spread6(cx) | (spread6(cy) << 1) | (spread6(cz) << 2);
-      key[j] = (cell << 14) | (unsigned)k;
+  for (int a = 0; a < 3; ++a) scale[a] = (float)(4 << nb[a]) / fmaxf(ext[a], 1e-30f);  // nb + 2 bits per axis
+  if (cells && tid == 0) {  // the grid's header, now: origin, scales and schedule need not stay in registers until the end
+    float *hd = reinterpret_cast<float *>(cells + (size_t)b * kCellInts) + 4100;
+    hd[0] = lo[0]; hd[1] = lo[1]; hd[2] = lo[2];
+    hd[3] = scale[0]; hd[4] = scale[1]; hd[5] = scale[2];
+    reinterpret_cast<int *>(hd)[7] = (int)sched;
+  }
+  // (near-)cubic clouds get the plain Morton code of rounds 1-4 from three bit-spreads; any other schedule goes through
+  // per-axis deposit tables in LDS (a table build, a barrier and three look-ups per point: ~2.5 us at 8 x 8192)
+  const bool cube = sched == kSchedCube;  // workgroup-uniform
+  if (!cube) {
+    if (tid < 768) {  // the three axes' deposit tables
+      const int a = tid >> 8, v = tid & 255;
+      unsigned code = 0;
+      int rem = nb[a] + 2;
+      for (int st = 0; st < 18; ++st)
+        if (sched_axis(sched, st) == a && rem > 0) {
+          --rem;
+          code |= (unsigned)((v >> rem) & 1) << (17 - st);
+        }
+      s_tab[tid] = code;
     }
+    __syncthreads();
+  }
+  // ---- keys (registers): cell << 14 | original index; padding sorts last.  Four points at a time; the
+  // 16-points-per-thread instantiation reads its points AGAIN here (L2 hits) instead of keeping 48 coordinate registers
+  // alive across the grid set-up above (it has exactly 128 registers and spilled ~60 of them to scratch otherwise).
+  constexpr bool RELOAD = PPT >= 16;
+  unsigned key[PPT];
+  const int q0 = (4 << nb[0]) - 1, q1 = (4 << nb[1]) - 1, q2 = (4 << nb[2]) - 1;
+#pragma unroll
+  for (int j0 = 0; j0 < PPT; j0 += 4) {
+    float rx[4], ry[4], rz[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (j0 + u >= PPT) continue;
+      if (RELOAD) {
+        const int k = min(wave * SEG + (j0 + u) * 64 + lane, N - 1);
+        rx[u] = pc[(size_t)k * 3]; ry[u] = pc[(size_t)k * 3 + 1]; rz[u] = pc[(size_t)k * 3 + 2];
+      } else {
+        rx[u] = px[j0 + u]; ry[u] = py[j0 + u]; rz[u] = pz[j0 + u];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (j0 + u >= PPT) continue;
+      const int k = wave * SEG + (j0 + u) * 64 + lane;
+      const unsigned cx = (unsigned)min(q0, max(0, (int)((rx[u] - lo[0]) * scale[0])));
+      const unsigned cy = (unsigned)min(q1, max(0, (int)((ry[u] - lo[1]) * scale[1])));
+      const unsigned cz = (unsigned)min(q2, max(0, (int)((rz[u] - lo[2]) * scale[2])));
+      const unsigned cell = cube ? spread6(cx) | (spread6(cy) << 1) | (spread6(cz) << 2)   // (workgroup-uniform choice)
+                                 : s_tab[cx] | s_tab[256 + cy] | s_tab[512 + cz];
+      key[j0 + u] = k < N ? (cell << 14) | (unsigned)k : 0xFFFFFFFFu;
+    }
+    if (RELOAD) __builtin_amdgcn_sched_barrier(0);
   }
   // ---- three stable counting passes over 6-bit digits of the cell.  Per pass: every wave ranks its keys digit by
   // digit (same-digit lanes found with 6 ballots; the running per-(wave, digit) count lives in LDS), one block scan
@@ -232,12 +312,7 @@ __global__ __launch_bounds__(kThreads) void spatial_sort_kernel(const float *__r
     __syncthreads();
     if (lane == 0) atomicAdd(&s_occupied, occupied);
     __syncthreads();
-    if (tid == 0) {
-      float *hd = reinterpret_cast<float *>(ct) + 4100;
-      hd[0] = lo[0]; hd[1] = lo[1]; hd[2] = lo[2];
-      hd[3] = scale[0]; hd[4] = scale[1]; hd[5] = scale[2];
-      ct[4106] = s_occupied < occ_min ? 1 : 0;
-    }
+    if (tid == 0) ct[4106] = s_occupied < occ_min ? 1 : 0;   // (the grid's header was written at the top)
   }
   SPROBE(10);
 }
@@ -247,7 +322,7 @@ int sort_launch(const float *xyz, int B, int N, float4 *sorted, float *gbox, int
   int npad = 2;
   while (npad < N) npad <<= 1;
   if (npad < 64 * kWaves) npad = 64 * kWaves;  // one 64-key step per wave at least
-  const size_t lds = sizeof(unsigned) * (2 * (size_t)npad + kWaves * 64) + sizeof(float) * 6 * kWaves;
+  const size_t lds = sizeof(unsigned) * (2 * (size_t)npad + kWaves * 64 + 3 * 256) + sizeof(float) * 6 * kWaves;
   DH3D_ALLOW_BIG_LDS((spatial_sort_kernel<PPT>));
   // fewer occupied cells than 0.6 x what a uniform cloud of N points leaves non-empty: not a cloud for cell lists (cells[4106])
   const int occ_min = (int)(0.6 * 4096.0 * (1.0 - exp(-(double)N / 4096.0)));
