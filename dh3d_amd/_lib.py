@@ -223,7 +223,7 @@ _RESTYPES = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
-ABI_VERSION = 3  # include/dh3d_hip.h DH3D_ABI_VERSION: the semantics (not just the signatures) this file was written against
+ABI_VERSION = 4  # include/dh3d_hip.h DH3D_ABI_VERSION: the semantics (not just the signatures) this file was written against
 
 
 def lib():

@@ -47,7 +47,7 @@ int dh3d_version(void);                 /* 100*major + minor */
  * dh3d_interp_bn_bwd_sums / dh3d_interp_bn_bwd_apply are no longer zeroed by the library ("zeroed by the CALLER").
  * A binding compares it with the DH3D_ABI_VERSION it was written against and refuses to run on a mismatch
  * (dh3d_amd/_lib.py does). */
-#define DH3D_ABI_VERSION 3
+#define DH3D_ABI_VERSION 4
 int dh3d_abi_version(void);
 const char *dh3d_arch(void);            /* "gfx950" */
 const char *dh3d_status_string(int st); /* static string */
