@@ -161,10 +161,14 @@ class Conv2D1x1(nn.Module):
 
     def tail_fusable(self, shortcut_conv, n):
         """forward_commuted_fused available: this (commuted) concat conv and the caller's shortcut conv are both
-        64 -> 128 on full-resolution rows of n points per cloud (rule on the points per cloud only, never the batch)."""
+        64 -> 128 on full-resolution rows of n points per cloud.  Rule on the points per cloud only, never the batch:
+        clouds of up to 4096 points (where the tail is the step's critical chain and the one-launch form replaces the
+        K = 256 GEMM with the up-sampling fused into its staging: global serial -20 us) take it by default, larger
+        clouds (where its two GEMMs would leave the slack beside the sampling chain) with DH3D_TAIL_FUSED=1 only."""
         p, q = self._prep or self.prepare(), shortcut_conv._prep or shortcut_conv.prepare()
-        return (TAIL_FUSED and self.cout == 128 and p.get("c_top") == 128 and self.cin - 128 == 64 and "wp3_bot" in p
-                and shortcut_conv.cin == 64 and shortcut_conv.cout == 128 and "wp3" in q and n % 32 == 0 and n > 4096)
+        return ((TAIL_FUSED if n > 4096 else TAIL_FUSED_SMALL) and self.cout == 128 and p.get("c_top") == 128
+                and self.cin - 128 == 64 and "wp3_bot" in p and shortcut_conv.cin == 64 and shortcut_conv.cout == 128
+                and "wp3" in q and n % 32 == 0 and n >= 1024)
 
     def forward_commuted_fused(self, coarse, idx, dist, x2, x1, shortcut_conv, l2cat, cw=None):
         """forward_commuted(partial = lower_partial(x2), residual = relu(BN(shortcut_conv(x1))), l2cat) with both 64 -> 128
@@ -173,7 +177,8 @@ class Conv2D1x1(nn.Module):
         if cw is None:
             cw = pm.linear(coarse, p["wp_top"], self.cout)
         return pm.local_tail_fused(x1, x2, q["wp3"], p["wp3_bot"], (q["b"], q["scale"], q["shift"]),
-                                   (p["b"], p["scale"], p["shift"]), cw, idx, dist, l2cat[0], l2cat[1])
+                                   (p["b"], p["scale"], p["shift"]), cw, idx, dist,
+                                   l2cat[0] if l2cat is not None else None, l2cat[1] if l2cat is not None else 0.0)
 
     def upsampled_supported(self, coarse, idx, x2):
         """Can forward_upsampled serve this call?  (same batch-independent rule as forward's x6 choice)"""
@@ -340,6 +345,8 @@ FLEX_TX6 = os.environ.get("DH3D_FLEX_TX6", "1") != "0"
 # 130 MB less HBM traffic per step, but the two GEMMs move from beside the sampling chain to behind it: one step at a
 # time 0.500 -> 0.507 ms, four in flight 0.252 vs 0.252-0.261 -- DEADENDS.md -- so off by default; the kernel stays tested)
 TAIL_FUSED = os.environ.get("DH3D_TAIL_FUSED", "0") == "1"
+# (DH3D_TAIL_FUSED_SMALL=0: clouds of <= 4096 points back on the K = 256 GEMM with the fused up-sampling + shortcut)
+TAIL_FUSED_SMALL = os.environ.get("DH3D_TAIL_FUSED_SMALL", "1") != "0"
 
 
 def compute_level(xyz, dilate, knn, ordered=None, fps_contract=None):

@@ -1,6 +1,7 @@
 // The tail of the local-descriptor forward behind the sampled level, in ONE launch (core/backbones.py:89-100,117-123,
 // core/model.py:177-181):
-//   out[n] = [ xyz[n] | l2_normalize( relu(BN_c( interp3(coarse Wtop)[n] + x2[n] Wbot + b_c )) + relu(BN_s( x1[n] Ws + b_s )) ) ]
+//   y[n]   = relu(BN_c( interp3(coarse Wtop)[n] + x2[n] Wbot + b_c )) + relu(BN_s( x1[n] Ws + b_s ))
+//   out[n] = [ xyz[n] | l2_normalize(y[n]) ]   (local descriptors)   or   y[n]   (the global path's input)
 // Before: two 64 -> 128 GEMM launches (linear_k64_x6_kernel: the shortcut conv on x1, the concat conv's lower block on x2,
 // each reading 16.7 MB and WRITING 33.5 MB at 8 x 8192 points) and interp_combine_kernel reading both maps back
 // (67 MB) -- 200 MB of HBM traffic, 52 us.  Here a wave owns 32 rows: both GEMMs run from registers (bf16x6:
@@ -39,6 +40,8 @@ struct TailArgs {
   long long R;
 };
 
+// L2CAT: [prefix | l2_normalize(y)] rows of 131 floats; else the plain [R, 128] map y (the global path's local features)
+template <bool L2CAT>
 __global__ __launch_bounds__(kTailWaves * 64) void local_tail_fused_kernel(TailArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   uint4 *s_w = reinterpret_cast<uint4 *>(s_raw);                              // [NCB][KB][3][64]: the shortcut weight, then the lower block
@@ -144,7 +147,8 @@ __global__ __launch_bounds__(kTailWaves * 64) void local_tail_fused_kernel(TailA
     shc[cb] = fmaf(pbc[cb], scc[cb], a.ep_c.shift ? a.ep_c.shift[col] : 0.f);
   }
   const float *cwb = a.cw + cloud * (long long)a.m * kTailD + lr;
-  float *orow = a.out + row0 * (kTailD + 3) + 3 + lr;
+  constexpr int OW = L2CAT ? kTailD + 3 : kTailD;
+  float *orow = a.out + row0 * OW + (L2CAT ? 3 : 0) + lr;
   const float *rw = s_rw + (size_t)wave * 32 * 8;
 #pragma unroll
   for (int rg = 0; rg < 16; rg += 2) {   // two rows per lane in flight: 24 gathers
@@ -173,15 +177,18 @@ __global__ __launch_bounds__(kTailWaves * 64) void local_tail_fused_kernel(TailA
         y[cb] = v;
         ss = fmaf(v, v, ss);
       }
-      ss = row16_sum_f32(ss);     // over the 32 lanes of this half (the row's 128 columns), in every lane
-      ss += __shfl_xor(ss, 16, 64);
-      const float inv = rsqrtf(fmaxf(ss, a.l2_eps));
+      float inv = 1.f;
+      if (L2CAT) {
+        ss = row16_sum_f32(ss);     // over the 32 lanes of this half (the row's 128 columns), in every lane
+        ss += __shfl_xor(ss, 16, 64);
+        inv = rsqrtf(fmaxf(ss, a.l2_eps));
+      }
 #pragma unroll
-      for (int cb = 0; cb < kTailNCB; ++cb) orow[(size_t)row * (kTailD + 3) + cb * 32] = y[cb] * inv;
+      for (int cb = 0; cb < kTailNCB; ++cb) orow[(size_t)row * OW + cb * 32] = L2CAT ? y[cb] * inv : y[cb];
     }
   }
   // the xyz prefix of the 32 rows: 96 floats
-  for (int e = lane; e < 96; e += 64) {
+  if (L2CAT) for (int e = lane; e < 96; e += 64) {
     const int p = e / 3, c = e - 3 * p;
     a.out[(row0 + p) * (kTailD + 3) + c] = a.prefix[(row0 + p) * 3 + c];
   }
@@ -194,8 +201,7 @@ DH3D_API int dh3d_local_tail_fused_fwd(const float *x1, const float *x2, const v
                                        const dh3d_epilogue *ep_concat, const float *coarse_w, const int32_t *idx,
                                        const float *dist, const float *prefix, float l2_eps, int B, int N, int M,
                                        float *out, void *stream) {
-  DH3D_REQUIRE(x1 && x2 && wpacked_x3_shortcut && wpacked_x3_lower && coarse_w && idx && dist && prefix && out && B > 0 &&
-               N > 0 && M > 0);
+  DH3D_REQUIRE(x1 && x2 && wpacked_x3_shortcut && wpacked_x3_lower && coarse_w && idx && dist && out && B > 0 && N > 0 && M > 0);
   DH3D_SUPPORTED(N % 32 == 0 && (long long)M * kTailD < (1ll << 31));
   DH3D_SUPPORTED((!ep_shortcut || ep_shortcut->act == DH3D_ACT_RELU) && (!ep_concat || ep_concat->act == DH3D_ACT_RELU));
   TailArgs a;
@@ -204,8 +210,13 @@ DH3D_API int dh3d_local_tail_fused_fwd(const float *x1, const float *x2, const v
   a.ep_s = dh3d_ep(ep_shortcut); a.ep_c = dh3d_ep(ep_concat);
   a.cw = coarse_w; a.idx = idx; a.dist = dist; a.prefix = prefix; a.l2_eps = l2_eps; a.out = out;
   a.n = N; a.m = M; a.R = (long long)B * N;
-  auto kern = local_tail_fused_kernel;
-  DH3D_ALLOW_BIG_LDS(kern);
-  hipLaunchKernelGGL(kern, dim3(dh3d_cdiv(a.R, 32 * kTailWaves)), dim3(kTailWaves * 64), kTailLds, (hipStream_t)stream, a);
+  const dim3 grid(dh3d_cdiv(a.R, 32 * kTailWaves)), block(kTailWaves * 64);
+  if (prefix) {
+    DH3D_ALLOW_BIG_LDS(local_tail_fused_kernel<true>);
+    hipLaunchKernelGGL(local_tail_fused_kernel<true>, grid, block, kTailLds, (hipStream_t)stream, a);
+  } else {   // no prefix: the plain [B, N, 128] map (l2_eps unused)
+    DH3D_ALLOW_BIG_LDS(local_tail_fused_kernel<false>);
+    hipLaunchKernelGGL(local_tail_fused_kernel<false>, grid, block, kTailLds, (hipStream_t)stream, a);
+  }
   return dh3d_launch_status();
 }

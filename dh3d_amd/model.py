@@ -352,9 +352,12 @@ class DH3D(nn.Module):
             # the shortcut conv and the concat conv's lower block run INSIDE the gather / epilogue kernel behind the
             # sampled level -- their two [Bt,N,128] maps (67 MB written and read back at 8 x 8192) never exist
             cconv = self.stage2.concat_conv1d.tfconv0 if getattr(self.stage2, "concat", False) else None
-            fused_tail = (_l2cat_eps is not None and not fuse_sc and shortcut is None and lower is None and cconv is not None
+            small = points.shape[1] <= 4096
+            fused_tail = ((_l2cat_eps is not None or small) and shortcut is None and lower is None and cconv is not None
                           and self._local.featdim == 128 and cconv.commuted_supported(128)
                           and cconv.tail_fusable(self.local_stage1_shortcut.tfconv0, points.shape[1]))
+            if fused_tail:
+                fuse_sc = False   # (the one-launch tail replaces the K = 256 GEMM with the shortcut fused into it)
             if shortcut is None and not fuse_sc and not fused_tail:
                 shortcut = self.local_stage1_shortcut(x1, act=pm.ACT_RELU)
             # larger clouds: stage 2's concat conv is commuted through its up-sampling -- its lower weight block meets

@@ -549,11 +549,11 @@ def local_tail_fused(x1, x2, wp3_shortcut, wp3_lower, ep_shortcut, ep_concat, co
     cw = L.require_cuda_f32(coarse_w, "coarse_w", 3)
     ix = L.require_cuda_i32(idx, "idx", 3)
     d = L.require_cuda_f32(dist, "dist", 3)
-    pf = L.require_cuda_f32(prefix, "prefix", 3)
+    pf = L.require_cuda_f32(prefix, "prefix", 3) if prefix is not None else None   # None: the plain [B,N,128] sum
     B, N, C = a.shape
     if C != 64 or b.shape != a.shape or cw.shape[2] != 128 or N % 32:
         raise ValueError("local_tail_fused: x1 / x2 [B,N,64], coarse_w [B,M,128], N % 32 == 0")
-    out = torch.empty((B, N, 131), dtype=torch.float32, device=a.device)
+    out = torch.empty((B, N, 131 if pf is not None else 128), dtype=torch.float32, device=a.device)
     e1, e2 = _ep(*ep_shortcut, ACT_RELU), _ep(*ep_concat, ACT_RELU)
     L.check(L.lib().dh3d_local_tail_fused_fwd(L.ptr(a), L.ptr(b), L.ptr(wp3_shortcut), L.ptr(wp3_lower), e1, e2, L.ptr(cw),
                                               L.ptr(ix), L.ptr(d), L.ptr(pf), float(l2_eps), B, N, cw.shape[1], L.ptr(out),

@@ -463,7 +463,8 @@ int dh3d_interp_combine_fwd(const float *coarse_w, const int32_t *idx, const flo
  *   out[n] = [ prefix[n] | l2_normalize( relu(BN_c(interp3(coarse_w)[n] + x2[n] W_lower + b_c)) + relu(BN_s(x1[n] W_s + b_s)) ) ]
  * x1, x2 [B,N,64]; wpacked_x3_* = dh3d_pack_weight_x3 of the [64,128] shortcut weight / of the concat conv's lower block
  * (f32-accurate bf16x6 products); ep_shortcut / ep_concat: bias + folded BatchNorm, activation ReLU; coarse_w [B,M,128];
- * idx / dist [B,N,3] from three_nn; prefix [B,N,3]; out [B,N,131].  N % 32 == 0. */
+ * idx / dist [B,N,3] from three_nn; prefix [B,N,3]; out [B,N,131].  N % 32 == 0.
+ * prefix == NULL: out [B,N,128] = the sum before the normalisation (the global path's local features; l2_eps unused). */
 int dh3d_local_tail_fused_fwd(const float *x1, const float *x2, const void *wpacked_x3_shortcut,
                               const void *wpacked_x3_lower, const dh3d_epilogue *ep_shortcut,
                               const dh3d_epilogue *ep_concat, const float *coarse_w, const int32_t *idx, const float *dist,

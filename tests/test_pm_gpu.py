@@ -750,3 +750,8 @@ def test_local_tail_fused_vs_float64_and_vs_the_three_launch_form(dev):
     ref = pm.interp_combine(T(cw), T(idx), T(dist), lo, pre_bias=T(epc[0]), scale=T(epc[1]), shift=T(epc[2]),
                             act=pm.ACT_RELU, residual=sc, l2cat=(T(xyz), 1e-8)).cpu().numpy()
     assert np.abs(got - ref).max() < 2e-6, np.abs(got - ref).max()
+    # no prefix: the plain sum (what the global path consumes)
+    plain = pm.local_tail_fused(T(x1), T(x2), pm.pack_weight_x3(T(Ws)), pm.pack_weight_x3(T(Wl)), tuple(map(T, eps)),
+                                tuple(map(T, epc)), T(cw), T(idx), T(dist), None, 0.0).cpu().numpy()
+    assert plain.shape == (B, N, 128)
+    assert np.abs(plain - y).max() <= 2e-6 * np.abs(y).max(), np.abs(plain - y).max()
