@@ -47,7 +47,7 @@ BF16_MFMA_PEAK_TF = 2500.0
 WORKLOADS = {
     "local": dict(preset="basic_config", B=8, N=8192, seed=2002, out="xyz_feat", inflight=4,
                   name="local-descriptor forward (basic_config), N=8192 K=8, batch=8"),
-    "global": dict(preset="global_config", B=32, N=4096, seed=3003, out="globaldesc", inflight=2,
+    "global": dict(preset="global_config", B=32, N=4096, seed=3003, out="globaldesc", inflight=3,
                    name="global-descriptor forward (global_config), N=4096, 64-cluster NetVLAD, batch=32"),
     "cfg5": dict(preset="detection_config", B=4, N=16384, seed=5005, out="xyz_feat_att", inflight=4,
                  name="dense local feature map (save_all path, detection_config), N=16384 K=8, batch=4, device kNN"),
@@ -854,7 +854,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=0,
                     help="independent steps in flight (graph instances on separate streams, each with its own batch "
                          "buffers, every step one full pass over one batch).  Default 0 = the workload's own (local 4, "
-                         "global 2, cfg5 4): a forward of this path is a latency chain on a few CUs (FPS: one CU per "
+                         "global 3, cfg5 4): a forward of this path is a latency chain on a few CUs (FPS: one CU per "
                          "cloud) followed by chip-wide kernels, so the engine overlaps consecutive batches; 1 = one step "
                          "at a time (also measured and reported as `one_step_at_a_time` in every line).  The training "
                          "step always runs one at a time")
