@@ -19,7 +19,7 @@ The forward step is a hipGraph replay of dh3d_amd.model.DH3D.forward.
 
 Steps in flight.  One forward of this path is a latency chain on a few CUs (farthest point sampling: one CU per cloud
 for two thirds of the local step) followed by chip-wide kernels, so an engine that extracts descriptors for a stream of
-batches keeps SEVERAL steps in flight (local and cfg5: four, global: two): one graph instance per step in flight, each on
+batches keeps SEVERAL steps in flight (local and cfg5: four, global: three): one graph instance per step in flight, each on
 its own stream with its own batch buffers; step i is one full pass over one batch on stream i % depth, and the K timed
 steps include the pipeline's fill and drain.  That is `value` since round 3 (`config.steps_in_flight`).  `one_step_at_a_time` in the same line is the number rounds 1-2 reported as
 `value` (each step finishes before the next one starts); `--inflight 1` makes it `value` again.  The training step
