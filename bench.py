@@ -880,6 +880,10 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or drop the torchrun "
                          "environment and let bench.py spawn the ranks itself)" % (args.gpus, world, args.gpus))
+    if os.environ.get("DH3D_BENCH_SHARE_GPU") == "1":
+        # dev: every rank on GPU 0 (with DH3D_DIST_BACKEND=gloo) -- exercises the N > 1 code path of this file on a
+        # one-GPU box; the numbers of such a run mean nothing
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit("bench.py: rank %d has no GPU (device_count=%d)" % (local_rank, torch.cuda.device_count()))
     dev = torch.device("cuda", local_rank)
