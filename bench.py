@@ -415,8 +415,11 @@ def step_kernel_rows(workload):
     if workload == "global":
         rows += [
             ("group_point_fwd4_kernel", 2, "group_point of the sampled rows (C=64, C=128)", 4 * Rs * (2 + 2 * 64 + 2 * 128), 0.0, "hbm"),
-            ("linear_x6_kernel<1, true>", 1, "concat conv [interp(c)|x2] + shortcut conv -> 128 @N (fused up-sampling)",
+            ("linear_x6_kernel<1, true>", 1, "concat conv [interp(c)|x2] + shortcut conv -> 128 @N (fused up-sampling; rounds 1-4)",
              4 * R * (64 + 64 + 6 + 128) + 4 * Rs * 128, 2.0 * R * 256 * 128, "hbm / matrix pipe"),
+            ("local_tail_fused_kernel", 1, "the local-feature tail in one launch: shortcut conv + concat conv's lower block + "
+                                           "up-sampling of the commuted upper block + BN/ReLU + sum -> 128 @N",
+             4 * R * (64 + 64 + 6 + 128) + 4 * Rs * 128, 2.0 * R * 2 * 64 * 128, "hbm / matrix pipe"),
             ("flex_conv_tx6_kernel<128, 256", 1, "flex_conv 128->256 @N/8 + cluster logits (global; bf16x6 tile GEMM)", ff(B, M, K, 128, 256)[0], ff(B, M, K, 128, 256)[2], "gather + matrix pipe / L2 (weights)"),
             ("flex_conv_pm_kernel<128, 256", 1, "flex_conv 128->256 @N/8 (global; exact-f32 tiles: rounds 1-3)", ff(B, M, K, 128, 256)[0], ff(B, M, K, 128, 256)[2], "f32 MFMA"),
             ("linear_x6_kernel<2, false>", 1, "attention conv 256->1024 on the coarse rows (commuted)", 4 * Rs * (256 + 1024), 2.0 * Rs * 256 * 1024, "matrix pipe"),
@@ -440,6 +443,8 @@ def step_kernel_rows(workload):
             ("linear_pm_kernel<2>", 1, "concat conv's upper block 128->128 on the coarse rows", 4 * Rs * 256, 2.0 * Rs * 128 * 128, "hbm"),
             ("interp_combine_kernel", 1, "up-sampling + bias/BN/ReLU + shortcut + l2-normalise/concat store @N",
              4 * R * (128 + 128 + 6 + 131) + 4 * Rs * 128, 2.0 * R * 3 * 128, "hbm"),
+            ("local_tail_fused_kernel", 1, "(DH3D_TAIL_FUSED=1) the three kernels above in one launch",
+             4 * R * (64 + 64 + 6 + 131) + 4 * Rs * 128, 2.0 * R * 2 * 64 * 128, "hbm / matrix pipe"),
         ]
     return rows
 
