@@ -1320,7 +1320,7 @@ def main():
                 "note": "weak scaling (32 clouds per GPU, the bench's --scaling weak) has no data-path collective: 8x by "
                         "construction, minus whatever eight processes on one host cost; strong scaling of ONE 32-cloud batch "
                         "(4 clouds per GPU) is bounded by the per-cloud latency chain, not by communication.  UNMEASURED on "
-                        "more than one GPU in rounds 1-4 (no 8-GPU node was available to the driver)"}
+                        "more than one GPU in rounds 1-5 (no 8-GPU node was available to the driver)"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("local", "global"):
         line["cpu_baseline"] = cpu_baseline(args.workload)
     D.barrier()
