@@ -833,7 +833,10 @@ DH3D_API int dh3d_linear_slices_pm_x6_fwd(const float *x1, int C1, const void *w
 // Rows beyond the slot capacity (never seen on uniform clouds) are read from global memory like before.
 constexpr int kIHP = 128;    // fine points per workgroup
 constexpr int kIHCap = 64;   // staged coarse rows per slice: a 128-point block touches 46 distinct rows on average, 62 at most (uniform clouds); 48 slots overflowed in 1/3-2/3 of the blocks
-constexpr int kIHPW = kIHP / 4;  // points per wave
+constexpr int kIHW = 8;             // waves per workgroup (two workgroups per CU: four waves per SIMD)
+constexpr int kIHT = kIHW * 64;      // threads
+constexpr int kIHPW = kIHP / kIHW;   // points per wave
+constexpr int kIHTab = (kIHP * 4 * 2 + kIHP + 32 + 33 + kIHCap + kIHP /*s_z*/ + kIHP /*s_inv*/ + 64 + 3) / 4 * 4;  // floats of tables
 
 // VLAD (the global descriptor path): the same walk continues into NetVLAD's soft assignment
 // (core/backbones.py:207-255) -- the up-sampled feature map is never built.  With x[n] = sum_t w_t c[i_t] (c = the
@@ -855,6 +858,34 @@ __device__ __forceinline__ float4 ih_row4(const float *s_rows, const float *gbas
   return *reinterpret_cast<const float4 *>(s_rows + (size_t)slot * 256 + lane * 4);
 }
 
+// Row requests go through buffer loads: a scalar resource (base of the slice) + ONE 32-bit byte offset per row in a VGPR.
+// (As flat 64-bit addresses the eight row offsets took sixteen registers and were spilled around the slice loop.)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ih_rsrc(const float *base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, -1, 0x00020000);  // raw, no bounds clamp
+}
+
+// A wave-uniform slot: through the scalar unit only where the overflow test branches on it (a plain LDS address needs a
+// VGPR anyway: three v_readfirstlane per point and slice saved in the common case).
+template <bool OVF>
+__device__ __forceinline__ int ih_uniform(int v) { return OVF ? __builtin_amdgcn_readfirstlane(v) : v; }
+
+// The same row as two packed-f32 pairs, and the inverse-distance mix on them: v_pk_mul_f32 / v_pk_fma_f32 do two lanes'
+// worth of idw_mix_fma per issue slot with the same association (bit-equal results).  Only for phases WITHOUT matrix
+// work beside them: packed f32 occupies the matrix pipe on gfx950.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct Row4 { f32x2 lo, hi; };
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+template <bool OVF>
+__device__ __forceinline__ Row4 ih_row4p(const float *s_rows, const float *gbase, int slot, int lane, int rs = 256) {
+  const float4 v = ih_row4<OVF>(s_rows, gbase, slot, lane, rs);
+  return Row4{f32x2{v.x, v.y}, f32x2{v.z, v.w}};
+}
+__device__ __forceinline__ Row4 idw_mix_pk(const Row4 a, const Row4 b, const Row4 c, float w1, float w2, float w3) {
+  const f32x2 W1 = {w1, w1}, W2 = {w2, w2}, W3 = {w3, w3};
+  return Row4{pk_fma(c.lo, W3, pk_fma(b.lo, W2, a.lo * W1)), pk_fma(c.hi, W3, pk_fma(b.hi, W2, a.hi * W1))};
+}
+
 struct VladTail {
   const float *coarse;    // [B, m, 256]
   const float *cw;        // [B, m, 64] = coarse @ cluster_weights
@@ -868,21 +899,23 @@ struct VladTail {
 };
 
 template <bool VLAD>
-__global__ __launch_bounds__(256) void interp_head_lds_kernel(const float *__restrict__ H, int NS, long long Rc,
+__global__ __launch_bounds__(kIHT, 2 * kIHW / 4) void interp_head_lds_kernel(const float *__restrict__ H, int NS, long long Rc,
                                                              const int32_t *__restrict__ idx,
                                                              const float *__restrict__ dist,
                                                              const float4 *__restrict__ order, int B, int n, int m,
                                                              int nblk, EpilogueArgs ep, const float *__restrict__ w_fc,
                                                              float b_fc, float *__restrict__ att, VladTail vt) {
   extern __shared__ __attribute__((aligned(16))) float s_ih[];
-  float *s_rows = s_ih;                                   // [kIHCap][256]   (reused as the partial-sum area at the end)
-  int *s_slot = reinterpret_cast<int *>(s_rows + kIHCap * 256);   // [kIHP][4] slot (or -1 - coarse row)
+  // the small tables FIRST: their addresses fit the 16-bit offset field of the ds instructions (behind 64 KB of rows every
+  // table read cost a v_add), the rows behind them
+  int *s_slot = reinterpret_cast<int *>(s_ih);                    // [kIHP][4] slot (or -1 - coarse row)
   float *s_w = reinterpret_cast<float *>(s_slot + kIHP * 4);      // [kIHP][4] interpolation weights
   int *s_orig = reinterpret_cast<int *>(s_w + kIHP * 4);          // [kIHP] original index of the fine point (-1: none)
   unsigned *s_bits = reinterpret_cast<unsigned *>(s_orig + kIHP); // [32] bitmap over the cloud's coarse rows
   int *s_pre = reinterpret_cast<int *>(s_bits + 32);              // [33] popcount prefix
   int *s_row = s_pre + 33;                                        // [kIHCap] slot -> coarse row
-  float *s_z = reinterpret_cast<float *>(s_row + kIHCap);         // [kIHP] logits
+  float *s_z = reinterpret_cast<float *>(s_row + kIHCap);         // [kIHP] logits, then s_inv [kIHP] and s_asum [64]
+  float *s_rows = s_ih + kIHTab;                                  // [kIHCap][256]   (reused by the NetVLAD part)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD x takes clouds x, x + 8, ...: a cloud's H (2 MB) stays in one L2
   const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
@@ -933,7 +966,7 @@ __global__ __launch_bounds__(256) void interp_head_lds_kernel(const float *__res
       s_slot[tid * 4 + t] = slot < kIHCap ? slot : -1 - j;
     }
   }
-  for (int j = tid; j < m; j += 256) {  // slot -> coarse row
+  for (int j = tid; j < m; j += kIHT) {  // slot -> coarse row
     if ((s_bits[j >> 5] >> (j & 31)) & 1u) {
       const int slot = s_pre[j >> 5] + __popc(s_bits[j >> 5] & ((1u << (j & 31)) - 1u));
       if (slot < kIHCap) s_row[slot] = j;
@@ -951,40 +984,60 @@ __global__ __launch_bounds__(256) void interp_head_lds_kernel(const float *__res
   // time when they ran one after the other).  The parked rows are ONE 64-float vector value: as a float4 array the
   // compiler kept them in scratch, stored behind every load and reloaded -- which is why the first attempt at this
   // double buffer measured slower (139 vs 100 us).
-  typedef float f32x64 __attribute__((ext_vector_type(64)));
-  static_assert(kIHCap / 4 <= 16, "parked rows: one f32x64");
-  int rowoff[kIHCap / 4];
-#pragma unroll
-  for (int u = 0; u < kIHCap / 4; ++u) {
-    const int r = wave + 4 * u;
-    rowoff[u] = (bi * m + s_row[r < nd ? r : 0]) * RS + lane * 4;
-  }
-  f32x64 rg;
-#define DH3D_IH_REQUEST(SL)                                                                     \
+  typedef float f32park __attribute__((ext_vector_type(4 * (kIHCap / kIHW))));
+  static_assert(kIHCap % kIHW == 0 && kIHCap / kIHW <= 16, "parked rows: one vector value");
+  f32park rg;
+  // Row requests: buffer loads off a scalar resource, the byte offset of a row rebuilt from the slot table each time (eight
+  // LDS broadcasts per wave and slice; kept in registers the offsets were spilled around the slice loop, and a scratch
+  // reload between two requests waits for the request before it: vmcnt counts in issue order).
+#define DH3D_IH_REQUEST(BASE, RSTRIDE)                                                          \
   {                                                                                             \
-    const float *Hn = H + (size_t)(SL) * SS;                                                    \
-    _Pragma("unroll") for (int u = 0; u < kIHCap / 4; ++u) {                                    \
-      const float4 v = *reinterpret_cast<const float4 *>(Hn + rowoff[u]);                       \
-      rg[4 * u] = v.x; rg[4 * u + 1] = v.y; rg[4 * u + 2] = v.z; rg[4 * u + 3] = v.w;           \
+    const __amdgpu_buffer_rsrc_t rs_ = ih_rsrc(BASE);                                           \
+    _Pragma("unroll") for (int u = 0; u < kIHCap / kIHW; ++u) {                                 \
+      const int r = wave + kIHW * u;                                                            \
+      const unsigned off_ = 4u * (unsigned)((bi * m + s_row[r < nd ? r : 0]) * (RSTRIDE) + lane * 4); \
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_, off_, 0, 0);                   \
+      rg[4 * u] = __uint_as_float(v.x); rg[4 * u + 1] = __uint_as_float(v.y);                   \
+      rg[4 * u + 2] = __uint_as_float(v.z); rg[4 * u + 3] = __uint_as_float(v.w);               \
     }                                                                                           \
   }
-  DH3D_IH_REQUEST(0)
+  DH3D_IH_REQUEST(H, RS)
   for (int sl = 0; sl < NS; ++sl) {
     const float *Hs = H + (size_t)sl * SS + (size_t)bi * m * RS;
+    // The slice's epilogue parameters FIRST, ahead of the next slice's row requests: vmcnt counts in issue order, so
+    // issued behind those requests (rounds 3-5) their first use -- the first point of the slice -- waited for the next
+    // slice's rows and the double buffer overlapped nothing.
+    const int c = sl * 256 + lane * 4;
+    // (four loads back to back, no branch between them -- a branch made each wait for the one before; an absent
+    // parameter reads w_fc and is replaced by its neutral value)
+    float4 pb = *reinterpret_cast<const float4 *>((ep.pre_bias ? ep.pre_bias : w_fc) + c);
+    float4 sc = *reinterpret_cast<const float4 *>((ep.scale ? ep.scale : w_fc) + c);
+    float4 sh = *reinterpret_cast<const float4 *>((ep.shift ? ep.shift : w_fc) + c);
+    const float4 wf = *reinterpret_cast<const float4 *>(w_fc + c);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < kIHCap / 4; ++u) {  // all slots, used or not: no branch between the loads and these stores
-      const int r = wave + 4 * u;
+    for (int u = 0; u < kIHCap / kIHW; ++u) {  // all slots, used or not: no branch between the loads and these stores
+      const int r = wave + kIHW * u;
       *reinterpret_cast<float4 *>(s_rows + (size_t)r * 256 + lane * 4) =
           make_float4(rg[4 * u], rg[4 * u + 1], rg[4 * u + 2], rg[4 * u + 3]);
     }
-    DH3D_IH_REQUEST(sl + 1 < NS ? sl + 1 : sl)  // (unconditional -- the last slice once more)
-    const int c = sl * 256 + lane * 4;
-    float4 pb = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = pb;
-    if (ep.pre_bias) pb = *reinterpret_cast<const float4 *>(ep.pre_bias + c);
-    if (ep.scale) sc = *reinterpret_cast<const float4 *>(ep.scale + c);
-    if (ep.shift) sh = *reinterpret_cast<const float4 *>(ep.shift + c);
+    {  // ONE straight-line request whatever comes next (a branch here joins paths with different numbers of loads in
+       // flight, and the counter wait behind the join then covers the requests as well): the next slice, or behind the
+       // last one the coarse FEATURE rows of the |x| pass below (same slots), or -- attention only -- the last slice again
+      const bool more = sl + 1 < NS;
+      const float *nb = more ? H + (size_t)(sl + 1) * SS : (VLAD ? vt.coarse : H + (size_t)sl * SS);
+      const int nrs = (more || !VLAD) ? RS : 256;
+#if !defined(DH3D_IH_SKIP) || !(DH3D_IH_SKIP & 2)
+      DH3D_IH_REQUEST(nb, nrs)
+#endif
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (!ep.pre_bias) pb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!ep.scale) sc = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (!ep.shift) sh = make_float4(0.f, 0.f, 0.f, 0.f);
     sh.x = fmaf(pb.x, sc.x, sh.x); sh.y = fmaf(pb.y, sc.y, sh.y); sh.z = fmaf(pb.z, sc.z, sh.z); sh.w = fmaf(pb.w, sc.w, sh.w);
-    const float4 wf = *reinterpret_cast<const float4 *>(w_fc + c);
+    const f32x2 sc_lo = {sc.x, sc.y}, sc_hi = {sc.z, sc.w}, sh_lo = {sh.x, sh.y}, sh_hi = {sh.z, sh.w};
+    const f32x2 wf_lo = {wf.x, wf.y}, wf_hi = {wf.z, wf.w}, lo2 = {lo, lo};
     __syncthreads();
     // ---- the wave's 32 points, four at a time (a plain loop: small code, bounded registers).  Slots and weights are
     // wave-uniform: through the scalar unit, so a row address is scalar base + lane offset and the rare overflow test
@@ -994,6 +1047,7 @@ __global__ __launch_bounds__(256) void interp_head_lds_kernel(const float *__res
     // cross-lane reduction per point instead of one per point and slice -- needs the loop unrolled 32 x: 280 VGPRs, spills.)
     auto slice_points = [&](auto ovf) __attribute__((always_inline)) {
       constexpr bool OVF = decltype(ovf)::value;
+#pragma nounroll
       for (int p = 0; p < kIHPW; p += 4) {
         float part[4];
 #pragma unroll
@@ -1001,15 +1055,13 @@ __global__ __launch_bounds__(256) void interp_head_lds_kernel(const float *__res
           const int pt = wave * kIHPW + p + h;
           const int4 si = *reinterpret_cast<const int4 *>(s_slot + pt * 4);
           const float4 sw = *reinterpret_cast<const float4 *>(s_w + pt * 4);
-          const int s0 = __builtin_amdgcn_readfirstlane(si.x), s1 = __builtin_amdgcn_readfirstlane(si.y),
-                    s2 = __builtin_amdgcn_readfirstlane(si.z);
-          const float4 v = idw_mix_fma(ih_row4<OVF>(s_rows, Hs, s0, lane, RS), ih_row4<OVF>(s_rows, Hs, s1, lane, RS),
-                                       ih_row4<OVF>(s_rows, Hs, s2, lane, RS), sw.x, sw.y, sw.z);  // padding: weight 0
-          float a = fmaxf(fmaf(v.x, sc.x, sh.x), lo) * wf.x;
-          a = fmaf(fmaxf(fmaf(v.y, sc.y, sh.y), lo), wf.y, a);
-          a = fmaf(fmaxf(fmaf(v.z, sc.z, sh.z), lo), wf.z, a);
-          a = fmaf(fmaxf(fmaf(v.w, sc.w, sh.w), lo), wf.w, a);
-          part[h] = a;
+          const int s0 = ih_uniform<OVF>(si.x), s1 = ih_uniform<OVF>(si.y), s2 = ih_uniform<OVF>(si.z);
+          const Row4 v = idw_mix_pk(ih_row4p<OVF>(s_rows, Hs, s0, lane, RS), ih_row4p<OVF>(s_rows, Hs, s1, lane, RS),
+                                    ih_row4p<OVF>(s_rows, Hs, s2, lane, RS), sw.x, sw.y, sw.z);  // padding: weight 0
+          const f32x2 t0 = __builtin_elementwise_max(pk_fma(v.lo, sc_lo, sh_lo), lo2);
+          const f32x2 t1 = __builtin_elementwise_max(pk_fma(v.hi, sc_hi, sh_hi), lo2);
+          const f32x2 d = pk_fma(t1, wf_hi, t0 * wf_lo);
+          part[h] = d.x + d.y;
         }
         // row sums of two points per reduction: one half-swap + five DPP adds, no LDS crossbar (wave_ops.h)
         const float t01 = pair_wave_sum_f32(part[0], part[1]), t23 = pair_wave_sum_f32(part[2], part[3]);
@@ -1019,7 +1071,9 @@ __global__ __launch_bounds__(256) void interp_head_lds_kernel(const float *__res
         }
       }
     };
+#if !defined(DH3D_IH_SKIP) || !(DH3D_IH_SKIP & 1)   // dev timing knob (tools/walk_phases.sh): results wrong when set
     if (overflow) slice_points(std::true_type{}); else slice_points(std::false_type{});
+#endif
     __syncthreads();  // the rows are overwritten by the next slice
   }
   if (tid < kIHP) {
@@ -1036,20 +1090,16 @@ __global__ __launch_bounds__(256) void interp_head_lds_kernel(const float *__res
   // ---- (a) |x|: the coarse feature rows, staged like a slice
   {
     const float *Cs = vt.coarse + (size_t)bi * m * 256;
-    float4 rg[kIHCap / 4];
 #pragma unroll
-    for (int u = 0; u < kIHCap / 4; ++u) {
-      const int r = wave + 4 * u;
-      rg[u] = *reinterpret_cast<const float4 *>(Cs + (size_t)s_row[r < nd ? r : 0] * 256 + lane * 4);
-    }
-#pragma unroll
-    for (int u = 0; u < kIHCap / 4; ++u) {
-      const int r = wave + 4 * u;
-      if (r < nd) *reinterpret_cast<float4 *>(s_rows + (size_t)r * 256 + lane * 4) = rg[u];
+    for (int u = 0; u < kIHCap / kIHW; ++u) {  // requested behind the last slice
+      const int r = wave + kIHW * u;
+      *reinterpret_cast<float4 *>(s_rows + (size_t)r * 256 + lane * 4) =
+          make_float4(rg[4 * u], rg[4 * u + 1], rg[4 * u + 2], rg[4 * u + 3]);
     }
     __syncthreads();
     auto norm_points = [&](auto ovf) __attribute__((always_inline)) {
       constexpr bool OVF = decltype(ovf)::value;
+#pragma nounroll
       for (int p = 0; p < kIHPW; p += 4) {
         float part[4];
 #pragma unroll
@@ -1057,11 +1107,11 @@ __global__ __launch_bounds__(256) void interp_head_lds_kernel(const float *__res
           const int pt = wave * kIHPW + p + h;
           const int4 si = *reinterpret_cast<const int4 *>(s_slot + pt * 4);
           const float4 sw = *reinterpret_cast<const float4 *>(s_w + pt * 4);
-          const int s0 = __builtin_amdgcn_readfirstlane(si.x), s1 = __builtin_amdgcn_readfirstlane(si.y),
-                    s2 = __builtin_amdgcn_readfirstlane(si.z);
-          const float4 v = idw_mix_fma(ih_row4<OVF>(s_rows, Cs, s0, lane), ih_row4<OVF>(s_rows, Cs, s1, lane),
-                                       ih_row4<OVF>(s_rows, Cs, s2, lane), sw.x, sw.y, sw.z);
-          part[h] = fmaf(v.w, v.w, fmaf(v.z, v.z, fmaf(v.y, v.y, v.x * v.x)));
+          const int s0 = ih_uniform<OVF>(si.x), s1 = ih_uniform<OVF>(si.y), s2 = ih_uniform<OVF>(si.z);
+          const Row4 v = idw_mix_pk(ih_row4p<OVF>(s_rows, Cs, s0, lane), ih_row4p<OVF>(s_rows, Cs, s1, lane),
+                                    ih_row4p<OVF>(s_rows, Cs, s2, lane), sw.x, sw.y, sw.z);
+          const f32x2 q = pk_fma(v.hi, v.hi, v.lo * v.lo);
+          part[h] = q.x + q.y;
         }
         const float t01 = pair_wave_sum_f32(part[0], part[1]), t23 = pair_wave_sum_f32(part[2], part[3]);
         if ((lane & 31) == 16) {  // tf.nn.l2_normalize: x * rsqrt(max(sum x^2, 1e-12))
@@ -1077,7 +1127,7 @@ __global__ __launch_bounds__(256) void interp_head_lds_kernel(const float *__res
   }
   // ---- (b, c): cw rows (64 floats each) at the head of the row buffer, A' behind them
   const float *Ws = vt.cw + (size_t)bi * m * 64;
-  for (int e = tid; e < nd * 16; e += 256) {
+  for (int e = tid; e < nd * 16; e += kIHT) {
     const int r = e >> 4, q = e & 15;
     *reinterpret_cast<float4 *>(s_rows + r * 64 + q * 4) = *reinterpret_cast<const float4 *>(Ws + (size_t)s_row[r] * 64 + q * 4);
   }
@@ -1089,6 +1139,7 @@ __global__ __launch_bounds__(256) void interp_head_lds_kernel(const float *__res
     float asum_acc = 0.f;
     auto assign_points = [&](auto ovf) __attribute__((always_inline)) {
       constexpr bool OVF = decltype(ovf)::value;
+#pragma nounroll
       for (int p = 0; p < kIHPW; p += 2) {
         float e2[2];
         int sl_[2][3];
@@ -1140,15 +1191,22 @@ __global__ __launch_bounds__(256) void interp_head_lds_kernel(const float *__res
     // ds_add_f32 retires roughly one lane every 2.4 cycles).  Wave = one 32x32 tile: slots 32*(wave>>1).., clusters
     // 32*(wave&1)..
     {
-      const int ti = wave >> 1, tj = wave & 1;
-      if (ti * 32 < nd) {  // block-uniform per wave pair
+      // (of the eight waves the first four -- one per SIMD -- take the four tiles; splitting the points over two copies of
+      // the tiles halved each wave's MFMA chain but doubled the atomics: 233 -> 228 us for the whole tail with ONE copy)
+#ifndef DH3D_IH_SCATTER_COPIES
+#define DH3D_IH_SCATTER_COPIES 1
+#endif
+      constexpr int kCopies = DH3D_IH_SCATTER_COPIES;
+      const int w4 = wave & 3, half = wave >> 2;
+      const int ti = w4 >> 1, tj = w4 & 1;
+      if (ti * 32 < nd && half < kCopies) {  // block-uniform per wave pair
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         const int jrow = ti * 32 + (lane & 31), kk = lane >> 5;
 #pragma unroll 4
-        for (int st = 0; st < kIHP / 2; ++st) {
-          const int pt = 2 * st + kk;
+        for (int st = 0; st < kIHP / 2 / kCopies; ++st) {
+          const int pt = half * (kIHP / kCopies) + 2 * st + kk;
           const int4 si = *reinterpret_cast<const int4 *>(s_slot + pt * 4);
           const float4 sw = *reinterpret_cast<const float4 *>(s_w + pt * 4);
           const float inv = s_inv[pt];
@@ -1158,7 +1216,11 @@ __global__ __launch_bounds__(256) void interp_head_lds_kernel(const float *__res
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int j = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;  // 32x32 accumulator layout
+#if !defined(DH3D_GT_SKIP) || !(DH3D_GT_SKIP & 8)
           if (j < nd) unsafeAtomicAdd(&Ab[(size_t)s_row[j] * 64 + tj * 32 + (lane & 31)], acc[r]);
+#else
+          if (j < nd && acc[r] == 123.456f) Ab[0] = acc[r];
+#endif
         }
       }
     }
@@ -1171,18 +1233,19 @@ __global__ __launch_bounds__(256) void interp_head_lds_kernel(const float *__res
 // order and the coarse rows are staged in LDS (m <= 1024); results equal dh3d_interp_head_fwd up to the summation order
 // of the 1024-term row dot.
 static size_t interp_head_lds_bytes() {
-  return sizeof(float) * ((size_t)kIHCap * 256 + kIHP * 4 * 2 + kIHP + 32 + 33 + kIHCap + kIHP /*s_z*/ + kIHP /*s_inv*/ + 64);
+  return sizeof(float) * ((size_t)kIHCap * 256 + kIHTab);
 }
 
 DH3D_API int dh3d_interp_head_sorted_fwd(const float *H, int Hd, const int32_t *idx, const float *dist,
                                          const float *order, int B, int n, int m, const dh3d_epilogue *ep,
                                          const float *w_fc, float b_fc, float *att, void *stream) {
   DH3D_REQUIRE(H && idx && dist && w_fc && att && B > 0 && n > 0 && m > 0 && Hd > 0);
-  DH3D_SUPPORTED(Hd % 256 == 0 && Hd <= 1024 && m <= 1024 && (!ep || ep->act != DH3D_ACT_SIGMOID));
+  DH3D_SUPPORTED(Hd % 256 == 0 && Hd <= 1024 && m <= 1024 && (!ep || ep->act != DH3D_ACT_SIGMOID) &&
+                 (long long)B * m * Hd < (1ll << 30) /* 32-bit byte offsets of the row requests */);
   const int nblk = dh3d_cdiv(n, kIHP);
   const int per_xcd = dh3d_cdiv(B, 8) * nblk;
   DH3D_ALLOW_BIG_LDS(interp_head_lds_kernel<false>);
-  hipLaunchKernelGGL(interp_head_lds_kernel<false>, dim3(8 * per_xcd), dim3(256), interp_head_lds_bytes(),
+  hipLaunchKernelGGL(interp_head_lds_kernel<false>, dim3(8 * per_xcd), dim3(kIHT), interp_head_lds_bytes(),
                      (hipStream_t)stream, H, Hd / 256, (long long)B * m, idx, dist, reinterpret_cast<const float4 *>(order),
                      B, n, m, nblk, dh3d_ep(ep), w_fc, b_fc, att, VladTail{});
   return dh3d_launch_status();
@@ -1194,14 +1257,15 @@ DH3D_API int dh3d_interp_head_sorted_fwd_dev(const float *H, int Hd, int row_maj
                                              const dh3d_epilogue *ep, const float *w_fc, const float *b_fc_dev,
                                              float *att, void *stream) {
   DH3D_REQUIRE(H && idx && dist && w_fc && b_fc_dev && att && B > 0 && n > 0 && m > 0 && Hd > 0);
-  DH3D_SUPPORTED(Hd % 256 == 0 && Hd <= 1024 && m <= 1024 && (!ep || ep->act != DH3D_ACT_SIGMOID));
+  DH3D_SUPPORTED(Hd % 256 == 0 && Hd <= 1024 && m <= 1024 && (!ep || ep->act != DH3D_ACT_SIGMOID) &&
+                 (long long)B * m * Hd < (1ll << 30) /* 32-bit byte offsets of the row requests */);
   const int nblk = dh3d_cdiv(n, kIHP);
   const int per_xcd = dh3d_cdiv(B, 8) * nblk;
   DH3D_ALLOW_BIG_LDS(interp_head_lds_kernel<false>);
   VladTail vt{};
   vt.b_dev = b_fc_dev;
   if (row_major) { vt.h_ss = 256; vt.h_rs = Hd; }  // H = [B*m][Hd] (one GEMM's output) instead of 256-column slices
-  hipLaunchKernelGGL(interp_head_lds_kernel<false>, dim3(8 * per_xcd), dim3(256), interp_head_lds_bytes(),
+  hipLaunchKernelGGL(interp_head_lds_kernel<false>, dim3(8 * per_xcd), dim3(kIHT), interp_head_lds_bytes(),
                      (hipStream_t)stream, H, Hd / 256, (long long)B * m, idx, dist, reinterpret_cast<const float4 *>(order),
                      B, n, m, nblk, dh3d_ep(ep), w_fc, 0.f, att, vt);
   return dh3d_launch_status();
@@ -1217,7 +1281,8 @@ static int global_tail_launch(const float *H, int Hd, const float *coarse, const
                               float *accum, bool zero_here, hipStream_t s, bool with_gemm = true) {
   DH3D_REQUIRE(H && coarse && cw && idx && dist && w_fc && cl_scale && cl_shift && accum);
   DH3D_REQUIRE(B > 0 && n > 0 && m > 0 && Hd > 0);
-  DH3D_SUPPORTED(Hd % 256 == 0 && Hd <= 1024 && m <= 1024 && (!ep || ep->act != DH3D_ACT_SIGMOID));
+  DH3D_SUPPORTED(Hd % 256 == 0 && Hd <= 1024 && m <= 1024 && (!ep || ep->act != DH3D_ACT_SIGMOID) &&
+                 (long long)B * m * Hd < (1ll << 30) /* 32-bit byte offsets of the row requests */);
   float *apart = accum, *asum = apart + (size_t)B * m * 64, *V = asum + (size_t)B * 64;
   if (zero_here &&
       hipMemsetAsync(accum, 0, sizeof(float) * ((size_t)B * m * 64 + (size_t)B * 64 + (with_gemm ? (size_t)B * 64 * 256 : 0)), s) != hipSuccess)
@@ -1225,7 +1290,7 @@ static int global_tail_launch(const float *H, int Hd, const float *coarse, const
   const int nblk = dh3d_cdiv(n, kIHP);
   const int per_xcd = dh3d_cdiv(B, 8) * nblk;
   DH3D_ALLOW_BIG_LDS(interp_head_lds_kernel<true>);
-  hipLaunchKernelGGL(interp_head_lds_kernel<true>, dim3(8 * per_xcd), dim3(256), interp_head_lds_bytes(), s, H, Hd / 256,
+  hipLaunchKernelGGL(interp_head_lds_kernel<true>, dim3(8 * per_xcd), dim3(kIHT), interp_head_lds_bytes(), s, H, Hd / 256,
                      (long long)B * m, idx, dist, reinterpret_cast<const float4 *>(order), B, n, m, nblk, dh3d_ep(ep),
                      w_fc, b_fc, att, VladTail{coarse, cw, cl_scale, cl_shift, apart, asum});
   const int st = dh3d_launch_status();
