@@ -825,7 +825,7 @@ DH3D_API int dh3d_linear_slices_pm_x6_fwd(const float *x1, int C1, const void *w
 // consecutive points of the Morton order are a compact region whose 384 neighbour references hit only ~35-45 DISTINCT
 // coarse rows: a workgroup finds them with a bitmap (one bit per coarse row of the cloud, prefix popcounts = slots),
 // and for each 256-channel slice stages those rows ONCE (1 KB each, <= 64 slots = 64 KB, so two workgroups share a CU)
-// and lets its four waves read them from LDS -- ~10x less L2 traffic.  The 64 lane partials of a point and slice are
+// and lets its eight waves read them from LDS -- ~10x less L2 traffic.  The 64 lane partials of a point and slice are
 // summed right away (two points per butterfly) into a per-point logit in LDS: a plain loop over the points, small code
 // and few registers (keeping 32 per-lane partials in registers across the slices, fully unrolled, cost 296-512 VGPRs
 // and, with the generic activation inlined 256 times, twice the instruction cache).  (The first attempt,
@@ -979,11 +979,13 @@ __global__ __launch_bounds__(kIHT, 2 * kIHW / 4) void interp_head_lds_kernel(con
   const int RS = vt.h_rs ? vt.h_rs : 256;
   const float lo = ep.act == DH3D_ACT_RELU ? 0.f : -__builtin_inff();  // ReLU as a clamp, or no activation
   if (tid < kIHP) s_z[tid] = 0.f;
-  // ---- staging: wave w takes slots w, w + 4, ...; the rows of slice sl + 1 are requested BEFORE the points of slice
+  // ---- staging: wave w takes slots w, w + 8, ...; the rows of slice sl + 1 are requested BEFORE the points of slice
   // sl are worked on and parked in registers until the buffer is free (staging and per-point work took about the same
-  // time when they ran one after the other).  The parked rows are ONE 64-float vector value: as a float4 array the
+  // time when they ran one after the other).  The parked rows are ONE 32-float vector value: as a float4 array the
   // compiler kept them in scratch, stored behind every load and reloaded -- which is why the first attempt at this
-  // double buffer measured slower (139 vs 100 us).
+  // double buffer measured slower (139 vs 100 us).  Measured by compiling parts out (tools/walk_phases.sh, 32 x 4096):
+  // slot table 17 us, the slices 39 (per-point work 36: LDS reads of 3 KB per point and slice are ~20 of it), |x| 9,
+  // soft assignment 7, MFMA scatter + atomics 17.
   typedef float f32park __attribute__((ext_vector_type(4 * (kIHCap / kIHW))));
   static_assert(kIHCap % kIHW == 0 && kIHCap / kIHW <= 16, "parked rows: one vector value");
   f32park rg;
@@ -1039,12 +1041,14 @@ __global__ __launch_bounds__(kIHT, 2 * kIHW / 4) void interp_head_lds_kernel(con
     const f32x2 sc_lo = {sc.x, sc.y}, sc_hi = {sc.z, sc.w}, sh_lo = {sh.x, sh.y}, sh_hi = {sh.z, sh.w};
     const f32x2 wf_lo = {wf.x, wf.y}, wf_hi = {wf.z, wf.w}, lo2 = {lo, lo};
     __syncthreads();
-    // ---- the wave's 32 points, four at a time (a plain loop: small code, bounded registers).  Slots and weights are
-    // wave-uniform: through the scalar unit, so a row address is scalar base + lane offset and the rare overflow test
-    // (a row beyond the slot capacity: read from global memory) is a scalar branch.  Per point and slice: three 16-byte
-    // LDS reads, 12 fma-class instructions for the mix, 4 x (fma, max, fma) for BatchNorm (pre-bias folded into the
-    // shift) + ReLU + the fc dot.  (Keeping the 32 per-lane partial sums in registers across the slices -- one
-    // cross-lane reduction per point instead of one per point and slice -- needs the loop unrolled 32 x: 280 VGPRs, spills.)
+    // ---- the wave's 16 points, four at a time (a plain loop: small code, bounded registers).  Slots and weights are
+    // wave-uniform; only the overflow variant sends the slots through the scalar unit (its test -- a row beyond the slot
+    // capacity: read from global memory -- is a scalar branch).  Per point and slice: three 16-byte LDS reads, six packed
+    // instructions for the mix, two packed fma + four max + two packed for BatchNorm (pre-bias folded into the shift) +
+    // ReLU + the fc dot: 23 VALU instructions where the scalar form had 37 -- which by itself changed nothing (116 us
+    // either way): the loop waited for the next slice's rows, see the parameter loads above.  (Keeping the per-lane
+    // partial sums in registers across the slices -- one cross-lane reduction per point instead of one per point and
+    // slice -- needs the loop fully unrolled: 280 VGPRs, spills.)
     auto slice_points = [&](auto ovf) __attribute__((always_inline)) {
       constexpr bool OVF = decltype(ovf)::value;
 #pragma nounroll
