@@ -432,6 +432,9 @@ class DH3D(nn.Module):
             att = self.globalatt(forglobal)
         return self._netvlad(forglobal, att, l2_eps=l2_eps)
 
+    OUTPUT_NAMES = frozenset(("pointclouds", "xyz", "knn_inds", "feat", "xyz_feat", "feat_l2normed", "attention",
+                              "xyz_feat_att", "globaldesc", "fps_inds", "sampled_knn_inds", "nn3_inds"))
+
     def forward(self, points, knn_inds=None, fetch=None):
         """points [Bt, N, 3] float32 on the GPU (anchor/pos/neg already concatenated, core/model.py:139-146).
         knn_inds [Bt, N, K] int32: optional precomputed neighbours (the reference requires them for
@@ -441,6 +444,10 @@ class DH3D(nn.Module):
         computed: the global-descriptor extraction (globaldesc_extract.py fetches 'globaldesc' only) skips the
         normalised per-point descriptors and the detector."""
         want = (lambda *names: True) if fetch is None else (lambda *names: any(n in fetch for n in names))
+        if fetch is not None:
+            unknown = sorted(set(fetch) - self.OUTPUT_NAMES)
+            if unknown:  # a TF session raises on an unknown fetch too; silently computing nothing would pass for speed
+                raise ValueError("unknown output name(s) %s: the forward produces %s" % (unknown, sorted(self.OUTPUT_NAMES)))
         self._check_mode()
         cfg = self.config
         if points.dim() != 3 or points.shape[2] != 3:

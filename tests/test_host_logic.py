@@ -202,3 +202,14 @@ def test_weights_version_moves_with_every_kind_of_weight_change():
     v2 = m.weights_version
     m.load_state_dict(m.state_dict())
     assert v0 < v1 < v2 < m.weights_version and m.__dict__.get("_bn_stale")
+
+
+def test_unknown_fetch_name_is_an_error():
+    """forward(fetch=...) computes only what is asked for: a misspelt name must not silently compute nothing."""
+    import pytest
+    from dh3d_amd import ConfigFactory
+    from dh3d_amd.model import DH3D
+    m = DH3D(ConfigFactory("global_config").getconfig()).init_synthetic(0)
+    with pytest.raises(ValueError, match="unknown output name"):
+        m.forward(torch.zeros(1, 64, 3), fetch=("global_desc",))
+    assert "globaldesc" in DH3D.OUTPUT_NAMES and "xyz_feat" in DH3D.OUTPUT_NAMES
