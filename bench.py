@@ -797,12 +797,22 @@ def compact_line(full, extras_path=None, limit=LINE_LIMIT):
         out["cpu_baseline"] = c
     if "global_scaling" in full:
         out["global_scaling"] = full["global_scaling"]
+    if isinstance(full.get("global"), dict):   # the other half of BASELINE.json's metric (fresh process, N = 1)
+        g = full["global"]
+        c = {k: g.get(k) for k in ("workload", "value", "ms_per_step", "steps_in_flight", "clouds_per_gpu", "points") if k in g}
+        if isinstance(g.get("one_step_at_a_time"), dict):
+            c["one_step_at_a_time"] = {"value": g["one_step_at_a_time"].get("value"),
+                                       "ms_per_step": g["one_step_at_a_time"].get("ms_per_step")}
+        if "error" in g:
+            c["error"] = str(g["error"])[:200]
+        out["global"] = c
     out["extras"] = extras_path
     out = _r(out)
     text = json.dumps(out, separators=(", ", ": "))
     # never over the limit: shed the optional blocks, least important first (none of these fire on today's record)
     for k in ("global_scaling.note", "roofline.traffic_source", "cpu_baseline.sample", "config.execution",
-              "config.weights", "config.parallelism", "phases_ms", "global_scaling", "cpu_baseline.all_cores"):
+              "config.weights", "config.parallelism", "phases_ms", "global_scaling", "cpu_baseline.all_cores",
+              "global.workload", "global"):
         if len(text.encode()) <= limit:
             break
         head, _, leaf = k.partition(".")
@@ -854,6 +864,9 @@ def main():
     ap.add_argument("--no-global-scaling", action="store_true",
                     help="with --gpus N > 1 and the default workload: skip the global path's weak / strong lines")
     ap.add_argument("--no-pmc", action="store_true", help="do not collect live PMC traffic for the roofline kernel")
+    ap.add_argument("--no-global-line", action="store_true",
+                    help="default workload at one GPU: do not measure the global-descriptor forward (the other half of "
+                         "BASELINE.json's metric) in a fresh process for the line's `global` block")
     ap.add_argument("--repeats", type=int, default=7,
                     help="further blocks of K timed steps after the contract block (median / min / max as extra keys)")
     ap.add_argument("--inflight", type=int, default=0,
@@ -1166,6 +1179,29 @@ def main():
         except Exception:  # noqa: BLE001 -- informational numbers: fall back to this process
             v, ms, _ = measure_in_flight(workload, depth, steps=steps)
             return v, ms
+
+    def fresh_process_line(workload):
+        """The compact record of `bench.py --workload w` (its own steps in flight AND one step at a time) measured in a
+        process of its own, for the default line's `global` block: BASELINE.json's metric names both forwards, the driver
+        runs this file once without flags."""
+        import subprocess
+        wl_ = WORKLOADS[workload]
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", workload, "--steps", str(args.steps),
+               "--warmup", str(args.warmup), "--no-extras", "--no-cpu-baseline", "--repeats", "0", "--extras-file", os.devnull]
+        try:
+            t0 = time.time()
+            out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300).stdout.decode()
+            rec = json.loads([ln for ln in out.splitlines() if ln.startswith('{"metric"')][-1])
+            return {"workload": wl_["name"], "value": rec["value"], "unit": rec["unit"], "ms_per_step": rec["ms_per_step"],
+                    "steps": rec["steps"], "warmup": rec["warmup"], "clouds_per_gpu": rec["config"]["clouds_per_gpu"],
+                    "points": rec["config"]["points"], "steps_in_flight": rec["config"]["steps_in_flight"],
+                    "one_step_at_a_time": rec.get("one_step_at_a_time"), "measured_in": "a fresh process of this file "
+                    "(--workload %s), same timed-region definition as `value`" % workload, "wall_s": time.time() - t0}
+        except Exception as e:  # noqa: BLE001 -- the headline must not be lost with it
+            return {"workload": wl_["name"], "error": repr(e)[:200]}
+
+    if rank == 0 and world == 1 and args.workload == "local" and not args.no_extras and not args.no_global_line:
+        line["global"] = fresh_process_line("global")
 
     # --- N > 1, default workload: the GLOBAL path's weak and strong figures ride on the same line (BASELINE's ">= 6.5x at 8
     # GPUs on the global-descriptor path" is read both ways; every rank takes part: the timed regions hold barriers)

@@ -35,6 +35,7 @@ _SIGNATURES = {
     "dh3d_version": [],
     "dh3d_abi_version": [],
     "dh3d_arch": [],
+    "dh3d_source_hash": [],
     "dh3d_status_string": [c_int],
     "dh3d_knn_bruteforce": [c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp],
     "dh3d_knn_bruteforce_xyz": [c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp],
@@ -211,6 +212,7 @@ _SIGNATURES = {
 }
 _RESTYPES = {
     "dh3d_arch": ctypes.c_char_p,
+    "dh3d_source_hash": ctypes.c_char_p,
     "dh3d_status_string": ctypes.c_char_p,
     "dh3d_netvlad_workspace_bytes": c_size_t,
     "dh3d_netvlad_head_workspace_bytes": c_size_t,
@@ -224,6 +226,25 @@ _RESTYPES = {
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 ABI_VERSION = 4  # include/dh3d_hip.h DH3D_ABI_VERSION: the semantics (not just the signatures) this file was written against
+
+
+def tree_source_hash():
+    """The hash dh3d_source_hash() must return for a library built from the sources of THIS tree (csrc/Makefile SRC_HASH:
+    sha256 over basename + newline + content of csrc/*.hip, csrc/*.h, csrc/Makefile and include/dh3d_hip.h in the
+    Makefile's $(sort ...) order, first 16 hex digits).  None when the sources are not there (an installed binary)."""
+    import glob
+    import hashlib
+    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    rel = [os.path.basename(f) for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))]
+    rel += ["../../include/dh3d_hip.h", "Makefile"]
+    if not os.path.isfile(os.path.join(csrc, "Makefile")):
+        return None
+    h = hashlib.sha256()
+    for r in sorted(set(rel)):   # (make's $(sort) is a plain byte-wise sort, as is Python's on ASCII names)
+        h.update((os.path.basename(r) + "\n").encode())
+        with open(os.path.join(csrc, r), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def lib():

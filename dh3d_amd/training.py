@@ -1,24 +1,30 @@
 """Siamese training step of the global-descriptor stage (BASELINE config 4; core/model.py:135-255 with
-core/configs.py:104-144 global_config), sharded over GPUs by cloud.
+core/configs.py:104-144 global_config), sharded over GPUs by cloud, and the stage-1 step of the local backbone
+(LocalTrainer) -- both on the hand-written HIP kernels of dh3d_amd.train_ops in BOTH directions, each replayed as one
+hipGraph per step.
 
-global_config freezes the local backbone (configs.py:112-113), so a step is:
-  1. frozen backbone + geometry on the fused HIP path (dh3d_amd.model, no autograd),
-  2. the trainable global head -- global_before_assemble flex_conv (backbones.py:178-186), attention MLP
-     (:156-173), NetVLAD + context gating (:202-320) -- with autograd: the custom ops go through the drop-in
-     operators of dh3d_amd.ops (their backward kernels are the registered gradients), the dense algebra and
-     training-mode BatchNorm are plain torch ops on the GPU,
-  3. all-gather of the [clouds_per_rank, 256] descriptors over RCCL (differentiable: backward keeps the
-     rank's own slice, every rank evaluates the identical full loss), lazy quadruplet loss
-     (core/losses.py:173-200), backward, SUM all-reduce of the head gradients, Adam with the staircase
-     exponential learning rate (core/model.py:248-255) and L2 weight decay on '.*/W' (model.py:239-243).
+global_config freezes the local backbone (configs.py:112-113), so a quadruplet step is:
+  1. frozen backbone + geometry on the fused HIP inference path (dh3d_amd.model, no autograd) -- or, with
+     backbone_bn="batch", the same producers with their BatchNorm epilogues replaced by the colstats / finalize / apply
+     kernels (backbone_local_batch_stats_hip: the reference's own semantics, batch statistics + EMA updates),
+  2. the trainable global head -- global_before_assemble flex_conv (backbones.py:178-186), attention MLP (:156-173),
+     NetVLAD + context gating (:202-320) -- as autograd nodes whose forward AND backward are HIP kernels
+     (global_head_hip: gemm_x6 / gemm_f32, flex_S / flex_scatter, the commuted walks of interp_train.hip and
+     netvlad_train.hip, training-mode BatchNorm in two HBM passes); torch contributes the autograd tape, the optimizer
+     and [Bt, 256]-sized element-wise glue, no GEMM,
+  3. all-gather of the [clouds_per_rank, 256] descriptors over RCCL (differentiable: backward keeps the rank's own
+     slice, every rank evaluates the identical full loss), lazy quadruplet loss (core/losses.py:173-200) on the device,
+     backward, ONE SUM all-reduce of the flat gradient arena, fused Adam with the staircase exponential learning rate
+     (core/model.py:248-255) and L2 weight decay on '.*/W' (model.py:239-243).
 
 BatchNorm statistics under sharding: `sync_bn=True` (default) all-reduces (sum, sum of squares, count) so the
 statistics equal the reference's single-GPU whole-batch statistics; `sync_bn=False` uses per-rank statistics.
-This path favours correctness over speed: it is the parity/coverage path for config 4, not a bench line.
+
+There is no tensor-op implementation of the step in this package: the plain-torch restatement the HIP step is compared
+with lives in tests/torch_reference.py.
 """
 import torch
 import torch.distributed as dist
-import torch.nn.functional as F
 
 from . import backbones as bb
 from . import dist as D
@@ -54,108 +60,9 @@ class _AllReduceSum(torch.autograd.Function):
         return D.all_reduce_sum_(grad.clone())
 
 
-def _batch_norm_train(x, channel_dim, gamma, beta, run_mean, run_var, eps, momentum, sync_bn, mask=None, unbiased=True):
-    """Training-mode BatchNorm over all dims but `channel_dim`; updates the running buffers in place.
-    `momentum` is the EMA decay (tensorpack 0.9, slim 0.999); `unbiased`: the moving variance takes the
-    Bessel-corrected batch variance (tf.nn.fused_batch_norm) -- every site but cluster_bn.  `mask` ([leading] bool)
-    drops padding clouds."""
-    dims = [d for d in range(x.dim()) if d != channel_dim]
-    shape = [1] * x.dim()
-    shape[channel_dim] = -1
-    if mask is not None:
-        w = mask.to(x.dtype).reshape([-1] + [1] * (x.dim() - 1))
-        cnt = w.sum() * (x.numel() / (x.shape[0] * x.shape[channel_dim]))
-        s1 = (x * w).sum(dims)
-        s2 = (x * x * w).sum(dims)
-    else:
-        cnt = torch.tensor(float(x.numel() / x.shape[channel_dim]), device=x.device)
-        s1 = x.sum(dims)
-        s2 = (x * x).sum(dims)
-    if sync_bn and D.collectives_active():
-        packed = _AllReduceSum.apply(torch.cat([s1, s2, cnt.reshape(1)]))
-        C = s1.numel()
-        s1, s2, cnt = packed[:C], packed[C:2 * C], packed[2 * C]
-    # a rank that holds only padding clouds (e.g. 22 clouds over 12 or 16 ranks) has cnt == 0 without sync_bn: its
-    # statistics are 0/0.  Guard the division and leave its running buffers alone -- every row of x is masked out of
-    # the loss there, so its gradients are exact zeros instead of NaN that the SUM all-reduce would spread.
-    empty = cnt <= 0
-    cnt = cnt.clamp_min(1.0)
-    mean = s1 / cnt
-    var = (s2 / cnt - mean * mean).clamp_min(0.0)
-    with torch.no_grad():
-        keep = empty.to(mean.dtype)  # 1 -> buffers unchanged
-        run_mean.copy_(keep * run_mean + (1 - keep) * (momentum * run_mean + (1 - momentum) * mean.detach()))
-        uvar = var.detach() * (cnt / (cnt - 1).clamp_min(1.0)) if unbiased else var.detach()
-        run_var.copy_(keep * run_var + (1 - keep) * (momentum * run_var + (1 - momentum) * uvar))
-    return (x - mean.reshape(shape)) * torch.rsqrt(var.reshape(shape) + eps) * gamma.reshape(shape) + beta.reshape(shape)
-
-
-def _bn(x, channel_dim, bnmod, training, sync_bn, mask):
-    tp = isinstance(bnmod, bb.TPBatchNorm)
-    rm, rv = (bnmod.mean_EMA, bnmod.variance_EMA) if tp else (bnmod.moving_mean, bnmod.moving_variance)
-    if training:
-        return _batch_norm_train(x, channel_dim, bnmod.gamma, bnmod.beta, rm, rv, bnmod.eps, 0.9 if tp else 0.999,
-                                 sync_bn, mask, bool(getattr(bnmod, "ema_unbiased", True)))
-    shape = [1] * x.dim()
-    shape[channel_dim] = -1
-    return (x - rm.reshape(shape)) * torch.rsqrt(rv.reshape(shape) + bnmod.eps) * bnmod.gamma.reshape(shape) + \
-        bnmod.beta.reshape(shape)
-
-
-@torch.no_grad()
-def backbone_local_batch_stats(model, points, geo, sync_bn=False, mask=None):
-    """The FROZEN local backbone as the reference runs it while global_config trains (core/backbones.py:104-127 under
-    core/tf_utils.py:145-153 freeze_variables(stop_gradient=False, skip_collection=True)): frozen means 'not in the
-    TRAINABLE collection' -- every BatchNorm still normalises with the statistics of the batch and updates its moving
-    averages.  Layer by layer on the fused kernels WITHOUT their folded BatchNorm epilogues (raw flex_conv /
-    conv_pointset / pooling outputs from HIP, the 1x1 convs, SE block and BatchNorm as tensor ops); the default
-    trainer uses the fused inference path with moving averages instead (a documented deviation),
-    this is `QuadrupletTrainer(backbone_bn="batch")`, compared with the oracle's training-mode graph in the tests.
-    Returns (localdesc [b,N,128], geometry level)."""
-    from . import pm
-
-    def bn_relu(x, bnmod, rows_dim):
-        return F.relu(_batch_norm_train(x, rows_dim, bnmod.gamma, bnmod.beta, bnmod.mean_EMA, bnmod.variance_EMA,
-                                        bnmod.eps, 0.9, sync_bn, mask, True))
-
-    def conv_bnrelu(x, fc1d):
-        conv = fc1d.tfconv0
-        return bn_relu(x @ conv.W.reshape(conv.cin, conv.cout) + conv.b, conv.bn, 2)
-
-    def flex_stack(mod, x, xyz, nbr):
-        for i in range(len(mod.outdims)):
-            fc, bn = getattr(mod, "flexconv_%d" % i), getattr(mod, "flexconv_%d_bn" % i)
-            y = pm.flex_conv(x.contiguous(), xyz, nbr, pm.pack_flex_weight(fc.position_theta.detach(),
-                                                                             fc.position_bias.detach()), fc.cout)
-            x = bn_relu(y + fc.feature_bias.reshape(1, 1, -1), bn, 2)
-        pool = pm.flex_pool(x.contiguous(), nbr)                                       # backbones.py:76-79
-        se = mod.se
-        sq = F.relu(pool @ se.f1.tfconv0.W.reshape(se.channels, -1) + se.f1.tfconv0.b)
-        sq = torch.sigmoid(sq @ se.f2.tfconv0.W.reshape(-1, se.channels) + se.f2.tfconv0.b)
-        return F.relu(x + x * sq)                                                       # backbones.py:45-55
-
-    if model._local.featdim < 128 or model.stage1.add_se != "max_pool":
-        raise NotImplementedError("backbone_bn='batch' covers the shipped backbone (featdim 128, max-pool SE)")
-    model._join_side(geo)  # the kNN of the full cloud runs on the geometry's side stream
-    nn_8 = geo.nbr if geo.nbr.shape[2] == 8 else geo.nbr[:, :, 0:8].contiguous()
-    ic = model.initconv
-    init = pm.conv_pointset_xyz(geo.xyz, nn_8, ic.position_theta.detach().contiguous(), ic.position_bias.detach().contiguous())
-    init = pm.flex_pool(bn_relu(init, model.initconv_bn, 2).contiguous(), nn_8)
-    x1 = flex_stack(model.stage1, init, geo.xyz, nn_8)
-    x2 = conv_bnrelu(x1, model.before_stage2_conv1d)
-    lv = geo.level(8, model.knn_num)
-    s2 = model.stage2
-    feat_s = bb.gather_rows(x2.contiguous(), lv["idx"])
-    y = flex_stack(s2, feat_s, lv["xyz_s"], lv["nbr_s"])
-    up = ops.three_interpolate(y.contiguous(), lv["nn3_idx"], pm.idw_weights(lv["nn3_dist"]).contiguous())
-    x2 = conv_bnrelu(torch.cat([up, x2], 2), s2.concat_conv1d)
-    feat = conv_bnrelu(x1, model.local_stage1_shortcut) + x2
-    return feat.contiguous(), lv
-
-
 @torch.no_grad()
 def backbone_local_batch_stats_hip(model, points, geo, sync_bn=False, mask=None):
-    """backbone_local_batch_stats -- the frozen backbone normalising with BATCH statistics and updating its moving
+    """The frozen backbone normalising with BATCH statistics and updating its moving
     averages, as the reference's global_config graph does (core/tf_utils.py:60-63,145-153; core/backbones.py:104-127)
     -- built from the HIP kernels only, so that the whole training step stays one replayable hipGraph:
 
@@ -222,7 +129,7 @@ def backbone_local_batch_stats_hip(model, points, geo, sync_bn=False, mask=None)
 
 class _FlexConvFactorised(torch.autograd.Function):
     """flex_conv for the training step, point-major, in its factorised form
-        out = [S0 | Sx | Sy | Sz] @ [bias; theta_x; theta_y; theta_z],  S0 = sum_k f[n_k],  Sd = sum_k dp_d(k) f[n_k]
+        out = [S0 | Sx | Sy | Sz] x [bias; theta_x; theta_y; theta_z],  S0 = sum_k f[n_k],  Sd = sum_k dp_d(k) f[n_k]
     (the form the fused inference kernel runs; the drop-in op `ops.flex_convolution` keeps the reference's
     9*K*Din*Dout-flop formulation and its atomics backward: 21 of the 32 ms of a 22-cloud step).  Forward = the fused
     HIP kernel; backward = the same factorisation differentiated, also in HIP (pm.flex_conv_bwd): dW = S^T dOut and
@@ -253,76 +160,20 @@ def flex_conv_factorised(feat, xyz, nbr, theta, bias):
     return _FlexConvFactorised.apply(feat.contiguous(), xyz.contiguous(), nbr.contiguous(), theta, bias)
 
 
-def global_head_autograd(model, points, localdesc, lv, bn_training=True, sync_bn=False, mask=None):
-    """Differentiable restatement of compute_global (core/model.py:112-133) on the parameters of `model`.
-
-    points [Bt,N,3], localdesc [Bt,N,128] (detached backbone output), lv = geometry level dict
-    (idx, xyz_s, nbr_s, nn3_dist, nn3_idx).  Returns the un-normalised global descriptor [Bt,256]."""
-    if getattr(model, "global_conv1d", False):
-        # core/backbones.py:189-197: 1x1 conv + BNReLU on the full-resolution descriptors (only the last conv of the
-        # loop reaches the output)
-        conv = model._global_front()[-1]
-        h = localdesc @ conv.W.reshape(conv.cin, conv.cout) + conv.b
-        forglobal = F.relu(_bn(h, 2, conv.bn, bn_training, sync_bn, mask)).contiguous()
-    else:
-        gba = model.global_before_assemble
-        fc, fbn = gba.flexconv_0, gba.flexconv_0_bn
-        feat_s = bb.gather_rows(localdesc, lv["idx"])                                   # [Bt,M,128]
-        if model.config.concat_xyz:
-            # core/backbones.py:180-181: [xyz | descriptors] into the flex_conv -- here literally, through the drop-in
-            # operator in the reference's channels-first layout (any channel count)
-            xin = torch.cat([lv["xyz_s"], feat_s], 2).transpose(1, 2).contiguous()      # [Bt,131,M]
-            x = ops.flex_convolution(xin, lv["xyz_s"].transpose(1, 2).contiguous(),
-                                     lv["nbr_s"].transpose(1, 2).contiguous(), fc.position_theta,
-                                     fc.position_bias).transpose(1, 2)
-        else:
-            x = flex_conv_factorised(feat_s, lv["xyz_s"], lv["nbr_s"], fc.position_theta, fc.position_bias)
-        x = x + fc.feature_bias.reshape(1, 1, -1)                                       # layers.py:330-331
-        new_feat = F.relu(_bn(x, 2, fbn, bn_training, sync_bn, mask)).contiguous()      # tf_utils.py:60-63; [Bt,M,256]
-        d = torch.clamp(lv["nn3_dist"], min=1e-10)                                      # backbones.py:92-95
-        w = (1.0 / d) / (1.0 / d).sum(2, keepdim=True)
-        forglobal = ops.three_interpolate(new_feat, lv["nn3_idx"], w.contiguous())      # [Bt,N,256]
-
-    att_mod = model.globalatt
-    h = forglobal
-    for i in range(len(att_mod.conv_dims)):
-        conv = getattr(att_mod, "detec_conv%d" % i)
-        h = h @ conv.W.reshape(conv.cin, conv.cout) + conv.b
-        h = F.relu(_bn(h, 2, conv.bn, bn_training, sync_bn, mask))
-    fcw = att_mod.detec_conv_fc
-    att = torch.sigmoid(h @ fcw.W.reshape(fcw.cin, 1) + fcw.b)                      # [Bt,N,1]
-
-    nv = model._netvlad
-    Bt, N, Dm = forglobal.shape
-    xr = forglobal.reshape(-1, Dm)
-    xr = xr * torch.rsqrt(torch.clamp((xr * xr).sum(1, keepdim=True), min=1e-12))   # tf.nn.l2_normalize
-    act = xr @ nv.cluster_weights
-    pmask = mask.repeat_interleave(N) if mask is not None else None
-    act = _bn(act, 1, nv.cluster_bn, bn_training, sync_bn, pmask)
-    act = torch.softmax(act, dim=1) * att.reshape(-1, 1)
-    act = act.reshape(Bt, N, nv.C)
-    a = act.sum(1, keepdim=True) * nv.cluster_weights2                               # [Bt,D,C]
-    vlad = torch.matmul(act.transpose(1, 2), xr.reshape(Bt, N, Dm)).transpose(1, 2) - a
-    vlad = vlad * torch.rsqrt(torch.clamp((vlad * vlad).sum(1, keepdim=True), min=1e-12))
-    vlad = vlad.reshape(Bt, nv.C * Dm)
-    vlad = vlad * torch.rsqrt(torch.clamp((vlad * vlad).sum(1, keepdim=True), min=1e-12))
-    v = _bn(vlad @ nv.hidden1_weights, 1, nv.bn, bn_training, sync_bn, mask)
-    gates = _bn(v @ nv.gating_weights, 1, nv.gating_bn, bn_training, sync_bn, mask)
-    return v * torch.sigmoid(gates)
-
-
 def global_head_hip(model, points, localdesc, lv, sync_bn=False, mask=None, commute_attention=True,
                     commute_netvlad=True):
     """compute_global (core/model.py:112-133) in training mode with every row-level operator -- flex_conv, the three
     training-mode BatchNorms on rows, three_interpolate, the attention MLP, NetVLAD's assignment / aggregation -- as a
     hand-written HIP kernel in BOTH directions (dh3d_amd.train_ops, csrc/train.hip / gemm.hip / flex_bwd.hip); what is
-    left to torch are [Bt, 256]- and [Bt, 16384]-sized per-cloud element-wise ops (microseconds).  Same function as
-    global_head_autograd(bn_training=True), which is kept as the plain-torch reference the tests compare with."""
+    left to torch are [Bt, 256]- and [Bt, 16384]-sized per-cloud element-wise ops (microseconds).  The tests compare it
+    with tests/torch_reference.global_head_autograd(bn_training=True).  Head shapes the kernels do not cover (more than one
+    attention conv or global flex_conv, NetVLAD without BatchNorm / gating: no shipped config) raise."""
     from . import train_ops as T
     gba, att_mod, nv = model.global_before_assemble, model.globalatt, model._netvlad
     conv1d = getattr(model, "global_conv1d", False)
     if (len(att_mod.conv_dims) != 1 or (not conv1d and len(gba.outdims) != 1) or not (nv.add_batch_norm and nv.gating)):
-        return global_head_autograd(model, points, localdesc, lv, True, sync_bn, mask)
+        raise NotImplementedError("global_head_hip covers the shipped global head (one attention conv, one "
+                                  "global_before_assemble flex_conv or the conv1d front, NetVLAD with BatchNorm + gating)")
     Bt, N = points.shape[0], points.shape[1]
     if conv1d:
         # global_before_assemble_conv1d (core/backbones.py:189-197): no sampled level, no interpolation -- a 1x1 conv +
@@ -428,21 +279,21 @@ class QuadrupletTrainer(object):
     every rank, e.g. generated from a shared seed), runs this rank's block and returns the loss."""
 
     def __init__(self, model, start_lr=None, decay_step=None, decay_rate=None, weight_decay=None, sync_bn=True,
-                 impl="hip", graph_backbone=True, graph_step=None, backbone_bn="ema"):
+                 graph_backbone=True, graph_step=None, backbone_bn="ema"):
         """Schedule / weight decay default to the model's config (core/configs.py:50-54,115-117).  sync_bn=True (the
         default) reproduces the reference's whole-batch BatchNorm statistics under sharding -- and keeps the running
         buffers identical on every rank; sync_bn=False normalises with per-rank statistics (a few clouds of one role
         each under the contiguous role-ordered partition) and lets the buffers diverge.
         backbone_bn: "ema" (default) -- the frozen backbone runs the fused inference path on its moving averages;
         "batch" -- it normalises with batch statistics and updates its moving averages, which is what the reference
-        graph does while global_config trains (backbone_local_batch_stats; slower, un-fused)."""
+        graph does while global_config trains (backbone_local_batch_stats_hip; slower, un-fused)."""
         if backbone_bn not in ("ema", "batch"):
             raise ValueError("backbone_bn must be 'ema' or 'batch'")
         self.model = model
         self.cfg = model.config
-        self.impl = impl          # "hip": train_ops kernels; "torch": the plain-torch restatement (test reference)
+        self.impl = "hip"         # (reported by bench.py; the tensor-op subclass of the tests says "torch")
         self.backbone_bn = backbone_bn
-        self.graph_backbone = graph_backbone and impl == "hip" and backbone_bn == "ema"
+        self.graph_backbone = graph_backbone and backbone_bn == "ema"
         self._bb_graphs = {}
         self.keep_grads, self.last_grads = False, None
         self._ev = None
@@ -466,9 +317,7 @@ class QuadrupletTrainer(object):
         # captured, so the CPU-test path stays eager.
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         capturable = world == 1 and not D.collectives_active() or (D.collectives_active() and dist.get_backend() == "nccl")
-        if backbone_bn == "batch" and impl != "hip":
-            capturable = False  # the tensor-op restatement rebuilds the backbone's folded copies on the host every step
-        self.graph_step = (impl == "hip" and capturable) if graph_step is None else (bool(graph_step) and capturable)
+        self.graph_step = capturable if graph_step is None else (bool(graph_step) and capturable)
         self._zarena = pm.ZeroArena()   # the step's accumulators: one fill per step (pm.ZeroArena)
         self._garena = None     # flat gradient arena of the sharded step (all-reduced in place, .grad are views of it)
         self._sched = (float(start_lr), int(decay_step), float(decay_rate))
@@ -499,33 +348,37 @@ class QuadrupletTrainer(object):
         self.model.eval()
         if self.backbone_bn == "batch":  # the reference's semantics: batch statistics + moving-average updates
             geo = self.model._geometry(block, None)
-            if self.impl == "hip":   # HIP kernels only, capturable (the moving averages are updated on the device)
-                localdesc, lv = backbone_local_batch_stats_hip(self.model, block, geo, self.sync_bn, m)
-                lv = {k: v for k, v in lv.items() if torch.is_tensor(v) or k == "_ordered"}
-            else:                    # the tensor-op restatement (test reference)
-                localdesc, lv = backbone_local_batch_stats(self.model, block, geo, self.sync_bn, m)
-                self.model.invalidate()  # the folded copies of the backbone's moving averages are stale now
+            localdesc, lv = self._backbone_batch_stats(block, geo, m)
         else:  # frozen backbone on the fused inference path (moving averages)
             localdesc, lv = self._backbone(block)
         self._mark(1)
-        if self.impl == "hip":
-            desc = global_head_hip(self.model, block, localdesc.detach(), lv, sync_bn=self.sync_bn, mask=m)
-        else:
-            desc = global_head_autograd(self.model, block, localdesc.detach(), lv, bn_training=True,
-                                        sync_bn=self.sync_bn, mask=m)
-        from . import train_ops as T
-        m1, m2 = cfg.global_triplet_margin or 0.5, cfg.global_quadruplet_margin or 0.2
-        if self.impl == "hip":
-            desc = T.l2_normalize_rows(desc, 1e-8)                                          # model.py:205
-        else:
-            desc = desc * torch.rsqrt(torch.clamp((desc * desc).sum(1, keepdim=True), min=1e-8))
+        desc = self._normalize(self._head(block, localdesc.detach(), lv, m))
         if not D.collectives_active() and desc.shape[0] == Bt:
             full = desc   # one rank, no padding: nothing to gather or slice (a clone, a fill and two copies per step)
         else:
             full = _AllGatherKeepOwn.apply(desc)[:Bt]
         if self.keep_desc:  # tests: the gathered, l2-normalised descriptors of this step
             self.last_desc = full.detach().clone()
-        if self.impl == "hip" and T.quadruplet_loss_supported(full, cfg.num_pos, cfg.num_neg):
+        return self._loss(full)
+
+    # The four blocks of a step (tests/torch_reference.TorchQuadrupletTrainer overrides them with tensor ops):
+    def _backbone_batch_stats(self, block, geo, m):
+        """HIP kernels only, capturable (the moving averages are updated on the device)."""
+        localdesc, lv = backbone_local_batch_stats_hip(self.model, block, geo, self.sync_bn, m)
+        return localdesc, {k: v for k, v in lv.items() if torch.is_tensor(v) or k == "_ordered"}
+
+    def _head(self, block, localdesc, lv, m):
+        return global_head_hip(self.model, block, localdesc, lv, sync_bn=self.sync_bn, mask=m)
+
+    def _normalize(self, desc):
+        from . import train_ops as T
+        return T.l2_normalize_rows(desc, 1e-8)                                              # model.py:205
+
+    def _loss(self, full):
+        from . import train_ops as T
+        cfg = self.cfg
+        m1, m2 = cfg.global_triplet_margin or 0.5, cfg.global_quadruplet_margin or 0.2
+        if T.quadruplet_loss_supported(full, cfg.num_pos, cfg.num_neg):
             return T.quadruplet_loss(full.contiguous(), cfg.batch_size, cfg.num_pos, cfg.num_neg, m1, m2)
         return losses.lazy_quadruplet_loss(full, cfg.batch_size, cfg.num_pos, cfg.num_neg, m1, m2)
 

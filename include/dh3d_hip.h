@@ -50,6 +50,10 @@ int dh3d_version(void);                 /* 100*major + minor */
 #define DH3D_ABI_VERSION 4
 int dh3d_abi_version(void);
 const char *dh3d_arch(void);            /* "gfx950" */
+/* First 16 hex digits of sha256 over (basename, content) of dh3d_amd/csrc/{*.hip, *.h, Makefile} and this header, sorted by
+ * path as the Makefile's $(sort ...) orders them -- baked in at build time so that a binding (dh3d_amd/_lib.py
+ * tree_source_hash, tests/test_abi.py) can tell a library built from THIS tree from a stale one that travelled with it. */
+const char *dh3d_source_hash(void);
 const char *dh3d_status_string(int st); /* static string */
 
 /* ===================================================================================== *

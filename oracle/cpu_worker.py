@@ -17,14 +17,22 @@ for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
 import numpy as np  # noqa: E402
 
 
-def cfg1(repeats):
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from oracle import cpu as O
+def cfg1_inputs():
+    """BASELINE config 1's inputs (seed 1001, one cloud of N=1024, K=8, flex_conv 32->32), in the reference
+    operators' layouts: positions [1,3,N], features [1,32,N], theta [3,32,32], bias [32,32].  tests/test_ops_gpu.py runs the
+    HIP operators on exactly these arrays."""
     rng = np.random.default_rng(1001)
     pts_T = np.ascontiguousarray(rng.random((1, 1024, 3), dtype=np.float32).transpose(0, 2, 1))
     feat = rng.standard_normal((1, 32, 1024)).astype(np.float32)
     theta = rng.standard_normal((3, 32, 32)).astype(np.float32)
     bias = rng.standard_normal((32, 32)).astype(np.float32)
+    return pts_T, feat, theta, bias
+
+
+def cfg1(repeats):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import cpu as O
+    pts_T, feat, theta, bias = cfg1_inputs()
     best = float("inf")
     for _ in range(repeats):
         t0 = time.perf_counter()

@@ -45,6 +45,14 @@ def test_invalid_arguments_are_status_codes_not_crashes():
     assert lib.dh3d_netvlad_workspace_bytes(4, 1024, 256, 64) > 0
 
 
+def test_library_was_built_from_this_tree():
+    """The loaded library carries the hash of the sources it was compiled from (csrc/Makefile SRC_HASH -> dh3d_source_hash):
+    a stale .so that travelled with the tree (built artefacts are git-ignored, not gpurun-ignored) fails here."""
+    from dh3d_amd import _lib
+    lib = _lib.lib()
+    assert lib.dh3d_source_hash().decode() == _lib.tree_source_hash()
+
+
 def test_python_ops_refuse_cpu_tensors():
     import pytest
     import torch
@@ -61,3 +69,40 @@ def test_oracle_is_not_imported_by_the_product():
         if fn.endswith(".py"):
             txt = open(os.path.join(pkg, fn)).read()
             assert "oracle" not in re.sub(r'""".*?"""', "", txt, flags=re.S), fn
+
+
+def _code_only(path):
+    """Source text without docstrings and comments."""
+    import io
+    import tokenize
+    out = []
+    for tok in tokenize.generate_tokens(io.StringIO(open(path).read()).readline):
+        if tok.type == tokenize.COMMENT:
+            continue
+        if tok.type == tokenize.STRING and tok.string.lstrip("rbuRBU").startswith(('"""', "'''")):
+            continue
+        out.append(tok.string)
+    return " ".join(out)
+
+
+def test_training_module_has_no_tensor_op_restatement():
+    """dh3d_amd/training.py runs the step on HIP kernels only: no tensor-op GEMM / activation / softmax path selectable at
+    run time (the plain-torch restatement the HIP step is compared with lives in tests/torch_reference.py), and nothing in
+    the package imports that test module."""
+    import ast
+    path = os.path.join(ROOT, "dh3d_amd", "training.py")
+    tree = ast.parse(open(path).read())
+    banned_attrs = {"matmul", "mm", "bmm", "addmm", "einsum", "softmax", "sigmoid", "relu", "linear", "batch_norm"}
+    for node in ast.walk(tree):
+        assert not (isinstance(node, ast.BinOp) and isinstance(node.op, ast.MatMult)), "matrix product at line %d" % node.lineno
+        if isinstance(node, ast.Attribute) and isinstance(node.value, ast.Name) and node.value.id in ("torch", "F"):
+            assert node.attr not in banned_attrs, "%s.%s at line %d" % (node.value.id, node.attr, node.lineno)
+        if isinstance(node, (ast.Import, ast.ImportFrom)):
+            names = [a.name for a in node.names] + [getattr(node, "module", "") or ""]
+            assert not any("functional" in n for n in names), "torch.nn.functional imported at line %d" % node.lineno
+        if isinstance(node, ast.arg):
+            assert node.arg != "impl", "an implementation switch at line %d" % node.lineno
+    pkg = os.path.join(ROOT, "dh3d_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            assert "torch_reference" not in _code_only(os.path.join(pkg, fn)), fn

@@ -41,6 +41,12 @@ def _canned(n_gpus=1, bloat=1):
         "batch_sweep_1gpu": {"points": [{"clouds_per_gpu": b} for b in (8, 4, 2, 1)]},
         "data_sensitivity": {"note": "d" * 400}, "repeats": {"ms_per_step": [0.25] * 7},
     }
+    if n_gpus == 1:   # the global-descriptor forward, measured in a fresh process (the other half of BASELINE's metric)
+        line["global"] = {"workload": bench.WORKLOADS["global"]["name"], "value": 58000.25, "unit": "point-clouds/sec",
+                          "ms_per_step": 0.5517, "steps": 20, "warmup": 5, "clouds_per_gpu": 32, "points": 4096,
+                          "steps_in_flight": 3, "measured_in": "m" * 200, "wall_s": 9.0,
+                          "one_step_at_a_time": {"value": 46600.5, "unit": "point-clouds/sec", "ms_per_step": 0.687,
+                                                 "note": "n" * 300}}
     if n_gpus > 1:
         line["global_scaling"] = {
             "workload": bench.WORKLOADS["global"]["name"], "steps_in_flight": 2,
@@ -76,6 +82,11 @@ def test_line_fits_and_round_trips(n_gpus):
     assert rec["extras"] == "gpurun_out/bench_extras.json"
     for gone in ("roofline_step", "other_workloads", "batch_sweep_1gpu", "data_sensitivity", "repeats", "kernels_ms"):
         assert gone not in rec
+    if n_gpus == 1:
+        g = rec["global"]
+        assert g["workload"] == bench.WORKLOADS["global"]["name"] and g["steps_in_flight"] == 3
+        assert g["value"] == pytest.approx(58000.25) and g["ms_per_step"] == pytest.approx(0.5517)
+        assert g["one_step_at_a_time"] == {"value": 46600.5, "ms_per_step": 0.687}
     if n_gpus > 1:
         g = rec["global_scaling"]
         assert g["weak"]["clouds_per_gpu"] == 32 and g["strong"]["clouds_per_gpu"] == 4
@@ -87,6 +98,14 @@ def test_line_sheds_optional_blocks_before_breaking_the_limit():
     assert len(text.encode()) <= 2048
     rec = json.loads(text)
     assert rec["value"] == pytest.approx(31416.1, rel=1e-5) and "roofline" in rec and "cpu_baseline" in rec
+
+
+def test_global_block_is_shed_last():
+    full = _canned(1, bloat=40)
+    text = bench.compact_line(full, extras_path="x.json", limit=2300)
+    rec = json.loads(text)
+    assert len(text.encode()) <= 2300
+    assert rec["global"]["value"] == pytest.approx(58000.25) and "one_step_at_a_time" in rec["global"]
 
 
 def test_side_file_holds_the_full_record(tmp_path):

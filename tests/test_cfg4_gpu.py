@@ -65,8 +65,10 @@ def oracle_steps(dev):
 
 def _step_forward(dev, impl, backbone_bn):
     from dh3d_amd.training import QuadrupletTrainer
+    from torch_reference import TorchQuadrupletTrainer
     m = _build(dev)
-    tr = QuadrupletTrainer(m, sync_bn=False, impl=impl, graph_step=False, graph_backbone=False, backbone_bn=backbone_bn)
+    cls = {"hip": QuadrupletTrainer, "torch": TorchQuadrupletTrainer}[impl]
+    tr = cls(m, sync_bn=False, graph_step=False, graph_backbone=False, backbone_bn=backbone_bn)
     tr.keep_desc = True
     loss = tr.forward_loss(_points().to(dev))
     return m, tr, loss
@@ -132,6 +134,7 @@ def test_cfg4_reference_semantics_backbone_runs_on_hip_kernels_only(dev, monkeyp
     test reference) on the descriptors and on every moving average it updates."""
     import torch.nn.functional as F
     from dh3d_amd import training as TR
+    import torch_reference
     pts = _points().to(dev)
     outs = {}
     for which in ("hip", "torch"):
@@ -148,7 +151,7 @@ def test_cfg4_reference_semantics_backbone_runs_on_hip_kernels_only(dev, monkeyp
                     mp.setattr(F, name, banned)
                 feat, lv = TR.backbone_local_batch_stats_hip(m, pts, geo)
         else:
-            feat, lv = TR.backbone_local_batch_stats(m, pts, geo)
+            feat, lv = torch_reference.backbone_local_batch_stats(m, pts, geo)
         torch.cuda.synchronize()
         outs[which] = (feat.clone(), {k: v.clone() for k, v in m.state_dict().items() if "EMA" in k})
     a, b = outs["hip"][0], outs["torch"][0]
@@ -214,7 +217,7 @@ def test_cfg4_gradients_vs_float64_central_differences_of_the_oracle_graph(dev):
     bt = b * (1 + p + ng + 1)
     pts = np.random.default_rng(15).random((bt, n, 3), dtype=np.float32)
     # HIP: loss + gradients of one step's forward / backward (no weight decay: it is added to the gradients separately)
-    tr = QuadrupletTrainer(m, sync_bn=False, impl="hip", graph_step=False, graph_backbone=False)
+    tr = QuadrupletTrainer(m, sync_bn=False, graph_step=False, graph_backbone=False)
     loss = tr.forward_loss(torch.from_numpy(pts).to(dev))
     loss.backward()
     names = {id(q): tf_variable_name(k) for k, q in m.named_parameters()}

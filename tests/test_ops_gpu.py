@@ -41,6 +41,24 @@ def test_knn_bitexact_vs_oracle(dev, oracle, B, N, K):
     assert np.array_equal(d.cpu().numpy(), ed)  # IEEE sqrt + explicit fma chain: bit-exact distances too
 
 
+def test_cfg1_exact_workload(dev, oracle):
+    """BASELINE config 1 as bench.py's cpu_baseline times it on the host (oracle.cpu_worker.cfg1: seed 1001, ONE cloud of
+    N=1024, K=8, knn_bruteforce + one flex_conv 32->32) -- the same arrays through the HIP drop-in operators: ids and
+    distance bits equal, the convolution within the reference's own criterion (test_flex_convolution.py:45)."""
+    from dh3d_amd import ops
+    from oracle.cpu_worker import cfg1_inputs
+    pos, feat, theta, bias = cfg1_inputs()
+    assert pos.shape == (1, 3, 1024) and feat.shape == (1, 32, 1024) and theta.shape == (3, 32, 32)
+    nn, d = ops.knn_bruteforce(T(pos, dev), 8)                                # [1, N, K]
+    enn, ed = oracle.knn_bruteforce(pos, 8)
+    assert np.array_equal(nn.cpu().numpy(), enn) and np.array_equal(d.cpu().numpy(), ed)
+    nbr = nn.transpose(1, 2).contiguous()                                      # every consumer wants [B, K, N]
+    out = ops.flex_convolution(T(feat, dev), T(pos, dev), nbr, T(theta, dev), T(bias, dev))
+    exp = oracle.flex_convolution(feat, pos, np.ascontiguousarray(enn.transpose(0, 2, 1)), theta, bias, True)
+    assert out.shape == (1, 32, 1024)
+    assert close_sum(out.cpu().numpy(), exp)
+
+
 def test_knn_golden_and_ties(dev, oracle):
     from dh3d_amd import ops
     c = load("fake_pointcloud.npz")

@@ -24,7 +24,7 @@ def _build(dev, seed=0, B=1, P=2, Ng=3):
 
 
 def test_autograd_head_matches_fused_path_in_eval_mode(dev):
-    from dh3d_amd.training import global_head_autograd
+    from torch_reference import global_head_autograd
     m = _build(dev)
     pts = torch.rand(3, 1024, 3, generator=torch.Generator().manual_seed(101)).to(dev)
     with torch.no_grad():
@@ -40,7 +40,8 @@ def test_autograd_head_matches_fused_path_in_eval_mode(dev):
 def test_directional_gradient_of_the_head(dev):
     """Analytic gradient (custom-op backward kernels + torch autograd) vs a central finite difference of the
     loss along a random direction in parameter space (f32: 2% tolerance)."""
-    from dh3d_amd.training import global_head_autograd, trainable_head_parameters
+    from torch_reference import global_head_autograd
+    from dh3d_amd.training import trainable_head_parameters
     m = _build(dev, seed=3)
     pts = torch.rand(7, 512, 3, generator=torch.Generator().manual_seed(102)).to(dev)  # B=1: 1 anchor + 2 pos + 3 neg + 1 other-neg
     with torch.no_grad():
@@ -76,7 +77,7 @@ def test_directional_gradient_of_the_head(dev):
 def test_shard_partial_gradients_sum_to_full_gradient(dev):
     """Emulates the 4-rank partition in one process (eval-mode BN so shards do not couple through statistics):
     sum over shards of d loss / d theta (each through its own clouds) == unsharded gradient."""
-    from dh3d_amd.training import global_head_autograd
+    from torch_reference import global_head_autograd
     from dh3d_amd import dist as D, losses
     m = _build(dev, seed=5, B=1, P=2, Ng=3)
     pts = torch.rand(7, 512, 3, generator=torch.Generator().manual_seed(103)).to(dev)
@@ -304,7 +305,7 @@ def test_trainer_step_world_size_2_matches_single_process(dev, tmp_path, sync_bn
 def test_trainer_survives_a_rank_with_only_padding_clouds(dev):
     """22 clouds over 12 or 16 ranks leave tail ranks with an all-False mask: statistics of zero rows must not turn
     into NaN (which the SUM all-reduce would spread) and must leave the running buffers alone."""
-    from dh3d_amd.training import _batch_norm_train
+    from torch_reference import batch_norm_train as _batch_norm_train
     x = torch.randn(2, 16, 8, device=dev, requires_grad=True)
     mask = torch.zeros(2, dtype=torch.bool, device=dev)
     rm, rv = torch.zeros(8, device=dev), torch.ones(8, device=dev)
@@ -364,7 +365,8 @@ def test_bn_train_kernels_match_torch(dev):
 def test_hip_head_matches_torch_head_forward_and_gradients(dev):
     """global_head_hip (hand-written kernels in both directions) == global_head_autograd (plain torch) on the same
     batch: descriptors, every trainable gradient, BatchNorm running buffers; with and without a padding cloud."""
-    from dh3d_amd.training import global_head_autograd, global_head_hip, trainable_head_parameters
+    from torch_reference import global_head_autograd
+    from dh3d_amd.training import global_head_hip, trainable_head_parameters
     for use_mask in (False, True):
         res = []
         for impl in (global_head_hip, global_head_autograd):
@@ -766,7 +768,8 @@ def test_hip_head_trains_the_other_global_front_ends(dev, variant):
     head (which runs concat_xyz literally -- 131 input channels through the drop-in flex_convolution)."""
     from dh3d_amd import ConfigFactory
     from dh3d_amd.model import DH3D
-    from dh3d_amd.training import global_head_hip, global_head_autograd, trainable_head_parameters, QuadrupletTrainer
+    from torch_reference import global_head_autograd
+    from dh3d_amd.training import global_head_hip, trainable_head_parameters, QuadrupletTrainer
     res = []
     for impl in (global_head_hip, global_head_autograd):
         cfg = ConfigFactory("global_config").getconfig()
