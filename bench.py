@@ -457,18 +457,25 @@ def knn_grid_executed_flops(workload, dev):
     wl = WORKLOADS[workload]
     pts = synthetic_clouds(wl["B"], wl["N"], wl["seed"], dev, 0)
     _, _, cells = pm.spatial_sort_cells(pts)
-    ct = cells[:, :4097].to(torch.int64).cpu().numpy()
-    cnt = np.diff(ct, axis=1)                                   # points per Morton-coded cell [B, 4096]
+    cells_h = cells.cpu().numpy()
+    ct = cells_h[:, :4097].astype(np.int64)
+    cnt = np.diff(ct, axis=1)                                   # points per grid cell, cells in code order [B, 4096]
     code = np.arange(4096)
-    def compact(v):                                             # every third bit of a 12-bit Morton code
-        return ((v >> 0) & 1) | ((v >> 2) & 2) | ((v >> 4) & 4) | ((v >> 6) & 8)
-    x, y, z = compact(code), compact(code >> 1), compact(code >> 2)
     total = 0.0
     for b in range(cnt.shape[0]):
-        g = np.zeros((18, 18, 18))
-        g[x + 1, y + 1, z + 1] = cnt[b]
-        box = sum(g[1 + dx:17 + dx, 1 + dy:17 + dy, 1 + dz:17 + dz] for dx in (-1, 0, 1) for dy in (-1, 0, 1) for dz in (-1, 0, 1))
-        total += float((g[1:17, 1:17, 1:17] * box).sum())
+        # per-axis cell coordinates from the cloud's own bit schedule (include/dh3d_hip.h, cells[4107]: field s = the axis
+        # of code bit 11 - s; a cube's 0x186186 is the plain z-y-x Morton code, any other cloud deals its bits by extent)
+        sched = int(cells_h[b, 4107]) & 0xFFFFFF
+        coord = [np.zeros(4096, np.int64) for _ in range(3)]
+        for st in range(12):
+            a = (sched >> (2 * st)) & 3
+            coord[a] = (coord[a] << 1) | ((code >> (11 - st)) & 1)
+        dims = [int(c.max()) + 1 for c in coord]
+        g = np.zeros((dims[0] + 2, dims[1] + 2, dims[2] + 2))
+        g[coord[0] + 1, coord[1] + 1, coord[2] + 1] = cnt[b]
+        box = sum(g[1 + dx:1 + dims[0] + dx, 1 + dy:1 + dims[1] + dy, 1 + dz:1 + dims[2] + dz]
+                  for dx in (-1, 0, 1) for dy in (-1, 0, 1) for dz in (-1, 0, 1))
+        total += float((g[1:1 + dims[0], 1:1 + dims[1], 1:1 + dims[2]] * box).sum())
     return 8.0 * total, total / (wl["B"] * wl["N"])
 
 

@@ -63,7 +63,12 @@ class Pipeline:
         return self._streams[slot]
 
     def input_buffer(self, slot):
-        """The slot's resident batch [Bt, N, 3]: write the next batch here (ordered before submit) for a zero-copy step."""
+        """The slot's resident batch [Bt, N, 3] for a zero-copy step.  WHERE the write is enqueued matters: submit() without
+        `points` does NOT order the slot's stream behind the caller's current stream, so write the next batch here ON
+        `stream(slot)` (`with torch.cuda.stream(pipe.stream(k)): buf.copy_(host_batch, non_blocking=True)` -- the copy then
+        also waits for the slot's previous step by stream order), or write it on the current stream and call
+        `submit(after_current=True)`.  A write on the current stream followed by a plain `submit()` races the graph replay
+        against it."""
         return self._runs[slot].static_input
 
     def knn_buffer(self, slot):

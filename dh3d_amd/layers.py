@@ -138,12 +138,25 @@ class Flex_Avg(nn.Module):
         self.register_buffer("position_bias", torch.eye(filters), persistent=False)  # not a variable upstream
 
     def _theta_is_zero(self):
-        """position_theta == 0 (what the reference initialises it to and never trains), looked up ONCE per version of
-        the tensor: asking the device on every call would be a host sync per forward and break hipGraph capture."""
-        key = (self.position_theta.data_ptr(), self.position_theta._version)
-        if self.__dict__.get("_zero_key") != key:
-            self._zero_key, self._zero = key, not bool(self.position_theta.any())
+        """position_theta == 0 (what the reference initialises it to and never trains).  Asking the device costs a host
+        sync and cannot happen inside a hipGraph capture, so: OUTSIDE a capture the tensor is re-checked on every call
+        (writes through `.data` -- p.data.copy_(...), common in loaders -- change neither data_ptr nor _version, so no
+        cache key can see them); UNDER capture the verdict of the last eager call stands -- run one eager forward after
+        changing theta, as hipGraph capture needs for warm-up anyway.  load_state_dict / .to() / .float() reset it."""
+        if self.__dict__.get("_zero") is None or not torch.cuda.is_current_stream_capturing():
+            self._zero = not bool(self.position_theta.any())
         return self._zero
+
+    def reset_theta_cache(self):
+        self._zero = None
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.reset_theta_cache()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.reset_theta_cache()
+        return super()._apply(fn, *args, **kwargs)
 
     def forward(self, features, positions, neighborhoods):
         from . import pm

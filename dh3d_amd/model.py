@@ -32,7 +32,10 @@ def tf_variable_name(state_dict_key):
 KNN_GRID = pm.KNN_GRID
 
 
-_DEV_RESERVE = int(os.environ["DH3D_DEV_RESERVE"]) if os.environ.get("DH3D_DEV_RESERVE") else None
+# Development A/B knobs (tools/single_stream_ab.py, the placement-hint sweeps): read only when DH3D_DEBUG_KNOBS=1, so a
+# production process cannot pick one up from a stray environment variable.
+_DEBUG_KNOBS = os.environ.get("DH3D_DEBUG_KNOBS") == "1"
+_DEV_RESERVE = int(os.environ["DH3D_DEV_RESERVE"]) if _DEBUG_KNOBS and os.environ.get("DH3D_DEV_RESERVE") else None
 
 
 class DH3D(nn.Module):
@@ -230,7 +233,7 @@ class DH3D(nn.Module):
             geo.ordered(cells=knn_inds is None and self.knn_num <= 8 and KNN_GRID)
         if self._geo_stream is None:
             self._geo_stream = torch.cuda.Stream(device=points.device)
-        side = main if getattr(self, "_single_stream", False) else self._geo_stream  # (dev: tools/single_stream_ab.py)
+        side = main if (_DEBUG_KNOBS and getattr(self, "_single_stream", False)) else self._geo_stream  # (dev: tools/single_stream_ab.py)
         fork = torch.cuda.Event()
         fork.record()  # the side stream needs the input (and the ordering) only
         geo._side = side
@@ -288,13 +291,6 @@ class DH3D(nn.Module):
             return None
         return ((ps["wp3"], ps["b"], ps["scale"], ps["shift"], pm.ACT_RELU), (pc["wp3_bot"], None, None, None, pm.ACT_NONE))
 
-    @staticmethod
-    def _side_is_critical(points):
-        """Which of the step's two chains ends last (measured model, MI355X, rounds 2-4): the FPS chain costs ~0.05 us per
-        point of a cloud whatever the batch, kNN(N) + stage 1 on the side stream ~2.5 us per 1000 points of the batch."""
-        B, N = points.shape[0], points.shape[1]
-        return 80.0 + 2.5e-3 * B * N - 0.05 * N > 60.0
-
     def _three_nn_before_sampled_level(self, points):
         """Where three_nn (+ the sampled set's sort) is enqueued: on the MAIN stream between the sampled set's kNN and its
         convolutions, or on the side stream behind stage 1 (beside those convolutions).  Placement only -- the results
@@ -304,7 +300,10 @@ class DH3D(nn.Module):
             local   main / side    0.5217 / 0.4996 ms          0.2322 / 0.2797 ms
         One step alone wants it on the side stream (it leaves the critical chain); with other steps in flight the
         side stream's slack belongs to THEIR chip-wide kernels and the shorter side chain wins.  So the engine's mode
-        decides (DH3D.steps_in_flight, set by Pipeline while it captures its slots)."""
+        decides (DH3D.steps_in_flight, set by Pipeline while it captures its slots).  Rounds 2-4 chose by a batch / cloud-size
+        model of which chain ends last instead; it predicted "main" for the serial global step, where "side" measures
+        3 % faster, and was removed.  Shapes outside the two measured workloads (cfg 5's 4 x 16384: tools/side_critical_ab.py
+        --workload cfg5) follow the same rule: in flight 0.600 -> 0.565 ms per step on the main stream."""
         return getattr(self, "steps_in_flight", 1) > 1
 
     def _join_side(self, geo):

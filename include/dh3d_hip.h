@@ -44,7 +44,11 @@ extern "C" {
 int dh3d_version(void);                 /* 100*major + minor */
 /* Bumped whenever the MEANING of an existing entry point changes under an unchanged signature (which a linker cannot
  * see).  History: 1 = rounds 1-2; 2 = the accumulators of dh3d_bn_colstats / dh3d_bn_bwd_sums / dh3d_interp_bn_colstats /
- * dh3d_interp_bn_bwd_sums / dh3d_interp_bn_bwd_apply are no longer zeroed by the library ("zeroed by the CALLER").
+ * dh3d_interp_bn_bwd_sums / dh3d_interp_bn_bwd_apply are no longer zeroed by the library ("zeroed by the CALLER");
+ * 3 (round 4) = dh3d_knn_grid takes the three outputs of dh3d_spatial_sort_cells (sorted, gbox, cells), serves any
+ * N <= 16384 and hands clouds the sort flags as crowded (cells[4106]) to the pruned scan; 4 (round 5) = the cell table
+ * describes a grid whose 12 code bits are dealt to the axes by extent (cells[4103..4105] = 2^(nb+2)/extent, cells[4107] =
+ * the bit schedule; see dh3d_spatial_sort_cells) and dh3d_knn_grid reads that header.
  * A binding compares it with the DH3D_ABI_VERSION it was written against and refuses to run on a mismatch
  * (dh3d_amd/_lib.py does). */
 #define DH3D_ABI_VERSION 4
@@ -226,11 +230,25 @@ int dh3d_spatial_sort(const float *xyz, int B, int N, float *sorted, float *gbox
 int dh3d_knn_sorted(const float *sorted, const float *gbox, int B, int N, int K, int32_t *nn, float *dist,
                     void *stream);
 
-/* dh3d_spatial_sort that also writes the CELL TABLE of the 16 x 16 x 16 grid over each cloud's bounding box: cells
- * [B, DH3D_CELL_INTS] int32 -- [0..4096] the first sorted position of every cell (cells in Morton order = the top 12 bits of
- * the sort key; [4096] = N), [4100..4105] as floats the grid origin and its 64 / extent scale per axis, [4106] = 1 when the
- * cloud's points crowd into fewer than 0.6 x the cells a uniform cloud of N points would occupy (street scenes, clusters:
- * dh3d_knn_grid then serves this cloud with the pruned scan of dh3d_knn_sorted), else 0. */
+/* dh3d_spatial_sort that also writes the CELL TABLE of a 4096-cell grid over each cloud's bounding box: cells
+ * [B, DH3D_CELL_INTS] int32.  The sort key is an 18-bit code; its top 12 bits are the GRID code, and since ABI 4 those 12
+ * bits are dealt to the axes BY EXTENT -- one at a time to the axis whose cells are the widest so far (at most 6 per axis;
+ * cell widths within 25 % of each other: z first, then y, then x), so axis a gets nb[a] grid bits (a cube: 4 + 4 + 4 = the
+ * plain z-y-x Morton code of ABI <= 3; a 60 x 60 x 8 slab: 5 + 5 + 2) and the grid is 2^nb[0] x 2^nb[1] x 2^nb[2] cells.
+ *   [0..4095]     first sorted position of every cell, cells ordered by their 12-bit code (an empty cell's entry = the
+ *                 next cell's); [4096] = N
+ *   [4100..4102]  as floats: the grid origin (x, y, z) = the bounding box's minimum
+ *   [4103..4105]  as floats: the quantisation scale per axis, 2^(nb[a] + 2) / extent[a] (a cell = 4 quantisation steps; the
+ *                 two sub-cell bits per axis are the key's low 6 bits, z y x z y x)
+ *   [4106]        1 when the cloud's points crowd into fewer than 0.6 x the cells a uniform cloud of N points would occupy
+ *                 (street scenes, clusters: dh3d_knn_grid then serves this cloud with the pruned scan of
+ *                 dh3d_knn_sorted), else 0
+ *   [4107]        the bit SCHEDULE: 12 x 2 bits, field s (bits 2s, 2s+1) = the axis (0 x, 1 y, 2 z) that grid-code bit
+ *                 11 - s belongs to -- field 0 is the code's MOST significant bit; within an axis the bits appear in the
+ *                 code from that axis' most significant cell-coordinate bit downwards.  0x186186 = z y x z y x ... (cube).
+ * To decode cell code c into per-axis cell coordinates: walk s = 0..11, append bit (c >> (11 - s)) & 1 to the coordinate of
+ * axis (sched >> 2s) & 3.  A table written by an ABI <= 3 sort (no schedule, scale 64 / extent) must not be handed to an
+ * ABI 4 dh3d_knn_grid. */
 #define DH3D_CELL_INTS 4112
 int dh3d_spatial_sort_cells(const float *xyz, int B, int N, float *sorted, float *gbox, int32_t *cells, void *stream);
 

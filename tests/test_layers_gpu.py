@@ -105,5 +105,11 @@ def test_flex_avg_layer_vs_oracle_flex_conv_with_zero_theta(dev, oracle):
     exp2 = oracle.flex_convolution(f, p_cf, nb_cf, theta, np.eye(C, dtype=np.float32), True)
     got2 = layer(T(f), T(p_cf), T(nb_cf)).cpu().numpy()
     assert np.abs(got2 - exp2).max() <= 1e-4 * np.abs(exp2).max()
+    # a write through .data (what loaders do) changes neither data_ptr nor _version: the layer must still notice
+    layer2 = Flex_Avg(C, C).to(dev)
+    assert np.array_equal(layer2(T(f), T(p_cf), T(nb_cf)).cpu().numpy(), exp)
+    layer2.position_theta.data.copy_(T(theta))
+    got3 = layer2(T(f), T(p_cf), T(nb_cf)).cpu().numpy()
+    assert np.abs(got3 - exp2).max() <= 1e-4 * np.abs(exp2).max()
     with pytest.raises(ValueError):
         Flex_Avg(32, 64)

@@ -1,5 +1,6 @@
 """Dev: steps in flight with each step on ONE stream (no side stream inside a step) against the two-stream step."""
 import os, sys, time
+os.environ["DH3D_DEBUG_KNOBS"] = "1"  # (dh3d_amd.model reads its dev knobs only under this flag)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch, bench
 dev = torch.device("cuda")
