@@ -804,9 +804,21 @@ def compact_line(full, extras_path=None, limit=LINE_LIMIT):
         out["cpu_baseline"] = c
     if "global_scaling" in full:
         out["global_scaling"] = full["global_scaling"]
+    if isinstance(full.get("value_streaming"), dict):   # the serving loop: host batch in (+ descriptors out) every step
+        v = full["value_streaming"]
+        c = {k: v.get(k) for k in ("value", "ms_per_step", "steps_in_flight") if k in v}
+        if "what" in v:
+            c["what"] = str(v["what"])[:160]
+        if isinstance(v.get("d2h_inclusive"), dict):
+            c["d2h_inclusive"] = {k: v["d2h_inclusive"].get(k) for k in ("value", "GBps_d2h")}
+        if "error" in v:
+            c["error"] = str(v["error"])[:160]
+        out["value_streaming"] = c
     if isinstance(full.get("global"), dict):   # the other half of BASELINE.json's metric (fresh process, N = 1)
         g = full["global"]
         c = {k: g.get(k) for k in ("workload", "value", "ms_per_step", "steps_in_flight", "clouds_per_gpu", "points") if k in g}
+        if isinstance(g.get("value_streaming"), dict):
+            c["value_streaming"] = {k: g["value_streaming"].get(k) for k in ("value", "ms_per_step")}
         if isinstance(g.get("one_step_at_a_time"), dict):
             c["one_step_at_a_time"] = {"value": g["one_step_at_a_time"].get("value"),
                                        "ms_per_step": g["one_step_at_a_time"].get("ms_per_step")}
@@ -819,7 +831,7 @@ def compact_line(full, extras_path=None, limit=LINE_LIMIT):
     # never over the limit: shed the optional blocks, least important first (none of these fire on today's record)
     for k in ("global_scaling.note", "roofline.traffic_source", "cpu_baseline.sample", "config.execution",
               "config.weights", "config.parallelism", "phases_ms", "global_scaling", "cpu_baseline.all_cores",
-              "global.workload", "global"):
+              "value_streaming.what", "value_streaming.d2h_inclusive", "value_streaming", "global.workload", "global"):
         if len(text.encode()) <= limit:
             break
         head, _, leaf = k.partition(".")
@@ -871,6 +883,8 @@ def main():
     ap.add_argument("--no-global-scaling", action="store_true",
                     help="with --gpus N > 1 and the default workload: skip the global path's weak / strong lines")
     ap.add_argument("--no-pmc", action="store_true", help="do not collect live PMC traffic for the roofline kernel")
+    ap.add_argument("--no-streaming", action="store_true",
+                    help="skip `value_streaming` (the same pipeline fed a different pinned-host batch every step)")
     ap.add_argument("--no-global-line", action="store_true",
                     help="default workload at one GPU: do not measure the global-descriptor forward (the other half of "
                          "BASELINE.json's metric) in a fresh process for the line's `global` block")
@@ -1081,7 +1095,7 @@ def main():
 
     _STREAM_POOL = []
 
-    def measure_in_flight(workload, depth=2, repeats=0, steps=None, strong_=None):
+    def measure_in_flight(workload, depth=2, repeats=0, steps=None, strong_=None, streaming=False):
         """Throughput with `depth` independent steps in flight: `depth` graph instances on `depth` streams, each with its
         own batch buffers; step i is one full pass over one batch on stream i % depth.  A single forward of this path
         leaves most of the GPU idle (FPS: one CU per cloud for two thirds of the step), so consecutive batches overlap;
@@ -1113,7 +1127,77 @@ def main():
                        "median_ms": float(np.median(blocks)), "min_ms": float(np.min(blocks)),
                        "max_ms": float(np.max(blocks)), "median_value": total / (float(np.median(blocks)) * 1e-3),
                        "note": "further timed blocks after the contract one; `value` is the first block"}
+            if streaming and world == 1:
+                try:
+                    _STREAMING[workload] = measure_streaming(pipe, wl, per, total, nsteps)
+                except Exception as e:  # noqa: BLE001 -- informational key
+                    _STREAMING[workload] = {"error": repr(e)[:200]}
         return total * nsteps / dt, dt / nsteps * 1e3, rep
+
+    _STREAMING = {}
+
+    def measure_streaming(pipe, wl, per, total, nsteps):
+        """The same pipeline as a SERVING loop (what engine.Pipeline.map runs; localdesc_extract.py:106-138,
+        globaldesc_extract.py:84-100): every step's batch is a DIFFERENT pinned-host batch, copied H2D on the slot's own
+        stream in front of the replay (Pipeline.submit(host_batch)); every step's output is consumed before its slot is
+        reused -- small outputs (the [B, 256] global descriptors) are copied D2H into pinned memory on the slot's stream,
+        the dense local map [B, N, 131] (34 MB per step: 140 GB/s at this step rate, more than a PCIe 5 x16 link carries)
+        is copied out of the slot's buffers into a device-side consumer's buffer (what Pipeline.map's clone does); the
+        D2H-inclusive rate of the dense map is reported beside it.  Timed like `value`: K steps, fill and drain included."""
+        depth = pipe.depth
+        nb = 2 * depth + 1
+        host = [torch.from_numpy(np.random.default_rng(wl["seed"] + 104729 * (i + 1)).random((per, wl["N"], 3), dtype=np.float32)).pin_memory()
+                for i in range(nb)]
+        name = wl["out"]
+        shape = tuple(pipe._runs[0].outputs[name].shape)
+        out_bytes = int(np.prod(shape)) * 4
+        small = out_bytes <= (1 << 20)
+        # two generations of host buffers per slot: the host-side consumer may lag a whole round behind the submitting loop
+        # (Pipeline keeps 2 * depth ticket events), so the loop blocks only on a step submitted 2 * depth steps ago
+        host_out = [torch.empty(shape, dtype=torch.float32).pin_memory() for _ in range(2 * depth)]
+        sink = [torch.empty(shape, dtype=torch.float32, device=dev) for _ in range(depth)]
+
+        # Both consumers live on the SLOT's stream (Pipeline.submit(fetch_to=...)): a separate consumer stream costs a
+        # cross-stream event pair per step and shares one of the process's four hardware queues with a slot -- its waits
+        # stall that slot (first version of this block: 6.7 k clouds/s against 33 k).
+        def loop(n, d2h):
+            tickets = []
+            for i in range(n):
+                if d2h and len(tickets) == 2 * depth:
+                    tickets.pop(0).event.synchronize()   # that step's descriptors are in host memory; its buffer is free again
+                k = pipe.next_slot
+                tickets.append(pipe.submit(host[i % nb], fetch_to={name: host_out[i % (2 * depth)] if d2h else sink[k]}))
+            if d2h:
+                for tk in tickets:
+                    tk.event.synchronize()
+
+        def timed(d2h):
+            loop(max(args.warmup, depth), d2h)
+            torch.cuda.synchronize()
+            D.barrier()
+            t0 = time.perf_counter()
+            loop(nsteps, d2h)
+            torch.cuda.synchronize()
+            D.barrier()
+            return time.perf_counter() - t0
+        rec = {"steps_in_flight": depth, "distinct_host_batches": nb, "h2d_bytes_per_step": per * wl["N"] * 12,
+               "output_bytes_per_step": out_bytes}
+        if small:
+            dt = timed(True)
+            rec.update({"value": total * nsteps / dt, "ms_per_step": dt / nsteps * 1e3,
+                        "what": "pinned host batch -> H2D on the slot's stream -> step -> D2H of `%s` into pinned host memory "
+                                "on the slot's stream; the host picks results up one round (2 x depth buffers) behind the submitting loop" % name})
+        else:
+            dt = timed(False)
+            rec.update({"value": total * nsteps / dt, "ms_per_step": dt / nsteps * 1e3,
+                        "what": "pinned host batch -> H2D on the slot's stream -> step -> `%s` copied out of the slot's buffers "
+                                "into the consumer's device buffer on the slot's stream" % name})
+            dt2 = timed(True)
+            rec["d2h_inclusive"] = {"value": total * nsteps / dt2, "ms_per_step": dt2 / nsteps * 1e3,
+                                    "GBps_d2h": out_bytes * nsteps / dt2 / 1e9,
+                                    "note": "the dense map copied to pinned host memory every step: bound by the host link, "
+                                            "not by the path (never `value`)"}
+        return rec
 
     pipelined = args.inflight > 1 and args.workload not in ("train", "train_local")
     value, ms, info = measure(args.workload)  # one step at a time (the definition of rounds 1-2; `value` for train)
@@ -1124,7 +1208,7 @@ def main():
     in_flight_error = None
     if pipelined:
         try:
-            value, ms, rep = measure_in_flight(args.workload, args.inflight, args.repeats)
+            value, ms, rep = measure_in_flight(args.workload, args.inflight, args.repeats, streaming=not args.no_streaming)
             if rep:
                 info["repeats"] = rep
         except Exception as e:  # noqa: BLE001 -- the line must not be lost: fall back to the one-at-a-time measurement
@@ -1149,6 +1233,8 @@ def main():
     }
     if in_flight_error:
         line["in_flight_error"] = in_flight_error
+    if pipelined and args.workload in _STREAMING:
+        line["value_streaming"] = _STREAMING[args.workload]
     if args.workload not in ("train", "train_local"):
         line["one_step_at_a_time"] = serial
     if args.workload == "train_local":
@@ -1176,7 +1262,7 @@ def main():
         import subprocess
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", workload, "--inflight", str(depth),
                "--steps", str(steps), "--warmup", str(args.warmup), "--no-extras", "--no-cpu-baseline", "--repeats", "0",
-               "--extras-file", os.devnull]
+               "--no-streaming", "--extras-file", os.devnull]
         if batch:
             cmd += ["--batch", str(batch)]
         try:
@@ -1202,7 +1288,8 @@ def main():
             return {"workload": wl_["name"], "value": rec["value"], "unit": rec["unit"], "ms_per_step": rec["ms_per_step"],
                     "steps": rec["steps"], "warmup": rec["warmup"], "clouds_per_gpu": rec["config"]["clouds_per_gpu"],
                     "points": rec["config"]["points"], "steps_in_flight": rec["config"]["steps_in_flight"],
-                    "one_step_at_a_time": rec.get("one_step_at_a_time"), "measured_in": "a fresh process of this file "
+                    "one_step_at_a_time": rec.get("one_step_at_a_time"), "value_streaming": rec.get("value_streaming"),
+                    "measured_in": "a fresh process of this file "
                     "(--workload %s), same timed-region definition as `value`" % workload, "wall_s": time.time() - t0}
         except Exception as e:  # noqa: BLE001 -- the headline must not be lost with it
             return {"workload": wl_["name"], "error": repr(e)[:200]}

@@ -37,6 +37,7 @@ _SIGNATURES = {
     "dh3d_arch": [],
     "dh3d_source_hash": [],
     "dh3d_status_string": [c_int],
+    "dh3d_stage_copy": [c_fp, c_fp, c_size_t, c_fp],
     "dh3d_knn_bruteforce": [c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp],
     "dh3d_knn_bruteforce_xyz": [c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp],
     "dh3d_flex_conv_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp],
@@ -110,6 +111,7 @@ _SIGNATURES = {
     "dh3d_fps_sorted": [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp],
     "dh3d_three_nn_sorted": [c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp],
     "dh3d_fps_sorted_xyz": [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp],
+    "dh3d_fps_sorted_ordered": [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp],
     "dh3d_fps_sorted_cloud": [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp],
     "dh3d_pack_weight": [c_fp, c_int, c_int, c_fp, c_fp],
     "dh3d_pack_flex_weight": [c_fp, c_fp, c_int, c_int, c_fp, c_fp],

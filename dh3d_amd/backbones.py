@@ -302,7 +302,7 @@ class Geometry(object):
         key = (dilate, knn)
         if key not in self.levels:
             self.levels[key] = compute_level(self.xyz, dilate, knn, ordered=self.sorted,
-                                             fps_contract=self.fps_contract)
+                                             fps_contract=self.fps_contract, cells=self.cells)
         return self.finish(self.levels[key]) if finish else self.levels[key]
 
     def start_nn3(self, lv):
@@ -349,7 +349,14 @@ TAIL_FUSED = os.environ.get("DH3D_TAIL_FUSED", "0") == "1"
 TAIL_FUSED_SMALL = os.environ.get("DH3D_TAIL_FUSED_SMALL", "1") != "0"
 
 
-def compute_level(xyz, dilate, knn, ordered=None, fps_contract=None):
+# dev A/B switches (round 6).  DH3D_FPS_ORDERED=0: the sampled set is sorted by its own launch again (spatial_sort_kernel<1>
+# behind the sampling) instead of leaving the FPS kernel in Morton order; DH3D_SAMPLED_GRID=0: the sampled set's kNN back on
+# the brute-force wave-per-query kernel instead of the cell lists on the table the FPS kernel writes.
+FPS_ORDERED = os.environ.get("DH3D_FPS_ORDERED", "1") != "0"
+SAMPLED_GRID = os.environ.get("DH3D_SAMPLED_GRID", "1") != "0"
+
+
+def compute_level(xyz, dilate, knn, ordered=None, fps_contract=None, cells=None):
     """FPS -> gather xyz -> kNN on the sampled set (three_nn back to the full set: finish_level).
 
     `ordered` = (records, group boxes) of pm.spatial_sort(xyz) if the caller has them: large clouds then use the
@@ -359,7 +366,14 @@ def compute_level(xyz, dilate, knn, ordered=None, fps_contract=None):
     (ops.farthest_point_sample)."""
     B, N, _ = xyz.shape
     npoint = N // dilate
-    if ordered is not None and 4096 <= N <= 16384 and fps_contract is None:
+    ordered_s, cells_s = None, None
+    if ordered is not None and 4096 <= N <= 8192 and fps_contract is None and FPS_ORDERED:
+        # the sampled set leaves the FPS kernel IN MORTON ORDER (a stable compaction of the picked positions of the sorted
+        # cloud: records, group boxes and -- with the cloud's cell table -- the subset's table on the cloud's grid):
+        # three_nn and the sampled set's kNN need no sort of their own behind the sampling
+        idx, xyz_s, srt_s, gbox_s, cells_s = pm.fps_sorted_ordered(ordered[0], ordered[1], npoint, cells=cells)
+        ordered_s = (srt_s, gbox_s)
+    elif ordered is not None and 4096 <= N <= 16384 and fps_contract is None:
         # (above 12288 points the kernel has no room for its LDS coordinate table and reads winners from the cloud)
         idx, xyz_s = pm.fps_sorted(ordered[0], ordered[1], npoint, with_xyz=True, xyz=xyz if N > 12288 else None)
     else:
@@ -368,10 +382,14 @@ def compute_level(xyz, dilate, knn, ordered=None, fps_contract=None):
         xyz_s = gather_rows(xyz, idx)
     ready = torch.cuda.Event()
     ready.record()  # xyz_s exists: three_nn may start on another stream while the sampled-set kNN runs here
-    ordered_s = None
-    # (cell lists on the sampled set -- spatial_sort_cells + knn_grid, which serves any size -- were measured here: the
-    #  sort joins the critical chain behind the FPS, local serial 0.532 -> 0.539 ms, in flight unchanged: DEADENDS.md)
-    if npoint <= 2048 or npoint > 16384:  # small sets: the brute-force kernel beats sort + pruned search (launch /
+    if cells_s is not None and knn <= 8 and pm.KNN_GRID and SAMPLED_GRID and npoint >= 256 and B * npoint >= 16384:
+        # cell lists on the table the FPS kernel wrote (a third of the brute-force kernel's instructions per query; with a
+        # sort of its own on the chain this lost: DEADENDS.md "the sampled levels on cell lists").  Only where the launch
+        # fills the chip: 64 queries per workgroup -- 32 x 512 is 256 workgroups (global serial 0.6732 -> 0.6671 ms, three
+        # in flight 0.5424 -> 0.5343), 8 x 1024 only 128 and latency-bound (local serial 0.4996 -> 0.5186: stays on the
+        # wave-per-query kernel)
+        nbr_s, _ = pm.knn_grid(ordered_s[0], ordered_s[1], cells_s, knn)
+    elif npoint <= 2048 or npoint > 16384:  # small sets: the brute-force kernel beats sort + pruned search (launch /
         nbr_s, _ = pm.knn_xyz(xyz_s, knn)  # latency bound); sets beyond the Morton sort's 14-bit ids: it is what serves any N
     elif knn <= 8 and pm.KNN_GRID:
         srt_s, gbox_s, cells_s = pm.spatial_sort_cells(xyz_s)

@@ -10,6 +10,13 @@
 
 namespace {
 
+#ifdef DH3D_SE_PROBE  // dev instrumentation (tools/se_res_phases.py): cycle stamps of se_res_mfma_kernel's phases, 64 workgroups
+__device__ long long g_seprobe[64 * 16];
+#define SEPROBE(i) do { if (threadIdx.x == 0 && blockIdx.x % 16 == 0 && blockIdx.x / 16 < 64) g_seprobe[(blockIdx.x / 16) * 16 + (i)] = clock64(); } while (0)
+#else
+#define SEPROBE(i) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------ weight packing
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restrict__ W, int Kd, int Dout,
                                                          float *__restrict__ packed) {
@@ -348,6 +355,7 @@ __global__ __launch_bounds__(256) void se_res_mfma_kernel(const float *__restric
   // POOL gathers neighbour rows of the tile's own cloud: every XCD gets a CONTIGUOUS range of tiles, so a cloud's map is
   // fetched into one L2 instead of all eight (PMC, 8 x 8192 x 64: FETCH_SIZE 57.9 MB raw with the round-robin order)
   const long long grow0 = (long long)(POOL ? dh3d_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x) * TMR;
+  SEPROBE(0);
   if (POOL) {
     // the tile's neighbour ids once into LDS (as row offsets; every id is used by C/4 lanes), then all K row reads of a
     // lane in flight together
@@ -360,6 +368,7 @@ __global__ __launch_bounds__(256) void se_res_mfma_kernel(const float *__restric
       }
       __syncthreads();
     }
+    SEPROBE(1);
     constexpr int CVP = C / 4;
     if (k8) {
       // two points per lane and pass: their 16 row reads are requested together and none sits under a branch (rows past
@@ -409,7 +418,9 @@ __global__ __launch_bounds__(256) void se_res_mfma_kernel(const float *__restric
   } else {
     stage_rows(pool, C, pool, 0, grow0, R, s_p, LDP);
   }
+  SEPROBE(2);
   __syncthreads();
+  SEPROBE(3);
   if (wave < RB) {  // squeeze: relu(pool @ W1 + b1)
     f32x16 acc[1];
     zero_acc<1>(acc);
@@ -421,7 +432,9 @@ __global__ __launch_bounds__(256) void se_res_mfma_kernel(const float *__restric
       s_h[(size_t)(wave * 32 + mfma_row(r, lane)) * LDH + (lane & 31)] = v > 0.f ? v : 0.f;
     }
   }
+  SEPROBE(4);
   __syncthreads();
+  SEPROBE(5);
   {  // excite: sigmoid(h @ W2 + b2) -> gate tile over the (dead) pooled rows
     // column blocks per wave: (row block = wave & 1, column blocks (wave >> 1) + 2 j), or with one row block: wave + 4 j
     constexpr int NT = C / 32 * RB / 4, CBS = 4 / RB;
@@ -439,7 +452,9 @@ __global__ __launch_bounds__(256) void se_res_mfma_kernel(const float *__restric
                                                                      // v_exp + v_rcp instead of the ~20 instructions of expf and an IEEE division)
     }
   }
+  SEPROBE(6);
   __syncthreads();
+  SEPROBE(7);
   constexpr int CV = C / 4;
   {
     // the tile's own rows: every pass's read requested before the first is used (rows past the end re-read the last row)
@@ -469,9 +484,11 @@ __global__ __launch_bounds__(256) void se_res_mfma_kernel(const float *__restric
       }
     }
   }
+  SEPROBE(8);
   if (CONV) {  // out2 = act(bn(tile @ Wconv + b)), C columns: C / 64 accumulators of 32 x 32 per wave
     constexpr int NTC = C / 32 * RB / 4, CBC = 4 / RB;
     __syncthreads();
+    SEPROBE(9);
     const int row0 = RB == 2 ? (wave & 1) * 32 : 0, cb0 = RB == 2 ? wave >> 1 : wave;
     f32x16 acc[NTC];
     zero_acc<NTC>(acc);
@@ -480,10 +497,13 @@ __global__ __launch_bounds__(256) void se_res_mfma_kernel(const float *__restric
     for (int j = 0; j < NTC; ++j) er[j] = epilogue_prefetch(cep, (cb0 + CBC * j) * 32 + (lane & 31));
     if constexpr (TAILS) tile_tail_k64_x6<LDP>(s_p, ta, grow0, R);  // on the block's output tile
     wave_gemm_f32<NTC>(s_p, LDP, row0, wconv, C / 8, cb0, CBC, acc);
+    SEPROBE(10);
     __syncthreads();
     wave_tiles_to_lds<NTC>(acc, er, cep.act, s_p, LDP, row0, cb0, CBC);
     __syncthreads();
+    SEPROBE(11);
     block_store_rows(s_p, LDP, TMR, grow0, R, C, nullptr, out2);
+    SEPROBE(12);
     if constexpr (TAILS) tile_tail_k64_x6<LDP>(s_p, tb, grow0, R);  // on the conv's output tile
   }
 }
@@ -797,3 +817,9 @@ DH3D_API int dh3d_l2norm_concat_fwd(const float *x, int R, int C, float eps, con
                      (long long)R, C, eps, prefix, P, out);
   return dh3d_launch_status();
 }
+
+#ifdef DH3D_SE_PROBE
+DH3D_API int dh3d_se_probe_read(long long *host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_seprobe), sizeof(long long) * n) == hipSuccess ? 0 : 3;
+}
+#endif

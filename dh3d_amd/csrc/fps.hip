@@ -172,11 +172,33 @@ __global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float *__restrict
 // an LDS ring instead of barriers (slower: the workers' instruction issue, four waves per SIMD, is the bottleneck).
 // TABLE: the by-original-index coordinate table lives in LDS (12 B per point: clouds of up to ~12 k points).  Larger
 // clouds (TABLE = false) read candidate coordinates from the cloud itself (`xyz`, L2-resident).
+// The sampled set in the cloud's own Morton order, written by the kernel's tail (round 6): the picks are a SUBSET of an
+// already sorted cloud, so a stable compaction of the picked positions is their spatial order -- records (x, y, z, pick
+// rank), one box per 64 records and (with the cloud's cell table given) the subset's cell table on the cloud's grid, i.e.
+// everything dh3d_spatial_sort_cells(sampled xyz) would hand to three_nn_sorted / knn_grid, without the second sort's
+// launch on the chain behind the sampling.  A point picked more than once (a cloud with fewer distinct points than picks)
+// yields one record per pick.
+struct FpsOrderedOut {
+  float4 *sorted_s;    // [B, m] or NULL: nothing below is written
+  float *gbox_s;       // [B, ceil(m / 64), 8]
+  const int *cells;    // [B, DH3D_CELL_INTS] of the cloud, or NULL
+  int *cells_s;        // [B, DH3D_CELL_INTS] of the sampled set (iff cells)
+  int occ_min;         // fewer occupied cells than this: cells_s[4106] = 1 (spatial.hip's rule for a set of m points)
+};
+
+__device__ __forceinline__ unsigned f32_ordered(float f) {  // monotonic float -> unsigned (for LDS atomicMin / atomicMax)
+  const unsigned u = __float_as_uint(f);
+  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float f32_unordered(unsigned u) {
+  return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+
 template <int PPT, int WAVES, bool TABLE>
 __global__ __launch_bounds__(64 * WAVES) void fps_list_kernel(const float4 *__restrict__ sorted,
                                                             const float *__restrict__ gbox, int N, int m,
                                                             int32_t *__restrict__ out, float *__restrict__ xyz_out,
-                                                            const float *__restrict__ xyz) {
+                                                            const float *__restrict__ xyz, FpsOrderedOut oo) {
   static_assert(PPT <= 32 && WAVES <= 16 && 64 % WAVES == 0, "one lane per (pick, box) pair, one lane per pool entry");
   constexpr int L = 64 / WAVES;                       // list entries per wave: the pool is one entry per judge lane
   constexpr int PP = 64 / PPT < 16 ? 64 / PPT : 16;   // picks box-tested per pass
@@ -452,13 +474,97 @@ __global__ __launch_bounds__(64 * WAVES) void fps_list_kernel(const float4 *__re
       xo[e] = TABLE ? (c == 0 ? s_x[k] : c == 1 ? s_y[k] : s_z[k]) : pc[(size_t)k * 3 + c];
     }
   }
+  if constexpr (TABLE) {
+    if (oo.sorted_s) {  // (uniform) the sampled set in Morton order: see FpsOrderedOut
+      constexpr int T = 64 * WAVES;
+      const int NGs = (m + 63) / 64;
+      unsigned *s_cnt = reinterpret_cast<unsigned *>(s_out + m);                      // [N + 1] picks per sorted position
+      unsigned short *s_pos = reinterpret_cast<unsigned short *>(s_cnt + N + 1);      // [N] original index -> sorted position
+      unsigned *s_box = reinterpret_cast<unsigned *>(s_pos + ((N + 1) & ~1));         // [NGs][6] ordered-uint min / max
+      unsigned *s_wsum = reinterpret_cast<unsigned *>(s_list);                        // [WAVES + 1] (the pool is dead)
+      for (int i = tid; i <= N; i += T) s_cnt[i] = 0u;
+      for (int i = tid; i < NGs * 6; i += T) s_box[i] = (i % 6) < 3 ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+      for (int j = 0; j < 2 * NP; ++j) {
+        const int i = (wave * PPT + j) * 64 + lane;
+        if (j < PPT && i < N) s_pos[fps_unkey(pkey[j])] = (unsigned short)i;
+      }
+      if (tid == 0) s_wsum[WAVES] = 0u;
+      __syncthreads();
+      for (int r = tid; r < m; r += T) atomicAdd(&s_cnt[s_pos[s_out[r]]], 1u);
+      __syncthreads();
+      // exclusive prefix over the sorted positions (thread t owns the chunk [t * CH, (t + 1) * CH) of [0, N]); s_cnt[N] = m
+      const int CH = (N + 1 + T - 1) / T;
+      unsigned mine = 0u;
+      for (int c = 0; c < CH; ++c) {
+        const int i = tid * CH + c;
+        if (i <= N) mine += s_cnt[i];
+      }
+      unsigned inc = mine;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned up = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += up;
+      }
+      if (lane == 63) s_wsum[wave] = inc;
+      __syncthreads();
+      unsigned base = inc - mine;
+      for (int w = 0; w < wave; ++w) base += s_wsum[w];
+      for (int c = 0; c < CH; ++c) {
+        const int i = tid * CH + c;
+        if (i <= N) {
+          const unsigned v = s_cnt[i];
+          s_cnt[i] = base;
+          base += v;
+        }
+      }
+      __syncthreads();
+      if (oo.cells) {  // the subset's cell table on the cloud's grid: cell c opens at the number of picks in front of it
+        const int *ct = oo.cells + (size_t)b * DH3D_CELL_INTS;
+        int *cs = oo.cells_s + (size_t)b * DH3D_CELL_INTS;
+        int occ = 0;
+        for (int c = tid; c <= 4096; c += T) {
+          const unsigned v = s_cnt[min(max(ct[c], 0), N)];
+          cs[c] = (int)v;
+          if (c < 4096) occ += (int)(s_cnt[min(max(ct[c + 1], 0), N)] > v);
+        }
+        for (int c = 4097 + tid; c < DH3D_CELL_INTS; c += T)
+          if (c != 4106) cs[c] = ct[c];  // origin, scales, bit schedule: the cloud's grid
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) occ += __shfl_xor(occ, off, 64);
+        if (lane == 0) atomicAdd(&s_wsum[WAVES], (unsigned)occ);
+      }
+      __syncthreads();  // every prefix value has been read: the counters now hand out the slots
+      if (oo.cells && tid == 0) oo.cells_s[(size_t)b * DH3D_CELL_INTS + 4106] = (int)s_wsum[WAVES] < oo.occ_min ? 1 : 0;
+      float4 *so = oo.sorted_s + (size_t)b * m;
+      for (int r = tid; r < m; r += T) {
+        const int k = s_out[r];
+        const unsigned slot = atomicAdd(&s_cnt[s_pos[k]], 1u);
+        const float x = s_x[k], y = s_y[k], z = s_z[k];
+        so[slot] = make_float4(x, y, z, __int_as_float(r));
+        unsigned *bx = s_box + (slot >> 6) * 6;
+        atomicMin(&bx[0], f32_ordered(x)); atomicMin(&bx[1], f32_ordered(y)); atomicMin(&bx[2], f32_ordered(z));
+        atomicMax(&bx[3], f32_ordered(x)); atomicMax(&bx[4], f32_ordered(y)); atomicMax(&bx[5], f32_ordered(z));
+      }
+      __syncthreads();
+      for (int g = tid; g < NGs; g += T) {
+        float *o = oo.gbox_s + ((size_t)b * NGs + g) * 8;
+        const unsigned *bx = s_box + g * 6;
+        o[0] = f32_unordered(bx[0]); o[1] = f32_unordered(bx[1]); o[2] = f32_unordered(bx[2]); o[3] = 0.f;
+        o[4] = f32_unordered(bx[3]); o[5] = f32_unordered(bx[4]); o[6] = f32_unordered(bx[5]); o[7] = 0.f;
+      }
+    }
+  }
 }
 
 template <int PPT, int WAVES>
 int fps_list_launch(const float *sorted, const float *gbox, int B, int N, int m, int32_t *out, float *xyz_out,
-                    const float *xyz, hipStream_t s) {
+                    const float *xyz, const FpsOrderedOut &oo, hipStream_t s) {
   const size_t small = sizeof(float) * (4 * 32 + 2 * 64 + 16 + 4 + (size_t)m);
-  const size_t lds = small + sizeof(float) * (size_t)3 * N;
+  // (ordered output: picks per sorted position [N + 1] u32, original index -> position [N] u16, boxes [m / 64][6] u32)
+  const size_t ordered = oo.sorted_s ? sizeof(unsigned) * ((size_t)N + 1) + sizeof(unsigned short) * (((size_t)N + 1) & ~(size_t)1) +
+                                           sizeof(unsigned) * 6 * (((size_t)m + 63) / 64) : 0;
+  const size_t lds = small + sizeof(float) * (size_t)3 * N + ordered;
   // The workgroup asks for the WHOLE CU's LDS whatever it needs: this kernel is the step's latency chain (one CU per
   // cloud, every instruction of the judge's chain counts), and a workgroup of another kernel that lands beside it takes
   // issue slots from its sixteen waves.  Same box, steps in flight: local 30.85 k -> 31.17 k clouds/s, one step at a time
@@ -467,12 +573,13 @@ int fps_list_launch(const float *sorted, const float *gbox, int B, int N, int m,
   if (lds <= whole_cu) {
     DH3D_ALLOW_BIG_LDS((fps_list_kernel<PPT, WAVES, true>));
     hipLaunchKernelGGL((fps_list_kernel<PPT, WAVES, true>), dim3(B), dim3(64 * WAVES), whole_cu, s,
-                       reinterpret_cast<const float4 *>(sorted), gbox, N, m, out, xyz_out, nullptr);
+                       reinterpret_cast<const float4 *>(sorted), gbox, N, m, out, xyz_out, nullptr, oo);
   } else {
+    if (oo.sorted_s) return DH3D_ERR_UNSUPPORTED;  // the ordered output lives beside the LDS coordinate table
     if (!xyz || small > whole_cu) return DH3D_ERR_UNSUPPORTED;  // no LDS table: the cloud itself is needed
     DH3D_ALLOW_BIG_LDS((fps_list_kernel<PPT, WAVES, false>));
     hipLaunchKernelGGL((fps_list_kernel<PPT, WAVES, false>), dim3(B), dim3(64 * WAVES), whole_cu, s,
-                       reinterpret_cast<const float4 *>(sorted), gbox, N, m, out, xyz_out, xyz);
+                       reinterpret_cast<const float4 *>(sorted), gbox, N, m, out, xyz_out, xyz, oo);
   }
   return dh3d_launch_status();
 }
@@ -569,17 +676,17 @@ DH3D_API int dh3d_farthest_point_sample(int B, int N, int m, const float *inp, f
 }
 
 static int fps_sorted_dispatch(const float *sorted, const float *gbox, int B, int N, int m, int32_t *out,
-                               float *xyz_out, const float *xyz, void *stream) {
+                               float *xyz_out, const float *xyz, void *stream, const FpsOrderedOut &oo = FpsOrderedOut{}) {
   DH3D_REQUIRE(sorted && gbox && out && B > 0 && N > 0 && m > 0);
   // the by-original-index coordinate table must fit LDS (12 B / point) unless the cloud itself is given
   DH3D_SUPPORTED(N <= 12288 || (xyz && N <= 16384));
   hipStream_t s = (hipStream_t)stream;
   const int gpw = ((N + 63) / 64 + 15) / 16;  // groups per wave, 16 waves per cloud
-  if (gpw <= 1) return fps_list_launch<1, 16>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);
-  if (gpw <= 2) return fps_list_launch<2, 16>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);
-  if (gpw <= 4) return fps_list_launch<4, 16>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);
-  if (gpw <= 8) return fps_list_launch<8, 16>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);
-  return fps_list_launch<16, 16>(sorted, gbox, B, N, m, out, xyz_out, xyz, s);
+  if (gpw <= 1) return fps_list_launch<1, 16>(sorted, gbox, B, N, m, out, xyz_out, xyz, oo, s);
+  if (gpw <= 2) return fps_list_launch<2, 16>(sorted, gbox, B, N, m, out, xyz_out, xyz, oo, s);
+  if (gpw <= 4) return fps_list_launch<4, 16>(sorted, gbox, B, N, m, out, xyz_out, xyz, oo, s);
+  if (gpw <= 8) return fps_list_launch<8, 16>(sorted, gbox, B, N, m, out, xyz_out, xyz, oo, s);
+  return fps_list_launch<16, 16>(sorted, gbox, B, N, m, out, xyz_out, xyz, oo, s);
 }
 
 DH3D_API int dh3d_fps_sorted(const float *sorted, const float *gbox, int B, int N, int m, int32_t *out,
@@ -601,6 +708,26 @@ DH3D_API int dh3d_fps_sorted_cloud(const float *sorted, const float *gbox, const
                                    int32_t *out, float *xyz_out, void *stream) {
   DH3D_REQUIRE(xyz);
   return fps_sorted_dispatch(sorted, gbox, B, N, m, out, xyz_out, xyz, stream);
+}
+
+// dh3d_fps_sorted_xyz + the SAMPLED SET IN MORTON ORDER out of the same kernel: sorted_s [B, m, 4] records (x, y, z,
+// bits(pick rank)), gbox_s [B, ceil(m / 64), 8], and -- when the cloud's cell table `cells` (dh3d_spatial_sort_cells) is
+// given -- cells_s [B, DH3D_CELL_INTS], the subset's table on the cloud's grid: what dh3d_spatial_sort_cells of xyz_out
+// would hand to dh3d_three_nn_sorted / dh3d_knn_grid (a valid order + boxes + table, not the identical arrays: the subset
+// inherits the cloud's grid and the cloud's order inside a cell).  N <= 8192 (the tail's tables live beside the LDS
+// coordinate table); larger clouds: DH3D_ERR_UNSUPPORTED, sort xyz_out instead.
+DH3D_API int dh3d_fps_sorted_ordered(const float *sorted, const float *gbox, const int32_t *cells, int B, int N, int m,
+                                     int32_t *out, float *xyz_out, float *sorted_s, float *gbox_s, int32_t *cells_s,
+                                     void *stream) {
+  DH3D_REQUIRE(xyz_out && sorted_s && gbox_s && ((cells == nullptr) == (cells_s == nullptr)));
+  DH3D_SUPPORTED(N <= 8192 && N < 65536);
+  FpsOrderedOut oo;
+  oo.sorted_s = reinterpret_cast<float4 *>(sorted_s);
+  oo.gbox_s = gbox_s;
+  oo.cells = cells;
+  oo.cells_s = cells_s;
+  oo.occ_min = (int)(0.6 * 4096.0 * (1.0 - exp(-(double)m / 4096.0)));  // spatial.hip sort_launch's rule for m points
+  return fps_sorted_dispatch(sorted, gbox, B, N, m, out, xyz_out, nullptr, stream, oo);
 }
 
 #ifdef DH3D_FPS_PROBE

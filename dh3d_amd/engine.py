@@ -9,6 +9,7 @@ exactly that graph, so a slot's outputs are bit-equal to the serial forward of t
 
     pipe = model.pipeline(example_points, depth=4, outputs=("xyz_feat",))
     t = pipe.submit(batch)            # copies `batch` into the slot's input buffer and replays the slot's graph
+                                      # (a pinned HOST batch: async H2D on the slot's own stream; fetch_to=: D2H behind it)
     ...                               # up to depth-1 further submits before the slot is reused
     outs = pipe.result(t)             # the CURRENT stream waits for that step; dict of the slot's static buffers
 
@@ -51,7 +52,9 @@ class Pipeline:
         finally:
             model.steps_in_flight = hint
         self._version = model.weights_version
-        self._events = [torch.cuda.Event() for _ in range(self.depth)]
+        # one event per step of the last TWO rounds over the slots: a ticket's event is not re-recorded until 2 * depth
+        # further submits, so a host-side consumer may lag a whole round behind the submitting loop without blocking it
+        self._events = [torch.cuda.Event() for _ in range(2 * self.depth)]
         self._consumed = [None] * self.depth  # event after which slot k's buffers may be overwritten
         self._seq = 0
         cur = torch.cuda.current_stream(dev)
@@ -79,21 +82,32 @@ class Pipeline:
         return self._seq % self.depth
 
     # ------------------------------------------------------------------ steps
-    def submit(self, points=None, knn_inds=None, after_current=None):
+    def submit(self, points=None, knn_inds=None, after_current=None, fetch_to=None):
         """Enqueue one full forward on the next slot.  `points` (optional) is copied into the slot's input buffer on the
         slot's stream, after the caller's stream has reached this point (so a batch produced on the current stream is
         complete) and after the previous consumer of this slot's outputs (result()) is done with them.
 
+        HOST batches (the serving loop: localdesc_extract.py:106-138, globaldesc_extract.py:84-100 feed numpy arrays): a
+        pinned CPU tensor is read by a staging kernel (dh3d_stage_copy) ON THE SLOT'S STREAM in front of the replay --
+        nothing on the device produced it, so the slot's stream is NOT ordered behind the current one (no event record +
+        wait per submit), and no copy engine sits on the step's chain (hipMemcpyAsync H2D on the slot's stream: 0.246 ->
+        0.407 ms per step of the local pipeline, tools/streaming_probe.py).  The caller keeps the pinned buffer
+        untouched until the step's ticket has completed.
+        `fetch_to` ({output name: pinned CPU tensor or device tensor}) appends the copies of those outputs on the same
+        stream (same kernel), in front of the ticket's event: `ticket.event.synchronize()` then means "the descriptors
+        are in host memory".
+
         Zero-copy (no `points`): the batch must already be in `input_buffer(slot)`, written ON `stream(slot)` -- or on
         the current stream with `after_current=True`, which orders the slot's stream behind the current one first (an
         event record + wait per submit: measured 31.1 k -> 26.4 k clouds/s on the local workload four deep, which is why
-        it is not the default for the zero-copy path).  With `points` given the order is always established."""
+        it is not the default for the zero-copy path).  With DEVICE `points` given the order is always established."""
         if self.model.weights_version != self._version:
             raise RuntimeError("the model's weights changed (optimiser step / invalidate / load_state_dict) after this "
                                "pipeline was captured: build a new one")
         k = self._seq % self.depth
         run, st = self._runs[k], self._streams[k]
-        if after_current or (after_current is None and (points is not None or knn_inds is not None)):
+        from_device = any(t is not None and t.is_cuda for t in (points, knn_inds))
+        if after_current or (after_current is None and from_device):
             st.wait_stream(torch.cuda.current_stream(run.static_input.device))
         # the copies below run on the slot's stream: tell the caching allocator, or a caller that drops `points`
         # right after submit() may see its block handed out again (on ITS stream) before the copy has read it
@@ -104,9 +118,19 @@ class Pipeline:
             st.wait_event(self._consumed[k])
             self._consumed[k] = None
         with torch.cuda.stream(st):
-            run(points, knn_inds)
-            self._events[k].record(st)
-        t = Ticket(k, self._events[k], self._seq)
+            outs = run(points, knn_inds)
+            if fetch_to:
+                from . import pm
+                for name, dst in fetch_to.items():
+                    src = outs[name]
+                    if (not dst.is_cuda and dst.is_pinned() and dst.is_contiguous() and src.is_contiguous()
+                            and dst.dtype == src.dtype and dst.numel() == src.numel()):
+                        pm.stage_copy(src, dst)   # a kernel on this stream: pinned host memory is written over the link
+                    else:
+                        dst.copy_(src, non_blocking=True)
+            ev = self._events[self._seq % (2 * self.depth)]
+            ev.record(st)
+        t = Ticket(k, ev, self._seq)
         self._seq += 1
         return t
 
@@ -135,19 +159,35 @@ class Pipeline:
             cur.wait_stream(st)
 
     def map(self, batches, clone=True):
-        """Run an iterable of batches `depth` deep and yield their output dicts in order (cloned by default: a slot's
-        buffers are overwritten `depth` steps later)."""
+        """Run an iterable of batches (device tensors or pinned host tensors) `depth` deep and yield their output dicts in
+        order.  clone=True (default): every step's outputs are copied out of the slot's buffers ON THE SLOT'S STREAM right
+        behind the replay (a slot's buffers are overwritten `depth` steps later), and the current stream waits for that
+        step's event before the dict is yielded -- one cross-stream dependency per step.  clone=False yields the slot's
+        static buffers themselves (valid until `depth` further submits) and orders the slot's next step behind the
+        current stream's position at the time the NEXT item is requested (release)."""
         tickets = []
         for b in batches:
             if len(tickets) == self.depth:
-                yield self._take(tickets.pop(0), clone)
-            tickets.append(self.submit(b))
+                yield from self._take(*tickets.pop(0), clone)
+            tickets.append(self._submit_for_map(b, clone))
         while tickets:
-            yield self._take(tickets.pop(0), clone)
+            yield from self._take(*tickets.pop(0), clone)
 
-    def _take(self, ticket, clone):
-        outs = self.result(ticket, wait="stream")
-        if clone:
-            outs = {k: v.clone() for k, v in outs.items()}
-        self.release(ticket)
-        return outs
+    def _submit_for_map(self, b, clone):
+        if not clone:
+            return self.submit(b), None
+        k = self.next_slot
+        with torch.cuda.stream(self._streams[k]):   # (allocated on the slot's stream: the copy below is their first use)
+            copies = {name: torch.empty_like(v) for name, v in self._runs[k].outputs.items()}
+        return self.submit(b, fetch_to=copies), copies
+
+    def _take(self, ticket, copies, clone):
+        cur = torch.cuda.current_stream()
+        if not clone:
+            yield self.result(ticket, wait="stream")
+            self.release(ticket)   # (runs when the consumer asks for the next item: its reads are enqueued by then)
+            return
+        cur.wait_event(ticket.event)
+        for v in copies.values():
+            v.record_stream(cur)   # handed from the slot's stream to the consumer's
+        yield copies

@@ -32,6 +32,15 @@ def tf_variable_name(state_dict_key):
 KNN_GRID = pm.KNN_GRID
 
 
+def _copy_in(src, dst):
+    """dst (a graph's static input) <- src: device tensors by copy_, pinned host tensors by the staging kernel."""
+    if (not src.is_cuda and src.is_pinned() and src.is_contiguous() and src.dtype == dst.dtype
+            and src.numel() == dst.numel()):
+        pm.stage_copy(src, dst)
+    else:
+        dst.copy_(src, non_blocking=True)
+
+
 # Development A/B knobs (tools/single_stream_ab.py, the placement-hint sweeps): read only when DH3D_DEBUG_KNOBS=1, so a
 # production process cannot pick one up from a stray environment variable.
 _DEBUG_KNOBS = os.environ.get("DH3D_DEBUG_KNOBS") == "1"
@@ -543,10 +552,12 @@ class DH3D(nn.Module):
             if self.weights_version != version:
                 raise RuntimeError("the model's weights changed (optimiser step / invalidate / load_state_dict) after this "
                                    "forward was captured: the graph holds packed copies of the old ones -- capture again")
+            # (a pinned HOST batch is read by a staging KERNEL on the current stream, in front of the replay -- no copy
+            # engine on the step's chain; engine.Pipeline.submit hands host batches over this way)
             if points is not None and points is not static_in:
-                static_in.copy_(points)
+                _copy_in(points, static_in)
             if static_knn is not None and knn_inds is not None and knn_inds is not static_knn:
-                static_knn.copy_(knn_inds)
+                _copy_in(knn_inds, static_knn)
             graph.replay()
             return outs
 

@@ -95,6 +95,23 @@ def fps_sorted(srt, gbox, npoint, with_xyz=False, xyz=None):
     return (out, xyz_s) if with_xyz else out
 
 
+def fps_sorted_ordered(srt, gbox, npoint, cells=None):
+    """fps_sorted(with_xyz=True) + the sampled set in the cloud's Morton order out of the same launch: returns
+    (idx [B,m], xyz_s [B,m,3], srt_s [B,m,4], gbox_s [B,ceil(m/64),8], cells_s [B,CELL_INTS] or None) -- srt_s / gbox_s /
+    cells_s are what spatial_sort_cells(xyz_s) would hand to three_nn_sorted / knn_grid (cells_s only when the cloud's
+    own table `cells` is given).  N <= 8192."""
+    B, N, _ = srt.shape
+    dev = srt.device
+    out = torch.empty((B, npoint), dtype=torch.int32, device=dev)
+    xyz_s = torch.empty((B, npoint, 3), dtype=torch.float32, device=dev)
+    srt_s = torch.empty((B, npoint, 4), dtype=torch.float32, device=dev)
+    gbox_s = torch.empty((B, (npoint + 63) // 64, 8), dtype=torch.float32, device=dev)
+    cells_s = torch.empty((B, CELL_INTS), dtype=torch.int32, device=dev) if cells is not None else None
+    L.check(L.lib().dh3d_fps_sorted_ordered(L.ptr(srt), L.ptr(gbox), L.ptr(cells), B, N, npoint, L.ptr(out), L.ptr(xyz_s),
+                                            L.ptr(srt_s), L.ptr(gbox_s), L.ptr(cells_s), L.stream_ptr()), "fps_sorted_ordered")
+    return out, xyz_s, srt_s, gbox_s, cells_s
+
+
 def three_nn_sorted(srt1, gbox1, srt2, gbox2):
     """three_nn from spatial_sort() outputs of the query cloud and of the candidate set: same (dist [B,n,3] squared,
     idx [B,n,3]) as ops.three_nn, original indexing on both sides."""
@@ -767,6 +784,22 @@ def gemm_nn(A, B, out=None, accumulate=False, bias=None):
     L.check(L.lib().dh3d_gemm_nn_f32(L.ptr(A), L.ptr(B), L.ptr(bias), M, K, N, 1 if accumulate else 0, L.ptr(C),
                                      L.stream_ptr()), "gemm_nn")
     return C
+
+
+def stage_copy(src, dst):
+    """dst <- src on the current stream by a kernel (dh3d_stage_copy): each side a contiguous CUDA tensor or a contiguous
+    PINNED CPU tensor (device-addressable), same byte count.  The serving loop's host <-> slot-buffer hand-over
+    (engine.Pipeline.submit): no copy engine, no engine-to-engine dependency on the step's chain."""
+    for t, nm in ((src, "src"), (dst, "dst")):
+        if not (t.is_cuda or t.is_pinned()):
+            raise ValueError("stage_copy: %s must be a CUDA tensor or a pinned CPU tensor" % nm)
+        if not t.is_contiguous():
+            raise ValueError("stage_copy: %s must be contiguous" % nm)
+    nbytes = src.numel() * src.element_size()
+    if nbytes != dst.numel() * dst.element_size():
+        raise ValueError("stage_copy: %d bytes into %d" % (nbytes, dst.numel() * dst.element_size()))
+    L.check(L.lib().dh3d_stage_copy(src.data_ptr(), dst.data_ptr(), nbytes, L.stream_ptr()), "stage_copy")
+    return dst
 
 
 def transpose_last2(x):

@@ -60,6 +60,13 @@ const char *dh3d_arch(void);            /* "gfx950" */
 const char *dh3d_source_hash(void);
 const char *dh3d_status_string(int st); /* static string */
 
+/* Staging copy on the given stream by a KERNEL (not a copy engine): `src` / `dst` are device pointers or PINNED host
+ * pointers (device-addressable: hipHostMalloc / torch pin_memory), 16-byte aligned.  For the serving loop around the hot
+ * path (the reference feeds numpy arrays and saves numpy arrays: localdesc_extract.py:106-138, globaldesc_extract.py:84-100):
+ * the batch goes host -> slot buffer and the descriptors slot buffer -> host on the SAME compute queue as the step, so no
+ * engine-to-engine hand-over sits on the step's chain.  No reference counterpart (TF's feed_dict / fetches). */
+int dh3d_stage_copy(const void *src, void *dst, size_t bytes, void *stream);
+
 /* ===================================================================================== *
  * A. Drop-in operators (reference layouts)
  * ===================================================================================== */
@@ -278,6 +285,14 @@ int dh3d_fps_sorted(const float *sorted, const float *gbox, int B, int N, int m,
 /* the same + xyz_out [B,m,3] = the sampled coordinates (group_point of the cloud by `out`, core/tf_utils.py:92-95) */
 int dh3d_fps_sorted_xyz(const float *sorted, const float *gbox, int B, int N, int m, int32_t *out, float *xyz_out,
                         void *stream);
+/* the same + the SAMPLED SET IN MORTON ORDER out of the same launch (round 6): sorted_s [B,m,4] records (x, y, z, bits(pick
+ * rank)), gbox_s [B, ceil(m/64), 8], and -- when `cells`, the cloud's table from dh3d_spatial_sort_cells, is given (else both
+ * NULL) -- cells_s [B, DH3D_CELL_INTS]: the subset's cell table on the CLOUD's grid (same origin / scales / schedule header,
+ * its own crowded verdict).  The picks are a subset of a sorted cloud, so a stable compaction of the picked positions is their
+ * spatial order: these are valid inputs for dh3d_three_nn_sorted (candidate side) and dh3d_knn_grid / dh3d_knn_sorted on
+ * the sampled set, without dh3d_spatial_sort_cells(xyz_out) on the chain behind the sampling.  N <= 8192. */
+int dh3d_fps_sorted_ordered(const float *sorted, const float *gbox, const int32_t *cells, int B, int N, int m, int32_t *out,
+                            float *xyz_out, float *sorted_s, float *gbox_s, int32_t *cells_s, void *stream);
 /* Same with the cloud itself (xyz [B,N,3], what dh3d_spatial_sort was given): clouds of up to 16384 points (above
  * 12288 the by-index coordinate table no longer fits the LDS and the kernel reads winners from xyz).  xyz_out may be NULL. */
 int dh3d_fps_sorted_cloud(const float *sorted, const float *gbox, const float *xyz, int B, int N, int m, int32_t *out,

@@ -216,3 +216,33 @@ def test_submit_copies_a_batch_the_caller_drops_at_once(dev):
     torch.cuda.synchronize()
     for g, e in zip(got, exp):
         assert torch.equal(g, e)
+
+
+def test_submit_host_batches_h2d_and_d2h_on_the_slot_stream(dev):
+    """The serving loop (localdesc_extract.py:106-138 / globaldesc_extract.py:84-100 feed host arrays and save host arrays):
+    pinned HOST batches go in through submit(host_batch) -- an asynchronous H2D copy on the slot's own stream, no ordering
+    behind the caller's stream -- and `fetch_to` brings the descriptors back into pinned host memory on the same stream;
+    ticket.event.synchronize() = "the descriptors are in host memory".  Every step against the serial forward of its batch."""
+    m = _build("global_config", dev, seed=43)
+    B, N, depth = 4, 4096, 3
+    rng = np.random.default_rng(4300)
+    host_in = [torch.from_numpy(rng.random((B, N, 3), dtype=np.float32)).pin_memory() for _ in range(2 * depth + 1)]
+    with torch.no_grad():
+        serial = [m(h.to(dev), fetch=("globaldesc",))["globaldesc"].cpu() for h in host_in]
+        pipe = m.pipeline(host_in[0].to(dev), depth=depth, outputs=("globaldesc",))
+        host_out = [torch.empty((B, 256), dtype=torch.float32).pin_memory() for _ in range(depth)]
+        tickets, got = [], []
+        for i, h in enumerate(host_in):
+            if len(tickets) == depth:
+                tk = tickets.pop(0)
+                tk.event.synchronize()
+                got.append(host_out[tk.slot].clone())
+            k = pipe.next_slot
+            tickets.append(pipe.submit(h, fetch_to={"globaldesc": host_out[k]}))
+        for tk in tickets:
+            tk.event.synchronize()
+            got.append(host_out[tk.slot].clone())
+    assert len(got) == len(serial)
+    for i, (g, s) in enumerate(zip(got, serial)):
+        # (the global tail sums A'^T c and the split-K projection with f32 atomics: run-to-run rounding, not bit-equal)
+        assert float((g - s).abs().max()) <= 2e-6, (i, (g - s).abs().max().item())
