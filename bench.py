@@ -811,6 +811,8 @@ def compact_line(full, extras_path=None, limit=LINE_LIMIT):
             c["what"] = str(v["what"])[:160]
         if isinstance(v.get("d2h_inclusive"), dict):
             c["d2h_inclusive"] = {k: v["d2h_inclusive"].get(k) for k in ("value", "GBps_d2h")}
+        if isinstance(v.get("steady_state"), dict):
+            c["steady_state"] = {k: v["steady_state"].get(k) for k in ("steps", "value", "ratio_to_resident")}
         if "error" in v:
             c["error"] = str(v["error"])[:160]
         out["value_streaming"] = c
@@ -819,6 +821,8 @@ def compact_line(full, extras_path=None, limit=LINE_LIMIT):
         c = {k: g.get(k) for k in ("workload", "value", "ms_per_step", "steps_in_flight", "clouds_per_gpu", "points") if k in g}
         if isinstance(g.get("value_streaming"), dict):
             c["value_streaming"] = {k: g["value_streaming"].get(k) for k in ("value", "ms_per_step")}
+            if isinstance(g["value_streaming"].get("steady_state"), dict):
+                c["value_streaming"]["steady_state_ratio"] = g["value_streaming"]["steady_state"].get("ratio_to_resident")
         if isinstance(g.get("one_step_at_a_time"), dict):
             c["one_step_at_a_time"] = {"value": g["one_step_at_a_time"].get("value"),
                                        "ms_per_step": g["one_step_at_a_time"].get("ms_per_step")}
@@ -831,7 +835,8 @@ def compact_line(full, extras_path=None, limit=LINE_LIMIT):
     # never over the limit: shed the optional blocks, least important first (none of these fire on today's record)
     for k in ("global_scaling.note", "roofline.traffic_source", "cpu_baseline.sample", "config.execution",
               "config.weights", "config.parallelism", "phases_ms", "global_scaling", "cpu_baseline.all_cores",
-              "value_streaming.what", "value_streaming.d2h_inclusive", "value_streaming", "global.workload", "global"):
+              "value_streaming.what", "value_streaming.d2h_inclusive", "value_streaming.steady_state", "value_streaming",
+              "global.workload", "global"):
         if len(text.encode()) <= limit:
             break
         head, _, leaf = k.partition(".")
@@ -1171,32 +1176,50 @@ def main():
                 for tk in tickets:
                     tk.event.synchronize()
 
-        def timed(d2h):
+        def timed(d2h, n=None):
+            n = n or nsteps
             loop(max(args.warmup, depth), d2h)
             torch.cuda.synchronize()
             D.barrier()
             t0 = time.perf_counter()
-            loop(nsteps, d2h)
+            loop(n, d2h)
             torch.cuda.synchronize()
             D.barrier()
             return time.perf_counter() - t0
+
+        def zero_copy_long(n):   # the resident-batch loop of `value` over the same long run, for the steady-state ratio
+            for _ in range(depth):
+                pipe.submit()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                pipe.submit()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
         rec = {"steps_in_flight": depth, "distinct_host_batches": nb, "h2d_bytes_per_step": per * wl["N"] * 12,
                "output_bytes_per_step": out_bytes}
+        long_n = 10 * nsteps
         if small:
             dt = timed(True)
             rec.update({"value": total * nsteps / dt, "ms_per_step": dt / nsteps * 1e3,
                         "what": "pinned host batch -> H2D on the slot's stream -> step -> D2H of `%s` into pinned host memory "
                                 "on the slot's stream; the host picks results up one round (2 x depth buffers) behind the submitting loop" % name})
+            dl, dz = timed(True, long_n), zero_copy_long(long_n)
         else:
             dt = timed(False)
             rec.update({"value": total * nsteps / dt, "ms_per_step": dt / nsteps * 1e3,
                         "what": "pinned host batch -> H2D on the slot's stream -> step -> `%s` copied out of the slot's buffers "
                                 "into the consumer's device buffer on the slot's stream" % name})
+            dl, dz = timed(False, long_n), zero_copy_long(long_n)
             dt2 = timed(True)
             rec["d2h_inclusive"] = {"value": total * nsteps / dt2, "ms_per_step": dt2 / nsteps * 1e3,
                                     "GBps_d2h": out_bytes * nsteps / dt2 / 1e9,
                                     "note": "the dense map copied to pinned host memory every step: bound by the host link, "
                                             "not by the path (never `value`)"}
+        # K = 20 steps through a pipeline `depth` deep weigh its fill and drain, where the staging copies' latency shows; over
+        # 10 K steps: the same loop against the resident-batch loop of `value`
+        rec["steady_state"] = {"steps": long_n, "value": total * long_n / dl, "ms_per_step": dl / long_n * 1e3,
+                               "resident_batches_ms_per_step": dz / long_n * 1e3, "ratio_to_resident": dz / dl}
         return rec
 
     pipelined = args.inflight > 1 and args.workload not in ("train", "train_local")

@@ -37,7 +37,7 @@ _SIGNATURES = {
     "dh3d_arch": [],
     "dh3d_source_hash": [],
     "dh3d_status_string": [c_int],
-    "dh3d_stage_copy": [c_fp, c_fp, c_size_t, c_fp],
+    "dh3d_stage_copy": [c_fp, c_fp, c_size_t, c_int, c_fp],
     "dh3d_knn_bruteforce": [c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp],
     "dh3d_knn_bruteforce_xyz": [c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp],
     "dh3d_flex_conv_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp],

@@ -159,14 +159,18 @@ class Conv2D1x1(nn.Module):
         return pm.interp_combine(cw, idx, dist, partial, pre_bias=p["b"], scale=p["scale"], shift=p["shift"], act=act,
                                  residual=residual, l2cat=l2cat)
 
-    def tail_fusable(self, shortcut_conv, n):
+    def tail_fusable(self, shortcut_conv, n, in_flight=False):
         """forward_commuted_fused available: this (commuted) concat conv and the caller's shortcut conv are both
-        64 -> 128 on full-resolution rows of n points per cloud.  Rule on the points per cloud only, never the batch:
-        clouds of up to 4096 points (where the tail is the step's critical chain and the one-launch form replaces the
-        K = 256 GEMM with the up-sampling fused into its staging: global serial -20 us) take it by default, larger
-        clouds (where its two GEMMs would leave the slack beside the sampling chain) with DH3D_TAIL_FUSED=1 only."""
+        64 -> 128 on full-resolution rows of n points per cloud.  Clouds of up to 4096 points (where the tail is the
+        step's critical chain and the one-launch form replaces the K = 256 GEMM with the up-sampling fused into its
+        staging: global serial -20 us) take it.  Larger clouds by the ENGINE'S MODE, like three_nn's placement
+        (DH3D._three_nn_before_sampled_level): one step at a time the two GEMMs are free beside the sampling chain and
+        the one-launch tail only lengthens the chain behind it (0.4747 -> 0.4801 ms); with steps in flight that slack
+        belongs to the other steps' kernels and 25 us of chip time + 130 MB of traffic less per step win (four in flight
+        0.2388 -> 0.2292 ms, round 6; placement only, same values).  DH3D_TAIL_FUSED=0 / 1 forces it off / on."""
         p, q = self._prep or self.prepare(), shortcut_conv._prep or shortcut_conv.prepare()
-        return ((TAIL_FUSED if n > 4096 else TAIL_FUSED_SMALL) and self.cout == 128 and p.get("c_top") == 128
+        big = in_flight if TAIL_FUSED is None else TAIL_FUSED
+        return ((big if n > 4096 else TAIL_FUSED_SMALL) and self.cout == 128 and p.get("c_top") == 128
                 and self.cin - 128 == 64 and "wp3_bot" in p and shortcut_conv.cin == 64 and shortcut_conv.cout == 128
                 and "wp3" in q and n % 32 == 0 and n >= 1024)
 
@@ -340,11 +344,11 @@ def gather_rows(points, idx):
 SE_TAILS = os.environ.get("DH3D_SE_TAILS", "0") == "1"
 # dev A/B switch (DH3D_FLEX_TX6=0: the exact-f32 MFMA tile kernel for the sampled levels)
 FLEX_TX6 = os.environ.get("DH3D_FLEX_TX6", "1") != "0"
-# dev A/B switch (DH3D_TAIL_FUSED=1: the local step's tail -- shortcut conv, the concat conv's lower block, up-sampling,
-# epilogue, l2-normalised rows -- as ONE launch, csrc/dense_tail.hip.  Measured: 27.5 us instead of 52 us of kernels and
-# 130 MB less HBM traffic per step, but the two GEMMs move from beside the sampling chain to behind it: one step at a
-# time 0.500 -> 0.507 ms, four in flight 0.252 vs 0.252-0.261 -- DEADENDS.md -- so off by default; the kernel stays tested)
-TAIL_FUSED = os.environ.get("DH3D_TAIL_FUSED", "0") == "1"
+# dev A/B switch (DH3D_TAIL_FUSED=0 / 1: the local step's tail -- shortcut conv, the concat conv's lower block, up-sampling,
+# epilogue, l2-normalised rows -- as ONE launch, csrc/dense_tail.hip, never / always for clouds of more than 4096 points.
+# 27.5 us instead of 52 us of kernels and 130 MB less HBM traffic per step, but the two GEMMs move from beside the sampling
+# chain to behind it.  Unset: with steps in flight only -- Conv2D1x1.tail_fusable)
+TAIL_FUSED = {"0": False, "1": True}.get(os.environ.get("DH3D_TAIL_FUSED", ""))   # None: by the engine's mode
 # (DH3D_TAIL_FUSED_SMALL=0: clouds of <= 4096 points back on the K = 256 GEMM with the fused up-sampling + shortcut)
 TAIL_FUSED_SMALL = os.environ.get("DH3D_TAIL_FUSED_SMALL", "1") != "0"
 

@@ -14,14 +14,16 @@ __global__ __launch_bounds__(256) void stage_copy_kernel(const uint4 *__restrict
 }
 }  // namespace
 
-DH3D_API int dh3d_stage_copy(const void *src, void *dst, size_t bytes, void *stream) {
+DH3D_API int dh3d_stage_copy(const void *src, void *dst, size_t bytes, int device_to_device, void *stream) {
   DH3D_REQUIRE(src && dst && bytes > 0);
   DH3D_SUPPORTED((reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0);
   const size_t n16 = bytes / 16;
   const int ntail = (int)(bytes - n16 * 16);
-  // a few CUs are enough to keep a host link busy (and all a copy should take from the steps in flight)
-  const size_t want = (n16 + 255) / 256;
-  const int blocks = (int)(want < 1 ? 1 : (want > 64 ? 64 : want));
+  // a few CUs are enough to keep a host link busy (and all a copy should take from the steps in flight); a copy between
+  // two device buffers (a consumer's own buffer for a slot's outputs) gets four 16-byte words per thread on up to 2048 blocks
+  const size_t want = device_to_device ? (n16 + 1023) / 1024 : (n16 + 255) / 256;
+  const size_t cap = device_to_device ? 2048 : 64;
+  const int blocks = (int)(want < 1 ? 1 : (want > cap ? cap : want));
   hipLaunchKernelGGL(stage_copy_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, static_cast<const uint4 *>(src),
                      static_cast<uint4 *>(dst), n16, static_cast<const unsigned char *>(src) + n16 * 16,
                      static_cast<unsigned char *>(dst) + n16 * 16, ntail);

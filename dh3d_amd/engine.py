@@ -4,8 +4,9 @@ One forward of this path leaves most of the chip idle -- farthest point sampling
 of the step -- so a server that has the next batch ready overlaps consecutive batches: batch i runs on
 slot i % depth while the previous depth-1 batches are still in their latency-bound phases.  The reference has no
 counterpart (a TF session runs one `sess.run` at a time, core/model.py:135-210 builds one graph); every slot computes
-exactly that graph, so a slot's outputs are bit-equal to the serial forward of the same batch
-(tests/test_engine_gpu.py).
+exactly that graph: a slot's index outputs (kNN, FPS, three_nn) are bit-equal to the serial forward of the same batch
+and its descriptors agree within 2e-6 (with steps in flight the model places three_nn differently and runs the local
+tail as one launch -- the same products in another association; tests/test_engine_gpu.py).
 
     pipe = model.pipeline(example_points, depth=4, outputs=("xyz_feat",))
     t = pipe.submit(batch)            # copies `batch` into the slot's input buffer and replays the slot's graph
@@ -123,9 +124,12 @@ class Pipeline:
                 from . import pm
                 for name, dst in fetch_to.items():
                     src = outs[name]
-                    if (not dst.is_cuda and dst.is_pinned() and dst.is_contiguous() and src.is_contiguous()
+                    if ((dst.is_cuda or dst.is_pinned()) and dst.is_contiguous() and src.is_contiguous()
                             and dst.dtype == src.dtype and dst.numel() == src.numel()):
-                        pm.stage_copy(src, dst)   # a kernel on this stream: pinned host memory is written over the link
+                        # a kernel on this stream (pinned host memory is written over the link).  Also for a device
+                        # destination: behind a host batch's staging kernel a tensor copy_ of the 34 MB local map on the
+                        # same stream took the step from 0.25 to 4.6 ms (bench.py value_streaming, round 6)
+                        pm.stage_copy(src, dst)
                     else:
                         dst.copy_(src, non_blocking=True)
             ev = self._events[self._seq % (2 * self.depth)]

@@ -363,7 +363,8 @@ class DH3D(nn.Module):
             small = points.shape[1] <= 4096
             fused_tail = ((_l2cat_eps is not None or small) and shortcut is None and lower is None and cconv is not None
                           and self._local.featdim == 128 and cconv.commuted_supported(128)
-                          and cconv.tail_fusable(self.local_stage1_shortcut.tfconv0, points.shape[1]))
+                          and cconv.tail_fusable(self.local_stage1_shortcut.tfconv0, points.shape[1],
+                                                 in_flight=getattr(self, "steps_in_flight", 1) > 1))
             if fused_tail:
                 fuse_sc = False   # (the one-launch tail replaces the K = 256 GEMM with the shortcut fused into it)
             if shortcut is None and not fuse_sc and not fused_tail:

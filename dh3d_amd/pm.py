@@ -798,7 +798,8 @@ def stage_copy(src, dst):
     nbytes = src.numel() * src.element_size()
     if nbytes != dst.numel() * dst.element_size():
         raise ValueError("stage_copy: %d bytes into %d" % (nbytes, dst.numel() * dst.element_size()))
-    L.check(L.lib().dh3d_stage_copy(src.data_ptr(), dst.data_ptr(), nbytes, L.stream_ptr()), "stage_copy")
+    L.check(L.lib().dh3d_stage_copy(src.data_ptr(), dst.data_ptr(), nbytes, int(src.is_cuda and dst.is_cuda),
+                                    L.stream_ptr()), "stage_copy")
     return dst
 
 

@@ -64,8 +64,9 @@ const char *dh3d_status_string(int st); /* static string */
  * pointers (device-addressable: hipHostMalloc / torch pin_memory), 16-byte aligned.  For the serving loop around the hot
  * path (the reference feeds numpy arrays and saves numpy arrays: localdesc_extract.py:106-138, globaldesc_extract.py:84-100):
  * the batch goes host -> slot buffer and the descriptors slot buffer -> host on the SAME compute queue as the step, so no
- * engine-to-engine hand-over sits on the step's chain.  No reference counterpart (TF's feed_dict / fetches). */
-int dh3d_stage_copy(const void *src, void *dst, size_t bytes, void *stream);
+ * engine-to-engine hand-over sits on the step's chain.  device_to_device != 0: both are device buffers (the launch is
+ * sized for HBM instead of for the host link).  No reference counterpart (TF's feed_dict / fetches). */
+int dh3d_stage_copy(const void *src, void *dst, size_t bytes, int device_to_device, void *stream);
 
 /* ===================================================================================== *
  * A. Drop-in operators (reference layouts)

@@ -44,12 +44,15 @@ def _canned(n_gpus=1, bloat=1):
     if n_gpus == 1:   # the serving loop on the same pipeline
         line["value_streaming"] = {"value": 32000.5, "ms_per_step": 0.25, "steps_in_flight": 4, "distinct_host_batches": 9,
                                    "h2d_bytes_per_step": 786432, "output_bytes_per_step": 34340864, "what": "w" * 400,
-                                   "d2h_inclusive": {"value": 12000.0, "ms_per_step": 0.66, "GBps_d2h": 51.5, "note": "n" * 200}}
+                                   "d2h_inclusive": {"value": 12000.0, "ms_per_step": 0.66, "GBps_d2h": 51.5, "note": "n" * 200},
+                                   "steady_state": {"steps": 200, "value": 34000.0, "ms_per_step": 0.235,
+                                                    "resident_batches_ms_per_step": 0.226, "ratio_to_resident": 0.962}}
     if n_gpus == 1:   # the global-descriptor forward, measured in a fresh process (the other half of BASELINE's metric)
         line["global"] = {"workload": bench.WORKLOADS["global"]["name"], "value": 58000.25, "unit": "point-clouds/sec",
                           "ms_per_step": 0.5517, "steps": 20, "warmup": 5, "clouds_per_gpu": 32, "points": 4096,
                           "steps_in_flight": 3, "measured_in": "m" * 200, "wall_s": 9.0,
-                          "value_streaming": {"value": 57000.0, "ms_per_step": 0.56, "what": "w" * 300},
+                          "value_streaming": {"value": 57000.0, "ms_per_step": 0.56, "what": "w" * 300,
+                                              "steady_state": {"steps": 200, "ratio_to_resident": 0.97}},
                           "one_step_at_a_time": {"value": 46600.5, "unit": "point-clouds/sec", "ms_per_step": 0.687,
                                                  "note": "n" * 300}}
     if n_gpus > 1:
@@ -92,10 +95,11 @@ def test_line_fits_and_round_trips(n_gpus):
         assert g["workload"] == bench.WORKLOADS["global"]["name"] and g["steps_in_flight"] == 3
         assert g["value"] == pytest.approx(58000.25) and g["ms_per_step"] == pytest.approx(0.5517)
         assert g["one_step_at_a_time"] == {"value": 46600.5, "ms_per_step": 0.687}
-        assert g["value_streaming"] == {"value": 57000.0, "ms_per_step": 0.56}
+        assert g["value_streaming"] == {"value": 57000.0, "ms_per_step": 0.56, "steady_state_ratio": 0.97}
         vs = rec["value_streaming"]
         assert vs["value"] == 32000.5 and vs["steps_in_flight"] == 4 and len(vs["what"]) <= 160
         assert vs["d2h_inclusive"] == {"value": 12000.0, "GBps_d2h": 51.5}
+        assert vs["steady_state"] == {"steps": 200, "value": 34000.0, "ratio_to_resident": 0.962}
     if n_gpus > 1:
         g = rec["global_scaling"]
         assert g["weak"]["clouds_per_gpu"] == 32 and g["strong"]["clouds_per_gpu"] == 4

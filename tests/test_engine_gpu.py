@@ -1,8 +1,9 @@
 """GPU: the steps-in-flight engine (dh3d_amd/engine.py) -- the mode bench.py's `value` is measured in.
 
   * every slot of a depth-4 pipeline at the BASELINE shape (B=8, N=8192), each with its OWN batch, against the serial
-    forward of the same batch: kNN / FPS / sampled-set kNN / three_nn ids and the descriptors bit-equal; one cloud per
-    slot against the CPU oracle (oracle/model_np.py) within 1e-4;
+    forward of the same batch: kNN / FPS / sampled-set kNN / three_nn ids bit-equal, the descriptors within 2e-6 (the
+    engine's mode selects the one-launch local tail); one cloud per slot against the CPU oracle (oracle/model_np.py)
+    within 1e-4;
   * the persistent flex_conv's placement hint (`reserve_cus_per_xcd`, the only thing a step in flight changes inside
     a kernel) at every value the engine can produce, against the oracle on a row sample and bit-equal to hint 0;
   * the global path two deep.
@@ -48,7 +49,13 @@ def test_local_pipeline_depth4_B8_N8192_slots_equal_serial_and_oracle(dev):
     for i, (g, s) in enumerate(zip(got, serial)):
         for k in IDS:
             assert torch.equal(g[k], s[k]), (i, k)
-        assert torch.equal(g["xyz_feat"], s["xyz_feat"]), (i, "xyz_feat", (g["xyz_feat"] - s["xyz_feat"]).abs().max().item())
+        # coordinates bit-equal; descriptors: with steps in flight the local tail runs as ONE launch (both 64 -> 128 GEMMs,
+        # up-sampling, BatchNorm / ReLU, sum and row normalisation in the accumulator layout, csrc/dense_tail.hip) where the
+        # serial forward runs three -- the same bf16x6 products summed in another association: 2e-6 on unit-norm rows
+        # (tests/test_pm_gpu.py::test_local_tail_fused_vs_float64_and_vs_the_three_launch_form), each within 1e-4 of the oracle
+        assert torch.equal(g["xyz_feat"][..., :3], s["xyz_feat"][..., :3]), i
+        d = float((g["xyz_feat"] - s["xyz_feat"]).abs().max())
+        assert d <= 2e-6, (i, "xyz_feat", d)
     # one cloud per slot against the oracle (a single 8192-point cloud takes the C restatement ~2 s)
     w = _weights_np(m)
     for slot in range(depth):

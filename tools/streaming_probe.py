@@ -35,6 +35,14 @@ with torch.no_grad():
         pipe.submit()
     def d2d_in(i): pipe.submit(devb[i % len(devb)])
     def d2d_in_nowait(i): pipe.submit(devb[i % len(devb)], after_current=False)
+    def sink_copy_plain(i):
+        k = pipe.next_slot
+        pipe.submit()
+        with torch.cuda.stream(pipe.stream(k)):
+            sink[k].copy_(pipe._runs[k].outputs[name], non_blocking=True)
+    def h2d_sink_stage(i):
+        k = pipe.next_slot
+        pipe.submit(host[i % len(host)], fetch_to={name: sink[k]})
     def sink_copy(i):
         k = pipe.next_slot
         pipe.submit(fetch_to={name: sink[k]})
@@ -60,7 +68,7 @@ with torch.no_grad():
                    ("device batch via submit(dev) [waits current]", d2d_in), ("device batch, after_current=False", d2d_in_nowait),
                    ("zero-copy + fetch_to device sink (copy_)", sink_copy), ("zero-copy + sink by a kernel (mul out=)", sink_kernel),
                    ("zero-copy + D2H of a small slice", d2h_small), ("zero-copy + D2H of the whole output", d2h_full),
-                   ("H2D + sink by kernel", h2d_sink_kernel), ("zero-copy submit() again", zero)):
+                   ("H2D + sink by kernel", h2d_sink_kernel), ("H2D + fetch_to device sink (staging kernels both ways)", h2d_sink_stage), ("zero-copy + torch copy_ sink", sink_copy_plain), ("zero-copy submit() again", zero)):
         try:
             print("%-52s %.4f ms per step" % (nm, timed(fn)), flush=True)
         except Exception as e:
