@@ -14,7 +14,7 @@ mkdir -p "$root/gpurun_out"
 for w in local global; do
   d=/tmp/prof_${tag}_$w
   rm -rf "$d"
-  (cd /tmp && rocprofv3 --kernel-trace --stats -d "$d" -o p -- python "$root/bench.py" --workload $w --no-cpu-baseline --no-extras --repeats 0 > /tmp/log_$w 2>&1)
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d "$d" -o p -- python "$root/bench.py" --workload $w --no-cpu-baseline --no-extras --no-streaming --repeats 0 > /tmp/log_$w 2>&1)
   f=$(find "$d" -name "*.db" | head -1)
   out="$root/gpurun_out/${tag}_kernel_stats_$w.txt"
   key="spatial_sort_kernel<8>"; [ $w = global ] && key="spatial_sort_kernel<4>"

@@ -20,12 +20,21 @@ Stores in front of a needed load are reported too (`stores_ahead`): the wait cov
 
     python tools/vmcnt_audit.py /tmp/isa/dense.s [--kernel se_res_mfma] [--all]
 
+A flagged wait whose parked loads are all read again within FAR instructions is batch ORDER noise (a batch of requests in
+flight, consumed in a slightly different order than issued: costs at most one request's latency); the ones to read are those
+with a load parked for longer that was issued SHORTLY before the wait (it may still be in flight) -- a prefetch for a later
+stage sitting in front of a load that is needed now: the finding-9 pattern.
+
 Approximations: program order = text order (forward branches inside a loop body are ignored, the report says when a loop
 has them); a destination register overwritten by a later instruction is not tracked; waits with vmcnt(0) at a loop's top
 that consume everything are not flagged (nothing parked).
 """
 import re
 import sys
+
+FAR = 64     # a parked load that is read again only this many instructions behind the wait is a prefetch, not batch order
+YOUNG = 150  # ... and it can still be in flight if it was issued fewer instructions than this before the wait (~5 cycles
+             # per instruction against 500-900 cycles of L2 / HBM latency)
 
 VM_LOAD = re.compile(r"^\s*(global_load|buffer_load|flat_load|scratch_load)\w*\s+(.*)$")
 VM_STORE = re.compile(r"^\s*(global_store|buffer_store|flat_store|scratch_store|global_atomic|buffer_atomic|flat_atomic)\w*\s+(.*)$")
@@ -72,6 +81,21 @@ def parse_kernels(path):
 
 def demangle(name):
     return re.sub(r"^_ZN12_GLOBAL__N_1\d+", "", name)[:90]
+
+
+def source_regs(ln):
+    body_txt = ln.split(";")[0]
+    mm = re.match(r"^\s*(\S+)\s+(.*)$", body_txt)
+    if not mm:
+        return set()
+    op, ops = mm.group(1), split_operands(mm.group(2))
+    srcs = ops if re.match(r"(global_store|buffer_store|flat_store|scratch_store|ds_write|ds_store|s_|global_atomic|v_cmp)", op) else ops[1:]
+    if op.startswith(("v_fmac", "v_pk_fmac", "v_mac")):
+        srcs = ops
+    used = set()
+    for o in srcs:
+        used |= regs_of(o)
+    return used
 
 
 def is_lds_dma(ops):
@@ -127,24 +151,22 @@ def audit_kernel(name, lines, verbose=False):
             window = seq[pos + 1:nxt]
             used = set()
             for ln in window:
-                body_txt = ln.split(";")[0]
-                mm = re.match(r"^\s*(\S+)\s+(.*)$", body_txt)
-                if not mm:
-                    continue
-                op, ops = mm.group(1), split_operands(mm.group(2))
-                srcs = ops if re.match(r"(global_store|buffer_store|flat_store|scratch_store|ds_write|ds_store|s_|global_atomic|v_cmp|v_mfma)", op) else ops[1:]
-                if op.startswith("v_mfma"):
-                    srcs = ops[1:]
-                if op.startswith(("v_fmac", "v_pk_fmac", "v_mac")):
-                    srcs = ops
-                for o in srcs:
-                    used |= regs_of(o)
+                used |= source_regs(ln)
             loads = [f for f in forced if f["kind"] == "load"]
             consumed = [f for f in loads if f["regs"] & used]
             if not consumed:
                 continue
             youngest_needed = max(f["pos"] for f in consumed)
             parked = [f for f in loads if f not in consumed and f["pos"] < youngest_needed and f["regs"]]
+            # how long is a parked load parked?  distance (instructions) from this wait to the first read of its registers;
+            # None = not read again before the end of the second copy of the loop body (a prefetch for a later iteration)
+            for f in parked:
+                f["age"] = pos - f["pos"]   # instructions between the parked load's issue and this wait
+                f["use_in"] = None
+                for q in range(pos + 1, len(seq)):
+                    if f["regs"] & source_regs(seq[q]):
+                        f["use_in"] = q - pos
+                        break
             stores_ahead = [f for f in forced if f["kind"] == "store" and f["pos"] < youngest_needed]
             if parked or (verbose and stores_ahead):
                 findings.append(dict(loop=(h, t), wait_line=h + (pos - len(body)), n=n, consumed=consumed, parked=parked,
@@ -171,7 +193,9 @@ def main(argv):
                 continue
             findings, nloops = audit_kernel(name, lines, verbose)
             flagged = [f for f in findings if f["parked"]]
-            print("%-92s loops %2d  flagged waits %2d" % (dem, nloops, len(flagged)))
+            severe = [f for f in flagged if any((c["use_in"] is None or c["use_in"] > FAR) and c["age"] < YOUNG for c in f["parked"])]
+            print("%-92s loops %2d  flagged waits %2d  of which a prefetch (not read for > %d instr.) issued < %d instr. before the wait: %2d"
+                  % (dem, nloops, len(flagged), FAR, YOUNG, len(severe)))
             for f in findings:
                 if not f["parked"] and not verbose:
                     continue
@@ -180,7 +204,9 @@ def main(argv):
                 for c in f["consumed"][:4]:
                     print("        needs   [%s@%d] %s" % ("prev" if c["copy"] == 0 else "this", c["pos"] % f["body_len"], c["text"]))
                 for c in f["parked"][:6]:
-                    print("        PARKED  [%s@%d] %s" % ("prev" if c["copy"] == 0 else "this", c["pos"] % f["body_len"], c["text"]))
+                    print("        PARKED  [%s@%d] %s   (issued %d instructions before the wait, read again after %s)"
+                          % ("prev" if c["copy"] == 0 else "this", c["pos"] % f["body_len"], c["text"], c["age"],
+                             "> one iteration" if c["use_in"] is None else c["use_in"]))
                 if len(f["parked"]) > 6:
                     print("        ... %d more parked loads" % (len(f["parked"]) - 6))
                 if f["stores_ahead"]:
