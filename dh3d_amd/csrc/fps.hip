@@ -320,12 +320,26 @@ __global__ __launch_bounds__(64 * WAVES) void fps_list_kernel(const float4 *__re
       }
       asm volatile("" :: "v"(b1), "v"(b2));
       wmax = wave_max_f32(b1);
-      const float tau = wmax - delta * wmax;
       const unsigned long long hit = __ballot(b1 == wmax);
-      const unsigned long long flag = __ballot(b1 > tau);
-      const unsigned long long two = __ballot(b2 > tau);  // two points of a lane inside the margin
+      // the listing margin.  One adaptive margin lists 2-3 lanes on average (it must stay clear of L + 1).  From 8 groups
+      // per wave on, three margins are probed at once (independent compares: delta, 1.5 delta, 2.25 delta) and the widest
+      // one that still lists at most L lanes, none with two points inside it, is taken: fuller lists, a lower bound, more
+      // picks per sync (8 x 8192: 335.4 -> 330.0 us, 4 x 16384: 739 -> 723; at 4 groups per wave 168.5 -> 170.6: off there).
+      // `cnt`, which steers delta, stays the NARROW probe's count.
+      const float tau0 = wmax - delta * wmax;
+      unsigned long long flag = __ballot(b1 > tau0);
+      unsigned long long two = __ballot(b2 > tau0);  // two points of a lane inside the margin
       const int cnt = __popcll(flag);
-      if (__popcll(hit) == 1 && two == 0ull && cnt >= 1 && cnt <= L) {
+      if (PPT >= 8) {
+        const float tau1 = wmax - (1.5f * delta) * wmax, tau2 = wmax - (2.25f * delta) * wmax;
+        const unsigned long long f1 = __ballot(b1 > tau1), f2 = __ballot(b1 > tau2);
+        const unsigned long long t1 = __ballot(b2 > tau1), t2 = __ballot(b2 > tau2);
+        const bool ok2 = __popcll(f2) <= L && t2 == 0ull, ok1 = __popcll(f1) <= L && t1 == 0ull;
+        flag = ok2 ? f2 : (ok1 ? f1 : flag);
+        two = ok2 ? t2 : (ok1 ? t1 : two);
+      }
+      const int cntl = __popcll(flag);
+      if (__popcll(hit) == 1 && two == 0ull && cntl >= 1 && cntl <= L) {
         // the usual case: one point holds the maximum, every lane inside the margin has ONE point there and they all
         // fit: list them in lane order; everything else is at or below tau
         const int slot = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(flag >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)flag, 0u));
