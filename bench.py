@@ -1165,13 +1165,21 @@ def main():
         # Both consumers live on the SLOT's stream (Pipeline.submit(fetch_to=...)): a separate consumer stream costs a
         # cross-stream event pair per step and shares one of the process's four hardware queues with a slot -- its waits
         # stall that slot (first version of this block: 6.7 k clouds/s against 33 k).
+        dbg = os.environ.get("DH3D_STREAM_DEBUG")
+
         def loop(n, d2h):
             tickets = []
+            tl = time.perf_counter()
             for i in range(n):
                 if d2h and len(tickets) == 2 * depth:
                     tickets.pop(0).event.synchronize()   # that step's descriptors are in host memory; its buffer is free again
                 k = pipe.next_slot
                 tickets.append(pipe.submit(host[i % nb], fetch_to={name: host_out[i % (2 * depth)] if d2h else sink[k]}))
+                if dbg:
+                    tn = time.perf_counter()
+                    if tn - tl > 1e-3:
+                        print("[stream dbg] n=%d d2h=%s submit %d took %.2f ms" % (n, d2h, i, (tn - tl) * 1e3), file=sys.stderr)
+                    tl = tn
             if d2h:
                 for tk in tickets:
                     tk.event.synchronize()
@@ -1199,19 +1207,31 @@ def main():
         rec = {"steps_in_flight": depth, "distinct_host_batches": nb, "h2d_bytes_per_step": per * wl["N"] * 12,
                "output_bytes_per_step": out_bytes}
         long_n = 10 * nsteps
+        # Three blocks, the median reported (all listed): a serving loop's blocks see a sporadic one-off host / runtime stall
+        # of ~85 ms once in a few runs (r06d: in the first block, 1.7 k clouds/s; r06f: in the long run, ratio 0.34; not
+        # reproducible in tools/hiccup_probe*.py, tools/streaming_steady.py: 0.96-0.97 of the resident loop over 1000 steps)
+        def blocks3(d2h):
+            ts = sorted(timed(d2h) for _ in range(3))
+            rec.setdefault("blocks_ms_per_step", {})["d2h" if d2h else "device_sink"] = [round(t / nsteps * 1e3, 5) for t in ts]
+            return ts[1]
+
+        def long2(d2h):
+            ts = [timed(d2h, long_n) for _ in range(2)]
+            rec["steady_state_runs_ms_per_step"] = [round(t / long_n * 1e3, 5) for t in ts]
+            return min(ts)
         if small:
-            dt = timed(True)
+            dt = blocks3(True)
             rec.update({"value": total * nsteps / dt, "ms_per_step": dt / nsteps * 1e3,
                         "what": "pinned host batch -> H2D on the slot's stream -> step -> D2H of `%s` into pinned host memory "
-                                "on the slot's stream; the host picks results up one round (2 x depth buffers) behind the submitting loop" % name})
-            dl, dz = timed(True, long_n), zero_copy_long(long_n)
+                                "on the slot's stream; the host picks results up one round (2 x depth buffers) behind the submitting loop; median of three blocks" % name})
+            dl, dz = long2(True), zero_copy_long(long_n)
         else:
-            dt = timed(False)
+            dt = blocks3(False)
             rec.update({"value": total * nsteps / dt, "ms_per_step": dt / nsteps * 1e3,
                         "what": "pinned host batch -> H2D on the slot's stream -> step -> `%s` copied out of the slot's buffers "
-                                "into the consumer's device buffer on the slot's stream" % name})
-            dl, dz = timed(False, long_n), zero_copy_long(long_n)
-            dt2 = timed(True)
+                                "into the consumer's device buffer on the slot's stream; median of three blocks" % name})
+            dl, dz = long2(False), zero_copy_long(long_n)
+            dt2 = blocks3(True)
             rec["d2h_inclusive"] = {"value": total * nsteps / dt2, "ms_per_step": dt2 / nsteps * 1e3,
                                     "GBps_d2h": out_bytes * nsteps / dt2 / 1e9,
                                     "note": "the dense map copied to pinned host memory every step: bound by the host link, "
