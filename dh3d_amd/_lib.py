@@ -202,6 +202,10 @@ _SIGNATURES = {
     "dh3d_netvlad_tail_workspace_bytes": [c_int, c_int, c_int, c_int],
     "dh3d_netvlad_tail_fwd": [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_float,
                               c_fp, c_size_t, c_fp, c_fp],
+    "dh3d_walk_plan_bytes": [c_int, c_int],
+    "dh3d_walk_plan": [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp],
+    "dh3d_global_walk_planned_fwd": [c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, ctypes.POINTER(Epilogue),
+                                     c_fp, c_float, c_fp, c_fp, c_fp, c_fp, c_int, c_fp],
     "dh3d_netvlad_tail_assign_fwd": [c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int,
                                      c_float, c_fp, c_size_t, c_fp, c_fp],
     "dh3d_global_walk_fwd": [c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, ctypes.POINTER(Epilogue), c_fp,
@@ -220,6 +224,7 @@ _RESTYPES = {
     "dh3d_netvlad_head_workspace_bytes": c_size_t,
     "dh3d_netvlad_fused_workspace_bytes": c_size_t,
     "dh3d_netvlad_tail_workspace_bytes": c_size_t,
+    "dh3d_walk_plan_bytes": c_size_t,
     "dh3d_flex_conv_fwd_workspace_bytes": c_size_t,
     "dh3d_flex_conv_bwd_workspace_bytes": c_size_t,
     "dh3d_flex_pool_fwd_workspace_bytes": c_size_t,

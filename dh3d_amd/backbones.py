@@ -434,6 +434,10 @@ def finish_level(xyz, lv, same_stream=False):
             L.check(L.lib().dh3d_three_nn(B, N, xyz_s.shape[1], L.ptr(xyz), L.ptr(xyz_s), L.ptr(d3), L.ptr(i3),
                                           L.stream_ptr()), "three_nn")
         lv["nn3_dist"], lv["nn3_idx"] = d3, i3
+        if lv.get("_want_walk_plan") and "_ordered" in lv and xyz_s.shape[1] <= 1024:
+            # the global tail's walk over the fine points (pm.global_tail): its per-block slot tables depend on three_nn's
+            # result only -- built here, behind three_nn and off the tail's chain (17 us of the walk when built inside it)
+            lv["walk_plan"] = pm.walk_plan(i3, d3, lv["_ordered"][0], xyz_s.shape[1])
     return lv
 
 

@@ -886,41 +886,21 @@ __device__ __forceinline__ Row4 idw_mix_pk(const Row4 a, const Row4 b, const Row
   return Row4{pk_fma(c.lo, W3, pk_fma(b.lo, W2, a.lo * W1)), pk_fma(c.hi, W3, pk_fma(b.hi, W2, a.hi * W1))};
 }
 
-struct VladTail {
-  const float *coarse;    // [B, m, 256]
-  const float *cw;        // [B, m, 64] = coarse @ cluster_weights
-  const float *cl_scale;  // [64] folded cluster BatchNorm
-  const float *cl_shift;
-  float *apart;           // [B, m, 64]  A' (zeroed by the launcher)
-  float *asum;            // [B, 64]     sum_n a[n,:] (zeroed by the launcher)
-  const float *b_dev;     // (either instantiation) the fc bias as a device scalar, added to b_fc; may be NULL
-  long long h_ss;         // (either) layout of H: slice stride and row stride in floats; 0 = the slice layout
-  int h_rs;               //          [NS][Rc][256] (h_ss = Rc * 256, h_rs = 256); row-major [Rc][Hd]: 256, Hd
-};
-
-template <bool VLAD>
-__global__ __launch_bounds__(kIHT, 2 * kIHW / 4) void interp_head_lds_kernel(const float *__restrict__ H, int NS, long long Rc,
-                                                             const int32_t *__restrict__ idx,
-                                                             const float *__restrict__ dist,
-                                                             const float4 *__restrict__ order, int B, int n, int m,
-                                                             int nblk, EpilogueArgs ep, const float *__restrict__ w_fc,
-                                                             float b_fc, float *__restrict__ att, VladTail vt) {
-  extern __shared__ __attribute__((aligned(16))) float s_ih[];
-  // the small tables FIRST: their addresses fit the 16-bit offset field of the ds instructions (behind 64 KB of rows every
-  // table read cost a v_add), the rows behind them
-  int *s_slot = reinterpret_cast<int *>(s_ih);                    // [kIHP][4] slot (or -1 - coarse row)
-  float *s_w = reinterpret_cast<float *>(s_slot + kIHP * 4);      // [kIHP][4] interpolation weights
-  int *s_orig = reinterpret_cast<int *>(s_w + kIHP * 4);          // [kIHP] original index of the fine point (-1: none)
-  unsigned *s_bits = reinterpret_cast<unsigned *>(s_orig + kIHP); // [32] bitmap over the cloud's coarse rows
-  int *s_pre = reinterpret_cast<int *>(s_bits + 32);              // [33] popcount prefix
-  int *s_row = s_pre + 33;                                        // [kIHCap] slot -> coarse row
-  float *s_z = reinterpret_cast<float *>(s_row + kIHCap);         // [kIHP] logits, then s_inv [kIHP] and s_asum [64]
-  float *s_rows = s_ih + kIHTab;                                  // [kIHCap][256]   (reused by the NetVLAD part)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // XCD x takes clouds x, x + 8, ...: a cloud's H (2 MB) stays in one L2
-  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
-  const int bi = xcd + 8 * (seq / nblk), blk = seq % nblk;
-  if (bi >= B) return;
+// The block's SLOT TABLE (first kIHPlan dwords of the workgroup's LDS: s_slot | s_w | s_orig | s_bits | s_pre | s_row), built
+// from the three_nn result: bitmap of the coarse rows the block's 128 points touch -> prefix popcounts -> slot = rank of the
+// row.  Three dependent global round trips (order -> idx / dist -> ...) and five barriers: 17 us of the walk when built in
+// the walk's own launch (round 5, tools/walk_phases.sh) -- round 6: walk_plan_kernel builds it once behind three_nn, off the
+// critical chain, and the walk copies the image in (dh3d_walk_plan / dh3d_global_walk_planned_fwd).
+constexpr int kIHPlan = (kIHP * 4 * 2 + kIHP + 32 + 33 + kIHCap + 3) / 4 * 4;  // dwords of the image (1284)
+__device__ __forceinline__ void ih_build_table(float *s_ih, const int32_t *__restrict__ idx, const float *__restrict__ dist,
+                                               const float4 *__restrict__ order, int bi, int blk, int n, int m) {
+  int *s_slot = reinterpret_cast<int *>(s_ih);
+  float *s_w = reinterpret_cast<float *>(s_slot + kIHP * 4);
+  int *s_orig = reinterpret_cast<int *>(s_w + kIHP * 4);
+  unsigned *s_bits = reinterpret_cast<unsigned *>(s_orig + kIHP);
+  int *s_pre = reinterpret_cast<int *>(s_bits + 32);
+  int *s_row = s_pre + 33;
+  const int tid = threadIdx.x;
   if (tid < 32) s_bits[tid] = 0u;
   __syncthreads();
   // ---- the block's points, their neighbours and weights; mark the coarse rows they touch
@@ -973,6 +953,61 @@ __global__ __launch_bounds__(kIHT, 2 * kIHW / 4) void interp_head_lds_kernel(con
     }
   }
   __syncthreads();
+}
+
+struct VladTail {
+  const float *coarse;    // [B, m, 256]
+  const float *cw;        // [B, m, 64] = coarse @ cluster_weights
+  const float *cl_scale;  // [64] folded cluster BatchNorm
+  const float *cl_shift;
+  float *apart;           // [B, m, 64]  A' (zeroed by the launcher)
+  float *asum;            // [B, 64]     sum_n a[n,:] (zeroed by the launcher)
+  const float *b_dev;     // (either instantiation) the fc bias as a device scalar, added to b_fc; may be NULL
+  long long h_ss;         // (either) layout of H: slice stride and row stride in floats; 0 = the slice layout
+  int h_rs;               //          [NS][Rc][256] (h_ss = Rc * 256, h_rs = 256); row-major [Rc][Hd]: 256, Hd
+  const int *plan;        // (either) slot tables of all blocks, [B][nblk][kIHPlan] dwords (dh3d_walk_plan), or NULL: built here
+};
+
+__global__ __launch_bounds__(kIHT) void walk_plan_kernel(const int32_t *__restrict__ idx, const float *__restrict__ dist,
+                                                         const float4 *__restrict__ order, int n, int m, int nblk,
+                                                         int *__restrict__ plan) {
+  __shared__ __attribute__((aligned(16))) float s_tab[kIHPlan];
+  const int bi = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+  ih_build_table(s_tab, idx, dist, order, bi, blk, n, m);
+  int4 *dst = reinterpret_cast<int4 *>(plan) + (size_t)(bi * nblk + blk) * (kIHPlan / 4);
+  for (int e = tid; e < kIHPlan / 4; e += kIHT) dst[e] = reinterpret_cast<const int4 *>(s_tab)[e];
+}
+
+template <bool VLAD>
+__global__ __launch_bounds__(kIHT, 2 * kIHW / 4) void interp_head_lds_kernel(const float *__restrict__ H, int NS, long long Rc,
+                                                             const int32_t *__restrict__ idx,
+                                                             const float *__restrict__ dist,
+                                                             const float4 *__restrict__ order, int B, int n, int m,
+                                                             int nblk, EpilogueArgs ep, const float *__restrict__ w_fc,
+                                                             float b_fc, float *__restrict__ att, VladTail vt) {
+  extern __shared__ __attribute__((aligned(16))) float s_ih[];
+  // the small tables FIRST: their addresses fit the 16-bit offset field of the ds instructions (behind 64 KB of rows every
+  // table read cost a v_add), the rows behind them
+  int *s_slot = reinterpret_cast<int *>(s_ih);                    // [kIHP][4] slot (or -1 - coarse row)
+  float *s_w = reinterpret_cast<float *>(s_slot + kIHP * 4);      // [kIHP][4] interpolation weights
+  int *s_orig = reinterpret_cast<int *>(s_w + kIHP * 4);          // [kIHP] original index of the fine point (-1: none)
+  unsigned *s_bits = reinterpret_cast<unsigned *>(s_orig + kIHP); // [32] bitmap over the cloud's coarse rows
+  int *s_pre = reinterpret_cast<int *>(s_bits + 32);              // [33] popcount prefix
+  int *s_row = s_pre + 33;                                        // [kIHCap] slot -> coarse row
+  float *s_z = reinterpret_cast<float *>(s_row + kIHCap);         // [kIHP] logits, then s_inv [kIHP] and s_asum [64]
+  float *s_rows = s_ih + kIHTab;                                  // [kIHCap][256]   (reused by the NetVLAD part)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // XCD x takes clouds x, x + 8, ...: a cloud's H (2 MB) stays in one L2
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int bi = xcd + 8 * (seq / nblk), blk = seq % nblk;
+  if (bi >= B) return;
+  if (vt.plan) {  // the table was built behind three_nn (walk_plan_kernel): one coalesced copy, one barrier
+    const int4 *src = reinterpret_cast<const int4 *>(vt.plan) + (size_t)(bi * nblk + blk) * (kIHPlan / 4);
+    for (int e = tid; e < kIHPlan / 4; e += kIHT) reinterpret_cast<int4 *>(s_ih)[e] = src[e];
+    __syncthreads();
+  } else {
+    ih_build_table(s_ih, idx, dist, order, bi, blk, n, m);
+  }
   const int nd = min(s_pre[32], kIHCap);
   const bool overflow = s_pre[32] > kIHCap;  // block-uniform: some rows are not staged
   const long long SS = vt.h_ss ? vt.h_ss : Rc * 256;
@@ -1282,7 +1317,8 @@ DH3D_API int dh3d_interp_head_sorted_fwd_dev(const float *H, int Hd, int row_maj
 static int global_tail_launch(const float *H, int Hd, const float *coarse, const float *cw, const int32_t *idx,
                               const float *dist, const float *order, int B, int n, int m, const dh3d_epilogue *ep,
                               const float *w_fc, float b_fc, const float *cl_scale, const float *cl_shift, float *att,
-                              float *accum, bool zero_here, hipStream_t s, bool with_gemm = true) {
+                              float *accum, bool zero_here, hipStream_t s, bool with_gemm = true,
+                              const int *plan = nullptr) {
   DH3D_REQUIRE(H && coarse && cw && idx && dist && w_fc && cl_scale && cl_shift && accum);
   DH3D_REQUIRE(B > 0 && n > 0 && m > 0 && Hd > 0);
   DH3D_SUPPORTED(Hd % 256 == 0 && Hd <= 1024 && m <= 1024 && (!ep || ep->act != DH3D_ACT_SIGMOID) &&
@@ -1296,7 +1332,7 @@ static int global_tail_launch(const float *H, int Hd, const float *coarse, const
   DH3D_ALLOW_BIG_LDS(interp_head_lds_kernel<true>);
   hipLaunchKernelGGL(interp_head_lds_kernel<true>, dim3(8 * per_xcd), dim3(kIHT), interp_head_lds_bytes(), s, H, Hd / 256,
                      (long long)B * m, idx, dist, reinterpret_cast<const float4 *>(order), B, n, m, nblk, dh3d_ep(ep),
-                     w_fc, b_fc, att, VladTail{coarse, cw, cl_scale, cl_shift, apart, asum});
+                     w_fc, b_fc, att, VladTail{coarse, cw, cl_scale, cl_shift, apart, asum, nullptr, 0, 0, plan});
   const int st = dh3d_launch_status();
   if (st != DH3D_OK || !with_gemm) return st;
   return dh3d_internal_gemm_tn_batched(apart, coarse, B, m, 64, 256, V, true, s);
@@ -1319,6 +1355,33 @@ DH3D_API int dh3d_global_walk_fwd(const float *H, int Hd, const float *coarse, c
                                   float *accum, int zero_accum, void *stream) {
   return global_tail_launch(H, Hd, coarse, cw, idx, dist, order, B, n, m, ep, w_fc, b_fc, cl_scale, cl_shift, att, accum,
                             zero_accum != 0, (hipStream_t)stream, false);
+}
+
+// The walk's slot tables built ahead of it (round 6): one image of kIHPlan dwords per 128-point block of the Morton order,
+// written behind three_nn (off the global step's critical chain) and copied into the walk's LDS with one coalesced read.
+// plan: dh3d_walk_plan_bytes(B, n) bytes; valid for the (idx, dist, order) it was built from.
+DH3D_API size_t dh3d_walk_plan_bytes(int B, int n) {
+  if (B <= 0 || n <= 0) return 0;
+  return sizeof(int) * (size_t)B * dh3d_cdiv(n, kIHP) * kIHPlan;
+}
+
+DH3D_API int dh3d_walk_plan(const int32_t *idx, const float *dist, const float *order, int B, int n, int m, void *plan,
+                            void *stream) {
+  DH3D_REQUIRE(idx && dist && plan && B > 0 && n > 0 && m > 0);
+  DH3D_SUPPORTED(m <= 1024 && B <= 65535);
+  const int nblk = dh3d_cdiv(n, kIHP);
+  hipLaunchKernelGGL(walk_plan_kernel, dim3(nblk, B), dim3(kIHT), 0, (hipStream_t)stream, idx, dist,
+                     reinterpret_cast<const float4 *>(order), n, m, nblk, static_cast<int *>(plan));
+  return dh3d_launch_status();
+}
+
+// dh3d_global_walk_fwd with the slot tables of dh3d_walk_plan (plan may be NULL: built inside the walk as before).
+DH3D_API int dh3d_global_walk_planned_fwd(const float *H, int Hd, const float *coarse, const float *cw, const int32_t *idx,
+                                          const float *dist, const float *order, const void *plan, int B, int n, int m,
+                                          const dh3d_epilogue *ep, const float *w_fc, float b_fc, const float *cl_scale,
+                                          const float *cl_shift, float *att, float *accum, int zero_accum, void *stream) {
+  return global_tail_launch(H, Hd, coarse, cw, idx, dist, order, B, n, m, ep, w_fc, b_fc, cl_scale, cl_shift, att, accum,
+                            zero_accum != 0, (hipStream_t)stream, false, static_cast<const int *>(plan));
 }
 
 DH3D_API int dh3d_interp_head_fwd(const float *H, int Hd, const int32_t *idx, const float *dist, int B, int n, int m,

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(1024) void netvlad_finalize(const float *__restrict
 __global__ __launch_bounds__(1024) void netvlad_assign_finalize(const float *__restrict__ apart /*[B][m][Cl]*/,
                                                                const float *__restrict__ coarse /*[B][m][D]*/,
                                                                const float *__restrict__ asum /*[B][Cl]*/,
-                                                               const float *__restrict__ W2 /*[D][Cl]*/, int m,
+                                                               const float *__restrict__ W2 /*[D][Cl]*/, int m, int B,
                                                                float *__restrict__ vlad /*[B][D*Cl]*/,
                                                                float *__restrict__ tot /*[B][Cl/kCG]*/) {
   extern __shared__ __attribute__((aligned(16))) float s_af[];
@@ -246,8 +246,14 @@ __global__ __launch_bounds__(1024) void netvlad_assign_finalize(const float *__r
   float *s_part = s_af + (size_t)m * 8; // [8 slices][8 clusters][256]
   __shared__ float s_csq[16][kCT];
   __shared__ float s_red[16];
-  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c0g = blockIdx.x * kCG;
+  // XCD-aware (round 6): workgroups go round-robin over the 8 XCDs, and as grid (8, B) the eight cluster groups of a cloud
+  // landed on eight DIFFERENT L2s -- every one of them fetched the cloud's 512 KB of coarse rows from the fabric (134 MB per
+  // launch for 16.8 MB of rows).  Linear id -> (XCD = id % 8 serves clouds XCD, XCD + 8, ...; the cloud's eight groups in a row).
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int b = xcd + 8 * (seq >> 3), cgi = seq & 7;
+  if (b >= B) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0g = cgi * kCG;
   const float *ab = apart + (size_t)b * m * kCl, *cb = coarse + (size_t)b * m * kD;
   for (int e = tid; e < m * 2; e += 1024) {  // rows x two float4
     const int j = e >> 1, h = e & 1;
@@ -257,7 +263,9 @@ __global__ __launch_bounds__(1024) void netvlad_assign_finalize(const float *__r
   {
     // 16 row slices, one per wave, all eight clusters per lane (32 accumulators): a slice is m / 16 rows = four batches of
     // eight 16-byte reads in flight.  The 16 partial tiles meet in LDS in two rounds (waves 8-15 store, waves 0-7 add
-    // theirs on top), so that the buffer stays at 8 tiles.
+    // theirs on top), so that the buffer stays at 8 tiles.  (Round 6: the first batch requested ahead of the staging and
+    // the batches double-buffered by hand -- 8 + 8 rows, 16 + 16 do not fit the 128 VGPRs of a 1024-thread workgroup --
+    // compiled to 172 bytes of scratch per lane and 65 us against 17.7.)
     const int d4 = lane * 4;
     const int per = (m + 15) >> 4, j0 = wave * per, j1 = min(m, j0 + per);
     float4 acc[8];
@@ -323,7 +331,7 @@ __global__ __launch_bounds__(1024) void netvlad_assign_finalize(const float *__r
     float all = 0.f;
 #pragma unroll
     for (int w = 0; w < 16; ++w) all += s_red[w];
-    tot[(size_t)b * (kCl / kCG) + blockIdx.x] = all;
+    tot[(size_t)b * (kCl / kCG) + cgi] = all;
   }
   float *o = vlad + (size_t)b * kD * kCl + (size_t)d * kCl + c0g + g * kCT;  // flatten d-major: index d*Cl + c
   *reinterpret_cast<float2 *>(o) = make_float2(v[0], v[1]);
@@ -422,15 +430,28 @@ __global__ __launch_bounds__(1024) void netvlad_gate(const float *__restrict__ p
   __shared__ float s_h[256];
   __shared__ float s_red[4];
   const int b = blockIdx.x, o = threadIdx.x & 255, q = threadIdx.x >> 8;
+  // the quarter's 64 gating weights are requested ahead of everything else (nothing here depends on them; behind the two
+  // barriers below they were four more exposed round trips)
+  const int j0 = q * (256 / 4);
+  float wv0[32], wv1[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) wv0[i] = Wg ? Wg[(size_t)(j0 + i) * O + o] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) wv1[i] = Wg ? Wg[(size_t)(j0 + 32 + i) * O + o] : 0.f;
   {
     const int per = (KS + 3) / 4, k0 = q * per, k1 = min(KS, k0 + per);
+    // sixteen partials requested before the first add (two per iteration were 16 dependent-looking round trips of the 32
+    // a thread sums at KS = 128: 11.0 us of a launch whose work is a 4 MB read)
     float h0 = 0.f, h1 = 0.f;
     int ks = k0;
-    for (; ks + 1 < k1; ks += 2) {
-      h0 += part[((size_t)ks * B + b) * O + o];
-      h1 += part[((size_t)(ks + 1) * B + b) * O + o];
+    for (; ks + 16 <= k1; ks += 16) {
+      float t[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t[i] = part[((size_t)(ks + i) * B + b) * O + o];
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) { h0 += t[i]; h1 += t[i + 1]; }
     }
-    if (ks < k1) h0 += part[((size_t)ks * B + b) * O + o];
+    for (; ks < k1; ++ks) h0 += part[((size_t)ks * B + b) * O + o];
     s_q[q][o] = h0 + h1;
   }
   __syncthreads();
@@ -447,13 +468,19 @@ __global__ __launch_bounds__(1024) void netvlad_gate(const float *__restrict__ p
   float v = h;
   if (Wg) {  // context gating (backbones.py:276-277,282-320); Wg == nullptr: gating=False
     float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
-    const int j0 = q * (256 / 4);
-#pragma unroll 4  // 16 weight loads in flight per thread instead of 4: the loop is 16 dependent L2 round trips otherwise
-    for (int j = j0; j < j0 + 256 / 4; j += 4) {
-      g0 = fmaf(s_h[j], Wg[(size_t)j * O + o], g0);
-      g1 = fmaf(s_h[j + 1], Wg[(size_t)(j + 1) * O + o], g1);
-      g2 = fmaf(s_h[j + 2], Wg[(size_t)(j + 2) * O + o], g2);
-      g3 = fmaf(s_h[j + 3], Wg[(size_t)(j + 3) * O + o], g3);
+#pragma unroll
+    for (int i = 0; i < 32; i += 4) {
+      g0 = fmaf(s_h[j0 + i], wv0[i], g0);
+      g1 = fmaf(s_h[j0 + i + 1], wv0[i + 1], g1);
+      g2 = fmaf(s_h[j0 + i + 2], wv0[i + 2], g2);
+      g3 = fmaf(s_h[j0 + i + 3], wv0[i + 3], g3);
+    }
+#pragma unroll
+    for (int i = 0; i < 32; i += 4) {
+      g0 = fmaf(s_h[j0 + 32 + i], wv1[i], g0);
+      g1 = fmaf(s_h[j0 + 32 + i + 1], wv1[i + 1], g1);
+      g2 = fmaf(s_h[j0 + 32 + i + 2], wv1[i + 2], g2);
+      g3 = fmaf(s_h[j0 + 32 + i + 3], wv1[i + 3], g3);
     }
     __syncthreads();  // s_q is reused
     s_q[q][o] = (g0 + g1) + (g2 + g3);
@@ -579,7 +606,7 @@ DH3D_API int dh3d_netvlad_tail_assign_fwd(const float *apart, const float *coars
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = sizeof(float) * ((size_t)m * 8 + 8 * 8 * kD);
   DH3D_ALLOW_BIG_LDS(netvlad_assign_finalize);
-  hipLaunchKernelGGL(netvlad_assign_finalize, dim3(kCl / kCG, B), dim3(1024), lds, s, apart, coarse, asum, W2, m, vlad, tot);
+  hipLaunchKernelGGL(netvlad_assign_finalize, dim3(8 * dh3d_cdiv(B, 8) * (kCl / kCG)), dim3(1024), lds, s, apart, coarse, asum, W2, m, B, vlad, tot);
   const int Kd = D * Cl, KS = dh3d_cdiv(Kd, kKSlice);
   hipLaunchKernelGGL(netvlad_hidden_splitk, dim3(KS, dh3d_cdiv(B, 32), O / 64), dim3(256), 0, s, vlad, Wh, B, Kd, O,
                      part);

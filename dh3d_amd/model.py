@@ -249,6 +249,8 @@ class DH3D(nn.Module):
         # stage2 (dilate2=8) and global (gl_dilate=8) share this level.  Enqueued BEFORE the side work: hipGraph keeps
         # a node's first-captured successor on its queue, and the FPS chain is the one that must not hop.
         geo._lv = geo.level(8, self.knn_num, finish=False)
+        if prezero_tail:  # the global tail's walk will run: its slot tables are built right behind three_nn (off its chain)
+            geo._lv["_want_walk_plan"] = True
         # three_nn needs the sampled coordinates only.  It goes where there is slack: the FPS chain is ~0.05 us per
         # point of a cloud whatever the batch, kNN(N) + stage 1 on the side stream ~2.5 us per 1000 points of the
         # batch -- big batches of small clouds (cfg 3) leave this stream waiting for stage 1, and three_nn beside
@@ -383,7 +385,8 @@ class DH3D(nn.Module):
             stage1_done = torch.cuda.Event()
             stage1_done.record()
             geo.start_nn3(geo._lv)  # three_nn: waits for the sampled coordinates, overlaps the N/8 convolutions
-            for t in (x2, x1 if (fuse_sc or fused_tail) else shortcut, geo._lv["nn3_dist"], geo._lv["nn3_idx"], lower):
+            for t in (x2, x1 if (fuse_sc or fused_tail) else shortcut, geo._lv["nn3_dist"], geo._lv["nn3_idx"], lower,
+                      geo._lv.get("walk_plan")):
                 if t is not None:
                     t.record_stream(main)
         main.wait_event(stage1_done)  # not the whole side stream: three_nn is joined at the interpolation (geo.finish)
@@ -430,7 +433,7 @@ class DH3D(nn.Module):
             return pm.global_tail(coarse, lv["nn3_idx"], lv["nn3_dist"], lv["_ordered"][0], gp["wslices"], last.cout,
                                   gp["w_fc"], gp["b_fc"], (lp["b"], lp["scale"], lp["shift"], pm.ACT_RELU), p["wc"],
                                   p["cs"], p["ch"], p["W2"], p["Wh"], p["s1"], p["h1"], p["Wg"], p["s2"], p["h2"],
-                                  l2_eps=l2_eps, accum=acc, cw=cw)
+                                  l2_eps=l2_eps, accum=acc, cw=cw, plan=lv.get("walk_plan"))
         forglobal = self.global_before_assemble(geo, localdesc)
         coarse, lv = getattr(self.global_before_assemble, "_last_coarse", (None, None))
         if coarse is not None and "nn3_idx" in lv and self.globalatt.interpolated_supported(coarse, lv["nn3_idx"]):

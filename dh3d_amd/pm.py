@@ -663,19 +663,33 @@ def netvlad_fused(x, att, wc_packed, bn_scale, bn_shift, W2, Wh, bn1_scale, bn1_
     return out
 
 
+def walk_plan(idx, dist, order, m):
+    """The slot tables of pm.global_tail's walk, built ahead of it (csrc/dense_x6.hip walk_plan_kernel): idx / dist [B,n,3]
+    from three_nn against m <= 1024 sampled points, order = spatial_sort records [B,n,4] of the fine cloud (or None).
+    Returns an opaque int32 tensor, valid for exactly these inputs."""
+    ix = L.require_cuda_i32(idx, "idx", 3)
+    d = L.require_cuda_f32(dist, "dist", 3)
+    B, n, _ = ix.shape
+    nbytes = L.lib().dh3d_walk_plan_bytes(B, n)
+    plan = torch.empty((nbytes // 4,), dtype=torch.int32, device=ix.device)
+    L.check(L.lib().dh3d_walk_plan(L.ptr(ix), L.ptr(d), L.ptr(order), B, n, int(m), L.ptr(plan), L.stream_ptr()), "walk_plan")
+    return plan
+
+
 def global_tail_accum_size(B, m):
     """floats of global_tail's accumulator block [ A' B*m*64 | asum B*64 ]."""
     return B * m * 64 + B * 64
 
 
 def global_tail(coarse, idx, dist, order, wslices_x3, Hd, w_fc, b_fc, att_ep, wc_packed, cl_scale, cl_shift, W2, Wh,
-                bn1_scale, bn1_shift, Wg, bn2_scale, bn2_shift, l2_eps=0.0, want_att=False, accum=None, cw=None):
+                bn1_scale, bn1_shift, Wg, bn2_scale, bn2_shift, l2_eps=0.0, want_att=False, accum=None, cw=None, plan=None):
     """three_interpolate -> attention head -> NetVLAD + gating, with the up-sampling commuted through both consumers: the
     fine points are walked once (csrc/dense_x6.hip VladTail), everything else runs on the coarse rows.
     coarse [B,m,256], idx/dist [B,n,3], order = spatial_sort records [B,n,4] of the fine cloud, att_ep =
     (pre_bias, scale, shift, act) of the attention's hidden layer.  accum (optional): a ZEROED float32 tensor of
     global_tail_accum_size(B, m) elements (the caller's fill, issued off the critical chain); cw (optional):
-    coarse @ cluster_weights if the caller has it already.  Returns the descriptor [B,O] (, att [B,n,1])."""
+    coarse @ cluster_weights if the caller has it already; plan (optional): walk_plan(idx, dist, order, m) of exactly these
+    inputs, built off the critical chain.  Returns the descriptor [B,O] (, att [B,n,1])."""
     x = L.require_cuda_f32(coarse, "coarse", 3)
     ix = L.require_cuda_i32(idx, "idx", 3)
     d = L.require_cuda_f32(dist, "dist", 3)
@@ -694,9 +708,11 @@ def global_tail(coarse, idx, dist, order, wslices_x3, Hd, w_fc, b_fc, att_ep, wc
     elif accum.numel() != global_tail_accum_size(B, m) or accum.dtype != torch.float32 or not accum.is_cuda:
         raise ValueError("global_tail: accum must be a zeroed float32 GPU tensor of global_tail_accum_size(B, m) elements")
     ep = _ep(*att_ep)
-    L.check(L.lib().dh3d_global_walk_fwd(L.ptr(H), Hd, L.ptr(x), L.ptr(cw), L.ptr(ix), L.ptr(d), L.ptr(order), B, n, m, ep,
-                                         L.ptr(w_fc), float(b_fc), L.ptr(cl_scale), L.ptr(cl_shift), L.ptr(att), L.ptr(accum),
-                                         1 if zero_here else 0, L.stream_ptr()), "global_walk")
+    if plan is not None and (plan.dtype != torch.int32 or plan.numel() * 4 != L.lib().dh3d_walk_plan_bytes(B, n)):
+        raise ValueError("global_tail: plan is not walk_plan(idx, dist, order, m) of these shapes")
+    L.check(L.lib().dh3d_global_walk_planned_fwd(L.ptr(H), Hd, L.ptr(x), L.ptr(cw), L.ptr(ix), L.ptr(d), L.ptr(order), L.ptr(plan),
+                                                 B, n, m, ep, L.ptr(w_fc), float(b_fc), L.ptr(cl_scale), L.ptr(cl_shift),
+                                                 L.ptr(att), L.ptr(accum), 1 if zero_here else 0, L.stream_ptr()), "global_walk")
     apart, asum = accum[:B * m * 64], accum[B * m * 64:]
     O = Wh.shape[1]
     ws_bytes = L.lib().dh3d_netvlad_tail_workspace_bytes(B, C, 64, O)

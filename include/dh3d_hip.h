@@ -753,6 +753,19 @@ int dh3d_netvlad_tail_fwd(const float *V, const float *asum, const float *W2, co
 int dh3d_global_walk_fwd(const float *H, int Hd, const float *coarse, const float *cw, const int32_t *idx, const float *dist,
                          const float *order, int B, int n, int m, const dh3d_epilogue *ep, const float *w_fc, float b_fc,
                          const float *cl_scale, const float *cl_shift, float *att, float *accum, int zero_accum, void *stream);
+/* Round 6: the walk's slot tables built AHEAD of it.  Inside the walk the table of a 128-point block (bitmap of the coarse
+ * rows its points touch -> prefix popcounts -> slots; three dependent global round trips + five barriers) was 17 of the
+ * launch's ~95 us at 32 x 4096.  dh3d_walk_plan builds every block's table from the three_nn result (idx, dist [B,n,3], order =
+ * dh3d_spatial_sort records of the fine cloud, may be NULL) into `plan` (dh3d_walk_plan_bytes(B, n) bytes, opaque: 1284
+ * dwords per block) -- launched behind dh3d_three_nn_*, off the critical chain -- and dh3d_global_walk_planned_fwd is
+ * dh3d_global_walk_fwd reading it (plan == NULL: the table is built inside the walk as before).  Same results bit for bit
+ * up to the order of the f32 atomics (as dh3d_global_walk_fwd).  m <= 1024. */
+size_t dh3d_walk_plan_bytes(int B, int n);
+int dh3d_walk_plan(const int32_t *idx, const float *dist, const float *order, int B, int n, int m, void *plan, void *stream);
+int dh3d_global_walk_planned_fwd(const float *H, int Hd, const float *coarse, const float *cw, const int32_t *idx,
+                                 const float *dist, const float *order, const void *plan, int B, int n, int m,
+                                 const dh3d_epilogue *ep, const float *w_fc, float b_fc, const float *cl_scale,
+                                 const float *cl_shift, float *att, float *accum, int zero_accum, void *stream);
 int dh3d_netvlad_tail_assign_fwd(const float *apart, const float *coarse, const float *asum, int m, const float *W2,
                                  const float *Wh, const float *bn1_scale, const float *bn1_shift, const float *Wg,
                                  const float *bn2_scale, const float *bn2_shift, int B, int D, int Cl, int O, float l2_eps,

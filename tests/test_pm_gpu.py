@@ -710,6 +710,15 @@ def test_global_tail_equals_upsample_attention_netvlad(dev, B, n, clustered):
     again = pm.global_tail(coarse, i3, d3, srt, slices, Hd, wfc, 0.2, (b, sc, sh, pm.ACT_RELU), wc, cs, ch, W2, Wh, s1, h1,
                            Wg, s2, h2, l2_eps=1e-8)
     assert float((again - got).abs().max()) <= 1e-6 * float(got.abs().max())
+    # round 6: the walk's slot tables built ahead of it (pm.walk_plan, behind three_nn in the model): same tables, same walk
+    plan = pm.walk_plan(i3, d3, srt, m)
+    planned, att_p = pm.global_tail(coarse, i3, d3, srt, slices, Hd, wfc, 0.2, (b, sc, sh, pm.ACT_RELU), wc, cs, ch, W2, Wh,
+                                    s1, h1, Wg, s2, h2, l2_eps=1e-8, want_att=True, plan=plan)
+    assert torch.equal(att_p, att)                       # no atomics on the attention path: bit-equal
+    assert float((planned - got).abs().max()) <= 1e-6 * float(got.abs().max())
+    with pytest.raises(ValueError):
+        pm.global_tail(coarse, i3, d3, srt, slices, Hd, wfc, 0.2, (b, sc, sh, pm.ACT_RELU), wc, cs, ch, W2, Wh, s1, h1, Wg, s2,
+                       h2, plan=plan[:-4])
 
 
 def test_local_tail_fused_vs_float64_and_vs_the_three_launch_form(dev):

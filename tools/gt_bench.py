@@ -26,4 +26,7 @@ s1, h1, s2, h2 = (0.5 + torch.rand(O, generator=g)).to(dev), 0.1 * r(O), (0.5 + 
 srt, _ = pm.spatial_sort(fine)
 t = event_time_ms(lambda: pm.global_tail(coarse, i3, d3, srt, slices, Hd, wfc, 0.2, (b, sc, sh, pm.ACT_RELU), wc, cs, ch, W2, Wh, s1, h1, Wg, s2, h2, l2_eps=1e-8), iters=20)
 t2 = event_time_ms(lambda: pm.interp_head(coarse, i3, d3, slices, Hd, wfc, 0.2, pre_bias=b, scale=sc, shift=sh, act=pm.ACT_RELU, order=srt), iters=20)
-print(os.environ.get("DH3D_HIP_LIB", "default"), "global_tail %.1f us   interp_head(sorted) %.1f us" % (t * 1e3, t2 * 1e3))
+plan = pm.walk_plan(i3, d3, srt, m)
+t3 = event_time_ms(lambda: pm.global_tail(coarse, i3, d3, srt, slices, Hd, wfc, 0.2, (b, sc, sh, pm.ACT_RELU), wc, cs, ch, W2, Wh, s1, h1, Wg, s2, h2, l2_eps=1e-8, plan=plan), iters=20)
+t4 = event_time_ms(lambda: pm.walk_plan(i3, d3, srt, m), iters=20)
+print(os.environ.get("DH3D_HIP_LIB", "default"), "global_tail %.1f us (with walk_plan: %.1f us; the plan itself %.1f)   interp_head(sorted) %.1f us" % (t * 1e3, t3 * 1e3, t4 * 1e3, t2 * 1e3))
