@@ -536,21 +536,26 @@ __global__ __launch_bounds__(256) void l2norm_concat_kernel(const float *__restr
 // A wave takes RPW consecutive rows of one cloud: lane r < RPW loads row r's three indices and distances and turns the
 // distances into weights ONCE (the six IEEE divisions cost ~14 instructions each and were issued per two rows);
 // the row loop fetches them with ds_bpermute.  No load sits under a branch (ragged tails clamp the row, the store is
-// predicated); the cloud comes from blockIdx.y (no 64-bit division).
+// predicated); the cloud comes from the block index (no 64-bit division).
 // PART / RES / L2CAT / ACT (-1: read ep.act) are compile-time so that the row loop is one basic block.
 template <int RPW, bool PART, bool RES, bool L2CAT, int ACT>
 __global__ __launch_bounds__(256) void interp_combine_kernel(const float *__restrict__ cw, const int32_t *__restrict__ idx,
                                                             const float *__restrict__ dist,
-                                                            const float *__restrict__ part, int n, int m,
+                                                            const float *__restrict__ part, int n, int m, int B, int nblk,
                                                             EpilogueArgs ep, const float *__restrict__ residual,
                                                             const float *__restrict__ prefix, float l2_eps,
                                                             float *__restrict__ out) {
   constexpr int C = 128;
   __shared__ float s_cat[L2CAT ? 4 * RPW * (C + 3) : 1];   // L2CAT: the four waves' output rows, staged for contiguous stores
   const int lane = threadIdx.x & 63, half = lane >> 5, sub = lane & 31, c4 = sub * 4;
-  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+  // XCD-aware (round 6): as grid (blocks, B) a cloud's blocks went round-robin over the eight XCDs and each L2 fetched every
+  // cloud's coarse rows; a linear grid with XCD x serving clouds x, x + 8, ... keeps a cloud's 512 KB in ONE L2
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int blk = seq % nblk;
+  const long long cloud = xcd + 8 * (seq / nblk);
+  if (cloud >= B) return;
+  const int row0 = (blk * 4 + (threadIdx.x >> 6)) * RPW;
   if (row0 >= n) return;
-  const long long cloud = blockIdx.y;
   const Ep4 e = ep4_prefetch(ep, c4);
   const int act = ACT >= 0 ? ACT : ep.act;
   int o1, o2, o3;
@@ -630,11 +635,12 @@ DH3D_API int dh3d_interp_combine_fwd(const float *coarse_w, const int32_t *idx, 
 #endif
   constexpr int kRows = DH3D_IC_ROWS;  // per wave
   const EpilogueArgs e = dh3d_ep(ep);
-  const dim3 grid(dh3d_cdiv(N, 4 * kRows), B);
+  const int nblk = dh3d_cdiv(N, 4 * kRows);
+  const dim3 grid(8 * dh3d_cdiv(B, 8) * nblk);
   hipStream_t s = (hipStream_t)stream;
 #define DH3D_IC_LAUNCH(PART, RES, L2, ACT)                                                                          \
   hipLaunchKernelGGL((interp_combine_kernel<kRows, PART, RES, L2, ACT>), grid, dim3(256), 0, s, coarse_w, idx, dist, \
-                     partial, N, M, e, residual, prefix, l2_eps, out)
+                     partial, N, M, B, nblk, e, residual, prefix, l2_eps, out)
 #define DH3D_IC_ACT(PART, RES, L2)                                     \
   {                                                                    \
     if (e.act == DH3D_ACT_RELU) DH3D_IC_LAUNCH(PART, RES, L2, DH3D_ACT_RELU); \

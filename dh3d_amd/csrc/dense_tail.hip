@@ -56,7 +56,9 @@ __global__ __launch_bounds__(kTailWaves * 64) void local_tail_fused_kernel(TailA
     s_w[tid + u * kTailWaves * 64] = a.wp_s[tid + u * kTailWaves * 64];
     wl[u] = a.wp_l[tid + u * kTailWaves * 64];
   }
-  const long long row0 = ((long long)blockIdx.x * kTailWaves + wave) * 32;
+  // (XCD-aware, round 6: contiguous tile ranges per XCD -- round-robin, every L2 fetched every cloud's coarse rows: 176 MB of
+  // fetches at 32 x 4096 where the operands are 80)
+  const long long row0 = ((long long)dh3d_xcd_remap(blockIdx.x, gridDim.x) * kTailWaves + wave) * 32;
   const bool alive = row0 < a.R;   // wave-uniform; n % 32 == 0: a tile lies inside one cloud and is complete
   const long long rowc = alive ? row0 : 0;
   const long long cloud = rowc / a.n;
