@@ -836,7 +836,9 @@ constexpr int kIHCap = 64;   // staged coarse rows per slice: a 128-point block 
 constexpr int kIHW = 8;             // waves per workgroup (two workgroups per CU: four waves per SIMD)
 constexpr int kIHT = kIHW * 64;      // threads
 constexpr int kIHPW = kIHP / kIHW;   // points per wave
-constexpr int kIHTab = (kIHP * 4 * 2 + kIHP + 32 + 33 + kIHCap + kIHP /*s_z*/ + kIHP /*s_inv*/ + 64 + 3) / 4 * 4;  // floats of tables
+constexpr int kIHLst = kIHCap + 1 + 3 * kIHP;  // slot-major reference lists: [kIHCap + 1] offsets, [3 * kIHP] entries (point * 4 + t)
+constexpr int kIHPlan = (kIHP * 4 * 2 + kIHP + 32 + 33 + kIHCap + kIHLst + 3) / 4 * 4;  // dwords of the plan image (1732)
+constexpr int kIHTab = kIHPlan + (kIHP /*s_z*/ + kIHP /*s_inv*/ + 64 + 3) / 4 * 4;  // floats of tables
 
 // VLAD (the global descriptor path): the same walk continues into NetVLAD's soft assignment
 // (core/backbones.py:207-255) -- the up-sampled feature map is never built.  With x[n] = sum_t w_t c[i_t] (c = the
@@ -886,12 +888,15 @@ __device__ __forceinline__ Row4 idw_mix_pk(const Row4 a, const Row4 b, const Row
   return Row4{pk_fma(c.lo, W3, pk_fma(b.lo, W2, a.lo * W1)), pk_fma(c.hi, W3, pk_fma(b.hi, W2, a.hi * W1))};
 }
 
-// The block's SLOT TABLE (first kIHPlan dwords of the workgroup's LDS: s_slot | s_w | s_orig | s_bits | s_pre | s_row), built
+// The block's SLOT TABLE (first kIHPlan dwords of the workgroup's LDS: s_slot | s_w | s_orig | s_bits | s_pre | s_row | lists), built
 // from the three_nn result: bitmap of the coarse rows the block's 128 points touch -> prefix popcounts -> slot = rank of the
 // row.  Three dependent global round trips (order -> idx / dist -> ...) and five barriers: 17 us of the walk when built in
 // the walk's own launch (round 5, tools/walk_phases.sh) -- round 6: walk_plan_kernel builds it once behind three_nn, off the
 // critical chain, and the walk copies the image in (dh3d_walk_plan / dh3d_global_walk_planned_fwd).
-constexpr int kIHPlan = (kIHP * 4 * 2 + kIHP + 32 + 33 + kIHCap + 3) / 4 * 4;  // dwords of the image (1284)
+// LISTS (the plan kernel): also the references to every staged row, slot-major -- s_loff[slot] .. s_loff[slot + 1] index
+// entries `point * 4 + t` of s_lst (within a list in the order of the LDS atomics that filled it: the scatter's sums are
+// f32 atomics anyway; sorting each list by one thread cost the plan 68 us) -- for the NetVLAD scatter of the walk.
+template <bool LISTS>
 __device__ __forceinline__ void ih_build_table(float *s_ih, const int32_t *__restrict__ idx, const float *__restrict__ dist,
                                                const float4 *__restrict__ order, int bi, int blk, int n, int m) {
   int *s_slot = reinterpret_cast<int *>(s_ih);
@@ -952,6 +957,37 @@ __device__ __forceinline__ void ih_build_table(float *s_ih, const int32_t *__res
       if (slot < kIHCap) s_row[slot] = j;
     }
   }
+  if (LISTS) {
+    int *s_loff = s_row + kIHCap, *s_lst = s_loff + kIHCap + 1;
+    __shared__ int s_cnt[kIHCap], s_fill[kIHCap];
+    if (tid < kIHCap) { s_cnt[tid] = 0; s_fill[tid] = 0; }
+    __syncthreads();
+    int sl3[3] = {-1, -1, -1};
+    if (tid < kIHP && s_orig[tid] >= 0) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        sl3[t] = s_slot[tid * 4 + t];
+        if (sl3[t] >= 0) atomicAdd(&s_cnt[sl3[t]], 1);
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {  // exclusive prefix of the kIHCap = 64 counts
+      const int c = s_cnt[tid];
+      int v = c;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(v, off, 64);
+        if (tid >= off) v += o;
+      }
+      s_loff[tid] = v - c;
+      if (tid == 63) s_loff[64] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+      if (sl3[t] >= 0) s_lst[s_loff[sl3[t]] + atomicAdd(&s_fill[sl3[t]], 1)] = tid * 4 + t;
+    __syncthreads();
+  }
   __syncthreads();
 }
 
@@ -973,7 +1009,7 @@ __global__ __launch_bounds__(kIHT) void walk_plan_kernel(const int32_t *__restri
                                                          int *__restrict__ plan) {
   __shared__ __attribute__((aligned(16))) float s_tab[kIHPlan];
   const int bi = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
-  ih_build_table(s_tab, idx, dist, order, bi, blk, n, m);
+  ih_build_table<true>(s_tab, idx, dist, order, bi, blk, n, m);
   int4 *dst = reinterpret_cast<int4 *>(plan) + (size_t)(bi * nblk + blk) * (kIHPlan / 4);
   for (int e = tid; e < kIHPlan / 4; e += kIHT) dst[e] = reinterpret_cast<const int4 *>(s_tab)[e];
 }
@@ -994,7 +1030,9 @@ __global__ __launch_bounds__(kIHT, 2 * kIHW / 4) void interp_head_lds_kernel(con
   unsigned *s_bits = reinterpret_cast<unsigned *>(s_orig + kIHP); // [32] bitmap over the cloud's coarse rows
   int *s_pre = reinterpret_cast<int *>(s_bits + 32);              // [33] popcount prefix
   int *s_row = s_pre + 33;                                        // [kIHCap] slot -> coarse row
-  float *s_z = reinterpret_cast<float *>(s_row + kIHCap);         // [kIHP] logits, then s_inv [kIHP] and s_asum [64]
+  int *s_loff = s_row + kIHCap;                                   // [kIHCap + 1] (planned walk only) offsets of the slots' reference lists
+  int *s_lst = s_loff + kIHCap + 1;                               // [3 kIHP] entries point * 4 + t, slot-major
+  float *s_z = s_ih + kIHPlan;                                    // [kIHP] logits, then s_inv [kIHP] and s_asum [64]
   float *s_rows = s_ih + kIHTab;                                  // [kIHCap][256]   (reused by the NetVLAD part)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD x takes clouds x, x + 8, ...: a cloud's H (2 MB) stays in one L2
@@ -1006,7 +1044,7 @@ __global__ __launch_bounds__(kIHT, 2 * kIHW / 4) void interp_head_lds_kernel(con
     for (int e = tid; e < kIHPlan / 4; e += kIHT) reinterpret_cast<int4 *>(s_ih)[e] = src[e];
     __syncthreads();
   } else {
-    ih_build_table(s_ih, idx, dist, order, bi, blk, n, m);
+    ih_build_table<false>(s_ih, idx, dist, order, bi, blk, n, m);
   }
   const int nd = min(s_pre[32], kIHCap);
   const bool overflow = s_pre[32] > kIHCap;  // block-uniform: some rows are not staged
@@ -1225,6 +1263,57 @@ __global__ __launch_bounds__(kIHT, 2 * kIHW / 4) void interp_head_lds_kernel(con
     unsafeAtomicAdd(&s_asum[lane], asum_acc);
     __syncthreads();
 #if !defined(DH3D_GT_SKIP) || !(DH3D_GT_SKIP & 4)
+    if (vt.plan) {
+      // Planned walk (round 6): the plan carries, per staged row, the list of the (point, t) references to it.  Wave w owns
+      // slots 8w .. 8w + 7 = ONE contiguous run of the slot-major list (~48 references): lane l fetches entry l and its
+      // coefficient w_t / |x| in parallel, then a uniform loop broadcasts them (v_readlane) and every lane = cluster adds
+      // coef * a[point, lane] -- one LDS read + one fma per reference -- flushing a row with one 64-lane atomic when the slot
+      // changes.  (The MFMA form below builds a [64 x 128] selection matrix by compares for 4 of the 8 waves: 12 us of the walk.)
+      float *Abp = vt.apart + (size_t)bi * m * 64;
+      const int s_first = wave * (kIHCap / kIHW), s_last = min(nd, s_first + kIHCap / kIHW);
+      if (s_first < s_last) {  // wave-uniform
+        // lane u <= 8 holds the list offset of slot s_first + u (the run's end for slots past nd)
+        const int offv = s_loff[min(s_first + (lane & 15), s_last)];
+        const int beg = __builtin_amdgcn_readlane(offv, 0);
+        const char *ap = reinterpret_cast<const char *>(s_a + lane);
+        int key = 0, loaded = -1;
+        float cf = 0.f;
+        int r0 = 0;  // position in the wave's run of references
+        for (int j = s_first; j < s_last; ++j) {
+          const int b1 = __builtin_amdgcn_readlane(offv, j - s_first + 1) - beg;
+          float acc = 0.f;
+          while (r0 < b1) {  // uniform
+            const int chunk = r0 >> 6;
+            if (chunk != loaded) {  // (once per wave unless its eight rows have more than 64 references)
+              const int p = beg + chunk * 64 + lane;
+              const int e = s_lst[min(p, 3 * kIHP - 1)];
+              key = (e >> 2) * 256;            // byte offset of the point's row of a[., 64]
+              cf = s_w[e] * s_inv[e >> 2];     // w_t / |x|
+              loaded = chunk;
+            }
+            const int stop = min(b1 - chunk * 64, 64);
+            int r = r0 & 63;
+            float acc2 = 0.f;
+            for (; r + 1 < stop; r += 2) {  // two references per trip: their LDS reads overlap (the compiler does not unroll this loop)
+              const int o0 = __builtin_amdgcn_readlane(key, r), o1 = __builtin_amdgcn_readlane(key, r + 1);
+              const float c0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cf), r));
+              const float c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cf), r + 1));
+              const float a0 = *reinterpret_cast<const float *>(ap + o0), a1 = *reinterpret_cast<const float *>(ap + o1);
+              acc = fmaf(c0, a0, acc);
+              acc2 = fmaf(c1, a1, acc2);
+            }
+            if (r < stop) {
+              const int o0 = __builtin_amdgcn_readlane(key, r);
+              const float c0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cf), r));
+              acc = fmaf(c0, *reinterpret_cast<const float *>(ap + o0), acc);
+            }
+            acc += acc2;
+            r0 = chunk * 64 + stop;
+          }
+          unsafeAtomicAdd(&Abp[(size_t)s_row[j] * 64 + lane], acc);
+        }
+      }
+    } else
     // A'[slot, k] = sum_n S[n, slot] * a[n, k] with S[n, slot_t(n)] = w_t(n) / |x_n|: a [64 x 128] x [128 x 64] product on
     // the matrix cores, S built in registers from the slot table (an LDS float atomic per (point, t, cluster) cost 115 us:
     // ds_add_f32 retires roughly one lane every 2.4 cycles).  Wave = one 32x32 tile: slots 32*(wave>>1).., clusters

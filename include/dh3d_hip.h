@@ -756,8 +756,9 @@ int dh3d_global_walk_fwd(const float *H, int Hd, const float *coarse, const floa
 /* Round 6: the walk's slot tables built AHEAD of it.  Inside the walk the table of a 128-point block (bitmap of the coarse
  * rows its points touch -> prefix popcounts -> slots; three dependent global round trips + five barriers) was 17 of the
  * launch's ~95 us at 32 x 4096.  dh3d_walk_plan builds every block's table from the three_nn result (idx, dist [B,n,3], order =
- * dh3d_spatial_sort records of the fine cloud, may be NULL) into `plan` (dh3d_walk_plan_bytes(B, n) bytes, opaque: 1284
- * dwords per block) -- launched behind dh3d_three_nn_*, off the critical chain -- and dh3d_global_walk_planned_fwd is
+ * dh3d_spatial_sort records of the fine cloud, may be NULL) into `plan` (dh3d_walk_plan_bytes(B, n) bytes, opaque:
+ * per block the slot table and the slot-major lists of the references to every staged row, which the planned walk's
+ * NetVLAD scatter follows instead of forming a selection matrix on the matrix pipe) -- launched behind dh3d_three_nn_*, off the critical chain -- and dh3d_global_walk_planned_fwd is
  * dh3d_global_walk_fwd reading it (plan == NULL: the table is built inside the walk as before).  Same results bit for bit
  * up to the order of the f32 atomics (as dh3d_global_walk_fwd).  m <= 1024. */
 size_t dh3d_walk_plan_bytes(int B, int n);
