@@ -322,7 +322,14 @@ class Geometry(object):
     def finish(self, lv):
         """Make nn3_dist / nn3_idx of a level usable on the current stream."""
         if "_nn3_done" in lv:
-            torch.cuda.current_stream().wait_event(lv["_nn3_done"])
+            # ONE wait per consuming stream: a second wait_event on the same stream is a second cross-queue edge in the
+            # captured graph -- it lands on whatever node comes next (the global block's slices GEMM, which does not read
+            # three_nn's result) and costs that node the ~6 us of a cross-queue dependency (round 6 timeline)
+            cur = torch.cuda.current_stream()
+            joined = lv.setdefault("_nn3_joined", [])
+            if not any(s == cur for s in joined):
+                cur.wait_event(lv["_nn3_done"])
+                joined.append(cur)
             return lv
         return finish_level(self.xyz, lv)
 

@@ -376,14 +376,16 @@ class DH3D(nn.Module):
             # gather / epilogue kernel are left (backbones.Conv2D1x1.forward_commuted)
             if lower is None and not fuse_sc and not fused_tail:
                 lower = self.stage2.commuted_partial(x2)
+            stage1_done = torch.cuda.Event()
+            stage1_done.record()
             if _prezero_tail and getattr(geo, "_tail_accum", None) is None:
                 # the global tail's accumulators (6 MB at cfg 3), zero-filled HERE, beside the sampling chain: the fill
-                # (a ~5 us node + its dependency gap) is off the critical chain when the tail starts
+                # (a ~5 us node + its dependency gap) is off the critical chain when the tail starts.  BEHIND the
+                # stage1_done record (round 6): in front of it the sampled level on the main stream waited for the fill too
+                # (its consumer, the walk, joins this stream through three_nn's event: geo.finish)
                 geo._tail_accum = torch.zeros((pm.global_tail_accum_size(points.shape[0], points.shape[1] // 8),),
                                               dtype=torch.float32, device=points.device)
                 geo._tail_accum.record_stream(main)
-            stage1_done = torch.cuda.Event()
-            stage1_done.record()
             geo.start_nn3(geo._lv)  # three_nn: waits for the sampled coordinates, overlaps the N/8 convolutions
             for t in (x2, x1 if (fuse_sc or fused_tail) else shortcut, geo._lv["nn3_dist"], geo._lv["nn3_idx"], lower,
                       geo._lv.get("walk_plan")):
