@@ -54,7 +54,9 @@ def _canned(n_gpus=1, bloat=1):
                           "value_streaming": {"value": 57000.0, "ms_per_step": 0.56, "what": "w" * 300,
                                               "steady_state": {"steps": 200, "ratio_to_resident": 0.97}},
                           "one_step_at_a_time": {"value": 46600.5, "unit": "point-clouds/sec", "ms_per_step": 0.687,
-                                                 "note": "n" * 300}}
+                                                 "note": "n" * 300},
+                          "at_20_steps": {"value": 57000.5, "ms_per_step": 0.561}}
+        line["at_20_steps"] = {"value": 35000.5, "ms_per_step": 0.2286}   # the K of rounds 1-5 beside today's default
     if n_gpus > 1:
         line["global_scaling"] = {
             "workload": bench.WORKLOADS["global"]["name"], "steps_in_flight": 2,
@@ -95,6 +97,8 @@ def test_line_fits_and_round_trips(n_gpus):
         assert g["workload"] == bench.WORKLOADS["global"]["name"] and g["steps_in_flight"] == 3
         assert g["value"] == pytest.approx(58000.25) and g["ms_per_step"] == pytest.approx(0.5517)
         assert g["one_step_at_a_time"] == {"value": 46600.5, "ms_per_step": 0.687}
+        assert g["at_20_steps"] == {"value": 57000.5, "ms_per_step": 0.561}
+        assert rec["at_20_steps"] == {"value": 35000.5, "ms_per_step": 0.2286}
         assert g["value_streaming"] == {"value": 57000.0, "ms_per_step": 0.56, "steady_state_ratio": 0.97}
         vs = rec["value_streaming"]
         assert vs["value"] == 32000.5 and vs["steps_in_flight"] == 4 and len(vs["what"]) <= 160
