@@ -1,11 +1,12 @@
 """Per-wave counters of knn_split_kernel (built with -DDH3D_KNN_PROBE, tools/gpu_knn_probe.sh) on the bench's clouds."""
 import ctypes, sys, torch, numpy as np
 sys.path.insert(0, ".")
-from bench import synthetic_clouds
+from bench import synthetic_clouds, real_oxford_clouds
+REAL = len(sys.argv) > 1 and sys.argv[1] == "real"
 lib = ctypes.CDLL("tools/libknn_probe.so")
 dev = torch.device("cuda")
 for B, N in ((8, 8192), (32, 4096)):
-    xyz = synthetic_clouds(B, N, 1234, dev)[..., :3].contiguous()
+    xyz = (real_oxford_clouds(B, N, dev) if REAL else synthetic_clouds(B, N, 1234, dev))[..., :3].contiguous()
     NG = (N + 63) // 64
     S = 4 if NG * B <= 1280 else 2
     srt = torch.empty(B, N, 4, device=dev); gbox = torch.empty(B, NG, 8, device=dev)
