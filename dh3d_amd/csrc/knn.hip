@@ -498,20 +498,26 @@ __global__ __launch_bounds__(64 * kSortedWaves) void knn_sorted_kernel(const flo
 // distance; the screen uses the smallest of all of these.  Published values are only ever replaced by smaller ones, so a stale read is still valid
 // (no barrier).  Every candidate is evaluated by exactly one wave with the same arithmetic, keys are unique: the merged
 // list is the list of the one-wave kernel, bit for bit.
+// The body is a device function over a raw LDS block (knn_split_lds_bytes<S>()): knn_split_kernel gives it a block of its
+// own, knn_grid_kernel ALIASES it with its candidate lists and serves a crowded cloud in the same launch (round 6: the
+// pruned scan as a second launch behind the cell lists was a 4.8 us no-op on every uniform cloud, and vice versa).
+template <int S>
+__host__ __device__ constexpr int knn_split_lds_bytes() {
+  return S * (64 * 3 * 4 + kQueue * 64 * 8 + 64 * 4 + 64 * 4 + 64 * 4);
+}
 template <int KMAX, int S>
-__global__ __launch_bounds__(64 * S) void knn_split_kernel(const float4 *__restrict__ sorted,
-                                                         const float *__restrict__ gbox, int N, int K,
-                                                         KnnLadder lad, int32_t *__restrict__ nn,
-                                                         float *__restrict__ dist, const int *__restrict__ gate) {
-  if (gate && !gate[(size_t)blockIdx.y * kCellInts + kCellFlag]) return;  // (dh3d_knn_grid: only the clouds the cell lists left)
+__device__ __forceinline__ void knn_split_body(const float4 *__restrict__ sorted, const float *__restrict__ gbox, int N, int K,
+                                               const KnnLadder lad, int32_t *__restrict__ nn, float *__restrict__ dist,
+                                               const int b, const int g, unsigned char *lds) {
   static_assert(KMAX * 64 * sizeof(u64) <= kQueue * 64 * sizeof(uint2), "a K-list fits its wave's survivor queue");
-  __shared__ __attribute__((aligned(16))) float s_c[S][64 * 3];  // pair-SoA image per wave
-  __shared__ uint2 s_q[S][kQueue * 64];
-  __shared__ int s_id[S][64];
-  __shared__ float s_share[S][64];  // per wave, per query: inflated square of the distance of its R-th entry
-  __shared__ float s_kth[S][64];    // ... and of its K-th entry (its own screening bound)
+  uint2 (*s_q)[kQueue * 64] = reinterpret_cast<uint2 (*)[kQueue * 64]>(lds);                     // [S] survivor queues
+  float (*s_c)[64 * 3] = reinterpret_cast<float (*)[64 * 3]>(lds + S * kQueue * 64 * 8);         // [S] pair-SoA image per wave
+  int (*s_id)[64] = reinterpret_cast<int (*)[64]>(lds + S * (kQueue * 64 * 8 + 64 * 3 * 4));     // [S]
+  float (*s_share)[64] = reinterpret_cast<float (*)[64]>(lds + S * (kQueue * 64 * 8 + 64 * 3 * 4 + 64 * 4));  // per wave, per query:
+                                                                 // inflated square of the distance of its R-th entry
+  float (*s_kth)[64] = reinterpret_cast<float (*)[64]>(lds + S * (kQueue * 64 * 8 + 64 * 3 * 4 + 64 * 8));    // ... and of its K-th
+                                                                 // entry (its own screening bound)
   constexpr int R = (KMAX + S - 1) / S - 1;
-  const int b = blockIdx.y, g = blockIdx.x;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int NG = (N + 63) / 64;
@@ -821,6 +827,17 @@ __global__ __launch_bounds__(64 * S) void knn_split_kernel(const float4 *__restr
   }
 }
 
+
+template <int KMAX, int S>
+__global__ __launch_bounds__(64 * S) void knn_split_kernel(const float4 *__restrict__ sorted,
+                                                         const float *__restrict__ gbox, int N, int K,
+                                                         KnnLadder lad, int32_t *__restrict__ nn,
+                                                         float *__restrict__ dist, const int *__restrict__ gate) {
+  if (gate && !gate[(size_t)blockIdx.y * kCellInts + kCellFlag]) return;  // (only the clouds the cell lists left)
+  __shared__ __attribute__((aligned(16))) unsigned char s_lds[knn_split_lds_bytes<S>()];
+  knn_split_body<KMAX, S>(sorted, gbox, N, K, lad, nn, dist, blockIdx.y, blockIdx.x, s_lds);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Small clouds (N <= 2048: the N/8 sampled sets of the model).  The lane-per-query kernels above leave most of the
 // chip idle there (B*N/64 waves, each a long dependent scan).  Here a WAVE owns a query: every lane holds
@@ -1120,13 +1137,25 @@ __device__ long long g_gprobe[64 * 8];
 
 // L = lanes per query (2, 4 or 8): fewer lanes = longer private candidate streams, but an insertion round serves 64 / L
 // queries and the merge has log2(L) steps.
-template <int L>
+// SF > 0 (L = 4: a workgroup is 64 queries, as in the pruned scan): a cloud the sort flagged as crowded is served HERE by
+// the pruned scan with SF waves per query group (knn_split_body on the same LDS block) -- one launch for both kinds of
+// cloud; SF = 0: such clouds are left to a second launch (dh3d_knn_grid).
+template <int L, int SF>
 __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict__ sorted, const float *__restrict__ gbox,
                                                       const int *__restrict__ cells, int N, int K, int D, KnnLadder lad,
                                                       int32_t *__restrict__ nn, float *__restrict__ dist) {
   constexpr int QB = 256 / L;  // queries per workgroup
+  static_assert(SF == 0 || (L == 4 && SF <= 4), "the merged scan: 64 queries per workgroup, at most four waves");
+  constexpr int kGridLds = 3 * 64 * 4 + QB * kGridCap * 2 + QB * 4;
+  constexpr int kSplitLds = SF > 0 ? knn_split_lds_bytes<(SF > 0 ? SF : 1)>() : 0;
+  __shared__ __attribute__((aligned(16))) unsigned char s_raw[kGridLds > kSplitLds ? kGridLds : kSplitLds];
   const int b = blockIdx.y, lane = threadIdx.x & 63, sub = lane & (L - 1);
-  if (cells[(size_t)b * kCellInts + kCellFlag]) return;  // dense cells: the pruned scan takes this cloud (dh3d_knn_grid)
+  if (cells[(size_t)b * kCellInts + kCellFlag]) {  // dense cells: the pruned scan takes this cloud
+    if constexpr (SF > 0) {
+      if (threadIdx.x < 64 * SF) knn_split_body<8, (SF > 0 ? SF : 1)>(sorted, gbox, N, K, lad, nn, dist, b, blockIdx.x, s_raw);
+    }
+    return;
+  }
   const int qi = blockIdx.x * QB + threadIdx.x / L;
   const bool valid = qi < N;
   const float4 *sc = sorted + (size_t)b * N;
@@ -1161,7 +1190,7 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict_
   }
   // the table index of cell (ax, ay, az): every axis' cell number with its bits at their places in the code (per
   // workgroup, in LDS: 64 entries per axis)
-  __shared__ unsigned s_ctab[3][64];
+  unsigned (*s_ctab)[64] = reinterpret_cast<unsigned (*)[64]>(s_raw);   // [3][64]
   if (threadIdx.x < 192) {
     const int a = threadIdx.x >> 6, v = threadIdx.x & 63;
     unsigned code = 0;
@@ -1226,8 +1255,8 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict_
       for (int i = 0; i < 8; ++i) st.keys[i] = ~0ull;
     }
   };
-  __shared__ unsigned short s_list[QB][kGridCap];
-  __shared__ int s_cnt[QB];
+  unsigned short (*s_list)[kGridCap] = reinterpret_cast<unsigned short (*)[kGridCap]>(s_raw + 3 * 64 * 4);   // [QB][kGridCap]
+  int *s_cnt = reinterpret_cast<int *>(s_raw + 3 * 64 * 4 + QB * kGridCap * 2);                                // [QB]
   const int qs = threadIdx.x / L;
   auto direct = [&](int j) {
     const float4 r = sc[j];
@@ -1444,11 +1473,20 @@ DH3D_API int dh3d_knn_grid(const float *sorted, const float *gbox, const int32_t
 #ifdef DH3D_GRID_DROP_BIAS
   D = D + (DH3D_GRID_DROP_BIAS) < 0 ? 0 : D + (DH3D_GRID_DROP_BIAS);
 #endif
-  hipLaunchKernelGGL(knn_grid_kernel<kLanes>, dim3(dh3d_cdiv(N, 256 / kLanes), B), dim3(256), 0, (hipStream_t)stream,
-                     reinterpret_cast<const float4 *>(sorted), gbox, cells, N, K, D, lad, nn, dist);
+  // The clouds whose points crowd into few cells (the sort's verdict, cells[kCellFlag]) go to the pruned scan -- in the SAME
+  // launch (four waves per query group = the cell lists' 256-thread workgroup) up to 4096 query groups, as a second launch
+  // (whose workgroups leave at once for the other clouds) for the one-wave scan beyond that
+  const long long groups = (long long)((N + 63) / 64) * B;
+  const dim3 grid(dh3d_cdiv(N, 256 / kLanes), B);
+  const float4 *so = reinterpret_cast<const float4 *>(sorted);
+  if (kLanes == 4 && groups <= 4096) {
+    // (four waves per group also where the scan on its own would use two: a two-wave scan inside the 256-thread workgroup
+    // leaves half of every workgroup's waves unused while it holds its LDS -- 32 x 4096 demo clouds 139.8 us against 112)
+    hipLaunchKernelGGL((knn_grid_kernel<4, 4>), grid, dim3(256), 0, (hipStream_t)stream, so, gbox, cells, N, K, D, lad, nn, dist);
+    return dh3d_launch_status();
+  }
+  hipLaunchKernelGGL((knn_grid_kernel<kLanes, 0>), grid, dim3(256), 0, (hipStream_t)stream, so, gbox, cells, N, K, D, lad, nn, dist);
   if (dh3d_launch_status() != DH3D_OK) return DH3D_ERR_LAUNCH;
-  // ... and the clouds whose points crowd into few cells (the sort's verdict, cells[kCellFlag]) on the pruned scan: every
-  // workgroup of the other clouds leaves at its first instruction
   return knn_sorted_launch(sorted, gbox, B, N, K, nn, dist, cells, stream);
 }
 
