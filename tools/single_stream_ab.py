@@ -6,7 +6,7 @@ import torch, bench
 dev = torch.device("cuda")
 wl = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "local"]
 for single in (True,):
-    for depth in (2, 4, 6):
+    for depth in (4, 6, 8, 12):
         model = bench.build_model(wl["preset"], dev, seed=0, num_points=wl["N"])
         model._single_stream = single
         pts = bench.synthetic_clouds(wl["B"], wl["N"], wl["seed"], dev, 0)
