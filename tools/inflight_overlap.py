@@ -4,7 +4,18 @@ import re, sqlite3, sys
 c = sqlite3.connect(sys.argv[1])
 rows = c.execute("select name, start, end from kernels order by start").fetchall()
 fps = [r for r in rows if "fps_list_kernel" in r[0]]
-t0, t1 = fps[-170][1], fps[-20][1]   # inside the LAST timed region of the run (bench.py --steps 200: the in-flight one)
+# the steady state of the in-flight region: the longest run of FPS launches that start less than GAP (0.4 ms; global: 0.6) apart (one step at a
+# time they are a step apart, and the clock-ramp replays in front of every timed region are synchronised one by one)
+starts = [r[1] for r in fps]
+GAP = int(float(sys.argv[2]) * 1000) if len(sys.argv) > 2 else 400000   # ns; argv[2] in us
+best, cur = (0, 0), 0
+for i in range(1, len(starts)):
+    if starts[i] - starts[i - 1] > GAP:
+        cur = i
+    if i - cur > best[1] - best[0]:
+        best = (cur, i)
+n = best[1] - best[0]
+t0, t1 = starts[best[0] + n // 4], starts[best[1] - n // 4]
 narrow = ("fps_list_kernel", "spatial_sort_kernel")
 win = [r for r in rows if t0 <= r[1] < t1 and not any(k in r[0] for k in narrow)]
 ev = sorted([(r[1], 1) for r in win] + [(min(r[2], t1), -1) for r in win])
