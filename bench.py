@@ -780,8 +780,9 @@ def compact_line(full, extras_path=None, limit=LINE_LIMIT):
     if "one_step_at_a_time" in full:
         s = full["one_step_at_a_time"]
         out["one_step_at_a_time"] = {"value": s.get("value"), "ms_per_step": s.get("ms_per_step")}
-    if isinstance(full.get("at_20_steps"), dict):   # the same pipeline over the K = 20 of rounds 1-5
-        out["at_20_steps"] = {k: full["at_20_steps"].get(k) for k in ("value", "ms_per_step")}
+    for key in ("at_20_steps", "at_100_steps"):   # the same pipeline over the other K (20: rounds 1-5 / the driver; 100: the default)
+        if isinstance(full.get(key), dict):
+            out[key] = {k: full[key].get(k) for k in ("value", "ms_per_step")}
     for k in ("phases_ms", "step_graphed", "collectives_per_step"):   # the training workloads' few scalars
         if k in full and len(json.dumps(full[k])) < 600:
             out[k] = full[k]
@@ -828,8 +829,9 @@ def compact_line(full, extras_path=None, limit=LINE_LIMIT):
         if isinstance(g.get("one_step_at_a_time"), dict):
             c["one_step_at_a_time"] = {"value": g["one_step_at_a_time"].get("value"),
                                        "ms_per_step": g["one_step_at_a_time"].get("ms_per_step")}
-        if isinstance(g.get("at_20_steps"), dict):
-            c["at_20_steps"] = {k: g["at_20_steps"].get(k) for k in ("value", "ms_per_step")}
+        for key in ("at_20_steps", "at_100_steps"):
+            if isinstance(g.get(key), dict):
+                c[key] = {k: g[key].get(k) for k in ("value", "ms_per_step")}
         if "error" in g:
             c["error"] = str(g["error"])[:200]
         out["global"] = c
@@ -877,7 +879,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # K = 100 by default since round 6: with steps in flight the K timed steps include the fill and the drain of the pipeline
-    # (four slots for the local forward), which weighed ~5 % at the K = 20 of rounds 1-5; the line keeps `at_20_steps`
+    # (four slots for the local forward), which weighed ~5 % at the K = 20 of rounds 1-5 (and of the driver's command line,
+    # `--steps 20 --warmup 5`); the line carries the other K's figure as `at_20_steps` / `at_100_steps`
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="local")
@@ -1131,9 +1134,12 @@ def main():
 
             nsteps = steps or args.steps
             dt = time_steps(step, pts, nsteps, args.warmup, dev)
-            if workload == args.workload and nsteps != 20 and not steps:  # the K of rounds 1-5, for comparison across rounds
-                d20 = time_steps(step, pts, 20, args.warmup, dev)
-                _AT20[workload] = {"value": total * 20 / d20, "ms_per_step": d20 / 20 * 1e3}
+            if workload == args.workload and not steps:
+                # the same pipeline over the OTHER K: 20 = the K of rounds 1-5 and of the driver's command line, 100 = this
+                # file's default (the timed region includes the fill and the drain of the slots: ~5 % at K = 20)
+                ko = 100 if nsteps == 20 else 20
+                dk = time_steps(step, pts, ko, args.warmup, dev)
+                _AT20[workload] = {"steps": ko, "value": total * ko / dk, "ms_per_step": dk / ko * 1e3}
             rep = None
             if repeats > 0:
                 blocks = repeat_blocks(step, pts, args.steps, dev, repeats)
@@ -1287,7 +1293,7 @@ def main():
     if in_flight_error:
         line["in_flight_error"] = in_flight_error
     if pipelined and args.workload in _AT20:
-        line["at_20_steps"] = _AT20[args.workload]
+        line["at_%d_steps" % _AT20[args.workload]["steps"]] = {k: _AT20[args.workload][k] for k in ("value", "ms_per_step")}
     if pipelined and args.workload in _STREAMING:
         line["value_streaming"] = _STREAMING[args.workload]
     if args.workload not in ("train", "train_local"):
@@ -1344,7 +1350,7 @@ def main():
                     "steps": rec["steps"], "warmup": rec["warmup"], "clouds_per_gpu": rec["config"]["clouds_per_gpu"],
                     "points": rec["config"]["points"], "steps_in_flight": rec["config"]["steps_in_flight"],
                     "one_step_at_a_time": rec.get("one_step_at_a_time"), "value_streaming": rec.get("value_streaming"),
-                    "at_20_steps": rec.get("at_20_steps"),
+                    "at_20_steps": rec.get("at_20_steps"), "at_100_steps": rec.get("at_100_steps"),
                     "measured_in": "a fresh process of this file "
                     "(--workload %s), same timed-region definition as `value`" % workload, "wall_s": time.time() - t0}
         except Exception as e:  # noqa: BLE001 -- the headline must not be lost with it

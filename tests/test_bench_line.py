@@ -99,6 +99,10 @@ def test_line_fits_and_round_trips(n_gpus):
         assert g["one_step_at_a_time"] == {"value": 46600.5, "ms_per_step": 0.687}
         assert g["at_20_steps"] == {"value": 57000.5, "ms_per_step": 0.561}
         assert rec["at_20_steps"] == {"value": 35000.5, "ms_per_step": 0.2286}
+        full2 = _canned(1)
+        full2["at_100_steps"] = full2.pop("at_20_steps")   # the driver's K = 20 run carries the default K's figure instead
+        rec2 = json.loads(bench.compact_line(full2, extras_path="x.json"))
+        assert rec2["at_100_steps"] == {"value": 35000.5, "ms_per_step": 0.2286} and "at_20_steps" not in rec2
         assert g["value_streaming"] == {"value": 57000.0, "ms_per_step": 0.56, "steady_state_ratio": 0.97}
         vs = rec["value_streaming"]
         assert vs["value"] == 32000.5 and vs["steps_in_flight"] == 4 and len(vs["what"]) <= 160
