@@ -508,7 +508,7 @@ __host__ __device__ constexpr int knn_split_lds_bytes() {
 template <int KMAX, int S>
 __device__ __forceinline__ void knn_split_body(const float4 *__restrict__ sorted, const float *__restrict__ gbox, int N, int K,
                                                const KnnLadder lad, int32_t *__restrict__ nn, float *__restrict__ dist,
-                                               const int b, const int g, unsigned char *lds) {
+                                               const int b, const int g, unsigned char *lds, const int wave0 = 0) {
   static_assert(KMAX * 64 * sizeof(u64) <= kQueue * 64 * sizeof(uint2), "a K-list fits its wave's survivor queue");
   uint2 (*s_q)[kQueue * 64] = reinterpret_cast<uint2 (*)[kQueue * 64]>(lds);                     // [S] survivor queues
   float (*s_c)[64 * 3] = reinterpret_cast<float (*)[64 * 3]>(lds + S * kQueue * 64 * 8);         // [S] pair-SoA image per wave
@@ -519,7 +519,7 @@ __device__ __forceinline__ void knn_split_body(const float4 *__restrict__ sorted
                                                                  // entry (its own screening bound)
   constexpr int R = (KMAX + S - 1) / S - 1;
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6) - wave0);   // (wave0: the first of this group's S waves)
   const int NG = (N + 63) / 64;
   const float4 *sc = sorted + (size_t)b * N;
   const float4 *gb = reinterpret_cast<const float4 *>(gbox) + (size_t)b * NG * 2;  // [lo.xyz,_ | hi.xyz,_]
@@ -835,7 +835,9 @@ __global__ __launch_bounds__(64 * S) void knn_split_kernel(const float4 *__restr
                                                          float *__restrict__ dist, const int *__restrict__ gate) {
   if (gate && !gate[(size_t)blockIdx.y * kCellInts + kCellFlag]) return;  // (only the clouds the cell lists left)
   __shared__ __attribute__((aligned(16))) unsigned char s_lds[knn_split_lds_bytes<S>()];
-  knn_split_body<KMAX, S>(sorted, gbox, N, K, lad, nn, dist, blockIdx.y, blockIdx.x, s_lds);
+  // (the group is rotated by the cloud: see knn_grid_kernel)
+  const unsigned ng = (unsigned)((N + 63) / 64);
+  knn_split_body<KMAX, S>(sorted, gbox, N, K, lad, nn, dist, blockIdx.y, (int)((blockIdx.x + 37u * blockIdx.y) % ng), s_lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1147,12 +1149,27 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict_
   constexpr int QB = 256 / L;  // queries per workgroup
   static_assert(SF == 0 || (L == 4 && SF <= 4), "the merged scan: 64 queries per workgroup, at most four waves");
   constexpr int kGridLds = 3 * 64 * 4 + QB * kGridCap * 2 + QB * 4;
-  constexpr int kSplitLds = SF > 0 ? knn_split_lds_bytes<(SF > 0 ? SF : 1)>() : 0;
+  constexpr int kSplitLds = SF == 2 ? 2 * knn_split_lds_bytes<2>() : SF > 0 ? knn_split_lds_bytes<(SF > 0 ? SF : 1)>() : 0;
   __shared__ __attribute__((aligned(16))) unsigned char s_raw[kGridLds > kSplitLds ? kGridLds : kSplitLds];
   const int b = blockIdx.y, lane = threadIdx.x & 63, sub = lane & (L - 1);
   if (cells[(size_t)b * kCellInts + kCellFlag]) {  // dense cells: the pruned scan takes this cloud
     if constexpr (SF > 0) {
-      if (threadIdx.x < 64 * SF) knn_split_body<8, (SF > 0 ? SF : 1)>(sorted, gbox, N, K, lad, nn, dist, b, blockIdx.x, s_raw);
+      // (the group a workgroup serves is rotated by the cloud: workgroups x, x + 256, ... share a CU, and with clouds of one
+      //  kind in a batch -- the same street, the same sensor -- the same x is the same kind of region in all of them: the
+      //  slow far-field groups of every cloud would meet on the same CUs)
+      const int ngq = (N + 63) / 64;
+      if constexpr (SF == 2) {
+        // TWO query groups per workgroup, two waves each (half the workgroups of a crowded cloud leave at once): a CU then
+        // carries eight groups instead of four, and the launch ends with its most loaded CU
+        const int half = (int)(threadIdx.x >> 7), pairs = (ngq + 1) / 2;
+        if ((int)blockIdx.x >= pairs) return;
+        const int g0 = (int)blockIdx.x + half * pairs;
+        if (g0 >= ngq) return;
+        knn_split_body<8, 2>(sorted, gbox, N, K, lad, nn, dist, b, (int)(((unsigned)g0 + 37u * (unsigned)b) % (unsigned)ngq),
+                             s_raw + half * knn_split_lds_bytes<2>(), half * 2);
+      } else if (threadIdx.x < 64 * SF) {
+        knn_split_body<8, (SF > 0 ? SF : 1)>(sorted, gbox, N, K, lad, nn, dist, b, (int)((blockIdx.x + 37u * (unsigned)b) % (unsigned)ngq), s_raw);
+      }
     }
     return;
   }
@@ -1480,9 +1497,12 @@ DH3D_API int dh3d_knn_grid(const float *sorted, const float *gbox, const int32_t
   const dim3 grid(dh3d_cdiv(N, 256 / kLanes), B);
   const float4 *so = reinterpret_cast<const float4 *>(sorted);
   if (kLanes == 4 && groups <= 4096) {
-    // (four waves per group also where the scan on its own would use two: a two-wave scan inside the 256-thread workgroup
-    // leaves half of every workgroup's waves unused while it holds its LDS -- 32 x 4096 demo clouds 139.8 us against 112)
-    hipLaunchKernelGGL((knn_grid_kernel<4, 4>), grid, dim3(256), 0, (hipStream_t)stream, so, gbox, cells, N, K, D, lad, nn, dist);
+    // (four waves per query group up to 1280 groups, as the scan on its own; beyond that two groups per workgroup with two
+    // waves each -- ONE two-wave group per 256-thread workgroup left half its waves unused while it held its LDS: 139.8 us)
+    if (groups > 1280)   // many query groups: two groups per workgroup, two waves each (32 x 4096 demo clouds: 97.7 us against 117.9)
+      hipLaunchKernelGGL((knn_grid_kernel<4, 2>), grid, dim3(256), 0, (hipStream_t)stream, so, gbox, cells, N, K, D, lad, nn, dist);
+    else
+      hipLaunchKernelGGL((knn_grid_kernel<4, 4>), grid, dim3(256), 0, (hipStream_t)stream, so, gbox, cells, N, K, D, lad, nn, dist);
     return dh3d_launch_status();
   }
   hipLaunchKernelGGL((knn_grid_kernel<kLanes, 0>), grid, dim3(256), 0, (hipStream_t)stream, so, gbox, cells, N, K, D, lad, nn, dist);
