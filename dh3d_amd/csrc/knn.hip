@@ -1173,7 +1173,9 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict_
     }
     return;
   }
-  const int qi = blockIdx.x * QB + threadIdx.x / L;
+  // (the cell lists too: a query group's work depends on where it sits in the Morton order -- the cloud's border, the big
+  //  jumps of the curve -- which is the same place in every cloud of a batch: rotated by the cloud like the scan's)
+  const int qi = (int)((blockIdx.x + 37u * (unsigned)b) % gridDim.x) * QB + threadIdx.x / L;
   const bool valid = qi < N;
   const float4 *sc = sorted + (size_t)b * N;
   const int *ct = cells + (size_t)b * kCellInts;

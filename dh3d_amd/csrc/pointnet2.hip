@@ -318,9 +318,12 @@ __global__ __launch_bounds__(kBlock) void three_nn_pruned_kernel(int n, int m, c
   __shared__ unsigned long long s_mk[3][3][64];  // partial lists of waves 1..3
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int j = blockIdx.x * 64 + lane;
+  // (the query group is rotated by the cloud: workgroups x, x + 256, ... share a CU -- the same group of every second cloud
+  //  -- and clouds of one kind have the same kind of region at the same place of their order: round 6, csrc/knn.hip)
+  const int bx = (int)((blockIdx.x + 37u * (unsigned)b) % gridDim.x);
+  const int j = bx * 64 + lane;
   const bool valid = j < n;
-  const float4 q = qs[(size_t)b * n + (valid ? j : blockIdx.x * 64)];
+  const float4 q = qs[(size_t)b * n + (valid ? j : bx * 64)];
   const float4 *cand = cs + (size_t)b * m;
   const f32x2 qx = {q.x, q.x}, qy = {q.y, q.y}, qz = {q.z, q.z};
   const int len32 = (m + 31) & ~31, nsteps = len32 >> 5;
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(kBlock) void three_nn_pruned_kernel(int n, int m, c
   }
   // boxes: the query group's, and (lane = candidate group) the candidates'
   const int NGq = (n + 63) / 64, MG = (m + 63) / 64;
-  const float *qb = qbox + ((size_t)b * NGq + blockIdx.x) * 8;
+  const float *qb = qbox + ((size_t)b * NGq + bx) * 8;
   const float qlx = qb[0], qly = qb[1], qlz = qb[2], qhx = qb[4], qhy = qb[5], qhz = qb[6];
   float clx = INFINITY, cly = INFINITY, clz = INFINITY, chx = -INFINITY, chy = -INFINITY, chz = -INFINITY, bd = INFINITY;
   if (lane < MG) {
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(kBlock) void three_nn_pruned_kernel(int n, int m, c
   };
 
   // A. one step per wave around the rank-proportional start
-  long long c0 = ((long long)blockIdx.x * 64 + 32) * m / n - 64;
+  long long c0 = ((long long)bx * 64 + 32) * m / n - 64;
   c0 = c0 < 0 ? 0 : c0;
   const int s0 = (int)(c0 >> 5);
   unsigned long long done = 0ull;  // steps of phase A (all four waves')
