@@ -1132,7 +1132,6 @@ __device__ __forceinline__ void knn_merge_sublanes(KnnState<8> &st) {
 
 #ifdef DH3D_GRID_PROBE  // dev instrumentation (tools/knn_grid_probe.py): cycle stamps of the first wave of 64 workgroups
 __device__ long long g_gprobe[64 * 8];
-__device__ long long g_gstat[8];
 #define GPROBE(i) do { if (threadIdx.x == 0 && blockIdx.x < 64 && blockIdx.y == 0) g_gprobe[blockIdx.x * 8 + (i)] = clock64(); } while (0)
 #else
 #define GPROBE(i) do { } while (0)
@@ -1177,9 +1176,6 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict_
   // (the cell lists too: a query group's work depends on where it sits in the Morton order -- the cloud's border, the big
   //  jumps of the curve -- which is the same place in every cloud of a batch: rotated by the cloud like the scan's)
   const int qi = (int)((blockIdx.x + 37u * (unsigned)b) % gridDim.x) * QB + threadIdx.x / L;
-#ifdef DH3D_GRID_PROBE
-  const long long pr_t00 = clock64();
-#endif
   const bool valid = qi < N;
   const float4 *sc = sorted + (size_t)b * N;
   const int *ct = cells + (size_t)b * kCellInts;
@@ -1427,10 +1423,6 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict_
   // (the list is emptied first, every point within the bound is offered again, nothing twice) and bounded: N / 64 box
   // tests per query dealt over its lanes.
   const bool done = !valid || exact || inside(2);
-#ifdef DH3D_GRID_PROBE   // (all workgroups: how many queries restart, what it costs their waves)
-  const long long pr_r0 = clock64();
-  const unsigned long long pr_nd = __ballot(!done);
-#endif
   if (__any(!done)) {
     if (done) {
       keep_one_copy();
@@ -1462,18 +1454,6 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float4 *__restrict_
     }
     knn_merge_sublanes<L>(st);
   }
-#ifdef DH3D_GRID_PROBE
-  if ((threadIdx.x & 63) == 0) {
-    const long long now = clock64();
-    atomicAdd((unsigned long long *)&g_gstat[0], (unsigned long long)(__popcll(pr_nd) / L));   // restarted queries
-    atomicAdd((unsigned long long *)&g_gstat[1], pr_nd ? 1ull : 0ull);                          // waves with a restart
-    atomicAdd((unsigned long long *)&g_gstat[2], (unsigned long long)(now - pr_r0));            // cycles in the restart section
-    atomicAdd((unsigned long long *)&g_gstat[3], (unsigned long long)(now - pr_t00));           // wave lifetimes
-    atomicMax((unsigned long long *)&g_gstat[4], (unsigned long long)(now - pr_t00));
-    atomicAdd((unsigned long long *)&g_gstat[5], 1ull);
-    atomicMax((unsigned long long *)&g_gstat[6], (unsigned long long)(now - pr_r0));
-  }
-#endif
   if (valid) {
     const int y = __float_as_int(qr.w);  // the query's original index
 #pragma unroll
@@ -1535,11 +1515,6 @@ DH3D_API int dh3d_knn_grid(const float *sorted, const float *gbox, const int32_t
 #ifdef DH3D_GRID_PROBE
 DH3D_API int dh3d_grid_probe_read(long long *host, int n) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gprobe), sizeof(long long) * n) == hipSuccess ? 0 : 3;
-}
-DH3D_API int dh3d_grid_stat_read(long long *host, int reset) {
-  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gstat), sizeof(long long) * 8) != hipSuccess) return 3;
-  if (reset) { long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; return hipMemcpyToSymbol(HIP_SYMBOL(g_gstat), z, sizeof(z)) == hipSuccess ? 0 : 3; }
-  return 0;
 }
 #endif
 
