@@ -5,7 +5,7 @@ import torch, bench
 from dh3d_amd import pm
 dev = torch.device("cuda")
 out = []
-for B, N in ((8, 8192), (32, 4096), (32, 512), (4, 16384)):
+for B, N in ((8, 8192), (32, 4096), (32, 512), (16, 1024), (8, 2048), (2, 8192), (4, 16384)):
     p = bench.synthetic_clouds(B, N, 2002, dev, 0)[..., :3].contiguous()
     srt, gbox, cells = pm.spatial_sort_cells(p)
     t = bench.event_time_ms(lambda: pm.knn_grid(srt, gbox, cells, 8), iters=30, warm=5) * 1e3
