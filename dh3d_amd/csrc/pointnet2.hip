@@ -421,7 +421,11 @@ __global__ __launch_bounds__(kBlock) void three_nn_pruned_kernel(int n, int m, c
   while (mask != 0ull) {
     const int g = __builtin_ctzll(mask);
     mask &= mask - 1;
-    if ((mine++ & 3) != wave) continue;
+    // the group's two 32-candidate steps are dealt to the waves ONE BY ONE (round 6: whole groups left a wave up to two steps
+    // behind its neighbours, and the workgroup ends with its slowest wave)
+    const bool own0 = (mine & 3) == wave, own1 = ((mine + 1) & 3) == wave;
+    mine += 2;
+    if (!own0 && !own1) continue;
     const float lx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(clx), g)),
                 ly = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cly), g)),
                 lz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(clz), g)),
@@ -434,7 +438,7 @@ __global__ __launch_bounds__(kBlock) void three_nn_pruned_kernel(int n, int m, c
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int st = 2 * g + h;
-      if (st < nsteps && !((done >> st) & 1ull)) scan_step(st);
+      if ((h == 0 ? own0 : own1) && st < nsteps && !((done >> st) & 1ull)) scan_step(st);
     }
   }
 
